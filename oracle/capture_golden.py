@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""Golden-vector capture for the EV2Gym.step() hot path (test infrastructure).
+
+Runs ONLY in the build container, where /root/reference exists.  It imports the
+reference (through oracle/ref_import.py), constructs `EV2Gym` for a matrix of
+(config, seed, action policy), and writes one `.npz` per case to tests/golden/:
+
+  scn_*   the *scenario*: every tensor `step()` reads, in this repo's schema
+          (ev2gym_amd/scenario.py documents the fields) -- captured right after
+          construction/reset (ev2gym_env.py:243-331).
+  act     the float64 action tensor [T, P] fed to the reference (a fresh copy
+          per step, because EV_Charger.step zeroes empty ports in place,
+          ev_charger.py:137-140).
+  trj_*   the *trajectory*: everything `step()` produces, every step.
+
+A fixture is data only (inputs + expected outputs); no reference source text
+is stored.  Re-generate with:  python oracle/capture_golden.py
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, HERE)
+warnings.filterwarnings("ignore")
+
+from ref_import import import_reference  # noqa: E402
+
+STAT_KEYS = ['total_ev_served', 'total_profits', 'total_energy_charged', 'total_energy_discharged',
+             'average_user_satisfaction', 'power_tracker_violation', 'tracking_error',
+             'energy_tracking_error', 'energy_user_satisfaction', 'std_energy_user_satisfaction',
+             'min_energy_user_satisfaction', 'total_steps_min_emergency_battery_capacity_violation',
+             'total_transformer_overload', 'battery_degradation', 'battery_degradation_calendar',
+             'battery_degradation_cycling', 'total_reward']
+
+
+def _yaml_variant(base, overrides, name):
+    import yaml
+    cfg = yaml.load(open(base), Loader=yaml.FullLoader)
+
+    def deep(d, o):
+        for k, v in o.items():
+            if isinstance(v, dict):
+                deep(d[k], v)
+            else:
+                d[k] = v
+    deep(cfg, overrides)
+    os.makedirs("/tmp/ev2g_cfg", exist_ok=True)
+    p = f"/tmp/ev2g_cfg/{name}.yaml"
+    yaml.dump(cfg, open(p, "w"))
+    return p
+
+
+def extract_scenario(env):
+    """Flatten the reference object graph into this repo's scenario schema."""
+    T = env.simulation_length
+    cs = env.charging_stations
+    C = len(cs)
+    nports = {c.n_ports for c in cs}
+    assert len(nports) == 1, "uniform ports per charger only"
+    R = len(env.transformers)
+    s = {}
+    s["scn_meta"] = np.array([T, env.timescale, C, cs[0].n_ports, R,
+                              int(bool(env.config['v2g_enabled'])), 20], dtype=np.int64)
+    s["scn_cs_min_charge_current"] = np.array([c.min_charge_current for c in cs], float)
+    s["scn_cs_max_charge_current"] = np.array([c.max_charge_current for c in cs], float)
+    s["scn_cs_min_discharge_current"] = np.array([c.min_discharge_current for c in cs], float)
+    s["scn_cs_max_discharge_current"] = np.array([c.max_discharge_current for c in cs], float)
+    s["scn_cs_voltage"] = np.array([c.voltage for c in cs], float)
+    s["scn_cs_phases"] = np.array([c.phases for c in cs], np.int32)
+    s["scn_cs_transformer"] = np.array([c.connected_transformer for c in cs], np.int32)
+    assert (env.charge_prices == env.charge_prices[0]).all()
+    assert (env.discharge_prices == env.discharge_prices[0]).all()
+    s["scn_charge_price"] = np.array(env.charge_prices[0], float)
+    s["scn_discharge_price"] = np.array(env.discharge_prices[0], float)
+    s["scn_power_setpoints"] = np.array(env.power_setpoints, float)
+    trs = env.transformers
+    s["scn_tr_max_power"] = np.array([t.max_power for t in trs], float)
+    s["scn_tr_min_power"] = np.array([t.min_power for t in trs], float)
+    s["scn_tr_inflexible_load"] = np.array([t.inflexible_load for t in trs], float)
+    s["scn_tr_solar_power"] = np.array([t.solar_power for t in trs], float)
+    s["scn_tr_load_forecast"] = np.array([t.inflexible_load_forecast for t in trs], float)
+    s["scn_tr_pv_forecast"] = np.array([t.pv_generation_forecast for t in trs], float)
+    s["scn_tr_voltage"] = np.array([t.voltage for t in trs], float)
+    nd = max([len(t.dr_events) for t in trs] + [1])
+    dr = np.zeros((R, nd, 3))
+    ndr = np.zeros(R, np.int32)
+    for i, t in enumerate(trs):
+        ndr[i] = len(t.dr_events)
+        for j, ev in enumerate(t.dr_events):
+            dr[i, j] = (ev['event_start_step'], ev['event_end_step'], ev['capacity_percentage'])
+    s["scn_tr_dr"] = dr
+    s["scn_tr_n_dr"] = ndr
+    s["scn_tr_steps_ahead"] = np.array([t.steps_ahead for t in trs], np.int32)
+    evs = env.EVs_profiles
+    luts, lut_keys = [], {}
+
+    def lut_id(d):
+        # 101-entry table of percent values; keys outside 0..100 fall back to `.get(..., 1)` (ev.py:288)
+        tab = tuple(float(d.get(i, 1)) for i in range(101))
+        assert all(0 <= k <= 100 for k in d.keys())
+        if tab not in lut_keys:
+            lut_keys[tab] = len(luts)
+            luts.append(tab)
+        return lut_keys[tab]
+    f = lambda name: np.array([getattr(e, name) for e in evs], float)  # noqa: E731
+    s["scn_ev_cs"] = np.array([e.location for e in evs], np.int32)
+    s["scn_ev_t_arr"] = np.array([e.time_of_arrival for e in evs], np.int32)
+    s["scn_ev_t_dep"] = np.array([e.time_of_departure for e in evs], np.int32)
+    s["scn_ev_cap0"] = f("battery_capacity_at_arrival")
+    s["scn_ev_B"] = f("battery_capacity")
+    s["scn_ev_desired"] = f("desired_capacity")
+    s["scn_ev_minB"] = f("min_battery_capacity")
+    s["scn_ev_min_emerg"] = f("min_emergency_battery_capacity")
+    s["scn_ev_pac_max"] = f("max_ac_charge_power")
+    s["scn_ev_pac_min"] = f("min_ac_charge_power")
+    s["scn_ev_pdis_max"] = f("max_discharge_power")
+    s["scn_ev_pdis_min"] = f("min_discharge_power")
+    s["scn_ev_ts"] = f("transition_soc")
+    s["scn_ev_tsm"] = f("transition_soc_multiplier")
+    s["scn_ev_phases"] = np.array([e.ev_phases for e in evs], np.int32)
+    eta_ch, eta_dis, lid = [], [], []
+    for e in evs:
+        if isinstance(e.charge_efficiency, dict):
+            assert e.discharge_efficiency == e.charge_efficiency
+            lid.append(lut_id(e.charge_efficiency))
+            eta_ch.append(np.nan)
+            eta_dis.append(np.nan)
+        else:
+            lid.append(-1)
+            eta_ch.append(float(e.charge_efficiency))
+            eta_dis.append(float(e.discharge_efficiency))
+    s["scn_ev_eta_ch"] = np.array(eta_ch, float)
+    s["scn_ev_eta_dis"] = np.array(eta_dis, float)
+    s["scn_ev_lut"] = np.array(lid, np.int32)
+    s["scn_lut"] = np.array(luts, float).reshape(-1, 101) if luts else np.zeros((0, 101))
+    return s
+
+
+def run_case(name, config, state_fn, reward_fn, seed, policy, steps=None):
+    from ev2gym.models.ev2gym_env import EV2Gym
+    import ev2gym.rl_agent.state as S
+    import ev2gym.rl_agent.reward as RW
+    env = EV2Gym(config_file=config, seed=seed, state_function=getattr(S, state_fn),
+                 reward_function=getattr(RW, reward_fn), generate_rnd_game=True)
+    obs0, _ = env.reset(seed=seed)
+    scn = extract_scenario(env)
+    T = env.simulation_length
+    P = env.number_of_ports
+    C = len(env.charging_stations)
+    R = len(env.transformers)
+    npc = env.charging_stations[0].n_ports
+    rng = np.random.default_rng(1000 + seed)
+    lo = -1.0 if env.config['v2g_enabled'] else 0.0
+    if policy == "ones":
+        act = np.ones((T, P))
+    elif policy == "neg":
+        act = -np.ones((T, P))
+    elif policy == "rand":
+        act = rng.uniform(lo, 1.0, (T, P))
+    elif policy == "wild":      # outside the action box -> normalisation / clamp path (ev_charger.py:143-149)
+        act = rng.uniform(-1.6 if lo < 0 else 0.0, 1.6, (T, P))
+    elif policy == "mixed":     # many exact zeros and sign flips (cycle counter, a==0 branch)
+        act = rng.uniform(lo, 1.0, (T, P)) * (rng.random((T, P)) < 0.7)
+        act[rng.random((T, P)) < 0.1] = 1.0
+    else:
+        raise ValueError(policy)
+    nT = T if steps is None else steps
+    D = len(obs0)
+    trj = dict(
+        trj_obs=np.zeros((nT + 1, D)), trj_reward=np.zeros(nT), trj_done=np.zeros(nT, np.uint8),
+        trj_mask=np.zeros((nT, P), np.uint8), trj_act_after=np.zeros((nT, P)),
+        trj_cap=np.full((nT, P), np.nan), trj_energy=np.full((nT, P), np.nan),
+        trj_current=np.full((nT, P), np.nan), trj_tot_e=np.full((nT, P), np.nan),
+        trj_req_e=np.full((nT, P), np.nan), trj_prev_power=np.full((nT, P), np.nan),
+        trj_cycles=np.full((nT, P), -1, np.int32),
+        trj_cs_power=np.zeros((nT, C)), trj_cs_amps=np.zeros((nT, C)), trj_cs_profits=np.zeros((nT, C)),
+        trj_cs_e_ch=np.zeros((nT, C)), trj_cs_e_dis=np.zeros((nT, C)),
+        trj_tr_power=np.zeros((nT, R)), trj_tr_amps=np.zeros((nT, R)), trj_tr_overload=np.zeros((nT, R)),
+        trj_n_departed=np.zeros(nT, np.int32), trj_sat_sum=np.zeros(nT),
+        trj_dep_port=np.full((nT, P), -1, np.int32), trj_dep_score=np.full((nT, P), np.nan),
+    )
+    trj["trj_obs"][0] = obs0
+    info = None
+    for t in range(nT):
+        a = act[t].copy()
+        obs, rew, done, trunc, info = env.step(a)
+        trj["trj_obs"][t + 1] = obs
+        trj["trj_reward"][t] = rew
+        trj["trj_done"][t] = done
+        trj["trj_mask"][t] = info["action_mask"].astype(np.uint8)
+        trj["trj_act_after"][t] = a
+        for i, cs in enumerate(env.charging_stations):
+            trj["trj_cs_power"][t, i] = cs.current_power_output
+            trj["trj_cs_amps"][t, i] = cs.current_total_amps
+            trj["trj_cs_profits"][t, i] = cs.total_profits
+            trj["trj_cs_e_ch"][t, i] = cs.total_energy_charged
+            trj["trj_cs_e_dis"][t, i] = cs.total_energy_discharged
+            for j, ev in enumerate(cs.evs_connected):
+                if ev is not None:
+                    p = i * npc + j
+                    trj["trj_cap"][t, p] = ev.current_capacity
+                    trj["trj_energy"][t, p] = ev.current_energy
+                    trj["trj_current"][t, p] = ev.actual_current
+                    trj["trj_tot_e"][t, p] = ev.total_energy_exchanged
+                    trj["trj_req_e"][t, p] = ev.required_energy
+                    trj["trj_prev_power"][t, p] = ev.previous_power
+                    trj["trj_cycles"][t, p] = ev.charging_cycles
+        for i, tr in enumerate(env.transformers):
+            trj["trj_tr_power"][t, i] = tr.current_power
+            trj["trj_tr_amps"][t, i] = tr.current_amps
+            trj["trj_tr_overload"][t, i] = env.tr_overload[i, t]
+        trj["trj_n_departed"][t] = len(env.departing_evs)
+        for k, ev in enumerate(env.departing_evs):
+            trj["trj_dep_port"][t, k] = ev.location * npc + ev.id
+            trj["trj_dep_score"][t, k] = ev.get_user_satisfaction()
+            trj["trj_sat_sum"][t] += ev.get_user_satisfaction()
+    trj["trj_usage"] = np.array(env.current_power_usage[:nT])
+    trj["trj_potential"] = np.array(env.charge_power_potential[:nT])
+    # per-session results at the end (env.EVs is in spawn order == profile order, ev2gym_env.py:401-414)
+    S_ = len(env.EVs_profiles)
+    trj["trj_ev_port"] = np.full(S_, -1, np.int32)
+    trj["trj_ev_final_cap"] = np.full(S_, np.nan)
+    trj["trj_ev_afap"] = np.full(S_, np.nan)
+    for k, ev in enumerate(env.EVs):
+        trj["trj_ev_port"][k] = ev.location * npc + ev.id
+        trj["trj_ev_final_cap"][k] = ev.current_capacity
+        trj["trj_ev_afap"][k] = ev.max_energy_AFAP
+    if nT == T:
+        trj["trj_stats"] = np.array([float(info[k]) for k in STAT_KEYS])
+    out = dict(scn)
+    out.update(trj)
+    out["act"] = act[:nT]
+    out["case"] = np.array([name, os.path.basename(config), state_fn, reward_fn, str(seed), policy])
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    occ = trj["trj_mask"].mean()
+    print(f"{name:28s} P={P:5d} R={R:3d} D={D:5d} S={S_:4d} occ={occ:.3f} "
+          f"size={os.path.getsize(path)/1024:.0f} KB", flush=True)
+
+
+def main():
+    import_reference()
+    base = "ev2gym/example_config_files/"
+    ppl = base + "V2GProfitPlusLoads.yaml"
+    pst = base + "PublicPST.yaml"
+    vmax = base + "V2GProfitMax.yaml"
+    PPL = ("V2G_profit_max_loads", "ProfitMax_TrPenalty_UserIncentives")
+    PST = ("PublicPST", "SquaredTrackingErrorReward")
+    VMX = ("V2G_profit_max", "profit_maximization")
+    only = set(sys.argv[1:])
+    cases = []
+    for seed, pol in [(1, "ones"), (2, "rand"), (3, "neg"), (4, "rand"), (5, "mixed"), (6, "wild")]:
+        cases.append((f"v2gppl_{pol}_s{seed}", ppl, *PPL, seed, pol, None))
+    for seed, pol in [(1, "ones"), (2, "rand"), (3, "rand"), (4, "mixed"), (5, "wild")]:
+        cases.append((f"pst_{pol}_s{seed}", pst, *PST, seed, pol, None))
+    # ceil-to-0.01 boundary trap: homogeneous specs, eta=1, transition_soc=1 (SURVEY.md §7 hard parts)
+    homog = _yaml_variant(vmax, {"heterogeneous_ev_specs": False}, "v2gmax_homog")
+    cases.append(("v2gmax_homog_ones_s1", homog, *VMX, 1, "ones", None))
+    cases.append(("v2gmax_homog_rand_s2", homog, *VMX, 2, "rand", None))
+    cases.append(("v2gmax_het_rand_s3", vmax, *VMX, 3, "rand", None))
+    # homogeneous two-stage model with non-zero minimum currents / powers (gates of ev_charger.py:168-186, ev.py:151-154)
+    gates = _yaml_variant(ppl, {"heterogeneous_ev_specs": False,
+                                "charging_station": {"min_charge_current": 6, "min_discharge_current": -6},
+                                "ev": {"transition_soc": 0.8, "min_ac_charge_power": 5, "min_discharge_power": -5,
+                                       "charge_efficiency": 0.93, "discharge_efficiency": 0.91, "ev_phases": 1}},
+                          "v2gppl_gates")
+    cases.append(("v2gppl_gates_rand_s7", gates, *PPL, 7, "rand", None))
+    cases.append(("v2gppl_gates_mixed_s8", gates, *PPL, 8, "mixed", None))
+    # BASELINE cfg2 shape: 50 chargers
+    c50 = _yaml_variant(ppl, {"number_of_charging_stations": 50}, "v2gppl_c50")
+    cases.append(("v2gppl_c50_rand_s9", c50, *PPL, 9, "rand", None))
+    # two ports per charger: normalisation + first-free port assignment
+    p2 = _yaml_variant(ppl, {"number_of_charging_stations": 12, "number_of_ports_per_cs": 2}, "v2gppl_p2")
+    cases.append(("v2gppl_p2_wild_s10", p2, *PPL, 10, "wild", None))
+    cases.append(("v2gppl_p2_rand_s11", p2, *PPL, 11, "rand", None))
+    p3 = _yaml_variant(pst, {"number_of_charging_stations": 7, "number_of_ports_per_cs": 3}, "pst_p3")
+    cases.append(("pst_p3_rand_s12", p3, *PST, 12, "rand", None))
+    # multi-transformer round-robin map (loaders.py:494-498): BASELINE cfg4 shape, scaled down
+    r5 = _yaml_variant(ppl, {"number_of_charging_stations": 60, "number_of_transformers": 5}, "v2gppl_c60_r5")
+    cases.append(("v2gppl_c60r5_rand_s13", r5, *PPL, 13, "rand", None))
+    r3 = _yaml_variant(ppl, {"number_of_charging_stations": 10, "number_of_transformers": 3}, "v2gppl_c10_r3")
+    cases.append(("v2gppl_c10r3_mixed_s14", r3, *PPL, 14, "mixed", None))
+    big = _yaml_variant(ppl, {"number_of_charging_stations": 1000, "number_of_transformers": 50}, "v2gppl_c1000_r50")
+    cases.append(("v2gppl_c1000r50_rand_s15", big, *PPL, 15, "rand", 16))
+    for c in cases:
+        if only and c[0] not in only:
+            continue
+        run_case(*c)
+
+
+if __name__ == "__main__":
+    main()
