@@ -1,0 +1,75 @@
+"""ctypes mirrors of include/ev2g.h (the C-ABI structs).  Keep in sync with the header."""
+import ctypes as C
+
+ABI_VERSION = 1
+LUT_LEN = 101
+N_STATS = 17
+
+REWARD_KINDS = {
+    "ProfitMax_TrPenalty_UserIncentives": 0,   # rl_agent/reward.py:34-44
+    "SquaredTrackingErrorReward": 1,           # rl_agent/reward.py:7-14
+    "profit_maximization": 2,                  # rl_agent/reward.py:78-87
+}
+STATE_KINDS = {
+    "V2G_profit_max_loads": 0,                 # rl_agent/state.py:108-155
+    "PublicPST": 1,                            # rl_agent/state.py:6-63
+    "V2G_profit_max": 2,                       # rl_agent/state.py:65-106
+}
+STAT_NAMES = [  # get_statistics(), utilities/utils.py:84-101
+    'total_ev_served', 'total_profits', 'total_energy_charged', 'total_energy_discharged',
+    'average_user_satisfaction', 'power_tracker_violation', 'tracking_error',
+    'energy_tracking_error', 'energy_user_satisfaction', 'std_energy_user_satisfaction',
+    'min_energy_user_satisfaction', 'total_steps_min_emergency_battery_capacity_violation',
+    'total_transformer_overload', 'battery_degradation', 'battery_degradation_calendar',
+    'battery_degradation_cycling', 'total_reward']
+
+ERR_DONE = -4
+ERR_OVERCURRENT = -5
+FLAG_LOG_CS_HISTORY = 1
+
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int32)
+_pl = C.POINTER(C.c_int64)
+
+# (field name, element ctype) of every pointer member, in header order
+BATCH_ARRAYS = [
+    ("cs_min_charge_current", C.c_double), ("cs_max_charge_current", C.c_double),
+    ("cs_min_discharge_current", C.c_double), ("cs_max_discharge_current", C.c_double),
+    ("cs_voltage", C.c_double), ("cs_phases", C.c_int32), ("cs_transformer", C.c_int32),
+    ("charge_price", C.c_double), ("discharge_price", C.c_double), ("power_setpoints", C.c_double),
+    ("tr_max_power", C.c_double), ("tr_min_power", C.c_double), ("tr_inflexible_load", C.c_double),
+    ("tr_solar_power", C.c_double), ("tr_load_forecast", C.c_double), ("tr_pv_forecast", C.c_double),
+    ("tr_dr", C.c_double), ("tr_n_dr", C.c_int32), ("tr_steps_ahead", C.c_int32),
+    ("env_session_start", C.c_int64),
+    ("ev_cs", C.c_int32), ("ev_t_arr", C.c_int32), ("ev_t_dep", C.c_int32), ("ev_phases", C.c_int32),
+    ("ev_lut", C.c_int32),
+    ("ev_cap0", C.c_double), ("ev_B", C.c_double), ("ev_desired", C.c_double), ("ev_minB", C.c_double),
+    ("ev_min_emerg", C.c_double), ("ev_pac_max", C.c_double), ("ev_pac_min", C.c_double),
+    ("ev_pdis_max", C.c_double), ("ev_pdis_min", C.c_double), ("ev_ts", C.c_double), ("ev_tsm", C.c_double),
+    ("ev_eta_ch", C.c_double), ("ev_eta_dis", C.c_double), ("lut", C.c_double),
+]
+
+
+class ScenarioBatchC(C.Structure):
+    _fields_ = [
+        ("n_envs", C.c_int32), ("n_steps", C.c_int32), ("timescale", C.c_int32), ("n_chargers", C.c_int32),
+        ("ports_per_charger", C.c_int32), ("n_transformers", C.c_int32), ("horizon", C.c_int32),
+        ("n_dr_max", C.c_int32), ("n_lut", C.c_int32), ("reserved0", C.c_int32), ("n_sessions", C.c_int64),
+    ] + [(name, C.POINTER(ct)) for name, ct in BATCH_ARRAYS]
+
+
+class ConfigC(C.Structure):
+    _fields_ = [("device", C.c_int32), ("reward_kind", C.c_int32), ("state_kind", C.c_int32),
+                ("flags", C.c_int32), ("stream", C.c_void_p)]
+
+
+class EnvViewC(C.Structure):
+    _fields_ = [
+        ("current_step", C.c_int32), ("n_ports", C.c_int32), ("n_chargers", C.c_int32),
+        ("n_transformers", C.c_int32), ("n_steps", C.c_int32),
+        ("port_capacity", _pd), ("port_energy", _pd), ("port_current", _pd), ("port_total_energy", _pd),
+        ("port_required_energy", _pd), ("port_prev_power", _pd), ("port_cycles", _pi), ("port_session", _pi),
+        ("cs_power", _pd), ("cs_amps", _pd), ("cs_profits", _pd), ("cs_energy_charged", _pd),
+        ("cs_energy_discharged", _pd), ("tr_power", _pd), ("tr_overload", _pd), ("power_usage", _pd),
+        ("power_potential", _pd), ("session_port", _pi), ("session_afap", _pd),
+    ]

@@ -1,0 +1,237 @@
+/*
+ * ev2g.h -- C-ABI of the MI355X-native vectorised EV2Gym step engine (libev2g_hip.so).
+ *
+ * The reference (StavrosOrf/EV2Gym) has no FFI/operator layer for this path; its boundary is the
+ * Python class ev2gym.models.ev2gym_env.EV2Gym (constructor :38-56, reset :243-331, step :333-447)
+ * plus the rl_agent.state / rl_agent.reward hooks.  Each entry point below names the reference
+ * interface it replaces.  Everything is `extern "C"`, plain pointers and sizes, no torch types.
+ *
+ * Conventions
+ *   E envs, C chargers/env, P = C * ports_per_charger ports/env, R transformers/env, T steps/episode,
+ *   H = 20 observation horizon (state.py:119,129-132).  All floating point is IEEE float64.
+ *   Port index p = charger * ports_per_charger + port  (the reference action / action_mask order,
+ *   ev2gym_env.py:363-385, :452-457).
+ *   Return value: 0 = ok, negative = EV2G_ERR_*; ev2g_last_error() returns a message.
+ *   A handle is bound to one GPU and one HIP stream and is not thread-safe; distinct handles may be
+ *   driven from distinct threads / processes (one process per GPU).
+ *   Unless stated otherwise every `double*` / `uint8_t*` argument of reset/step/get_* is a DEVICE
+ *   pointer (hipMalloc'd, or a torch-ROCm tensor's data_ptr()); the scenario batch is HOST memory,
+ *   borrowed only for the duration of ev2g_load_scenarios().
+ */
+#ifndef EV2G_H
+#define EV2G_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EV2G_ABI_VERSION 1
+
+/* reward_function built-ins (rl_agent/reward.py) */
+#define EV2G_REWARD_PROFITMAX_TRPENALTY_USERINCENTIVES 0 /* reward.py:34-44  */
+#define EV2G_REWARD_SQUARED_TRACKING_ERROR 1             /* reward.py:7-14   */
+#define EV2G_REWARD_PROFIT_MAXIMIZATION 2                /* reward.py:78-87  */
+/* state_function built-ins (rl_agent/state.py) */
+#define EV2G_STATE_V2G_PROFIT_MAX_LOADS 0 /* state.py:108-155, D = 2+H + 2H*R + 2P */
+#define EV2G_STATE_PUBLIC_PST 1           /* state.py:6-63,    D = 3 + 3P          */
+#define EV2G_STATE_V2G_PROFIT_MAX 2       /* state.py:65-106,  D = 2+H + 2P        */
+
+#define EV2G_OK 0
+#define EV2G_ERR_ARG -1       /* bad argument / inconsistent scenario                         */
+#define EV2G_ERR_HIP -2       /* HIP runtime error                                            */
+#define EV2G_ERR_STATE -3     /* call out of order (e.g. step before load)                    */
+#define EV2G_ERR_DONE -4      /* step() after done: `assert not self.done` ev2gym_env.py:343  */
+#define EV2G_ERR_OVERCURRENT -5 /* charger over-current Exception, ev_charger.py:203-205       */
+
+#define EV2G_LUT_LEN 101 /* efficiency table 0..100 A, utils.py:282-288 */
+#define EV2G_N_STATS 17  /* get_statistics() scalar keys, utils.py:84-101 */
+
+/* flags for ev2g_config.flags */
+#define EV2G_FLAG_LOG_CS_HISTORY 1 /* keep cs_power / cs_current [E,C,T] (ev2gym_env.py:533-535) */
+
+typedef struct ev2g_handle ev2g_handle;
+
+typedef struct ev2g_config {
+    int32_t device;      /* HIP device ordinal                                                   */
+    int32_t reward_kind; /* EV2G_REWARD_*  -- replaces the `reward_function` ctor kwarg (:47)    */
+    int32_t state_kind;  /* EV2G_STATE_*   -- replaces the `state_function` ctor kwarg (:46)     */
+    int32_t flags;       /* EV2G_FLAG_*                                                          */
+    void *stream;        /* hipStream_t to launch on; NULL = a stream owned by the handle        */
+} ev2g_config;
+
+/*
+ * Scenario batch: every tensor EV2Gym.step() reads, for E independent envs that share one YAML
+ * config (same chargers / sizes).  It is what the reference builds in __init__/reset()
+ * (load_ev_charger_profiles loaders.py:299-365, load_transformers :227-296, EV_spawner
+ * utils.py:477-557, load_electricity_prices loaders.py:392-461, load_power_setpoints :92-103).
+ * HOST pointers, row-major, borrowed during the call.
+ */
+typedef struct ev2g_scenario_batch {
+    int32_t n_envs;            /* E */
+    int32_t n_steps;           /* T  = simulation_length                                  */
+    int32_t timescale;         /* minutes per step                                        */
+    int32_t n_chargers;        /* C                                                       */
+    int32_t ports_per_charger; /* uniform n_ports                                         */
+    int32_t n_transformers;    /* R                                                       */
+    int32_t horizon;           /* H, must be 20                                           */
+    int32_t n_dr_max;          /* ND: slots per transformer in tr_dr                      */
+    int32_t n_lut;             /* NL efficiency tables                                    */
+    int32_t reserved0;
+    int64_t n_sessions;        /* total EV sessions over all envs = env_session_start[E]  */
+
+    /* chargers [C]  (EV_Charger.__init__ ev_charger.py:41-94) */
+    const double *cs_min_charge_current;
+    const double *cs_max_charge_current;
+    const double *cs_min_discharge_current; /* <= 0 */
+    const double *cs_max_discharge_current; /* <= 0 */
+    const double *cs_voltage;
+    const int32_t *cs_phases;
+    const int32_t *cs_transformer; /* connected_transformer, loaders.py:494-498 */
+
+    /* per env [E,T]: row 0 of charge_prices / discharge_prices (identical for all chargers,
+       loaders.py:423-424,439-442; charge price is negative) and power_setpoints */
+    const double *charge_price;
+    const double *discharge_price;
+    const double *power_setpoints;
+
+    /* per (env, transformer) [E,R,T]  (Transformer.__init__ transformer.py:38-78) */
+    const double *tr_max_power;
+    const double *tr_min_power;
+    const double *tr_inflexible_load;
+    const double *tr_solar_power;
+    const double *tr_load_forecast; /* inflexible_load_forecast as it stands after reset() */
+    const double *tr_pv_forecast;   /* pv_generation_forecast  as it stands after reset()  */
+    const double *tr_dr;            /* [E,R,ND,3] (event_start_step, event_end_step, capacity_percentage) */
+    const int32_t *tr_n_dr;         /* [E,R] number of valid events                        */
+    const int32_t *tr_steps_ahead;  /* [E,R] transformer.py:66                             */
+
+    /* EV sessions, CSR by env, in EVs_profiles order (sorted by arrival; utils.py:531-553) */
+    const int64_t *env_session_start; /* [E+1] */
+    const int32_t *ev_cs;             /* EV.location                                       */
+    const int32_t *ev_t_arr;          /* time_of_arrival                                   */
+    const int32_t *ev_t_dep;          /* time_of_departure                                 */
+    const int32_t *ev_phases;         /* ev_phases                                         */
+    const int32_t *ev_lut;            /* efficiency table id, -1 = scalar efficiencies     */
+    const double *ev_cap0;            /* battery_capacity_at_arrival                       */
+    const double *ev_B;               /* battery_capacity                                  */
+    const double *ev_desired;         /* desired_capacity (kWh)                            */
+    const double *ev_minB;            /* min_battery_capacity                              */
+    const double *ev_min_emerg;       /* min_emergency_battery_capacity                    */
+    const double *ev_pac_max;         /* max_ac_charge_power                               */
+    const double *ev_pac_min;         /* min_ac_charge_power                               */
+    const double *ev_pdis_max;        /* max_discharge_power (<= 0)                        */
+    const double *ev_pdis_min;        /* min_discharge_power (<= 0)                        */
+    const double *ev_ts;              /* transition_soc                                    */
+    const double *ev_tsm;             /* transition_soc_multiplier                         */
+    const double *ev_eta_ch;          /* scalar charge efficiency (ignored if ev_lut >= 0) */
+    const double *ev_eta_dis;         /* scalar discharge efficiency                       */
+    const double *lut;                /* [NL,101] percent, spawner fill utils.py:273-290   */
+} ev2g_scenario_batch;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int ev2g_abi_version(void);
+/* EV2Gym.__init__ (ev2gym_env.py:38-241): bind a device/stream and choose the fused hooks. */
+int ev2g_create(const ev2g_config *cfg, ev2g_handle **out);
+void ev2g_destroy(ev2g_handle *h);
+const char *ev2g_last_error(const ev2g_handle *h); /* h may be NULL: last create() error */
+
+/* The scenario-construction half of __init__/reset(): copies the batch to HBM, resolves every
+ * session's port by replaying EV_Charger.spawn_ev's first-free rule (ev_charger.py:266-286,
+ * action-independent), precomputes max_energy_AFAP (ev.py:407-440).  May be called again to
+ * swap the scenario pool (same shapes or not).  Leaves the handle in the reset state. */
+int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b);
+
+/* shapes */
+int ev2g_n_envs(const ev2g_handle *h);
+int ev2g_n_ports(const ev2g_handle *h); /* P */
+int ev2g_obs_dim(const ev2g_handle *h); /* D */
+int ev2g_n_steps(const ev2g_handle *h); /* T */
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/* EV2Gym.reset() state-init part (ev2gym_env.py:298-306,329-331; init_statistic_variables
+ * utils.py:794-861; EV_Charger.reset ev_charger.py:96-112) for every env of the batch, on the same
+ * scenarios.  obs [E,D] may be NULL. */
+int ev2g_reset(ev2g_handle *h, double *obs);
+
+/* EV2Gym.step(actions) for all E envs (ev2gym_env.py:333-447).
+ *   actions     [E,P] float64, read-only here (the reference zeroes empty ports in the caller's
+ *               array, ev_charger.py:139; the single-env Python facade reproduces that)
+ *   obs         [E,D] state_function(env) after the step
+ *   reward      [E]
+ *   done        [E]   current_step >= simulation_length (:460)
+ *   action_mask [E,P] 1 where a port holds an EV after the spawn phase (:452-457); may be NULL
+ * Asynchronous on the handle's stream.  Returns EV2G_ERR_DONE if the batch is already done. */
+int ev2g_step(ev2g_handle *h, const double *actions, double *obs, double *reward, uint8_t *done,
+              uint8_t *action_mask);
+
+/* K consecutive steps from a device-resident action source, enqueued without host round trips.
+ * actions: [K,E,P] (action_step_stride = E*P) or one [E,P] block reused (stride 0).
+ * Output k is written at base + k*<stride> elements (stride 0 = overwrite one buffer).
+ * When the episode ends inside the K steps and auto_reset != 0, ev2g_reset() semantics are applied
+ * and stepping continues (the terminal obs of that step is the post-reset observation is NOT used:
+ * the terminal step still reports its own obs; the reset happens before the next step). */
+int ev2g_step_n(ev2g_handle *h, int k_steps, const double *actions, int64_t action_step_stride,
+                double *obs, int64_t obs_step_stride, double *reward, int64_t reward_step_stride,
+                uint8_t *done, int64_t done_step_stride, uint8_t *action_mask,
+                int64_t mask_step_stride, int auto_reset);
+
+int ev2g_current_step(const ev2g_handle *h);
+/* data-dependent faults recorded since the last reset (per-env flag word, device side):
+ * returns 0 or EV2G_ERR_OVERCURRENT; synchronises the stream. */
+int ev2g_check_faults(ev2g_handle *h, int32_t *first_bad_env);
+
+/* ---- episode statistics (get_statistics utils.py:12-123) ------------------------------------ */
+/* stats [E,EV2G_N_STATS] float64 DEVICE pointer, key order = ev2g_stat_name(i). */
+int ev2g_get_stats(ev2g_handle *h, double *stats);
+const char *ev2g_stat_name(int i);
+
+/* ---- inspection (feeds the read-only Python facade of the reference object graph) ----------- */
+/* HOST output buffers; any may be NULL.  Synchronises.  Port arrays are in reference port order;
+ * empty ports are NaN / -1.  */
+typedef struct ev2g_env_view {
+    int32_t current_step;
+    int32_t n_ports, n_chargers, n_transformers, n_steps;
+    double *port_capacity;        /* [P] EV.current_capacity                */
+    double *port_energy;          /* [P] EV.current_energy                  */
+    double *port_current;         /* [P] EV.actual_current                  */
+    double *port_total_energy;    /* [P] EV.total_energy_exchanged          */
+    double *port_required_energy; /* [P] EV.required_energy                 */
+    double *port_prev_power;      /* [P] EV.previous_power                  */
+    int32_t *port_cycles;         /* [P] EV.charging_cycles                 */
+    int32_t *port_session;        /* [P] index into the env's session list  */
+    double *cs_power;             /* [C] EV_Charger.current_power_output    */
+    double *cs_amps;              /* [C] EV_Charger.current_total_amps      */
+    double *cs_profits;           /* [C] total_profits                      */
+    double *cs_energy_charged;    /* [C] total_energy_charged               */
+    double *cs_energy_discharged; /* [C] total_energy_discharged            */
+    double *tr_power;             /* [R] Transformer.current_power          */
+    double *tr_overload;          /* [R,T] env.tr_overload                  */
+    double *power_usage;          /* [T] env.current_power_usage            */
+    double *power_potential;      /* [T] env.charge_power_potential         */
+    int32_t *session_port;        /* [S_env] resolved port of every session */
+    double *session_afap;         /* [S_env] EV.max_energy_AFAP             */
+} ev2g_env_view;
+int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *view);
+
+/* ---- plain device-memory helpers so a ctypes host needs no other HIP binding --------------- */
+void *ev2g_malloc(ev2g_handle *h, size_t bytes);
+void ev2g_free(ev2g_handle *h, void *p);
+int ev2g_memcpy_h2d(ev2g_handle *h, void *dst, const void *src, size_t bytes);
+int ev2g_memcpy_d2h(ev2g_handle *h, void *dst, const void *src, size_t bytes);
+int ev2g_synchronize(ev2g_handle *h);
+/* fills [n] doubles with uniform(lo,hi) from a counter-based generator (Philox-free splitmix64
+ * keyed on (seed, index)); the same function exists on the host as ev2g_host_uniform so CPU and
+ * GPU legs of a benchmark see identical action tensors (RandomAgent, heuristics.py:546-558). */
+int ev2g_fill_uniform(ev2g_handle *h, double *dst, int64_t n, uint64_t seed, double lo, double hi);
+void ev2g_host_uniform(double *dst, int64_t n, uint64_t seed, double lo, double hi);
+/* elapsed GPU time of the kernels enqueued by the last ev2g_step_n(), measured with HIP events on
+ * the handle's stream; total over the K launches, in milliseconds. */
+double ev2g_last_step_n_kernel_ms(ev2g_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EV2G_H */
