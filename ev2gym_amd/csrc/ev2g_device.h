@@ -1,0 +1,736 @@
+// ev2g_device.h -- CDNA4 (gfx950) device code of the vectorised EV2Gym step engine.
+//
+// One launch advances E independent envs by one (or K) timesteps of EV2Gym.step()
+// (reference ev2gym/models/ev2gym_env.py:333-447).  Work decomposition:
+//   * a 256-thread workgroup owns G = max(1, 256 / P) whole envs; lane <-> (env, port slot);
+//   * port slots are stored TRANSFORMER-MAJOR (the order both state functions emit, state.py:37-57,
+//     :128-151), so every transformer is a contiguous lane run and the observation is written in order;
+//   * phase 1  per-port: action -> amps -> two-stage charge / discharge -> ceil2, departures, arrivals,
+//              per-port observation columns, action mask (EV_Charger.step ev_charger.py:114-233,
+//              EV.step ev.py:138-186, spawn ev2gym_env.py:399-417);
+//   * phase 2  LDS-staged segmented reduction: per-port results are staged in LDS, each (env, transformer)
+//              segment is summed by a sub-wave lane group with __shfl_xor butterflies (fixed tree =>
+//              bit-reproducible), then R partials per env are folded (Transformer.step transformer.py:269-274);
+//   * phase 3  per-env: overload, reward, histories, observation head + forecast / limit windows
+//              (rl_agent/reward.py, rl_agent/state.py, transformer.py:142-188).
+// No cross-workgroup communication exists (envs are independent), so the K-step variant just loops in
+// the block.  Everything is float64; compiled with -ffp-contract=off and the reference's operation order,
+// because EV.my_ceil (ev.py:188-189) amplifies 1-ulp differences to 0.01 kWh.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EV2G_BLOCK 256
+#define EV2G_NQ 8  // staged quantities per port
+
+struct DevScn {  // read-only scenario + layout, device pointers
+    int E, T, C, npc, P, R, D, ND, dt;
+    int reward_kind, state_kind, flags;
+    int G;        // envs per workgroup
+    int gs;       // lanes per reduction group (power of two, 4..64)
+    int n_groups; // workgroups = ceil(E / G)
+    double sixty_over_dt;  // 60 / timescale   (ev.py:296)
+    double dt_over_60;     // timescale / 60   (ev.py:355)
+    // slot tables [P] (slot = transformer-major port order)
+    const int *slot_port, *slot_cs, *slot_obs, *slot_tr;
+    // chargers [C]
+    const double *cs_imin, *cs_imax, *cs_dmin, *cs_dmax_abs, *cs_volt, *cs_maxp, *cs_minp;
+    const double *cs_vk;  // [C,4] voltage*sqrt(k), k = 0..3
+    const int *cs_ph;
+    // transformers: slot segments [R+1], obs column of the 40-wide window block [R]
+    const int *tr_seg, *tr_obs;
+    // env series [E,T]
+    const double *price_ch, *price_dis, *setpoint;
+    // transformer series [E,R,T], [E,R]
+    const double *tr_maxp, *tr_minp, *tr_infl, *tr_solar, *tr_lf, *tr_pvf, *tr_peak;
+    const double *tr_dr;  // [E,R,ND,3]
+    const int *tr_ndr, *tr_ahead;
+    // sessions in device order (env, slot, arrival)
+    const int *ss_tarr, *ss_tdep, *ss_ntarr, *ss_ntdep, *ss_phases, *ss_lut;
+    const double *ss_cap0, *ss_B, *ss_des, *ss_minB, *ss_emerg, *ss_pacmax, *ss_pacmin, *ss_pdismax, *ss_pdismin,
+        *ss_ts, *ss_tsm, *ss_etach, *ss_etadis;
+    const double *lut;  // [NL,101]
+    // per port [E*P]: first session (or -1) and its window
+    const int *port_first;
+    const int2 *port_first_win;
+};
+
+struct DevState {  // mutable engine state, device pointers
+    double *cap, *tot_e, *prev_power;  // [E*P] EV.current_capacity / total_energy_exchanged / previous_power
+    int2 *win;                         // [E*P] {t_arr, t_dep} of the attached-or-next session (INT_MAX = none)
+    int2 *sc;                          // [E*P] {session index, charging_cycles}
+    double *cs_sat_sum;                // [E*C] EV_Charger.total_user_satisfaction
+    int *cs_served;                    // [E*C] EV_Charger.total_evs_served
+    double *cs_profits, *cs_e_ch, *cs_e_dis;  // [E*C] (EV2G_FLAG_LOG_CS_HISTORY) else nullptr
+    double *cs_power_hist, *cs_cur_hist;      // [T,E,C] (flag) else nullptr
+    double *cs_power_now, *cs_cur_now;        // [E*C] last step (flag)
+    double *env_acc;                   // [E,8] total_reward, profits, e_charged, e_discharged, emerg_violations
+    int *env_fault;                    // [E]
+    double *usage_hist, *pot_hist;     // [T,E]  env.current_power_usage / charge_power_potential (time-major)
+    double *over_hist;                 // [T,E,R] env.tr_overload
+    double *tr_power_now;              // [E,R]  Transformer.current_power of the last step
+    double *sess_final_cap;            // [S] capacity at departure
+    double *port_energy, *port_current;  // [E*P] EV.current_energy / actual_current of the last step
+};
+
+struct StepIO {
+    const double *actions; long long a_stride;
+    double *obs;           long long o_stride;
+    double *reward;        long long r_stride;
+    uint8_t *done;         long long d_stride;
+    uint8_t *mask;         long long m_stride;
+};
+
+#define EV2G_INT_MAX 0x7fffffff
+
+__device__ __forceinline__ double ceil2(double a) { return ceil(a * 100.0) / 100.0; }       // ev.py:188-189
+__device__ __forceinline__ double rnd5(double x) { return rint(x * 100000.0) / 100000.0; }  // ev_charger.py:157
+
+// dict.get(np.round(amps), 1): integer keys 0..100 exist, anything else -> 1   (ev.py:287-290, :375-379)
+__device__ __forceinline__ double lut_get(const double *__restrict__ lut, int id, double key) {
+    if (key >= 0.0 && key <= 100.0) return lut[id * 101 + (int)key];
+    return 1.0;
+}
+
+struct EvOut {
+    double energy, current;  // EV.current_energy (kWh this step), EV.actual_current (A)
+    int emerg;               // crossed min_emergency_battery_capacity (ev.py:401-402)
+    int active;              // EV.step went past the `amps == 0` early return (state was updated)
+};
+
+// EV.step + _charge/_discharge (ev.py:138-186, :240-355, :357-405) on one session's registers.
+// `cap`, `tot_e`, `prev_power`, `cycles` are updated in place.
+__device__ __forceinline__ EvOut ev_step(const DevScn &s, int ss, int cs, double amps, int ph_cs, double &cap,
+                                         double &tot_e, double &prev_power, int &cycles) {
+    EvOut o;
+    o.energy = 0.0;
+    o.current = 0.0;
+    o.emerg = 0;
+    o.active = 0;
+    const double *vk = s.cs_vk + cs * 4;
+    const double v_gate = vk[ph_cs];  // voltage*sqrt(charger phases): the min-power gates use the charger's phases
+    if (amps > 0.0 && amps < s.ss_pacmin[ss] * 1000.0 / v_gate)
+        amps = 0.0;
+    else if (amps < 0.0 && amps > s.ss_pdismin[ss] * 1000.0 / v_gate)
+        amps = 0.0;
+    if (amps == 0.0) return o;  // no ceil, previous_power untouched (ev.py:158-163)
+    o.active = 1;
+    if (prev_power == 0.0 || (prev_power / amps) < 0.0) cycles += 1;
+    const int evph = s.ss_phases[ss];
+    const double v = vk[evph < ph_cs ? evph : ph_cs];
+    const double B = s.ss_B[ss];
+    const int lut = s.ss_lut[ss];
+    if (amps > 0.0) {
+        const double eta = (lut >= 0) ? lut_get(s.lut, lut, rint(amps)) / 100.0 : s.ss_etach[ss];
+        const double pacmax = s.ss_pacmax[ss];
+        double pilot_dsoc = eta * amps * v / 1000.0 / B / s.sixty_over_dt;
+        const double max_dsoc = eta * pacmax / B / s.sixty_over_dt;
+        if (pilot_dsoc > max_dsoc) pilot_dsoc = max_dsoc;
+        const double soc = cap / B;
+        const double ts = s.ss_ts[ss];
+        double curr_soc;
+        if (ts == 1.0) {
+            curr_soc = pilot_dsoc + soc;
+            if (curr_soc > 1.0) curr_soc = 1.0;
+        } else {
+            const double tsm = s.ss_tsm[ss];
+            const double pts = ts + (pilot_dsoc - max_dsoc) / max_dsoc * (ts - 1.0);
+            double new_soc;
+            if (soc < pts) {
+                if (1.0 <= (pts - soc) / pilot_dsoc)
+                    new_soc = pilot_dsoc + soc;
+                else
+                    new_soc = 1.0 + exp(tsm * (pilot_dsoc + soc - pts) / (pts - 1.0)) * (pts - 1.0);
+            } else {
+                new_soc = 1.0 + exp(tsm * pilot_dsoc / (pts - 1.0)) * (soc - 1.0);
+            }
+            const double lim = (max_dsoc > pilot_dsoc) ? pilot_dsoc : max_dsoc;
+            curr_soc = (new_soc - soc > lim) ? (lim + soc) : new_soc;
+        }
+        const double dsoc = curr_soc - soc;
+        cap = curr_soc * B;
+        o.energy = dsoc * B;
+        o.current = o.energy / s.dt_over_60 * 1000.0 / v;
+    } else {
+        double given_power = amps * v / 1000.0;
+        const double pdismax = s.ss_pdismax[ss];
+        if (fabs(given_power) > fabs(pdismax)) given_power = pdismax;
+        const double eta = (lut >= 0) ? lut_get(s.lut, lut, fabs(rint(amps))) / 100.0 : s.ss_etadis[ss];
+        double given_energy = given_power * eta * (double)s.dt / 60.0;
+        const double minB = s.ss_minB[ss];
+        const double cap_before = cap;
+        if (cap + given_energy < minB) {
+            if (cap > minB) {
+                o.energy = -(cap - minB);
+                given_energy = o.energy;
+            } else {
+                o.energy = 0.0;
+                given_energy = 0.0;
+            }
+            cap = minB;
+        } else {
+            o.energy = given_energy;
+            cap += given_energy;
+        }
+        const double emerg = s.ss_emerg[ss];
+        if (cap_before > emerg && cap < emerg) o.emerg = 1;
+        o.current = given_energy * 60.0 / (double)s.dt * 1000.0 / v;
+    }
+    prev_power = o.energy;
+    tot_e += o.energy;
+    cap = ceil2(cap);
+    return o;
+}
+
+// Transformer.get_power_limits(step, 20)[j]  (transformer.py:142-171)
+__device__ __forceinline__ double power_limit_at(const DevScn &s, int er, int step, int j) {
+    const double peak = s.tr_peak[er];
+    double v = peak * 1.0;
+    const int nd = s.tr_ndr[er];
+    const int ahead = s.tr_ahead[er];
+    for (int k = 0; k < nd; k++) {
+        const double *ev = s.tr_dr + ((long long)er * s.ND + k) * 3;
+        const int es = (int)ev[0], ee = (int)ev[1];
+        if (step + ahead >= es && ee >= step) {
+            int a, b;
+            if (step > es) { a = 0; b = ee - step; }
+            else { a = es - step; b = ee - step; }
+            if (a < 0) a = -a;
+            if (b < 0) b = -b;
+            if (j >= a && j < b) v = peak - peak * ev[2] / 100.0;
+        }
+    }
+    return v;
+}
+
+// (loads - pv)[j] of Transformer.get_load_pv_forecast(step, 20)  (transformer.py:173-188).  The reference
+// overwrites forecast[step] with the actual value on every call, so after observing step s the window is
+// [actual[s], forecast[s+1..]] tail-padded with forecast[T-1], which itself became actual[T-1] once s >= T-1.
+__device__ __forceinline__ double load_minus_pv_at(const DevScn &s, long long erT, int step, int j) {
+    const int T = s.T;
+    const int k = step + j;
+    double l, p;
+    if (k < T) {
+        if (j == 0) { l = s.tr_infl[erT + k]; p = s.tr_solar[erT + k]; }
+        else        { l = s.tr_lf[erT + k];   p = s.tr_pvf[erT + k]; }
+    } else if (step >= T - 1) { l = 1.0 * s.tr_infl[erT + T - 1]; p = 1.0 * s.tr_solar[erT + T - 1]; }
+    else                      { l = 1.0 * s.tr_lf[erT + T - 1];   p = 1.0 * s.tr_pvf[erT + T - 1]; }
+    return l - p;
+}
+
+// butterfly sum over aligned lane groups of width gs (power of two <= 64): fixed tree, deterministic
+__device__ __forceinline__ double group_sum(double v, int gs) {
+    for (int d = gs >> 1; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Observation columns that do not belong to a port: head + per-transformer windows, for env `e` at step
+// counter `sstep` (= current_step after the increment), written cooperatively by `nl` lanes (lane id `l`).
+__device__ __forceinline__ void write_obs_env(const DevScn &s, double *__restrict__ obs_e, int e, int sstep,
+                                              double usage_prev, int l, int nl) {
+    const int T = s.T;
+    if (s.state_kind == 1) {  // PublicPST state.py:6-35
+        if (l == 0) {
+            obs_e[0] = (double)sstep / (double)T;
+            obs_e[1] = (sstep < T) ? s.setpoint[(long long)e * T + sstep] : 0.0;
+            obs_e[2] = usage_prev;
+        }
+        return;
+    }
+    // V2G_profit_max(_loads) state.py:65-83, :108-135
+    for (int c = l; c < 22; c += nl) {
+        double v;
+        if (c == 0) v = (double)sstep;
+        else if (c == 1) v = usage_prev;
+        else {
+            const int k = sstep + (c - 2);
+            v = (k < T) ? fabs(s.price_ch[(long long)e * T + k]) : 0.0;
+        }
+        obs_e[c] = v;
+    }
+    if (s.state_kind == 0) {
+        const int n = s.R * 40;
+        for (int i = l; i < n; i += nl) {
+            const int r = i / 40, j = i - r * 40;
+            const int er = e * s.R + r;
+            double v = (j < 20) ? load_minus_pv_at(s, (long long)er * T, sstep, j) : power_limit_at(s, er, sstep, j - 20);
+            obs_e[s.tr_obs[r] + j] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reset: EV2Gym.reset() state-init part (ev2gym_env.py:298-306,329-331; utils.py:794-861; ev_charger.py:96-112)
+__global__ void __launch_bounds__(EV2G_BLOCK) ev2g_reset_kernel(DevScn s, DevState st, double *__restrict__ obs) {
+    const int grp = blockIdx.x;
+    const int e0 = grp * s.G;
+    const int ne = min(s.G, s.E - e0);
+    const int P = s.P;
+    for (int idx = threadIdx.x; idx < ne * P; idx += EV2G_BLOCK) {
+        const int el = idx / P, q = idx - el * P;
+        const int e = e0 + el;
+        const long long g = (long long)e * P + q;
+        st.win[g] = s.port_first_win[g];
+        st.sc[g] = make_int2(s.port_first[g], 0);
+        st.cap[g] = 0.0;
+        st.tot_e[g] = 0.0;
+        st.prev_power[g] = 0.0;
+        st.port_energy[g] = 0.0;
+        st.port_current[g] = 0.0;
+        if (obs) {
+            double *o = obs + (long long)e * s.D + s.slot_obs[q];
+            o[0] = 0.0;
+            o[1] = 0.0;
+            if (s.state_kind == 1) o[2] = 0.0;
+        }
+    }
+    for (int idx = threadIdx.x; idx < ne * s.C; idx += EV2G_BLOCK) {
+        const long long g = (long long)e0 * s.C + idx;
+        st.cs_sat_sum[g] = 0.0;
+        st.cs_served[g] = 0;
+        if (st.cs_profits) { st.cs_profits[g] = 0.0; st.cs_e_ch[g] = 0.0; st.cs_e_dis[g] = 0.0; st.cs_power_now[g] = 0.0; st.cs_cur_now[g] = 0.0; }
+    }
+    for (int idx = threadIdx.x; idx < ne * 8; idx += EV2G_BLOCK) st.env_acc[(long long)e0 * 8 + idx] = 0.0;
+    for (int idx = threadIdx.x; idx < ne; idx += EV2G_BLOCK) st.env_fault[e0 + idx] = 0;
+    for (int idx = threadIdx.x; idx < ne * s.R; idx += EV2G_BLOCK) st.tr_power_now[(long long)e0 * s.R + idx] = 0.0;
+    if (obs) {
+        const int lpe = EV2G_BLOCK / ne;  // lanes per env
+        const int el = threadIdx.x / lpe;
+        if (el < ne) write_obs_env(s, obs + (long long)(e0 + el) * s.D, e0 + el, 0, 0.0, threadIdx.x - el * lpe, lpe);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// step: EV2Gym.step() for the envs of this workgroup, k_steps consecutive timesteps starting at t0.
+// Dynamic LDS: double stage[EV2G_NQ][N] ; double tsum[EV2G_NQ][G*R] ; double esum[EV2G_NQ][G]   (N = G*P)
+__global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevState st, StepIO io, int t0, int k_steps,
+                                                               int auto_reset) {
+    extern __shared__ double lds[];
+    // XCD-aware env-group mapping: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD a
+    // contiguous range of env groups so that each XCD's L2 holds a contiguous slice of the state arrays.
+    int grp;
+    {
+        const int nb = gridDim.x, b = blockIdx.x;
+        const int per = nb >> 3;
+        grp = (nb & 7) == 0 ? (b & 7) * per + (b >> 3) : b;
+    }
+    const int P = s.P, R = s.R, T = s.T, C = s.C, npc = s.npc;
+    const int e0 = grp * s.G;
+    const int ne = min(s.G, s.E - e0);
+    const int N = ne * P;
+    const int NS = s.G * P;  // stride of the staging arrays
+    double *stage = lds;
+    double *tsum = lds + (size_t)EV2G_NQ * NS;
+    double *esum = tsum + (size_t)EV2G_NQ * s.G * R;
+    const int tid = threadIdx.x;
+    const bool log_cs = st.cs_profits != nullptr;
+
+    int t = t0;
+    for (int kk = 0; kk < k_steps; kk++) {
+        if (t >= T) {  // episode finished inside a fused run
+            if (!auto_reset) break;
+            // in-kernel ev2g_reset for this workgroup's envs
+            for (int idx = tid; idx < N; idx += EV2G_BLOCK) {
+                const long long g = (long long)e0 * P + idx;
+                st.win[g] = s.port_first_win[g];
+                st.sc[g] = make_int2(s.port_first[g], 0);
+                st.port_energy[g] = 0.0;
+                st.port_current[g] = 0.0;
+            }
+            for (int idx = tid; idx < ne * C; idx += EV2G_BLOCK) {
+                const long long g = (long long)e0 * C + idx;
+                st.cs_sat_sum[g] = 0.0;
+                st.cs_served[g] = 0;
+                if (log_cs) { st.cs_profits[g] = 0.0; st.cs_e_ch[g] = 0.0; st.cs_e_dis[g] = 0.0; }
+            }
+            for (int idx = tid; idx < ne * 8; idx += EV2G_BLOCK) st.env_acc[(long long)e0 * 8 + idx] = 0.0;
+            for (int idx = tid; idx < ne; idx += EV2G_BLOCK) st.pot_hist[e0 + idx] = 0.0;
+            t = 0;
+            __syncthreads();
+        }
+        const double *__restrict__ actions = io.actions + (long long)kk * io.a_stride;
+        double *__restrict__ obs = io.obs ? io.obs + (long long)kk * io.o_stride : nullptr;
+        uint8_t *__restrict__ mask = io.mask ? io.mask + (long long)kk * io.m_stride : nullptr;
+        const int sstep = t + 1;
+
+        // ---------------- phase 1: per port ----------------
+        for (int idx = tid; idx < N; idx += EV2G_BLOCK) {
+            const int el = idx / P, q = idx - el * P;
+            const int e = e0 + el;
+            const long long g = (long long)e * P + q;
+            const int cs = s.slot_cs[q];
+            const int pref = s.slot_port[q];
+            int2 w = st.win[g];
+            const bool occ = (w.x <= t) && (t <= w.y);
+            double a = actions[(long long)e * P + pref];
+            if (!occ) a = 0.0;  // ev_charger.py:137-140
+            if (npc == 1) {     // ev_charger.py:143-149 with one port: a/a
+                if (a > 1.0) a = a / a;
+                else if (a < -1.0) a = -a / a;
+            } else {
+                const int j0 = q - (pref - cs * npc);  // slot of the charger's port 0 (ports of a charger are adjacent)
+                double S = 0.0;
+                for (int j = 0; j < npc; j++) {
+                    const int2 wj = st.win[g - q + j0 + j];
+                    const bool oj = (wj.x <= t) && (t <= wj.y);
+                    const double aj = oj ? actions[(long long)e * P + cs * npc + j] : 0.0;
+                    S = S + aj;
+                }
+                if (S > 1.0) a = a / S;
+                else if (S < -1.0) a = -a / S;
+            }
+            double energy = 0.0, current = 0.0, profit = 0.0, e_ch = 0.0, e_dis = 0.0, satpen = 0.0, pot = 0.0, emerg = 0.0;
+            double cap = 0.0, tot_e = 0.0;
+            int ss = -1;
+            if (occ) {
+                const double x = rnd5(a);
+                int2 sc = st.sc[g];
+                ss = sc.x;
+                cap = st.cap[g];
+                tot_e = st.tot_e[g];
+                if (x != 0.0) {
+                    double amps;
+                    const int ph = s.cs_ph[cs];
+                    if (x > 0.0) {
+                        amps = x * s.cs_imax[cs];
+                        if (amps < s.cs_imin[cs] - 0.01) amps = 0.0;
+                    } else {
+                        amps = x * s.cs_dmax_abs[cs];
+                        if (amps > s.cs_dmin[cs] - 0.01) amps = s.cs_dmin[cs];
+                    }
+                    double prev_power = st.prev_power[g];
+                    int cycles = sc.y;
+                    EvOut o = ev_step(s, ss, cs, amps, ph, cap, tot_e, prev_power, cycles);
+                    energy = o.energy;
+                    current = o.current;
+                    emerg = (double)o.emerg;
+                    const double ae = fabs(energy);
+                    if (x > 0.0) { profit = ae * s.price_ch[(long long)e * T + t]; e_ch = ae; }
+                    else         { profit = ae * s.price_dis[(long long)e * T + t]; e_dis = ae; }
+                    if (o.active) {
+                        st.cap[g] = cap;
+                        st.tot_e[g] = tot_e;
+                        st.prev_power[g] = prev_power;
+                        if (cycles != sc.y) st.sc[g] = make_int2(ss, cycles);
+                    }
+                }
+                st.port_energy[g] = energy;
+                st.port_current[g] = current;
+                // departure (ev_charger.py:209-229, ev.py:191-214)
+                if (t >= w.y) {
+                    const double des = s.ss_des[ss];
+                    const double score = (cap < des - 0.001) ? cap / des : 1.0;
+                    if (s.reward_kind != 1) satpen = 100.0 * exp(-10.0 * score);
+                    const long long gc = (long long)e * C + cs;
+                    if (npc == 1) {
+                        st.cs_served[gc] += 1;
+                        st.cs_sat_sum[gc] += score;
+                    } else {
+                        atomicAdd(&st.cs_served[gc], 1);
+                        atomicAdd(&st.cs_sat_sum[gc], score);
+                    }
+                    st.sess_final_cap[ss] = cap;
+                    w = make_int2(s.ss_ntarr[ss], s.ss_ntdep[ss]);
+                    ss = (w.x != EV2G_INT_MAX) ? ss + 1 : -1;
+                    st.win[g] = w;
+                    st.sc[g] = make_int2(ss, 0);
+                }
+            }
+            // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
+            bool occ_after = (w.x <= sstep) && (sstep <= w.y);
+            if (w.x == sstep) {
+                if (ss < 0) ss = st.sc[g].x;
+                cap = s.ss_cap0[ss];
+                tot_e = 0.0;
+                st.cap[g] = cap;
+                st.tot_e[g] = 0.0;
+                st.prev_power[g] = 0.0;
+                st.port_energy[g] = 0.0;
+                st.port_current[g] = 0.0;
+            }
+            if (mask) mask[(long long)e * P + pref] = occ_after ? 1 : 0;
+            // per-port observation columns + charge power potential (state.py, utils.py:760-791)
+            double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+            if (occ_after) {
+                const double B = s.ss_B[ss];
+                const double soc = cap / B;
+                if (s.state_kind == 1) { o0 = (soc == 1.0) ? 1.0 : 0.5; o1 = tot_e; o2 = (double)(sstep - w.x); }
+                else { o0 = soc; o1 = (double)(w.y - sstep); }
+                if (soc < 1.0 && w.y > sstep) {
+                    const int ph = s.cs_ph[cs];
+                    const int evph = s.ss_phases[ss];
+                    const int k = evph < ph ? evph : ph;
+                    const double sq_v = s.cs_vk[cs * 4 + k];  // sqrt(min(phases, ev_phases)) * voltage
+                    const double ev_current = s.ss_pacmax[ss] * 1000.0 / sq_v;
+                    const double cur = (ev_current < s.cs_imax[cs]) ? ev_current : s.cs_imax[cs];
+                    pot = sq_v * cur / 1000.0;
+                }
+            }
+            if (npc == 1) {  // per-charger clamp (utils.py:779-789)
+                const double mx = s.cs_maxp[cs], mn = s.cs_minp[cs];
+                pot = (pot > mx) ? mx : ((pot < mn) ? 0.0 : pot);
+            }
+            if (obs) {
+                double *o = obs + (long long)e * s.D + s.slot_obs[q];
+                o[0] = o0;
+                o[1] = o1;
+                if (s.state_kind == 1) o[2] = o2;
+            }
+            stage[0 * NS + idx] = energy * 60.0 / (double)s.dt;  // contribution to current_power_output
+            stage[1 * NS + idx] = current;
+            stage[2 * NS + idx] = profit;
+            stage[3 * NS + idx] = satpen;
+            stage[4 * NS + idx] = pot;
+            stage[5 * NS + idx] = e_ch;
+            stage[6 * NS + idx] = e_dis;
+            stage[7 * NS + idx] = emerg;
+        }
+        __syncthreads();
+
+        // ---------------- phase 1b: per charger (multi-port chargers, or charger history) ----------------
+        if (npc > 1 || log_cs) {
+            for (int idx = tid; idx < N; idx += EV2G_BLOCK) {
+                const int el = idx / P, q = idx - el * P;
+                const int cs = s.slot_cs[q];
+                const int pref = s.slot_port[q];
+                if (pref != cs * npc) continue;  // leader = port 0 of the charger
+                const int e = e0 + el;
+                double pw = 0.0, cur = 0.0, pr = 0.0, ec = 0.0, ed = 0.0, pp = 0.0;
+                bool fault = false;
+                for (int j = 0; j < npc; j++) {  // sequential, port order (ev_charger.py:155-205)
+                    pw += stage[0 * NS + idx + j];
+                    cur += stage[1 * NS + idx + j];
+                    pr += stage[2 * NS + idx + j];
+                    ec += stage[5 * NS + idx + j];
+                    ed += stage[6 * NS + idx + j];
+                    pp += stage[4 * NS + idx + j];
+                    if (cur - 0.0001 > s.cs_imax[cs]) fault = true;
+                }
+                if (fault) st.env_fault[e] = 1;
+                if (npc > 1) {
+                    const double mx = s.cs_maxp[cs], mn = s.cs_minp[cs];
+                    pp = (pp > mx) ? mx : ((pp < mn) ? 0.0 : pp);
+                    stage[4 * NS + idx] = pp;
+                    for (int j = 1; j < npc; j++) stage[4 * NS + idx + j] = 0.0;
+                }
+                if (log_cs) {
+                    const long long gc = (long long)e * C + cs;
+                    st.cs_profits[gc] += pr;
+                    st.cs_e_ch[gc] += ec;
+                    st.cs_e_dis[gc] += ed;
+                    st.cs_power_now[gc] = pw;
+                    st.cs_cur_now[gc] = cur;
+                    st.cs_power_hist[((long long)t * s.E + e) * C + cs] = pw;
+                    st.cs_cur_hist[((long long)t * s.E + e) * C + cs] = cur;
+                }
+            }
+            __syncthreads();
+        } else {
+            // single-port chargers: over-current check per port (ev_charger.py:203-205)
+            for (int idx = tid; idx < N; idx += EV2G_BLOCK) {
+                const int el = idx / P, q = idx - el * P;
+                if (stage[1 * NS + idx] - 0.0001 > s.cs_imax[s.slot_cs[q]]) st.env_fault[e0 + el] = 1;
+            }
+        }
+
+        // ---------------- phase 2: LDS-staged segmented reduction ----------------
+        {
+            const int gs = s.gs;
+            const int gid = tid / gs, gl = tid - gid * gs;
+            const int ngr = EV2G_BLOCK / gs;
+            const int ntask = ne * R;
+            const int npass = (ntask + ngr - 1) / ngr;
+            for (int pass = 0; pass < npass; pass++) {
+                const int task = pass * ngr + gid;
+                const bool live = task < ntask;
+                const int el = live ? task / R : 0;
+                const int r = live ? task - el * R : 0;
+                const int a = el * P + s.tr_seg[r], b = el * P + s.tr_seg[r + 1];
+                double acc[EV2G_NQ];
+#pragma unroll
+                for (int k = 0; k < EV2G_NQ; k++) acc[k] = 0.0;
+                if (live)
+                    for (int i = a + gl; i < b; i += gs) {
+#pragma unroll
+                        for (int k = 0; k < EV2G_NQ; k++) acc[k] += stage[k * NS + i];
+                    }
+#pragma unroll
+                for (int k = 0; k < EV2G_NQ; k++) acc[k] = group_sum(acc[k], gs);
+                if (live && gl == 0) {
+#pragma unroll
+                    for (int k = 0; k < EV2G_NQ; k++) tsum[k * (s.G * R) + task] = acc[k];
+                }
+            }
+        }
+        __syncthreads();
+        // fold the R transformer partials of each env: thread (el, k)
+        for (int idx = tid; idx < ne * EV2G_NQ; idx += EV2G_BLOCK) {
+            const int el = idx / EV2G_NQ, k = idx - el * EV2G_NQ;
+            double v = 0.0;
+            for (int r = 0; r < R; r++) v += tsum[k * (s.G * R) + el * R + r];
+            esum[k * s.G + el] = v;
+        }
+        __syncthreads();
+
+        // ---------------- phase 3: per env ----------------
+        {
+            const int lpe = EV2G_BLOCK / ne;  // lanes per env
+            const int el = tid / lpe, l = tid - el * lpe;
+            if (el < ne) {
+                const int e = e0 + el;
+                const double usage = esum[0 * s.G + el];
+                // transformers: Transformer.reset + step + get_how_overloaded (transformer.py:258-302)
+                double over_sum = 0.0;  // only lane 0 uses it
+                if (l == 0) {
+                    for (int r = 0; r < R; r++) {
+                        const long long erT = ((long long)e * R + r) * T + t;
+                        double ptr = s.tr_infl[erT] + s.tr_solar[erT];
+                        ptr += tsum[0 * (s.G * R) + el * R + r];
+                        const double mx = s.tr_maxp[erT], mn = s.tr_minp[erT];
+                        const double over = (ptr > mx + 0.0001 || ptr < mn - 0.0001) ? fabs(ptr - mx) : 0.0;
+                        st.over_hist[((long long)t * s.E + e) * R + r] = over;
+                        st.tr_power_now[(long long)e * R + r] = ptr;
+                        over_sum += 100.0 * over;
+                    }
+                    st.usage_hist[(long long)t * s.E + e] = usage;
+                    const double pot = esum[4 * s.G + el];
+                    if (sstep < T) st.pot_hist[(long long)sstep * s.E + e] = pot;
+                    double reward;
+                    const double costs = esum[2 * s.G + el];
+                    if (s.reward_kind == 1) {  // SquaredTrackingErrorReward reward.py:7-14
+                        const double sp = s.setpoint[(long long)e * T + t];
+                        const double pp = st.pot_hist[(long long)t * s.E + e];
+                        const double m = (pp < sp) ? pp : sp;
+                        const double d = m - usage;
+                        reward = -(d * d);
+                    } else if (s.reward_kind == 2) {  // profit_maximization reward.py:78-87
+                        reward = costs - esum[3 * s.G + el];
+                    } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
+                        reward = costs - over_sum - esum[3 * s.G + el];
+                    }
+                    double *acc = st.env_acc + (long long)e * 8;
+                    acc[0] += reward;
+                    acc[1] += costs;
+                    acc[2] += esum[5 * s.G + el];
+                    acc[3] += esum[6 * s.G + el];
+                    acc[4] += esum[7 * s.G + el];
+                    if (io.reward) io.reward[(long long)kk * io.r_stride + e] = reward;
+                    if (io.done) io.done[(long long)kk * io.d_stride + e] = (sstep >= T) ? 1 : 0;
+                }
+                if (obs) write_obs_env(s, obs + (long long)e * s.D, e, sstep, usage, l, lpe);
+            }
+        }
+        t += 1;
+        __syncthreads();
+    }
+}
+
+// counter-based uniform generator (splitmix64 of (seed, index)); identical on host (ev2g_host_uniform)
+__host__ __device__ inline double ev2g_u01(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__global__ void ev2g_fill_uniform_kernel(double *dst, long long n, uint64_t seed, double lo, double hi) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = lo + (hi - lo) * ev2g_u01(seed, (uint64_t)i);
+}
+
+// episode statistics (get_statistics utils.py:12-123) -- one thread per env
+__global__ void ev2g_stats_kernel(DevScn s, DevState st, const long long *__restrict__ env_sess /*[E+1] device order*/,
+                                  const double *__restrict__ ss_afap, int cur_step, double *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= s.E) return;
+    const int T = s.T, C = s.C, R = s.R, P = s.P;
+    double served = 0.0, sat = 0.0;
+    int nsat = 0;
+    for (int c = 0; c < C; c++) {
+        const int n = st.cs_served[(long long)e * C + c];
+        served += n;
+        if (n > 0) { sat += st.cs_sat_sum[(long long)e * C + c] / n; nsat++; }
+    }
+    double over = 0.0;
+    for (int t = 0; t < T; t++)
+        for (int r = 0; r < R; r++) over += st.over_hist[((long long)t * s.E + e) * R + r];
+    double te = 0.0, ete = 0.0, ptv = 0.0;
+    for (int t = 0; t < T; t++) {
+        const double sp = s.setpoint[(long long)e * T + t], u = st.usage_hist[(long long)t * s.E + e];
+        const double d = sp - u;
+        te += d * d;
+        ete += fabs(d);
+        if (u > sp) ptv += u - sp;
+    }
+    ete *= (double)s.dt / 60.0;
+    // energy user satisfaction over every spawned session (utils.py:57-63): e_actual / max_energy_AFAP * 100
+    double sum = 0.0, mn = INFINITY;
+    int n = 0;
+    for (int q = 0; q < P; q++) {
+        const long long g = (long long)e * P + q;
+        const int first = s.port_first[g];
+        if (first < 0) continue;
+        const int2 w = st.win[g];
+        int cur = st.sc[g].x;  // attached-or-next session, -1 when the port's list is exhausted
+        int last;              // sessions [first, last) have been spawned
+        bool attached = false;
+        if (cur < 0) {
+            // exhausted: every session of the port was spawned; find the end by walking the chain
+            last = first;
+            while (s.ss_ntarr[last] != EV2G_INT_MAX) last++;
+            last += 1;
+        } else {
+            attached = (w.x <= cur_step);  // spawned at the end of step t_arr-1 => present once current_step >= t_arr
+            last = attached ? cur + 1 : cur;
+        }
+        for (int k = first; k < last; k++) {
+            const double capk = (attached && k == last - 1) ? st.cap[g] : st.sess_final_cap[k];
+            const double v = capk / ss_afap[k] * 100.0;
+            sum += v;
+            if (v < mn) mn = v;
+            n++;
+        }
+    }
+    double mean = NAN, sd = NAN, mnv = NAN;
+    if (n > 0) {
+        mean = sum / n;
+        double var = 0.0;
+        for (int q = 0; q < P; q++) {
+            const long long g = (long long)e * P + q;
+            const int first = s.port_first[g];
+            if (first < 0) continue;
+            const int2 w = st.win[g];
+            int cur = st.sc[g].x, last;
+            bool attached = false;
+            if (cur < 0) { last = first; while (s.ss_ntarr[last] != EV2G_INT_MAX) last++; last += 1; }
+            else { attached = (w.x <= cur_step); last = attached ? cur + 1 : cur; }
+            for (int k = first; k < last; k++) {
+                const double capk = (attached && k == last - 1) ? st.cap[g] : st.sess_final_cap[k];
+                const double v = capk / ss_afap[k] * 100.0 - mean;
+                var += v * v;
+            }
+        }
+        sd = sqrt(var / n);
+        mnv = mn;
+    }
+    const double *acc = st.env_acc + (long long)e * 8;
+    double *o = out + (long long)e * 17;
+    o[0] = served;
+    o[1] = acc[1];
+    o[2] = acc[2];
+    o[3] = acc[3];
+    o[4] = nsat ? sat / nsat : NAN;
+    o[5] = ptv;
+    o[6] = te;
+    o[7] = ete;
+    o[8] = mean;
+    o[9] = sd;
+    o[10] = mnv;
+    o[11] = acc[4];
+    o[12] = over;
+    o[13] = NAN;  // battery degradation: needs the per-session SoC log (not in this round)
+    o[14] = NAN;
+    o[15] = NAN;
+    o[16] = acc[0];
+}

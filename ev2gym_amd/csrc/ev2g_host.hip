@@ -1,0 +1,714 @@
+// ev2g_host.hip -- host side of libev2g_hip.so: the C-ABI of include/ev2g.h over HIP.
+//
+// Scenario packing (the host half of ev2g_load_scenarios) turns the reference-shaped batch
+// (chargers, transformers, EVs_profiles-ordered sessions) into the device layout documented in
+// ev2g_device.h / DESIGN.md:  transformer-major port slots, sessions sorted by (env, slot, arrival)
+// with the next session's window chained in, per-port first-session tables, max_energy_AFAP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ev2g.h"
+#include "ev2g_device.h"
+
+static thread_local std::string g_create_error;
+
+struct ev2g_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    ev2g_config cfg{};
+    bool loaded = false;
+    DevScn scn{};
+    DevState st{};
+    std::vector<void *> scn_allocs, st_allocs, user_allocs;
+    // host mirrors for peek / stats
+    int E = 0, T = 0, C = 0, npc = 0, P = 0, R = 0, D = 0;
+    long long S = 0;
+    std::vector<int> slot_port, port_slot;
+    std::vector<long long> env_sess_start;      // [E+1] host order
+    std::vector<int> host_to_dev;               // [S] device session index of host session
+    std::vector<int> sess_port;                 // [S] resolved reference port, host order
+    std::vector<double> sess_afap;              // [S] host order
+    long long *d_env_sess = nullptr;            // unused placeholder for the stats kernel signature
+    double *d_ss_afap = nullptr;                // [S] device order
+    int current_step = 0;
+    size_t lds_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::string err;
+};
+
+#define HIPCHK(h, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+            return EV2G_ERR_HIP;                                                                     \
+        }                                                                                            \
+    } while (0)
+
+static int fail(ev2g_handle *h, int code, const std::string &msg) {
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+template <typename T>
+static int upload(ev2g_handle *h, std::vector<void *> &pool, const T *src, size_t n, T **dst) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIPCHK(h, hipMalloc(&p, bytes));
+    pool.push_back(p);
+    if (n) HIPCHK(h, hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    *dst = (T *)p;
+    return 0;
+}
+template <typename T>
+static int dalloc(ev2g_handle *h, std::vector<void *> &pool, size_t n, T **dst) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIPCHK(h, hipMalloc(&p, bytes));
+    HIPCHK(h, hipMemsetAsync(p, 0, bytes, h->stream));
+    pool.push_back(p);
+    *dst = (T *)p;
+    return 0;
+}
+static void free_pool(std::vector<void *> &pool) {
+    for (void *p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+extern "C" {
+
+int ev2g_abi_version(void) { return EV2G_ABI_VERSION; }
+
+const char *ev2g_last_error(const ev2g_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ev2g_create(const ev2g_config *cfg, ev2g_handle **out) {
+    if (!cfg || !out) return fail(nullptr, EV2G_ERR_ARG, "ev2g_create: null argument");
+    if (cfg->reward_kind < 0 || cfg->reward_kind > 2 || cfg->state_kind < 0 || cfg->state_kind > 2)
+        return fail(nullptr, EV2G_ERR_ARG, "ev2g_create: unknown reward_kind/state_kind");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(nullptr, EV2G_ERR_HIP, "ev2g_create: no HIP device visible (the engine has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= n) return fail(nullptr, EV2G_ERR_ARG, "ev2g_create: device ordinal out of range");
+    ev2g_handle *h = new ev2g_handle();
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    if (hipSetDevice(h->device) != hipSuccess) {
+        delete h;
+        return fail(nullptr, EV2G_ERR_HIP, "ev2g_create: hipSetDevice failed");
+    }
+    if (cfg->stream) {
+        h->stream = (hipStream_t)cfg->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete h;
+            return fail(nullptr, EV2G_ERR_HIP, "ev2g_create: hipStreamCreate failed");
+        }
+        h->own_stream = true;
+    }
+    (void)hipEventCreate(&h->ev0);
+    (void)hipEventCreate(&h->ev1);
+    *out = h;
+    return EV2G_OK;
+}
+
+void ev2g_destroy(ev2g_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    free_pool(h->scn_allocs);
+    free_pool(h->st_allocs);
+    free_pool(h->user_allocs);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int ev2g_n_envs(const ev2g_handle *h) { return h ? h->E : 0; }
+int ev2g_n_ports(const ev2g_handle *h) { return h ? h->P : 0; }
+int ev2g_obs_dim(const ev2g_handle *h) { return h ? h->D : 0; }
+int ev2g_n_steps(const ev2g_handle *h) { return h ? h->T : 0; }
+int ev2g_current_step(const ev2g_handle *h) { return h ? h->current_step : 0; }
+
+static const char *kStatNames[EV2G_N_STATS] = {
+    "total_ev_served", "total_profits", "total_energy_charged", "total_energy_discharged",
+    "average_user_satisfaction", "power_tracker_violation", "tracking_error", "energy_tracking_error",
+    "energy_user_satisfaction", "std_energy_user_satisfaction", "min_energy_user_satisfaction",
+    "total_steps_min_emergency_battery_capacity_violation", "total_transformer_overload",
+    "battery_degradation", "battery_degradation_calendar", "battery_degradation_cycling", "total_reward"};
+const char *ev2g_stat_name(int i) { return (i >= 0 && i < EV2G_N_STATS) ? kStatNames[i] : ""; }
+
+// EV.calculate_max_energy_with_AFAP (ev.py:407-440)
+static double afap_energy(const ev2g_scenario_batch *b, long long s, double max_cs_power) {
+    const double pac = b->ev_pac_max[s];
+    const double max_power = (std::fabs(max_cs_power) > std::fabs(pac)) ? pac : max_cs_power;
+    double eff;
+    if (b->ev_lut[s] >= 0) {
+        double m = 0;
+        for (int k = 0; k < EV2G_LUT_LEN; k++) m = std::max(m, b->lut[(size_t)b->ev_lut[s] * EV2G_LUT_LEN + k]);
+        eff = m / 100.0;
+    } else
+        eff = b->ev_eta_ch[s];
+    double x = b->ev_cap0[s];
+    for (int k = b->ev_t_arr[s]; k < b->ev_t_dep[s] + 1; k++) {
+        x += max_power * eff * b->timescale / 60.0;
+        x = std::ceil(x * 100.0) / 100.0;
+        if (x > b->ev_B[s]) {
+            x = b->ev_B[s];
+            break;
+        }
+    }
+    return x;
+}
+
+int ev2g_reset(ev2g_handle *h, double *obs);
+
+int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
+    if (!h || !b) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: null argument");
+    (void)hipSetDevice(h->device);
+    const int E = b->n_envs, T = b->n_steps, C = b->n_chargers, npc = b->ports_per_charger, R = b->n_transformers;
+    const int ND = std::max(b->n_dr_max, 0);
+    if (E <= 0 || T <= 0 || C <= 0 || npc <= 0 || R <= 0 || b->timescale <= 0)
+        return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: non-positive size");
+    if (b->horizon != 20) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: horizon must be 20 (state.py:119,129-132)");
+    if (npc > 32) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: more than 32 ports per charger unsupported");
+    const int P = C * npc;
+    const long long S = b->env_session_start[E];
+    if (S != b->n_sessions || b->env_session_start[0] != 0)
+        return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: env_session_start inconsistent with n_sessions");
+    if (S > 0x7ffffff0LL) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: too many sessions for 32-bit indices");
+    for (int c = 0; c < C; c++) {
+        if (b->cs_transformer[c] < 0 || b->cs_transformer[c] >= R)
+            return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: cs_transformer out of range");
+        if (b->cs_phases[c] < 1 || b->cs_phases[c] > 3)
+            return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: cs_phases must be 1..3");
+    }
+    (void)hipStreamSynchronize(h->stream);
+    free_pool(h->scn_allocs);
+    free_pool(h->st_allocs);
+    h->loaded = false;
+
+    // ---- slot order: transformer-major, chargers in id order inside a transformer, ports adjacent ----
+    std::vector<int> slot_port(P), slot_cs(P), slot_tr(P), slot_obs(P), port_slot(P), tr_seg(R + 1, 0), tr_obs(R);
+    {
+        int q = 0;
+        for (int r = 0; r < R; r++) {
+            tr_seg[r] = q;
+            for (int c = 0; c < C; c++)
+                if (b->cs_transformer[c] == r)
+                    for (int j = 0; j < npc; j++) {
+                        slot_port[q] = c * npc + j;
+                        slot_cs[q] = c;
+                        slot_tr[q] = r;
+                        port_slot[c * npc + j] = q;
+                        q++;
+                    }
+        }
+        tr_seg[R] = q;
+    }
+    const int sk = h->cfg.state_kind;
+    int D;
+    if (sk == EV2G_STATE_PUBLIC_PST) {
+        D = 3 + 3 * P;
+        for (int q = 0; q < P; q++) slot_obs[q] = 3 + 3 * q;
+        for (int r = 0; r < R; r++) tr_obs[r] = 0;
+    } else if (sk == EV2G_STATE_V2G_PROFIT_MAX) {
+        D = 22 + 2 * P;
+        for (int q = 0; q < P; q++) slot_obs[q] = 22 + 2 * q;
+        for (int r = 0; r < R; r++) tr_obs[r] = 0;
+    } else {
+        D = 22 + 40 * R + 2 * P;
+        for (int r = 0; r < R; r++) tr_obs[r] = 22 + 40 * r + 2 * tr_seg[r];
+        for (int q = 0; q < P; q++) slot_obs[q] = 22 + 40 * (slot_tr[q] + 1) + 2 * q;
+    }
+    int max_seg = 1;
+    for (int r = 0; r < R; r++) max_seg = std::max(max_seg, tr_seg[r + 1] - tr_seg[r]);
+
+    // ---- resolve ports (first-free replay, ev_charger.py:266-286) and order sessions by (env, slot, arrival) ----
+    std::vector<int> sess_port((size_t)S), host_to_dev((size_t)S);
+    std::vector<long long> dev_to_host((size_t)S);
+    std::vector<int> port_first((size_t)E * P, -1);
+    std::vector<int2> port_first_win((size_t)E * P, make_int2(EV2G_INT_MAX, EV2G_INT_MAX));
+    {
+        std::vector<int> free_at((size_t)C * npc);
+        std::vector<std::pair<long long, long long>> keyed;  // (slot, host idx)
+        long long d = 0;
+        for (int e = 0; e < E; e++) {
+            std::fill(free_at.begin(), free_at.end(), 0);
+            const long long s0 = b->env_session_start[e], s1 = b->env_session_start[e + 1];
+            if (s1 < s0) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: env_session_start not monotone");
+            keyed.clear();
+            int prev_arr = 0;
+            for (long long s = s0; s < s1; s++) {
+                const int cs = b->ev_cs[s], ta = b->ev_t_arr[s], td = b->ev_t_dep[s];
+                if (cs < 0 || cs >= C) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: ev_cs out of range");
+                if (ta < 1 || td < ta) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: need 1 <= t_arr <= t_dep");
+                if (ta < prev_arr) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: sessions must be sorted by arrival");
+                if (b->ev_phases[s] < 1 || b->ev_phases[s] > 3)
+                    return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: ev_phases must be 1..3");
+                if (b->ev_lut[s] >= b->n_lut) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: ev_lut out of range");
+                prev_arr = ta;
+                int slot = -1;
+                for (int j = 0; j < npc; j++)
+                    if (free_at[(size_t)cs * npc + j] <= ta - 1) {  // attached at the end of step ta-1
+                        slot = j;
+                        break;
+                    }
+                if (slot < 0)
+                    return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: no free port for a session (assert n_evs_connected < n_ports, ev_charger.py:271)");
+                free_at[(size_t)cs * npc + slot] = td;  // freed inside step td, before that step's spawns
+                sess_port[s] = cs * npc + slot;
+                keyed.emplace_back((long long)port_slot[cs * npc + slot], s);
+            }
+            std::stable_sort(keyed.begin(), keyed.end(),
+                             [](const auto &x, const auto &y) { return x.first < y.first; });
+            for (auto &kv : keyed) {
+                host_to_dev[kv.second] = (int)d;
+                dev_to_host[d] = kv.second;
+                const size_t g = (size_t)e * P + kv.first;
+                if (port_first[g] < 0) {
+                    port_first[g] = (int)d;
+                    port_first_win[g] = make_int2(b->ev_t_arr[kv.second], b->ev_t_dep[kv.second]);
+                }
+                d++;
+            }
+        }
+    }
+    // ---- gather session fields into device order, chain the next window ----
+#define GATHER(type, name, src)                                 \
+    std::vector<type> name((size_t)S);                          \
+    for (long long d = 0; d < S; d++) name[d] = b->src[dev_to_host[d]];
+    GATHER(int, ss_tarr, ev_t_arr)
+    GATHER(int, ss_tdep, ev_t_dep)
+    GATHER(int, ss_phases, ev_phases)
+    GATHER(int, ss_lut, ev_lut)
+    GATHER(double, ss_cap0, ev_cap0)
+    GATHER(double, ss_B, ev_B)
+    GATHER(double, ss_des, ev_desired)
+    GATHER(double, ss_minB, ev_minB)
+    GATHER(double, ss_emerg, ev_min_emerg)
+    GATHER(double, ss_pacmax, ev_pac_max)
+    GATHER(double, ss_pacmin, ev_pac_min)
+    GATHER(double, ss_pdismax, ev_pdis_max)
+    GATHER(double, ss_pdismin, ev_pdis_min)
+    GATHER(double, ss_ts, ev_ts)
+    GATHER(double, ss_tsm, ev_tsm)
+    GATHER(double, ss_etach, ev_eta_ch)
+    GATHER(double, ss_etadis, ev_eta_dis)
+#undef GATHER
+    std::vector<int> ss_ntarr((size_t)S, EV2G_INT_MAX), ss_ntdep((size_t)S, EV2G_INT_MAX);
+    std::vector<double> ss_afap((size_t)S), sess_afap_host((size_t)S);
+    for (long long d = 0; d + 1 < S; d++) {
+        const long long a = dev_to_host[d], c = dev_to_host[d + 1];
+        // same env and same port => the next device session is this port's next session
+        bool same_env = false;
+        {
+            // env of a host session: binary search in env_session_start
+            const int64_t *st = b->env_session_start;
+            const int64_t *ua = std::upper_bound(st, st + E + 1, (int64_t)a);
+            const int64_t *uc = std::upper_bound(st, st + E + 1, (int64_t)c);
+            same_env = (ua == uc);
+        }
+        if (same_env && sess_port[a] == sess_port[c]) {
+            ss_ntarr[d] = ss_tarr[d + 1];
+            ss_ntdep[d] = ss_tdep[d + 1];
+        }
+    }
+    std::vector<double> cs_maxp(C), cs_minp(C), cs_vk((size_t)C * 4), cs_dmax_abs(C);
+    for (int c = 0; c < C; c++) {
+        const double V = b->cs_voltage[c];
+        for (int k = 0; k < 4; k++) cs_vk[(size_t)c * 4 + k] = V * std::sqrt((double)k);
+        const double sq = std::sqrt((double)b->cs_phases[c]);
+        cs_maxp[c] = sq * V * b->cs_max_charge_current[c] / 1000;  // utils.py:779-782
+        cs_minp[c] = sq * V * b->cs_min_charge_current[c] / 1000;
+        cs_dmax_abs[c] = std::fabs(b->cs_max_discharge_current[c]);
+    }
+    for (long long s = 0; s < S; s++) {
+        const int cs = b->ev_cs[s];
+        // EV_Charger.get_max_power (ev_charger.py:251-252)
+        const double mp = b->cs_max_charge_current[cs] * b->cs_voltage[cs] * std::sqrt((double)b->cs_phases[cs]) / 1000;
+        sess_afap_host[s] = afap_energy(b, s, mp);
+        ss_afap[host_to_dev[s]] = sess_afap_host[s];
+    }
+    std::vector<double> tr_peak((size_t)E * R);
+    for (size_t er = 0; er < (size_t)E * R; er++) {
+        double m = b->tr_max_power[er * T];
+        for (int t = 1; t < T; t++) m = std::max(m, b->tr_max_power[er * T + t]);
+        tr_peak[er] = m;
+    }
+
+    // ---- launch geometry ----
+    DevScn &s = h->scn;
+    s = DevScn{};
+    s.E = E; s.T = T; s.C = C; s.npc = npc; s.P = P; s.R = R; s.D = D; s.ND = std::max(ND, 1); s.dt = b->timescale;
+    s.reward_kind = h->cfg.reward_kind; s.state_kind = sk; s.flags = h->cfg.flags;
+    s.G = std::max(1, EV2G_BLOCK / P);
+    s.G = std::min(s.G, E);
+    {
+        int gs = 4;
+        while (gs < 64 && gs < max_seg) gs <<= 1;
+        s.gs = gs;
+    }
+    s.n_groups = (E + s.G - 1) / s.G;
+    s.sixty_over_dt = 60.0 / (double)b->timescale;
+    s.dt_over_60 = (double)b->timescale / 60.0;
+    h->lds_bytes = sizeof(double) * ((size_t)EV2G_NQ * s.G * P + (size_t)EV2G_NQ * s.G * R + (size_t)EV2G_NQ * s.G);
+    if (h->lds_bytes > 160 * 1024)
+        return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: ports per env exceed the LDS staging capacity (P <= ~2400)");
+    if (h->lds_bytes > 64 * 1024) {
+        HIPCHK(h, hipFuncSetAttribute((const void *)ev2g_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)h->lds_bytes));
+    }
+
+    // ---- upload ----
+    auto &pool = h->scn_allocs;
+    int rc = 0;
+#define UP(dst, vec) if ((rc = upload(h, pool, (vec).data(), (vec).size(), &(dst)))) return rc;
+#define UPP(dst, ptr, n) if ((rc = upload(h, pool, (ptr), (size_t)(n), &(dst)))) return rc;
+    int *ip; double *dp; int2 *i2p;
+    UP(ip, slot_port) s.slot_port = ip;
+    UP(ip, slot_cs) s.slot_cs = ip;
+    UP(ip, slot_obs) s.slot_obs = ip;
+    UP(ip, slot_tr) s.slot_tr = ip;
+    UPP(dp, b->cs_min_charge_current, C) s.cs_imin = dp;
+    UPP(dp, b->cs_max_charge_current, C) s.cs_imax = dp;
+    UPP(dp, b->cs_min_discharge_current, C) s.cs_dmin = dp;
+    UP(dp, cs_dmax_abs) s.cs_dmax_abs = dp;
+    UPP(dp, b->cs_voltage, C) s.cs_volt = dp;
+    UP(dp, cs_maxp) s.cs_maxp = dp;
+    UP(dp, cs_minp) s.cs_minp = dp;
+    UP(dp, cs_vk) s.cs_vk = dp;
+    UPP(ip, b->cs_phases, C) s.cs_ph = ip;
+    UP(ip, tr_seg) s.tr_seg = ip;
+    UP(ip, tr_obs) s.tr_obs = ip;
+    UPP(dp, b->charge_price, (size_t)E * T) s.price_ch = dp;
+    UPP(dp, b->discharge_price, (size_t)E * T) s.price_dis = dp;
+    UPP(dp, b->power_setpoints, (size_t)E * T) s.setpoint = dp;
+    UPP(dp, b->tr_max_power, (size_t)E * R * T) s.tr_maxp = dp;
+    UPP(dp, b->tr_min_power, (size_t)E * R * T) s.tr_minp = dp;
+    UPP(dp, b->tr_inflexible_load, (size_t)E * R * T) s.tr_infl = dp;
+    UPP(dp, b->tr_solar_power, (size_t)E * R * T) s.tr_solar = dp;
+    UPP(dp, b->tr_load_forecast, (size_t)E * R * T) s.tr_lf = dp;
+    UPP(dp, b->tr_pv_forecast, (size_t)E * R * T) s.tr_pvf = dp;
+    UP(dp, tr_peak) s.tr_peak = dp;
+    UPP(dp, b->tr_dr, (size_t)E * R * ND * 3) s.tr_dr = dp;
+    UPP(ip, b->tr_n_dr, (size_t)E * R) s.tr_ndr = ip;
+    UPP(ip, b->tr_steps_ahead, (size_t)E * R) s.tr_ahead = ip;
+    UP(ip, ss_tarr) s.ss_tarr = ip;
+    UP(ip, ss_tdep) s.ss_tdep = ip;
+    UP(ip, ss_ntarr) s.ss_ntarr = ip;
+    UP(ip, ss_ntdep) s.ss_ntdep = ip;
+    UP(ip, ss_phases) s.ss_phases = ip;
+    UP(ip, ss_lut) s.ss_lut = ip;
+    UP(dp, ss_cap0) s.ss_cap0 = dp;
+    UP(dp, ss_B) s.ss_B = dp;
+    UP(dp, ss_des) s.ss_des = dp;
+    UP(dp, ss_minB) s.ss_minB = dp;
+    UP(dp, ss_emerg) s.ss_emerg = dp;
+    UP(dp, ss_pacmax) s.ss_pacmax = dp;
+    UP(dp, ss_pacmin) s.ss_pacmin = dp;
+    UP(dp, ss_pdismax) s.ss_pdismax = dp;
+    UP(dp, ss_pdismin) s.ss_pdismin = dp;
+    UP(dp, ss_ts) s.ss_ts = dp;
+    UP(dp, ss_tsm) s.ss_tsm = dp;
+    UP(dp, ss_etach) s.ss_etach = dp;
+    UP(dp, ss_etadis) s.ss_etadis = dp;
+    UPP(dp, b->lut, (size_t)b->n_lut * EV2G_LUT_LEN) s.lut = dp;
+    UP(ip, port_first) s.port_first = ip;
+    UP(i2p, port_first_win) s.port_first_win = i2p;
+    UP(dp, ss_afap) h->d_ss_afap = dp;
+#undef UP
+#undef UPP
+    // ---- state ----
+    DevState &st = h->st;
+    st = DevState{};
+    auto &sp = h->st_allocs;
+    const size_t EP = (size_t)E * P, EC = (size_t)E * C;
+#define AL(field, n) if ((rc = dalloc(h, sp, (size_t)(n), &st.field))) return rc;
+    AL(cap, EP) AL(tot_e, EP) AL(prev_power, EP) AL(win, EP) AL(sc, EP) AL(port_energy, EP) AL(port_current, EP)
+    AL(cs_sat_sum, EC) AL(cs_served, EC)
+    if (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) {
+        AL(cs_profits, EC) AL(cs_e_ch, EC) AL(cs_e_dis, EC) AL(cs_power_now, EC) AL(cs_cur_now, EC)
+        AL(cs_power_hist, (size_t)T * EC) AL(cs_cur_hist, (size_t)T * EC)
+    }
+    AL(env_acc, (size_t)E * 8) AL(env_fault, E)
+    AL(usage_hist, (size_t)T * E) AL(pot_hist, (size_t)T * E) AL(over_hist, (size_t)T * E * R)
+    AL(tr_power_now, (size_t)E * R) AL(sess_final_cap, S)
+#undef AL
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
+
+    h->E = E; h->T = T; h->C = C; h->npc = npc; h->P = P; h->R = R; h->D = D; h->S = S;
+    h->slot_port = slot_port;
+    h->port_slot = port_slot;
+    h->env_sess_start.assign(b->env_session_start, b->env_session_start + E + 1);
+    h->host_to_dev = host_to_dev;
+    h->sess_port = sess_port;
+    h->sess_afap = sess_afap_host;
+    h->loaded = true;
+    return ev2g_reset(h, nullptr);
+}
+
+int ev2g_reset(ev2g_handle *h, double *obs) {
+    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_reset: no scenarios loaded");
+    (void)hipSetDevice(h->device);
+    const DevScn &s = h->scn;
+    HIPCHK(h, hipMemsetAsync(h->st.usage_hist, 0, sizeof(double) * (size_t)s.T * s.E, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->st.pot_hist, 0, sizeof(double) * (size_t)s.T * s.E, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->st.over_hist, 0, sizeof(double) * (size_t)s.T * s.E * s.R, h->stream));
+    if (h->st.cs_power_hist) {
+        HIPCHK(h, hipMemsetAsync(h->st.cs_power_hist, 0, sizeof(double) * (size_t)s.T * s.E * s.C, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->st.cs_cur_hist, 0, sizeof(double) * (size_t)s.T * s.E * s.C, h->stream));
+    }
+    hipLaunchKernelGGL(ev2g_reset_kernel, dim3(s.n_groups), dim3(EV2G_BLOCK), 0, h->stream, s, h->st, obs);
+    HIPCHK(h, hipGetLastError());
+    h->current_step = 0;
+    return EV2G_OK;
+}
+
+static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int auto_reset) {
+    const DevScn &s = h->scn;
+    hipLaunchKernelGGL(ev2g_step_kernel, dim3(s.n_groups), dim3(EV2G_BLOCK), h->lds_bytes, h->stream, s, h->st, io, t0,
+                       k, auto_reset);
+    HIPCHK(h, hipGetLastError());
+    return EV2G_OK;
+}
+
+int ev2g_step(ev2g_handle *h, const double *actions, double *obs, double *reward, uint8_t *done, uint8_t *action_mask) {
+    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_step: no scenarios loaded");
+    if (!actions) return fail(h, EV2G_ERR_ARG, "ev2g_step: actions is null");
+    if (h->current_step >= h->T)
+        return fail(h, EV2G_ERR_DONE, "ev2g_step: episode is done, reset the environment (ev2gym_env.py:343)");
+    (void)hipSetDevice(h->device);
+    StepIO io{actions, 0, obs, 0, reward, 0, done, 0, action_mask, 0};
+    int rc = launch_steps(h, io, h->current_step, 1, 0);
+    if (rc) return rc;
+    h->current_step += 1;
+    h->timed = false;
+    return EV2G_OK;
+}
+
+int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, int64_t a_stride, double *obs,
+                int64_t o_stride, double *reward, int64_t r_stride, uint8_t *done, int64_t d_stride, uint8_t *mask,
+                int64_t m_stride, int auto_reset) {
+    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_step_n: no scenarios loaded");
+    if (!actions || k_steps < 0) return fail(h, EV2G_ERR_ARG, "ev2g_step_n: bad arguments");
+    (void)hipSetDevice(h->device);
+    int rc = EV2G_OK;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    if (mode == EV2G_STEPN_PERSISTENT) {
+        int k = k_steps;
+        if (!auto_reset) k = std::min(k, h->T - h->current_step);
+        StepIO io{actions, a_stride, obs, o_stride, reward, r_stride, done, d_stride, mask, m_stride};
+        if (k > 0) rc = launch_steps(h, io, h->current_step, k, auto_reset);
+        if (rc) return rc;
+        if (auto_reset) {
+            // replay the step counter on the host: reset happens lazily before the step that follows a terminal one
+            int t = h->current_step;
+            for (int i = 0; i < k; i++) { if (t >= h->T) t = 0; t++; }
+            h->current_step = t;
+        } else {
+            h->current_step += k;
+        }
+        if (k < k_steps) rc = fail(h, EV2G_ERR_DONE, "ev2g_step_n: episode finished before k_steps (auto_reset off)");
+    } else {
+        for (int i = 0; i < k_steps; i++) {
+            if (h->current_step >= h->T) {
+                if (!auto_reset) { rc = fail(h, EV2G_ERR_DONE, "ev2g_step_n: episode finished before k_steps (auto_reset off)"); break; }
+                int r2 = ev2g_reset(h, nullptr);
+                if (r2) return r2;
+            }
+            StepIO io{actions + (long long)i * a_stride, 0,
+                      obs ? obs + (long long)i * o_stride : nullptr, 0,
+                      reward ? reward + (long long)i * r_stride : nullptr, 0,
+                      done ? done + (long long)i * d_stride : nullptr, 0,
+                      mask ? mask + (long long)i * m_stride : nullptr, 0};
+            int r2 = launch_steps(h, io, h->current_step, 1, 0);
+            if (r2) return r2;
+            h->current_step += 1;
+        }
+    }
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return rc;
+}
+
+double ev2g_last_step_n_kernel_ms(ev2g_handle *h) {
+    if (!h || !h->timed) return -1.0;
+    if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+int ev2g_check_faults(ev2g_handle *h, int32_t *first_bad_env) {
+    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_check_faults: no scenarios loaded");
+    (void)hipSetDevice(h->device);
+    std::vector<int> f(h->E);
+    HIPCHK(h, hipMemcpyAsync(f.data(), h->st.env_fault, sizeof(int) * h->E, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int e = 0; e < h->E; e++)
+        if (f[e]) {
+            if (first_bad_env) *first_bad_env = e;
+            return fail(h, EV2G_ERR_OVERCURRENT, "charger over-current: sum of amps is higher than max charge current (ev_charger.py:203-205)");
+        }
+    return EV2G_OK;
+}
+
+int ev2g_get_stats(ev2g_handle *h, double *stats) {
+    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_get_stats: no scenarios loaded");
+    if (!stats) return fail(h, EV2G_ERR_ARG, "ev2g_get_stats: null output");
+    (void)hipSetDevice(h->device);
+    const int nb = (h->E + 63) / 64;
+    hipLaunchKernelGGL(ev2g_stats_kernel, dim3(nb), dim3(64), 0, h->stream, h->scn, h->st, (const long long *)nullptr,
+                       (const double *)h->d_ss_afap, h->current_step, stats);
+    HIPCHK(h, hipGetLastError());
+    return EV2G_OK;
+}
+
+int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *v) {
+    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_peek: no scenarios loaded");
+    if (!v || env < 0 || env >= h->E) return fail(h, EV2G_ERR_ARG, "ev2g_peek: bad arguments");
+    (void)hipSetDevice(h->device);
+    const int P = h->P, C = h->C, R = h->R, T = h->T, E = h->E;
+    const DevState &st = h->st;
+    std::vector<double> cap(P), tot(P), prev(P), pe(P), pc(P);
+    std::vector<int2> win(P), sc(P);
+    const size_t off = (size_t)env * P;
+#define D2H(dst, src, n, type) HIPCHK(h, hipMemcpyAsync((dst), (src), sizeof(type) * (size_t)(n), hipMemcpyDeviceToHost, h->stream))
+    D2H(cap.data(), st.cap + off, P, double);
+    D2H(tot.data(), st.tot_e + off, P, double);
+    D2H(prev.data(), st.prev_power + off, P, double);
+    D2H(pe.data(), st.port_energy + off, P, double);
+    D2H(pc.data(), st.port_current + off, P, double);
+    D2H(win.data(), st.win + off, P, int2);
+    D2H(sc.data(), st.sc + off, P, int2);
+    std::vector<double> trp(R), csv;
+    D2H(trp.data(), st.tr_power_now + (size_t)env * R, R, double);
+    const bool log_cs = st.cs_profits != nullptr;
+    if (log_cs) {
+        csv.resize((size_t)5 * C);
+        D2H(csv.data() + 0 * C, st.cs_power_now + (size_t)env * C, C, double);
+        D2H(csv.data() + 1 * C, st.cs_cur_now + (size_t)env * C, C, double);
+        D2H(csv.data() + 2 * C, st.cs_profits + (size_t)env * C, C, double);
+        D2H(csv.data() + 3 * C, st.cs_e_ch + (size_t)env * C, C, double);
+        D2H(csv.data() + 4 * C, st.cs_e_dis + (size_t)env * C, C, double);
+    }
+    // time-major histories: strided 2D copies
+    std::vector<double> usage(T), pot(T), over((size_t)T * R);
+    HIPCHK(h, hipMemcpy2DAsync(usage.data(), sizeof(double), st.usage_hist + env, sizeof(double) * E, sizeof(double), T,
+                               hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(pot.data(), sizeof(double), st.pot_hist + env, sizeof(double) * E, sizeof(double), T,
+                               hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(over.data(), sizeof(double) * R, st.over_hist + (size_t)env * R, sizeof(double) * E * R,
+                               sizeof(double) * R, T, hipMemcpyDeviceToHost, h->stream));
+#undef D2H
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int t = h->current_step;
+    v->current_step = t;
+    v->n_ports = P; v->n_chargers = C; v->n_transformers = R; v->n_steps = T;
+    const long long s0 = h->env_sess_start[env], s1 = h->env_sess_start[env + 1];
+    std::vector<int> dev_to_local;  // device idx -> env-local host idx
+    if (v->port_session) {
+        // inverse map restricted to this env
+        int dmin = 0x7fffffff;
+        for (long long s = s0; s < s1; s++) dmin = std::min(dmin, h->host_to_dev[s]);
+        dev_to_local.assign((size_t)(s1 - s0), -1);
+        for (long long s = s0; s < s1; s++) dev_to_local[h->host_to_dev[s] - dmin] = (int)(s - s0);
+        for (int q = 0; q < P; q++) {
+            const bool occ = win[q].x <= t && t <= win[q].y && sc[q].x >= 0;
+            v->port_session[h->slot_port[q]] = occ ? dev_to_local[sc[q].x - dmin] : -1;
+        }
+    }
+    const double nan = std::nan("");
+    for (int q = 0; q < P; q++) {
+        const int p = h->slot_port[q];
+        // after step t-1 the port holds an EV iff its window covers the current step counter
+        const bool occ = win[q].x <= t && t <= win[q].y;
+        if (v->port_capacity) v->port_capacity[p] = occ ? cap[q] : nan;
+        if (v->port_energy) v->port_energy[p] = occ ? pe[q] : nan;
+        if (v->port_current) v->port_current[p] = occ ? pc[q] : nan;
+        if (v->port_total_energy) v->port_total_energy[p] = occ ? tot[q] : nan;
+        if (v->port_prev_power) v->port_prev_power[p] = occ ? prev[q] : nan;
+        if (v->port_required_energy) v->port_required_energy[p] = nan;  // filled by the Python facade (B - cap0 - tot_e)
+        if (v->port_cycles) v->port_cycles[p] = occ ? sc[q].y : -1;
+    }
+    for (int c = 0; c < C; c++) {
+        if (v->cs_power) v->cs_power[c] = log_cs ? csv[0 * C + c] : nan;
+        if (v->cs_amps) v->cs_amps[c] = log_cs ? csv[1 * C + c] : nan;
+        if (v->cs_profits) v->cs_profits[c] = log_cs ? csv[2 * C + c] : nan;
+        if (v->cs_energy_charged) v->cs_energy_charged[c] = log_cs ? csv[3 * C + c] : nan;
+        if (v->cs_energy_discharged) v->cs_energy_discharged[c] = log_cs ? csv[4 * C + c] : nan;
+    }
+    if (v->tr_power) std::copy(trp.begin(), trp.end(), v->tr_power);
+    if (v->tr_overload)
+        for (int r = 0; r < R; r++)
+            for (int k = 0; k < T; k++) v->tr_overload[(size_t)r * T + k] = over[(size_t)k * R + r];
+    if (v->power_usage) std::copy(usage.begin(), usage.end(), v->power_usage);
+    if (v->power_potential) std::copy(pot.begin(), pot.end(), v->power_potential);
+    for (long long s = s0; s < s1; s++) {
+        if (v->session_port) v->session_port[s - s0] = h->sess_port[s];
+        if (v->session_afap) v->session_afap[s - s0] = h->sess_afap[s];
+    }
+    return EV2G_OK;
+}
+
+void *ev2g_malloc(ev2g_handle *h, size_t bytes) {
+    if (!h) return nullptr;
+    (void)hipSetDevice(h->device);
+    void *p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(bytes, 1)) != hipSuccess) {
+        h->err = "ev2g_malloc: hipMalloc failed";
+        return nullptr;
+    }
+    h->user_allocs.push_back(p);
+    return p;
+}
+void ev2g_free(ev2g_handle *h, void *p) {
+    if (!h || !p) return;
+    auto it = std::find(h->user_allocs.begin(), h->user_allocs.end(), p);
+    if (it != h->user_allocs.end()) h->user_allocs.erase(it);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(p);
+}
+int ev2g_memcpy_h2d(ev2g_handle *h, void *dst, const void *src, size_t bytes) {
+    if (!h) return EV2G_ERR_ARG;
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return EV2G_OK;
+}
+int ev2g_memcpy_d2h(ev2g_handle *h, void *dst, const void *src, size_t bytes) {
+    if (!h) return EV2G_ERR_ARG;
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return EV2G_OK;
+}
+int ev2g_synchronize(ev2g_handle *h) {
+    if (!h) return EV2G_ERR_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return EV2G_OK;
+}
+int ev2g_fill_uniform(ev2g_handle *h, double *dst, int64_t n, uint64_t seed, double lo, double hi) {
+    if (!h || !dst || n < 0) return fail(h, EV2G_ERR_ARG, "ev2g_fill_uniform: bad arguments");
+    (void)hipSetDevice(h->device);
+    const int nb = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    if (n) hipLaunchKernelGGL(ev2g_fill_uniform_kernel, dim3(std::max(nb, 1)), dim3(256), 0, h->stream, dst, (long long)n, seed, lo, hi);
+    HIPCHK(h, hipGetLastError());
+    return EV2G_OK;
+}
+void ev2g_host_uniform(double *dst, int64_t n, uint64_t seed, double lo, double hi) {
+    for (int64_t i = 0; i < n; i++) dst[i] = lo + (hi - lo) * ev2g_u01(seed, (uint64_t)i);
+}
+
+}  // extern "C"

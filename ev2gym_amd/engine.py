@@ -1,0 +1,246 @@
+"""ctypes host binding of libev2g_hip.so (include/ev2g.h).  The thin layer between the Python surface
+(`EV2GymVec`, `EV2Gym` facade) and the HIP kernels; there is no CPU fallback: importing works anywhere,
+creating an engine without the built library or without a GPU raises.
+
+Reference boundary being replaced: ev2gym.models.ev2gym_env.EV2Gym (reset :243-331, step :333-447).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import _abi
+from .scenario import ScenarioBatch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libev2g_hip.so")
+_lib = None
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[ev2g {code}] {msg}")
+        self.code = code
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libev2g_hip.so and declare the prototypes.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or _LIB_PATH
+    if not os.path.exists(path):
+        raise EngineError(-2, f"{path} not found: build it with `python -m ev2gym_amd.build` "
+                              "(hipcc --offload-arch=gfx950); the step engine has no CPU fallback")
+    L = C.CDLL(path)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    protos = {
+        "ev2g_abi_version": (C.c_int, []),
+        "ev2g_create": (C.c_int, [C.POINTER(_abi.ConfigC), C.POINTER(vp)]),
+        "ev2g_destroy": (None, [vp]),
+        "ev2g_last_error": (C.c_char_p, [vp]),
+        "ev2g_load_scenarios": (C.c_int, [vp, C.POINTER(_abi.ScenarioBatchC)]),
+        "ev2g_n_envs": (C.c_int, [vp]), "ev2g_n_ports": (C.c_int, [vp]), "ev2g_obs_dim": (C.c_int, [vp]),
+        "ev2g_n_steps": (C.c_int, [vp]), "ev2g_current_step": (C.c_int, [vp]),
+        "ev2g_reset": (C.c_int, [vp, vp]),
+        "ev2g_step": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+        "ev2g_step_n": (C.c_int, [vp, C.c_int, C.c_int, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, C.c_int]),
+        "ev2g_check_faults": (C.c_int, [vp, C.POINTER(i32)]),
+        "ev2g_get_stats": (C.c_int, [vp, vp]),
+        "ev2g_stat_name": (C.c_char_p, [C.c_int]),
+        "ev2g_peek": (C.c_int, [vp, C.c_int, C.POINTER(_abi.EnvViewC)]),
+        "ev2g_malloc": (vp, [vp, C.c_size_t]),
+        "ev2g_free": (None, [vp, vp]),
+        "ev2g_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "ev2g_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "ev2g_synchronize": (C.c_int, [vp]),
+        "ev2g_fill_uniform": (C.c_int, [vp, vp, i64, C.c_uint64, dbl, dbl]),
+        "ev2g_host_uniform": (None, [vp, i64, C.c_uint64, dbl, dbl]),
+        "ev2g_last_step_n_kernel_ms": (dbl, [vp]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(L, name)  # AttributeError here = the .so does not export what include/ev2g.h declares
+        fn.restype = res
+        fn.argtypes = args
+    if L.ev2g_abi_version() != _abi.ABI_VERSION:
+        raise EngineError(-1, "libev2g_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "ev2g_abi_version", "ev2g_create", "ev2g_destroy", "ev2g_last_error", "ev2g_load_scenarios", "ev2g_n_envs",
+    "ev2g_n_ports", "ev2g_obs_dim", "ev2g_n_steps", "ev2g_current_step", "ev2g_reset", "ev2g_step", "ev2g_step_n",
+    "ev2g_check_faults", "ev2g_get_stats", "ev2g_stat_name", "ev2g_peek", "ev2g_malloc", "ev2g_free",
+    "ev2g_memcpy_h2d", "ev2g_memcpy_d2h", "ev2g_synchronize", "ev2g_fill_uniform", "ev2g_host_uniform",
+    "ev2g_last_step_n_kernel_ms"]
+
+
+def _ptr(x):
+    """Device address of a DeviceBuffer / torch tensor / raw int (None -> NULL)."""
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if hasattr(x, "data_ptr"):
+        return int(x.data_ptr())
+    return int(x)
+
+
+class DeviceBuffer:
+    """A hipMalloc'd array owned by an engine handle (for hosts that do not use torch)."""
+
+    def __init__(self, engine: "Engine", shape, dtype):
+        self.engine = engine
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = engine._lib.ev2g_malloc(engine._h, self.nbytes)
+        if not self.ptr:
+            raise EngineError(-2, engine.last_error())
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr, self.dtype)
+        assert arr.nbytes == self.nbytes, (arr.shape, self.shape)
+        self.engine._check(self.engine._lib.ev2g_memcpy_h2d(self.engine._h, self.ptr, arr.ctypes.data, self.nbytes))
+        return self
+
+    def to_host(self):
+        out = np.empty(self.shape, self.dtype)
+        self.engine._check(self.engine._lib.ev2g_memcpy_d2h(self.engine._h, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def at(self, index_elems: int):
+        return self.ptr + int(index_elems) * self.dtype.itemsize
+
+    def free(self):
+        if self.ptr and self.engine._h:
+            self.engine._lib.ev2g_free(self.engine._h, self.ptr)
+        self.ptr = None
+
+
+class Engine:
+    """One handle = one GPU = one HIP stream; E envs resident in HBM."""
+
+    def __init__(self, batch: ScenarioBatch, reward_kind: int, state_kind: int, device: int = 0, flags: int = 0,
+                 stream: Optional[int] = None):
+        self._lib = load_library()
+        self._h = None
+        cfg = _abi.ConfigC(int(device), int(reward_kind), int(state_kind), int(flags), stream)
+        h = C.c_void_p()
+        rc = self._lib.ev2g_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise EngineError(rc, (self._lib.ev2g_last_error(None) or b"").decode())
+        self._h = h
+        self.reward_kind, self.state_kind, self.flags, self.device = reward_kind, state_kind, flags, device
+        self.load(batch)
+
+    # ---- scenario ----------------------------------------------------------------------------
+    def load(self, batch: ScenarioBatch):
+        cb = batch.to_c()
+        self._check(self._lib.ev2g_load_scenarios(self._h, C.byref(cb)))
+        self.batch = batch
+        self.E = self._lib.ev2g_n_envs(self._h)
+        self.P = self._lib.ev2g_n_ports(self._h)
+        self.D = self._lib.ev2g_obs_dim(self._h)
+        self.T = self._lib.ev2g_n_steps(self._h)
+        self.C, self.R = batch.n_chargers, batch.n_transformers
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def last_error(self) -> str:
+        return (self._lib.ev2g_last_error(self._h) or b"").decode()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self.last_error())
+
+    def empty(self, shape, dtype=np.float64) -> DeviceBuffer:
+        return DeviceBuffer(self, shape, dtype)
+
+    def synchronize(self):
+        self._check(self._lib.ev2g_synchronize(self._h))
+
+    @property
+    def current_step(self) -> int:
+        return self._lib.ev2g_current_step(self._h)
+
+    # ---- hot path ------------------------------------------------------------------------------
+    def reset(self, obs=None):
+        self._check(self._lib.ev2g_reset(self._h, _ptr(obs)))
+
+    def step(self, actions, obs=None, reward=None, done=None, mask=None):
+        self._check(self._lib.ev2g_step(self._h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(mask)))
+
+    def step_n(self, k, actions, a_stride, obs=None, o_stride=0, reward=None, r_stride=0, done=None, d_stride=0,
+               mask=None, m_stride=0, auto_reset=True, persistent=False):
+        rc = self._lib.ev2g_step_n(self._h, int(k), 1 if persistent else 0, _ptr(actions), int(a_stride), _ptr(obs),
+                                   int(o_stride), _ptr(reward), int(r_stride), _ptr(done), int(d_stride), _ptr(mask),
+                                   int(m_stride), 1 if auto_reset else 0)
+        self._check(rc)
+
+    def last_step_n_kernel_ms(self) -> float:
+        return float(self._lib.ev2g_last_step_n_kernel_ms(self._h))
+
+    def check_faults(self):
+        bad = C.c_int32(-1)
+        rc = self._lib.ev2g_check_faults(self._h, C.byref(bad))
+        if rc != 0:
+            raise EngineError(rc, f"env {bad.value}: " + self.last_error())
+
+    def fill_uniform(self, dst, n, seed, lo, hi):
+        self._check(self._lib.ev2g_fill_uniform(self._h, _ptr(dst), int(n), int(seed), float(lo), float(hi)))
+
+    # ---- statistics / inspection ---------------------------------------------------------------
+    def stats(self, out=None) -> np.ndarray:
+        """[E,17] get_statistics() scalars (utils.py:84-101) as a host array (or into a device `out`)."""
+        if out is not None:
+            self._check(self._lib.ev2g_get_stats(self._h, _ptr(out)))
+            return out
+        buf = self.empty((self.E, _abi.N_STATS))
+        try:
+            self._check(self._lib.ev2g_get_stats(self._h, buf.ptr))
+            return buf.to_host()
+        finally:
+            buf.free()
+
+    def peek(self, env: int = 0) -> dict:
+        """Host copy of one env's state in the reference's port order (feeds the EV2Gym facade)."""
+        P, Cn, R, T = self.P, self.C, self.R, self.T
+        st = self.batch.arrays["env_session_start"]
+        S = int(st[env + 1] - st[env])
+        f8 = lambda *s: np.empty(s, np.float64)  # noqa: E731
+        i4 = lambda *s: np.empty(s, np.int32)  # noqa: E731
+        d = dict(port_capacity=f8(P), port_energy=f8(P), port_current=f8(P), port_total_energy=f8(P),
+                 port_required_energy=f8(P), port_prev_power=f8(P), port_cycles=i4(P), port_session=i4(P),
+                 cs_power=f8(Cn), cs_amps=f8(Cn), cs_profits=f8(Cn), cs_energy_charged=f8(Cn),
+                 cs_energy_discharged=f8(Cn), tr_power=f8(R), tr_overload=f8(R, T), power_usage=f8(T),
+                 power_potential=f8(T), session_port=i4(max(S, 1)), session_afap=f8(max(S, 1)))
+        v = _abi.EnvViewC()
+        for k, a in d.items():
+            ct = C.c_double if a.dtype == np.float64 else C.c_int32
+            setattr(v, k, a.ctypes.data_as(C.POINTER(ct)))
+        self._check(self._lib.ev2g_peek(self._h, int(env), C.byref(v)))
+        d["session_port"] = d["session_port"][:S]
+        d["session_afap"] = d["session_afap"][:S]
+        d["current_step"] = int(v.current_step)
+        return d
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ev2g_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def host_uniform(n, seed, lo, hi) -> np.ndarray:
+    """Host twin of Engine.fill_uniform (same counter-based generator)."""
+    out = np.empty(int(n))
+    load_library().ev2g_host_uniform(out.ctypes.data, int(n), int(seed), float(lo), float(hi))
+    return out

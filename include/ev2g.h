@@ -170,10 +170,15 @@ int ev2g_step(ev2g_handle *h, const double *actions, double *obs, double *reward
 /* K consecutive steps from a device-resident action source, enqueued without host round trips.
  * actions: [K,E,P] (action_step_stride = E*P) or one [E,P] block reused (stride 0).
  * Output k is written at base + k*<stride> elements (stride 0 = overwrite one buffer).
- * When the episode ends inside the K steps and auto_reset != 0, ev2g_reset() semantics are applied
- * and stepping continues (the terminal obs of that step is the post-reset observation is NOT used:
- * the terminal step still reports its own obs; the reset happens before the next step). */
-int ev2g_step_n(ev2g_handle *h, int k_steps, const double *actions, int64_t action_step_stride,
+ *   mode 0  one kernel launch per step, enqueued back to back from C;
+ *   mode 1  ONE persistent launch: every workgroup loops over the K steps of its own envs (envs are
+ *           independent, so no grid-wide synchronisation is needed).
+ * If the episode ends inside the K steps: with auto_reset != 0 the envs are reset (ev2g_reset
+ * semantics, same scenarios) before the next step -- the terminal step still reports its own obs --
+ * otherwise stepping stops there and EV2G_ERR_DONE is returned. */
+#define EV2G_STEPN_PER_STEP_LAUNCH 0
+#define EV2G_STEPN_PERSISTENT 1
+int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, int64_t action_step_stride,
                 double *obs, int64_t obs_step_stride, double *reward, int64_t reward_step_stride,
                 uint8_t *done, int64_t done_step_stride, uint8_t *action_mask,
                 int64_t mask_step_stride, int auto_reset);

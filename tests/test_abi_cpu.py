@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/ev2g.h declares, and fails loudly (no CPU fallback) when no GPU is present."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, has_gpu
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ev2g.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ev2g_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from ev2gym_amd import build, engine
+    lib = build.build()
+    L = ctypes.CDLL(lib)
+    decl = _declared_symbols()
+    assert len(decl) >= 20
+    for name in decl:
+        assert hasattr(L, name), f"{name} declared in include/ev2g.h but not exported"
+    assert set(engine.EXPORTED_SYMBOLS) == set(decl)
+    assert L.ev2g_abi_version() == 1
+
+
+def test_struct_mirrors_match_header_field_order():
+    from ev2gym_amd import _abi
+    txt = open(os.path.join(ROOT, "include", "ev2g.h")).read()
+    body = txt[txt.index("typedef struct ev2g_scenario_batch {"):txt.index("} ev2g_scenario_batch;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\*?\s*([a-zA-Z_0-9]+);", body)
+    assert names == [f[0] for f in _abi.ScenarioBatchC._fields_]
+    body = txt[txt.index("typedef struct ev2g_env_view {"):txt.index("} ev2g_env_view;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n for part in re.findall(r"(?:int32_t|double)\s+([^;]+);", body) for n in re.split(r"[,\s\*]+", part) if n]
+    assert names == [f[0] for f in _abi.EnvViewC._fields_]
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback():
+    from ev2gym_amd.engine import Engine, EngineError
+    from conftest import GOLDEN_FILES, load_golden
+    z, batch, rk, sk = load_golden(GOLDEN_FILES[0])
+    with pytest.raises(EngineError):
+        Engine(batch, rk, sk)
+
+
+def test_host_uniform_matches_splitmix_definition():
+    import numpy as np
+    from ev2gym_amd.engine import host_uniform
+    u = host_uniform(1000, 42, -1.0, 1.0)
+    assert u.min() >= -1.0 and u.max() < 1.0 and abs(u.mean()) < 0.1
+    assert np.array_equal(u, host_uniform(1000, 42, -1.0, 1.0))
+    assert not np.array_equal(u, host_uniform(1000, 43, -1.0, 1.0))

@@ -1,0 +1,181 @@
+"""Parity of the HIP engine (through the C-ABI) against the reference goldens and the CPU oracle.
+
+Bar (BASELINE.json north_star): <=1e-6 relative on float64 SoC / power, bit-exact on EV arrival /
+departure indexing.  We hold the engine to a much tighter 1e-9: per-port arithmetic follows the
+reference's operation order (-ffp-contract=off) and is expected to be bit-identical up to device
+`exp`; only the per-transformer / per-env sums use a different (fixed-tree) order.
+"""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_FILES, GOLDEN_IDS, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def _close(a, b, what, tol=RTOL):
+    a = np.asarray(a, float)
+    b = np.asarray(b, float)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert (np.isnan(a) == np.isnan(b)).all(), f"{what}: NaN pattern (port occupancy) differs"
+    scale = np.maximum(1.0, np.abs(np.nan_to_num(b)))
+    err = np.nan_to_num(np.abs(a - b) / scale)
+    assert err.max(initial=0.0) <= tol, f"{what}: max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+def _engine(batch, rk, sk, flags=1):
+    from ev2gym_amd.engine import Engine
+    return Engine(batch, rk, sk, device=0, flags=flags)
+
+
+@pytest.mark.parametrize("path", GOLDEN_FILES, ids=GOLDEN_IDS)
+def test_engine_matches_reference_golden(path):
+    z, batch, rk, sk = load_golden(path)
+    eng = _engine(batch, rk, sk)
+    E, P, D = eng.E, eng.P, eng.D
+    assert D == z["trj_obs"].shape[1]
+    d_act, d_obs = eng.empty((E, P)), eng.empty((E, D))
+    d_rew, d_done, d_mask = eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
+    eng.reset(d_obs)
+    _close(d_obs.to_host()[0], z["trj_obs"][0], "reset obs")
+    nT = len(z["act"])
+    for t in range(nT):
+        d_act.upload(z["act"][t:t + 1])
+        eng.step(d_act, d_obs, d_rew, d_done, d_mask)
+        _close(d_obs.to_host()[0], z["trj_obs"][t + 1], f"obs[{t}]")
+        _close(d_rew.to_host()[0], z["trj_reward"][t], f"reward[{t}]")
+        assert d_done.to_host()[0] == z["trj_done"][t]
+        assert (d_mask.to_host()[0] == z["trj_mask"][t]).all(), f"action_mask[{t}] (arrival/departure indexing)"
+        pk = eng.peek(0)
+        _close(pk["port_capacity"], z["trj_cap"][t], f"capacity[{t}]")
+        _close(pk["port_energy"], z["trj_energy"][t], f"energy[{t}]")
+        _close(pk["port_current"], z["trj_current"][t], f"current[{t}]")
+        _close(pk["port_total_energy"], z["trj_tot_e"][t], f"tot_e[{t}]")
+        _close(pk["port_prev_power"], z["trj_prev_power"][t], f"prev_power[{t}]")
+        assert (pk["port_cycles"] == z["trj_cycles"][t]).all(), f"cycles[{t}]"
+        _close(pk["cs_power"], z["trj_cs_power"][t], f"cs_power[{t}]")
+        _close(pk["cs_amps"], z["trj_cs_amps"][t], f"cs_amps[{t}]")
+        _close(pk["cs_profits"], z["trj_cs_profits"][t], f"cs_profits[{t}]")
+        _close(pk["cs_energy_charged"], z["trj_cs_e_ch"][t], f"cs_e_ch[{t}]")
+        _close(pk["cs_energy_discharged"], z["trj_cs_e_dis"][t], f"cs_e_dis[{t}]")
+        _close(pk["tr_power"], z["trj_tr_power"][t], f"tr_power[{t}]")
+    pk = eng.peek(0)
+    _close(pk["power_usage"][:nT], z["trj_usage"], "current_power_usage")
+    _close(pk["power_potential"][:nT], z["trj_potential"], "charge_power_potential")
+    _close(pk["tr_overload"][:, :nT].T, z["trj_tr_overload"], "tr_overload")
+    m = z["trj_ev_port"] >= 0
+    assert (pk["session_port"][m] == z["trj_ev_port"][m]).all(), "first-free port assignment"
+    _close(pk["session_afap"][m], z["trj_ev_afap"][m], "max_energy_AFAP")
+    eng.check_faults()
+    if "trj_stats" in z:
+        from ev2gym_amd import _abi
+        st = eng.stats()[0]
+        for i, k in enumerate(_abi.STAT_NAMES):
+            g = z["trj_stats"][i]
+            if k.startswith("battery_degradation"):
+                continue  # SoC-log based statistics are not produced by the engine yet ("next")
+            if np.isnan(g):
+                assert np.isnan(st[i]), k
+            else:
+                assert abs(st[i] - g) <= 1e-9 * max(1.0, abs(g)), (k, st[i], g)
+        with pytest.raises(Exception):
+            eng.step(d_act, d_obs, d_rew, d_done, d_mask)  # `assert not self.done` ev2gym_env.py:343
+    eng.close()
+
+
+def _tiled(name, E):
+    import os
+    from conftest import GOLDEN_DIR
+    z, batch, rk, sk = load_golden(os.path.join(GOLDEN_DIR, name + ".npz"))
+    return batch.tile(E), rk, sk
+
+
+@pytest.mark.parametrize("name,E,lo", [("v2gppl_c50_rand_s9", 333, -1.0), ("pst_rand_s2", 517, 0.0),
+                                       ("v2gppl_c60r5_rand_s13", 97, -1.0), ("v2gppl_p2_rand_s11", 130, -1.3),
+                                       ("pst_p3_rand_s12", 77, 0.0), ("v2gppl_c1000r50_rand_s15", 9, -1.0)])
+def test_engine_matches_oracle_batched(name, E, lo):
+    """Many envs per launch, a different action stream per env: engine == CPU oracle at every step."""
+    from ev2gym_amd.engine import host_uniform
+    from oracle.oracle import Oracle
+    batch, rk, sk = _tiled(name, E)
+    eng = _engine(batch, rk, sk, flags=0)
+    ora = Oracle(batch, rk, sk)
+    P, D, T = eng.P, eng.D, eng.T
+    d_act, d_obs = eng.empty((E, P)), eng.empty((E, D))
+    d_rew, d_done, d_mask = eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
+    eng.reset(d_obs)
+    _close(d_obs.to_host(), ora.reset(), "reset obs")
+    nT = T if P < 500 else 24
+    for t in range(nT):
+        eng.fill_uniform(d_act, E * P, 77 + t, lo, 1.0)
+        a = host_uniform(E * P, 77 + t, lo, 1.0).reshape(E, P)
+        assert (d_act.to_host() == a).all(), "device and host action generators must agree bit for bit"
+        eng.step(d_act, d_obs, d_rew, d_done, d_mask)
+        obs, rew, done, mask, rc = ora.step(a)
+        assert rc == 0
+        assert (d_mask.to_host() == mask).all(), f"mask[{t}]"
+        _close(d_obs.to_host(), obs, f"obs[{t}]")
+        _close(d_rew.to_host(), rew, f"reward[{t}]")
+        assert (d_done.to_host() == done).all()
+    for e in (0, E // 2, E - 1):
+        pk, po = eng.peek(e), ora.peek(e)
+        _close(pk["port_capacity"], po["cap"], "capacity")
+        _close(pk["port_total_energy"], po["tot_e"], "tot_e")
+        assert (pk["port_cycles"] == po["cycles"]).all()
+        assert (pk["port_session"] == po["session"]).all()
+        _close(pk["power_usage"], po["usage"], "usage")
+        _close(pk["power_potential"], po["potential"], "potential")
+        _close(pk["tr_overload"], po["tr_overload"], "tr_overload")
+    if nT == T:
+        st, so = eng.stats(), ora.stats()
+        keep = [i for i in range(17) if i not in (13, 14, 15)]
+        _close(st[:, keep], so[:, keep], "episode stats")
+    eng.check_faults()
+    eng.close()
+    ora.close()
+
+
+@pytest.mark.parametrize("name,E", [("v2gppl_c50_rand_s9", 260), ("pst_rand_s3", 100)])
+def test_persistent_multi_step_launch_is_bit_identical(name, E):
+    """ev2g_step_n: one persistent launch for K steps == K single-step launches, across an episode boundary."""
+    batch, rk, sk = _tiled(name, E)
+    eng = _engine(batch, rk, sk, flags=0)
+    P, D, T = eng.P, eng.D, eng.T
+    K = T + 9  # crosses the auto-reset
+    lo = -1.0 if batch.v2g_enabled else 0.0
+    d_act = eng.empty((K, E, P))
+    eng.fill_uniform(d_act, K * E * P, 5, lo, 1.0)
+    outs = []
+    for persistent in (False, True):
+        d_obs, d_rew = eng.empty((K, E, D)), eng.empty((K, E))
+        d_done, d_mask = eng.empty((K, E), np.uint8), eng.empty((K, E, P), np.uint8)
+        eng.reset()
+        eng.step_n(K, d_act, E * P, d_obs, E * D, d_rew, E, d_done, E, d_mask, E * P, auto_reset=True,
+                   persistent=persistent)
+        assert eng.current_step == 9
+        assert eng.last_step_n_kernel_ms() > 0
+        outs.append((d_obs.to_host(), d_rew.to_host(), d_done.to_host(), d_mask.to_host()))
+        for b in (d_obs, d_rew, d_done, d_mask):
+            b.free()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert outs[0][2][T - 1].all() and not outs[0][2][T].any()
+    # the second episode (after the in-kernel reset) replays the first one's scenario: same masks
+    assert np.array_equal(outs[0][3][:9], outs[0][3][T:T + 9])
+    eng.close()
+
+
+def test_engine_is_deterministic():
+    batch, rk, sk = _tiled("v2gppl_c60r5_rand_s13", 64)
+    res = []
+    for _ in range(2):
+        eng = _engine(batch, rk, sk, flags=0)
+        K, E, P, D = 40, eng.E, eng.P, eng.D
+        d_act, d_obs, d_rew = eng.empty((K, E, P)), eng.empty((K, E, D)), eng.empty((K, E))
+        eng.fill_uniform(d_act, K * E * P, 11, -1.0, 1.0)
+        eng.step_n(K, d_act, E * P, d_obs, E * D, d_rew, E)
+        res.append((d_obs.to_host(), d_rew.to_host()))
+        eng.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
