@@ -1,0 +1,331 @@
+"""Vectorised synthetic scenario generator: builds the tensors `EV2Gym.step()` reads for E envs at once.
+
+The reference builds one scenario per `reset()` with Python loops and pandas look-ups
+(EV_spawner utils.py:477-557, spawn_single_EV :177-345, load_transformers loaders.py:227-296 +
+transformer.py:80-256, load_electricity_prices loaders.py:392-461, generate_power_setpoints
+utils.py:664-757), which costs 0.16-1.2 s per env and would dominate a GPU-resident
+step engine.  This module draws the same *kind* of scenario -- same structure, same constraints,
+statistically comparable (not bit-identical: the reference's RNG streams and CSV data sets are not
+reproduced) -- for thousands of envs with numpy array operations:
+
+  * arrivals: a Bernoulli trial per (port, step) against a time-of-day rate, with the reference's
+    "port must have been empty for 3 steps" rule and the end-of-simulation cut-off;
+  * EV specs: a fleet table (battery size, AC power, 3-phase efficiency-vs-current table) or homogeneous
+    config values; two-stage model parameters as in spawn_single_EV;
+  * prices: hourly day-ahead-like curve, negated for charging (loaders.py:439-442);
+  * transformers: inflexible load + PV + forecasts + one demand-response event (transformer.py:80-256);
+  * power setpoints (PublicPST): price-weighted spread of each session's energy, median-smoothed.
+
+`step()` parity never depends on this file: tests feed identical tensors to the engine and the oracle.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import _abi
+from .scenario import ScenarioBatch
+
+# A synthetic V2G-capable fleet: (share, battery kWh, max AC kW, efficiency % at 6..16 A in 2 A steps)
+_FLEET_V2G = [
+    (0.22, 57.5, 11.0, (87, 87, 90, 90, 90, 90)),
+    (0.18, 57.5, 11.0, (87, 87, 90, 90, 90, 90)),
+    (0.13, 64.8, 11.0, (90, 90, 90, 90, 90, 90)),
+    (0.11, 58.0, 11.0, (87, 87, 90, 90, 90, 90)),
+    (0.10, 58.0, 11.0, (87, 90, 90, 90, 90, 90)),
+    (0.09, 64.0, 11.0, (90, 90, 93, 93, 93, 93)),
+    (0.09, 46.3, 7.4, (84, 87, 90, 90, 90, 90)),
+    (0.08, 77.0, 11.0, (90, 90, 90, 90, 90, 90)),
+]
+
+
+def _lut_from_levels(levels, values):
+    """Nearest-non-zero fill of a {current level -> efficiency %} map over 0..100 A (utils.py:279-288)."""
+    tab = np.zeros(_abi.LUT_LEN)
+    lv = np.asarray(levels)
+    for i in range(_abi.LUT_LEN):
+        tab[i] = values[int(np.argmin(np.abs(lv - i)))]
+    return tab
+
+
+@dataclass
+class GenConfig:
+    """Mirror of the YAML keys the reference reads (V2GProfitPlusLoads.yaml / PublicPST.yaml)."""
+    n_envs: int = 1
+    simulation_length: int = 112
+    timescale: int = 15
+    number_of_charging_stations: int = 25
+    number_of_ports_per_cs: int = 1
+    number_of_transformers: int = 1
+    scenario: str = "workplace"          # workplace | public
+    spawn_multiplier: float = 5.0
+    hour: int = 5
+    v2g_enabled: bool = True
+    discharge_price_factor: float = 1.0
+    power_setpoint_enabled: bool = False
+    power_setpoint_flexiblity: float = 80.0
+    inflexible_loads: bool = True
+    solar_power: bool = True
+    demand_response: bool = True
+    heterogeneous_ev_specs: bool = True
+    fleet_with_efficiency_tables: bool = True   # ev_specs_v2g_enabled2024-like; False = scalar eta in [0.95,1]
+    transformer_max_power: float = 100.0
+    cs_min_charge_current: float = 0.0
+    cs_max_charge_current: float = 32.0
+    cs_min_discharge_current: float = 0.0
+    cs_max_discharge_current: float = -32.0
+    cs_voltage: float = 400.0
+    cs_phases: int = 3
+    ev_battery_capacity: float = 50.0
+    ev_max_ac_charge_power: float = 11.0
+    ev_min_ac_charge_power: float = 0.0
+    ev_max_discharge_power: float = -11.0
+    ev_min_discharge_power: float = 0.0
+    ev_phases: int = 3
+    ev_charge_efficiency: float = 1.0
+    ev_discharge_efficiency: float = 1.0
+    ev_transition_soc: float = 1.0
+    ev_transition_soc_multiplier: float = 5.0
+    ev_min_battery_capacity: float = 5.0
+    ev_min_time_of_stay: int = 180
+    ev_min_emergency_battery_capacity: float = 25.0
+    ev_desired_capacity: float = 1.0
+    seed: int = 0
+
+    @staticmethod
+    def v2g_profit_plus_loads(n_envs, n_chargers=50, n_transformers=1, seed=0, **kw):
+        return GenConfig(n_envs=n_envs, number_of_charging_stations=n_chargers,
+                         number_of_transformers=n_transformers, seed=seed, **kw)
+
+    @staticmethod
+    def public_pst(n_envs, n_chargers=20, seed=0, **kw):
+        d = dict(scenario="public", v2g_enabled=False, power_setpoint_enabled=True, inflexible_loads=False,
+                 solar_power=False, demand_response=False, fleet_with_efficiency_tables=False,
+                 cs_max_charge_current=16.0, cs_max_discharge_current=0.0, ev_min_time_of_stay=60)
+        d.update(kw)
+        return GenConfig(n_envs=n_envs, number_of_charging_stations=n_chargers, seed=seed, **d)
+
+
+def _arrival_rate(scenario, hours):
+    """Arrivals per port per hour in percent (the role of distribution-of-arrival.csv), by hour of day."""
+    h = np.asarray(hours, float)
+    if scenario == "workplace":
+        r = 7.4 * np.exp(-0.5 * ((h - 8.3) / 1.1) ** 2) + 1.2 * np.exp(-0.5 * ((h - 13.0) / 1.5) ** 2)
+        r = np.where((h < 6) | (h > 18), 0.0, r)
+    else:  # public
+        r = 0.25 + 1.7 * np.exp(-0.5 * ((h - 9.5) / 2.5) ** 2) + 1.9 * np.exp(-0.5 * ((h - 17.0) / 3.0) ** 2)
+    return r
+
+
+def _mean_stay_hours(scenario, hours):
+    h = np.asarray(hours, float)
+    if scenario == "workplace":
+        return np.clip(9.0 - 0.75 * (h - 7.0), 2.0, 9.5)
+    return np.clip(4.5 - 0.12 * (h - 8.0), 1.5, 6.0)
+
+
+def _mean_energy_kwh(scenario, hours):
+    h = np.asarray(hours, float)
+    return 22.0 + 6.0 * np.cos((h - 9.0) / 24.0 * 2 * np.pi) if scenario == "workplace" else 20.0 + 4.0 * np.cos((h - 12.0) / 24.0 * 2 * np.pi)
+
+
+def generate(cfg: GenConfig) -> ScenarioBatch:
+    rng = np.random.default_rng(cfg.seed)
+    E, T, dt = cfg.n_envs, cfg.simulation_length, cfg.timescale
+    Cn, npc, R = cfg.number_of_charging_stations, cfg.number_of_ports_per_cs, cfg.number_of_transformers
+    P = Cn * npc
+    a = {}
+    # ---- chargers (load_ev_charger_profiles loaders.py:342-365; load_grid :494-498) ----
+    a["cs_min_charge_current"] = np.full(Cn, cfg.cs_min_charge_current)
+    a["cs_max_charge_current"] = np.full(Cn, cfg.cs_max_charge_current)
+    a["cs_min_discharge_current"] = np.full(Cn, cfg.cs_min_discharge_current if cfg.v2g_enabled else 0.0)
+    a["cs_max_discharge_current"] = np.full(Cn, cfg.cs_max_discharge_current if cfg.v2g_enabled else 0.0)
+    a["cs_voltage"] = np.full(Cn, cfg.cs_voltage)
+    a["cs_phases"] = np.full(Cn, cfg.cs_phases, np.int32)
+    a["cs_transformer"] = (np.arange(Cn) % R).astype(np.int32)
+
+    step_hours = cfg.hour + np.arange(T + 24) * dt / 60.0          # hour-of-day (unwrapped) of every step
+    hod = step_hours % 24.0
+
+    # ---- prices (load_electricity_prices loaders.py:392-461): hourly, EUR/MWh -> EUR/kWh ----
+    hour_idx = np.floor(step_hours[:T]).astype(int)
+    n_hours = hour_idx.max() + 1
+    base = 75 + 40 * np.sin((np.arange(n_hours) % 24 - 7) / 24 * 2 * np.pi) + 30 * np.sin((np.arange(n_hours) % 24 - 17) / 12 * 2 * np.pi)
+    hourly = np.maximum(base[None, :] * rng.uniform(0.6, 1.6, (E, 1)) + rng.normal(0, 12, (E, n_hours)), 3.0)
+    price = np.round(hourly, 2)[:, hour_idx] / 1000.0
+    a["charge_price"] = -price
+    a["discharge_price"] = price * cfg.discharge_price_factor
+
+    # ---- EV sessions (EV_spawner utils.py:477-557) ----
+    min_stay_steps = cfg.ev_min_time_of_stay // dt
+    free_from = np.zeros((E, P), np.int64)       # first spawn step t at which the port passes the 3-step-empty rule
+    rate = _arrival_rate(cfg.scenario, hod) * (dt / 60.0) * cfg.spawn_multiplier   # percent per step
+    stay_mean = _mean_stay_hours(cfg.scenario, hod)
+    energy_mean = _mean_energy_kwh(cfg.scenario, hod)
+    if cfg.heterogeneous_ev_specs:
+        share = np.array([f[0] for f in _FLEET_V2G])
+        share = share / share.sum()
+        fleet_B = np.array([f[1] for f in _FLEET_V2G])
+        fleet_pac = np.array([f[2] for f in _FLEET_V2G])
+    se, sp, st_, sB, spac, scap0, stdep, smodel = [], [], [], [], [], [], [], []
+    for t in range(2, T - min_stay_steps - 1):
+        u = rng.random((E, P)) * 100.0
+        spawn = (free_from <= t) & (u < rate[t])
+        if not spawn.any():
+            continue
+        e_idx, p_idx = np.nonzero(spawn)
+        n = len(e_idx)
+        req = rng.normal(energy_mean[t], 0.5 * energy_mean[t], n)
+        req = np.where(req < 5, rng.integers(5, 10, n), req)
+        if cfg.heterogeneous_ev_specs:
+            model = rng.choice(len(share), n, p=share)
+            B = fleet_B[model]
+            pac = fleet_pac[model]
+        else:
+            model = np.zeros(n, int)
+            B = np.full(n, cfg.ev_battery_capacity)
+            pac = np.full(n, cfg.ev_max_ac_charge_power)
+        cap0 = np.where(B < req, rng.integers(1, np.maximum(B.astype(int), 2), n), B - req)
+        cap0 = np.where(cap0 > cfg.ev_desired_capacity * B, rng.integers(1, np.maximum(B.astype(int), 2), n), cap0)
+        cap0 = np.where((cap0 < cfg.ev_min_battery_capacity) & (B > 2 * cfg.ev_min_battery_capacity),
+                        cfg.ev_min_battery_capacity, cap0)
+        stay = rng.normal(stay_mean[t], 0.2 * stay_mean[t], n) * 60.0 / dt + 1
+        stay = np.maximum(stay, min_stay_steps)
+        keep = ~(stay + t + 4 >= T)          # empty_ports_at_end_of_simulation (utils.py:254-256)
+        e_idx, p_idx, B, pac, cap0, stay, model = e_idx[keep], p_idx[keep], B[keep], pac[keep], cap0[keep], stay[keep], model[keep]
+        tdep = (stay + t + 3).astype(np.int64)
+        # occupancy_list[t+1 : t_dep] = 1 and the 3-step look-back (utils.py:534-552) => next spawn step >= t_dep + 2
+        free_from[e_idx, p_idx] = tdep + 2
+        se.append(e_idx); sp.append(p_idx); st_.append(np.full(len(e_idx), t + 1)); sB.append(B); spac.append(pac)
+        scap0.append(cap0); stdep.append(tdep); smodel.append(model)
+    if se:
+        se, sp, st_, sB, spac, scap0, stdep, smodel = [np.concatenate(x) for x in (se, sp, st_, sB, spac, scap0, stdep, smodel)]
+    else:
+        se = sp = st_ = stdep = smodel = np.zeros(0, np.int64)
+        sB = spac = scap0 = np.zeros(0)
+    order = np.lexsort((sp, st_, se))          # env, then arrival step, then (charger, port) order
+    se, sp, st_, sB, spac, scap0, stdep, smodel = [x[order] for x in (se, sp, st_, sB, spac, scap0, stdep, smodel)]
+    S = len(se)
+    a["env_session_start"] = np.concatenate([[0], np.cumsum(np.bincount(se, minlength=E))]).astype(np.int64)
+    a["ev_cs"] = (sp // npc).astype(np.int32)
+    a["ev_t_arr"] = st_.astype(np.int32)
+    a["ev_t_dep"] = stdep.astype(np.int32)
+    a["ev_cap0"] = scap0.astype(float)
+    a["ev_B"] = sB
+    a["ev_desired"] = cfg.ev_desired_capacity * sB
+    a["ev_minB"] = np.full(S, cfg.ev_min_battery_capacity)
+    a["ev_min_emerg"] = np.where(cfg.ev_min_emergency_battery_capacity > sB, 0.7 * sB, cfg.ev_min_emergency_battery_capacity)
+    a["ev_pac_max"] = spac
+    a["ev_tsm"] = np.full(S, cfg.ev_transition_soc_multiplier)
+    if cfg.heterogeneous_ev_specs:
+        a["ev_pac_min"] = np.zeros(S)
+        a["ev_pdis_max"] = -spac if cfg.v2g_enabled else np.zeros(S)
+        a["ev_pdis_min"] = np.zeros(S)
+        a["ev_phases"] = np.full(S, 3, np.int32)
+        a["ev_ts"] = np.round(0.9 - (rng.random(S) + 0.00001) / 5, 3)
+        if cfg.fleet_with_efficiency_tables:
+            levels = [6, 8, 10, 12, 14, 16]
+            a["lut"] = np.stack([_lut_from_levels(levels, f[3]) for f in _FLEET_V2G])
+            a["ev_lut"] = smodel.astype(np.int32)
+            a["ev_eta_ch"] = np.full(S, np.nan)
+            a["ev_eta_dis"] = np.full(S, np.nan)
+        else:
+            a["lut"] = np.zeros((0, _abi.LUT_LEN))
+            a["ev_lut"] = np.full(S, -1, np.int32)
+            a["ev_eta_ch"] = np.round(1 - (rng.random(S) + 0.00001) / 20, 3)
+            a["ev_eta_dis"] = np.round(1 - (rng.random(S) + 0.00001) / 20, 3)
+    else:
+        a["ev_pac_min"] = np.full(S, cfg.ev_min_ac_charge_power)
+        a["ev_pdis_max"] = np.full(S, cfg.ev_max_discharge_power)
+        a["ev_pdis_min"] = np.full(S, cfg.ev_min_discharge_power)
+        a["ev_phases"] = np.full(S, cfg.ev_phases, np.int32)
+        a["ev_ts"] = np.full(S, cfg.ev_transition_soc)
+        a["lut"] = np.zeros((0, _abi.LUT_LEN))
+        a["ev_lut"] = np.full(S, -1, np.int32)
+        a["ev_eta_ch"] = np.full(S, cfg.ev_charge_efficiency)
+        a["ev_eta_dis"] = np.full(S, cfg.ev_discharge_efficiency)
+
+    # ---- transformers (loaders.py:227-296, transformer.py:38-256) ----
+    maxp = np.full((E, R, T), cfg.transformer_max_power)
+    minp = -maxp.copy()
+    tod = (hod[:T])[None, None, :]
+    if cfg.inflexible_loads:
+        shape = 0.35 + 0.25 * np.sin((tod / 24.0 - 0.3) * 2 * np.pi) ** 2 + 0.5 * np.exp(-((tod / 24.0 - 0.8) / 0.08) ** 2)
+        infl = shape * rng.uniform(0.6, 1.4, (E, R, 1)) + rng.normal(0, 0.03, (E, R, T))
+        infl = np.abs(infl)
+        mult = rng.normal(1.0, 0.1, (E, R, 1))
+        infl = infl * mult * (cfg.transformer_max_power / infl.max(axis=2, keepdims=True) + 0.0000001)
+        infl = np.clip(infl, minp, maxp)
+    else:
+        infl = np.zeros((E, R, T))
+    if cfg.solar_power:
+        sun = np.clip(np.sin((tod - 6.5) / 13.0 * np.pi), 0, None) ** 1.5 * rng.uniform(0.3, 1.0, (E, 1, 1))
+        solar = -(sun * rng.uniform(0.9, 1.1, (E, R, 1))) * rng.normal(1.0, 0.1, (E, R, 1)) * cfg.transformer_max_power
+        solar = np.where(tod < 24, solar, solar)
+    else:
+        solar = np.zeros((E, R, T))
+    steps_ahead = 60 // dt
+    dr = np.zeros((E, R, 1, 3))
+    ndr = np.zeros((E, R), np.int32)
+    if cfg.demand_response:
+        start_min = np.clip(rng.normal(12 * 60, 2 * 60, (E, R)), 0, 23 * 60)
+        es = (start_min // dt - (cfg.hour * 60) // dt).astype(int)
+        ee = es + 60 // dt
+        cap = np.clip(rng.normal(35, 5, (E, R)), 0, 100)
+        tt = np.arange(T)[None, None, :]
+        inside = (tt >= es[..., None]) & (tt < ee[..., None])
+        maxp = np.where(inside, maxp - maxp * cap[..., None] / 100, maxp)
+        # if the load exceeds the reduced limit inside the event, the limit is lifted to the load's maximum
+        over = (inside & (infl > maxp)).any(axis=2)
+        load_max = np.where(inside, infl, -np.inf).max(axis=2)
+        maxp = np.where(inside & over[..., None], load_max[..., None], maxp)
+        cap = np.where(over, 100 * (1 - load_max / maxp.max(axis=2)), cap)
+        dr[:, :, 0, 0], dr[:, :, 0, 1], dr[:, :, 0, 2] = es, ee, cap
+        ndr[:] = 1
+    lf = np.clip(rng.normal(0.30 * infl, np.abs(0.05 * infl)), minp, maxp) if cfg.inflexible_loads else np.zeros((E, R, T))
+    pvf = rng.normal(0.20 * solar, np.abs(0.05 * solar)) if cfg.solar_power else np.zeros((E, R, T))
+    # reset() already observed step 0 (transformer.py:178-180)
+    lf[:, :, 0] = infl[:, :, 0]
+    pvf[:, :, 0] = solar[:, :, 0]
+    a["tr_max_power"], a["tr_min_power"] = maxp, minp
+    a["tr_inflexible_load"], a["tr_solar_power"] = infl, solar
+    a["tr_load_forecast"], a["tr_pv_forecast"] = lf, pvf
+    a["tr_dr"], a["tr_n_dr"] = dr, ndr
+    a["tr_steps_ahead"] = np.full((E, R), steps_ahead, np.int32)
+
+    # ---- power setpoints (generate_power_setpoints utils.py:664-757, simplified & vectorised) ----
+    if cfg.power_setpoint_enabled and S:
+        pr = np.abs(a["charge_price"])
+        pr = pr / pr.max(axis=1, keepdims=True)
+        sq = np.sqrt(cfg.cs_phases)
+        min_cs = cfg.cs_min_charge_current * cfg.cs_voltage * sq / 1000
+        max_cs = cfg.cs_max_charge_current * cfg.cs_voltage * sq / 1000
+        tt = np.arange(T)[None, :]
+        win = (tt >= (a["ev_t_arr"][:, None] + 1)) & (tt < a["ev_t_dep"][:, None])     # steps t+2 .. t_dep-1
+        w = np.abs(rng.normal(1 - pr[se], np.maximum(pr[se].min(axis=1, keepdims=True), 1e-3))) * win
+        w = w / np.maximum(w.sum(axis=1, keepdims=True), 1e-12)
+        need = (a["ev_B"] - a["ev_cap0"]) * (100 + cfg.power_setpoint_flexiblity) / 100
+        load = w * need[:, None] * 60 / dt
+        lo = np.maximum(a["ev_pac_min"], min_cs)[:, None]
+        hi = np.minimum(a["ev_pac_max"], max_cs)[:, None]
+        load = np.where((load > 0) & (load < lo), 0.0, np.minimum(load, hi))
+        sp_ = np.zeros((E, T))
+        np.add.at(sp_, se, load)
+        k = 5 * max(1, int(15 / dt))
+        pad = np.pad(sp_, ((0, 0), (k // 2, k - 1 - k // 2)), mode="edge")
+        sp_ = np.median(np.lib.stride_tricks.sliding_window_view(pad, k, axis=1), axis=2)
+        a["power_setpoints"] = sp_
+    else:
+        a["power_setpoints"] = np.zeros((E, T))
+    return ScenarioBatch(E, T, dt, Cn, npc, R, cfg.v2g_enabled, 20, a).finalize()
+
+
+def occupancy_fraction(batch: ScenarioBatch) -> float:
+    """phi: fraction of port-steps with an EV connected after the spawn phase (the action_mask mean)."""
+    a = batch.arrays
+    T = batch.n_steps
+    # present after step t (mask[t]) for t in [t_arr-1, t_dep-1]  ->  min(t_dep, T) - (t_arr - 1) masked steps
+    n = np.clip(np.minimum(a["ev_t_dep"], T) - (a["ev_t_arr"] - 1), 0, None).sum()
+    return float(n) / (batch.n_envs * batch.n_ports * T)
