@@ -23,6 +23,16 @@
 #define EV2G_BLOCK 256
 #define EV2G_NQ 8  // staged quantities per port
 
+// One EV session, 128 bytes = one cache line: everything the per-step battery maths needs (ev.py:68-113).
+struct __attribute__((aligned(128))) SessRec {
+    double B, cap0, des, minB, emerg, pacmax, pdismax, ts, tsm, eta_ch, eta_dis;
+    double gate_ch;   // min_ac_charge_power*1000/(voltage*sqrt(charger phases))   (ev.py:151)
+    double gate_dis;  // min_discharge_power*1000/(voltage*sqrt(charger phases))   (ev.py:153)
+    double v;         // voltage*sqrt(min(charger phases, ev_phases))              (ev.py:169,279,365)
+    int nt_arr, nt_dep;  // window of the next session on the same port (EV2G_INT_MAX = none)
+    int lut, pad;        // efficiency table id or -1
+};
+
 struct DevScn {  // read-only scenario + layout, device pointers
     int E, T, C, npc, P, R, D, ND, dt;
     int reward_kind, state_kind, flags;
@@ -53,6 +63,7 @@ struct DevScn {  // read-only scenario + layout, device pointers
     // per port [E*P]: first session (or -1) and its window
     const int *port_first;
     const int2 *port_first_win;
+    const SessRec *rec;  // [S] AoS twin of the ss_* arrays (v2 kernels)
 };
 
 struct DevState {  // mutable engine state, device pointers

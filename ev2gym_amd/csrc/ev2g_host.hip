@@ -15,6 +15,7 @@
 
 #include "../../include/ev2g.h"
 #include "ev2g_device.h"
+#include "ev2g_step_v2.h"
 
 static thread_local std::string g_create_error;
 
@@ -37,6 +38,9 @@ struct ev2g_handle {
     std::vector<double> sess_afap;              // [S] host order
     long long *d_env_sess = nullptr;            // unused placeholder for the stats kernel signature
     double *d_ss_afap = nullptr;                // [S] device order
+    DevScn *d_scn = nullptr;                    // device copies of scn / st (v2 kernels take pointers)
+    DevState *d_st = nullptr;
+    int block = 0;                              // 256/512/1024: v2 kernel; 0: generic kernel (P > 1024)
     int current_step = 0;
     size_t lds_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -352,7 +356,10 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     s = DevScn{};
     s.E = E; s.T = T; s.C = C; s.npc = npc; s.P = P; s.R = R; s.D = D; s.ND = std::max(ND, 1); s.dt = b->timescale;
     s.reward_kind = h->cfg.reward_kind; s.state_kind = sk; s.flags = h->cfg.flags;
-    s.G = std::max(1, EV2G_BLOCK / P);
+    // v2 kernel: one home lane per port, BLOCK >= P; the generic kernel handles larger envs
+    h->block = (P <= 256) ? 256 : (P <= 512) ? 512 : (P <= 1024) ? 1024 : 0;
+    const int blk = h->block ? h->block : EV2G_BLOCK;
+    s.G = std::max(1, blk / P);
     s.G = std::min(s.G, E);
     {
         int gs = 4;
@@ -362,12 +369,33 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     s.n_groups = (E + s.G - 1) / s.G;
     s.sixty_over_dt = 60.0 / (double)b->timescale;
     s.dt_over_60 = (double)b->timescale / 60.0;
-    h->lds_bytes = sizeof(double) * ((size_t)EV2G_NQ * s.G * P + (size_t)EV2G_NQ * s.G * R + (size_t)EV2G_NQ * s.G);
+    if (h->block)
+        h->lds_bytes = ev2g_v2_lds_bytes(s.G * P, s.G * R, s.G);
+    else
+        h->lds_bytes = sizeof(double) * ((size_t)EV2G_NQ * s.G * P + (size_t)EV2G_NQ * s.G * R + (size_t)EV2G_NQ * s.G);
     if (h->lds_bytes > 160 * 1024)
         return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: ports per env exceed the LDS staging capacity (P <= ~2400)");
-    if (h->lds_bytes > 64 * 1024) {
-        HIPCHK(h, hipFuncSetAttribute((const void *)ev2g_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)h->lds_bytes));
+    {
+        const void *fn = h->block == 256 ? (const void *)ev2g_step_v2<256>
+                         : h->block == 512 ? (const void *)ev2g_step_v2<512>
+                         : h->block == 1024 ? (const void *)ev2g_step_v2<1024> : (const void *)ev2g_step_kernel;
+        if (h->lds_bytes > 48 * 1024)
+            HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    }
+    // AoS session records (one cache line each) for the v2 kernel
+    std::vector<SessRec> recs((size_t)std::max<long long>(S, 1));
+    for (long long d = 0; d < S; d++) {
+        const long long hs = dev_to_host[d];
+        const int cs = b->ev_cs[hs];
+        SessRec &r = recs[d];
+        r.B = ss_B[d]; r.cap0 = ss_cap0[d]; r.des = ss_des[d]; r.minB = ss_minB[d]; r.emerg = ss_emerg[d];
+        r.pacmax = ss_pacmax[d]; r.pdismax = ss_pdismax[d]; r.ts = ss_ts[d]; r.tsm = ss_tsm[d];
+        r.eta_ch = ss_etach[d]; r.eta_dis = ss_etadis[d];
+        const double v_gate = cs_vk[(size_t)cs * 4 + b->cs_phases[cs]];
+        r.gate_ch = ss_pacmin[d] * 1000.0 / v_gate;
+        r.gate_dis = ss_pdismin[d] * 1000.0 / v_gate;
+        r.v = cs_vk[(size_t)cs * 4 + std::min(b->cs_phases[cs], ss_phases[d])];
+        r.nt_arr = ss_ntarr[d]; r.nt_dep = ss_ntdep[d]; r.lut = ss_lut[d]; r.pad = 0;
     }
 
     // ---- upload ----
@@ -427,6 +455,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     UP(ip, port_first) s.port_first = ip;
     UP(i2p, port_first_win) s.port_first_win = i2p;
     UP(dp, ss_afap) h->d_ss_afap = dp;
+    { SessRec *rp; UP(rp, recs) s.rec = rp; }
 #undef UP
 #undef UPP
     // ---- state ----
@@ -445,6 +474,8 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     AL(usage_hist, (size_t)T * E) AL(pot_hist, (size_t)T * E) AL(over_hist, (size_t)T * E * R)
     AL(tr_power_now, (size_t)E * R) AL(sess_final_cap, S)
 #undef AL
+    if ((rc = upload(h, sp, &h->scn, 1, &h->d_scn))) return rc;
+    if ((rc = upload(h, sp, &h->st, 1, &h->d_st))) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
 
     h->E = E; h->T = T; h->C = C; h->npc = npc; h->P = P; h->R = R; h->D = D; h->S = S;
@@ -477,8 +508,19 @@ int ev2g_reset(ev2g_handle *h, double *obs) {
 
 static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int auto_reset) {
     const DevScn &s = h->scn;
-    hipLaunchKernelGGL(ev2g_step_kernel, dim3(s.n_groups), dim3(EV2G_BLOCK), h->lds_bytes, h->stream, s, h->st, io, t0,
-                       k, auto_reset);
+    switch (h->block) {
+    case 256:
+        hipLaunchKernelGGL(ev2g_step_v2<256>, dim3(s.n_groups), dim3(256), h->lds_bytes, h->stream, h->d_scn, h->d_st, io, t0, k, auto_reset);
+        break;
+    case 512:
+        hipLaunchKernelGGL(ev2g_step_v2<512>, dim3(s.n_groups), dim3(512), h->lds_bytes, h->stream, h->d_scn, h->d_st, io, t0, k, auto_reset);
+        break;
+    case 1024:
+        hipLaunchKernelGGL(ev2g_step_v2<1024>, dim3(s.n_groups), dim3(1024), h->lds_bytes, h->stream, h->d_scn, h->d_st, io, t0, k, auto_reset);
+        break;
+    default:
+        hipLaunchKernelGGL(ev2g_step_kernel, dim3(s.n_groups), dim3(EV2G_BLOCK), h->lds_bytes, h->stream, s, h->st, io, t0, k, auto_reset);
+    }
     HIPCHK(h, hipGetLastError());
     return EV2G_OK;
 }
