@@ -64,10 +64,12 @@ struct DevScn {  // read-only scenario + layout, device pointers
     const int *port_first;
     const int2 *port_first_win;
     const SessRec *rec;  // [S] AoS twin of the ss_* arrays (v2 kernels)
+    const double *win_tab;  // [E,R,T+1,40] precomputed (loads-pv)[20] | power_limits[20] per observation step, or nullptr
 };
 
 struct DevState {  // mutable engine state, device pointers
     double *cap, *tot_e, *prev_power;  // [E*P] EV.current_capacity / total_energy_exchanged / previous_power
+    double *bcap, *potc;               // [E*P] battery_capacity and charge-power-potential term of the attached EV (v2)
     int2 *win;                         // [E*P] {t_arr, t_dep} of the attached-or-next session (INT_MAX = none)
     int2 *sc;                          // [E*P] {session index, charging_cycles}
     double *cs_sat_sum;                // [E*C] EV_Charger.total_user_satisfaction
@@ -82,6 +84,7 @@ struct DevState {  // mutable engine state, device pointers
     double *tr_power_now;              // [E,R]  Transformer.current_power of the last step
     double *sess_final_cap;            // [S] capacity at departure
     double *port_energy, *port_current;  // [E*P] EV.current_energy / actual_current of the last step
+    unsigned long long *dbg;             // [n_groups*8] phase timing (EV2G_PHASE_TIMING builds only), else nullptr
 };
 
 struct StepIO {
@@ -633,6 +636,20 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
         }
         t += 1;
         __syncthreads();
+    }
+}
+
+// One-off at load time: materialise the per-(env, transformer, observation step) 40-wide window
+// [ (loads - pv)[20] | power_limits[20] ] (transformer.py:142-188) so that the step kernel streams it with
+// one coalesced load per lane instead of re-deriving it through dependent gathers every step.
+__global__ void ev2g_build_window_table_kernel(DevScn s, double *__restrict__ tab) {
+    const long long n = (long long)s.E * s.R * (s.T + 1) * 40;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % 40);
+        const long long k = i / 40;
+        const int step = (int)(k % (s.T + 1));
+        const int er = (int)(k / (s.T + 1));
+        tab[i] = (j < 20) ? load_minus_pv_at(s, (long long)er * s.T, step, j) : power_limit_at(s, er, step, j - 20);
     }
 }
 

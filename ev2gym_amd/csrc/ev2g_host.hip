@@ -370,7 +370,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     s.sixty_over_dt = 60.0 / (double)b->timescale;
     s.dt_over_60 = (double)b->timescale / 60.0;
     if (h->block)
-        h->lds_bytes = ev2g_v2_lds_bytes(s.G * P, s.G * R, s.G);
+        h->lds_bytes = ev2g_v2_lds_bytes(s.G * P, s.G * R, s.G, R);
     else
         h->lds_bytes = sizeof(double) * ((size_t)EV2G_NQ * s.G * P + (size_t)EV2G_NQ * s.G * R + (size_t)EV2G_NQ * s.G);
     if (h->lds_bytes > 160 * 1024)
@@ -458,13 +458,24 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     { SessRec *rp; UP(rp, recs) s.rec = rp; }
 #undef UP
 #undef UPP
+    s.win_tab = nullptr;
+    if (sk == EV2G_STATE_V2G_PROFIT_MAX_LOADS && h->block) {
+        double *tab = nullptr;
+        const size_t n = (size_t)E * R * (T + 1) * 40;
+        HIPCHK(h, hipMalloc((void **)&tab, n * sizeof(double)));
+        pool.push_back(tab);
+        const int nb = (int)std::min<size_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(ev2g_build_window_table_kernel, dim3(nb), dim3(256), 0, h->stream, s, tab);
+        HIPCHK(h, hipGetLastError());
+        s.win_tab = tab;
+    }
     // ---- state ----
     DevState &st = h->st;
     st = DevState{};
     auto &sp = h->st_allocs;
     const size_t EP = (size_t)E * P, EC = (size_t)E * C;
 #define AL(field, n) if ((rc = dalloc(h, sp, (size_t)(n), &st.field))) return rc;
-    AL(cap, EP) AL(tot_e, EP) AL(prev_power, EP) AL(win, EP) AL(sc, EP) AL(port_energy, EP) AL(port_current, EP)
+    AL(cap, EP) AL(tot_e, EP) AL(prev_power, EP) AL(bcap, EP) AL(potc, EP) AL(win, EP) AL(sc, EP) AL(port_energy, EP) AL(port_current, EP)
     AL(cs_sat_sum, EC) AL(cs_served, EC)
     if (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) {
         AL(cs_profits, EC) AL(cs_e_ch, EC) AL(cs_e_dis, EC) AL(cs_power_now, EC) AL(cs_cur_now, EC)
@@ -473,6 +484,9 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     AL(env_acc, (size_t)E * 8) AL(env_fault, E)
     AL(usage_hist, (size_t)T * E) AL(pot_hist, (size_t)T * E) AL(over_hist, (size_t)T * E * R)
     AL(tr_power_now, (size_t)E * R) AL(sess_final_cap, S)
+#ifdef EV2G_PHASE_TIMING
+    AL(dbg, (size_t)s.n_groups * 8)
+#endif
 #undef AL
     if ((rc = upload(h, sp, &h->scn, 1, &h->d_scn))) return rc;
     if ((rc = upload(h, sp, &h->st, 1, &h->d_st))) return rc;
@@ -510,13 +524,13 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
     const DevScn &s = h->scn;
     switch (h->block) {
     case 256:
-        hipLaunchKernelGGL(ev2g_step_v2<256>, dim3(s.n_groups), dim3(256), h->lds_bytes, h->stream, h->d_scn, h->d_st, io, t0, k, auto_reset);
+        hipLaunchKernelGGL(ev2g_step_v2<256>, dim3(s.n_groups), dim3(256), h->lds_bytes, h->stream, s, h->st, io, t0, k, auto_reset);
         break;
     case 512:
-        hipLaunchKernelGGL(ev2g_step_v2<512>, dim3(s.n_groups), dim3(512), h->lds_bytes, h->stream, h->d_scn, h->d_st, io, t0, k, auto_reset);
+        hipLaunchKernelGGL(ev2g_step_v2<512>, dim3(s.n_groups), dim3(512), h->lds_bytes, h->stream, s, h->st, io, t0, k, auto_reset);
         break;
     case 1024:
-        hipLaunchKernelGGL(ev2g_step_v2<1024>, dim3(s.n_groups), dim3(1024), h->lds_bytes, h->stream, h->d_scn, h->d_st, io, t0, k, auto_reset);
+        hipLaunchKernelGGL(ev2g_step_v2<1024>, dim3(s.n_groups), dim3(1024), h->lds_bytes, h->stream, s, h->st, io, t0, k, auto_reset);
         break;
     default:
         hipLaunchKernelGGL(ev2g_step_kernel, dim3(s.n_groups), dim3(EV2G_BLOCK), h->lds_bytes, h->stream, s, h->st, io, t0, k, auto_reset);
@@ -703,6 +717,16 @@ int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *v) {
     }
     return EV2G_OK;
 }
+
+#ifdef EV2G_PHASE_TIMING
+int ev2g_debug_phase_ticks(ev2g_handle *h, unsigned long long *out8) {
+    std::vector<unsigned long long> v((size_t)h->scn.n_groups * 8);
+    HIPCHK(h, hipMemcpy(v.data(), h->st.dbg, v.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) { out8[i] = 0; for (int b = 0; b < h->scn.n_groups; b++) out8[i] += v[(size_t)b * 8 + i]; }
+    HIPCHK(h, hipMemset(h->st.dbg, 0, v.size() * 8));
+    return 0;
+}
+#endif
 
 void *ev2g_malloc(ev2g_handle *h, size_t bytes) {
     if (!h) return nullptr;

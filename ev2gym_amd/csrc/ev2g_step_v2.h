@@ -1,8 +1,9 @@
 // ev2g_step_v2.h -- the production step kernel (P <= BLOCK ports per env; the generic kernel in
 // ev2g_device.h covers larger envs).
 //
-// Per workgroup: G = BLOCK / P whole envs, one HOME lane per port that keeps the port's dynamic state
-// (window, session, capacity, energy counters) in REGISTERS across the fused steps of one launch.
+// Per workgroup: G = BLOCK / P whole envs, one HOME lane per port; the port's dynamic state (window, session,
+// capacity, energy counters) stays resident in LDS across the fused steps of one launch, so neither the home
+// lanes nor the compacted worker lanes carry long-lived registers and the kernel fits 4 workgroups per CU.
 // Per step:
 //   A  home lanes: action -> charger-level amps (ev_charger.py:137-186); lanes whose EV really charges or
 //      discharges append themselves to a compact work list in LDS (charge items grow from the front,
@@ -19,6 +20,23 @@
 // Envs never communicate, so the K-step variant simply loops inside the workgroup (no grid sync).
 #pragma once
 #include "ev2g_device.h"
+
+// Optional per-phase cycle accounting (tools/phase_timing.py builds a private .so with -DEV2G_PHASE_TIMING;
+// the product library never has it).  dbg[block][phase] accumulates s_memtime ticks seen by wave 0 lane 0.
+#ifdef EV2G_PHASE_TIMING
+#define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(); unsigned long long pt_acc[8] = {0,0,0,0,0,0,0,0};
+#define PT_MARK(i) { unsigned long long n_ = __builtin_readcyclecounter(); pt_acc[i] += n_ - pt_last; pt_last = n_; }
+#define PT_FLUSH if (threadIdx.x == 0 && st.dbg) { for (int i_ = 0; i_ < 8; i_++) st.dbg[(size_t)blockIdx.x * 8 + i_] += pt_acc[i_]; }
+#else
+#define PT_DECL
+#define PT_MARK(i)
+#define PT_FLUSH
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would serialise
+// every global prefetch issued at the top of a step against the first barrier; global memory is never used
+// to communicate inside a workgroup here (only LDS is), so "s_waitcnt lgkmcnt(0); s_barrier" is sufficient.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct EvRes {
     double cap, prev_power, tot_e, energy, current;
@@ -86,17 +104,16 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, const double *__restr
 }
 
 // LDS carve-up for ev2g_step_v2 (doubles first, then ints); NS = G*P, NT = G*R
-__host__ __device__ inline size_t ev2g_v2_lds_bytes(int NS, int NT, int G) {
-    return sizeof(double) * ((size_t)EV2G_NQ * NS + 4 * (size_t)NS + (size_t)EV2G_NQ * NT + (size_t)EV2G_NQ * G) +
-           sizeof(int) * (4 * (size_t)NS + 4);
+__host__ __device__ inline size_t ev2g_v2_lds_bytes(int NS, int NT, int G, int R) {
+    return sizeof(double) * ((size_t)(EV2G_NQ + 6) * NS + (size_t)EV2G_NQ * NT + (size_t)EV2G_NQ * G + (size_t)NT +
+                             (size_t)G * 6) +
+           sizeof(int) * (6 * (size_t)NS + (size_t)R + 1 + 4);
 }
 
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) ev2g_step_v2(const DevScn *__restrict__ Sp, const DevState *__restrict__ STp,
-                                                      StepIO io, int t0, int k_steps, int auto_reset) {
+__global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const DevState st, StepIO io, int t0,
+                                                         int k_steps, int auto_reset) {
     extern __shared__ double lds[];
-    const DevScn &S = *Sp;
-    const DevState &st = *STp;
     const int P = S.P, R = S.R, T = S.T, C = S.C, npc = S.npc, E = S.E, D = S.D, G = S.G;
     int grp;
     {   // XCD-aware mapping: workgroup b runs on XCD b % 8; give each XCD a contiguous range of env groups
@@ -106,264 +123,311 @@ __global__ void __launch_bounds__(BLOCK) ev2g_step_v2(const DevScn *__restrict__
     const int e0 = grp * G;
     const int ne = min(G, E - e0);
     const int N = ne * P, NS = G * P, NT = G * R;
-    double *stage = lds;                          // [NQ][NS] per-port results, by home index
-    double *hs_amps = stage + (size_t)EV2G_NQ * NS;  // work item inputs / outputs, by home index
-    double *hs_cap = hs_amps + NS, *hs_prev = hs_cap + NS, *hs_tot = hs_prev + NS;
-    double *tsum = hs_tot + NS;                   // [NQ][NT]
-    double *esum = tsum + (size_t)EV2G_NQ * NT;   // [NQ][G]
-    int *hs_ss = (int *)(esum + (size_t)EV2G_NQ * G);
-    int *hs_cyc = hs_ss + NS, *items = hs_cyc + NS, *occf = items + NS, *cnt = occf + NS;  // cnt[0] charge, cnt[1] discharge
+    // ---- LDS: per-port results, resident port state, reduction scratch ----
+    double *stage = lds;                                   // [NQ][NS] per-port step results, by home index
+    double *s_cap = stage + (size_t)EV2G_NQ * NS;          // EV.current_capacity
+    double *s_tot = s_cap + NS, *s_prev = s_tot + NS;      // total_energy_exchanged, previous_power
+    double *s_bcap = s_prev + NS, *s_potc = s_bcap + NS;   // battery_capacity, charge-power-potential term
+    double *s_amps = s_potc + NS;                          // phase A: amps; phase B: replaced by EV.current_energy
+    double *tsum = s_amps + NS;                            // [NQ][NT]
+    double *esum = tsum + (size_t)EV2G_NQ * NT;            // [NQ][G]
+    double *over_l = esum + (size_t)EV2G_NQ * G;           // [NT] 100 * overload of each (env, transformer)
+    double *eacc = over_l + NT;                            // [G][5] episode accumulators
+    double *pot_prev = eacc + (size_t)G * 5;               // [G] charge_power_potential[t]
+    int *s_ta = (int *)(pot_prev + G);                     // window {t_arr, t_dep} of the attached-or-next session
+    int *s_td = s_ta + NS, *s_ss = s_td + NS, *s_cyc = s_ss + NS;  // session index, charging_cycles
+    int *s_dirty = s_cyc + NS;                             // bit0: cap/tot/prev/cycles changed, bit1: window changed
+    int *items = s_dirty + NS, *seg = items + NS, *cnt = seg + R + 1;  // cnt[0] charge, cnt[1] discharge
     const int tid = threadIdx.x;
     const bool log_cs = st.cs_profits != nullptr;
     const double dtd = (double)S.dt, sixty_over_dt = S.sixty_over_dt, dt_over_60 = S.dt_over_60;
 
-    // ---- home lane set-up (once per launch) ----
+    // ---- home lane set-up (once per launch): global state -> LDS ----
     const bool valid = tid < N;
     const int el = valid ? tid / P : 0;
     const int q = valid ? tid - el * P : 0;
     const int e = e0 + el;
-    const long long g = (long long)e * P + q;
+    const int g = e * P + q;  // 32-bit element offsets: the engine requires E*P, E*D, E*R*T < 2^31
     const int cs = S.slot_cs[q], pref = S.slot_port[q], ocol = S.slot_obs[q];
-    const double imax = S.cs_imax[cs], imin = S.cs_imin[cs], dmin = S.cs_dmin[cs], dmaxabs = S.cs_dmax_abs[cs];
-    const double cs_maxp = S.cs_maxp[cs], cs_minp = S.cs_minp[cs];
-    int2 w = make_int2(EV2G_INT_MAX, EV2G_INT_MAX);
-    int ss = -1, cycles = 0;
-    double cap = 0.0, tot_e = 0.0, prev_power = 0.0, Bcap = 1.0, pot_c = 0.0, last_e = 0.0, last_i = 0.0;
-    bool dirty_state = false, dirty_win = false, dirty_last = false;
     int t = t0;
     if (valid) {
-        w = st.win[g];
+        const int2 w = st.win[g];
         const int2 sc = st.sc[g];
-        ss = sc.x;
-        cycles = sc.y;
+        s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = sc.x; s_cyc[tid] = sc.y; s_dirty[tid] = 0;
         if (w.x <= t && t <= w.y) {
-            cap = st.cap[g];
-            tot_e = st.tot_e[g];
-            prev_power = st.prev_power[g];
-            const SessRec &r = S.rec[ss];
-            Bcap = r.B;
-            const double evc = r.pacmax * 1000.0 / r.v;            // utils.py:773-777
-            pot_c = r.v * ((evc < imax) ? evc : imax) / 1000.0;
+            s_cap[tid] = st.cap[g]; s_tot[tid] = st.tot_e[g]; s_prev[tid] = st.prev_power[g];
+            s_bcap[tid] = st.bcap[g]; s_potc[tid] = st.potc[g];
+        } else {
+            s_cap[tid] = 0.0; s_tot[tid] = 0.0; s_prev[tid] = 0.0; s_bcap[tid] = 1.0; s_potc[tid] = 0.0;
         }
     }
+    // env-level lanes: thread i < ne*R owns (env, transformer) pair i; thread pel*lpe owns env pel
+    const int lpe = BLOCK / ne;
+    const int pel = tid / lpe, pl = tid - pel * lpe;
+    const bool env_lane = pel < ne;
+    const int pe = e0 + (env_lane ? pel : 0);
     if (tid < 2) cnt[tid] = 0;
-    if (npc > 1 && valid) occf[tid] = (w.x <= t && t <= w.y) ? 1 : 0;  // sibling ports read occupancy from LDS
+    for (int i = tid; i <= R; i += BLOCK) seg[i] = S.tr_seg[i];
+    for (int i = tid; i < ne * 5; i += BLOCK) eacc[i] = 0.0;
+    for (int i = tid; i < ne; i += BLOCK) pot_prev[i] = (t < T) ? st.pot_hist[t * E + e0 + i] : 0.0;
+    double a_next = (valid && k_steps > 0 && t < T) ? io.actions[e * P + pref] : 0.0;
     __syncthreads();
 
+    PT_DECL
     for (int kk = 0; kk < k_steps; kk++) {
+        PT_MARK(7)
+        // Defeat loop-invariant hoisting of per-lane addresses: LLVM would otherwise precompute ~60 LDS / global
+        // addresses before the step loop and keep them alive across it (they end up in scratch).  Re-deriving an
+        // address costs one or two VALU ops per use; the indices below are opaque to the optimiser per iteration.
+        int tid_l = tid, g_l = g, e_l = e, cs_l = cs, pref_l = pref, ocol_l = ocol, pe_l = pe, pl_l = pl, pel_l = pel;
+        asm volatile("" : "+v"(tid_l), "+v"(g_l), "+v"(e_l), "+v"(cs_l), "+v"(pref_l), "+v"(ocol_l), "+v"(pe_l), "+v"(pl_l), "+v"(pel_l));
         if (t >= T) {  // episode finished inside a fused run: in-kernel ev2g_reset for this workgroup
             if (!auto_reset) break;
             if (valid) {
-                w = S.port_first_win[g];
-                ss = S.port_first[g];
-                cycles = 0; cap = 0.0; tot_e = 0.0; prev_power = 0.0; last_e = 0.0; last_i = 0.0;
-                dirty_state = dirty_win = dirty_last = true;
-                if (npc > 1) occf[tid] = 0;
+                const int2 w = S.port_first_win[g_l];
+                s_ta[tid_l] = w.x; s_td[tid_l] = w.y; s_ss[tid_l] = S.port_first[g_l]; s_cyc[tid_l] = 0;
+                s_cap[tid_l] = 0.0; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_dirty[tid_l] = 3;
+                st.port_energy[g_l] = 0.0;
+                st.port_current[g_l] = 0.0;
             }
-            for (int i = tid; i < ne * C; i += BLOCK) {
-                const long long gc = (long long)e0 * C + i;
+            for (int i = tid_l; i < ne * C; i += BLOCK) {
+                const int gc = e0 * C + i;
                 st.cs_sat_sum[gc] = 0.0;
                 st.cs_served[gc] = 0;
                 if (log_cs) { st.cs_profits[gc] = 0.0; st.cs_e_ch[gc] = 0.0; st.cs_e_dis[gc] = 0.0; }
             }
-            for (int i = tid; i < ne * 8; i += BLOCK) st.env_acc[(long long)e0 * 8 + i] = 0.0;
-            for (int i = tid; i < ne; i += BLOCK) st.pot_hist[e0 + i] = 0.0;
+            for (int i = tid_l; i < ne * 8; i += BLOCK) st.env_acc[e0 * 8 + i] = 0.0;
+            for (int i = tid_l; i < ne * 5; i += BLOCK) eacc[i] = 0.0;
+            for (int i = tid_l; i < ne; i += BLOCK) pot_prev[i] = 0.0;
             t = 0;
-            __syncthreads();
+            lds_barrier();
         }
-        const double *__restrict__ actions = io.actions + (long long)kk * io.a_stride;
         double *__restrict__ obs = io.obs ? io.obs + (long long)kk * io.o_stride : nullptr;
         uint8_t *__restrict__ mask = io.mask ? io.mask + (long long)kk * io.m_stride : nullptr;
         const int sstep = t + 1;
+        const bool last_step = (kk == k_steps - 1) || (sstep >= T && !auto_reset);
+
+        // ---- prefetch what the env-level phases of this step need (the loads stay in flight across the LDS-only
+        //      barriers and land while phases A-D run) ----
+        double pf_infl = 0.0, pf_solar = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
+        if (tid_l < ne * R) {
+            const int erT = (e0 * R + tid_l) * T + t;
+            pf_infl = S.tr_infl[erT]; pf_solar = S.tr_solar[erT]; pf_maxp = S.tr_maxp[erT]; pf_minp = S.tr_minp[erT];
+        }
+        if (env_lane && pl_l == 0 && S.reward_kind == 1) pf_sp = S.setpoint[pe_l * T + t];
+        // head / window columns of the observation this step emits (step counter sstep): one coalesced load per lane
+        double pf_ob0 = 0.0, pf_ob1 = 0.0;
+        const int nhead = (S.state_kind == 1) ? 0 : 20 + ((S.state_kind == 0) ? 40 * R : 0);
+        if (env_lane && obs) {
+            if (S.state_kind == 1) {
+                if (pl_l == 0) pf_ob0 = (sstep < T) ? S.setpoint[pe_l * T + sstep] : 0.0;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int c = pl_l + u * lpe;
+                    double v = 0.0;
+                    if (c < 20) {
+                        const int k = sstep + c;
+                        v = (k < T) ? fabs(S.price_ch[pe_l * T + k]) : 0.0;
+                    } else if (c < nhead) {
+                        const int i = c - 20, r = i / 40, j = i - r * 40;
+                        v = S.win_tab[(((long long)pe_l * R + r) * (T + 1) + sstep) * 40 + j];
+                    }
+                    if (u == 0) pf_ob0 = v; else pf_ob1 = v;
+                }
+            }
+        }
 
         // ---------------- A: home lanes, charger level (ev_charger.py:137-186) ----------------
-        const bool occ = valid && (w.x <= t) && (t <= w.y);
-        double amps = 0.0, x = 0.0;
+        bool occ = false;
         if (valid) {
-            double a = occ ? actions[(long long)e * P + pref] : 0.0;
+            const int ta = s_ta[tid_l], td = s_td[tid_l];
+            occ = (ta <= t) && (t <= td);
+            double a = occ ? a_next : 0.0;
             if (npc == 1) {
                 if (a > 1.0) a = a / a;
                 else if (a < -1.0) a = -a / a;
             } else {
-                const int j0 = q - (pref - cs * npc);
+                const double *__restrict__ actions = io.actions + (long long)kk * io.a_stride;
+                const int j0 = tid_l - (pref_l - cs_l * npc);
                 double Ssum = 0.0;
                 for (int j = 0; j < npc; j++) {  // sequential python sum() over the charger's ports
-                    const bool oj = occf[tid - q + j0 + j] != 0;
-                    Ssum = Ssum + (oj ? actions[(long long)e * P + cs * npc + j] : 0.0);
+                    const bool oj = (s_ta[j0 + j] <= t) && (t <= s_td[j0 + j]);
+                    Ssum = Ssum + (oj ? actions[e_l * P + cs_l * npc + j] : 0.0);
                 }
                 if (Ssum > 1.0) a = a / Ssum;
                 else if (Ssum < -1.0) a = -a / Ssum;
             }
+            double amps = 0.0;
             if (occ) {
-                x = rnd5(a);
-                if (x > 0.0) { amps = x * imax; if (amps < imin - 0.01) amps = 0.0; }
-                else if (x < 0.0) { amps = x * dmaxabs; if (amps > dmin - 0.01) amps = dmin; }
+                const double x = rnd5(a);
+                if (x > 0.0) { amps = x * S.cs_imax[cs_l]; if (amps < S.cs_imin[cs_l] - 0.01) amps = 0.0; }
+                else if (x < 0.0) { const double dmin = S.cs_dmin[cs_l]; amps = x * S.cs_dmax_abs[cs_l]; if (amps > dmin - 0.01) amps = dmin; }
             }
-            stage[0 * NS + tid] = 0.0;
-            stage[4 * NS + tid] = 0.0;
-            stage[5 * NS + tid] = 0.0;
-            stage[6 * NS + tid] = 0.0;
-            stage[7 * NS + tid] = 0.0;
+            s_amps[tid_l] = amps;
+            stage[0 * NS + tid_l] = 0.0;
+            stage[4 * NS + tid_l] = 0.0;
+            stage[5 * NS + tid_l] = 0.0;
+            stage[6 * NS + tid_l] = 0.0;
+            stage[7 * NS + tid_l] = 0.0;
+            if (amps != 0.0) items[(amps > 0.0) ? atomicAdd(&cnt[0], 1) : NS - 1 - atomicAdd(&cnt[1], 1)] = tid_l;
+            // next step's action: issued now, consumed after the barriers of this step
+            const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
+            a_next = more ? (io.actions + (long long)(kk + 1) * io.a_stride)[e_l * P + pref_l] : 0.0;
         }
-        const bool active = occ && amps != 0.0;
-        if (active) {
-            const int pos = (amps > 0.0) ? atomicAdd(&cnt[0], 1) : NS - 1 - atomicAdd(&cnt[1], 1);
-            items[pos] = tid;
-            hs_amps[tid] = amps;
-            hs_cap[tid] = cap;
-            hs_prev[tid] = prev_power;
-            hs_tot[tid] = tot_e;
-            hs_ss[tid] = ss;
-            hs_cyc[tid] = cycles;
-        }
-        __syncthreads();
+        PT_MARK(0)
+        lds_barrier();
+        PT_MARK(1)
 
         // ---------------- B: worker lanes, battery maths on the compact list ----------------
         {
             const int nch = cnt[0], ndis = cnt[1];
             const int nchp = (nch + 63) & ~63;  // discharge items start on a wavefront boundary
-            for (int i = tid; i < nchp + ndis; i += BLOCK) {
+            for (int i = tid_l; i < nchp + ndis; i += BLOCK) {
                 int h = -1;
                 if (i < nch) h = items[i];
                 else if (i >= nchp) h = items[NS - 1 - (i - nchp)];
                 if (h >= 0) {
-                    const SessRec r = S.rec[hs_ss[h]];
-                    const EvRes o = ev_math(r, S.lut, hs_amps[h], hs_cap[h], hs_prev[h], hs_tot[h], hs_cyc[h],
-                                            sixty_over_dt, dt_over_60, dtd);
-                    hs_cap[h] = o.cap;
-                    hs_prev[h] = o.prev_power;
-                    hs_tot[h] = o.tot_e;
-                    hs_cyc[h] = o.cycles;
-                    hs_amps[h] = o.energy;  // slot reused: EV.current_energy
-                    const double ae = fabs(o.energy);
+                    const SessRec r = S.rec[s_ss[h]];
+                    const double cap0 = s_cap[h], prev0 = s_prev[h];
+                    const int cyc0 = s_cyc[h];
+                    const EvRes o = ev_math(r, S.lut, s_amps[h], cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd);
+                    if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
+                    s_cap[h] = o.cap;
+                    s_prev[h] = o.prev_power;
+                    s_tot[h] = o.tot_e;
+                    s_cyc[h] = o.cycles;
+                    s_amps[h] = o.energy;
                     stage[0 * NS + h] = o.energy * 60.0 / dtd;
-                    stage[(i < nch ? 4 : 5) * NS + h] = ae;
+                    stage[(i < nch ? 4 : 5) * NS + h] = fabs(o.energy);
                     stage[6 * NS + h] = (double)o.emerg;
                     stage[7 * NS + h] = o.current;
                 }
             }
         }
-        __syncthreads();
-        if (tid < 2) cnt[tid] = 0;
+        PT_MARK(2)
+        lds_barrier();
+        PT_MARK(1)
+        if (tid_l < 2) cnt[tid_l] = 0;
 
-        // ---------------- C: home lanes: read back, departures, arrivals, observation columns ----------------
+        // ---------------- C: home lanes: departures, arrivals, observation columns ----------------
         if (valid) {
             double profit = 0.0, satpen = 0.0, pot = 0.0;
+            int ta = s_ta[tid_l], td = s_td[tid_l];
+            double cap = s_cap[tid_l];
             if (occ) {
-                double energy = 0.0, current = 0.0;
-                if (active) {
-                    const double ncap = hs_cap[tid];
-                    energy = hs_amps[tid];
-                    current = stage[7 * NS + tid];
-                    const int ncyc = hs_cyc[tid];
-                    const double nprev = hs_prev[tid];
-                    if (ncyc != cycles || energy != 0.0 || ncap != cap || nprev != prev_power) dirty_state = true;
-                    cap = ncap;
-                    prev_power = nprev;
-                    tot_e = hs_tot[tid];
-                    cycles = ncyc;
-                    const double ae = fabs(energy);
-                    // charge price is negative: profit += |E| * price (ev_charger.py:178,194)
-                    profit = ae * ((x > 0.0) ? S.price_ch[(long long)e * T + t] : S.price_dis[(long long)e * T + t]);
-                    if (npc == 1 && current - 0.0001 > imax) st.env_fault[e] = 1;  // ev_charger.py:203-205
+                const double energy = s_amps[tid_l];  // 0 for idle EVs (phase A stored amps == 0)
+                const double current = stage[7 * NS + tid_l];
+                if (energy != 0.0) {  // profit += |E| * price, by the sign of the ACTION (ev_charger.py:178,194): the
+                    // worker staged |E| under "charged" (4) or "discharged" (5); a charge step can return a tiny
+                    // negative energy when ceil2 left the capacity above the battery size
+                    const double ech = stage[4 * NS + tid_l];
+                    profit = (ech != 0.0) ? ech * S.price_ch[e_l * T + t] : stage[5 * NS + tid_l] * S.price_dis[e_l * T + t];
                 }
-                dirty_last = true;  // the stored last-step values are not loaded at launch: rewrite whenever occupied
-                last_e = energy;
-                last_i = current;
-                if (t >= w.y) {  // departure (ev_charger.py:209-229, ev.py:191-214)
+                if (npc == 1 && current - 0.0001 > S.cs_imax[cs_l]) st.env_fault[e_l] = 1;  // ev_charger.py:203-205
+                if (last_step) { st.port_energy[g_l] = energy; st.port_current[g_l] = current; }
+                if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
+                    const int ss = s_ss[tid_l];
                     const SessRec &r = S.rec[ss];
                     const double des = r.des;
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
                     if (S.reward_kind != 1) satpen = 100.0 * exp(-10.0 * score);
-                    const long long gc = (long long)e * C + cs;
+                    const int gc = e_l * C + cs_l;
                     if (npc == 1) { st.cs_served[gc] += 1; st.cs_sat_sum[gc] += score; }
                     else { atomicAdd(&st.cs_served[gc], 1); atomicAdd(&st.cs_sat_sum[gc], score); }
                     st.sess_final_cap[ss] = cap;
-                    w = make_int2(r.nt_arr, r.nt_dep);
-                    ss = (w.x != EV2G_INT_MAX) ? ss + 1 : -1;
-                    cycles = 0;
-                    dirty_win = true;
+                    ta = r.nt_arr; td = r.nt_dep;
+                    s_ta[tid_l] = ta; s_td[tid_l] = td;
+                    s_ss[tid_l] = (ta != EV2G_INT_MAX) ? ss + 1 : -1;
+                    s_cyc[tid_l] = 0;
+                    s_dirty[tid_l] |= 2;
                 }
             }
-            if (w.x == sstep) {  // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
-                const SessRec &r = S.rec[ss];
+            if (ta == sstep) {  // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
+                const SessRec &r = S.rec[s_ss[tid_l]];
                 cap = r.cap0;
-                tot_e = 0.0;
-                prev_power = 0.0;
-                cycles = 0;
-                Bcap = r.B;
-                const double evc = r.pacmax * 1000.0 / r.v;
-                pot_c = r.v * ((evc < imax) ? evc : imax) / 1000.0;
-                last_e = 0.0;
-                last_i = 0.0;
-                dirty_state = true;
-                dirty_last = true;
+                const double B = r.B, v = r.v;
+                const double evc = r.pacmax * 1000.0 / v;            // utils.py:773-777
+                const double imax = S.cs_imax[cs_l];
+                const double potc = v * ((evc < imax) ? evc : imax) / 1000.0;
+                s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
+                st.bcap[g_l] = B;
+                st.potc[g_l] = potc;
+                st.port_energy[g_l] = 0.0;
+                st.port_current[g_l] = 0.0;
+                s_dirty[tid_l] |= 1;
             }
-            const bool occ_after = (w.x <= sstep) && (sstep <= w.y);
-            if (npc > 1) occf[tid] = occ_after ? 1 : 0;
-            if (mask) mask[(long long)e * P + pref] = occ_after ? 1 : 0;
+            const bool occ_after = (ta <= sstep) && (sstep <= td);
+            if (mask) mask[e_l * P + pref_l] = occ_after ? 1 : 0;
             double o0 = 0.0, o1 = 0.0, o2 = 0.0;
             if (occ_after) {
-                const double soc = cap / Bcap;
-                if (S.state_kind == 1) { o0 = (soc == 1.0) ? 1.0 : 0.5; o1 = tot_e; o2 = (double)(sstep - w.x); }
-                else { o0 = soc; o1 = (double)(w.y - sstep); }
-                if (soc < 1.0 && w.y > sstep) pot = pot_c;  // utils.py:771
+                const double soc = cap / s_bcap[tid_l];
+                if (S.state_kind == 1) { o0 = (soc == 1.0) ? 1.0 : 0.5; o1 = s_tot[tid_l]; o2 = (double)(sstep - ta); }
+                else { o0 = soc; o1 = (double)(td - sstep); }
+                if (soc < 1.0 && td > sstep) pot = s_potc[tid_l];  // utils.py:771
             }
-            if (npc == 1) pot = (pot > cs_maxp) ? cs_maxp : ((pot < cs_minp) ? 0.0 : pot);  // utils.py:779-789
+            if (npc == 1) {  // per-charger clamp (utils.py:779-789)
+                const double mx = S.cs_maxp[cs_l], mn = S.cs_minp[cs_l];
+                pot = (pot > mx) ? mx : ((pot < mn) ? 0.0 : pot);
+            }
             if (obs) {
-                double *o = obs + (long long)e * D + ocol;
+                double *o = obs + (e_l * D + ocol_l);
                 o[0] = o0;
                 o[1] = o1;
                 if (S.state_kind == 1) o[2] = o2;
             }
-            stage[1 * NS + tid] = profit;
-            stage[2 * NS + tid] = satpen;
-            stage[3 * NS + tid] = pot;
+            stage[1 * NS + tid_l] = profit;
+            stage[2 * NS + tid_l] = satpen;
+            stage[3 * NS + tid_l] = pot;
         }
-        __syncthreads();
+        PT_MARK(3)
+        lds_barrier();
+        PT_MARK(1)
 
         // ---------------- C2: per charger (multi-port chargers, or charger history) ----------------
         if (npc > 1 || log_cs) {
-            if (valid && pref == cs * npc) {  // leader = port 0 of the charger
+            if (valid && pref_l == cs_l * npc) {  // leader = port 0 of the charger
                 double pw = 0.0, cur = 0.0, pr = 0.0, ec = 0.0, ed = 0.0, pp = 0.0;
                 bool fault = false;
+                const double imax = S.cs_imax[cs_l];
                 for (int j = 0; j < npc; j++) {  // sequential, port order (ev_charger.py:155-205)
-                    pw += stage[0 * NS + tid + j];
-                    cur += stage[7 * NS + tid + j];
-                    pr += stage[1 * NS + tid + j];
-                    ec += stage[4 * NS + tid + j];
-                    ed += stage[5 * NS + tid + j];
-                    pp += stage[3 * NS + tid + j];
+                    pw += stage[0 * NS + tid_l + j];
+                    cur += stage[7 * NS + tid_l + j];
+                    pr += stage[1 * NS + tid_l + j];
+                    ec += stage[4 * NS + tid_l + j];
+                    ed += stage[5 * NS + tid_l + j];
+                    pp += stage[3 * NS + tid_l + j];
                     if (cur - 0.0001 > imax) fault = true;
                 }
-                if (fault) st.env_fault[e] = 1;
+                if (fault) st.env_fault[e_l] = 1;
                 if (npc > 1) {
-                    pp = (pp > cs_maxp) ? cs_maxp : ((pp < cs_minp) ? 0.0 : pp);
-                    stage[3 * NS + tid] = pp;
-                    for (int j = 1; j < npc; j++) stage[3 * NS + tid + j] = 0.0;
+                    const double mx = S.cs_maxp[cs_l], mn = S.cs_minp[cs_l];
+                    pp = (pp > mx) ? mx : ((pp < mn) ? 0.0 : pp);
+                    stage[3 * NS + tid_l] = pp;
+                    for (int j = 1; j < npc; j++) stage[3 * NS + tid_l + j] = 0.0;
                 }
                 if (log_cs) {
-                    const long long gc = (long long)e * C + cs;
+                    const int gc = e_l * C + cs_l;
                     st.cs_profits[gc] += pr;
                     st.cs_e_ch[gc] += ec;
                     st.cs_e_dis[gc] += ed;
                     st.cs_power_now[gc] = pw;
                     st.cs_cur_now[gc] = cur;
-                    st.cs_power_hist[((long long)t * E + e) * C + cs] = pw;
-                    st.cs_cur_hist[((long long)t * E + e) * C + cs] = cur;
+                    st.cs_power_hist[(t * E + e_l) * C + cs_l] = pw;
+                    st.cs_cur_hist[(t * E + e_l) * C + cs_l] = cur;
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
 
         // ---------------- D: LDS-staged segmented reduction, one wavefront per (env, transformer) ----------------
         {
-            const int wv = tid >> 6, lane = tid & 63, nw = BLOCK >> 6;
+            const int wv = tid_l >> 6, lane = tid_l & 63, nw = BLOCK >> 6;
             const int k = lane >> 3, j = lane & 7;
             const int ntask = ne * R;
             for (int task = wv; task < ntask; task += nw) {
                 const int tel = task / R, r = task - tel * R;
-                const int a = tel * P + S.tr_seg[r], b = tel * P + S.tr_seg[r + 1];
+                const int a = tel * P + seg[r], b = tel * P + seg[r + 1];
                 double acc = 0.0;
                 for (int i = a + j; i < b; i += 8) acc += stage[k * NS + i];
                 acc += __shfl_xor(acc, 1, 64);
@@ -372,75 +436,99 @@ __global__ void __launch_bounds__(BLOCK) ev2g_step_v2(const DevScn *__restrict__
                 if (j == 0) tsum[k * NT + task] = acc;
             }
         }
-        __syncthreads();
+        PT_MARK(4)
+        lds_barrier();
+        PT_MARK(1)
+
+        // ---------------- E1: per (env, transformer): Transformer.reset + step + get_how_overloaded ----------------
+        if (tid_l < ne * R) {  // transformer.py:258-302
+            double ptr = pf_infl + pf_solar;
+            ptr += tsum[0 * NT + tid_l];
+            const double over = (ptr > pf_maxp + 0.0001 || ptr < pf_minp - 0.0001) ? fabs(ptr - pf_maxp) : 0.0;
+            const int tel = tid_l / R, r = tid_l - tel * R;
+            st.over_hist[(t * E + e0 + tel) * R + r] = over;
+            if (last_step) st.tr_power_now[(e0 + tel) * R + r] = ptr;
+            over_l[tid_l] = 100.0 * over;
+        }
         if (R > 1) {
-            for (int i = tid; i < ne * EV2G_NQ; i += BLOCK) {
+            for (int i = tid_l; i < ne * EV2G_NQ; i += BLOCK) {
                 const int tel = i / EV2G_NQ, k = i - tel * EV2G_NQ;
                 double v = 0.0;
                 for (int r = 0; r < R; r++) v += tsum[k * NT + tel * R + r];
                 esum[k * G + tel] = v;
             }
-            __syncthreads();
         }
+        lds_barrier();
         const double *es = (R > 1) ? esum : tsum;
         const int esn = (R > 1) ? G : NT;
 
-        // ---------------- E: per env ----------------
-        {
-            const int lpe = BLOCK / ne;
-            const int pel = tid / lpe, l = tid - pel * lpe;
-            if (pel < ne) {
-                const int pe = e0 + pel;
-                const double usage = es[0 * esn + pel];
-                if (l == 0) {
-                    double over_sum = 0.0;
-                    for (int r = 0; r < R; r++) {  // Transformer.reset + step + get_how_overloaded (transformer.py:258-302)
-                        const long long erT = ((long long)pe * R + r) * T + t;
-                        double ptr = S.tr_infl[erT] + S.tr_solar[erT];
-                        ptr += tsum[0 * NT + pel * R + r];
-                        const double mx = S.tr_maxp[erT], mn = S.tr_minp[erT];
-                        const double over = (ptr > mx + 0.0001 || ptr < mn - 0.0001) ? fabs(ptr - mx) : 0.0;
-                        st.over_hist[((long long)t * E + pe) * R + r] = over;
-                        st.tr_power_now[(long long)pe * R + r] = ptr;
-                        over_sum += 100.0 * over;
-                    }
-                    st.usage_hist[(long long)t * E + pe] = usage;
-                    if (sstep < T) st.pot_hist[(long long)sstep * E + pe] = es[3 * esn + pel];
-                    const double costs = es[1 * esn + pel];
-                    double reward;
-                    if (S.reward_kind == 1) {  // SquaredTrackingErrorReward reward.py:7-14
-                        const double sp = S.setpoint[(long long)pe * T + t];
-                        const double pp = st.pot_hist[(long long)t * E + pe];
-                        const double m = (pp < sp) ? pp : sp;
-                        const double d = m - usage;
-                        reward = -(d * d);
-                    } else if (S.reward_kind == 2) {  // profit_maximization reward.py:78-87
-                        reward = costs - es[2 * esn + pel];
-                    } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
-                        reward = costs - over_sum - es[2 * esn + pel];
-                    }
-                    double *acc = st.env_acc + (long long)pe * 8;
-                    acc[0] += reward;
-                    acc[1] += costs;
-                    acc[2] += es[4 * esn + pel];
-                    acc[3] += es[5 * esn + pel];
-                    acc[4] += es[6 * esn + pel];
-                    if (io.reward) io.reward[(long long)kk * io.r_stride + pe] = reward;
-                    if (io.done) io.done[(long long)kk * io.d_stride + pe] = (sstep >= T) ? 1 : 0;
+        // ---------------- E2: per env: reward, histories, observation head ----------------
+        if (env_lane) {
+            const double usage = es[0 * esn + pel_l];
+            if (pl_l == 0) {
+                double over_sum = 0.0;
+                for (int r = 0; r < R; r++) over_sum += over_l[pel_l * R + r];
+                st.usage_hist[t * E + pe_l] = usage;
+                const double potn = es[3 * esn + pel_l];
+                if (sstep < T) st.pot_hist[sstep * E + pe_l] = potn;
+                const double costs = es[1 * esn + pel_l];
+                double reward;
+                if (S.reward_kind == 1) {  // SquaredTrackingErrorReward reward.py:7-14
+                    const double pp = pot_prev[pel_l];
+                    const double m = (pp < pf_sp) ? pp : pf_sp;
+                    const double d = m - usage;
+                    reward = -(d * d);
+                } else if (S.reward_kind == 2) {  // profit_maximization reward.py:78-87
+                    reward = costs - es[2 * esn + pel_l];
+                } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
+                    reward = costs - over_sum - es[2 * esn + pel_l];
                 }
-                if (obs) write_obs_env(S, obs + (long long)pe * D, pe, sstep, usage, l, lpe);
+                pot_prev[pel_l] = potn;
+                double *acc = eacc + pel_l * 5;
+                acc[0] += reward;
+                acc[1] += costs;
+                acc[2] += es[4 * esn + pel_l];
+                acc[3] += es[5 * esn + pel_l];
+                acc[4] += es[6 * esn + pel_l];
+                if (io.reward) io.reward[(long long)kk * io.r_stride + pe_l] = reward;
+                if (io.done) io.done[(long long)kk * io.d_stride + pe_l] = (sstep >= T) ? 1 : 0;
+                if (sstep >= T || last_step) {  // flush the episode accumulators (get_statistics reads them)
+                    double *ga = st.env_acc + pe_l * 8;
+                    for (int i = 0; i < 5; i++) { ga[i] += acc[i]; acc[i] = 0.0; }
+                }
+            }
+            if (obs) {
+                double *o = obs + pe_l * D;
+                if (S.state_kind == 1) {  // PublicPST state.py:6-35
+                    if (pl_l == 0) { o[0] = (double)sstep / (double)T; o[1] = pf_ob0; o[2] = usage; }
+                } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135
+                    if (pl_l == 0) { o[0] = (double)sstep; o[1] = usage; }
+                    int c = pl_l;
+                    if (c < 20) o[2 + c] = pf_ob0;
+                    else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; o[S.tr_obs[r] + j] = pf_ob0; }
+                    c = pl_l + lpe;
+                    if (c < 20) o[2 + c] = pf_ob1;
+                    else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; o[S.tr_obs[r] + j] = pf_ob1; }
+                    // envs with more head columns than two passes of their lanes (many transformers): the rest, unprefetched
+                    for (c = pl_l + 2 * lpe; c < nhead; c += lpe) {
+                        const int i = c - 20, r = i / 40, j = i - r * 40;
+                        o[S.tr_obs[r] + j] = S.win_tab[(((long long)pe_l * R + r) * (T + 1) + sstep) * 40 + j];
+                    }
+                }
             }
         }
+        PT_MARK(5)
         t += 1;
-        // no barrier needed here: the next step's phase A only touches stage[0,4..7], hs_*, items and cnt,
-        // none of which phase E reads; tsum/esum are rewritten only after three more barriers.
+        // no barrier needed here: the next step's phase A only touches stage[0,4..7], s_amps, items and cnt, none
+        // of which phase E reads; tsum/esum/over_l are rewritten only after three more barriers.
     }
-
-    // ---- write the register-resident port state back ----
+    PT_FLUSH
+    // ---- write the LDS-resident port state back ----
+    __syncthreads();
     if (valid) {
-        if (dirty_win) { st.win[g] = w; }
-        if (dirty_win || dirty_state) st.sc[g] = make_int2(ss, cycles);
-        if (dirty_state) { st.cap[g] = cap; st.tot_e[g] = tot_e; st.prev_power[g] = prev_power; }
-        if (dirty_last) { st.port_energy[g] = last_e; st.port_current[g] = last_i; }
+        const int d = s_dirty[tid];
+        if (d & 2) st.win[g] = make_int2(s_ta[tid], s_td[tid]);
+        if (d) st.sc[g] = make_int2(s_ss[tid], s_cyc[tid]);
+        if (d & 1) { st.cap[g] = s_cap[tid]; st.tot_e[g] = s_tot[tid]; st.prev_power[g] = s_prev[tid]; }
     }
 }
