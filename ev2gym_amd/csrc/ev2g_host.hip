@@ -38,8 +38,7 @@ struct ev2g_handle {
     std::vector<double> sess_afap;              // [S] host order
     long long *d_env_sess = nullptr;            // unused placeholder for the stats kernel signature
     double *d_ss_afap = nullptr;                // [S] device order
-    DevScn *d_scn = nullptr;                    // device copies of scn / st (v2 kernels take pointers)
-    DevState *d_st = nullptr;
+    V2P *d_v2p = nullptr;                       // device copy of the v2 kernel's parameter block
     int block = 0;                              // 256/512/1024: v2 kernel; 0: generic kernel (P > 1024)
     int current_step = 0;
     size_t lds_bytes = 0;
@@ -488,8 +487,11 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     AL(dbg, (size_t)s.n_groups * 8)
 #endif
 #undef AL
-    if ((rc = upload(h, sp, &h->scn, 1, &h->d_scn))) return rc;
-    if ((rc = upload(h, sp, &h->st, 1, &h->d_st))) return rc;
+    {
+        V2P v2p;
+        ev2g_v2_fill_params(v2p, h->scn, h->st);
+        if ((rc = upload(h, sp, &v2p, 1, &h->d_v2p))) return rc;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
 
     h->E = E; h->T = T; h->C = C; h->npc = npc; h->P = P; h->R = R; h->D = D; h->S = S;
@@ -524,13 +526,13 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
     const DevScn &s = h->scn;
     switch (h->block) {
     case 256:
-        hipLaunchKernelGGL(ev2g_step_v2<256>, dim3(s.n_groups), dim3(256), h->lds_bytes, h->stream, s, h->st, io, t0, k, auto_reset);
+        hipLaunchKernelGGL(ev2g_step_v2<256>, dim3(s.n_groups), dim3(256), h->lds_bytes, h->stream, (const V2P *)h->d_v2p, io, t0, k, auto_reset);
         break;
     case 512:
-        hipLaunchKernelGGL(ev2g_step_v2<512>, dim3(s.n_groups), dim3(512), h->lds_bytes, h->stream, s, h->st, io, t0, k, auto_reset);
+        hipLaunchKernelGGL(ev2g_step_v2<512>, dim3(s.n_groups), dim3(512), h->lds_bytes, h->stream, (const V2P *)h->d_v2p, io, t0, k, auto_reset);
         break;
     case 1024:
-        hipLaunchKernelGGL(ev2g_step_v2<1024>, dim3(s.n_groups), dim3(1024), h->lds_bytes, h->stream, s, h->st, io, t0, k, auto_reset);
+        hipLaunchKernelGGL(ev2g_step_v2<1024>, dim3(s.n_groups), dim3(1024), h->lds_bytes, h->stream, (const V2P *)h->d_v2p, io, t0, k, auto_reset);
         break;
     default:
         hipLaunchKernelGGL(ev2g_step_kernel, dim3(s.n_groups), dim3(EV2G_BLOCK), h->lds_bytes, h->stream, s, h->st, io, t0, k, auto_reset);

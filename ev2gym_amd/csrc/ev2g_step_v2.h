@@ -26,7 +26,7 @@
 #ifdef EV2G_PHASE_TIMING
 #define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(); unsigned long long pt_acc[8] = {0,0,0,0,0,0,0,0};
 #define PT_MARK(i) { unsigned long long n_ = __builtin_readcyclecounter(); pt_acc[i] += n_ - pt_last; pt_last = n_; }
-#define PT_FLUSH if (threadIdx.x == 0 && st.dbg) { for (int i_ = 0; i_ < 8; i_++) st.dbg[(size_t)blockIdx.x * 8 + i_] += pt_acc[i_]; }
+#define PT_FLUSH if (threadIdx.x == 0 && S->dbg) { for (int i_ = 0; i_ < 8; i_++) S->dbg[(size_t)blockIdx.x * 8 + i_] += pt_acc[i_]; }
 #else
 #define PT_DECL
 #define PT_MARK(i)
@@ -103,18 +103,75 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, const double *__restr
     return o;
 }
 
+// Pointer members carry the global address space explicitly, so that loads through a struct that itself lives in
+// device memory still compile to global_load / s_load (a plain `T*` read from memory would be a flat pointer, and
+// flat accesses tick lgkmcnt, which the LDS-only barriers wait on).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EV2G_GP(T) T __attribute__((address_space(1))) *
+#else
+#define EV2G_GP(T) T *
+#endif
+#define EV2G_SETP(dst, src) dst = (decltype(dst))(unsigned long long)(src)
+
+// Everything ev2g_step_v2 reads, resident in device memory (uploaded once per ev2g_load_scenarios).  The kernel
+// reads it through the scalar cache INSIDE the step loop (opaque pointer per iteration): passing these ~70 values
+// as by-value kernel arguments made LLVM hoist all of them above the loop and spill >200 SGPRs to VGPR lanes,
+// which was 40 % of the VALU instruction stream.
+struct V2P {
+    int E, T, C, npc, P, R, D, G, dt, reward_kind, state_kind, pad0;
+    double sixty_over_dt, dt_over_60;
+    EV2G_GP(const int) slot_cs; EV2G_GP(const int) slot_port; EV2G_GP(const int) slot_obs;
+    EV2G_GP(const int) tr_seg; EV2G_GP(const int) tr_obs; EV2G_GP(const int) port_first;
+    EV2G_GP(const int2) port_first_win;
+    EV2G_GP(const double) cs_imax; EV2G_GP(const double) cs_imin; EV2G_GP(const double) cs_dmin;
+    EV2G_GP(const double) cs_dmax_abs; EV2G_GP(const double) cs_maxp; EV2G_GP(const double) cs_minp;
+    EV2G_GP(const double) price_ch; EV2G_GP(const double) price_dis; EV2G_GP(const double) setpoint;
+    EV2G_GP(const double) tr_infl; EV2G_GP(const double) tr_solar; EV2G_GP(const double) tr_maxp;
+    EV2G_GP(const double) tr_minp; EV2G_GP(const double) win_tab; EV2G_GP(const double) lut;
+    EV2G_GP(const SessRec) rec;
+    EV2G_GP(double) cap; EV2G_GP(double) tot_e; EV2G_GP(double) prev_power; EV2G_GP(double) bcap; EV2G_GP(double) potc;
+    EV2G_GP(int2) win; EV2G_GP(int2) sc;
+    EV2G_GP(double) cs_sat_sum; EV2G_GP(int) cs_served;
+    EV2G_GP(double) cs_profits; EV2G_GP(double) cs_e_ch; EV2G_GP(double) cs_e_dis;
+    EV2G_GP(double) cs_power_hist; EV2G_GP(double) cs_cur_hist; EV2G_GP(double) cs_power_now; EV2G_GP(double) cs_cur_now;
+    EV2G_GP(double) env_acc; EV2G_GP(int) env_fault;
+    EV2G_GP(double) usage_hist; EV2G_GP(double) pot_hist; EV2G_GP(double) over_hist; EV2G_GP(double) tr_power_now;
+    EV2G_GP(double) sess_final_cap; EV2G_GP(double) port_energy; EV2G_GP(double) port_current;
+    EV2G_GP(unsigned long long) dbg;
+};
+
+inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
+    p.E = s.E; p.T = s.T; p.C = s.C; p.npc = s.npc; p.P = s.P; p.R = s.R; p.D = s.D; p.G = s.G; p.dt = s.dt;
+    p.reward_kind = s.reward_kind; p.state_kind = s.state_kind; p.pad0 = 0;
+    p.sixty_over_dt = s.sixty_over_dt; p.dt_over_60 = s.dt_over_60;
+#define CPS(f) EV2G_SETP(p.f, s.f);
+#define CPT(f) EV2G_SETP(p.f, st.f);
+    CPS(slot_cs) CPS(slot_port) CPS(slot_obs) CPS(tr_seg) CPS(tr_obs) CPS(port_first) CPS(port_first_win)
+    CPS(cs_imax) CPS(cs_imin) CPS(cs_dmin) CPS(cs_dmax_abs) CPS(cs_maxp) CPS(cs_minp)
+    CPS(price_ch) CPS(price_dis) CPS(setpoint) CPS(tr_infl) CPS(tr_solar) CPS(tr_maxp) CPS(tr_minp)
+    CPS(win_tab) CPS(lut) CPS(rec)
+    CPT(cap) CPT(tot_e) CPT(prev_power) CPT(bcap) CPT(potc) CPT(win) CPT(sc) CPT(cs_sat_sum) CPT(cs_served)
+    CPT(cs_profits) CPT(cs_e_ch) CPT(cs_e_dis) CPT(cs_power_hist) CPT(cs_cur_hist) CPT(cs_power_now) CPT(cs_cur_now)
+    CPT(env_acc) CPT(env_fault) CPT(usage_hist) CPT(pot_hist) CPT(over_hist) CPT(tr_power_now)
+    CPT(sess_final_cap) CPT(port_energy) CPT(port_current) CPT(dbg)
+#undef CPS
+#undef CPT
+}
+
 // LDS carve-up for ev2g_step_v2 (doubles first, then ints); NS = G*P, NT = G*R
 __host__ __device__ inline size_t ev2g_v2_lds_bytes(int NS, int NT, int G, int R) {
     return sizeof(double) * ((size_t)(EV2G_NQ + 6) * NS + (size_t)EV2G_NQ * NT + (size_t)EV2G_NQ * G + (size_t)NT +
                              (size_t)G * 6) +
-           sizeof(int) * (6 * (size_t)NS + (size_t)R + 1 + 4);
+           sizeof(int) * (6 * (size_t)NS + 2 * (size_t)R + 1 + 4);
 }
 
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const DevState st, StepIO io, int t0,
+__global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__ params, StepIO io, int t0,
                                                          int k_steps, int auto_reset) {
     extern __shared__ double lds[];
-    const int P = S.P, R = S.R, T = S.T, C = S.C, npc = S.npc, E = S.E, D = S.D, G = S.G;
+    typedef const V2P __attribute__((address_space(4))) *ParamPtr;  // constant address space: scalar loads
+    ParamPtr S = (ParamPtr)(unsigned long long)params;
+    const int P = S->P, R = S->R, T = S->T, C = S->C, npc = S->npc, E = S->E, D = S->D, G = S->G;
     int grp;
     {   // XCD-aware mapping: workgroup b runs on XCD b % 8; give each XCD a contiguous range of env groups
         const int nb = gridDim.x, b = blockIdx.x, per = nb >> 3;
@@ -137,10 +194,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
     int *s_ta = (int *)(pot_prev + G);                     // window {t_arr, t_dep} of the attached-or-next session
     int *s_td = s_ta + NS, *s_ss = s_td + NS, *s_cyc = s_ss + NS;  // session index, charging_cycles
     int *s_dirty = s_cyc + NS;                             // bit0: cap/tot/prev/cycles changed, bit1: window changed
-    int *items = s_dirty + NS, *seg = items + NS, *cnt = seg + R + 1;  // cnt[0] charge, cnt[1] discharge
+    int *items = s_dirty + NS, *seg = items + NS, *trobs = seg + R + 1, *cnt = trobs + R;  // cnt[0] charge, cnt[1] discharge
     const int tid = threadIdx.x;
-    const bool log_cs = st.cs_profits != nullptr;
-    const double dtd = (double)S.dt, sixty_over_dt = S.sixty_over_dt, dt_over_60 = S.dt_over_60;
+    const bool log_cs = S->cs_profits != nullptr;
+    const double dtd = (double)S->dt, sixty_over_dt = S->sixty_over_dt, dt_over_60 = S->dt_over_60;
 
     // ---- home lane set-up (once per launch): global state -> LDS ----
     const bool valid = tid < N;
@@ -148,15 +205,18 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
     const int q = valid ? tid - el * P : 0;
     const int e = e0 + el;
     const int g = e * P + q;  // 32-bit element offsets: the engine requires E*P, E*D, E*R*T < 2^31
-    const int cs = S.slot_cs[q], pref = S.slot_port[q], ocol = S.slot_obs[q];
+    const int cs = S->slot_cs[q], pref = S->slot_port[q], ocol = S->slot_obs[q];
+    // charger constants of this lane's port (ev_charger.py:41-94), live in registers for the whole launch
+    const double c_imax = S->cs_imax[cs], c_thr_ch = S->cs_imin[cs] - 0.01, c_dmin = S->cs_dmin[cs], c_dmaxabs = S->cs_dmax_abs[cs];
+    const double c_maxp = S->cs_maxp[cs], c_minp = S->cs_minp[cs];
     int t = t0;
     if (valid) {
-        const int2 w = st.win[g];
-        const int2 sc = st.sc[g];
+        const int2 w = S->win[g];
+        const int2 sc = S->sc[g];
         s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = sc.x; s_cyc[tid] = sc.y; s_dirty[tid] = 0;
         if (w.x <= t && t <= w.y) {
-            s_cap[tid] = st.cap[g]; s_tot[tid] = st.tot_e[g]; s_prev[tid] = st.prev_power[g];
-            s_bcap[tid] = st.bcap[g]; s_potc[tid] = st.potc[g];
+            s_cap[tid] = S->cap[g]; s_tot[tid] = S->tot_e[g]; s_prev[tid] = S->prev_power[g];
+            s_bcap[tid] = S->bcap[g]; s_potc[tid] = S->potc[g];
         } else {
             s_cap[tid] = 0.0; s_tot[tid] = 0.0; s_prev[tid] = 0.0; s_bcap[tid] = 1.0; s_potc[tid] = 0.0;
         }
@@ -167,9 +227,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
     const bool env_lane = pel < ne;
     const int pe = e0 + (env_lane ? pel : 0);
     if (tid < 2) cnt[tid] = 0;
-    for (int i = tid; i <= R; i += BLOCK) seg[i] = S.tr_seg[i];
+    for (int i = tid; i <= R; i += BLOCK) seg[i] = S->tr_seg[i];
+    for (int i = tid; i < R; i += BLOCK) trobs[i] = S->tr_obs[i];
     for (int i = tid; i < ne * 5; i += BLOCK) eacc[i] = 0.0;
-    for (int i = tid; i < ne; i += BLOCK) pot_prev[i] = (t < T) ? st.pot_hist[t * E + e0 + i] : 0.0;
+    for (int i = tid; i < ne; i += BLOCK) pot_prev[i] = (t < T) ? S->pot_hist[t * E + e0 + i] : 0.0;
     double a_next = (valid && k_steps > 0 && t < T) ? io.actions[e * P + pref] : 0.0;
     __syncthreads();
 
@@ -179,24 +240,25 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
         // Defeat loop-invariant hoisting of per-lane addresses: LLVM would otherwise precompute ~60 LDS / global
         // addresses before the step loop and keep them alive across it (they end up in scratch).  Re-deriving an
         // address costs one or two VALU ops per use; the indices below are opaque to the optimiser per iteration.
+        asm volatile("" : "+s"(S));  // parameters are (re)loaded through the scalar cache where they are used
         int tid_l = tid, g_l = g, e_l = e, cs_l = cs, pref_l = pref, ocol_l = ocol, pe_l = pe, pl_l = pl, pel_l = pel;
         asm volatile("" : "+v"(tid_l), "+v"(g_l), "+v"(e_l), "+v"(cs_l), "+v"(pref_l), "+v"(ocol_l), "+v"(pe_l), "+v"(pl_l), "+v"(pel_l));
         if (t >= T) {  // episode finished inside a fused run: in-kernel ev2g_reset for this workgroup
             if (!auto_reset) break;
             if (valid) {
-                const int2 w = S.port_first_win[g_l];
-                s_ta[tid_l] = w.x; s_td[tid_l] = w.y; s_ss[tid_l] = S.port_first[g_l]; s_cyc[tid_l] = 0;
+                const int2 w = S->port_first_win[g_l];
+                s_ta[tid_l] = w.x; s_td[tid_l] = w.y; s_ss[tid_l] = S->port_first[g_l]; s_cyc[tid_l] = 0;
                 s_cap[tid_l] = 0.0; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_dirty[tid_l] = 3;
-                st.port_energy[g_l] = 0.0;
-                st.port_current[g_l] = 0.0;
+                S->port_energy[g_l] = 0.0;
+                S->port_current[g_l] = 0.0;
             }
             for (int i = tid_l; i < ne * C; i += BLOCK) {
                 const int gc = e0 * C + i;
-                st.cs_sat_sum[gc] = 0.0;
-                st.cs_served[gc] = 0;
-                if (log_cs) { st.cs_profits[gc] = 0.0; st.cs_e_ch[gc] = 0.0; st.cs_e_dis[gc] = 0.0; }
+                S->cs_sat_sum[gc] = 0.0;
+                S->cs_served[gc] = 0;
+                if (log_cs) { S->cs_profits[gc] = 0.0; S->cs_e_ch[gc] = 0.0; S->cs_e_dis[gc] = 0.0; }
             }
-            for (int i = tid_l; i < ne * 8; i += BLOCK) st.env_acc[e0 * 8 + i] = 0.0;
+            for (int i = tid_l; i < ne * 8; i += BLOCK) S->env_acc[e0 * 8 + i] = 0.0;
             for (int i = tid_l; i < ne * 5; i += BLOCK) eacc[i] = 0.0;
             for (int i = tid_l; i < ne; i += BLOCK) pot_prev[i] = 0.0;
             t = 0;
@@ -206,37 +268,6 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
         uint8_t *__restrict__ mask = io.mask ? io.mask + (long long)kk * io.m_stride : nullptr;
         const int sstep = t + 1;
         const bool last_step = (kk == k_steps - 1) || (sstep >= T && !auto_reset);
-
-        // ---- prefetch what the env-level phases of this step need (the loads stay in flight across the LDS-only
-        //      barriers and land while phases A-D run) ----
-        double pf_infl = 0.0, pf_solar = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
-        if (tid_l < ne * R) {
-            const int erT = (e0 * R + tid_l) * T + t;
-            pf_infl = S.tr_infl[erT]; pf_solar = S.tr_solar[erT]; pf_maxp = S.tr_maxp[erT]; pf_minp = S.tr_minp[erT];
-        }
-        if (env_lane && pl_l == 0 && S.reward_kind == 1) pf_sp = S.setpoint[pe_l * T + t];
-        // head / window columns of the observation this step emits (step counter sstep): one coalesced load per lane
-        double pf_ob0 = 0.0, pf_ob1 = 0.0;
-        const int nhead = (S.state_kind == 1) ? 0 : 20 + ((S.state_kind == 0) ? 40 * R : 0);
-        if (env_lane && obs) {
-            if (S.state_kind == 1) {
-                if (pl_l == 0) pf_ob0 = (sstep < T) ? S.setpoint[pe_l * T + sstep] : 0.0;
-            } else {
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const int c = pl_l + u * lpe;
-                    double v = 0.0;
-                    if (c < 20) {
-                        const int k = sstep + c;
-                        v = (k < T) ? fabs(S.price_ch[pe_l * T + k]) : 0.0;
-                    } else if (c < nhead) {
-                        const int i = c - 20, r = i / 40, j = i - r * 40;
-                        v = S.win_tab[(((long long)pe_l * R + r) * (T + 1) + sstep) * 40 + j];
-                    }
-                    if (u == 0) pf_ob0 = v; else pf_ob1 = v;
-                }
-            }
-        }
 
         // ---------------- A: home lanes, charger level (ev_charger.py:137-186) ----------------
         bool occ = false;
@@ -261,8 +292,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
             double amps = 0.0;
             if (occ) {
                 const double x = rnd5(a);
-                if (x > 0.0) { amps = x * S.cs_imax[cs_l]; if (amps < S.cs_imin[cs_l] - 0.01) amps = 0.0; }
-                else if (x < 0.0) { const double dmin = S.cs_dmin[cs_l]; amps = x * S.cs_dmax_abs[cs_l]; if (amps > dmin - 0.01) amps = dmin; }
+                if (x > 0.0) { amps = x * c_imax; if (amps < c_thr_ch) amps = 0.0; }
+                else if (x < 0.0) { amps = x * c_dmaxabs; if (amps > c_dmin - 0.01) amps = c_dmin; }
             }
             s_amps[tid_l] = amps;
             stage[0 * NS + tid_l] = 0.0;
@@ -275,6 +306,39 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
             const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
             a_next = more ? (io.actions + (long long)(kk + 1) * io.a_stride)[e_l * P + pref_l] : 0.0;
         }
+        // ---- prefetch what phases C-E of this step need (issued AFTER phase A consumed its own operands, so that
+        //      phase A never waits on them; the loads stay in flight across the LDS-only barriers) ----
+        double pf_infl = 0.0, pf_solar = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
+        if (tid_l < ne * R) {
+            const int erT = (e0 * R + tid_l) * T + t;
+            pf_infl = S->tr_infl[erT]; pf_solar = S->tr_solar[erT]; pf_maxp = S->tr_maxp[erT]; pf_minp = S->tr_minp[erT];
+        }
+        if (env_lane && pl_l == 0 && S->reward_kind == 1) pf_sp = S->setpoint[pe_l * T + t];
+        double pf_pch = 0.0, pf_pdis = 0.0;
+        if (valid) { pf_pch = S->price_ch[e_l * T + t]; pf_pdis = S->price_dis[e_l * T + t]; }
+        // head / window columns of the observation this step emits (step counter sstep): one coalesced load per lane
+        double pf_ob0 = 0.0, pf_ob1 = 0.0;
+        const int nhead = (S->state_kind == 1) ? 0 : 20 + ((S->state_kind == 0) ? 40 * R : 0);
+        if (env_lane && obs) {
+            if (S->state_kind == 1) {
+                if (pl_l == 0) pf_ob0 = (sstep < T) ? S->setpoint[pe_l * T + sstep] : 0.0;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int c = pl_l + u * lpe;
+                    double v = 0.0;
+                    if (c < 20) {
+                        const int k = sstep + c;
+                        v = (k < T) ? S->price_ch[pe_l * T + k] : 0.0;  // |.| is applied at the store: touching v here would stall on the load
+                    } else if (c < nhead) {
+                        const int i = c - 20, r = i / 40, j = i - r * 40;
+                        v = S->win_tab[(((long long)pe_l * R + r) * (T + 1) + sstep) * 40 + j];
+                    }
+                    if (u == 0) pf_ob0 = v; else pf_ob1 = v;
+                }
+            }
+        }
+
         PT_MARK(0)
         lds_barrier();
         PT_MARK(1)
@@ -288,10 +352,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
                 if (i < nch) h = items[i];
                 else if (i >= nchp) h = items[NS - 1 - (i - nchp)];
                 if (h >= 0) {
-                    const SessRec r = S.rec[s_ss[h]];
+                    const SessRec r = *(const SessRec *)(S->rec + s_ss[h]);
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
-                    const EvRes o = ev_math(r, S.lut, s_amps[h], cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd);
+                    const EvRes o = ev_math(r, (const double *)S->lut, s_amps[h], cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd);
                     if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
                     s_cap[h] = o.cap;
                     s_prev[h] = o.prev_power;
@@ -311,6 +375,11 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
         if (tid_l < 2) cnt[tid_l] = 0;
 
         // ---------------- C: home lanes: departures, arrivals, observation columns ----------------
+        // All prefetches (issued at the end of phase A, one battery-maths phase ago) are collected HERE, before this
+        // phase issues its global stores: on gfx9-family ISAs vmcnt counts loads and stores together and they
+        // retire out of order with respect to each other, so a load consumed while younger stores are pending costs
+        // a full vmcnt(0) drain of those stores.  s_waitcnt vmcnt(0) expcnt(7) lgkmcnt(15):
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         if (valid) {
             double profit = 0.0, satpen = 0.0, pot = 0.0;
             int ta = s_ta[tid_l], td = s_td[tid_l];
@@ -322,20 +391,20 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
                     // worker staged |E| under "charged" (4) or "discharged" (5); a charge step can return a tiny
                     // negative energy when ceil2 left the capacity above the battery size
                     const double ech = stage[4 * NS + tid_l];
-                    profit = (ech != 0.0) ? ech * S.price_ch[e_l * T + t] : stage[5 * NS + tid_l] * S.price_dis[e_l * T + t];
+                    profit = (ech != 0.0) ? ech * pf_pch : stage[5 * NS + tid_l] * pf_pdis;
                 }
-                if (npc == 1 && current - 0.0001 > S.cs_imax[cs_l]) st.env_fault[e_l] = 1;  // ev_charger.py:203-205
-                if (last_step) { st.port_energy[g_l] = energy; st.port_current[g_l] = current; }
+                if (npc == 1 && current - 0.0001 > c_imax) S->env_fault[e_l] = 1;  // ev_charger.py:203-205
+                if (last_step) { S->port_energy[g_l] = energy; S->port_current[g_l] = current; }
                 if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
                     const int ss = s_ss[tid_l];
-                    const SessRec &r = S.rec[ss];
+                    const SessRec &r = *(const SessRec *)(S->rec + ss);
                     const double des = r.des;
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
-                    if (S.reward_kind != 1) satpen = 100.0 * exp(-10.0 * score);
+                    if (S->reward_kind != 1) satpen = 100.0 * exp(-10.0 * score);
                     const int gc = e_l * C + cs_l;
-                    if (npc == 1) { st.cs_served[gc] += 1; st.cs_sat_sum[gc] += score; }
-                    else { atomicAdd(&st.cs_served[gc], 1); atomicAdd(&st.cs_sat_sum[gc], score); }
-                    st.sess_final_cap[ss] = cap;
+                    if (npc == 1) { S->cs_served[gc] += 1; S->cs_sat_sum[gc] += score; }
+                    else { atomicAdd(&S->cs_served[gc], 1); atomicAdd(&S->cs_sat_sum[gc], score); }
+                    S->sess_final_cap[ss] = cap;
                     ta = r.nt_arr; td = r.nt_dep;
                     s_ta[tid_l] = ta; s_td[tid_l] = td;
                     s_ss[tid_l] = (ta != EV2G_INT_MAX) ? ss + 1 : -1;
@@ -344,17 +413,16 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
                 }
             }
             if (ta == sstep) {  // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
-                const SessRec &r = S.rec[s_ss[tid_l]];
+                const SessRec &r = *(const SessRec *)(S->rec + s_ss[tid_l]);
                 cap = r.cap0;
                 const double B = r.B, v = r.v;
                 const double evc = r.pacmax * 1000.0 / v;            // utils.py:773-777
-                const double imax = S.cs_imax[cs_l];
-                const double potc = v * ((evc < imax) ? evc : imax) / 1000.0;
+                const double potc = v * ((evc < c_imax) ? evc : c_imax) / 1000.0;
                 s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
-                st.bcap[g_l] = B;
-                st.potc[g_l] = potc;
-                st.port_energy[g_l] = 0.0;
-                st.port_current[g_l] = 0.0;
+                S->bcap[g_l] = B;
+                S->potc[g_l] = potc;
+                S->port_energy[g_l] = 0.0;
+                S->port_current[g_l] = 0.0;
                 s_dirty[tid_l] |= 1;
             }
             const bool occ_after = (ta <= sstep) && (sstep <= td);
@@ -362,19 +430,16 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
             double o0 = 0.0, o1 = 0.0, o2 = 0.0;
             if (occ_after) {
                 const double soc = cap / s_bcap[tid_l];
-                if (S.state_kind == 1) { o0 = (soc == 1.0) ? 1.0 : 0.5; o1 = s_tot[tid_l]; o2 = (double)(sstep - ta); }
+                if (S->state_kind == 1) { o0 = (soc == 1.0) ? 1.0 : 0.5; o1 = s_tot[tid_l]; o2 = (double)(sstep - ta); }
                 else { o0 = soc; o1 = (double)(td - sstep); }
                 if (soc < 1.0 && td > sstep) pot = s_potc[tid_l];  // utils.py:771
             }
-            if (npc == 1) {  // per-charger clamp (utils.py:779-789)
-                const double mx = S.cs_maxp[cs_l], mn = S.cs_minp[cs_l];
-                pot = (pot > mx) ? mx : ((pot < mn) ? 0.0 : pot);
-            }
+            if (npc == 1) pot = (pot > c_maxp) ? c_maxp : ((pot < c_minp) ? 0.0 : pot);  // per-charger clamp (utils.py:779-789)
             if (obs) {
                 double *o = obs + (e_l * D + ocol_l);
                 o[0] = o0;
                 o[1] = o1;
-                if (S.state_kind == 1) o[2] = o2;
+                if (S->state_kind == 1) o[2] = o2;
             }
             stage[1 * NS + tid_l] = profit;
             stage[2 * NS + tid_l] = satpen;
@@ -389,7 +454,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
             if (valid && pref_l == cs_l * npc) {  // leader = port 0 of the charger
                 double pw = 0.0, cur = 0.0, pr = 0.0, ec = 0.0, ed = 0.0, pp = 0.0;
                 bool fault = false;
-                const double imax = S.cs_imax[cs_l];
+                const double imax = c_imax;
                 for (int j = 0; j < npc; j++) {  // sequential, port order (ev_charger.py:155-205)
                     pw += stage[0 * NS + tid_l + j];
                     cur += stage[7 * NS + tid_l + j];
@@ -399,22 +464,22 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
                     pp += stage[3 * NS + tid_l + j];
                     if (cur - 0.0001 > imax) fault = true;
                 }
-                if (fault) st.env_fault[e_l] = 1;
+                if (fault) S->env_fault[e_l] = 1;
                 if (npc > 1) {
-                    const double mx = S.cs_maxp[cs_l], mn = S.cs_minp[cs_l];
+                    const double mx = c_maxp, mn = c_minp;
                     pp = (pp > mx) ? mx : ((pp < mn) ? 0.0 : pp);
                     stage[3 * NS + tid_l] = pp;
                     for (int j = 1; j < npc; j++) stage[3 * NS + tid_l + j] = 0.0;
                 }
                 if (log_cs) {
                     const int gc = e_l * C + cs_l;
-                    st.cs_profits[gc] += pr;
-                    st.cs_e_ch[gc] += ec;
-                    st.cs_e_dis[gc] += ed;
-                    st.cs_power_now[gc] = pw;
-                    st.cs_cur_now[gc] = cur;
-                    st.cs_power_hist[(t * E + e_l) * C + cs_l] = pw;
-                    st.cs_cur_hist[(t * E + e_l) * C + cs_l] = cur;
+                    S->cs_profits[gc] += pr;
+                    S->cs_e_ch[gc] += ec;
+                    S->cs_e_dis[gc] += ed;
+                    S->cs_power_now[gc] = pw;
+                    S->cs_cur_now[gc] = cur;
+                    S->cs_power_hist[(t * E + e_l) * C + cs_l] = pw;
+                    S->cs_cur_hist[(t * E + e_l) * C + cs_l] = cur;
                 }
             }
             lds_barrier();
@@ -428,8 +493,11 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
             for (int task = wv; task < ntask; task += nw) {
                 const int tel = task / R, r = task - tel * R;
                 const int a = tel * P + seg[r], b = tel * P + seg[r + 1];
-                double acc = 0.0;
-                for (int i = a + j; i < b; i += 8) acc += stage[k * NS + i];
+                double acc = 0.0, acc2 = 0.0;  // two chains: the LDS reads of a segment overlap
+                int i = a + j;
+                for (; i + 8 < b; i += 16) { acc += stage[k * NS + i]; acc2 += stage[k * NS + i + 8]; }
+                if (i < b) acc += stage[k * NS + i];
+                acc += acc2;
                 acc += __shfl_xor(acc, 1, 64);
                 acc += __shfl_xor(acc, 2, 64);
                 acc += __shfl_xor(acc, 4, 64);
@@ -446,8 +514,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
             ptr += tsum[0 * NT + tid_l];
             const double over = (ptr > pf_maxp + 0.0001 || ptr < pf_minp - 0.0001) ? fabs(ptr - pf_maxp) : 0.0;
             const int tel = tid_l / R, r = tid_l - tel * R;
-            st.over_hist[(t * E + e0 + tel) * R + r] = over;
-            if (last_step) st.tr_power_now[(e0 + tel) * R + r] = ptr;
+            S->over_hist[(t * E + e0 + tel) * R + r] = over;
+            if (last_step) S->tr_power_now[(e0 + tel) * R + r] = ptr;
             over_l[tid_l] = 100.0 * over;
         }
         if (R > 1) {
@@ -468,17 +536,17 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
             if (pl_l == 0) {
                 double over_sum = 0.0;
                 for (int r = 0; r < R; r++) over_sum += over_l[pel_l * R + r];
-                st.usage_hist[t * E + pe_l] = usage;
+                S->usage_hist[t * E + pe_l] = usage;
                 const double potn = es[3 * esn + pel_l];
-                if (sstep < T) st.pot_hist[sstep * E + pe_l] = potn;
+                if (sstep < T) S->pot_hist[sstep * E + pe_l] = potn;
                 const double costs = es[1 * esn + pel_l];
                 double reward;
-                if (S.reward_kind == 1) {  // SquaredTrackingErrorReward reward.py:7-14
+                if (S->reward_kind == 1) {  // SquaredTrackingErrorReward reward.py:7-14
                     const double pp = pot_prev[pel_l];
                     const double m = (pp < pf_sp) ? pp : pf_sp;
                     const double d = m - usage;
                     reward = -(d * d);
-                } else if (S.reward_kind == 2) {  // profit_maximization reward.py:78-87
+                } else if (S->reward_kind == 2) {  // profit_maximization reward.py:78-87
                     reward = costs - es[2 * esn + pel_l];
                 } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
                     reward = costs - over_sum - es[2 * esn + pel_l];
@@ -493,26 +561,26 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
                 if (io.reward) io.reward[(long long)kk * io.r_stride + pe_l] = reward;
                 if (io.done) io.done[(long long)kk * io.d_stride + pe_l] = (sstep >= T) ? 1 : 0;
                 if (sstep >= T || last_step) {  // flush the episode accumulators (get_statistics reads them)
-                    double *ga = st.env_acc + pe_l * 8;
+                    auto ga = S->env_acc + pe_l * 8;
                     for (int i = 0; i < 5; i++) { ga[i] += acc[i]; acc[i] = 0.0; }
                 }
             }
             if (obs) {
                 double *o = obs + pe_l * D;
-                if (S.state_kind == 1) {  // PublicPST state.py:6-35
+                if (S->state_kind == 1) {  // PublicPST state.py:6-35
                     if (pl_l == 0) { o[0] = (double)sstep / (double)T; o[1] = pf_ob0; o[2] = usage; }
                 } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135
                     if (pl_l == 0) { o[0] = (double)sstep; o[1] = usage; }
                     int c = pl_l;
-                    if (c < 20) o[2 + c] = pf_ob0;
-                    else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; o[S.tr_obs[r] + j] = pf_ob0; }
+                    if (c < 20) o[2 + c] = fabs(pf_ob0);
+                    else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; o[trobs[r] + j] = pf_ob0; }
                     c = pl_l + lpe;
-                    if (c < 20) o[2 + c] = pf_ob1;
-                    else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; o[S.tr_obs[r] + j] = pf_ob1; }
+                    if (c < 20) o[2 + c] = fabs(pf_ob1);
+                    else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; o[trobs[r] + j] = pf_ob1; }
                     // envs with more head columns than two passes of their lanes (many transformers): the rest, unprefetched
                     for (c = pl_l + 2 * lpe; c < nhead; c += lpe) {
                         const int i = c - 20, r = i / 40, j = i - r * 40;
-                        o[S.tr_obs[r] + j] = S.win_tab[(((long long)pe_l * R + r) * (T + 1) + sstep) * 40 + j];
+                        o[trobs[r] + j] = S->win_tab[(((long long)pe_l * R + r) * (T + 1) + sstep) * 40 + j];
                     }
                 }
             }
@@ -527,8 +595,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const DevScn S, const D
     __syncthreads();
     if (valid) {
         const int d = s_dirty[tid];
-        if (d & 2) st.win[g] = make_int2(s_ta[tid], s_td[tid]);
-        if (d) st.sc[g] = make_int2(s_ss[tid], s_cyc[tid]);
-        if (d & 1) { st.cap[g] = s_cap[tid]; st.tot_e[g] = s_tot[tid]; st.prev_power[g] = s_prev[tid]; }
+        if (d & 2) S->win[g] = make_int2(s_ta[tid], s_td[tid]);
+        if (d) S->sc[g] = make_int2(s_ss[tid], s_cyc[tid]);
+        if (d & 1) { S->cap[g] = s_cap[tid]; S->tot_e[g] = s_tot[tid]; S->prev_power[g] = s_prev[tid]; }
     }
 }

@@ -21,7 +21,7 @@ eng = engine.Engine(batch, _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl[
 P, D, T = eng.P, eng.D, eng.T
 acts = eng.empty((T, E, P)); eng.fill_uniform(acts, T * E * P, 1, wl["lo"], 1.0)
 obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
-names = ["A home/charger", "barrier waits", "B battery maths", "C home readback/obs cols", "D reduce", "E env-level+obs head", "-", "loop top"]
+names = ["A1 state+amps", "barrier waits", "B battery maths", "C home", "D reduce", "E env-level", "A2 lds writes+atomics+a_next", "A3 prefetch issue + loop top"]
 for persistent in (True, False):
     eng.reset(obs)
     eng.step_n(T, acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=persistent)
