@@ -26,6 +26,7 @@ STAT_NAMES = [  # get_statistics(), utilities/utils.py:84-101
 ERR_DONE = -4
 ERR_OVERCURRENT = -5
 FLAG_LOG_CS_HISTORY = 1
+FLAG_NULL_STREAM = 2
 
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int32)
@@ -71,5 +72,5 @@ class EnvViewC(C.Structure):
         ("port_required_energy", _pd), ("port_prev_power", _pd), ("port_cycles", _pi), ("port_session", _pi),
         ("cs_power", _pd), ("cs_amps", _pd), ("cs_profits", _pd), ("cs_energy_charged", _pd),
         ("cs_energy_discharged", _pd), ("tr_power", _pd), ("tr_overload", _pd), ("power_usage", _pd),
-        ("power_potential", _pd), ("session_port", _pi), ("session_afap", _pd),
+        ("power_potential", _pd), ("session_port", _pi), ("session_afap", _pd), ("session_final_cap", _pd),
     ]

@@ -111,6 +111,8 @@ int ev2g_create(const ev2g_config *cfg, ev2g_handle **out) {
     }
     if (cfg->stream) {
         h->stream = (hipStream_t)cfg->stream;
+    } else if (cfg->flags & EV2G_FLAG_NULL_STREAM) {
+        h->stream = nullptr;  // legacy default stream
     } else {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
             delete h;
@@ -713,6 +715,14 @@ int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *v) {
             for (int k = 0; k < T; k++) v->tr_overload[(size_t)r * T + k] = over[(size_t)k * R + r];
     if (v->power_usage) std::copy(usage.begin(), usage.end(), v->power_usage);
     if (v->power_potential) std::copy(pot.begin(), pot.end(), v->power_potential);
+    std::vector<double> fcap;
+    if (v->session_final_cap && s1 > s0) {
+        int dmin = 0x7fffffff;
+        for (long long s = s0; s < s1; s++) dmin = std::min(dmin, h->host_to_dev[s]);
+        fcap.resize((size_t)(s1 - s0));
+        HIPCHK(h, hipMemcpy(fcap.data(), st.sess_final_cap + dmin, sizeof(double) * (size_t)(s1 - s0), hipMemcpyDeviceToHost));
+        for (long long s = s0; s < s1; s++) v->session_final_cap[s - s0] = fcap[h->host_to_dev[s] - dmin];
+    }
     for (long long s = s0; s < s1; s++) {
         if (v->session_port) v->session_port[s - s0] = h->sess_port[s];
         if (v->session_afap) v->session_afap[s - s0] = h->sess_afap[s];

@@ -31,6 +31,14 @@ def load_library(path: Optional[str] = None):
     if _lib is not None:
         return _lib
     path = path or _LIB_PATH
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME).  If ours were loaded
+    # first from /opt/rocm, torch would later bring up a second runtime and fail with "No HIP GPUs are available";
+    # importing torch first makes the dynamic linker resolve our DT_NEEDED libamdhip64.so.7 to torch's copy.
+    if os.environ.get("EV2G_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(path):
         raise EngineError(-2, f"{path} not found: build it with `python -m ev2gym_amd.build` "
                               "(hipcc --offload-arch=gfx950); the step engine has no CPU fallback")
@@ -216,7 +224,8 @@ class Engine:
                  port_required_energy=f8(P), port_prev_power=f8(P), port_cycles=i4(P), port_session=i4(P),
                  cs_power=f8(Cn), cs_amps=f8(Cn), cs_profits=f8(Cn), cs_energy_charged=f8(Cn),
                  cs_energy_discharged=f8(Cn), tr_power=f8(R), tr_overload=f8(R, T), power_usage=f8(T),
-                 power_potential=f8(T), session_port=i4(max(S, 1)), session_afap=f8(max(S, 1)))
+                 power_potential=f8(T), session_port=i4(max(S, 1)), session_afap=f8(max(S, 1)),
+                 session_final_cap=f8(max(S, 1)))
         v = _abi.EnvViewC()
         for k, a in d.items():
             ct = C.c_double if a.dtype == np.float64 else C.c_int32
@@ -224,6 +233,7 @@ class Engine:
         self._check(self._lib.ev2g_peek(self._h, int(env), C.byref(v)))
         d["session_port"] = d["session_port"][:S]
         d["session_afap"] = d["session_afap"][:S]
+        d["session_final_cap"] = d["session_final_cap"][:S]
         d["current_step"] = int(v.current_step)
         return d
 

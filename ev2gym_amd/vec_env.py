@@ -1,0 +1,209 @@
+"""EV2GymVec: thousands of EV2Gym envs advanced per call by the HIP engine.
+
+Keeps the reference's surface (ev2gym/models/ev2gym_env.py: constructor kwargs :38-56, `reset()` :243-331,
+`step(actions)` :333-447, `set_reward_function/set_cost_function`), batched over a leading env axis:
+
+    env = EV2GymVec(config_file="V2GProfitPlusLoads.yaml", num_envs=4096, device=0,
+                    state_function=V2G_profit_max_loads, reward_function=ProfitMax_TrPenalty_UserIncentives)
+    obs, _ = env.reset()                       # [E, D]
+    obs, reward, done, truncated, info = env.step(actions)   # actions [E, P] in [-1, 1]
+
+Arrays are torch CUDA tensors when torch sees the GPU (zero-copy: the engine writes through `data_ptr()` on
+torch's current stream -- the SB3 path), otherwise engine-owned device buffers mirrored to numpy.
+Only the fused built-in state / reward functions run here; arbitrary Python callables need the single-env
+facade (`ev2gym_amd.env.EV2Gym`), which says so instead of silently falling back.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from . import _abi
+from .config import gen_config_from_yaml, load_yaml
+from .engine import Engine, EngineError
+from .scenario import ScenarioBatch
+from .scenario_gen import GenConfig, generate
+
+
+class Box:
+    """Minimal stand-in for gymnasium.spaces.Box (gymnasium is optional)."""
+
+    def __init__(self, low, high, shape, dtype=np.float64):
+        self.low = np.full(shape, low, dtype) if np.isscalar(low) else np.asarray(low, dtype)
+        self.high = np.full(shape, high, dtype) if np.isscalar(high) else np.asarray(high, dtype)
+        self.shape = tuple(shape)
+        self.dtype = np.dtype(dtype)
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+
+def _kind(fn, table, what):
+    """Resolve a state/reward plugin to a fused kernel id (by marker attribute, then by name)."""
+    if fn is None:
+        return None
+    if isinstance(fn, str):
+        if fn in table:
+            return table[fn]
+        raise ValueError(f"unknown {what} '{fn}'")
+    k = getattr(fn, "_ev2g_kind", None)
+    if k is not None:
+        return int(k)
+    name = getattr(fn, "__name__", "")
+    if name in table and getattr(fn, "__module__", "").startswith("ev2gym"):
+        return table[name]   # the reference's own built-in of that name
+    return None
+
+
+class EV2GymVec:
+    def __init__(self, config_file=None, num_envs: int = 1, device: int = 0, state_function="PublicPST",
+                 reward_function="SquaredTrackingErrorReward", cost_function=None, seed: Optional[int] = None,
+                 scenarios: Optional[ScenarioBatch] = None, auto_reset: bool = False, log_cs_history: bool = False,
+                 use_torch: Optional[bool] = None, rank: int = 0, world_size: int = 1, verbose: bool = False, **unused):
+        self.state_kind = _kind(state_function, _abi.STATE_KINDS, "state_function")
+        self.reward_kind = _kind(reward_function, _abi.REWARD_KINDS, "reward_function")
+        if self.state_kind is None or self.reward_kind is None:
+            raise NotImplementedError(
+                "EV2GymVec fuses only the built-in state/reward functions "
+                f"({sorted(_abi.STATE_KINDS)} / {sorted(_abi.REWARD_KINDS)}); "
+                "user-defined callables run through the single-env facade ev2gym_amd.env.EV2Gym")
+        if cost_function is not None:
+            raise NotImplementedError("cost_function is evaluated by the single-env facade only")
+        self.seed = 0 if seed is None else int(seed)
+        if scenarios is None:
+            if config_file is None:
+                raise AssertionError("Please provide a config file!!!")   # ev2gym_env.py:64
+            self.config = load_yaml(config_file)
+            total = int(num_envs) * int(world_size)
+            gen = gen_config_from_yaml(self.config, total, self.seed)
+            full = generate(gen)
+            scenarios = full.shard(rank, world_size) if world_size > 1 else full
+        else:
+            self.config = None
+        self.scenarios = scenarios
+        self.rank, self.world_size = rank, world_size
+        if use_torch is None:
+            try:
+                import torch
+                use_torch = torch.cuda.is_available()
+            except Exception:
+                use_torch = False
+        self._torch = None
+        stream = None
+        if use_torch:
+            import torch
+            self._torch = torch
+            torch.cuda.set_device(device)
+            stream = torch.cuda.current_stream(device).cuda_stream or None
+        flags = _abi.FLAG_LOG_CS_HISTORY if log_cs_history else 0
+        if use_torch and stream is None:
+            flags |= _abi.FLAG_NULL_STREAM   # torch's current stream is the default stream: share it
+        self.engine = Engine(scenarios, self.reward_kind, self.state_kind, device=device, flags=flags, stream=stream)
+        e = self.engine
+        self.num_envs, self.number_of_ports, self.obs_dim = e.E, e.P, e.D
+        self.simulation_length = e.T
+        self.v2g_enabled = scenarios.v2g_enabled
+        self.auto_reset = auto_reset
+        self.device = device
+        low = -1.0 if self.v2g_enabled else 0.0
+        self.action_space = Box(low, 1.0, (self.number_of_ports,))           # ev2gym_env.py:226-231
+        self.observation_space = Box(-np.inf, np.inf, (self.obs_dim,))       # ev2gym_env.py:234-238
+        self._obs = self._alloc((e.E, e.D))
+        self._rew = self._alloc((e.E,))
+        self._done = self._alloc((e.E,), np.uint8)
+        self._mask = self._alloc((e.E, e.P), np.uint8)
+        self._act = self._alloc((e.E, e.P))
+        self.stats = None
+        self.reset()
+
+    # ---- buffers ---------------------------------------------------------------------------------
+    def _alloc(self, shape, dtype=np.float64):
+        if self._torch is not None:
+            t = self._torch
+            td = {np.dtype(np.float64): t.float64, np.dtype(np.uint8): t.uint8}[np.dtype(dtype)]
+            return t.empty(shape, dtype=td, device=f"cuda:{self.device}")
+        return self.engine.empty(shape, dtype)
+
+    def _out(self, buf):
+        return buf if self._torch is not None else buf.to_host()
+
+    def full_like_actions(self, value: float):
+        if self._torch is not None:
+            return self._torch.full((self.num_envs, self.number_of_ports), float(value), dtype=self._torch.float64,
+                                    device=f"cuda:{self.device}")
+        return np.full((self.num_envs, self.number_of_ports), float(value))
+
+    def uniform_actions(self, seed: int, low: float, high: float):
+        """Device-side uniform actions (counter-based, reproducible on the host with engine.host_uniform)."""
+        self.engine.fill_uniform(self._act, self.num_envs * self.number_of_ports, seed, low, high)
+        return self._act
+
+    # ---- gym surface -------------------------------------------------------------------------------
+    @property
+    def current_step(self) -> int:
+        return self.engine.current_step
+
+    def reset(self, seed=None, options=None, **kwargs):
+        """Re-arms every env on its scenario (state-init part of EV2Gym.reset, ev2gym_env.py:298-331)."""
+        self.engine.reset(self._obs)
+        self.stats = None
+        return self._out(self._obs), {}
+
+    def _as_device_actions(self, actions):
+        if self._torch is not None and self._torch.is_tensor(actions):
+            a = actions
+            if a.dtype != self._torch.float64 or not a.is_cuda or not a.is_contiguous():
+                a = a.to(device=f"cuda:{self.device}", dtype=self._torch.float64).contiguous()  # widened on entry
+            assert tuple(a.shape) == (self.num_envs, self.number_of_ports)
+            return a
+        if actions is self._act:
+            return actions
+        a = np.ascontiguousarray(actions, np.float64)   # contract: actions are widened to float64 on entry
+        assert a.shape == (self.num_envs, self.number_of_ports), a.shape
+        if self._torch is not None:
+            self._act.copy_(self._torch.from_numpy(a))
+        else:
+            self._act.upload(a)
+        return self._act
+
+    def step(self, actions):
+        if self.engine.current_step >= self.simulation_length:
+            raise AssertionError("Episode is done, please reset the environment")   # ev2gym_env.py:343
+        a = self._as_device_actions(actions)
+        self.engine.step(a, self._obs, self._rew, self._done, self._mask)
+        info = {"action_mask": self._out(self._mask), "cost": None}
+        finished = self.engine.current_step >= self.simulation_length
+        if finished:
+            self.engine.check_faults()
+            self.stats = self.get_statistics()
+            info.update(self.stats)
+            if self.auto_reset:
+                info["terminal_observation"] = self._out(self._obs).clone() if self._torch is not None else self._out(self._obs)
+                rew, done = self._out(self._rew), self._out(self._done)
+                if self._torch is not None:
+                    rew, done = rew.clone(), done.clone()
+                self.engine.reset(self._obs)
+                return self._out(self._obs), rew, done, self._false(), info
+        return self._out(self._obs), self._out(self._rew), self._out(self._done), self._false(), info
+
+    def _false(self):
+        if self._torch is not None:
+            return self._torch.zeros(self.num_envs, dtype=self._torch.bool, device=f"cuda:{self.device}")
+        return np.zeros(self.num_envs, bool)
+
+    def get_statistics(self) -> dict:
+        """Per-env episode statistics, keys of get_statistics() (utilities/utils.py:84-101), each an [E] array."""
+        st = self.engine.stats()
+        return {k: st[:, i] for i, k in enumerate(_abi.STAT_NAMES)}
+
+    def get_statistics_all_ranks(self):
+        """[world*E, 17] statistics of every rank (one RCCL all-gather per episode)."""
+        from .dist import gather_stats
+        return gather_stats(self)
+
+    def set_reward_function(self, reward_function):
+        raise NotImplementedError("the fused reward is chosen at construction (it selects the kernel specialisation)")
+
+    def close(self):
+        self.engine.close()

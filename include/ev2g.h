@@ -51,6 +51,7 @@ extern "C" {
 
 /* flags for ev2g_config.flags */
 #define EV2G_FLAG_LOG_CS_HISTORY 1 /* keep cs_power / cs_current [E,C,T] (ev2gym_env.py:533-535) */
+#define EV2G_FLAG_NULL_STREAM 2    /* launch on the legacy default stream (torch's default stream) */
 
 typedef struct ev2g_handle ev2g_handle;
 
@@ -59,7 +60,8 @@ typedef struct ev2g_config {
     int32_t reward_kind; /* EV2G_REWARD_*  -- replaces the `reward_function` ctor kwarg (:47)    */
     int32_t state_kind;  /* EV2G_STATE_*   -- replaces the `state_function` ctor kwarg (:46)     */
     int32_t flags;       /* EV2G_FLAG_*                                                          */
-    void *stream;        /* hipStream_t to launch on; NULL = a stream owned by the handle        */
+    void *stream;        /* hipStream_t to launch on; NULL = a stream owned by the handle (or the
+                            default stream with EV2G_FLAG_NULL_STREAM)                          */
 } ev2g_config;
 
 /*
@@ -218,6 +220,7 @@ typedef struct ev2g_env_view {
     double *power_potential;      /* [T] env.charge_power_potential         */
     int32_t *session_port;        /* [S_env] resolved port of every session */
     double *session_afap;         /* [S_env] EV.max_energy_AFAP             */
+    double *session_final_cap;    /* [S_env] capacity at departure (NaN while not departed) */
 } ev2g_env_view;
 int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *view);
 

@@ -1,0 +1,121 @@
+"""The reference's Python surface on top of the HIP engine: single-env facade (object graph, fused and host-side
+plugins), vectorised env, heuristics.  Checked against the reference goldens and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, load_golden
+
+pytestmark = pytest.mark.gpu
+CFG = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "ev2gym_amd", "example_config_files")
+
+
+def _close(a, b, what, tol=1e-9):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    assert err.max(initial=0.0) <= tol, f"{what}: {err.max():.3e}"
+
+
+@pytest.mark.parametrize("name", ["v2gppl_rand_s2", "pst_rand_s2", "v2gmax_het_rand_s3", "v2gppl_p2_rand_s11",
+                                  "v2gppl_c10r3_mixed_s14"])
+@pytest.mark.parametrize("host_plugins", [False, True], ids=["fused", "host_plugins"])
+def test_facade_reproduces_reference_episode(name, host_plugins):
+    """EV2Gym facade == reference trajectory, with the plugins fused in the kernel and evaluated on the host."""
+    from ev2gym_amd.env import EV2Gym
+    from ev2gym_amd.rl_agent import reward as R, state as S
+    z, batch, rk, sk = load_golden(os.path.join(GOLDEN_DIR, name + ".npz"))
+    sf = getattr(S, str(z["case"][2]))
+    rf = getattr(R, str(z["case"][3]))
+    if host_plugins:   # strip the fusion marker: these become "user-defined" callables evaluated through the facade
+        sf0, rf0 = sf, rf
+        sf = lambda env, *a: sf0(env, *a)  # noqa: E731
+        rf = lambda env, *a: rf0(env, *a)  # noqa: E731
+    env = EV2Gym(scenario=batch, state_function=sf, reward_function=rf)
+    obs, _ = env.reset()
+    _close(obs, z["trj_obs"][0], "reset obs")
+    for t in range(len(z["act"])):
+        a = z["act"][t].copy()
+        obs, rew, done, trunc, info = env.step(a)
+        assert (a == z["trj_act_after"][t]).all(), "empty-port actions are zeroed in the caller's array"
+        _close(obs, z["trj_obs"][t + 1], f"obs[{t}]")
+        _close(rew, z["trj_reward"][t], f"reward[{t}]")
+        assert done == bool(z["trj_done"][t]) and trunc is False
+        assert (info["action_mask"] == z["trj_mask"][t]).all()
+        assert len(env.departing_evs) == z["trj_n_departed"][t]
+    assert done
+    for k in ("total_ev_served", "total_profits", "total_energy_charged", "total_transformer_overload", "total_reward"):
+        g = z["trj_stats"][__import__("ev2gym_amd")._abi.STAT_NAMES.index(k)]
+        _close(info[k], g, k)
+    with pytest.raises(AssertionError):
+        env.step(z["act"][0].copy())
+    env.close()
+
+
+def test_facade_object_graph_and_heuristics():
+    from ev2gym_amd.baselines.heuristics import ChargeAsFastAsPossible
+    from ev2gym_amd.env import EV2Gym
+    z, batch, rk, sk = load_golden(os.path.join(GOLDEN_DIR, "v2gppl_ones_s1.npz"))
+    env = EV2Gym(scenario=batch, state_function="V2G_profit_max_loads", reward_function="ProfitMax_TrPenalty_UserIncentives")
+    agent = ChargeAsFastAsPossible()
+    for t in range(40):
+        obs, rew, done, _, info = env.step(agent.get_action(env))
+        _close(rew, z["trj_reward"][t], f"reward[{t}]")
+        for i, cs in enumerate(env.charging_stations):
+            for j, ev in enumerate(cs.evs_connected):
+                p = i * cs.n_ports + j
+                if ev is None:
+                    assert np.isnan(z["trj_cap"][t, p])
+                else:
+                    _close(ev.current_capacity, z["trj_cap"][t, p], "ev.current_capacity")
+                    _close(ev.get_soc() * ev.battery_capacity, z["trj_cap"][t, p], "soc")
+                    _close(ev.required_energy, z["trj_req_e"][t, p], "required_energy", 1e-9)
+            _close(cs.current_power_output, z["trj_cs_power"][t, i], "cs power")
+        _close(env.transformers[0].current_power, z["trj_tr_power"][t, 0], "tr power")
+        _close(env.current_power_usage[t], z["trj_usage"][t], "usage")
+    env.close()
+
+
+@pytest.mark.parametrize("use_torch", [True, False], ids=["torch_tensors", "ctypes_buffers"])
+@pytest.mark.parametrize("cfg,sf,rf", [("V2GProfitPlusLoads.yaml", "V2G_profit_max_loads", "ProfitMax_TrPenalty_UserIncentives"),
+                                       ("PublicPST.yaml", "PublicPST", "SquaredTrackingErrorReward")])
+def test_vec_env_from_yaml_matches_oracle(cfg, sf, rf, use_torch):
+    from ev2gym_amd import _abi
+    from ev2gym_amd.baselines.heuristics import RandomAgent
+    from ev2gym_amd.engine import host_uniform
+    from ev2gym_amd.vec_env import EV2GymVec
+    from oracle.oracle import Oracle
+    env = EV2GymVec(config_file=os.path.join(CFG, cfg), num_envs=96, state_function=sf, reward_function=rf, seed=3,
+                    auto_reset=True, use_torch=use_torch)
+    ora = Oracle(env.scenarios, _abi.REWARD_KINDS[rf], _abi.STATE_KINDS[sf])
+    obs, _ = env.reset()
+    to_np = lambda x: x.cpu().numpy() if hasattr(x, "cpu") else (x.to_host() if hasattr(x, "to_host") else np.asarray(x))  # noqa: E731
+    _close(to_np(obs), ora.reset(), "reset obs")
+    agent = RandomAgent(seed=5)
+    E, P, T = env.num_envs, env.number_of_ports, env.simulation_length
+    lo = -1.0 if env.v2g_enabled else 0.0
+    for t in range(T):
+        a = agent.get_action(env)
+        a_host = host_uniform(E * P, 5 * 1000003 + t + 1, lo, 1.0).reshape(E, P)
+        assert np.array_equal(to_np(a), a_host)
+        obs, rew, done, trunc, info = env.step(a)
+        o_obs, o_rew, o_done, o_mask, rc = ora.step(a_host)
+        _close(to_np(rew), o_rew, f"reward[{t}]")
+        assert np.array_equal(to_np(done), o_done)
+        assert np.array_equal(to_np(info["action_mask"]), o_mask)
+        if t < T - 1:
+            _close(to_np(obs), o_obs, f"obs[{t}]")
+    # auto_reset: the terminal step returns the reset observation, the terminal one rides in info, stats are per env
+    _close(to_np(info["terminal_observation"]), o_obs, "terminal obs")
+    st = ora.stats()
+    _close(to_np(obs), ora.reset(), "obs after auto-reset")
+    _close(info["total_profits"], st[:, 1], "total_profits")
+    _close(info["total_reward"], st[:, 16], "total_reward")
+    assert env.current_step == 0
+    env.close()
+
+
+def test_vec_env_rejects_unfused_plugins():
+    from ev2gym_amd.vec_env import EV2GymVec
+    with pytest.raises(NotImplementedError):
+        EV2GymVec(config_file=os.path.join(CFG, "PublicPST.yaml"), num_envs=4, state_function=lambda env: None)
