@@ -46,6 +46,19 @@ WORKLOADS = {
 }
 
 
+def measured_traffic(workload, launch, steps_per_launch, envs):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes (profiles/r01_hbm_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH doubled per the gfx950 note in
+    MI355X_MICROARCH.md), or None when this workload / launch shape was not profiled."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))[workload][launch]
+    except Exception:
+        return None
+    if abs(t["steps_per_launch"] - steps_per_launch) > 1e-9 or envs != WORKLOADS[workload]["envs"]:
+        return None
+    return (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
+
+
 def cpu_baseline(batch, rk, sk, lo, budget_s=12.0):
     """The C oracle (a scalar port of the reference step(), oracle/ev2g_oracle.c) timed on this box's host
     cores, single thread, on whole episodes of a prefix of the same env batch."""
@@ -194,8 +207,9 @@ def main():
         "wall_s_by_launch_mode": {m: round(w, 6) for m, w in wall.items()},
         "env_steps_per_s_by_launch_mode": {m: env_steps_total / w for m, w in wall.items()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "ev2g_step_kernel", "avg_launch_us": launch_s * 1e6,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.workload, best, kern_steps / n_launch, E),
+                     "kernel": f"ev2g_step_v2<{256 if P <= 256 else 512 if P <= 512 else 1024}>" if P <= 1024 else "ev2g_step_kernel",
+                     "avg_launch_us": launch_s * 1e6,
                      "steps_per_launch": kern_steps / n_launch,
                      "algorithmic_bytes_per_env_step": bytes_env_step},
     }

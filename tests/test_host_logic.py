@@ -1,0 +1,121 @@
+"""Host-side logic that needs no GPU: scenario batches, the vectorised generator, YAML mapping."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_FILES, ROOT, load_golden
+from ev2gym_amd import _abi
+from ev2gym_amd.config import gen_config_from_yaml
+from ev2gym_amd.scenario import ScenarioBatch, resolve_ports
+from ev2gym_amd.scenario_gen import GenConfig, generate, occupancy_fraction
+
+CFG = os.path.join(ROOT, "ev2gym_amd", "example_config_files")
+
+
+def _same_25cs():
+    out = []
+    for f in GOLDEN_FILES:
+        if os.path.basename(f).startswith("v2gppl_") and "_s" in f:
+            z, b, rk, sk = load_golden(f)
+            if b.n_chargers == 25 and b.ports_per_charger == 1 and b.arrays["cs_min_charge_current"][0] == 0:
+                out.append(b)
+    return out
+
+
+def test_concat_select_roundtrip_and_lut_dedup():
+    bs = _same_25cs()
+    assert len(bs) >= 4
+    cat = ScenarioBatch.concat(bs)
+    assert cat.n_envs == len(bs) and cat.n_sessions == sum(b.n_sessions for b in bs)
+    assert cat.n_lut <= 8   # identical efficiency tables are shared
+    for i, b in enumerate(bs):
+        one = cat.select([i])
+        for k in ("ev_t_arr", "ev_t_dep", "ev_cap0", "ev_B", "ev_ts", "charge_price", "tr_max_power"):
+            assert np.array_equal(np.asarray(one.arrays[k]).reshape(-1), np.asarray(b.arrays[k]).reshape(-1)), k
+        lut_a = one.arrays["lut"][np.maximum(one.arrays["ev_lut"], 0)]
+        lut_b = b.arrays["lut"][np.maximum(b.arrays["ev_lut"], 0)]
+        assert np.array_equal(lut_a, lut_b)
+
+
+def test_shards_partition_the_batch():
+    cat = ScenarioBatch.concat(_same_25cs()).tile(11)
+    parts = [cat.shard(r, 3) for r in range(3)]
+    assert sum(p.n_envs for p in parts) == 11
+    again = ScenarioBatch.concat(parts)
+    for k in ("ev_t_arr", "ev_cap0", "env_session_start", "charge_price", "tr_dr"):
+        assert np.array_equal(again.arrays[k], cat.arrays[k]), k
+
+
+def test_save_load(tmp_path):
+    b = generate(GenConfig.public_pst(5, 7, seed=4))
+    p = str(tmp_path / "b.npz")
+    b.save(p)
+    c = ScenarioBatch.load(p)
+    for k, v in b.arrays.items():
+        assert np.array_equal(v, c.arrays[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("cfg", [GenConfig.v2g_profit_plus_loads(64, 50, seed=1), GenConfig.public_pst(64, 20, seed=2),
+                                 GenConfig.v2g_profit_plus_loads(8, 12, 3, seed=3, number_of_ports_per_cs=2),
+                                 GenConfig.v2g_profit_plus_loads(3, 200, 10, seed=5, heterogeneous_ev_specs=False)])
+def test_generator_respects_the_spawner_rules(cfg):
+    b = generate(cfg)
+    a = b.arrays
+    T = b.n_steps
+    assert (a["ev_t_arr"] >= 3).all() and (a["ev_t_dep"] > a["ev_t_arr"]).all()
+    assert (a["ev_t_dep"] + 1 < T).all(), "empty_ports_at_end_of_simulation (utils.py:254-256)"
+    assert (a["ev_cap0"] > 0).all() and (a["ev_cap0"] <= a["ev_B"]).all()
+    assert (a["charge_price"] <= 0).all() and (a["discharge_price"] >= 0).all()
+    st = a["env_session_start"]
+    for e in range(b.n_envs):   # arrival order inside every env
+        assert (np.diff(a["ev_t_arr"][st[e]:st[e + 1]]) >= 0).all()
+    ports = resolve_ports(b)     # first-free replay never runs out of ports
+    assert (ports >= 0).all()
+    # a port is never double booked
+    for e in range(min(b.n_envs, 8)):
+        sl = slice(st[e], st[e + 1])
+        for p in np.unique(ports[sl]):
+            m = ports[sl] == p
+            ta, td = a["ev_t_arr"][sl][m], a["ev_t_dep"][sl][m]
+            assert (ta[1:] > td[:-1]).all()
+    phi = occupancy_fraction(b)
+    assert 0.05 < phi < 0.5
+    if cfg.demand_response:
+        assert (a["tr_n_dr"] == 1).all()
+        assert (a["tr_max_power"].min(axis=2) < cfg.transformer_max_power).any()
+    if cfg.power_setpoint_enabled:
+        assert a["power_setpoints"].max() > 0
+
+
+def test_generator_is_deterministic_and_seeded():
+    a = generate(GenConfig.v2g_profit_plus_loads(16, 10, seed=7))
+    b = generate(GenConfig.v2g_profit_plus_loads(16, 10, seed=7))
+    c = generate(GenConfig.v2g_profit_plus_loads(16, 10, seed=8))
+    assert all(np.array_equal(a.arrays[k], b.arrays[k], equal_nan=True) for k in a.arrays)
+    assert not np.array_equal(a.arrays["ev_cap0"], c.arrays["ev_cap0"])
+
+
+@pytest.mark.parametrize("name,P,R,v2g,setp", [("V2GProfitPlusLoads.yaml", 25, 1, True, False), ("PublicPST.yaml", 20, 1, False, True),
+                                               ("V2GProfitPlusLoads_50cs.yaml", 50, 1, True, False),
+                                               ("V2GProfitPlusLoads_1000cs_50tr.yaml", 1000, 50, True, False)])
+def test_yaml_schema_maps_onto_the_generator(name, P, R, v2g, setp):
+    g = gen_config_from_yaml(os.path.join(CFG, name), 2, seed=1)
+    b = generate(g)
+    assert (b.n_ports, b.n_transformers, b.v2g_enabled) == (P, R, v2g)
+    assert (b.arrays["power_setpoints"].max() > 0) == setp
+    assert b.obs_dim(_abi.STATE_KINDS["V2G_profit_max_loads"]) == 22 + 40 * R + 2 * P
+    assert b.obs_dim(_abi.STATE_KINDS["PublicPST"]) == 3 + 3 * P
+    if R > 1:   # round-robin charger -> transformer map (loaders.py:494-498)
+        assert np.array_equal(b.arrays["cs_transformer"], np.arange(P) % R)
+
+
+def test_plugin_resolution():
+    from ev2gym_amd.rl_agent import reward as R, state as S
+    from ev2gym_amd.vec_env import _kind
+    assert _kind(S.PublicPST, _abi.STATE_KINDS, "s") == 1 and _kind("V2G_profit_max_loads", _abi.STATE_KINDS, "s") == 0
+    assert _kind(R.profit_maximization, _abi.REWARD_KINDS, "r") == 2
+    assert _kind(R.SimpleReward, _abi.REWARD_KINDS, "r") is None          # host-evaluated plugin
+    assert _kind(lambda env: 0.0, _abi.REWARD_KINDS, "r") is None
+    with pytest.raises(ValueError):
+        _kind("NoSuchReward", _abi.REWARD_KINDS, "r")
