@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
     ap.add_argument("--launch", default="auto", choices=["auto", "per_step", "persistent"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-soc-log", action="store_true", help="skip the SoC log that the battery-degradation statistics need")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -126,7 +127,8 @@ def main():
     # engine kernels, torch allocations and the RCCL gather all run on ONE explicit (non-default) stream
     tstream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(tstream)
-    eng = Engine(batch, rk, sk, device=local_rank, stream=tstream.cuda_stream)
+    eng = Engine(batch, rk, sk, device=local_rank, stream=tstream.cuda_stream,
+                 flags=0 if args.no_soc_log else _abi.FLAG_LOG_SOC)
     P, D, T = eng.P, eng.D, eng.T
     dev = torch.device("cuda", local_rank)
     acts = torch.empty((T, E, P), dtype=torch.float64, device=dev)
@@ -201,7 +203,7 @@ def main():
         "ms_per_step": wall[best] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": E, "chargers": C_,
-                   "transformers": R_, "steps_per_episode": T, "obs_dim": D, "occupancy_phi": round(phi, 4),
+                   "transformers": R_, "steps_per_episode": T, "obs_dim": D, "occupancy_phi": round(phi, 4), "soc_log": not args.no_soc_log,
                    "launch": best, "parallelism": f"env-sharded x{world}, RCCL all_gather of episode stats only"},
         "port_steps_per_s": value * P,
         "wall_s_by_launch_mode": {m: round(w, 6) for m, w in wall.items()},

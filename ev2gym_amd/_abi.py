@@ -27,6 +27,7 @@ ERR_DONE = -4
 ERR_OVERCURRENT = -5
 FLAG_LOG_CS_HISTORY = 1
 FLAG_NULL_STREAM = 2
+FLAG_LOG_SOC = 4
 
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int32)

@@ -83,6 +83,9 @@ struct DevState {  // mutable engine state, device pointers
     double *over_hist;                 // [T,E,R] env.tr_overload
     double *tr_power_now;              // [E,R]  Transformer.current_power of the last step
     double *sess_final_cap;            // [S] capacity at departure
+    double *soc_log;                   // [T,E*P] (EV2G_FLAG_LOG_SOC) capacity before each EV.step, negated when the step was inactive
+    double *abs_e;                     // [E*P]  (flag) EV.abs_total_energy_exchanged of the attached session
+    double *sess_abs_e;                // [S]    (flag) the same, frozen at departure
     double *port_energy, *port_current;  // [E*P] EV.current_energy / actual_current of the last step
     unsigned long long *dbg;             // [n_groups*8] phase timing (EV2G_PHASE_TIMING builds only), else nullptr
 };
@@ -402,6 +405,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 ss = sc.x;
                 cap = st.cap[g];
                 tot_e = st.tot_e[g];
+                const double cap_before = cap;
                 if (x != 0.0) {
                     double amps;
                     const int ph = s.cs_ph[cs];
@@ -430,6 +434,10 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 }
                 st.port_energy[g] = energy;
                 st.port_current[g] = current;
+                if (st.soc_log) {  // historic_soc / active_steps (ev.py:156,162,185) and abs_total_energy_exchanged (:180)
+                    st.soc_log[(long long)t * s.E * P + g] = (current != 0.0) ? cap_before : -cap_before;
+                    if (energy != 0.0) st.abs_e[g] += fabs(energy);
+                }
                 // departure (ev_charger.py:209-229, ev.py:191-214)
                 if (t >= w.y) {
                     const double des = s.ss_des[ss];
@@ -444,6 +452,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                         atomicAdd(&st.cs_sat_sum[gc], score);
                     }
                     st.sess_final_cap[ss] = cap;
+                    if (st.soc_log) st.sess_abs_e[ss] = st.abs_e[g];
                     w = make_int2(s.ss_ntarr[ss], s.ss_ntdep[ss]);
                     ss = (w.x != EV2G_INT_MAX) ? ss + 1 : -1;
                     st.win[g] = w;
@@ -459,6 +468,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 st.cap[g] = cap;
                 st.tot_e[g] = 0.0;
                 st.prev_power[g] = 0.0;
+                if (st.soc_log) st.abs_e[g] = 0.0;
                 st.port_energy[g] = 0.0;
                 st.port_current[g] = 0.0;
             }
@@ -667,88 +677,143 @@ __global__ void ev2g_fill_uniform_kernel(double *dst, long long n, uint64_t seed
         dst[i] = lo + (hi - lo) * ev2g_u01(seed, (uint64_t)i);
 }
 
-// episode statistics (get_statistics utils.py:12-123) -- one thread per env
-__global__ void ev2g_stats_kernel(DevScn s, DevState st, const long long *__restrict__ env_sess /*[E+1] device order*/,
-                                  const double *__restrict__ ss_afap, int cur_step, double *__restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+// episode statistics (get_statistics utils.py:12-123) -- one wavefront per env, lanes strided over chargers / steps /
+// ports; partial sums are combined with fixed xor-butterflies (bit-reproducible).
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+    for (int d = 32; d > 0; d >>= 1) v = fmin(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+// sessions [first, last) of port g have been spawned; `attached`: the last of them is still on the port
+__device__ __forceinline__ void port_sessions(const DevScn &s, const DevState &st, long long g, int cur_step, int &first,
+                                              int &last, bool &attached) {
+    first = s.port_first[g];
+    last = first;
+    attached = false;
+    if (first < 0) return;
+    const int2 w = st.win[g];
+    const int cur = st.sc[g].x;  // attached-or-next session, -1 when the port's list is exhausted
+    if (cur < 0) {
+        while (s.ss_ntarr[last] != EV2G_INT_MAX) last++;
+        last += 1;
+    } else {
+        attached = (w.x <= cur_step);  // spawned at the end of step t_arr-1
+        last = attached ? cur + 1 : cur;
+    }
+}
+
+__global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, const long long *__restrict__ unused,
+                                                        const double *__restrict__ ss_afap, int cur_step,
+                                                        double *__restrict__ out) {
+    const int e = blockIdx.x, lane = threadIdx.x;
     if (e >= s.E) return;
     const int T = s.T, C = s.C, R = s.R, P = s.P;
-    double served = 0.0, sat = 0.0;
-    int nsat = 0;
-    for (int c = 0; c < C; c++) {
+    double served = 0.0, sat = 0.0, nsat = 0.0;
+    for (int c = lane; c < C; c += 64) {
         const int n = st.cs_served[(long long)e * C + c];
         served += n;
-        if (n > 0) { sat += st.cs_sat_sum[(long long)e * C + c] / n; nsat++; }
+        if (n > 0) { sat += st.cs_sat_sum[(long long)e * C + c] / n; nsat += 1.0; }
     }
-    double over = 0.0;
-    for (int t = 0; t < T; t++)
+    served = wave_sum(served); sat = wave_sum(sat); nsat = wave_sum(nsat);
+    double over = 0.0, te = 0.0, ete = 0.0, ptv = 0.0;
+    for (int t = lane; t < T; t += 64) {
         for (int r = 0; r < R; r++) over += st.over_hist[((long long)t * s.E + e) * R + r];
-    double te = 0.0, ete = 0.0, ptv = 0.0;
-    for (int t = 0; t < T; t++) {
         const double sp = s.setpoint[(long long)e * T + t], u = st.usage_hist[(long long)t * s.E + e];
         const double d = sp - u;
         te += d * d;
         ete += fabs(d);
         if (u > sp) ptv += u - sp;
     }
+    over = wave_sum(over); te = wave_sum(te); ete = wave_sum(ete); ptv = wave_sum(ptv);
     ete *= (double)s.dt / 60.0;
-    // energy user satisfaction over every spawned session (utils.py:57-63): e_actual / max_energy_AFAP * 100
-    double sum = 0.0, mn = INFINITY;
-    int n = 0;
-    for (int q = 0; q < P; q++) {
+    // energy user satisfaction (utils.py:57-63) and battery degradation (ev.py:442-521) over every spawned session
+    const double e0 = 7.543e6, e1 = 23.75e6, e2 = 6976, z0 = 7.348e-3, z1 = 3.667, z2 = 7.6e-4, z3 = 4.081e-3;
+    const double b_cap_ah = 2.05, b_cap_kwh = 78, d_dist = 15000, b_age = 2 * 365, G_ = 0.186;
+    const double theta = 298.15, kk = 0.8263, v_min = 3.3324;
+    const long long EP = (long long)s.E * P;
+    const bool log_soc = st.soc_log != nullptr;
+    double sum = 0.0, mn = INFINITY, cnt = 0.0, deg_cal = 0.0, deg_cyc = 0.0;
+    for (int q = lane; q < P; q += 64) {
         const long long g = (long long)e * P + q;
-        const int first = s.port_first[g];
-        if (first < 0) continue;
-        const int2 w = st.win[g];
-        int cur = st.sc[g].x;  // attached-or-next session, -1 when the port's list is exhausted
-        int last;              // sessions [first, last) have been spawned
-        bool attached = false;
-        if (cur < 0) {
-            // exhausted: every session of the port was spawned; find the end by walking the chain
-            last = first;
-            while (s.ss_ntarr[last] != EV2G_INT_MAX) last++;
-            last += 1;
-        } else {
-            attached = (w.x <= cur_step);  // spawned at the end of step t_arr-1 => present once current_step >= t_arr
-            last = attached ? cur + 1 : cur;
-        }
+        int first, last;
+        bool attached;
+        port_sessions(s, st, g, cur_step, first, last, attached);
         for (int k = first; k < last; k++) {
-            const double capk = (attached && k == last - 1) ? st.cap[g] : st.sess_final_cap[k];
+            const bool live = attached && k == last - 1;
+            const double capk = live ? st.cap[g] : st.sess_final_cap[k];
             const double v = capk / ss_afap[k] * 100.0;
             sum += v;
-            if (v < mn) mn = v;
-            n++;
+            mn = fmin(mn, v);
+            cnt += 1.0;
+            if (log_soc) {
+                const double B = s.ss_B[k];
+                const int ta = s.ss_tarr[k], td = s.ss_tdep[k];
+                const int tend = min(td, cur_step - 1);
+                const double soc_f = capk / B;
+                double hs = 0.0, fs = 0.0;
+                int n = 0, nf = 0;
+                for (int t = ta; t <= tend; t++) {  // historic_soc / active_steps (sign bit set = inactive step)
+                    const double x = st.soc_log[(long long)t * EP + g];
+                    const double soc = fabs(x) / B;
+                    hs += soc; n++;
+                    if (__double_as_longlong(x) >= 0) { fs += soc; nf++; }
+                }
+                hs += soc_f; n++;
+                fs += soc_f; nf++;
+                const double avg_soc = hs / n, avg_f = fs / nf;
+                double mad = 0.0;
+                for (int t = ta; t <= tend; t++) {
+                    const double x = st.soc_log[(long long)t * EP + g];
+                    if (__double_as_longlong(x) >= 0) mad += fabs(avg_f - fabs(x) / B);
+                }
+                mad += fabs(avg_f - soc_f);
+                const double delta_DoD = 2 * (mad / nf);
+                const double T_sim = (td - ta + 1) * (double)s.dt / (60 * 24);
+                const double v_avg = v_min + kk * avg_soc;
+                const double alpha = (e0 * v_avg - e1) * exp(-e2 / theta);
+                deg_cal += alpha * 0.75 * T_sim / pow(b_age, 0.25);
+                const double v_half = v_min + kk * 0.5;
+                const double beta = z0 * (v_half - z1) * (v_half - z1) + z2 + z3 * delta_DoD;
+                const double abs_e = live ? st.abs_e[g] : st.sess_abs_e[k];
+                const double Q_sim = (abs_e / b_cap_kwh) * b_cap_ah;
+                const double Q_acc = 2 * (b_age * (d_dist / 365) * G_ * b_cap_ah) / b_cap_kwh;
+                deg_cyc += beta * 0.5 * Q_sim / pow(Q_acc, 0.5);
+            }
         }
     }
+    sum = wave_sum(sum); cnt = wave_sum(cnt); mn = wave_min(mn);
+    deg_cal = wave_sum(deg_cal); deg_cyc = wave_sum(deg_cyc);
     double mean = NAN, sd = NAN, mnv = NAN;
-    if (n > 0) {
-        mean = sum / n;
+    if (cnt > 0.0) {
+        mean = sum / cnt;
         double var = 0.0;
-        for (int q = 0; q < P; q++) {
+        for (int q = lane; q < P; q += 64) {
             const long long g = (long long)e * P + q;
-            const int first = s.port_first[g];
-            if (first < 0) continue;
-            const int2 w = st.win[g];
-            int cur = st.sc[g].x, last;
-            bool attached = false;
-            if (cur < 0) { last = first; while (s.ss_ntarr[last] != EV2G_INT_MAX) last++; last += 1; }
-            else { attached = (w.x <= cur_step); last = attached ? cur + 1 : cur; }
+            int first, last;
+            bool attached;
+            port_sessions(s, st, g, cur_step, first, last, attached);
             for (int k = first; k < last; k++) {
                 const double capk = (attached && k == last - 1) ? st.cap[g] : st.sess_final_cap[k];
                 const double v = capk / ss_afap[k] * 100.0 - mean;
                 var += v * v;
             }
         }
-        sd = sqrt(var / n);
+        var = wave_sum(var);
+        sd = sqrt(var / cnt);
         mnv = mn;
     }
+    if (lane != 0) return;
     const double *acc = st.env_acc + (long long)e * 8;
     double *o = out + (long long)e * 17;
     o[0] = served;
     o[1] = acc[1];
     o[2] = acc[2];
     o[3] = acc[3];
-    o[4] = nsat ? sat / nsat : NAN;
+    o[4] = (nsat > 0.0) ? sat / nsat : NAN;
     o[5] = ptv;
     o[6] = te;
     o[7] = ete;
@@ -757,8 +822,8 @@ __global__ void ev2g_stats_kernel(DevScn s, DevState st, const long long *__rest
     o[10] = mnv;
     o[11] = acc[4];
     o[12] = over;
-    o[13] = NAN;  // battery degradation: needs the per-session SoC log (not in this round)
-    o[14] = NAN;
-    o[15] = NAN;
+    o[13] = log_soc ? deg_cal + deg_cyc : NAN;
+    o[14] = log_soc ? deg_cal : NAN;
+    o[15] = log_soc ? deg_cyc : NAN;
     o[16] = acc[0];
 }

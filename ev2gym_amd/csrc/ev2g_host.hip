@@ -485,6 +485,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     AL(env_acc, (size_t)E * 8) AL(env_fault, E)
     AL(usage_hist, (size_t)T * E) AL(pot_hist, (size_t)T * E) AL(over_hist, (size_t)T * E * R)
     AL(tr_power_now, (size_t)E * R) AL(sess_final_cap, S)
+    if (h->cfg.flags & EV2G_FLAG_LOG_SOC) { AL(soc_log, (size_t)T * EP) AL(abs_e, EP) AL(sess_abs_e, S) }
 #ifdef EV2G_PHASE_TIMING
     AL(dbg, (size_t)s.n_groups * 8)
 #endif
@@ -628,8 +629,7 @@ int ev2g_get_stats(ev2g_handle *h, double *stats) {
     if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_get_stats: no scenarios loaded");
     if (!stats) return fail(h, EV2G_ERR_ARG, "ev2g_get_stats: null output");
     (void)hipSetDevice(h->device);
-    const int nb = (h->E + 63) / 64;
-    hipLaunchKernelGGL(ev2g_stats_kernel, dim3(nb), dim3(64), 0, h->stream, h->scn, h->st, (const long long *)nullptr,
+    hipLaunchKernelGGL(ev2g_stats_kernel, dim3(h->E), dim3(64), 0, h->stream, h->scn, h->st, (const long long *)nullptr,
                        (const double *)h->d_ss_afap, h->current_step, stats);
     HIPCHK(h, hipGetLastError());
     return EV2G_OK;

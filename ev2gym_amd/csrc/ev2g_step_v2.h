@@ -137,6 +137,7 @@ struct V2P {
     EV2G_GP(double) env_acc; EV2G_GP(int) env_fault;
     EV2G_GP(double) usage_hist; EV2G_GP(double) pot_hist; EV2G_GP(double) over_hist; EV2G_GP(double) tr_power_now;
     EV2G_GP(double) sess_final_cap; EV2G_GP(double) port_energy; EV2G_GP(double) port_current;
+    EV2G_GP(double) soc_log; EV2G_GP(double) abs_e; EV2G_GP(double) sess_abs_e;
     EV2G_GP(unsigned long long) dbg;
 };
 
@@ -153,14 +154,14 @@ inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
     CPT(cap) CPT(tot_e) CPT(prev_power) CPT(bcap) CPT(potc) CPT(win) CPT(sc) CPT(cs_sat_sum) CPT(cs_served)
     CPT(cs_profits) CPT(cs_e_ch) CPT(cs_e_dis) CPT(cs_power_hist) CPT(cs_cur_hist) CPT(cs_power_now) CPT(cs_cur_now)
     CPT(env_acc) CPT(env_fault) CPT(usage_hist) CPT(pot_hist) CPT(over_hist) CPT(tr_power_now)
-    CPT(sess_final_cap) CPT(port_energy) CPT(port_current) CPT(dbg)
+    CPT(sess_final_cap) CPT(port_energy) CPT(port_current) CPT(soc_log) CPT(abs_e) CPT(sess_abs_e) CPT(dbg)
 #undef CPS
 #undef CPT
 }
 
 // LDS carve-up for ev2g_step_v2 (doubles first, then ints); NS = G*P, NT = G*R
 __host__ __device__ inline size_t ev2g_v2_lds_bytes(int NS, int NT, int G, int R) {
-    return sizeof(double) * ((size_t)(EV2G_NQ + 6) * NS + (size_t)EV2G_NQ * NT + (size_t)EV2G_NQ * G + (size_t)NT +
+    return sizeof(double) * ((size_t)(EV2G_NQ + 7) * NS + (size_t)EV2G_NQ * NT + (size_t)EV2G_NQ * G + (size_t)NT +
                              (size_t)G * 6) +
            sizeof(int) * (6 * (size_t)NS + 2 * (size_t)R + 1 + 4);
 }
@@ -186,7 +187,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     double *s_tot = s_cap + NS, *s_prev = s_tot + NS;      // total_energy_exchanged, previous_power
     double *s_bcap = s_prev + NS, *s_potc = s_bcap + NS;   // battery_capacity, charge-power-potential term
     double *s_amps = s_potc + NS;                          // phase A: amps; phase B: replaced by EV.current_energy
-    double *tsum = s_amps + NS;                            // [NQ][NT]
+    double *s_abse = s_amps + NS;                          // EV.abs_total_energy_exchanged (EV2G_FLAG_LOG_SOC)
+    double *tsum = s_abse + NS;                            // [NQ][NT]
     double *esum = tsum + (size_t)EV2G_NQ * NT;            // [NQ][G]
     double *over_l = esum + (size_t)EV2G_NQ * G;           // [NT] 100 * overload of each (env, transformer)
     double *eacc = over_l + NT;                            // [G][5] episode accumulators
@@ -197,6 +199,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     int *items = s_dirty + NS, *seg = items + NS, *trobs = seg + R + 1, *cnt = trobs + R;  // cnt[0] charge, cnt[1] discharge
     const int tid = threadIdx.x;
     const bool log_cs = S->cs_profits != nullptr;
+    const bool log_soc = S->soc_log != nullptr;
     const double dtd = (double)S->dt, sixty_over_dt = S->sixty_over_dt, dt_over_60 = S->dt_over_60;
 
     // ---- home lane set-up (once per launch): global state -> LDS ----
@@ -217,7 +220,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
         if (w.x <= t && t <= w.y) {
             s_cap[tid] = S->cap[g]; s_tot[tid] = S->tot_e[g]; s_prev[tid] = S->prev_power[g];
             s_bcap[tid] = S->bcap[g]; s_potc[tid] = S->potc[g];
+            s_abse[tid] = log_soc ? S->abs_e[g] : 0.0;
         } else {
+            s_abse[tid] = 0.0;
             s_cap[tid] = 0.0; s_tot[tid] = 0.0; s_prev[tid] = 0.0; s_bcap[tid] = 1.0; s_potc[tid] = 0.0;
         }
     }
@@ -248,7 +253,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             if (valid) {
                 const int2 w = S->port_first_win[g_l];
                 s_ta[tid_l] = w.x; s_td[tid_l] = w.y; s_ss[tid_l] = S->port_first[g_l]; s_cyc[tid_l] = 0;
-                s_cap[tid_l] = 0.0; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_dirty[tid_l] = 3;
+                s_cap[tid_l] = 0.0; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_abse[tid_l] = 0.0; s_dirty[tid_l] = 3;
                 S->port_energy[g_l] = 0.0;
                 S->port_current[g_l] = 0.0;
             }
@@ -271,9 +276,11 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
 
         // ---------------- A: home lanes, charger level (ev_charger.py:137-186) ----------------
         bool occ = false;
+        double cap_before = 0.0;
         if (valid) {
             const int ta = s_ta[tid_l], td = s_td[tid_l];
             occ = (ta <= t) && (t <= td);
+            if (log_soc && occ) cap_before = s_cap[tid_l];
             double a = occ ? a_next : 0.0;
             if (npc == 1) {
                 if (a > 1.0) a = a / a;
@@ -362,6 +369,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                     s_tot[h] = o.tot_e;
                     s_cyc[h] = o.cycles;
                     s_amps[h] = o.energy;
+                    if (log_soc) s_abse[h] += fabs(o.energy);
                     stage[0 * NS + h] = o.energy * 60.0 / dtd;
                     stage[(i < nch ? 4 : 5) * NS + h] = fabs(o.energy);
                     stage[6 * NS + h] = (double)o.emerg;
@@ -395,6 +403,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 }
                 if (npc == 1 && current - 0.0001 > c_imax) S->env_fault[e_l] = 1;  // ev_charger.py:203-205
                 if (last_step) { S->port_energy[g_l] = energy; S->port_current[g_l] = current; }
+                if (log_soc)  // historic_soc / active_steps (ev.py:156,162,185): capacity before the step, negated if inactive
+                    S->soc_log[(long long)t * E * P + g_l] = (current != 0.0) ? cap_before : -cap_before;
                 if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
                     const int ss = s_ss[tid_l];
                     const SessRec &r = *(const SessRec *)(S->rec + ss);
@@ -405,6 +415,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                     if (npc == 1) { S->cs_served[gc] += 1; S->cs_sat_sum[gc] += score; }
                     else { atomicAdd(&S->cs_served[gc], 1); atomicAdd(&S->cs_sat_sum[gc], score); }
                     S->sess_final_cap[ss] = cap;
+                    if (log_soc) S->sess_abs_e[ss] = s_abse[tid_l];
                     ta = r.nt_arr; td = r.nt_dep;
                     s_ta[tid_l] = ta; s_td[tid_l] = td;
                     s_ss[tid_l] = (ta != EV2G_INT_MAX) ? ss + 1 : -1;
@@ -419,6 +430,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 const double evc = r.pacmax * 1000.0 / v;            // utils.py:773-777
                 const double potc = v * ((evc < c_imax) ? evc : c_imax) / 1000.0;
                 s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
+                s_abse[tid_l] = 0.0;
                 S->bcap[g_l] = B;
                 S->potc[g_l] = potc;
                 S->port_energy[g_l] = 0.0;
@@ -597,6 +609,6 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
         const int d = s_dirty[tid];
         if (d & 2) S->win[g] = make_int2(s_ta[tid], s_td[tid]);
         if (d) S->sc[g] = make_int2(s_ss[tid], s_cyc[tid]);
-        if (d & 1) { S->cap[g] = s_cap[tid]; S->tot_e[g] = s_tot[tid]; S->prev_power[g] = s_prev[tid]; }
+        if (d & 1) { S->cap[g] = s_cap[tid]; S->tot_e[g] = s_tot[tid]; S->prev_power[g] = s_prev[tid]; if (log_soc) S->abs_e[g] = s_abse[tid]; }
     }
 }

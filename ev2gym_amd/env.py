@@ -254,6 +254,7 @@ class EV2Gym:
         self._host_state = sk is None     # user-defined callables: evaluated here on the host
         self._host_reward = rk is None
         flags = _abi.FLAG_LOG_CS_HISTORY if (log_cs_history or self._host_reward or cost_function) else 0
+        flags |= _abi.FLAG_LOG_SOC
         self.engine = Engine(scenario, rk if rk is not None else 2, sk if sk is not None else 2, device=device, flags=flags)
         e = self.engine
         self.simulation_length, self.timescale = e.T, scenario.timescale

@@ -59,7 +59,7 @@ def _kind(fn, table, what):
 class EV2GymVec:
     def __init__(self, config_file=None, num_envs: int = 1, device: int = 0, state_function="PublicPST",
                  reward_function="SquaredTrackingErrorReward", cost_function=None, seed: Optional[int] = None,
-                 scenarios: Optional[ScenarioBatch] = None, auto_reset: bool = False, log_cs_history: bool = False,
+                 scenarios: Optional[ScenarioBatch] = None, auto_reset: bool = False, log_cs_history: bool = False, log_soc: bool = True,
                  use_torch: Optional[bool] = None, rank: int = 0, world_size: int = 1, verbose: bool = False, **unused):
         self.state_kind = _kind(state_function, _abi.STATE_KINDS, "state_function")
         self.reward_kind = _kind(reward_function, _abi.REWARD_KINDS, "reward_function")
@@ -97,6 +97,8 @@ class EV2GymVec:
             torch.cuda.set_device(device)
             stream = torch.cuda.current_stream(device).cuda_stream or None
         flags = _abi.FLAG_LOG_CS_HISTORY if log_cs_history else 0
+        if log_soc:
+            flags |= _abi.FLAG_LOG_SOC   # battery-degradation statistics need the SoC log (ev.py:442-521)
         if use_torch and stream is None:
             flags |= _abi.FLAG_NULL_STREAM   # torch's current stream is the default stream: share it
         self.engine = Engine(scenarios, self.reward_kind, self.state_kind, device=device, flags=flags, stream=stream)

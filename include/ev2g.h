@@ -52,6 +52,8 @@ extern "C" {
 /* flags for ev2g_config.flags */
 #define EV2G_FLAG_LOG_CS_HISTORY 1 /* keep cs_power / cs_current [E,C,T] (ev2gym_env.py:533-535) */
 #define EV2G_FLAG_NULL_STREAM 2    /* launch on the legacy default stream (torch's default stream) */
+#define EV2G_FLAG_LOG_SOC 4        /* keep the per-step SoC log + |energy| sums that EV.get_battery_degradation needs
+                                      (ev.py:156,162,180,185,442-521); without it the three degradation stats are NaN */
 
 typedef struct ev2g_handle ev2g_handle;
 

@@ -25,7 +25,7 @@ def _close(a, b, what, tol=RTOL):
     assert err.max(initial=0.0) <= tol, f"{what}: max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
 
 
-def _engine(batch, rk, sk, flags=1):
+def _engine(batch, rk, sk, flags=1 | 4):
     from ev2gym_amd.engine import Engine
     return Engine(batch, rk, sk, device=0, flags=flags)
 
@@ -74,8 +74,6 @@ def test_engine_matches_reference_golden(path):
         st = eng.stats()[0]
         for i, k in enumerate(_abi.STAT_NAMES):
             g = z["trj_stats"][i]
-            if k.startswith("battery_degradation"):
-                continue  # SoC-log based statistics are not produced by the engine yet ("next")
             if np.isnan(g):
                 assert np.isnan(st[i]), k
             else:
@@ -100,7 +98,7 @@ def test_engine_matches_oracle_batched(name, E, lo):
     from ev2gym_amd.engine import host_uniform
     from oracle.oracle import Oracle
     batch, rk, sk = _tiled(name, E)
-    eng = _engine(batch, rk, sk, flags=0)
+    eng = _engine(batch, rk, sk, flags=4)
     ora = Oracle(batch, rk, sk)
     P, D, T = eng.P, eng.D, eng.T
     d_act, d_obs = eng.empty((E, P)), eng.empty((E, D))
@@ -130,8 +128,7 @@ def test_engine_matches_oracle_batched(name, E, lo):
         _close(pk["tr_overload"], po["tr_overload"], "tr_overload")
     if nT == T:
         st, so = eng.stats(), ora.stats()
-        keep = [i for i in range(17) if i not in (13, 14, 15)]
-        _close(st[:, keep], so[:, keep], "episode stats")
+        _close(st, so, "episode stats (incl. battery degradation from the SoC log)")
     eng.check_faults()
     eng.close()
     ora.close()
