@@ -16,6 +16,7 @@
 #include "../../include/ev2g.h"
 #include "ev2g_device.h"
 #include "ev2g_step_v2.h"
+#include "ev2g_step_wave.h"
 
 static thread_local std::string g_create_error;
 
@@ -40,6 +41,7 @@ struct ev2g_handle {
     double *d_ss_afap = nullptr;                // [S] device order
     V2P *d_v2p = nullptr;                       // device copy of the v2 kernel's parameter block
     int block = 0;                              // 256/512/1024: v2 kernel; 0: generic kernel (P > 1024)
+    bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
     int current_step = 0;
     size_t lds_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -362,6 +364,8 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     const int blk = h->block ? h->block : EV2G_BLOCK;
     s.G = std::max(1, blk / P);
     s.G = std::min(s.G, E);
+    h->wave_path = (P <= 64 && R == 1 && npc == 1 && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY));
+    if (h->wave_path) s.G = 4 * (64 / P);   // wave-aligned: 64/P envs per wavefront, 4 wavefronts per workgroup
     {
         int gs = 4;
         while (gs < 64 && gs < max_seg) gs <<= 1;
@@ -370,7 +374,9 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     s.n_groups = (E + s.G - 1) / s.G;
     s.sixty_over_dt = 60.0 / (double)b->timescale;
     s.dt_over_60 = (double)b->timescale / 60.0;
-    if (h->block)
+    if (h->wave_path)
+        h->lds_bytes = ev2g_wave_lds_bytes();
+    else if (h->block)
         h->lds_bytes = ev2g_v2_lds_bytes(s.G * P, s.G * R, s.G, R);
     else
         h->lds_bytes = sizeof(double) * ((size_t)EV2G_NQ * s.G * P + (size_t)EV2G_NQ * s.G * R + (size_t)EV2G_NQ * s.G);
@@ -527,6 +533,22 @@ int ev2g_reset(ev2g_handle *h, double *obs) {
 
 static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int auto_reset) {
     const DevScn &s = h->scn;
+    if (h->wave_path) {
+        const V2P *pp = (const V2P *)h->d_v2p;
+#define EV2G_WAVE_CASE(SK, RK)                                                                                         \
+    case SK * 3 + RK:                                                                                                  \
+        hipLaunchKernelGGL((ev2g_step_wave<SK, RK>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, \
+                           pp, io, t0, k, auto_reset);                                                                 \
+        break;
+        switch (s.state_kind * 3 + s.reward_kind) {
+            EV2G_WAVE_CASE(0, 0) EV2G_WAVE_CASE(0, 1) EV2G_WAVE_CASE(0, 2)
+            EV2G_WAVE_CASE(1, 0) EV2G_WAVE_CASE(1, 1) EV2G_WAVE_CASE(1, 2)
+            EV2G_WAVE_CASE(2, 0) EV2G_WAVE_CASE(2, 1) EV2G_WAVE_CASE(2, 2)
+        }
+#undef EV2G_WAVE_CASE
+        HIPCHK(h, hipGetLastError());
+        return EV2G_OK;
+    }
     switch (h->block) {
     case 256:
         hipLaunchKernelGGL(ev2g_step_v2<256>, dim3(s.n_groups), dim3(256), h->lds_bytes, h->stream, (const V2P *)h->d_v2p, io, t0, k, auto_reset);

@@ -1,0 +1,360 @@
+// ev2g_step_wave.h -- fast path of the step kernel for the common shape: P <= 64 ports per env, one transformer,
+// single-port chargers (BASELINE cfg2 / cfg3 / cfg5 and the reference's shipped YAML files).
+//
+// Same phases and the same arithmetic as ev2g_step_v2 (ev2g_step_v2.h), with two structural differences:
+//   * WAVE-ALIGNED envs: a wavefront owns EPW = 64 / P whole envs (lanes [0, EPW*P)).  Everything that concerns one
+//     env after the battery maths -- departures / arrivals, observation columns, the per-env reduction, transformer
+//     overload, reward, observation head -- then happens inside ONE wavefront, ordered by s_waitcnt only.  Only the
+//     compaction hand-off (home lanes -> worker lanes -> home lanes) crosses wavefronts, so a step has TWO workgroup
+//     barriers instead of five or six.
+//   * specialised at compile time on the fused (state, reward) plugin pair, so the plugin branches, their loads and
+//     their registers disappear.
+// The reduction is still LDS-staged and fixed-order (8 quantities x 8 lanes, two chains, 3 xor steps), i.e.
+// bit-reproducible, and identical in value to the generic kernel's (same tree).
+#pragma once
+#include "ev2g_step_v2.h"
+
+#define EV2G_WAVE_BLOCK 256
+
+__host__ __device__ inline size_t ev2g_wave_lds_bytes() {
+    const size_t NS = EV2G_WAVE_BLOCK;
+    return sizeof(double) * ((EV2G_NQ + 7) * NS) + sizeof(int) * (6 * NS + 8);
+}
+
+template <int SK, int RK>
+__global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
+                                                                     int k_steps, int auto_reset) {
+    extern __shared__ double lds[];
+    typedef const V2P __attribute__((address_space(4))) *ParamPtr;
+    ParamPtr S = (ParamPtr)(unsigned long long)params;
+    constexpr int NS = EV2G_WAVE_BLOCK;
+    const int P = S->P, T = S->T, E = S->E, D = S->D;
+    const int EPW = 64 / P;   // envs per wavefront
+    const int G = 4 * EPW;    // envs per workgroup
+    int grp;
+    {   // XCD-aware mapping: workgroup b runs on XCD b % 8; give each XCD a contiguous range of env groups
+        const int nb = gridDim.x, b = blockIdx.x, per = nb >> 3;
+        grp = (nb & 7) == 0 ? (b & 7) * per + (b >> 3) : b;
+    }
+    const int e0 = grp * G;
+    double *stage = lds;                                   // [NQ][NS] per-port step results, by home index (= tid)
+    double *s_cap = stage + (size_t)EV2G_NQ * NS;
+    double *s_tot = s_cap + NS, *s_prev = s_tot + NS, *s_bcap = s_prev + NS, *s_potc = s_bcap + NS;
+    double *s_amps = s_potc + NS, *s_abse = s_amps + NS;
+    int *s_ta = (int *)(s_abse + NS);
+    int *s_td = s_ta + NS, *s_ss = s_td + NS, *s_cyc = s_ss + NS, *s_dirty = s_cyc + NS, *items = s_dirty + NS;
+    int *cnt = items + NS;  // cnt[2*(kk&1) + {0 charge, 1 discharge}]
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const bool log_soc = S->soc_log != nullptr;
+    const double dtd = (double)S->dt, sixty_over_dt = S->sixty_over_dt, dt_over_60 = S->dt_over_60;
+
+    // ---- home lane set-up ----
+    const int elw = lane / P;            // env inside the wavefront
+    const int q = lane - elw * P;        // port slot (== reference port: one transformer, single-port chargers)
+    const int e = e0 + wv * EPW + elw;
+    const bool valid = (elw < EPW) && (e < E);
+    const int g = valid ? e * P + q : 0;
+    const int ocol = (SK == 1) ? 3 + 3 * q : (SK == 0 ? 62 + 2 * q : 22 + 2 * q);
+    const int cs = valid ? q : 0;
+    const double c_imax = S->cs_imax[cs], c_thr_ch = S->cs_imin[cs] - 0.01, c_dmin = S->cs_dmin[cs], c_dmaxabs = S->cs_dmax_abs[cs];
+    const double c_maxp = S->cs_maxp[cs], c_minp = S->cs_minp[cs];
+    int t = t0;
+    if (valid) {
+        const int2 w = S->win[g];
+        const int2 sc = S->sc[g];
+        s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = sc.x; s_cyc[tid] = sc.y; s_dirty[tid] = 0;
+        if (w.x <= t && t <= w.y) {
+            s_cap[tid] = S->cap[g]; s_tot[tid] = S->tot_e[g]; s_prev[tid] = S->prev_power[g];
+            s_bcap[tid] = S->bcap[g]; s_potc[tid] = S->potc[g];
+            s_abse[tid] = log_soc ? S->abs_e[g] : 0.0;
+        } else {
+            s_cap[tid] = 0.0; s_tot[tid] = 0.0; s_prev[tid] = 0.0; s_bcap[tid] = 1.0; s_potc[tid] = 0.0; s_abse[tid] = 0.0;
+        }
+    }
+    const bool head = valid && q == 0;   // one lane per env: env-level scalars
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0, acc4 = 0.0;   // episode accumulators (head lanes)
+    double pot_prev = (head && t < T) ? S->pot_hist[t * E + e] : 0.0;   // charge_power_potential[t]
+    if (tid < 4) cnt[tid] = 0;
+    for (int k = 0; k < EV2G_NQ; k++) stage[k * NS + tid] = 0.0;
+    double a_next = (valid && k_steps > 0 && t < T) ? io.actions[g] : 0.0;
+    __syncthreads();
+
+    for (int kk = 0; kk < k_steps; kk++) {
+        asm volatile("" : "+s"(S));
+        int tid_l = tid, g_l = g, e_l = e, q_l = q, lane_l = lane;
+        asm volatile("" : "+v"(tid_l), "+v"(g_l), "+v"(e_l), "+v"(q_l), "+v"(lane_l));
+        if (t >= T) {  // episode finished inside a fused run: in-kernel ev2g_reset for this workgroup
+            if (!auto_reset) break;
+            if (valid) {
+                const int2 w = S->port_first_win[g_l];
+                s_ta[tid_l] = w.x; s_td[tid_l] = w.y; s_ss[tid_l] = S->port_first[g_l]; s_cyc[tid_l] = 0;
+                s_cap[tid_l] = 0.0; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_abse[tid_l] = 0.0; s_dirty[tid_l] = 3;
+                S->port_energy[g_l] = 0.0;
+                S->port_current[g_l] = 0.0;
+                S->cs_sat_sum[g_l] = 0.0;   // single-port chargers: charger index == port index
+                S->cs_served[g_l] = 0;
+            }
+            if (head) { for (int i = 0; i < 8; i++) S->env_acc[e_l * 8 + i] = 0.0; }
+            acc0 = acc1 = acc2 = acc3 = acc4 = 0.0;
+            pot_prev = 0.0;
+            t = 0;
+        }
+        double *__restrict__ obs = io.obs ? io.obs + (long long)kk * io.o_stride : nullptr;
+        uint8_t *__restrict__ mask = io.mask ? io.mask + (long long)kk * io.m_stride : nullptr;
+        const int sstep = t + 1;
+        const bool last_step = (kk == k_steps - 1) || (sstep >= T && !auto_reset);
+        int *cntk = cnt + 2 * (kk & 1);
+
+        // ---------------- A: home lanes, charger level (ev_charger.py:137-186) ----------------
+        bool occ = false;
+        double cap_before = 0.0;
+        if (valid) {
+            const int ta = s_ta[tid_l], td = s_td[tid_l];
+            occ = (ta <= t) && (t <= td);
+            if (log_soc && occ) cap_before = s_cap[tid_l];
+            double a = occ ? a_next : 0.0;
+            if (a > 1.0) a = a / a;            // one port per charger: a / sum(a)
+            else if (a < -1.0) a = -a / a;
+            double amps = 0.0;
+            if (occ) {
+                const double x = rnd5(a);
+                if (x > 0.0) { amps = x * c_imax; if (amps < c_thr_ch) amps = 0.0; }
+                else if (x < 0.0) { amps = x * c_dmaxabs; if (amps > c_dmin - 0.01) amps = c_dmin; }
+            }
+            s_amps[tid_l] = amps;
+            stage[0 * NS + tid_l] = 0.0;
+            stage[4 * NS + tid_l] = 0.0;
+            stage[5 * NS + tid_l] = 0.0;
+            stage[6 * NS + tid_l] = 0.0;
+            stage[7 * NS + tid_l] = 0.0;
+            if (amps != 0.0) items[(amps > 0.0) ? atomicAdd(&cntk[0], 1) : NS - 1 - atomicAdd(&cntk[1], 1)] = tid_l;
+        }
+        // ---- prefetch what the rest of this step needs (collected before the stores of phase C) ----
+        const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
+        a_next = (valid && more) ? (io.actions + (long long)(kk + 1) * io.a_stride)[g_l] : 0.0;
+        double pf_pch = 0.0, pf_pdis = 0.0, pf_infl = 0.0, pf_solar = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
+        if (valid) { pf_pch = S->price_ch[e_l * T + t]; pf_pdis = S->price_dis[e_l * T + t]; }
+        if (head) {
+            if (RK == 0) { pf_infl = S->tr_infl[e_l * T + t]; pf_solar = S->tr_solar[e_l * T + t]; pf_maxp = S->tr_maxp[e_l * T + t]; pf_minp = S->tr_minp[e_l * T + t]; }
+            if (RK == 1) pf_sp = S->setpoint[e_l * T + t];
+        }
+        // observation head columns of this env, distributed over its P lanes: column c = q, q+P, q+2P
+        double pf_ob0 = 0.0, pf_ob1 = 0.0, pf_ob2 = 0.0;
+        constexpr int NHEAD = (SK == 1) ? 0 : (SK == 0 ? 60 : 20);   // 20 prices (+ 40 window columns)
+        if (valid && obs) {
+            if (SK == 1) {
+                if (q_l == 0) pf_ob0 = (sstep < T) ? S->setpoint[e_l * T + sstep] : 0.0;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int c = q_l + u * P;
+                    double v = 0.0;
+                    if (c < 20) { const int k = sstep + c; v = (k < T) ? S->price_ch[e_l * T + k] : 0.0; }
+                    else if (c < NHEAD) v = S->win_tab[((long long)e_l * (T + 1) + sstep) * 40 + (c - 20)];
+                    if (u == 0) pf_ob0 = v; else if (u == 1) pf_ob1 = v; else pf_ob2 = v;
+                }
+            }
+        }
+        lds_barrier();
+        if (tid_l < 2) cnt[2 * ((kk + 1) & 1) + tid_l] = 0;   // next step's counters (last used two barriers ago)
+
+        // ---------------- B: worker lanes, battery maths on the compact list ----------------
+        {
+            const int nch = cntk[0], ndis = cntk[1];
+            const int nchp = (nch + 63) & ~63;
+            for (int i = tid_l; i < nchp + ndis; i += EV2G_WAVE_BLOCK) {
+                int h = -1;
+                if (i < nch) h = items[i];
+                else if (i >= nchp) h = items[NS - 1 - (i - nchp)];
+                if (h >= 0) {
+                    const SessRec r = *(const SessRec *)(S->rec + s_ss[h]);
+                    const double cap0 = s_cap[h], prev0 = s_prev[h];
+                    const int cyc0 = s_cyc[h];
+                    const EvRes o = ev_math(r, (const double *)S->lut, s_amps[h], cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd);
+                    if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
+                    s_cap[h] = o.cap;
+                    s_prev[h] = o.prev_power;
+                    s_tot[h] = o.tot_e;
+                    s_cyc[h] = o.cycles;
+                    s_amps[h] = o.energy;
+                    if (log_soc) s_abse[h] += fabs(o.energy);
+                    stage[0 * NS + h] = o.energy * 60.0 / dtd;
+                    stage[(i < nch ? 4 : 5) * NS + h] = fabs(o.energy);
+                    stage[6 * NS + h] = (double)o.emerg;
+                    stage[7 * NS + h] = o.current;
+                }
+            }
+        }
+        lds_barrier();
+
+        // ---------------- C: home lanes (from here on everything of one env lives in one wavefront) ----------------
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // collect the prefetches before this phase issues stores (vmcnt(0))
+        if (valid) {
+            double profit = 0.0, satpen = 0.0, pot = 0.0;
+            int ta = s_ta[tid_l], td = s_td[tid_l];
+            double cap = s_cap[tid_l];
+            if (occ) {
+                const double energy = s_amps[tid_l];
+                const double current = stage[7 * NS + tid_l];
+                if (energy != 0.0) {  // profit by the sign of the ACTION (ev_charger.py:178,194), staged under 4 / 5
+                    const double ech = stage[4 * NS + tid_l];
+                    profit = (ech != 0.0) ? ech * pf_pch : stage[5 * NS + tid_l] * pf_pdis;
+                }
+                if (current - 0.0001 > c_imax) S->env_fault[e_l] = 1;  // ev_charger.py:203-205
+                if (last_step) { S->port_energy[g_l] = energy; S->port_current[g_l] = current; }
+                if (log_soc) S->soc_log[(long long)t * E * P + g_l] = (current != 0.0) ? cap_before : -cap_before;
+                if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
+                    const int ss = s_ss[tid_l];
+                    const SessRec &r = *(const SessRec *)(S->rec + ss);
+                    const double des = r.des;
+                    const double score = (cap < des - 0.001) ? cap / des : 1.0;
+                    if (RK != 1) satpen = 100.0 * exp(-10.0 * score);
+                    S->cs_served[g_l] += 1;
+                    S->cs_sat_sum[g_l] += score;
+                    S->sess_final_cap[ss] = cap;
+                    if (log_soc) S->sess_abs_e[ss] = s_abse[tid_l];
+                    ta = r.nt_arr; td = r.nt_dep;
+                    s_ta[tid_l] = ta; s_td[tid_l] = td;
+                    s_ss[tid_l] = (ta != EV2G_INT_MAX) ? ss + 1 : -1;
+                    s_cyc[tid_l] = 0;
+                    s_dirty[tid_l] |= 2;
+                }
+            }
+            if (ta == sstep) {  // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
+                const SessRec &r = *(const SessRec *)(S->rec + s_ss[tid_l]);
+                cap = r.cap0;
+                const double B = r.B, v = r.v;
+                const double evc = r.pacmax * 1000.0 / v;            // utils.py:773-777
+                const double potc = v * ((evc < c_imax) ? evc : c_imax) / 1000.0;
+                s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
+                s_abse[tid_l] = 0.0;
+                S->bcap[g_l] = B;
+                S->potc[g_l] = potc;
+                S->port_energy[g_l] = 0.0;
+                S->port_current[g_l] = 0.0;
+                s_dirty[tid_l] |= 1;
+            }
+            const bool occ_after = (ta <= sstep) && (sstep <= td);
+            if (mask) mask[g_l] = occ_after ? 1 : 0;
+            double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+            if (occ_after) {
+                const double soc = cap / s_bcap[tid_l];
+                if (SK == 1) { o0 = (soc == 1.0) ? 1.0 : 0.5; o1 = s_tot[tid_l]; o2 = (double)(sstep - ta); }
+                else { o0 = soc; o1 = (double)(td - sstep); }
+                if (soc < 1.0 && td > sstep) pot = s_potc[tid_l];  // utils.py:771
+            }
+            pot = (pot > c_maxp) ? c_maxp : ((pot < c_minp) ? 0.0 : pot);  // per-charger clamp (utils.py:779-789)
+            if (obs) {
+                double *o = obs + (e_l * D + ocol);
+                o[0] = o0;
+                o[1] = o1;
+                if (SK == 1) o[2] = o2;
+            }
+            stage[1 * NS + tid_l] = profit;
+            stage[2 * NS + tid_l] = satpen;
+            stage[3 * NS + tid_l] = pot;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wavefront's LDS writes are visible to itself
+
+        // ---------------- D: per-env reduction inside the wavefront (same fixed tree as the generic kernel) ----------------
+        // lane = k*8 + j: quantity k, chain j; env elw's sums end up in lane k*8 (j == 0) and are broadcast below
+        double esum[EV2G_NQ];
+#pragma unroll
+        for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = 0.0;
+        {
+            const int k = lane_l >> 3, j = lane_l & 7;
+            const int wbase = (tid_l & ~63);
+#pragma unroll 1
+            for (int w = 0; w < EPW; w++) {
+                const int a = wbase + w * P, b = a + P;
+                double acc = 0.0, accb = 0.0;
+                int i = a + j;
+                for (; i + 8 < b; i += 16) { acc += stage[k * NS + i]; accb += stage[k * NS + i + 8]; }
+                if (i < b) acc += stage[k * NS + i];
+                acc += accb;
+                acc += __shfl_xor(acc, 1, 64);
+                acc += __shfl_xor(acc, 2, 64);
+                acc += __shfl_xor(acc, 4, 64);
+#pragma unroll
+                for (int kq = 0; kq < EV2G_NQ; kq++) {
+                    const double v = __shfl(acc, kq * 8, 64);
+                    if (w == elw) esum[kq] = v;
+                }
+            }
+        }
+
+        // ---------------- E: per env (head lane) + observation head (the env's lanes) ----------------
+        const double usage = esum[0];
+        if (head) {
+            double over100 = 0.0;
+            if (RK == 0) {  // Transformer.reset + step + get_how_overloaded (transformer.py:258-302)
+                double ptr = pf_infl + pf_solar;
+                ptr += usage;
+                const double over = (ptr > pf_maxp + 0.0001 || ptr < pf_minp - 0.0001) ? fabs(ptr - pf_maxp) : 0.0;
+                S->over_hist[t * E + e_l] = over;
+                if (last_step) S->tr_power_now[e_l] = ptr;
+                over100 = 100.0 * over;
+            } else {
+                const int erT = e_l * T + t;
+                double ptr = S->tr_infl[erT] + S->tr_solar[erT];
+                ptr += usage;
+                const double mx = S->tr_maxp[erT], mn = S->tr_minp[erT];
+                const double over = (ptr > mx + 0.0001 || ptr < mn - 0.0001) ? fabs(ptr - mx) : 0.0;
+                S->over_hist[t * E + e_l] = over;
+                if (last_step) S->tr_power_now[e_l] = ptr;
+            }
+            S->usage_hist[t * E + e_l] = usage;
+            const double potn = esum[3];
+            if (sstep < T) S->pot_hist[sstep * E + e_l] = potn;
+            const double costs = esum[1];
+            double reward;
+            if (RK == 1) {  // SquaredTrackingErrorReward reward.py:7-14
+                const double m = (pot_prev < pf_sp) ? pot_prev : pf_sp;
+                const double d = m - usage;
+                reward = -(d * d);
+            } else if (RK == 2) {  // profit_maximization reward.py:78-87
+                reward = costs - esum[2];
+            } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
+                reward = costs - over100 - esum[2];
+            }
+            pot_prev = potn;
+            acc0 += reward; acc1 += costs; acc2 += esum[4]; acc3 += esum[5]; acc4 += esum[6];
+            if (io.reward) io.reward[(long long)kk * io.r_stride + e_l] = reward;
+            if (io.done) io.done[(long long)kk * io.d_stride + e_l] = (sstep >= T) ? 1 : 0;
+            if (sstep >= T || last_step) {  // flush the episode accumulators (get_statistics reads them)
+                auto ga = S->env_acc + e_l * 8;
+                ga[0] += acc0; ga[1] += acc1; ga[2] += acc2; ga[3] += acc3; ga[4] += acc4;
+                acc0 = acc1 = acc2 = acc3 = acc4 = 0.0;
+            }
+        }
+        if (valid && obs) {
+            double *o = obs + e_l * D;
+            if (SK == 1) {  // PublicPST state.py:6-35
+                if (q_l == 0) { o[0] = (double)sstep / (double)T; o[1] = pf_ob0; o[2] = usage; }
+            } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135
+                if (q_l == 0) { o[0] = (double)sstep; o[1] = usage; }
+                int c = q_l;
+                if (c < 20) o[2 + c] = fabs(pf_ob0); else if (c < NHEAD) o[2 + c] = pf_ob0;
+                c = q_l + P;
+                if (c < 20) o[2 + c] = fabs(pf_ob1); else if (c < NHEAD) o[2 + c] = pf_ob1;
+                c = q_l + 2 * P;
+                if (c < 20) o[2 + c] = fabs(pf_ob2); else if (c < NHEAD) o[2 + c] = pf_ob2;
+                for (c = q_l + 3 * P; c < NHEAD; c += P) {   // tiny envs (P < 20): the remaining columns, unprefetched
+                    if (c < 20) { const int k = sstep + c; o[2 + c] = (k < T) ? fabs(S->price_ch[e_l * T + k]) : 0.0; }
+                    else o[2 + c] = S->win_tab[((long long)e_l * (T + 1) + sstep) * 40 + (c - 20)];
+                }
+            }
+        }
+        t += 1;
+        // The next step's phase A rewrites stage[0,4..7] / s_amps of this wavefront's own lanes only after this
+        // wavefront finished reading them (program order); other wavefronts never touch these slots outside phase B,
+        // which is fenced by the two barriers.
+    }
+    __syncthreads();
+    if (valid) {
+        const int d = s_dirty[tid];
+        if (d & 2) S->win[g] = make_int2(s_ta[tid], s_td[tid]);
+        if (d) S->sc[g] = make_int2(s_ss[tid], s_cyc[tid]);
+        if (d & 1) { S->cap[g] = s_cap[tid]; S->tot_e[g] = s_tot[tid]; S->prev_power[g] = s_prev[tid]; if (log_soc) S->abs_e[g] = s_abse[tid]; }
+    }
+}
