@@ -76,10 +76,12 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     double pot_prev = (head && t < T) ? S->pot_hist[t * E + e] : 0.0;   // charge_power_potential[t]
     if (tid < 4) cnt[tid] = 0;
     for (int k = 0; k < EV2G_NQ; k++) stage[k * NS + tid] = 0.0;
-    double a_next = (valid && k_steps > 0 && t < T) ? io.actions[g] : 0.0;
+    double a_next = io.actions[valid ? g : e0 * P];
     __syncthreads();
 
+    PT_DECL
     for (int kk = 0; kk < k_steps; kk++) {
+        PT_MARK(7)
         asm volatile("" : "+s"(S));
         int tid_l = tid, g_l = g, e_l = e, q_l = q, lane_l = lane;
         asm volatile("" : "+v"(tid_l), "+v"(g_l), "+v"(e_l), "+v"(q_l), "+v"(lane_l));
@@ -129,33 +131,38 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             stage[7 * NS + tid_l] = 0.0;
             if (amps != 0.0) items[(amps > 0.0) ? atomicAdd(&cntk[0], 1) : NS - 1 - atomicAdd(&cntk[1], 1)] = tid_l;
         }
+        PT_MARK(0)
         // ---- prefetch what the rest of this step needs (collected before the stores of phase C) ----
+        // Every prefetch is ONE unconditional load from a clamped (always valid) address; the conditions are applied
+        // where the value is consumed.  A load inside a divergent branch whose result merges with a default makes the
+        // compiler serialise on the destination register (write-after-write) with a full vmcnt(0) drain.
         const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
-        a_next = (valid && more) ? (io.actions + (long long)(kk + 1) * io.a_stride)[g_l] : 0.0;
-        double pf_pch = 0.0, pf_pdis = 0.0, pf_infl = 0.0, pf_solar = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
-        if (valid) { pf_pch = S->price_ch[e_l * T + t]; pf_pdis = S->price_dis[e_l * T + t]; }
-        if (head) {
-            if (RK == 0) { pf_infl = S->tr_infl[e_l * T + t]; pf_solar = S->tr_solar[e_l * T + t]; pf_maxp = S->tr_maxp[e_l * T + t]; pf_minp = S->tr_minp[e_l * T + t]; }
-            if (RK == 1) pf_sp = S->setpoint[e_l * T + t];
-        }
+        const int ec = valid ? e_l : e0;   // clamped env for idle lanes
+        const int gc = valid ? g_l : e0 * P;
+        a_next = (io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride)[gc];
+        const double pf_pch = S->price_ch[ec * T + t], pf_pdis = S->price_dis[ec * T + t];
+        double pf_infl = 0.0, pf_solar = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
+        if (RK == 0) { pf_infl = S->tr_infl[ec * T + t]; pf_solar = S->tr_solar[ec * T + t]; pf_maxp = S->tr_maxp[ec * T + t]; pf_minp = S->tr_minp[ec * T + t]; }
+        if (RK == 1) pf_sp = S->setpoint[ec * T + t];
         // observation head columns of this env, distributed over its P lanes: column c = q, q+P, q+2P
         double pf_ob0 = 0.0, pf_ob1 = 0.0, pf_ob2 = 0.0;
         constexpr int NHEAD = (SK == 1) ? 0 : (SK == 0 ? 60 : 20);   // 20 prices (+ 40 window columns)
-        if (valid && obs) {
-            if (SK == 1) {
-                if (q_l == 0) pf_ob0 = (sstep < T) ? S->setpoint[e_l * T + sstep] : 0.0;
-            } else {
+        if (SK == 1) {
+            pf_ob0 = S->setpoint[ec * T + min(sstep, T - 1)];   // used by the head lane only, masked by sstep < T
+        } else {
+            const double *pprice = (const double *)S->price_ch + ec * T;
+            const double *pwin = (SK == 0) ? (const double *)S->win_tab + ((long long)ec * (T + 1) + sstep) * 40 : pprice;
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    const int c = q_l + u * P;
-                    double v = 0.0;
-                    if (c < 20) { const int k = sstep + c; v = (k < T) ? S->price_ch[e_l * T + k] : 0.0; }
-                    else if (c < NHEAD) v = S->win_tab[((long long)e_l * (T + 1) + sstep) * 40 + (c - 20)];
-                    if (u == 0) pf_ob0 = v; else if (u == 1) pf_ob1 = v; else pf_ob2 = v;
-                }
+            for (int u = 0; u < 3; u++) {
+                const int c = q_l + u * P;
+                const double *pa = (c < 20) ? pprice + min(sstep + c, T - 1) : ((c < NHEAD) ? pwin + (c - 20) : pprice);
+                const double v = *pa;
+                if (u == 0) pf_ob0 = v; else if (u == 1) pf_ob1 = v; else pf_ob2 = v;
             }
         }
+        PT_MARK(6)
         lds_barrier();
+        PT_MARK(1)
         if (tid_l < 2) cnt[2 * ((kk + 1) & 1) + tid_l] = 0;   // next step's counters (last used two barriers ago)
 
         // ---------------- B: worker lanes, battery maths on the compact list ----------------
@@ -185,7 +192,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 }
             }
         }
+        PT_MARK(2)
         lds_barrier();
+        PT_MARK(1)
 
         // ---------------- C: home lanes (from here on everything of one env lives in one wavefront) ----------------
         __builtin_amdgcn_s_waitcnt(0x0F70);   // collect the prefetches before this phase issues stores (vmcnt(0))
@@ -255,6 +264,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             stage[3 * NS + tid_l] = pot;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wavefront's LDS writes are visible to itself
+        PT_MARK(3)
 
         // ---------------- D: per-env reduction inside the wavefront (same fixed tree as the generic kernel) ----------------
         // lane = k*8 + j: quantity k, chain j; env elw's sums end up in lane k*8 (j == 0) and are broadcast below
@@ -283,6 +293,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
         }
 
+        PT_MARK(4)
         // ---------------- E: per env (head lane) + observation head (the env's lanes) ----------------
         const double usage = esum[0];
         if (head) {
@@ -330,26 +341,28 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         if (valid && obs) {
             double *o = obs + e_l * D;
             if (SK == 1) {  // PublicPST state.py:6-35
-                if (q_l == 0) { o[0] = (double)sstep / (double)T; o[1] = pf_ob0; o[2] = usage; }
+                if (q_l == 0) { o[0] = (double)sstep / (double)T; o[1] = (sstep < T) ? pf_ob0 : 0.0; o[2] = usage; }
             } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135
                 if (q_l == 0) { o[0] = (double)sstep; o[1] = usage; }
                 int c = q_l;
-                if (c < 20) o[2 + c] = fabs(pf_ob0); else if (c < NHEAD) o[2 + c] = pf_ob0;
+                if (c < 20) o[2 + c] = (sstep + c < T) ? fabs(pf_ob0) : 0.0; else if (c < NHEAD) o[2 + c] = pf_ob0;
                 c = q_l + P;
-                if (c < 20) o[2 + c] = fabs(pf_ob1); else if (c < NHEAD) o[2 + c] = pf_ob1;
+                if (c < 20) o[2 + c] = (sstep + c < T) ? fabs(pf_ob1) : 0.0; else if (c < NHEAD) o[2 + c] = pf_ob1;
                 c = q_l + 2 * P;
-                if (c < 20) o[2 + c] = fabs(pf_ob2); else if (c < NHEAD) o[2 + c] = pf_ob2;
+                if (c < 20) o[2 + c] = (sstep + c < T) ? fabs(pf_ob2) : 0.0; else if (c < NHEAD) o[2 + c] = pf_ob2;
                 for (c = q_l + 3 * P; c < NHEAD; c += P) {   // tiny envs (P < 20): the remaining columns, unprefetched
                     if (c < 20) { const int k = sstep + c; o[2 + c] = (k < T) ? fabs(S->price_ch[e_l * T + k]) : 0.0; }
                     else o[2 + c] = S->win_tab[((long long)e_l * (T + 1) + sstep) * 40 + (c - 20)];
                 }
             }
         }
+        PT_MARK(5)
         t += 1;
         // The next step's phase A rewrites stage[0,4..7] / s_amps of this wavefront's own lanes only after this
         // wavefront finished reading them (program order); other wavefronts never touch these slots outside phase B,
         // which is fenced by the two barriers.
     }
+    PT_FLUSH
     __syncthreads();
     if (valid) {
         const int d = s_dirty[tid];

@@ -21,7 +21,7 @@ eng = engine.Engine(batch, _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl[
 P, D, T = eng.P, eng.D, eng.T
 acts = eng.empty((T, E, P)); eng.fill_uniform(acts, T * E * P, 1, wl["lo"], 1.0)
 obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
-names = ["A1 state+amps", "barrier waits", "B battery maths", "C home", "D reduce", "E env-level", "A2 lds writes+atomics+a_next", "A3 prefetch issue + loop top"]
+names = ["A home/charger", "barrier waits", "B battery maths", "C home", "D reduce", "E env-level", "prefetch issue", "loop top"]
 for persistent in (True, False):
     eng.reset(obs)
     eng.step_n(T, acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=persistent)
@@ -30,7 +30,8 @@ for persistent in (True, False):
     L.ev2g_debug_phase_ticks(eng._h, out)
     v = np.array(list(out), float)
     ms = eng.last_step_n_kernel_ms()
-    ng = (E + (256 // P if P <= 256 else 1) - 1) // max(1, (256 // P if P <= 256 else 1))
+    G = 4 * (64 // P) if (P <= 64 and batch.n_transformers == 1) else max(1, 256 // P)
+    ng = (E + G - 1) // G
     tot = v.sum()
     print(f"{wname} persistent={persistent}: {ms*1e3/T:.2f} us/step, {tot/T/ng:.0f} ticks per workgroup-step")
     for n, x in zip(names, v):
