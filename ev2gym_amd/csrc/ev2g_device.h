@@ -36,6 +36,7 @@ struct __attribute__((aligned(128))) SessRec {
 struct DevScn {  // read-only scenario + layout, device pointers
     int E, T, C, npc, P, R, D, ND, dt;
     int reward_kind, state_kind, flags;
+    int n_lut;    // number of efficiency tables
     int G;        // envs per workgroup
     int gs;       // lanes per reduction group (power of two, 4..64)
     int n_groups; // workgroups = ceil(E / G)

@@ -358,14 +358,14 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     DevScn &s = h->scn;
     s = DevScn{};
     s.E = E; s.T = T; s.C = C; s.npc = npc; s.P = P; s.R = R; s.D = D; s.ND = std::max(ND, 1); s.dt = b->timescale;
-    s.reward_kind = h->cfg.reward_kind; s.state_kind = sk; s.flags = h->cfg.flags;
+    s.reward_kind = h->cfg.reward_kind; s.state_kind = sk; s.flags = h->cfg.flags; s.n_lut = b->n_lut;
     // v2 kernel: one home lane per port, BLOCK >= P; the generic kernel handles larger envs
     h->block = (P <= 256) ? 256 : (P <= 512) ? 512 : (P <= 1024) ? 1024 : 0;
     const int blk = h->block ? h->block : EV2G_BLOCK;
     s.G = std::max(1, blk / P);
     s.G = std::min(s.G, E);
     h->wave_path = (P <= 64 && R == 1 && npc == 1 && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY));
-    if (h->wave_path) s.G = 4 * (64 / P);   // wave-aligned: 64/P envs per wavefront, 4 wavefronts per workgroup
+    if (h->wave_path) s.G = (EV2G_WAVE_BLOCK / 64) * (64 / P);   // wave-aligned: 64/P envs per wavefront
     {
         int gs = 4;
         while (gs < 64 && gs < max_seg) gs <<= 1;

@@ -45,7 +45,13 @@ struct EvRes {
 
 // EV.step + _charge/_discharge (ev.py:138-186, :240-355, :357-405) from one session record.
 // Same operation order as the reference (and as oracle/ev2g_oracle.c); -ffp-contract=off.
-__device__ __forceinline__ EvRes ev_math(const SessRec &r, const double *__restrict__ lut, double amps, double cap,
+// `lutv` is the efficiency-table entry for this step's current (percent), looked up by the caller:
+// dict.get(np.round(amps), 1) for charging, dict.get(abs(np.round(amps)), 1) for discharging (ev.py:287-290, :375-379).
+__device__ __forceinline__ int ev_lut_index(int lut, double amps) {
+    const double key = fabs(rint(amps));  // np.round = half-even; charging amps are positive
+    return (key <= 100.0) ? lut * 101 + (int)key : -1;  // -1: key outside 0..100 -> the dict default 1
+}
+__device__ __forceinline__ EvRes ev_math(const SessRec &r, double lutv, double amps, double cap,
                                          double prev_power, double tot_e, int cycles, double sixty_over_dt,
                                          double dt_over_60, double dt) {
     EvRes o;
@@ -56,7 +62,7 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, const double *__restr
     if (prev_power == 0.0 || (prev_power / amps) < 0.0) o.cycles = cycles + 1;
     const double B = r.B, v = r.v;
     if (amps > 0.0) {
-        const double eta = (r.lut >= 0) ? lut_get(lut, r.lut, rint(amps)) / 100.0 : r.eta_ch;
+        const double eta = (r.lut >= 0) ? lutv / 100.0 : r.eta_ch;
         double pilot_dsoc = eta * amps * v / 1000.0 / B / sixty_over_dt;
         const double max_dsoc = eta * r.pacmax / B / sixty_over_dt;
         if (pilot_dsoc > max_dsoc) pilot_dsoc = max_dsoc;
@@ -67,13 +73,13 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, const double *__restr
             if (curr_soc > 1.0) curr_soc = 1.0;
         } else {
             const double pts = r.ts + (pilot_dsoc - max_dsoc) / max_dsoc * (r.ts - 1.0);
-            double new_soc;
-            if (soc < pts) {
-                if (1.0 <= (pts - soc) / pilot_dsoc) new_soc = pilot_dsoc + soc;
-                else new_soc = 1.0 + exp(r.tsm * (pilot_dsoc + soc - pts) / (pts - 1.0)) * (pts - 1.0);
-            } else {
-                new_soc = 1.0 + exp(r.tsm * pilot_dsoc / (pts - 1.0)) * (soc - 1.0);
-            }
+            // the two exponential branches of ev.py:318-334 share one exp(): per lane exactly one of them applies, the
+            // operands of the selected one are evaluated in the reference's order, the other one costs nothing
+            const bool below = soc < pts;
+            const double num = below ? r.tsm * (pilot_dsoc + soc - pts) : r.tsm * pilot_dsoc;
+            const double fac = below ? (pts - 1.0) : (soc - 1.0);
+            double new_soc = 1.0 + exp(num / (pts - 1.0)) * fac;
+            if (below && 1.0 <= (pts - soc) / pilot_dsoc) new_soc = pilot_dsoc + soc;
             const double lim = (max_dsoc > pilot_dsoc) ? pilot_dsoc : max_dsoc;
             curr_soc = (new_soc - soc > lim) ? (lim + soc) : new_soc;
         }
@@ -84,7 +90,7 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, const double *__restr
     } else {
         double given_power = amps * v / 1000.0;
         if (fabs(given_power) > fabs(r.pdismax)) given_power = r.pdismax;
-        const double eta = (r.lut >= 0) ? lut_get(lut, r.lut, fabs(rint(amps))) / 100.0 : r.eta_dis;
+        const double eta = (r.lut >= 0) ? lutv / 100.0 : r.eta_dis;
         double given_energy = given_power * eta * dt / 60.0;
         if (cap + given_energy < r.minB) {
             if (cap > r.minB) { o.energy = -(cap - r.minB); given_energy = o.energy; }
@@ -118,7 +124,7 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, const double *__restr
 // as by-value kernel arguments made LLVM hoist all of them above the loop and spill >200 SGPRs to VGPR lanes,
 // which was 40 % of the VALU instruction stream.
 struct V2P {
-    int E, T, C, npc, P, R, D, G, dt, reward_kind, state_kind, pad0;
+    int E, T, C, npc, P, R, D, G, dt, reward_kind, state_kind, n_lut;
     double sixty_over_dt, dt_over_60;
     EV2G_GP(const int) slot_cs; EV2G_GP(const int) slot_port; EV2G_GP(const int) slot_obs;
     EV2G_GP(const int) tr_seg; EV2G_GP(const int) tr_obs; EV2G_GP(const int) port_first;
@@ -143,7 +149,7 @@ struct V2P {
 
 inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
     p.E = s.E; p.T = s.T; p.C = s.C; p.npc = s.npc; p.P = s.P; p.R = s.R; p.D = s.D; p.G = s.G; p.dt = s.dt;
-    p.reward_kind = s.reward_kind; p.state_kind = s.state_kind; p.pad0 = 0;
+    p.reward_kind = s.reward_kind; p.state_kind = s.state_kind; p.n_lut = s.n_lut;
     p.sixty_over_dt = s.sixty_over_dt; p.dt_over_60 = s.dt_over_60;
 #define CPS(f) EV2G_SETP(p.f, s.f);
 #define CPT(f) EV2G_SETP(p.f, st.f);
@@ -362,7 +368,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                     const SessRec r = *(const SessRec *)(S->rec + s_ss[h]);
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
-                    const EvRes o = ev_math(r, (const double *)S->lut, s_amps[h], cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd);
+                    const double amps_h = s_amps[h];
+                    double lutv = 1.0;
+                    if (r.lut >= 0) { const int li = ev_lut_index(r.lut, amps_h); if (li >= 0) lutv = S->lut[li]; }
+                    const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd);
                     if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
                     s_cap[h] = o.cap;
                     s_prev[h] = o.prev_power;

@@ -14,11 +14,15 @@
 #pragma once
 #include "ev2g_step_v2.h"
 
+// efficiency tables staged in LDS for fused multi-step launches (8 tables x 101 entries)
+#define EV2G_WAVE_LUT_LDS 0
+#ifndef EV2G_WAVE_BLOCK
 #define EV2G_WAVE_BLOCK 256
+#endif
 
 __host__ __device__ inline size_t ev2g_wave_lds_bytes() {
     const size_t NS = EV2G_WAVE_BLOCK;
-    return sizeof(double) * ((EV2G_NQ + 7) * NS) + sizeof(int) * (6 * NS + 8);
+    return sizeof(double) * ((EV2G_NQ + 7) * NS + EV2G_WAVE_LUT_LDS) + sizeof(int) * (6 * NS + 8);
 }
 
 template <int SK, int RK>
@@ -30,7 +34,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     constexpr int NS = EV2G_WAVE_BLOCK;
     const int P = S->P, T = S->T, E = S->E, D = S->D;
     const int EPW = 64 / P;   // envs per wavefront
-    const int G = 4 * EPW;    // envs per workgroup
+    const int G = (EV2G_WAVE_BLOCK / 64) * EPW;    // envs per workgroup
     int grp;
     {   // XCD-aware mapping: workgroup b runs on XCD b % 8; give each XCD a contiguous range of env groups
         const int nb = gridDim.x, b = blockIdx.x, per = nb >> 3;
@@ -41,7 +45,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     double *s_cap = stage + (size_t)EV2G_NQ * NS;
     double *s_tot = s_cap + NS, *s_prev = s_tot + NS, *s_bcap = s_prev + NS, *s_potc = s_bcap + NS;
     double *s_amps = s_potc + NS, *s_abse = s_amps + NS;
-    int *s_ta = (int *)(s_abse + NS);
+    double *s_lut = s_abse + NS;                           // [EV2G_WAVE_LUT_LDS] efficiency tables (fused launches only)
+    int *s_ta = (int *)(s_lut + EV2G_WAVE_LUT_LDS);
     int *s_td = s_ta + NS, *s_ss = s_td + NS, *s_cyc = s_ss + NS, *s_dirty = s_cyc + NS, *items = s_dirty + NS;
     int *cnt = items + NS;  // cnt[2*(kk&1) + {0 charge, 1 discharge}]
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -76,6 +81,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     double pot_prev = (head && t < T) ? S->pot_hist[t * E + e] : 0.0;   // charge_power_potential[t]
     if (tid < 4) cnt[tid] = 0;
     for (int k = 0; k < EV2G_NQ; k++) stage[k * NS + tid] = 0.0;
+    // a fused launch amortises staging the efficiency tables in LDS: the table look-up then no longer adds an L2 round
+    // trip behind the session-record load on the critical path of the battery maths
+    const int lut_lds_n = (k_steps >= 8 && EV2G_WAVE_LUT_LDS > 0) ? min(S->n_lut * 101, EV2G_WAVE_LUT_LDS) : 0;
+    for (int i = tid; i < lut_lds_n; i += EV2G_WAVE_BLOCK) s_lut[i] = S->lut[i];
     double a_next = io.actions[valid ? g : e0 * P];
     __syncthreads();
 
@@ -177,7 +186,13 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     const SessRec r = *(const SessRec *)(S->rec + s_ss[h]);
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
-                    const EvRes o = ev_math(r, (const double *)S->lut, s_amps[h], cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd);
+                    const double amps_h = s_amps[h];
+                    double lutv = 1.0;
+                    if (r.lut >= 0) {
+                        const int li = ev_lut_index(r.lut, amps_h);
+                        if (li >= 0) lutv = (li < lut_lds_n) ? s_lut[li] : S->lut[li];
+                    }
+                    const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd);
                     if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
                     s_cap[h] = o.cap;
                     s_prev[h] = o.prev_power;

@@ -30,7 +30,7 @@ for persistent in (True, False):
     L.ev2g_debug_phase_ticks(eng._h, out)
     v = np.array(list(out), float)
     ms = eng.last_step_n_kernel_ms()
-    G = 4 * (64 // P) if (P <= 64 and batch.n_transformers == 1) else max(1, 256 // P)
+    G = int(os.environ.get('EV2G_WB', '256')) // 64 * (64 // P) if (P <= 64 and batch.n_transformers == 1) else max(1, 256 // P)
     ng = (E + G - 1) // G
     tot = v.sum()
     print(f"{wname} persistent={persistent}: {ms*1e3/T:.2f} us/step, {tot/T/ng:.0f} ticks per workgroup-step")
