@@ -17,6 +17,8 @@
 #include "ev2g_device.h"
 #include "ev2g_step_v2.h"
 #include "ev2g_step_wave.h"
+#include "ev2g_step_list.h"
+#include <cstdlib>
 
 static thread_local std::string g_create_error;
 
@@ -42,6 +44,8 @@ struct ev2g_handle {
     V2P *d_v2p = nullptr;                       // device copy of the v2 kernel's parameter block
     int block = 0;                              // 256/512/1024: v2 kernel; 0: generic kernel (P > 1024)
     bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
+    bool list_path = false;                     // ev2g_step_list: same shape, 4 <= P (work proportional to occupied ports)
+    int list_wb = 128;                          // workgroup size of the list kernel (128 or 256)
     int current_step = 0;
     size_t lds_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -367,6 +371,16 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     h->wave_path = (P <= 64 && R == 1 && npc == 1 && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY));
     if (h->wave_path) s.G = (EV2G_WAVE_BLOCK / 64) * (64 / P);   // wave-aligned: 64/P envs per wavefront
     {
+        // Kernel choice for the common shape.  Default: ev2g_step_wave (fastest measured).  EV2G_KERNEL
+        // selects the alternatives that are kept and parity-tested: "list" / "list256" (attached-list kernel, work
+        // proportional to occupied ports) and "v2" (the generic port-per-lane kernel).
+        const char *kn = std::getenv("EV2G_KERNEL");
+        h->list_path = h->wave_path && P >= 4 && kn && (std::string(kn) == "list" || std::string(kn) == "list256");
+        if (kn && std::string(kn) == "v2") { h->wave_path = h->list_path = false; s.G = std::min(std::max(1, blk / P), E); }
+        h->list_wb = (kn && std::string(kn) == "list256") ? 256 : 128;
+        if (h->list_path) s.G = (h->list_wb / 64) * (64 / P);
+    }
+    {
         int gs = 4;
         while (gs < 64 && gs < max_seg) gs <<= 1;
         s.gs = gs;
@@ -374,7 +388,9 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     s.n_groups = (E + s.G - 1) / s.G;
     s.sixty_over_dt = 60.0 / (double)b->timescale;
     s.dt_over_60 = (double)b->timescale / 60.0;
-    if (h->wave_path)
+    if (h->list_path)
+        h->lds_bytes = ev2g_list_lds_bytes(h->list_wb);
+    else if (h->wave_path)
         h->lds_bytes = ev2g_wave_lds_bytes();
     else if (h->block)
         h->lds_bytes = ev2g_v2_lds_bytes(s.G * P, s.G * R, s.G, R);
@@ -533,6 +549,26 @@ int ev2g_reset(ev2g_handle *h, double *obs) {
 
 static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int auto_reset) {
     const DevScn &s = h->scn;
+    if (h->list_path) {
+        const V2P *pp = (const V2P *)h->d_v2p;
+#define EV2G_LIST_CASE(SK, RK)                                                                                        \
+    case SK * 3 + RK:                                                                                                 \
+        if (h->list_wb == 128)                                                                                        \
+            hipLaunchKernelGGL((ev2g_step_list<SK, RK, 128>), dim3(s.n_groups), dim3(128), h->lds_bytes, h->stream,   \
+                               pp, io, t0, k, auto_reset);                                                            \
+        else                                                                                                          \
+            hipLaunchKernelGGL((ev2g_step_list<SK, RK, 256>), dim3(s.n_groups), dim3(256), h->lds_bytes, h->stream,   \
+                               pp, io, t0, k, auto_reset);                                                            \
+        break;
+        switch (s.state_kind * 3 + s.reward_kind) {
+            EV2G_LIST_CASE(0, 0) EV2G_LIST_CASE(0, 1) EV2G_LIST_CASE(0, 2)
+            EV2G_LIST_CASE(1, 0) EV2G_LIST_CASE(1, 1) EV2G_LIST_CASE(1, 2)
+            EV2G_LIST_CASE(2, 0) EV2G_LIST_CASE(2, 1) EV2G_LIST_CASE(2, 2)
+        }
+#undef EV2G_LIST_CASE
+        HIPCHK(h, hipGetLastError());
+        return EV2G_OK;
+    }
     if (h->wave_path) {
         const V2P *pp = (const V2P *)h->d_v2p;
 #define EV2G_WAVE_CASE(SK, RK)                                                                                         \

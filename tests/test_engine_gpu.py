@@ -176,3 +176,37 @@ def test_engine_is_deterministic():
         res.append((d_obs.to_host(), d_rew.to_host()))
         eng.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("kernel", ["wave", "list", "list256", "v2"])
+@pytest.mark.parametrize("name,E,lo", [("v2gppl_c50_rand_s9", 131, -1.0), ("pst_rand_s2", 203, 0.0)])
+def test_every_kernel_variant_matches_oracle(kernel, name, E, lo, monkeypatch):
+    """The common shape (P <= 64, one transformer, single-port chargers) has three kernels: the wave-aligned default,
+    the attached-list kernel and the generic one.  All of them must reproduce the oracle, persistent launch included."""
+    from ev2gym_amd.engine import host_uniform
+    from oracle.oracle import Oracle
+    monkeypatch.setenv("EV2G_KERNEL", kernel)
+    batch, rk, sk = _tiled(name, E)
+    eng = _engine(batch, rk, sk, flags=4)
+    ora = Oracle(batch, rk, sk)
+    P, D, T = eng.P, eng.D, eng.T
+    K = T
+    d_act = eng.empty((K, E, P))
+    eng.fill_uniform(d_act, K * E * P, 31, lo, 1.0)
+    acts = host_uniform(K * E * P, 31, lo, 1.0).reshape(K, E, P)
+    d_obs, d_rew, d_mask = eng.empty((K, E, D)), eng.empty((K, E)), eng.empty((K, E, P), np.uint8)
+    eng.reset()
+    eng.step_n(40, d_act, E * P, d_obs, E * D, d_rew, E, None, 0, d_mask, E * P, auto_reset=False, persistent=True)
+    for k in range(40, K):   # finish the episode with single-step launches
+        eng.step(d_act.at(k * E * P), d_obs.at(k * E * D), d_rew.at(k * E), None, d_mask.at(k * E * P))
+    obs, rew, mask = d_obs.to_host(), d_rew.to_host(), d_mask.to_host()
+    ora.reset()
+    for k in range(K):
+        o_obs, o_rew, o_done, o_mask, rc = ora.step(acts[k].copy())
+        assert (mask[k] == o_mask).all(), f"mask[{k}]"
+        _close(obs[k], o_obs, f"obs[{k}]")
+        _close(rew[k], o_rew, f"reward[{k}]")
+    _close(eng.stats(), ora.stats(), "episode stats")
+    eng.check_faults()
+    eng.close()
+    ora.close()
