@@ -300,9 +300,14 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 acc += __shfl_xor(acc, 1, 64);
                 acc += __shfl_xor(acc, 2, 64);
                 acc += __shfl_xor(acc, 4, 64);
+                // hand the 8 sums (lanes 0, 8, ..., 56) to every lane of env w: v_readlane to SGPRs, no LDS crossbar trip
+                const long long acc64 = __double_as_longlong(acc);
+                const int lo32 = (int)(acc64 & 0xffffffffLL), hi32 = (int)(acc64 >> 32);
 #pragma unroll
                 for (int kq = 0; kq < EV2G_NQ; kq++) {
-                    const double v = __shfl(acc, kq * 8, 64);
+                    const unsigned rl = (unsigned)__builtin_amdgcn_readlane(lo32, kq * 8);
+                    const unsigned rh = (unsigned)__builtin_amdgcn_readlane(hi32, kq * 8);
+                    const double v = __longlong_as_double((long long)(((unsigned long long)rh << 32) | rl));
                     if (w == elw) esum[kq] = v;
                 }
             }
