@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     for (int i = tid; i < R; i += BLOCK) trobs[i] = S->tr_obs[i];
     for (int i = tid; i < ne * 5; i += BLOCK) eacc[i] = 0.0;
     for (int i = tid; i < ne; i += BLOCK) pot_prev[i] = (t < T) ? S->pot_hist[t * E + e0 + i] : 0.0;
-    double a_next = (valid && k_steps > 0 && t < T) ? io.actions[e * P + pref] : 0.0;
+    double a_next = io.actions[valid ? e * P + pref : e0 * P];
     __syncthreads();
 
     PT_DECL
@@ -316,39 +316,41 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             stage[7 * NS + tid_l] = 0.0;
             if (amps != 0.0) items[(amps > 0.0) ? atomicAdd(&cnt[0], 1) : NS - 1 - atomicAdd(&cnt[1], 1)] = tid_l;
             // next step's action: issued now, consumed after the barriers of this step
-            const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
-            a_next = more ? (io.actions + (long long)(kk + 1) * io.a_stride)[e_l * P + pref_l] : 0.0;
+
         }
         // ---- prefetch what phases C-E of this step need (issued AFTER phase A consumed its own operands, so that
         //      phase A never waits on them; the loads stay in flight across the LDS-only barriers) ----
-        double pf_infl = 0.0, pf_solar = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
-        if (tid_l < ne * R) {
-            const int erT = (e0 * R + tid_l) * T + t;
-            pf_infl = S->tr_infl[erT]; pf_solar = S->tr_solar[erT]; pf_maxp = S->tr_maxp[erT]; pf_minp = S->tr_minp[erT];
+        {
+            const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
+            a_next = (io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride)[valid ? e_l * P + pref_l : e0 * P];
         }
-        if (env_lane && pl_l == 0 && S->reward_kind == 1) pf_sp = S->setpoint[pe_l * T + t];
-        double pf_pch = 0.0, pf_pdis = 0.0;
-        if (valid) { pf_pch = S->price_ch[e_l * T + t]; pf_pdis = S->price_dis[e_l * T + t]; }
+        // Every prefetch is ONE unconditional load from a clamped (always valid) address; the conditions are applied where
+        // the value is consumed.  A load in a divergent branch whose result merges with a default makes the compiler
+        // serialise on the destination register (write-after-write) with a full vmcnt(0) drain.
+        const int erT = (e0 * R + min(tid_l, ne * R - 1)) * T + t;
+        const double pf_infl = S->tr_infl[erT], pf_solar = S->tr_solar[erT], pf_maxp = S->tr_maxp[erT], pf_minp = S->tr_minp[erT];
+        const int pec = e0 + min(pel_l, ne - 1);       // clamped env of this lane's env-level role
+        const double pf_sp = S->setpoint[pec * T + t];
+        const int evc = valid ? e_l : e0;              // clamped env of this lane's home role
+        const double pf_pch = S->price_ch[evc * T + t], pf_pdis = S->price_dis[evc * T + t];
         // head / window columns of the observation this step emits (step counter sstep): one coalesced load per lane
         double pf_ob0 = 0.0, pf_ob1 = 0.0;
         const int nhead = (S->state_kind == 1) ? 0 : 20 + ((S->state_kind == 0) ? 40 * R : 0);
-        if (env_lane && obs) {
-            if (S->state_kind == 1) {
-                if (pl_l == 0) pf_ob0 = (sstep < T) ? S->setpoint[pe_l * T + sstep] : 0.0;
-            } else {
+        if (S->state_kind == 1) {
+            pf_ob0 = S->setpoint[pec * T + min(sstep, T - 1)];   // consumed by pl == 0, masked by sstep < T
+        } else {
+            const double *pprice = (const double *)S->price_ch + pec * T;
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const int c = pl_l + u * lpe;
-                    double v = 0.0;
-                    if (c < 20) {
-                        const int k = sstep + c;
-                        v = (k < T) ? S->price_ch[pe_l * T + k] : 0.0;  // |.| is applied at the store: touching v here would stall on the load
-                    } else if (c < nhead) {
-                        const int i = c - 20, r = i / 40, j = i - r * 40;
-                        v = S->win_tab[(((long long)pe_l * R + r) * (T + 1) + sstep) * 40 + j];
-                    }
-                    if (u == 0) pf_ob0 = v; else pf_ob1 = v;
+            for (int u = 0; u < 2; u++) {
+                const int c = pl_l + u * lpe;
+                const double *pa = pprice;
+                if (c < 20) pa = pprice + min(sstep + c, T - 1);
+                else if (c < nhead) {
+                    const int i = c - 20, r = i / 40, j = i - r * 40;
+                    pa = (const double *)S->win_tab + (((long long)pec * R + r) * (T + 1) + sstep) * 40 + j;
                 }
+                const double v = *pa;
+                if (u == 0) pf_ob0 = v; else pf_ob1 = v;
             }
         }
 
@@ -589,14 +591,14 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             if (obs) {
                 double *o = obs + pe_l * D;
                 if (S->state_kind == 1) {  // PublicPST state.py:6-35
-                    if (pl_l == 0) { o[0] = (double)sstep / (double)T; o[1] = pf_ob0; o[2] = usage; }
+                    if (pl_l == 0) { o[0] = (double)sstep / (double)T; o[1] = (sstep < T) ? pf_ob0 : 0.0; o[2] = usage; }
                 } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135
                     if (pl_l == 0) { o[0] = (double)sstep; o[1] = usage; }
                     int c = pl_l;
-                    if (c < 20) o[2 + c] = fabs(pf_ob0);
+                    if (c < 20) o[2 + c] = (sstep + c < T) ? fabs(pf_ob0) : 0.0;
                     else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; o[trobs[r] + j] = pf_ob0; }
                     c = pl_l + lpe;
-                    if (c < 20) o[2 + c] = fabs(pf_ob1);
+                    if (c < 20) o[2 + c] = (sstep + c < T) ? fabs(pf_ob1) : 0.0;
                     else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; o[trobs[r] + j] = pf_ob1; }
                     // envs with more head columns than two passes of their lanes (many transformers): the rest, unprefetched
                     for (c = pl_l + 2 * lpe; c < nhead; c += lpe) {
