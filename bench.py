@@ -46,6 +46,16 @@ WORKLOADS = {
 }
 
 
+def kernel_name(batch, sk, rk):
+    """Which step kernel ev2g_load_scenarios() selects for this shape (ev2gym_amd/csrc/ev2g_host.hip)."""
+    P, R, npc = batch.n_ports, batch.n_transformers, batch.ports_per_charger
+    k = os.environ.get("EV2G_KERNEL", "")
+    if P <= 64 and R == 1 and npc == 1 and k != "v2":
+        return (f"ev2g_step_list<{sk},{rk},{256 if k == 'list256' else 128}>" if k in ("list", "list256") and P >= 4
+                else f"ev2g_step_wave<{sk},{rk}>")
+    return f"ev2g_step_v2<{256 if P <= 256 else 512 if P <= 512 else 1024}>" if P <= 1024 else "ev2g_step_kernel"
+
+
 def measured_traffic(workload, launch, steps_per_launch, envs):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes (profiles/r01_hbm_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH doubled per the gfx950 note in
@@ -210,7 +220,7 @@ def main():
         "env_steps_per_s_by_launch_mode": {m: env_steps_total / w for m, w in wall.items()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.workload, best, kern_steps / n_launch, E),
-                     "kernel": f"ev2g_step_v2<{256 if P <= 256 else 512 if P <= 512 else 1024}>" if P <= 1024 else "ev2g_step_kernel",
+                     "kernel": kernel_name(batch, sk, rk),
                      "avg_launch_us": launch_s * 1e6,
                      "steps_per_launch": kern_steps / n_launch,
                      "algorithmic_bytes_per_env_step": bytes_env_step},
