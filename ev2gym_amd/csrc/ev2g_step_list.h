@@ -223,8 +223,9 @@ __global__ void __launch_bounds__(WB, 4) ev2g_step_list(const V2P *__restrict__ 
                     if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
                         const double score = (cap < r.des - 0.001) ? cap / r.des : 1.0;
                         if (RK != 1) satpen = 100.0 * exp(-10.0 * score);
-                        S->cs_served[hg] += 1;
-                        S->cs_sat_sum[hg] += score;
+                        // fire-and-forget device atomics: no returned value => no memory round trip on this path
+                        __hip_atomic_fetch_add(&S->cs_served[hg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(&S->cs_sat_sum[hg], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         S->sess_final_cap[ss] = cap;
                         if (log_soc) S->sess_abs_e[ss] = s_abse[h];
                         ta = r.nt_arr; td = r.nt_dep;

@@ -423,8 +423,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
                     if (S->reward_kind != 1) satpen = 100.0 * exp(-10.0 * score);
                     const int gc = e_l * C + cs_l;
-                    if (npc == 1) { S->cs_served[gc] += 1; S->cs_sat_sum[gc] += score; }
-                    else { atomicAdd(&S->cs_served[gc], 1); atomicAdd(&S->cs_sat_sum[gc], score); }
+                    // fire-and-forget device atomics (no returned value => no memory round trip on this path)
+                    __hip_atomic_fetch_add(&S->cs_served[gc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&S->cs_sat_sum[gc], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     S->sess_final_cap[ss] = cap;
                     if (log_soc) S->sess_abs_e[ss] = s_abse[tid_l];
                     ta = r.nt_arr; td = r.nt_dep;

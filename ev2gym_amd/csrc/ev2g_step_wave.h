@@ -233,8 +233,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     const double des = r.des;
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
                     if (RK != 1) satpen = 100.0 * exp(-10.0 * score);
-                    S->cs_served[g_l] += 1;
-                    S->cs_sat_sum[g_l] += score;
+                    // fire-and-forget device atomics (no returned value => no memory round trip on this path); exactly one
+                    // lane updates a given charger per step, so the result does not depend on any ordering
+                    __hip_atomic_fetch_add(&S->cs_served[g_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&S->cs_sat_sum[g_l], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     S->sess_final_cap[ss] = cap;
                     if (log_soc) S->sess_abs_e[ss] = s_abse[tid_l];
                     ta = r.nt_arr; td = r.nt_dep;
