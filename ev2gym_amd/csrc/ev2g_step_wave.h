@@ -25,6 +25,20 @@ __host__ __device__ inline size_t ev2g_wave_lds_bytes() {
     return sizeof(double) * ((EV2G_NQ + 7) * NS + EV2G_WAVE_LUT_LDS) + sizeof(int) * (6 * NS + 8);
 }
 
+// xor-butterfly partners inside 8-lane groups through DPP (VALU cross-lane moves, a few cycles) instead of
+// ds_bpermute (an LDS crossbar round trip per step): quad_perm [1,0,3,2], quad_perm [2,3,0,1], and
+// quad_perm [3,2,1,0] followed by row_half_mirror (i -> 3-i in the quad, then 7-i in the half row = i ^ 4).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double xor1_f64(double v) { return dpp_mov_f64<0xB1>(v); }
+__device__ __forceinline__ double xor2_f64(double v) { return dpp_mov_f64<0x4E>(v); }
+__device__ __forceinline__ double xor4_f64(double v) { return dpp_mov_f64<0x141>(dpp_mov_f64<0x1B>(v)); }
+
 template <int SK, int RK>
 __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
                                                                      int k_steps, int auto_reset) {
@@ -294,14 +308,22 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
 #pragma unroll 1
             for (int w = 0; w < EPW; w++) {
                 const int a = wbase + w * P, b = a + P;
+                // all LDS reads of the segment are issued first (P <= 64: at most 4 + 4 per lane), then summed in the
+                // same order as the generic kernel's two chains
+                double xa[4], xb[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = a + j + 16 * u;
+                    xa[u] = (i < b) ? stage[k * NS + min(i, NS - 1)] : 0.0;
+                    xb[u] = (i + 8 < b) ? stage[k * NS + min(i + 8, NS - 1)] : 0.0;
+                }
                 double acc = 0.0, accb = 0.0;
-                int i = a + j;
-                for (; i + 8 < b; i += 16) { acc += stage[k * NS + i]; accb += stage[k * NS + i + 8]; }
-                if (i < b) acc += stage[k * NS + i];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { acc += xa[u]; accb += xb[u]; }
                 acc += accb;
-                acc += __shfl_xor(acc, 1, 64);
-                acc += __shfl_xor(acc, 2, 64);
-                acc += __shfl_xor(acc, 4, 64);
+                acc += xor1_f64(acc);
+                acc += xor2_f64(acc);
+                acc += xor4_f64(acc);
                 // hand the 8 sums (lanes 0, 8, ..., 56) to every lane of env w: v_readlane to SGPRs, no LDS crossbar trip
                 const long long acc64 = __double_as_longlong(acc);
                 const int lo32 = (int)(acc64 & 0xffffffffLL), hi32 = (int)(acc64 >> 32);
