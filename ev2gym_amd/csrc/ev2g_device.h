@@ -54,6 +54,7 @@ struct DevScn {  // read-only scenario + layout, device pointers
     const double *price_ch, *price_dis, *setpoint;
     // transformer series [E,R,T], [E,R]
     const double *tr_maxp, *tr_minp, *tr_infl, *tr_solar, *tr_lf, *tr_pvf, *tr_peak;
+    const double *tr_base;  // [E,R,T] inflexible_load + solar_power (Transformer.reset, transformer.py:262-263)
     const double *tr_dr;  // [E,R,ND,3]
     const int *tr_ndr, *tr_ahead;
     // sessions in device order (env, slot, arrival)

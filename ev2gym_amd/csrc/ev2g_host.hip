@@ -368,7 +368,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     const int blk = h->block ? h->block : EV2G_BLOCK;
     s.G = std::max(1, blk / P);
     s.G = std::min(s.G, E);
-    h->wave_path = (P <= 64 && R == 1 && npc == 1 && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY));
+    h->wave_path = (P >= 2 && P <= 64 && R == 1 && npc == 1 && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY));
     if (h->wave_path) s.G = (EV2G_WAVE_BLOCK / 64) * (64 / P);   // wave-aligned: 64/P envs per wavefront
     {
         // Kernel choice for the common shape.  Default: ev2g_step_wave (fastest measured).  EV2G_KERNEL
@@ -391,7 +391,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     if (h->list_path)
         h->lds_bytes = ev2g_list_lds_bytes(h->list_wb);
     else if (h->wave_path)
-        h->lds_bytes = ev2g_wave_lds_bytes();
+        h->lds_bytes = ev2g_wave_lds_bytes(s.G);
     else if (h->block)
         h->lds_bytes = ev2g_v2_lds_bytes(s.G * P, s.G * R, s.G, R);
     else
@@ -452,6 +452,11 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     UPP(dp, b->tr_load_forecast, (size_t)E * R * T) s.tr_lf = dp;
     UPP(dp, b->tr_pv_forecast, (size_t)E * R * T) s.tr_pvf = dp;
     UP(dp, tr_peak) s.tr_peak = dp;
+    {
+        std::vector<double> tr_base((size_t)E * R * T);
+        for (size_t i = 0; i < tr_base.size(); i++) tr_base[i] = b->tr_inflexible_load[i] + b->tr_solar_power[i];
+        UP(dp, tr_base) s.tr_base = dp;
+    }
     UPP(dp, b->tr_dr, (size_t)E * R * ND * 3) s.tr_dr = dp;
     UPP(ip, b->tr_n_dr, (size_t)E * R) s.tr_ndr = ip;
     UPP(ip, b->tr_steps_ahead, (size_t)E * R) s.tr_ahead = ip;

@@ -132,7 +132,7 @@ struct V2P {
     EV2G_GP(const double) cs_imax; EV2G_GP(const double) cs_imin; EV2G_GP(const double) cs_dmin;
     EV2G_GP(const double) cs_dmax_abs; EV2G_GP(const double) cs_maxp; EV2G_GP(const double) cs_minp;
     EV2G_GP(const double) price_ch; EV2G_GP(const double) price_dis; EV2G_GP(const double) setpoint;
-    EV2G_GP(const double) tr_infl; EV2G_GP(const double) tr_solar; EV2G_GP(const double) tr_maxp;
+    EV2G_GP(const double) tr_infl; EV2G_GP(const double) tr_solar; EV2G_GP(const double) tr_base; EV2G_GP(const double) tr_maxp;
     EV2G_GP(const double) tr_minp; EV2G_GP(const double) win_tab; EV2G_GP(const double) lut;
     EV2G_GP(const SessRec) rec;
     EV2G_GP(double) cap; EV2G_GP(double) tot_e; EV2G_GP(double) prev_power; EV2G_GP(double) bcap; EV2G_GP(double) potc;
@@ -155,7 +155,7 @@ inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
 #define CPT(f) EV2G_SETP(p.f, st.f);
     CPS(slot_cs) CPS(slot_port) CPS(slot_obs) CPS(tr_seg) CPS(tr_obs) CPS(port_first) CPS(port_first_win)
     CPS(cs_imax) CPS(cs_imin) CPS(cs_dmin) CPS(cs_dmax_abs) CPS(cs_maxp) CPS(cs_minp)
-    CPS(price_ch) CPS(price_dis) CPS(setpoint) CPS(tr_infl) CPS(tr_solar) CPS(tr_maxp) CPS(tr_minp)
+    CPS(price_ch) CPS(price_dis) CPS(setpoint) CPS(tr_infl) CPS(tr_solar) CPS(tr_base) CPS(tr_maxp) CPS(tr_minp)
     CPS(win_tab) CPS(lut) CPS(rec)
     CPT(cap) CPT(tot_e) CPT(prev_power) CPT(bcap) CPT(potc) CPT(win) CPT(sc) CPT(cs_sat_sum) CPT(cs_served)
     CPT(cs_profits) CPT(cs_e_ch) CPT(cs_e_dis) CPT(cs_power_hist) CPT(cs_cur_hist) CPT(cs_power_now) CPT(cs_cur_now)

@@ -20,9 +20,9 @@
 #define EV2G_WAVE_BLOCK 256
 #endif
 
-__host__ __device__ inline size_t ev2g_wave_lds_bytes() {
+__host__ __device__ inline size_t ev2g_wave_lds_bytes(int envs_per_group) {
     const size_t NS = EV2G_WAVE_BLOCK;
-    return sizeof(double) * ((EV2G_NQ + 7) * NS + EV2G_WAVE_LUT_LDS) + sizeof(int) * (6 * NS + 8);
+    return sizeof(double) * ((EV2G_NQ + 7) * NS + EV2G_WAVE_LUT_LDS + 6 * (size_t)envs_per_group + 4 * 64) + sizeof(int) * (6 * NS + 8);
 }
 
 // xor-butterfly partners inside 8-lane groups through DPP (VALU cross-lane moves, a few cycles) instead of
@@ -60,7 +60,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     double *s_tot = s_cap + NS, *s_prev = s_tot + NS, *s_bcap = s_prev + NS, *s_potc = s_bcap + NS;
     double *s_amps = s_potc + NS, *s_abse = s_amps + NS;
     double *s_lut = s_abse + NS;                           // [EV2G_WAVE_LUT_LDS] efficiency tables (fused launches only)
-    int *s_ta = (int *)(s_lut + EV2G_WAVE_LUT_LDS);
+    double *eacc = s_lut + EV2G_WAVE_LUT_LDS;              // [G][6] episode accumulators + charge_power_potential[t], per env
+    double *s_cst = eacc + 6 * G;                          // [4][64] per-charger gates and clamps (rarely changing operands
+                                                           // kept out of the register file): imin-0.01, dmin, max power, min power
+    int *s_ta = (int *)(s_cst + 4 * 64);
     int *s_td = s_ta + NS, *s_ss = s_td + NS, *s_cyc = s_ss + NS, *s_dirty = s_cyc + NS, *items = s_dirty + NS;
     int *cnt = items + NS;  // cnt[2*(kk&1) + {0 charge, 1 discharge}]
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -75,8 +78,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     const int g = valid ? e * P + q : 0;
     const int ocol = (SK == 1) ? 3 + 3 * q : (SK == 0 ? 62 + 2 * q : 22 + 2 * q);
     const int cs = valid ? q : 0;
-    const double c_imax = S->cs_imax[cs], c_thr_ch = S->cs_imin[cs] - 0.01, c_dmin = S->cs_dmin[cs], c_dmaxabs = S->cs_dmax_abs[cs];
-    const double c_maxp = S->cs_maxp[cs], c_minp = S->cs_minp[cs];
+    const double c_imax = S->cs_imax[cs], c_dmaxabs = S->cs_dmax_abs[cs];
+    if (tid < P) {
+        s_cst[0 * 64 + tid] = S->cs_imin[tid] - 0.01; s_cst[1 * 64 + tid] = S->cs_dmin[tid];
+        s_cst[2 * 64 + tid] = S->cs_maxp[tid]; s_cst[3 * 64 + tid] = S->cs_minp[tid];
+    }
     int t = t0;
     if (valid) {
         const int2 w = S->win[g];
@@ -91,8 +97,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         }
     }
     const bool head = valid && q == 0;   // one lane per env: env-level scalars
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0, acc4 = 0.0;   // episode accumulators (head lanes)
-    double pot_prev = (head && t < T) ? S->pot_hist[t * E + e] : 0.0;   // charge_power_potential[t]
+    const int elg = wv * EPW + elw;      // env inside the workgroup
+    if (head) {   // episode accumulators and charge_power_potential[t] live in LDS (only head lanes use them)
+        for (int i = 0; i < 5; i++) eacc[elg * 6 + i] = 0.0;
+        eacc[elg * 6 + 5] = (t < T) ? S->pot_hist[t * E + e] : 0.0;
+    }
     if (tid < 4) cnt[tid] = 0;
     for (int k = 0; k < EV2G_NQ; k++) stage[k * NS + tid] = 0.0;
     // a fused launch amortises staging the efficiency tables in LDS: the table look-up then no longer adds an L2 round
@@ -119,9 +128,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 S->cs_sat_sum[g_l] = 0.0;   // single-port chargers: charger index == port index
                 S->cs_served[g_l] = 0;
             }
-            if (head) { for (int i = 0; i < 8; i++) S->env_acc[e_l * 8 + i] = 0.0; }
-            acc0 = acc1 = acc2 = acc3 = acc4 = 0.0;
-            pot_prev = 0.0;
+            if (head) {
+                for (int i = 0; i < 8; i++) S->env_acc[e_l * 8 + i] = 0.0;
+                for (int i = 0; i < 6; i++) eacc[elg * 6 + i] = 0.0;
+            }
             t = 0;
         }
         double *__restrict__ obs = io.obs ? io.obs + (long long)kk * io.o_stride : nullptr;
@@ -138,13 +148,14 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             occ = (ta <= t) && (t <= td);
             if (log_soc && occ) cap_before = s_cap[tid_l];
             double a = occ ? a_next : 0.0;
-            if (a > 1.0) a = a / a;            // one port per charger: a / sum(a)
-            else if (a < -1.0) a = -a / a;
+            // one port per charger: a / sum(a) = a / a, which is exactly +-1 for every finite action (ev_charger.py:143-149)
+            if (a > 1.0) a = 1.0;
+            else if (a < -1.0) a = -1.0;
             double amps = 0.0;
             if (occ) {
                 const double x = rnd5(a);
-                if (x > 0.0) { amps = x * c_imax; if (amps < c_thr_ch) amps = 0.0; }
-                else if (x < 0.0) { amps = x * c_dmaxabs; if (amps > c_dmin - 0.01) amps = c_dmin; }
+                if (x > 0.0) { amps = x * c_imax; if (amps < s_cst[0 * 64 + q_l]) amps = 0.0; }
+                else if (x < 0.0) { const double c_dmin = s_cst[1 * 64 + q_l]; amps = x * c_dmaxabs; if (amps > c_dmin - 0.01) amps = c_dmin; }
             }
             s_amps[tid_l] = amps;
             stage[0 * NS + tid_l] = 0.0;
@@ -164,8 +175,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const int gc = valid ? g_l : e0 * P;
         a_next = (io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride)[gc];
         const double pf_pch = S->price_ch[ec * T + t], pf_pdis = S->price_dis[ec * T + t];
-        double pf_infl = 0.0, pf_solar = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
-        if (RK == 0) { pf_infl = S->tr_infl[ec * T + t]; pf_solar = S->tr_solar[ec * T + t]; pf_maxp = S->tr_maxp[ec * T + t]; pf_minp = S->tr_minp[ec * T + t]; }
+        double pf_base = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
+        if (RK == 0) { pf_base = S->tr_base[ec * T + t]; pf_maxp = S->tr_maxp[ec * T + t]; pf_minp = S->tr_minp[ec * T + t]; }
         if (RK == 1) pf_sp = S->setpoint[ec * T + t];
         // observation head columns of this env, distributed over its P lanes: column c = q, q+P, q+2P
         double pf_ob0 = 0.0, pf_ob1 = 0.0, pf_ob2 = 0.0;
@@ -283,7 +294,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 else { o0 = soc; o1 = (double)(td - sstep); }
                 if (soc < 1.0 && td > sstep) pot = s_potc[tid_l];  // utils.py:771
             }
-            pot = (pot > c_maxp) ? c_maxp : ((pot < c_minp) ? 0.0 : pot);  // per-charger clamp (utils.py:779-789)
+            {   // per-charger clamp (utils.py:779-789)
+                const double c_maxp = s_cst[2 * 64 + q_l], c_minp = s_cst[3 * 64 + q_l];
+                pot = (pot > c_maxp) ? c_maxp : ((pot < c_minp) ? 0.0 : pot);
+            }
             if (obs) {
                 double *o = obs + (e_l * D + ocol);
                 o[0] = o0;
@@ -341,9 +355,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // ---------------- E: per env (head lane) + observation head (the env's lanes) ----------------
         const double usage = esum[0];
         if (head) {
+            double *ea = eacc + elg * 6;
             double over100 = 0.0;
             if (RK == 0) {  // Transformer.reset + step + get_how_overloaded (transformer.py:258-302)
-                double ptr = pf_infl + pf_solar;
+                double ptr = pf_base;   // inflexible_load[t] + solar_power[t]
                 ptr += usage;
                 const double over = (ptr > pf_maxp + 0.0001 || ptr < pf_minp - 0.0001) ? fabs(ptr - pf_maxp) : 0.0;
                 S->over_hist[t * E + e_l] = over;
@@ -351,7 +366,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 over100 = 100.0 * over;
             } else {
                 const int erT = e_l * T + t;
-                double ptr = S->tr_infl[erT] + S->tr_solar[erT];
+                double ptr = S->tr_base[erT];
                 ptr += usage;
                 const double mx = S->tr_maxp[erT], mn = S->tr_minp[erT];
                 const double over = (ptr > mx + 0.0001 || ptr < mn - 0.0001) ? fabs(ptr - mx) : 0.0;
@@ -364,7 +379,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             const double costs = esum[1];
             double reward;
             if (RK == 1) {  // SquaredTrackingErrorReward reward.py:7-14
-                const double m = (pot_prev < pf_sp) ? pot_prev : pf_sp;
+                const double pp = ea[5];
+                const double m = (pp < pf_sp) ? pp : pf_sp;
                 const double d = m - usage;
                 reward = -(d * d);
             } else if (RK == 2) {  // profit_maximization reward.py:78-87
@@ -372,14 +388,13 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
                 reward = costs - over100 - esum[2];
             }
-            pot_prev = potn;
-            acc0 += reward; acc1 += costs; acc2 += esum[4]; acc3 += esum[5]; acc4 += esum[6];
+            ea[5] = potn;
+            ea[0] += reward; ea[1] += costs; ea[2] += esum[4]; ea[3] += esum[5]; ea[4] += esum[6];
             if (io.reward) io.reward[(long long)kk * io.r_stride + e_l] = reward;
             if (io.done) io.done[(long long)kk * io.d_stride + e_l] = (sstep >= T) ? 1 : 0;
             if (sstep >= T || last_step) {  // flush the episode accumulators (get_statistics reads them)
                 auto ga = S->env_acc + e_l * 8;
-                ga[0] += acc0; ga[1] += acc1; ga[2] += acc2; ga[3] += acc3; ga[4] += acc4;
-                acc0 = acc1 = acc2 = acc3 = acc4 = 0.0;
+                for (int i = 0; i < 5; i++) { ga[i] += ea[i]; ea[i] = 0.0; }
             }
         }
         if (valid && obs) {
