@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     for (int i = tid; i < lut_lds_n; i += EV2G_WAVE_BLOCK) s_lut[i] = S->lut[i];
     double a_next = io.actions[valid ? g : e0 * P];
     __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_next));   // the first action has landed: a plain value for the loop
 
     PT_DECL
     for (int kk = 0; kk < k_steps; kk++) {
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const int ec = valid ? e_l : e0;   // clamped env for idle lanes
         const int gc = valid ? g_l : e0 * P;
         a_next = (io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride)[gc];
-        const double pf_pch = S->price_ch[ec * T + t], pf_pdis = S->price_dis[ec * T + t];
+        double pf_pch = S->price_ch[ec * T + t], pf_pdis = S->price_dis[ec * T + t];
         double pf_base = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
         if (RK == 0) { pf_base = S->tr_base[ec * T + t]; pf_maxp = S->tr_maxp[ec * T + t]; pf_minp = S->tr_minp[ec * T + t]; }
         if (RK == 1) pf_sp = S->setpoint[ec * T + t];
@@ -238,6 +239,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
 
         // ---------------- C: home lanes (from here on everything of one env lives in one wavefront) ----------------
         __builtin_amdgcn_s_waitcnt(0x0F70);   // collect the prefetches before this phase issues stores (vmcnt(0))
+        // ... and make that visible to the compiler's wait-count tracking: as outputs of this (empty) asm the
+        // prefetched registers are plain values from here on, so their later uses -- after this phase's stores, and
+        // across the loop back-edge for the next action -- no longer cost a conservative vmcnt(0) drain
+        asm volatile("" : "+v"(a_next), "+v"(pf_pch), "+v"(pf_pdis), "+v"(pf_base), "+v"(pf_maxp), "+v"(pf_minp),
+                     "+v"(pf_sp), "+v"(pf_ob0), "+v"(pf_ob1), "+v"(pf_ob2));
         if (valid) {
             double profit = 0.0, satpen = 0.0, pot = 0.0;
             int ta = s_ta[tid_l], td = s_td[tid_l];
