@@ -8,7 +8,7 @@ timed region contains the step kernels, the per-episode statistics kernel, the p
 N > 1 -- the RCCL all-gather of the episode statistics (the only collective on the path).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4] [--envs E_per_gpu]
-                  [--launch per_step|persistent]
+                  [--launch per_step|persistent] [--actor mlp]
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
 """
@@ -95,8 +95,28 @@ def cpu_baseline(batch, rk, sk, lo, budget_s=12.0):
         t_total += time.perf_counter() - t0
         steps += E * T
         episodes += 1
+    # same oracle, one thread per host core over disjoint env ranges (envs are independent; ctypes drops the GIL)
+    import threading
+    nthr = max(1, min(os.cpu_count() or 1, n // 8))
+    bounds = np.linspace(0, E, nthr + 1).astype(int)
+    mt_steps, mt_total, mt_eps = 0, 0.0, 0
+    while nthr > 1 and mt_total < budget_s / 3 and mt_eps < 64:
+        ora.reset()
+        a = acts.copy()
+
+        def work(i):
+            for t in range(T):
+                ora.step_range_nocopy(int(bounds[i]), int(bounds[i + 1]), a[t], obs, rew, done, mask)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(nthr)]
+        t0 = time.perf_counter()
+        [x.start() for x in th]
+        [x.join() for x in th]
+        mt_total += time.perf_counter() - t0
+        mt_steps += E * T
+        mt_eps += 1
+    all_cores = dict(value=mt_steps / mt_total, cores=nthr, episodes=mt_eps) if mt_eps else None
     ora.close()
-    return dict(value=steps / t_total, unit="env-steps/s", cores=1, kind="port",
+    return dict(value=steps / t_total, unit="env-steps/s", cores=1, kind="port", all_cores=all_cores,
                 sample=f"{n} envs x {episodes} episodes x {T} steps of the same workload, C oracle -O2, 1 thread; "
                        f"reference CPython step() measured at build time: 1075 env-steps/s/core at 50 chargers (BASELINE.md)")
 
@@ -111,8 +131,13 @@ def main():
     ap.add_argument("--launch", default="auto", choices=["auto", "per_step", "persistent"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-soc-log", action="store_true", help="skip the SoC log that the battery-degradation statistics need")
+    ap.add_argument("--actor", default="none", choices=["none", "mlp"],
+                    help="mlp: BASELINE configs[4]-shaped rollout -- a torch actor (obs->400->300->P, tanh; SB3-DDPG shape, "
+                         "random weights, fp32) produces the actions on the device between steps (forces per_step launches)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
+    if args.actor != "none":
+        args.launch = "per_step"
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -150,13 +175,30 @@ def main():
     stats = torch.empty((E, _abi.N_STATS), dtype=torch.float64, device=dev)
     gathered = torch.empty((world * E, _abi.N_STATS), dtype=torch.float64, device=dev) if world > 1 else None
 
+    actor = None
+    if args.actor == "mlp":
+        torch.manual_seed(1234 + rank)
+        lo_a = wl["lo"]
+        net = torch.nn.Sequential(torch.nn.Linear(D, 400), torch.nn.ReLU(), torch.nn.Linear(400, 300), torch.nn.ReLU(),
+                                  torch.nn.Linear(300, P), torch.nn.Tanh()).to(dev)
+        a_buf = torch.empty((E, P), dtype=torch.float64, device=dev)
+
+        @torch.no_grad()
+        def actor(o):
+            a = net(o.to(torch.float32))
+            if lo_a == 0.0:
+                a = a * 0.5 + 0.5
+            a_buf.copy_(a)
+            return a_buf
+
     def run(n_steps, persistent, timing=None):
         """n_steps batched steps; whole episodes where possible; stats (+gather) and reset at episode ends."""
         left = n_steps
         while left > 0:
             t = eng.current_step
-            k = min(left, T - t)
-            eng.step_n(k, acts[t], E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=persistent)
+            k = 1 if actor is not None else min(left, T - t)
+            a_src = actor(obs) if actor is not None else acts[t]
+            eng.step_n(k, a_src, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=persistent)
             if timing is not None:
                 timing.append((eng.last_step_n_kernel_ms(), k))
             left -= k
@@ -214,7 +256,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": E, "chargers": C_,
                    "transformers": R_, "steps_per_episode": T, "obs_dim": D, "occupancy_phi": round(phi, 4), "soc_log": not args.no_soc_log,
-                   "launch": best, "parallelism": f"env-sharded x{world}, RCCL all_gather of episode stats only"},
+                   "launch": best, "actor": args.actor, "parallelism": f"env-sharded x{world}, RCCL all_gather of episode stats only"},
         "port_steps_per_s": value * P,
         "wall_s_by_launch_mode": {m: round(w, 6) for m, w in wall.items()},
         "env_steps_per_s_by_launch_mode": {m: env_steps_total / w for m, w in wall.items()},

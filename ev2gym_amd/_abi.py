@@ -23,6 +23,10 @@ STAT_NAMES = [  # get_statistics(), utilities/utils.py:84-101
     'total_transformer_overload', 'battery_degradation', 'battery_degradation_calendar',
     'battery_degradation_cycling', 'total_reward']
 
+# grid-simulation keys of the same dict (utils.py:103-112): constant 0 because simulate_grid is out of scope
+GRID_STAT_ZEROS = ('saved_grid_energy', 'voltage_violation', 'voltage_violation_counter',
+                   'voltage_violation_counter_per_step')
+
 ERR_DONE = -4
 ERR_OVERCURRENT = -5
 FLAG_LOG_CS_HISTORY = 1

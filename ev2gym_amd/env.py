@@ -236,8 +236,12 @@ class EV2Gym:
                  lightweight_plots=False, empty_ports_at_end_of_simulation=True, extra_sim_name=None, verbose=False,
                  render_mode=None, scenario: Optional[ScenarioBatch] = None, device: int = 0,
                  log_cs_history: bool = True):
-        if load_from_replay_path is not None or save_replay or save_plots or render_mode:
-            raise NotImplementedError("replay files, plots and rendering are outside the accelerated path (SURVEY.md §2)")
+        if save_replay or save_plots or render_mode:
+            raise NotImplementedError("writing replay pickles, plots and rendering are outside the accelerated path (SURVEY.md §2)")
+        if scenario is None and load_from_replay_path is not None:   # ev2gym_env.py:102-116
+            from .replay import load_replay
+            v2g = bool(load_yaml(config_file)["v2g_enabled"]) if config_file is not None else None
+            scenario = load_replay(load_from_replay_path, v2g_enabled=v2g)
         if scenario is None:
             assert config_file is not None, "Please provide a config file!!!"   # ev2gym_env.py:64
             self.config = load_yaml(config_file)
@@ -363,6 +367,7 @@ class EV2Gym:
             self.done = True
             st = self.engine.stats()[0]
             self.stats = {k: st[i] for i, k in enumerate(_abi.STAT_NAMES)}
+            self.stats.update({k: 0 for k in _abi.GRID_STAT_ZEROS})
             if self._host_reward:
                 self.stats["total_reward"] = self.total_reward
             self.stats["action_mask"] = mask

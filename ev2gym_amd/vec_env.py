@@ -60,7 +60,8 @@ class EV2GymVec:
     def __init__(self, config_file=None, num_envs: int = 1, device: int = 0, state_function="PublicPST",
                  reward_function="SquaredTrackingErrorReward", cost_function=None, seed: Optional[int] = None,
                  scenarios: Optional[ScenarioBatch] = None, auto_reset: bool = False, log_cs_history: bool = False, log_soc: bool = True,
-                 use_torch: Optional[bool] = None, rank: int = 0, world_size: int = 1, verbose: bool = False, **unused):
+                 use_torch: Optional[bool] = None, rank: int = 0, world_size: int = 1, verbose: bool = False,
+                 load_from_replay_path=None, **unused):
         self.state_kind = _kind(state_function, _abi.STATE_KINDS, "state_function")
         self.reward_kind = _kind(reward_function, _abi.REWARD_KINDS, "reward_function")
         if self.state_kind is None or self.reward_kind is None:
@@ -71,6 +72,11 @@ class EV2GymVec:
         if cost_function is not None:
             raise NotImplementedError("cost_function is evaluated by the single-env facade only")
         self.seed = 0 if seed is None else int(seed)
+        if scenarios is None and load_from_replay_path is not None:
+            # one replay file, or a list of them recorded with the same config: one env per file (ev2gym_env.py:102-116)
+            from .replay import load_replay
+            paths = [load_from_replay_path] if isinstance(load_from_replay_path, (str, bytes, bytearray)) else list(load_from_replay_path)
+            scenarios = ScenarioBatch.concat([load_replay(p) for p in paths]) if len(paths) > 1 else load_replay(paths[0])
         if scenarios is None:
             if config_file is None:
                 raise AssertionError("Please provide a config file!!!")   # ev2gym_env.py:64
@@ -197,7 +203,10 @@ class EV2GymVec:
     def get_statistics(self) -> dict:
         """Per-env episode statistics, keys of get_statistics() (utilities/utils.py:84-101), each an [E] array."""
         st = self.engine.stats()
-        return {k: st[:, i] for i, k in enumerate(_abi.STAT_NAMES)}
+        out = {k: st[:, i] for i, k in enumerate(_abi.STAT_NAMES)}
+        zero = st[:, 0] * 0
+        out.update({k: zero for k in _abi.GRID_STAT_ZEROS})
+        return out
 
     def get_statistics_all_ranks(self):
         """[world*E, 17] statistics of every rank (one RCCL all-gather per episode)."""

@@ -141,12 +141,13 @@ def extract_scenario(env):
     return s
 
 
-def run_case(name, config, state_fn, reward_fn, seed, policy, steps=None):
+def run_case(name, config, state_fn, reward_fn, seed, policy, steps=None, env=None, extra=None):
     from ev2gym.models.ev2gym_env import EV2Gym
     import ev2gym.rl_agent.state as S
     import ev2gym.rl_agent.reward as RW
-    env = EV2Gym(config_file=config, seed=seed, state_function=getattr(S, state_fn),
-                 reward_function=getattr(RW, reward_fn), generate_rnd_game=True)
+    if env is None:
+        env = EV2Gym(config_file=config, seed=seed, state_function=getattr(S, state_fn),
+                     reward_function=getattr(RW, reward_fn), generate_rnd_game=True)
     obs0, _ = env.reset(seed=seed)
     scn = extract_scenario(env)
     T = env.simulation_length
@@ -234,6 +235,7 @@ def run_case(name, config, state_fn, reward_fn, seed, policy, steps=None):
         trj["trj_stats"] = np.array([float(info[k]) for k in STAT_KEYS])
     out = dict(scn)
     out.update(trj)
+    out.update(extra or {})
     out["act"] = act[:nT]
     out["case"] = np.array([name, os.path.basename(config), state_fn, reward_fn, str(seed), policy])
     os.makedirs(OUT, exist_ok=True)
@@ -242,6 +244,40 @@ def run_case(name, config, state_fn, reward_fn, seed, policy, steps=None):
     occ = trj["trj_mask"].mean()
     print(f"{name:28s} P={P:5d} R={R:3d} D={D:5d} S={S_:4d} occ={occ:.3f} "
           f"size={os.path.getsize(path)/1024:.0f} KB", flush=True)
+
+
+REPLAY_TENSORS = ("u", "ev_arrival", "t_dep", "energy_at_arrival", "ev_max_energy", "ev_max_ch_power",
+                  "ev_max_dis_power", "ev_des_energy", "port_max_charge_current", "port_min_charge_current",
+                  "port_max_discharge_current", "port_min_discharge_current", "voltages", "cs_transformer",
+                  "charge_prices", "discharge_prices", "power_setpoints")
+
+
+def run_replay_case(name, config, state_fn, reward_fn, seed, policy):
+    """Replay round trip (replay.py:10-174, ev2gym_env.py:102-116): episode A is recorded with save_replay=True,
+    env B is constructed from the pickle and driven with `policy`; the fixture holds the pickle bytes (data the
+    reference wrote), B's scenario / trajectory and the tensors EvCityReplay derived."""
+    import glob
+    import pickle
+    import shutil
+    from ev2gym.models.ev2gym_env import EV2Gym
+    import ev2gym.rl_agent.state as S
+    import ev2gym.rl_agent.reward as RW
+    rdir = f"/tmp/ev2g_replay/{name}/"
+    shutil.rmtree(rdir, ignore_errors=True)
+    os.makedirs(rdir)
+    kw = dict(config_file=config, state_function=getattr(S, state_fn), reward_function=getattr(RW, reward_fn))
+    env_a = EV2Gym(seed=seed, generate_rnd_game=True, save_replay=True, replay_save_path=rdir, **kw)
+    env_a.reset(seed=seed)
+    for _ in range(env_a.simulation_length):
+        env_a.step(np.ones(env_a.number_of_ports))
+    pkl = glob.glob(rdir + "*.pkl")[0]
+    blob = open(pkl, "rb").read()
+    rep = pickle.loads(blob)
+    extra = {"replay_pkl": np.frombuffer(blob, np.uint8)}
+    for k in REPLAY_TENSORS:
+        extra["rep_" + k] = np.asarray(getattr(rep, k), float)
+    env_b = EV2Gym(load_from_replay_path=pkl, **kw)
+    run_case(name, config, state_fn, reward_fn, seed, policy, env=env_b, extra=extra)
 
 
 def main():
@@ -292,6 +328,11 @@ def main():
         if only and c[0] not in only:
             continue
         run_case(*c)
+    # replay files: the reference's on-disk scenario format
+    for c in [("replay_v2gppl_p2_rand_s21", p2, *PPL, 21, "rand"), ("replay_pst_rand_s22", pst, *PST, 22, "rand")]:
+        if only and c[0] not in only:
+            continue
+        run_replay_case(*c)
 
 
 if __name__ == "__main__":
