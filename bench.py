@@ -104,9 +104,8 @@ def cpu_baseline(batch, rk, sk, lo, budget_s=12.0):
         ora.reset()
         a = acts.copy()
 
-        def work(i):
-            for t in range(T):
-                ora.step_range_nocopy(int(bounds[i]), int(bounds[i + 1]), a[t], obs, rew, done, mask)
+        def work(i):   # one C call per thread and episode
+            ora.run_range_nocopy(int(bounds[i]), int(bounds[i + 1]), T, a, E * P, obs, rew, done, mask)
         th = [threading.Thread(target=work, args=(i,)) for i in range(nthr)]
         t0 = time.perf_counter()
         [x.start() for x in th]

@@ -480,6 +480,11 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     UP(dp, ss_etach) s.ss_etach = dp;
     UP(dp, ss_etadis) s.ss_etadis = dp;
     UPP(dp, b->lut, (size_t)b->n_lut * EV2G_LUT_LEN) s.lut = dp;
+    // the same tables as efficiencies (percent / 100, the division of ev.py:290,379 done once): what V2P::lut points at
+    std::vector<double> lut_eta((size_t)b->n_lut * EV2G_LUT_LEN);
+    for (size_t i = 0; i < lut_eta.size(); i++) lut_eta[i] = b->lut[i] / 100.0;
+    double *d_lut_eta = nullptr;
+    UP(d_lut_eta, lut_eta)
     UP(ip, port_first) s.port_first = ip;
     UP(i2p, port_first_win) s.port_first_win = i2p;
     UP(dp, ss_afap) h->d_ss_afap = dp;
@@ -520,6 +525,9 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     {
         V2P v2p;
         ev2g_v2_fill_params(v2p, h->scn, h->st);
+        EV2G_SETP(v2p.lut, d_lut_eta);
+        int ex = 0;   // 60/dt a power of two and dt/60 its exact reciprocal -> divisions by them are multiplications
+        v2p.pow2_dt = (std::frexp(h->scn.sixty_over_dt, &ex) == 0.5 && h->scn.sixty_over_dt * h->scn.dt_over_60 == 1.0) ? 1 : 0;
         if ((rc = upload(h, sp, &v2p, 1, &h->d_v2p))) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging vectors die here

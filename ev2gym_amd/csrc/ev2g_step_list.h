@@ -58,6 +58,7 @@ __global__ void __launch_bounds__(WB, 4) ev2g_step_list(const V2P *__restrict__ 
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const bool log_soc = S->soc_log != nullptr;
     const double dtd = (double)S->dt, sixty_over_dt = S->sixty_over_dt, dt_over_60 = S->dt_over_60;
+    const bool pow2_dt = S->pow2_dt != 0;
 
     // ---- home lane set-up: port state -> LDS ----
     const int elw = lane / P;
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(WB, 4) ev2g_step_list(const V2P *__restrict__ 
                     double a = s_act[h];
                     if (a > 1.0) a = a / a;
                     else if (a < -1.0) a = -a / a;
-                    const double x = rnd5(a);
+                    const double x = rnd5_x(a);
                     double amps = 0.0;
                     if (x > 0.0) { amps = x * c_imax; if (amps < S->cs_imin[hq] - 0.01) amps = 0.0; }
                     else if (x < 0.0) { const double dmin = S->cs_dmin[hq]; amps = x * S->cs_dmax_abs[hq]; if (amps > dmin - 0.01) amps = dmin; }
@@ -197,11 +198,11 @@ __global__ void __launch_bounds__(WB, 4) ev2g_step_list(const V2P *__restrict__ 
                     const double cap_before = cap;
                     double energy = 0.0, current = 0.0;
                     if (amps != 0.0) {
-                        double lutv = 1.0;
+                        double lutv = 1.0 / 100.0;
                         if (r.lut >= 0) { const int li = ev_lut_index(r.lut, amps); if (li >= 0) lutv = S->lut[li]; }
                         const double prev0 = s_prev[h];
                         const int cyc0 = s_cyc[h];
-                        const EvRes o = ev_math(r, lutv, amps, cap, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd);
+                        const EvRes o = ev_math(r, lutv, amps, cap, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt);
                         dirty = (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap || o.prev_power != prev0);
                         cap = o.cap;
                         s_prev[h] = o.prev_power;

@@ -27,6 +27,10 @@
 #define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(); unsigned long long pt_acc[8] = {0,0,0,0,0,0,0,0};
 #define PT_MARK(i) { unsigned long long n_ = __builtin_readcyclecounter(); pt_acc[i] += n_ - pt_last; pt_last = n_; }
 #define PT_FLUSH if (threadIdx.x == 0 && S->dbg) { for (int i_ = 0; i_ < 8; i_++) S->dbg[(size_t)blockIdx.x * 8 + i_] += pt_acc[i_]; }
+#elif defined(EV2G_PHASE_MARKERS)   /* ISA analysis only: phase boundaries as comments in the -S output */
+#define PT_DECL
+#define PT_MARK(i) asm volatile("; PHASE_MARK " #i);
+#define PT_FLUSH
 #else
 #define PT_DECL
 #define PT_MARK(i)
@@ -45,26 +49,37 @@ struct EvRes {
 
 // EV.step + _charge/_discharge (ev.py:138-186, :240-355, :357-405) from one session record.
 // Same operation order as the reference (and as oracle/ev2g_oracle.c); -ffp-contract=off.
-// `lutv` is the efficiency-table entry for this step's current (percent), looked up by the caller:
+// `lutv` is the efficiency-table entry for this step's current ALREADY divided by 100 (V2P::lut), looked up by the caller:
 // dict.get(np.round(amps), 1) for charging, dict.get(abs(np.round(amps)), 1) for discharging (ev.py:287-290, :375-379).
 __device__ __forceinline__ int ev_lut_index(int lut, double amps) {
     const double key = fabs(rint(amps));  // np.round = half-even; charging amps are positive
     return (key <= 100.0) ? lut * 101 + (int)key : -1;  // -1: key outside 0..100 -> the dict default 1
 }
+//
+// Divisions are the expensive part (~14 instructions each).  Only rewrites that are exact for EVERY input are used:
+//   * `previous_power / amps < 0` (ev.py:166) is a sign test: both operands are finite and non-zero here and the
+//     quotient of values of these magnitudes cannot underflow to -0;
+//   * `lutv` arrives already divided by 100 (the host divides the table once, same IEEE operation);
+//   * `1 <= (pts - soc) / pilot_dsoc` (ev.py:318) is `pts - soc >= pilot_dsoc`: for y > 0 the correctly rounded
+//     quotient is >= 1 exactly when x >= y (x < y gives x/y <= 1 - 2^-53, which rounds below 1);
+//   * when 60/dt is a power of two (dt = 15, 30, 60 -- every shipped config) `x / (60/dt)` is `x * (dt/60)` and
+//     `x / (dt/60)` is `x * (60/dt)`, bit for bit (`pow2_dt`, uniform);
+//   * the final `ceil(cap*100)/100` goes through div_int_by_const (exhaustively verified range).
 __device__ __forceinline__ EvRes ev_math(const SessRec &r, double lutv, double amps, double cap,
                                          double prev_power, double tot_e, int cycles, double sixty_over_dt,
-                                         double dt_over_60, double dt) {
+                                         double dt_over_60, double dt, bool pow2_dt) {
     EvRes o;
     o.cap = cap; o.prev_power = prev_power; o.tot_e = tot_e; o.energy = 0.0; o.current = 0.0; o.cycles = cycles; o.emerg = 0;
     if (amps > 0.0 && amps < r.gate_ch) amps = 0.0;
     else if (amps < 0.0 && amps > r.gate_dis) amps = 0.0;
     if (amps == 0.0) return o;  // ev.py:158-163: no ceil, previous_power untouched
-    if (prev_power == 0.0 || (prev_power / amps) < 0.0) o.cycles = cycles + 1;
+    if (prev_power == 0.0 || ((prev_power < 0.0) != (amps < 0.0))) o.cycles = cycles + 1;
     const double B = r.B, v = r.v;
     if (amps > 0.0) {
-        const double eta = (r.lut >= 0) ? lutv / 100.0 : r.eta_ch;
-        double pilot_dsoc = eta * amps * v / 1000.0 / B / sixty_over_dt;
-        const double max_dsoc = eta * r.pacmax / B / sixty_over_dt;
+        const double eta = (r.lut >= 0) ? lutv : r.eta_ch;
+        const double pd0 = eta * amps * v / 1000.0 / B, md0 = eta * r.pacmax / B;
+        double pilot_dsoc = pow2_dt ? pd0 * dt_over_60 : pd0 / sixty_over_dt;
+        const double max_dsoc = pow2_dt ? md0 * dt_over_60 : md0 / sixty_over_dt;
         if (pilot_dsoc > max_dsoc) pilot_dsoc = max_dsoc;
         const double soc = cap / B;
         double curr_soc;
@@ -79,18 +94,18 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, double lutv, double a
             const double num = below ? r.tsm * (pilot_dsoc + soc - pts) : r.tsm * pilot_dsoc;
             const double fac = below ? (pts - 1.0) : (soc - 1.0);
             double new_soc = 1.0 + exp(num / (pts - 1.0)) * fac;
-            if (below && 1.0 <= (pts - soc) / pilot_dsoc) new_soc = pilot_dsoc + soc;
+            if (below && (pilot_dsoc > 0.0 ? (pts - soc >= pilot_dsoc) : (1.0 <= (pts - soc) / pilot_dsoc))) new_soc = pilot_dsoc + soc;
             const double lim = (max_dsoc > pilot_dsoc) ? pilot_dsoc : max_dsoc;
             curr_soc = (new_soc - soc > lim) ? (lim + soc) : new_soc;
         }
         const double dsoc = curr_soc - soc;
         o.cap = curr_soc * B;
         o.energy = dsoc * B;
-        o.current = o.energy / dt_over_60 * 1000.0 / v;
+        o.current = (pow2_dt ? o.energy * sixty_over_dt : o.energy / dt_over_60) * 1000.0 / v;
     } else {
         double given_power = amps * v / 1000.0;
         if (fabs(given_power) > fabs(r.pdismax)) given_power = r.pdismax;
-        const double eta = (r.lut >= 0) ? lutv / 100.0 : r.eta_dis;
+        const double eta = (r.lut >= 0) ? lutv : r.eta_dis;
         double given_energy = given_power * eta * dt / 60.0;
         if (cap + given_energy < r.minB) {
             if (cap > r.minB) { o.energy = -(cap - r.minB); given_energy = o.energy; }
@@ -105,7 +120,7 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, double lutv, double a
     }
     o.prev_power = o.energy;
     o.tot_e = tot_e + o.energy;
-    o.cap = ceil2(o.cap);
+    o.cap = ceil2_x(o.cap);
     return o;
 }
 
@@ -124,7 +139,7 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, double lutv, double a
 // as by-value kernel arguments made LLVM hoist all of them above the loop and spill >200 SGPRs to VGPR lanes,
 // which was 40 % of the VALU instruction stream.
 struct V2P {
-    int E, T, C, npc, P, R, D, G, dt, reward_kind, state_kind, n_lut;
+    int E, T, C, npc, P, R, D, G, dt, reward_kind, state_kind, n_lut, pow2_dt;
     double sixty_over_dt, dt_over_60;
     EV2G_GP(const int) slot_cs; EV2G_GP(const int) slot_port; EV2G_GP(const int) slot_obs;
     EV2G_GP(const int) tr_seg; EV2G_GP(const int) tr_obs; EV2G_GP(const int) port_first;
@@ -207,6 +222,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     const bool log_cs = S->cs_profits != nullptr;
     const bool log_soc = S->soc_log != nullptr;
     const double dtd = (double)S->dt, sixty_over_dt = S->sixty_over_dt, dt_over_60 = S->dt_over_60;
+    const bool pow2_dt = S->pow2_dt != 0;
 
     // ---- home lane set-up (once per launch): global state -> LDS ----
     const bool valid = tid < N;
@@ -304,7 +320,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             }
             double amps = 0.0;
             if (occ) {
-                const double x = rnd5(a);
+                const double x = rnd5_x(a);
                 if (x > 0.0) { amps = x * c_imax; if (amps < c_thr_ch) amps = 0.0; }
                 else if (x < 0.0) { amps = x * c_dmaxabs; if (amps > c_dmin - 0.01) amps = c_dmin; }
             }
@@ -371,9 +387,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
                     const double amps_h = s_amps[h];
-                    double lutv = 1.0;
+                    double lutv = 1.0 / 100.0;
                     if (r.lut >= 0) { const int li = ev_lut_index(r.lut, amps_h); if (li >= 0) lutv = S->lut[li]; }
-                    const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd);
+                    const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt);
                     if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
                     s_cap[h] = o.cap;
                     s_prev[h] = o.prev_power;

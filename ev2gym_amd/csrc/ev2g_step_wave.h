@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const bool log_soc = S->soc_log != nullptr;
     const double dtd = (double)S->dt, sixty_over_dt = S->sixty_over_dt, dt_over_60 = S->dt_over_60;
+    const bool pow2_dt = S->pow2_dt != 0;
 
     // ---- home lane set-up ----
     const int elw = lane / P;            // env inside the wavefront
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             else if (a < -1.0) a = -1.0;
             double amps = 0.0;
             if (occ) {
-                const double x = rnd5(a);
+                const double x = rnd5_x(a);
                 if (x > 0.0) { amps = x * c_imax; if (amps < s_cst[0 * 64 + q_l]) amps = 0.0; }
                 else if (x < 0.0) { const double c_dmin = s_cst[1 * 64 + q_l]; amps = x * c_dmaxabs; if (amps > c_dmin - 0.01) amps = c_dmin; }
             }
@@ -213,12 +214,12 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
                     const double amps_h = s_amps[h];
-                    double lutv = 1.0;
+                    double lutv = 1.0 / 100.0;
                     if (r.lut >= 0) {
                         const int li = ev_lut_index(r.lut, amps_h);
                         if (li >= 0) lutv = (li < lut_lds_n) ? s_lut[li] : S->lut[li];
                     }
-                    const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd);
+                    const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt);
                     if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
                     s_cap[h] = o.cap;
                     s_prev[h] = o.prev_power;

@@ -875,6 +875,18 @@ int ev2g_oracle_step_range(void *h, int e0, int e1, double *actions, double *obs
     return rc;
 }
 
+/* k consecutive steps of envs [e0,e1) with actions[step] = actions + step*a_stride ([E,P] each); outputs hold the
+ * last step.  One call per worker thread and episode: the multi-core leg of bench.py's cpu_baseline. */
+int ev2g_oracle_run_range(void *h, int e0, int e1, int k, double *actions, long long a_stride, double *obs,
+                          double *reward, uint8_t *done, uint8_t *mask) {
+    int rc = 0;
+    for (int s = 0; s < k; s++) {
+        int r = ev2g_oracle_step_range(h, e0, e1, actions + (size_t)s * (size_t)a_stride, obs, reward, done, mask);
+        if (r && !rc) rc = r;
+    }
+    return rc;
+}
+
 int ev2g_oracle_step(void *h, double *actions, double *obs, double *reward, uint8_t *done, uint8_t *mask) {
     return ev2g_oracle_step_range(h, 0, ((Oracle *)h)->E, actions, obs, reward, done, mask);
 }

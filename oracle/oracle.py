@@ -35,6 +35,7 @@ def lib():
         L.ev2g_oracle_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.ev2g_oracle_step.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.ev2g_oracle_step_range.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.ev2g_oracle_run_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong] + [C.c_void_p] * 4
         L.ev2g_oracle_peek.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 21
         L.ev2g_oracle_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.ev2g_oracle_destroy.argtypes = [C.c_void_p]
@@ -71,6 +72,10 @@ class Oracle:
         mask = np.empty((self.E, self.P), np.uint8)
         rc = lib().ev2g_oracle_step(self.h, _p(actions), _p(obs), _p(rew), _p(done), _p(mask))
         return obs, rew, done, mask, rc
+
+    def run_range_nocopy(self, e0, e1, k, actions, a_stride, obs, rew, done, mask):
+        """k steps of envs [e0,e1) in one C call (actions[step] at actions + step*a_stride doubles)."""
+        return lib().ev2g_oracle_run_range(self.h, e0, e1, k, _p(actions), a_stride, _p(obs), _p(rew), _p(done), _p(mask))
 
     def step_range_nocopy(self, e0, e1, actions, obs, rew, done, mask):
         return lib().ev2g_oracle_step_range(self.h, e0, e1, _p(actions), _p(obs), _p(rew), _p(done), _p(mask))
