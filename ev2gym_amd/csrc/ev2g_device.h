@@ -680,6 +680,25 @@ __global__ void ev2g_build_window_table_kernel(DevScn s, double *__restrict__ ta
     }
 }
 
+// Observation head table of the one-transformer fast path: row (env, step s) holds columns 2..2+NH of the observation
+// that describes step s -- |charge price| for steps s..s+19, zero past the horizon (state.py:75-83 / :121-129), then,
+// when the state has them (NH == 60), the 40 window columns of ev2g_build_window_table_kernel.  The step kernel copies
+// a row per env-step with one base pointer and no per-column logic.
+__global__ void ev2g_build_head_table_kernel(const double *__restrict__ price_ch, const double *__restrict__ win_tab,
+                                             int E, int T, int NH, double *__restrict__ tab) {
+    const long long n = (long long)E * (T + 1) * NH;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % NH);
+        const long long row = i / NH;
+        const int step = (int)(row % (T + 1));
+        const long long e = row / (T + 1);
+        double v;
+        if (c < 20) { const int k = step + c; v = (k < T) ? fabs(price_ch[e * T + k]) : 0.0; }
+        else v = win_tab[row * 40 + (c - 20)];
+        tab[i] = v;
+    }
+}
+
 // counter-based uniform generator (splitmix64 of (seed, index)); identical on host (ev2g_host_uniform)
 __host__ __device__ inline double ev2g_u01(uint64_t seed, uint64_t i) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (i + 1);

@@ -369,6 +369,13 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     s.G = std::max(1, blk / P);
     s.G = std::min(s.G, E);
     h->wave_path = (P >= 2 && P <= 64 && R == 1 && npc == 1 && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY));
+    {   // ev2g_step_wave addresses every array as base + 32-bit byte offset: all of them must stay below 4 GiB
+        const unsigned long long lim = 1ull << 32;
+        const unsigned long long biggest = std::max({(unsigned long long)E * P * 8, (unsigned long long)E * D * 8,
+                                                     (unsigned long long)E * (T + 1) * 60 * 8, (unsigned long long)S * sizeof(SessRec),
+                                                     (unsigned long long)E * T * 8});
+        if (biggest >= lim) h->wave_path = false;
+    }
     if (h->wave_path) s.G = (EV2G_WAVE_BLOCK / 64) * (64 / P);   // wave-aligned: 64/P envs per wavefront
     {
         // Kernel choice for the common shape.  Default: ev2g_step_wave (fastest measured).  EV2G_KERNEL
@@ -502,6 +509,16 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         HIPCHK(h, hipGetLastError());
         s.win_tab = tab;
     }
+    double *d_head_tab = nullptr;
+    if ((h->wave_path || h->list_path) && sk != EV2G_STATE_PUBLIC_PST) {
+        const int NH = (sk == EV2G_STATE_V2G_PROFIT_MAX_LOADS) ? 60 : 20;
+        const size_t n = (size_t)E * (T + 1) * NH;
+        HIPCHK(h, hipMalloc((void **)&d_head_tab, n * sizeof(double)));
+        pool.push_back(d_head_tab);
+        const int nb = (int)std::min<size_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(ev2g_build_head_table_kernel, dim3(nb), dim3(256), 0, h->stream, s.price_ch, s.win_tab, E, T, NH, d_head_tab);
+        HIPCHK(h, hipGetLastError());
+    }
     // ---- state ----
     DevState &st = h->st;
     st = DevState{};
@@ -526,6 +543,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         V2P v2p;
         ev2g_v2_fill_params(v2p, h->scn, h->st);
         EV2G_SETP(v2p.lut, d_lut_eta);
+        EV2G_SETP(v2p.head_tab, d_head_tab);
         int ex = 0;   // 60/dt a power of two and dt/60 its exact reciprocal -> divisions by them are multiplications
         v2p.pow2_dt = (std::frexp(h->scn.sixty_over_dt, &ex) == 0.5 && h->scn.sixty_over_dt * h->scn.dt_over_60 == 1.0) ? 1 : 0;
         if ((rc = upload(h, sp, &v2p, 1, &h->d_v2p))) return rc;

@@ -39,6 +39,27 @@ __device__ __forceinline__ double xor1_f64(double v) { return dpp_mov_f64<0xB1>(
 __device__ __forceinline__ double xor2_f64(double v) { return dpp_mov_f64<0x4E>(v); }
 __device__ __forceinline__ double xor4_f64(double v) { return dpp_mov_f64<0x141>(dpp_mov_f64<0x1B>(v)); }
 
+// Global accesses as  uniform base (an SGPR pair) + 32-bit unsigned BYTE offset (one VGPR):  the
+// `global_load/store v, v_off, s[base:base+1]` form.  Indexing a pointer with a (sign-extended) int instead makes every
+// access carry a 64-bit VALU address computation (v_ashrrev + v_lshl_add_u64, an address VGPR pair each).  The host
+// selects this kernel only when every array it addresses is smaller than 4 GiB (ev2g_host.hip).
+typedef const char __attribute__((address_space(1))) *gcptr;
+typedef char __attribute__((address_space(1))) *gptr;
+template <class T, class B> __device__ __forceinline__ T ldg32(B base, unsigned boff) {
+    return *(const T __attribute__((address_space(1))) *)((gcptr)base + boff);
+}
+template <class T, class B> __device__ __forceinline__ void stg32(B base, unsigned boff, T v) {
+    *(T __attribute__((address_space(1))) *)((gptr)base + boff) = v;
+}
+typedef double d2v __attribute__((ext_vector_type(2)));   // builtin vectors: loadable from any address space
+typedef int i2v __attribute__((ext_vector_type(2)));
+template <class B> __device__ __forceinline__ SessRec ldg32_rec(B base, unsigned boff) {   // 8 x 16-byte loads
+    union { SessRec r; d2v v[sizeof(SessRec) / 16]; } u;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(SessRec) / 16); i++) u.v[i] = ldg32<d2v>(base, boff + 16u * i);
+    return u.r;
+}
+
 template <int SK, int RK>
 __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
                                                                      int k_steps, int auto_reset) {
@@ -86,13 +107,15 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     }
     int t = t0;
     if (valid) {
-        const int2 w = S->win[g];
-        const int2 sc = S->sc[g];
+        const unsigned g8 = (unsigned)g * 8u;
+        const i2v w = ldg32<i2v>(S->win, g8);
+        const i2v sc = ldg32<i2v>(S->sc, g8);
         s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = sc.x; s_cyc[tid] = sc.y; s_dirty[tid] = 0;
         if (w.x <= t && t <= w.y) {
-            s_cap[tid] = S->cap[g]; s_tot[tid] = S->tot_e[g]; s_prev[tid] = S->prev_power[g];
-            s_bcap[tid] = S->bcap[g]; s_potc[tid] = S->potc[g];
-            s_abse[tid] = log_soc ? S->abs_e[g] : 0.0;
+            s_cap[tid] = ldg32<double>(S->cap, g8); s_tot[tid] = ldg32<double>(S->tot_e, g8);
+            s_prev[tid] = ldg32<double>(S->prev_power, g8);
+            s_bcap[tid] = ldg32<double>(S->bcap, g8); s_potc[tid] = ldg32<double>(S->potc, g8);
+            s_abse[tid] = log_soc ? ldg32<double>(S->abs_e, g8) : 0.0;
         } else {
             s_cap[tid] = 0.0; s_tot[tid] = 0.0; s_prev[tid] = 0.0; s_bcap[tid] = 1.0; s_potc[tid] = 0.0; s_abse[tid] = 0.0;
         }
@@ -109,7 +132,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     // trip behind the session-record load on the critical path of the battery maths
     const int lut_lds_n = (k_steps >= 8 && EV2G_WAVE_LUT_LDS > 0) ? min(S->n_lut * 101, EV2G_WAVE_LUT_LDS) : 0;
     for (int i = tid; i < lut_lds_n; i += EV2G_WAVE_BLOCK) s_lut[i] = S->lut[i];
-    double a_next = io.actions[valid ? g : e0 * P];
+    double a_next = ldg32<double>(io.actions, (unsigned)(valid ? g : e0 * P) * 8u);
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_next));   // the first action has landed: a plain value for the loop
 
@@ -119,16 +142,17 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         asm volatile("" : "+s"(S));
         int tid_l = tid, g_l = g, e_l = e, q_l = q, lane_l = lane;
         asm volatile("" : "+v"(tid_l), "+v"(g_l), "+v"(e_l), "+v"(q_l), "+v"(lane_l));
+        const unsigned g8 = (unsigned)g_l * 8u;   // byte offset of this port in every [E*P] float64 / int2 array
         if (t >= T) {  // episode finished inside a fused run: in-kernel ev2g_reset for this workgroup
             if (!auto_reset) break;
             if (valid) {
-                const int2 w = S->port_first_win[g_l];
-                s_ta[tid_l] = w.x; s_td[tid_l] = w.y; s_ss[tid_l] = S->port_first[g_l]; s_cyc[tid_l] = 0;
+                const i2v w = ldg32<i2v>(S->port_first_win, g8);
+                s_ta[tid_l] = w.x; s_td[tid_l] = w.y; s_ss[tid_l] = ldg32<int>(S->port_first, g8 >> 1); s_cyc[tid_l] = 0;
                 s_cap[tid_l] = 0.0; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_abse[tid_l] = 0.0; s_dirty[tid_l] = 3;
-                S->port_energy[g_l] = 0.0;
-                S->port_current[g_l] = 0.0;
-                S->cs_sat_sum[g_l] = 0.0;   // single-port chargers: charger index == port index
-                S->cs_served[g_l] = 0;
+                stg32<double>(S->port_energy, g8, 0.0);
+                stg32<double>(S->port_current, g8, 0.0);
+                stg32<double>(S->cs_sat_sum, g8, 0.0);   // single-port chargers: charger index == port index
+                stg32<int>(S->cs_served, g8 >> 1, 0);
             }
             if (head) {
                 for (int i = 0; i < 8; i++) S->env_acc[e_l * 8 + i] = 0.0;
@@ -136,8 +160,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
             t = 0;
         }
-        double *__restrict__ obs = io.obs ? io.obs + (long long)kk * io.o_stride : nullptr;
-        uint8_t *__restrict__ mask = io.mask ? io.mask + (long long)kk * io.m_stride : nullptr;
+        double *obs = io.obs ? io.obs + (long long)kk * io.o_stride : nullptr;       // uniform bases (scalar arithmetic)
+        uint8_t *mask = io.mask ? io.mask + (long long)kk * io.m_stride : nullptr;
         const int sstep = t + 1;
         const bool last_step = (kk == k_steps - 1) || (sstep >= T && !auto_reset);
         int *cntk = cnt + 2 * (kk & 1);
@@ -175,24 +199,26 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
         const int ec = valid ? e_l : e0;   // clamped env for idle lanes
         const int gc = valid ? g_l : e0 * P;
-        a_next = (io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride)[gc];
-        double pf_pch = S->price_ch[ec * T + t], pf_pdis = S->price_dis[ec * T + t];
+        a_next = ldg32<double>(io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride, (unsigned)gc * 8u);
+        const unsigned eT8 = (unsigned)(ec * T) * 8u;   // this env's row in the [E,T] series
+        const unsigned et8 = eT8 + (unsigned)t * 8u;
+        double pf_pch = ldg32<double>(S->price_ch, et8), pf_pdis = ldg32<double>(S->price_dis, et8);
         double pf_base = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
-        if (RK == 0) { pf_base = S->tr_base[ec * T + t]; pf_maxp = S->tr_maxp[ec * T + t]; pf_minp = S->tr_minp[ec * T + t]; }
-        if (RK == 1) pf_sp = S->setpoint[ec * T + t];
+        if (RK == 0) { pf_base = ldg32<double>(S->tr_base, et8); pf_maxp = ldg32<double>(S->tr_maxp, et8); pf_minp = ldg32<double>(S->tr_minp, et8); }
+        if (RK == 1) pf_sp = ldg32<double>(S->setpoint, et8);
         // observation head columns of this env, distributed over its P lanes: column c = q, q+P, q+2P
         double pf_ob0 = 0.0, pf_ob1 = 0.0, pf_ob2 = 0.0;
         constexpr int NHEAD = (SK == 1) ? 0 : (SK == 0 ? 60 : 20);   // 20 prices (+ 40 window columns)
         if (SK == 1) {
-            pf_ob0 = S->setpoint[ec * T + min(sstep, T - 1)];   // used by the head lane only, masked by sstep < T
+            pf_ob0 = ldg32<double>(S->setpoint, eT8 + (unsigned)min(sstep, T - 1) * 8u);   // used by the head lane only, masked by sstep < T
         } else {
-            const double *pprice = (const double *)S->price_ch + ec * T;
-            const double *pwin = (SK == 0) ? (const double *)S->win_tab + ((long long)ec * (T + 1) + sstep) * 40 : pprice;
+            // observation head table [E, T+1, NHEAD]: |charge price| window (zero-padded) + load/PV/limit window, exactly
+            // the values of columns 2..2+NHEAD of the observation emitted at the end of step sstep-1 (state.py:65-83, :108-135)
+            const unsigned h8 = (unsigned)((ec * (T + 1) + sstep) * NHEAD) * 8u;
 #pragma unroll
             for (int u = 0; u < 3; u++) {
                 const int c = q_l + u * P;
-                const double *pa = (c < 20) ? pprice + min(sstep + c, T - 1) : ((c < NHEAD) ? pwin + (c - 20) : pprice);
-                const double v = *pa;
+                const double v = ldg32<double>(S->head_tab, h8 + (unsigned)min(c, NHEAD - 1) * 8u);
                 if (u == 0) pf_ob0 = v; else if (u == 1) pf_ob1 = v; else pf_ob2 = v;
             }
         }
@@ -210,14 +236,14 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 if (i < nch) h = items[i];
                 else if (i >= nchp) h = items[NS - 1 - (i - nchp)];
                 if (h >= 0) {
-                    const SessRec r = *(const SessRec *)(S->rec + s_ss[h]);
+                    const SessRec r = ldg32_rec(S->rec, (unsigned)s_ss[h] * (unsigned)sizeof(SessRec));
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
                     const double amps_h = s_amps[h];
                     double lutv = 1.0 / 100.0;
                     if (r.lut >= 0) {
                         const int li = ev_lut_index(r.lut, amps_h);
-                        if (li >= 0) lutv = (li < lut_lds_n) ? s_lut[li] : S->lut[li];
+                        if (li >= 0) lutv = (li < lut_lds_n) ? s_lut[li] : ldg32<double>(S->lut, (unsigned)li * 8u);
                     }
                     const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt);
                     if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
@@ -256,22 +282,25 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     const double ech = stage[4 * NS + tid_l];
                     profit = (ech != 0.0) ? ech * pf_pch : stage[5 * NS + tid_l] * pf_pdis;
                 }
-                if (current - 0.0001 > c_imax) S->env_fault[e_l] = 1;  // ev_charger.py:203-205
-                if (last_step) { S->port_energy[g_l] = energy; S->port_current[g_l] = current; }
-                if (log_soc) S->soc_log[(long long)t * E * P + g_l] = (current != 0.0) ? cap_before : -cap_before;
+                if (current - 0.0001 > c_imax) stg32<int>(S->env_fault, (unsigned)e_l * 4u, 1);  // ev_charger.py:203-205
+                if (last_step) { stg32<double>(S->port_energy, g8, energy); stg32<double>(S->port_current, g8, current); }
+                if (log_soc) stg32<double>(S->soc_log + (long long)t * E * P, g8, (current != 0.0) ? cap_before : -cap_before);
                 if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
                     const int ss = s_ss[tid_l];
-                    const SessRec &r = *(const SessRec *)(S->rec + ss);
-                    const double des = r.des;
+                    const unsigned r8 = (unsigned)ss * (unsigned)sizeof(SessRec);
+                    const double des = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, des));
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
                     if (RK != 1) satpen = 100.0 * exp(-10.0 * score);
                     // fire-and-forget device atomics (no returned value => no memory round trip on this path); exactly one
                     // lane updates a given charger per step, so the result does not depend on any ordering
-                    __hip_atomic_fetch_add(&S->cs_served[g_l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(&S->cs_sat_sum[g_l], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    S->sess_final_cap[ss] = cap;
-                    if (log_soc) S->sess_abs_e[ss] = s_abse[tid_l];
-                    ta = r.nt_arr; td = r.nt_dep;
+                    __hip_atomic_fetch_add((int __attribute__((address_space(1))) *)((gptr)S->cs_served + (g8 >> 1)), 1,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_sat_sum + g8), score,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    stg32<double>(S->sess_final_cap, (unsigned)ss * 8u, cap);
+                    if (log_soc) stg32<double>(S->sess_abs_e, (unsigned)ss * 8u, s_abse[tid_l]);
+                    const i2v nx = ldg32<i2v>(S->rec, r8 + (unsigned)offsetof(SessRec, nt_arr));
+                    ta = nx.x; td = nx.y;
                     s_ta[tid_l] = ta; s_td[tid_l] = td;
                     s_ss[tid_l] = (ta != EV2G_INT_MAX) ? ss + 1 : -1;
                     s_cyc[tid_l] = 0;
@@ -279,21 +308,22 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 }
             }
             if (ta == sstep) {  // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
-                const SessRec &r = *(const SessRec *)(S->rec + s_ss[tid_l]);
-                cap = r.cap0;
-                const double B = r.B, v = r.v;
-                const double evc = r.pacmax * 1000.0 / v;            // utils.py:773-777
+                const unsigned r8 = (unsigned)s_ss[tid_l] * (unsigned)sizeof(SessRec);
+                cap = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, cap0));
+                const double B = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, B));
+                const double v = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, v));
+                const double evc = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, pacmax)) * 1000.0 / v;            // utils.py:773-777
                 const double potc = v * ((evc < c_imax) ? evc : c_imax) / 1000.0;
                 s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
                 s_abse[tid_l] = 0.0;
-                S->bcap[g_l] = B;
-                S->potc[g_l] = potc;
-                S->port_energy[g_l] = 0.0;
-                S->port_current[g_l] = 0.0;
+                stg32<double>(S->bcap, g8, B);
+                stg32<double>(S->potc, g8, potc);
+                stg32<double>(S->port_energy, g8, 0.0);
+                stg32<double>(S->port_current, g8, 0.0);
                 s_dirty[tid_l] |= 1;
             }
             const bool occ_after = (ta <= sstep) && (sstep <= td);
-            if (mask) mask[g_l] = occ_after ? 1 : 0;
+            if (mask) stg32<uint8_t>(mask, (unsigned)g_l, occ_after ? 1 : 0);
             double o0 = 0.0, o1 = 0.0, o2 = 0.0;
             if (occ_after) {
                 const double soc = cap / s_bcap[tid_l];
@@ -306,10 +336,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 pot = (pot > c_maxp) ? c_maxp : ((pot < c_minp) ? 0.0 : pot);
             }
             if (obs) {
-                double *o = obs + (e_l * D + ocol);
-                o[0] = o0;
-                o[1] = o1;
-                if (SK == 1) o[2] = o2;
+                const unsigned o8 = (unsigned)(e_l * D + ocol) * 8u;
+                stg32<double>(obs, o8, o0);
+                stg32<double>(obs, o8 + 8u, o1);
+                if (SK == 1) stg32<double>(obs, o8 + 16u, o2);
             }
             stage[1 * NS + tid_l] = profit;
             stage[2 * NS + tid_l] = satpen;
@@ -363,26 +393,27 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const double usage = esum[0];
         if (head) {
             double *ea = eacc + elg * 6;
+            const unsigned e8 = (unsigned)e_l * 8u;
             double over100 = 0.0;
             if (RK == 0) {  // Transformer.reset + step + get_how_overloaded (transformer.py:258-302)
                 double ptr = pf_base;   // inflexible_load[t] + solar_power[t]
                 ptr += usage;
                 const double over = (ptr > pf_maxp + 0.0001 || ptr < pf_minp - 0.0001) ? fabs(ptr - pf_maxp) : 0.0;
-                S->over_hist[t * E + e_l] = over;
-                if (last_step) S->tr_power_now[e_l] = ptr;
+                stg32<double>(S->over_hist + (long long)t * E, e8, over);
+                if (last_step) stg32<double>(S->tr_power_now, e8, ptr);
                 over100 = 100.0 * over;
             } else {
-                const int erT = e_l * T + t;
-                double ptr = S->tr_base[erT];
+                const unsigned erT8 = (unsigned)(e_l * T + t) * 8u;
+                double ptr = ldg32<double>(S->tr_base, erT8);
                 ptr += usage;
-                const double mx = S->tr_maxp[erT], mn = S->tr_minp[erT];
+                const double mx = ldg32<double>(S->tr_maxp, erT8), mn = ldg32<double>(S->tr_minp, erT8);
                 const double over = (ptr > mx + 0.0001 || ptr < mn - 0.0001) ? fabs(ptr - mx) : 0.0;
-                S->over_hist[t * E + e_l] = over;
-                if (last_step) S->tr_power_now[e_l] = ptr;
+                stg32<double>(S->over_hist + (long long)t * E, e8, over);
+                if (last_step) stg32<double>(S->tr_power_now, e8, ptr);
             }
-            S->usage_hist[t * E + e_l] = usage;
+            stg32<double>(S->usage_hist + (long long)t * E, e8, usage);
             const double potn = esum[3];
-            if (sstep < T) S->pot_hist[sstep * E + e_l] = potn;
+            if (sstep < T) stg32<double>(S->pot_hist + (long long)sstep * E, e8, potn);
             const double costs = esum[1];
             double reward;
             if (RK == 1) {  // SquaredTrackingErrorReward reward.py:7-14
@@ -397,29 +428,35 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
             ea[5] = potn;
             ea[0] += reward; ea[1] += costs; ea[2] += esum[4]; ea[3] += esum[5]; ea[4] += esum[6];
-            if (io.reward) io.reward[(long long)kk * io.r_stride + e_l] = reward;
-            if (io.done) io.done[(long long)kk * io.d_stride + e_l] = (sstep >= T) ? 1 : 0;
+            if (io.reward) stg32<double>(io.reward + (long long)kk * io.r_stride, e8, reward);
+            if (io.done) stg32<uint8_t>(io.done + (long long)kk * io.d_stride, (unsigned)e_l, (sstep >= T) ? 1 : 0);
             if (sstep >= T || last_step) {  // flush the episode accumulators (get_statistics reads them)
-                auto ga = S->env_acc + e_l * 8;
-                for (int i = 0; i < 5; i++) { ga[i] += ea[i]; ea[i] = 0.0; }
+                for (int i = 0; i < 5; i++) {
+                    const unsigned a8 = (unsigned)e_l * 64u + (unsigned)i * 8u;
+                    stg32<double>(S->env_acc, a8, ldg32<double>(S->env_acc, a8) + ea[i]);
+                    ea[i] = 0.0;
+                }
             }
         }
         if (valid && obs) {
-            double *o = obs + e_l * D;
+            const unsigned o8 = (unsigned)(e_l * D) * 8u;
             if (SK == 1) {  // PublicPST state.py:6-35
-                if (q_l == 0) { o[0] = (double)sstep / (double)T; o[1] = (sstep < T) ? pf_ob0 : 0.0; o[2] = usage; }
-            } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135
-                if (q_l == 0) { o[0] = (double)sstep; o[1] = usage; }
-                int c = q_l;
-                if (c < 20) o[2 + c] = (sstep + c < T) ? fabs(pf_ob0) : 0.0; else if (c < NHEAD) o[2 + c] = pf_ob0;
-                c = q_l + P;
-                if (c < 20) o[2 + c] = (sstep + c < T) ? fabs(pf_ob1) : 0.0; else if (c < NHEAD) o[2 + c] = pf_ob1;
-                c = q_l + 2 * P;
-                if (c < 20) o[2 + c] = (sstep + c < T) ? fabs(pf_ob2) : 0.0; else if (c < NHEAD) o[2 + c] = pf_ob2;
-                for (c = q_l + 3 * P; c < NHEAD; c += P) {   // tiny envs (P < 20): the remaining columns, unprefetched
-                    if (c < 20) { const int k = sstep + c; o[2 + c] = (k < T) ? fabs(S->price_ch[e_l * T + k]) : 0.0; }
-                    else o[2 + c] = S->win_tab[((long long)e_l * (T + 1) + sstep) * 40 + (c - 20)];
+                if (q_l == 0) {
+                    stg32<double>(obs, o8, (double)sstep / (double)T);
+                    stg32<double>(obs, o8 + 8u, (sstep < T) ? pf_ob0 : 0.0);
+                    stg32<double>(obs, o8 + 16u, usage);
                 }
+            } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135: columns 2.. are a copy of the head table row
+                if (q_l == 0) { stg32<double>(obs, o8, (double)sstep); stg32<double>(obs, o8 + 8u, usage); }
+                int c = q_l;
+                if (c < NHEAD) stg32<double>(obs, o8 + (unsigned)(2 + c) * 8u, pf_ob0);
+                c = q_l + P;
+                if (c < NHEAD) stg32<double>(obs, o8 + (unsigned)(2 + c) * 8u, pf_ob1);
+                c = q_l + 2 * P;
+                if (c < NHEAD) stg32<double>(obs, o8 + (unsigned)(2 + c) * 8u, pf_ob2);
+                const unsigned h8 = (unsigned)((e_l * (T + 1) + sstep) * NHEAD) * 8u;
+                for (c = q_l + 3 * P; c < NHEAD; c += P)    // tiny envs (P < 20): the remaining columns, unprefetched
+                    stg32<double>(obs, o8 + (unsigned)(2 + c) * 8u, ldg32<double>(S->head_tab, h8 + (unsigned)c * 8u));
             }
         }
         PT_MARK(5)
@@ -432,8 +469,12 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     __syncthreads();
     if (valid) {
         const int d = s_dirty[tid];
-        if (d & 2) S->win[g] = make_int2(s_ta[tid], s_td[tid]);
-        if (d) S->sc[g] = make_int2(s_ss[tid], s_cyc[tid]);
-        if (d & 1) { S->cap[g] = s_cap[tid]; S->tot_e[g] = s_tot[tid]; S->prev_power[g] = s_prev[tid]; if (log_soc) S->abs_e[g] = s_abse[tid]; }
+        const unsigned g8 = (unsigned)g * 8u;
+        if (d & 2) stg32<i2v>(S->win, g8, (i2v){s_ta[tid], s_td[tid]});
+        if (d) stg32<i2v>(S->sc, g8, (i2v){s_ss[tid], s_cyc[tid]});
+        if (d & 1) {
+            stg32<double>(S->cap, g8, s_cap[tid]); stg32<double>(S->tot_e, g8, s_tot[tid]); stg32<double>(S->prev_power, g8, s_prev[tid]);
+            if (log_soc) stg32<double>(S->abs_e, g8, s_abse[tid]);
+        }
     }
 }
