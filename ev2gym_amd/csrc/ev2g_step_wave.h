@@ -348,25 +348,27 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wavefront's LDS writes are visible to itself
         PT_MARK(3)
 
-        // ---------------- D: per-env reduction inside the wavefront (same fixed tree as the generic kernel) ----------------
-        // lane = k*8 + j: quantity k, chain j; env elw's sums end up in lane k*8 (j == 0) and are broadcast below
-        double esum[EV2G_NQ];
-#pragma unroll
-        for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = 0.0;
+        // ---------------- D: per-env reduction inside the wavefront (fixed tree: bit-reproducible) ----------------
+        // lane = k*8 + j: quantity k, chain j.  Every lane issues its 8 LDS reads unconditionally (clamped index, masked
+        // by a select; the slots of idle lanes hold zeros), sums two chains, and three DPP xor-butterflies leave env w's
+        // sum of quantity k in lane k*8.  That lane parks it in the env's head slot of the stage row it just reduced
+        // (stage[k][first port of env w]; only this lane ever reads that slot in this phase), where the head lane --
+        // the only consumer of env-level sums -- picks all eight up below.  LDS operations of one wavefront execute in
+        // order, so no barrier is involved.
         {
             const int k = lane_l >> 3, j = lane_l & 7;
             const int wbase = (tid_l & ~63);
+            const double *row = stage + k * NS;
 #pragma unroll 1
             for (int w = 0; w < EPW; w++) {
                 const int a = wbase + w * P, b = a + P;
-                // all LDS reads of the segment are issued first (P <= 64: at most 4 + 4 per lane), then summed in the
-                // same order as the generic kernel's two chains
                 double xa[4], xb[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int i = a + j + 16 * u;
-                    xa[u] = (i < b) ? stage[k * NS + min(i, NS - 1)] : 0.0;
-                    xb[u] = (i + 8 < b) ? stage[k * NS + min(i + 8, NS - 1)] : 0.0;
+                    const double ra = row[min(i, NS - 1)], rb = row[min(i + 8, NS - 1)];
+                    xa[u] = (i < b) ? ra : 0.0;
+                    xb[u] = (i + 8 < b) ? rb : 0.0;
                 }
                 double acc = 0.0, accb = 0.0;
 #pragma unroll
@@ -375,18 +377,13 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 acc += xor1_f64(acc);
                 acc += xor2_f64(acc);
                 acc += xor4_f64(acc);
-                // hand the 8 sums (lanes 0, 8, ..., 56) to every lane of env w: v_readlane to SGPRs, no LDS crossbar trip
-                const long long acc64 = __double_as_longlong(acc);
-                const int lo32 = (int)(acc64 & 0xffffffffLL), hi32 = (int)(acc64 >> 32);
-#pragma unroll
-                for (int kq = 0; kq < EV2G_NQ; kq++) {
-                    const unsigned rl = (unsigned)__builtin_amdgcn_readlane(lo32, kq * 8);
-                    const unsigned rh = (unsigned)__builtin_amdgcn_readlane(hi32, kq * 8);
-                    const double v = __longlong_as_double((long long)(((unsigned long long)rh << 32) | rl));
-                    if (w == elw) esum[kq] = v;
-                }
+                if (j == 0) stage[k * NS + a] = acc;
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double esum[EV2G_NQ];
+#pragma unroll
+        for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = stage[kq * NS + tid_l];   // meaningful in head lanes only
 
         PT_MARK(4)
         // ---------------- E: per env (head lane) + observation head (the env's lanes) ----------------
