@@ -89,6 +89,7 @@ struct DevState {  // mutable engine state, device pointers
     double *abs_e;                     // [E*P]  (flag) EV.abs_total_energy_exchanged of the attached session
     double *sess_abs_e;                // [S]    (flag) the same, frozen at departure
     double *port_energy, *port_current;  // [E*P] EV.current_energy / actual_current of the last step
+    int *port_lut;                       // [E*P] efficiency-table id of the attached EV (-1: scalar efficiencies); fast path only
     unsigned long long *dbg;             // [n_groups*8] phase timing (EV2G_PHASE_TIMING builds only), else nullptr
 };
 

@@ -525,7 +525,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     auto &sp = h->st_allocs;
     const size_t EP = (size_t)E * P, EC = (size_t)E * C;
 #define AL(field, n) if ((rc = dalloc(h, sp, (size_t)(n), &st.field))) return rc;
-    AL(cap, EP) AL(tot_e, EP) AL(prev_power, EP) AL(bcap, EP) AL(potc, EP) AL(win, EP) AL(sc, EP) AL(port_energy, EP) AL(port_current, EP)
+    AL(cap, EP) AL(tot_e, EP) AL(prev_power, EP) AL(bcap, EP) AL(potc, EP) AL(win, EP) AL(sc, EP) AL(port_energy, EP) AL(port_current, EP) AL(port_lut, EP)
     AL(cs_sat_sum, EC) AL(cs_served, EC)
     if (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) {
         AL(cs_profits, EC) AL(cs_e_ch, EC) AL(cs_e_dis, EC) AL(cs_power_now, EC) AL(cs_cur_now, EC)

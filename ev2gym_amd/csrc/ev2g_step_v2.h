@@ -158,7 +158,7 @@ struct V2P {
     EV2G_GP(double) cs_power_hist; EV2G_GP(double) cs_cur_hist; EV2G_GP(double) cs_power_now; EV2G_GP(double) cs_cur_now;
     EV2G_GP(double) env_acc; EV2G_GP(int) env_fault;
     EV2G_GP(double) usage_hist; EV2G_GP(double) pot_hist; EV2G_GP(double) over_hist; EV2G_GP(double) tr_power_now;
-    EV2G_GP(double) sess_final_cap; EV2G_GP(double) port_energy; EV2G_GP(double) port_current;
+    EV2G_GP(double) sess_final_cap; EV2G_GP(double) port_energy; EV2G_GP(double) port_current; EV2G_GP(int) port_lut;
     EV2G_GP(double) soc_log; EV2G_GP(double) abs_e; EV2G_GP(double) sess_abs_e;
     EV2G_GP(unsigned long long) dbg;
 };
@@ -177,7 +177,7 @@ inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
     CPT(cap) CPT(tot_e) CPT(prev_power) CPT(bcap) CPT(potc) CPT(win) CPT(sc) CPT(cs_sat_sum) CPT(cs_served)
     CPT(cs_profits) CPT(cs_e_ch) CPT(cs_e_dis) CPT(cs_power_hist) CPT(cs_cur_hist) CPT(cs_power_now) CPT(cs_cur_now)
     CPT(env_acc) CPT(env_fault) CPT(usage_hist) CPT(pot_hist) CPT(over_hist) CPT(tr_power_now)
-    CPT(sess_final_cap) CPT(port_energy) CPT(port_current) CPT(soc_log) CPT(abs_e) CPT(sess_abs_e) CPT(dbg)
+    CPT(sess_final_cap) CPT(port_energy) CPT(port_current) CPT(port_lut) CPT(soc_log) CPT(abs_e) CPT(sess_abs_e) CPT(dbg)
 #undef CPS
 #undef CPT
 }

@@ -14,15 +14,13 @@
 #pragma once
 #include "ev2g_step_v2.h"
 
-// efficiency tables staged in LDS for fused multi-step launches (8 tables x 101 entries)
-#define EV2G_WAVE_LUT_LDS 0
 #ifndef EV2G_WAVE_BLOCK
 #define EV2G_WAVE_BLOCK 256
 #endif
 
 __host__ __device__ inline size_t ev2g_wave_lds_bytes(int envs_per_group) {
     const size_t NS = EV2G_WAVE_BLOCK;
-    return sizeof(double) * ((EV2G_NQ + 7) * NS + EV2G_WAVE_LUT_LDS + 6 * (size_t)envs_per_group + 4 * 64) + sizeof(int) * (6 * NS + 8);
+    return sizeof(double) * ((EV2G_NQ + 7) * NS + 6 * (size_t)envs_per_group + 4 * 64) + sizeof(int) * (6 * NS + 8);
 }
 
 // xor-butterfly partners inside 8-lane groups through DPP (VALU cross-lane moves, a few cycles) instead of
@@ -53,10 +51,14 @@ template <class T, class B> __device__ __forceinline__ void stg32(B base, unsign
 }
 typedef double d2v __attribute__((ext_vector_type(2)));   // builtin vectors: loadable from any address space
 typedef int i2v __attribute__((ext_vector_type(2)));
-template <class B> __device__ __forceinline__ SessRec ldg32_rec(B base, unsigned boff) {   // 8 x 16-byte loads
+// The whole record in one memory round trip: 8 x 16-byte loads issued back to back, then pinned by an empty asm so
+// that the compiler cannot sink the ones a later branch does not need behind that branch (it otherwise loads the
+// two gate fields first and the rest only after testing them: two dependent round trips).
+template <class B> __device__ __forceinline__ SessRec ldg32_rec(B base, unsigned boff) {
     union { SessRec r; d2v v[sizeof(SessRec) / 16]; } u;
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(SessRec) / 16); i++) u.v[i] = ldg32<d2v>(base, boff + 16u * i);
+    asm volatile("" : "+v"(u.v[0]), "+v"(u.v[1]), "+v"(u.v[2]), "+v"(u.v[3]), "+v"(u.v[4]), "+v"(u.v[5]), "+v"(u.v[6]), "+v"(u.v[7]));
     return u.r;
 }
 
@@ -80,8 +82,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     double *s_cap = stage + (size_t)EV2G_NQ * NS;
     double *s_tot = s_cap + NS, *s_prev = s_tot + NS, *s_bcap = s_prev + NS, *s_potc = s_bcap + NS;
     double *s_amps = s_potc + NS, *s_abse = s_amps + NS;
-    double *s_lut = s_abse + NS;                           // [EV2G_WAVE_LUT_LDS] efficiency tables (fused launches only)
-    double *eacc = s_lut + EV2G_WAVE_LUT_LDS;              // [G][6] episode accumulators + charge_power_potential[t], per env
+    double *eacc = s_abse + NS;                            // [G][6] episode accumulators + charge_power_potential[t], per env
     double *s_cst = eacc + 6 * G;                          // [4][64] per-charger gates and clamps (rarely changing operands
                                                            // kept out of the register file): imin-0.01, dmin, max power, min power
     int *s_ta = (int *)(s_cst + 4 * 64);
@@ -110,7 +111,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const unsigned g8 = (unsigned)g * 8u;
         const i2v w = ldg32<i2v>(S->win, g8);
         const i2v sc = ldg32<i2v>(S->sc, g8);
-        s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = sc.x; s_cyc[tid] = sc.y; s_dirty[tid] = 0;
+        s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = sc.x; s_cyc[tid] = sc.y;
+        // s_dirty: bits 0,1 = what the epilogue must write back; bits 8.. = 1 + efficiency-table id of the attached EV, so
+        // that the battery maths can issue the table look-up together with (not behind) the session-record load
+        s_dirty[tid] = (ldg32<int>(S->port_lut, g8 >> 1) + 1) << 8;
         if (w.x <= t && t <= w.y) {
             s_cap[tid] = ldg32<double>(S->cap, g8); s_tot[tid] = ldg32<double>(S->tot_e, g8);
             s_prev[tid] = ldg32<double>(S->prev_power, g8);
@@ -128,10 +132,6 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     }
     if (tid < 4) cnt[tid] = 0;
     for (int k = 0; k < EV2G_NQ; k++) stage[k * NS + tid] = 0.0;
-    // a fused launch amortises staging the efficiency tables in LDS: the table look-up then no longer adds an L2 round
-    // trip behind the session-record load on the critical path of the battery maths
-    const int lut_lds_n = (k_steps >= 8 && EV2G_WAVE_LUT_LDS > 0) ? min(S->n_lut * 101, EV2G_WAVE_LUT_LDS) : 0;
-    for (int i = tid; i < lut_lds_n; i += EV2G_WAVE_BLOCK) s_lut[i] = S->lut[i];
     double a_next = ldg32<double>(io.actions, (unsigned)(valid ? g : e0 * P) * 8u);
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_next));   // the first action has landed: a plain value for the loop
@@ -236,15 +236,17 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 if (i < nch) h = items[i];
                 else if (i >= nchp) h = items[NS - 1 - (i - nchp)];
                 if (h >= 0) {
+                    const double amps_h = s_amps[h];
+                    const int lut_id = (s_dirty[h] >> 8) - 1;
+                    // table entry and session record are independent loads: one memory round trip, not two.  The look-up
+                    // is unconditional (clamped index); whether it applies is decided where it is used.
+                    const int li = (lut_id >= 0) ? ev_lut_index(lut_id, amps_h) : -1;
+                    double lut_raw = ldg32<double>(S->lut, (unsigned)max(li, 0) * 8u);
                     const SessRec r = ldg32_rec(S->rec, (unsigned)s_ss[h] * (unsigned)sizeof(SessRec));
+                    asm volatile("" : "+v"(lut_raw));
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
-                    const double amps_h = s_amps[h];
-                    double lutv = 1.0 / 100.0;
-                    if (r.lut >= 0) {
-                        const int li = ev_lut_index(r.lut, amps_h);
-                        if (li >= 0) lutv = (li < lut_lds_n) ? s_lut[li] : ldg32<double>(S->lut, (unsigned)li * 8u);
-                    }
+                    const double lutv = (li >= 0) ? lut_raw : 1.0 / 100.0;
                     const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt);
                     if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
                     s_cap[h] = o.cap;
@@ -316,11 +318,13 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 const double potc = v * ((evc < c_imax) ? evc : c_imax) / 1000.0;
                 s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
                 s_abse[tid_l] = 0.0;
+                const int lut_new = ldg32<int>(S->rec, r8 + (unsigned)offsetof(SessRec, lut));
+                stg32<int>(S->port_lut, g8 >> 1, lut_new);
                 stg32<double>(S->bcap, g8, B);
                 stg32<double>(S->potc, g8, potc);
                 stg32<double>(S->port_energy, g8, 0.0);
                 stg32<double>(S->port_current, g8, 0.0);
-                s_dirty[tid_l] |= 1;
+                s_dirty[tid_l] = (s_dirty[tid_l] & 3) | 1 | ((lut_new + 1) << 8);
             }
             const bool occ_after = (ta <= sstep) && (sstep <= td);
             if (mask) stg32<uint8_t>(mask, (unsigned)g_l, occ_after ? 1 : 0);
@@ -468,7 +472,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const int d = s_dirty[tid];
         const unsigned g8 = (unsigned)g * 8u;
         if (d & 2) stg32<i2v>(S->win, g8, (i2v){s_ta[tid], s_td[tid]});
-        if (d) stg32<i2v>(S->sc, g8, (i2v){s_ss[tid], s_cyc[tid]});
+        if (d & 3) stg32<i2v>(S->sc, g8, (i2v){s_ss[tid], s_cyc[tid]});
         if (d & 1) {
             stg32<double>(S->cap, g8, s_cap[tid]); stg32<double>(S->tot_e, g8, s_tot[tid]); stg32<double>(S->prev_power, g8, s_prev[tid]);
             if (log_soc) stg32<double>(S->abs_e, g8, s_abse[tid]);
