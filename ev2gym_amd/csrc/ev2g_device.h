@@ -69,7 +69,17 @@ struct DevScn {  // read-only scenario + layout, device pointers
     const double *win_tab;  // [E,R,T+1,40] precomputed (loads-pv)[20] | power_limits[20] per observation step, or nullptr
 };
 
+// The [E*P]-shaped state arrays live in ONE allocation of equal slices (slice = max(E*P, E*C) * 8 bytes), in this
+// order; likewise {usage, potential, overload} histories and the two per-session result arrays.  Every kernel keeps
+// using the individual pointers below; the fast-path kernel derives them from the slab base with scalar adds, which
+// replaces ~25 pointer fetches per step by a handful (ev2g_step_wave.h).
+enum { EV2G_PS_CAP = 0, EV2G_PS_TOT, EV2G_PS_PREV, EV2G_PS_BCAP, EV2G_PS_POTC, EV2G_PS_PENERGY, EV2G_PS_PCURRENT, EV2G_PS_ABSE,
+       EV2G_PS_SATSUM, EV2G_PS_WIN, EV2G_PS_SC, EV2G_PS_SERVED, EV2G_PS_LUT, EV2G_PS_N };
+
 struct DevState {  // mutable engine state, device pointers
+    char *slab_port; unsigned long long slab_port_slice;   // EV2G_PS_* slices, bytes per slice
+    double *slab_hist;   // usage_hist | pot_hist | over_hist   ([T,E] each when R == 1)
+    double *slab_sess;   // sess_final_cap | sess_abs_e         ([S] each)
     double *cap, *tot_e, *prev_power;  // [E*P] EV.current_capacity / total_energy_exchanged / previous_power
     double *bcap, *potc;               // [E*P] battery_capacity and charge-power-potential term of the attached EV (v2)
     int2 *win;                         // [E*P] {t_arr, t_dep} of the attached-or-next session (INT_MAX = none)
@@ -697,6 +707,17 @@ __global__ void ev2g_build_head_table_kernel(const double *__restrict__ price_ch
         if (c < 20) { const int k = step + c; v = (k < T) ? fabs(price_ch[e * T + k]) : 0.0; }
         else v = win_tab[row * 40 + (c - 20)];
         tab[i] = v;
+    }
+}
+
+// Per (env, step) scalars of the one-transformer fast path, interleaved so that one base pointer and three 16-byte
+// loads fetch them: {charge price, discharge price, inflexible+solar, max_power, min_power, setpoint, 0, 0}.
+__global__ void ev2g_build_step_table_kernel(DevScn s, double *__restrict__ tab) {
+    const long long n = (long long)s.E * s.T;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        double *o = tab + i * 8;
+        o[0] = s.price_ch[i]; o[1] = s.price_dis[i]; o[2] = s.tr_base[i]; o[3] = s.tr_maxp[i]; o[4] = s.tr_minp[i];
+        o[5] = s.setpoint[i]; o[6] = 0.0; o[7] = 0.0;
     }
 }
 

@@ -373,7 +373,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         const unsigned long long lim = 1ull << 32;
         const unsigned long long biggest = std::max({(unsigned long long)E * P * 8, (unsigned long long)E * D * 8,
                                                      (unsigned long long)E * (T + 1) * 60 * 8, (unsigned long long)S * sizeof(SessRec),
-                                                     (unsigned long long)E * T * 8});
+                                                     (unsigned long long)E * T * 64});
         if (biggest >= lim) h->wave_path = false;
     }
     if (h->wave_path) s.G = (EV2G_WAVE_BLOCK / 64) * (64 / P);   // wave-aligned: 64/P envs per wavefront
@@ -509,6 +509,15 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         HIPCHK(h, hipGetLastError());
         s.win_tab = tab;
     }
+    double *d_step_tab = nullptr;
+    if (h->wave_path || h->list_path) {   // R == 1: [E,T] series interleaved per (env, step)
+        const size_t n = (size_t)E * T * 8;
+        HIPCHK(h, hipMalloc((void **)&d_step_tab, n * sizeof(double)));
+        pool.push_back(d_step_tab);
+        const int nb = (int)std::min<size_t>(((size_t)E * T + 255) / 256, 4096);
+        hipLaunchKernelGGL(ev2g_build_step_table_kernel, dim3(nb), dim3(256), 0, h->stream, s, d_step_tab);
+        HIPCHK(h, hipGetLastError());
+    }
     double *d_head_tab = nullptr;
     if ((h->wave_path || h->list_path) && sk != EV2G_STATE_PUBLIC_PST) {
         const int NH = (sk == EV2G_STATE_V2G_PROFIT_MAX_LOADS) ? 60 : 20;
@@ -525,16 +534,30 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     auto &sp = h->st_allocs;
     const size_t EP = (size_t)E * P, EC = (size_t)E * C;
 #define AL(field, n) if ((rc = dalloc(h, sp, (size_t)(n), &st.field))) return rc;
-    AL(cap, EP) AL(tot_e, EP) AL(prev_power, EP) AL(bcap, EP) AL(potc, EP) AL(win, EP) AL(sc, EP) AL(port_energy, EP) AL(port_current, EP) AL(port_lut, EP)
-    AL(cs_sat_sum, EC) AL(cs_served, EC)
+    {   // per-port state: one slab, EV2G_PS_* slices
+        const size_t slice = std::max(EP, EC) * 8;
+        if ((rc = dalloc(h, sp, slice * EV2G_PS_N, &st.slab_port))) return rc;
+        st.slab_port_slice = slice;
+#define SLICE(T, k) ((T *)(st.slab_port + slice * (size_t)(k)))
+        st.cap = SLICE(double, EV2G_PS_CAP); st.tot_e = SLICE(double, EV2G_PS_TOT); st.prev_power = SLICE(double, EV2G_PS_PREV);
+        st.bcap = SLICE(double, EV2G_PS_BCAP); st.potc = SLICE(double, EV2G_PS_POTC);
+        st.port_energy = SLICE(double, EV2G_PS_PENERGY); st.port_current = SLICE(double, EV2G_PS_PCURRENT);
+        st.cs_sat_sum = SLICE(double, EV2G_PS_SATSUM); st.win = SLICE(int2, EV2G_PS_WIN); st.sc = SLICE(int2, EV2G_PS_SC);
+        st.cs_served = SLICE(int, EV2G_PS_SERVED); st.port_lut = SLICE(int, EV2G_PS_LUT);
+        if (h->cfg.flags & EV2G_FLAG_LOG_SOC) st.abs_e = SLICE(double, EV2G_PS_ABSE);
+#undef SLICE
+    }
     if (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) {
         AL(cs_profits, EC) AL(cs_e_ch, EC) AL(cs_e_dis, EC) AL(cs_power_now, EC) AL(cs_cur_now, EC)
         AL(cs_power_hist, (size_t)T * EC) AL(cs_cur_hist, (size_t)T * EC)
     }
     AL(env_acc, (size_t)E * 8) AL(env_fault, E)
-    AL(usage_hist, (size_t)T * E) AL(pot_hist, (size_t)T * E) AL(over_hist, (size_t)T * E * R)
-    AL(tr_power_now, (size_t)E * R) AL(sess_final_cap, S)
-    if (h->cfg.flags & EV2G_FLAG_LOG_SOC) { AL(soc_log, (size_t)T * EP) AL(abs_e, EP) AL(sess_abs_e, S) }
+    AL(slab_hist, (size_t)T * E * (2 + R))
+    st.usage_hist = st.slab_hist; st.pot_hist = st.slab_hist + (size_t)T * E; st.over_hist = st.slab_hist + (size_t)T * E * 2;
+    AL(slab_sess, (size_t)std::max<long long>(S, 1) * 2)
+    st.sess_final_cap = st.slab_sess;
+    AL(tr_power_now, (size_t)E * R)
+    if (h->cfg.flags & EV2G_FLAG_LOG_SOC) { AL(soc_log, (size_t)T * EP) st.sess_abs_e = st.slab_sess + (size_t)std::max<long long>(S, 1); }
 #ifdef EV2G_PHASE_TIMING
     AL(dbg, (size_t)s.n_groups * 8)
 #endif
@@ -544,6 +567,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         ev2g_v2_fill_params(v2p, h->scn, h->st);
         EV2G_SETP(v2p.lut, d_lut_eta);
         EV2G_SETP(v2p.head_tab, d_head_tab);
+        EV2G_SETP(v2p.step_tab, d_step_tab);
         int ex = 0;   // 60/dt a power of two and dt/60 its exact reciprocal -> divisions by them are multiplications
         v2p.pow2_dt = (std::frexp(h->scn.sixty_over_dt, &ex) == 0.5 && h->scn.sixty_over_dt * h->scn.dt_over_60 == 1.0) ? 1 : 0;
         if ((rc = upload(h, sp, &v2p, 1, &h->d_v2p))) return rc;

@@ -149,6 +149,9 @@ struct V2P {
     EV2G_GP(const double) price_ch; EV2G_GP(const double) price_dis; EV2G_GP(const double) setpoint;
     EV2G_GP(const double) tr_infl; EV2G_GP(const double) tr_solar; EV2G_GP(const double) tr_base; EV2G_GP(const double) tr_maxp;
     EV2G_GP(const double) tr_minp; EV2G_GP(const double) win_tab; EV2G_GP(const double) lut;
+    EV2G_GP(const double) step_tab;   // [E, T, 8] per (env, step) scalars (fast path only, ev2g_build_step_table_kernel)
+    EV2G_GP(char) slab_port; unsigned long long slab_port_slice;   // DevState slabs (ev2g_device.h)
+    EV2G_GP(double) slab_hist; EV2G_GP(double) slab_sess; unsigned long long hist_slice, sess_slice;   // bytes
     EV2G_GP(const double) head_tab;   // [E, T+1, NH] observation head rows (fast path only, ev2g_build_head_table_kernel)
     EV2G_GP(const SessRec) rec;
     EV2G_GP(double) cap; EV2G_GP(double) tot_e; EV2G_GP(double) prev_power; EV2G_GP(double) bcap; EV2G_GP(double) potc;
@@ -168,6 +171,11 @@ inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
     p.reward_kind = s.reward_kind; p.state_kind = s.state_kind; p.n_lut = s.n_lut;
     p.sixty_over_dt = s.sixty_over_dt; p.dt_over_60 = s.dt_over_60;
     p.pow2_dt = 0; EV2G_SETP(p.head_tab, (const double *)nullptr);
+    EV2G_SETP(p.step_tab, (const double *)nullptr);
+    EV2G_SETP(p.slab_port, st.slab_port); p.slab_port_slice = st.slab_port_slice;
+    EV2G_SETP(p.slab_hist, st.slab_hist); EV2G_SETP(p.slab_sess, st.slab_sess);
+    p.hist_slice = (unsigned long long)s.T * s.E * 8ull;
+    p.sess_slice = (unsigned long long)(st.sess_abs_e ? (st.sess_abs_e - st.slab_sess) : 0) * 8ull;
 #define CPS(f) EV2G_SETP(p.f, s.f);
 #define CPT(f) EV2G_SETP(p.f, st.f);
     CPS(slot_cs) CPS(slot_port) CPS(slot_obs) CPS(tr_seg) CPS(tr_obs) CPS(port_first) CPS(port_first_win)

@@ -70,6 +70,12 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     ParamPtr S = (ParamPtr)(unsigned long long)params;
     constexpr int NS = EV2G_WAVE_BLOCK;
     const int P = S->P, T = S->T, E = S->E, D = S->D;
+    // state slabs (ev2g_device.h): every [E*P] array is slabP + k * PS8, the three [T,E] histories slabH + k * HS8, the
+    // two per-session result arrays slabS + k * SS8 -- scalar adds on three base pointers instead of one pointer fetch
+    // from the parameter block per array and use
+    const gptr slabP = (gptr)S->slab_port, slabH = (gptr)S->slab_hist, slabS = (gptr)S->slab_sess;
+    const unsigned long long PS8 = S->slab_port_slice, HS8 = S->hist_slice, SS8 = S->sess_slice;
+#define PA(k) (slabP + PS8 * (unsigned long long)(k))
     const int EPW = 64 / P;   // envs per wavefront
     const int G = (EV2G_WAVE_BLOCK / 64) * EPW;    // envs per workgroup
     int grp;
@@ -109,17 +115,17 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     int t = t0;
     if (valid) {
         const unsigned g8 = (unsigned)g * 8u;
-        const i2v w = ldg32<i2v>(S->win, g8);
-        const i2v sc = ldg32<i2v>(S->sc, g8);
+        const i2v w = ldg32<i2v>(PA(EV2G_PS_WIN), g8);
+        const i2v sc = ldg32<i2v>(PA(EV2G_PS_SC), g8);
         s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = sc.x; s_cyc[tid] = sc.y;
         // s_dirty: bits 0,1 = what the epilogue must write back; bits 8.. = 1 + efficiency-table id of the attached EV, so
         // that the battery maths can issue the table look-up together with (not behind) the session-record load
-        s_dirty[tid] = (ldg32<int>(S->port_lut, g8 >> 1) + 1) << 8;
+        s_dirty[tid] = (ldg32<int>(PA(EV2G_PS_LUT), g8 >> 1) + 1) << 8;
         if (w.x <= t && t <= w.y) {
-            s_cap[tid] = ldg32<double>(S->cap, g8); s_tot[tid] = ldg32<double>(S->tot_e, g8);
-            s_prev[tid] = ldg32<double>(S->prev_power, g8);
-            s_bcap[tid] = ldg32<double>(S->bcap, g8); s_potc[tid] = ldg32<double>(S->potc, g8);
-            s_abse[tid] = log_soc ? ldg32<double>(S->abs_e, g8) : 0.0;
+            s_cap[tid] = ldg32<double>(PA(EV2G_PS_CAP), g8); s_tot[tid] = ldg32<double>(PA(EV2G_PS_TOT), g8);
+            s_prev[tid] = ldg32<double>(PA(EV2G_PS_PREV), g8);
+            s_bcap[tid] = ldg32<double>(PA(EV2G_PS_BCAP), g8); s_potc[tid] = ldg32<double>(PA(EV2G_PS_POTC), g8);
+            s_abse[tid] = log_soc ? ldg32<double>(PA(EV2G_PS_ABSE), g8) : 0.0;
         } else {
             s_cap[tid] = 0.0; s_tot[tid] = 0.0; s_prev[tid] = 0.0; s_bcap[tid] = 1.0; s_potc[tid] = 0.0; s_abse[tid] = 0.0;
         }
@@ -149,10 +155,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 const i2v w = ldg32<i2v>(S->port_first_win, g8);
                 s_ta[tid_l] = w.x; s_td[tid_l] = w.y; s_ss[tid_l] = ldg32<int>(S->port_first, g8 >> 1); s_cyc[tid_l] = 0;
                 s_cap[tid_l] = 0.0; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_abse[tid_l] = 0.0; s_dirty[tid_l] = 3;
-                stg32<double>(S->port_energy, g8, 0.0);
-                stg32<double>(S->port_current, g8, 0.0);
-                stg32<double>(S->cs_sat_sum, g8, 0.0);   // single-port chargers: charger index == port index
-                stg32<int>(S->cs_served, g8 >> 1, 0);
+                stg32<double>(PA(EV2G_PS_PENERGY), g8, 0.0);
+                stg32<double>(PA(EV2G_PS_PCURRENT), g8, 0.0);
+                stg32<double>(PA(EV2G_PS_SATSUM), g8, 0.0);   // single-port chargers: charger index == port index
+                stg32<int>(PA(EV2G_PS_SERVED), g8 >> 1, 0);
             }
             if (head) {
                 for (int i = 0; i < 8; i++) S->env_acc[e_l * 8 + i] = 0.0;
@@ -200,17 +206,21 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const int ec = valid ? e_l : e0;   // clamped env for idle lanes
         const int gc = valid ? g_l : e0 * P;
         a_next = ldg32<double>(io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride, (unsigned)gc * 8u);
-        const unsigned eT8 = (unsigned)(ec * T) * 8u;   // this env's row in the [E,T] series
-        const unsigned et8 = eT8 + (unsigned)t * 8u;
-        double pf_pch = ldg32<double>(S->price_ch, et8), pf_pdis = ldg32<double>(S->price_dis, et8);
+        const unsigned eT64 = (unsigned)(ec * T) * 64u;   // this env's rows in the [E,T,8] step table
+        const unsigned et64 = eT64 + (unsigned)t * 64u;
+        const d2v st0 = ldg32<d2v>(S->step_tab, et64);                                  // charge price, discharge price
+        double pf_pch = st0.x, pf_pdis = st0.y;
         double pf_base = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
-        if (RK == 0) { pf_base = ldg32<double>(S->tr_base, et8); pf_maxp = ldg32<double>(S->tr_maxp, et8); pf_minp = ldg32<double>(S->tr_minp, et8); }
-        if (RK == 1) pf_sp = ldg32<double>(S->setpoint, et8);
+        if (RK == 0) {
+            const d2v st1 = ldg32<d2v>(S->step_tab, et64 + 16u);                        // inflexible + solar, max_power
+            pf_base = st1.x; pf_maxp = st1.y; pf_minp = ldg32<double>(S->step_tab, et64 + 32u);
+        }
+        if (RK == 1) pf_sp = ldg32<double>(S->step_tab, et64 + 40u);
         // observation head columns of this env, distributed over its P lanes: column c = q, q+P, q+2P
         double pf_ob0 = 0.0, pf_ob1 = 0.0, pf_ob2 = 0.0;
         constexpr int NHEAD = (SK == 1) ? 0 : (SK == 0 ? 60 : 20);   // 20 prices (+ 40 window columns)
         if (SK == 1) {
-            pf_ob0 = ldg32<double>(S->setpoint, eT8 + (unsigned)min(sstep, T - 1) * 8u);   // used by the head lane only, masked by sstep < T
+            pf_ob0 = ldg32<double>(S->step_tab, eT64 + (unsigned)min(sstep, T - 1) * 64u + 40u);   // next setpoint; head lane only, masked by sstep < T
         } else {
             // observation head table [E, T+1, NHEAD]: |charge price| window (zero-padded) + load/PV/limit window, exactly
             // the values of columns 2..2+NHEAD of the observation emitted at the end of step sstep-1 (state.py:65-83, :108-135)
@@ -285,7 +295,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     profit = (ech != 0.0) ? ech * pf_pch : stage[5 * NS + tid_l] * pf_pdis;
                 }
                 if (current - 0.0001 > c_imax) stg32<int>(S->env_fault, (unsigned)e_l * 4u, 1);  // ev_charger.py:203-205
-                if (last_step) { stg32<double>(S->port_energy, g8, energy); stg32<double>(S->port_current, g8, current); }
+                if (last_step) { stg32<double>(PA(EV2G_PS_PENERGY), g8, energy); stg32<double>(PA(EV2G_PS_PCURRENT), g8, current); }
                 if (log_soc) stg32<double>(S->soc_log + (long long)t * E * P, g8, (current != 0.0) ? cap_before : -cap_before);
                 if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
                     const int ss = s_ss[tid_l];
@@ -295,12 +305,12 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     if (RK != 1) satpen = 100.0 * exp(-10.0 * score);
                     // fire-and-forget device atomics (no returned value => no memory round trip on this path); exactly one
                     // lane updates a given charger per step, so the result does not depend on any ordering
-                    __hip_atomic_fetch_add((int __attribute__((address_space(1))) *)((gptr)S->cs_served + (g8 >> 1)), 1,
+                    __hip_atomic_fetch_add((int __attribute__((address_space(1))) *)(PA(EV2G_PS_SERVED) + (g8 >> 1)), 1,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_sat_sum + g8), score,
+                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)(PA(EV2G_PS_SATSUM) + g8), score,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    stg32<double>(S->sess_final_cap, (unsigned)ss * 8u, cap);
-                    if (log_soc) stg32<double>(S->sess_abs_e, (unsigned)ss * 8u, s_abse[tid_l]);
+                    stg32<double>(slabS, (unsigned)ss * 8u, cap);
+                    if (log_soc) stg32<double>((slabS + SS8), (unsigned)ss * 8u, s_abse[tid_l]);
                     const i2v nx = ldg32<i2v>(S->rec, r8 + (unsigned)offsetof(SessRec, nt_arr));
                     ta = nx.x; td = nx.y;
                     s_ta[tid_l] = ta; s_td[tid_l] = td;
@@ -319,11 +329,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
                 s_abse[tid_l] = 0.0;
                 const int lut_new = ldg32<int>(S->rec, r8 + (unsigned)offsetof(SessRec, lut));
-                stg32<int>(S->port_lut, g8 >> 1, lut_new);
-                stg32<double>(S->bcap, g8, B);
-                stg32<double>(S->potc, g8, potc);
-                stg32<double>(S->port_energy, g8, 0.0);
-                stg32<double>(S->port_current, g8, 0.0);
+                stg32<int>(PA(EV2G_PS_LUT), g8 >> 1, lut_new);
+                stg32<double>(PA(EV2G_PS_BCAP), g8, B);
+                stg32<double>(PA(EV2G_PS_POTC), g8, potc);
+                stg32<double>(PA(EV2G_PS_PENERGY), g8, 0.0);
+                stg32<double>(PA(EV2G_PS_PCURRENT), g8, 0.0);
                 s_dirty[tid_l] = (s_dirty[tid_l] & 3) | 1 | ((lut_new + 1) << 8);
             }
             const bool occ_after = (ta <= sstep) && (sstep <= td);
@@ -400,21 +410,21 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 double ptr = pf_base;   // inflexible_load[t] + solar_power[t]
                 ptr += usage;
                 const double over = (ptr > pf_maxp + 0.0001 || ptr < pf_minp - 0.0001) ? fabs(ptr - pf_maxp) : 0.0;
-                stg32<double>(S->over_hist + (long long)t * E, e8, over);
+                stg32<double>((slabH + 2 * HS8) + (long long)t * E * 8, e8, over);
                 if (last_step) stg32<double>(S->tr_power_now, e8, ptr);
                 over100 = 100.0 * over;
             } else {
-                const unsigned erT8 = (unsigned)(e_l * T + t) * 8u;
-                double ptr = ldg32<double>(S->tr_base, erT8);
+                const unsigned erT64 = (unsigned)(e_l * T + t) * 64u;
+                double ptr = ldg32<double>(S->step_tab, erT64 + 16u);
                 ptr += usage;
-                const double mx = ldg32<double>(S->tr_maxp, erT8), mn = ldg32<double>(S->tr_minp, erT8);
+                const double mx = ldg32<double>(S->step_tab, erT64 + 24u), mn = ldg32<double>(S->step_tab, erT64 + 32u);
                 const double over = (ptr > mx + 0.0001 || ptr < mn - 0.0001) ? fabs(ptr - mx) : 0.0;
-                stg32<double>(S->over_hist + (long long)t * E, e8, over);
+                stg32<double>((slabH + 2 * HS8) + (long long)t * E * 8, e8, over);
                 if (last_step) stg32<double>(S->tr_power_now, e8, ptr);
             }
-            stg32<double>(S->usage_hist + (long long)t * E, e8, usage);
+            stg32<double>(slabH + (long long)t * E * 8, e8, usage);
             const double potn = esum[3];
-            if (sstep < T) stg32<double>(S->pot_hist + (long long)sstep * E, e8, potn);
+            if (sstep < T) stg32<double>((slabH + HS8) + (long long)sstep * E * 8, e8, potn);
             const double costs = esum[1];
             double reward;
             if (RK == 1) {  // SquaredTrackingErrorReward reward.py:7-14
@@ -471,11 +481,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     if (valid) {
         const int d = s_dirty[tid];
         const unsigned g8 = (unsigned)g * 8u;
-        if (d & 2) stg32<i2v>(S->win, g8, (i2v){s_ta[tid], s_td[tid]});
-        if (d & 3) stg32<i2v>(S->sc, g8, (i2v){s_ss[tid], s_cyc[tid]});
+        if (d & 2) stg32<i2v>(PA(EV2G_PS_WIN), g8, (i2v){s_ta[tid], s_td[tid]});
+        if (d & 3) stg32<i2v>(PA(EV2G_PS_SC), g8, (i2v){s_ss[tid], s_cyc[tid]});
         if (d & 1) {
-            stg32<double>(S->cap, g8, s_cap[tid]); stg32<double>(S->tot_e, g8, s_tot[tid]); stg32<double>(S->prev_power, g8, s_prev[tid]);
-            if (log_soc) stg32<double>(S->abs_e, g8, s_abse[tid]);
+            stg32<double>(PA(EV2G_PS_CAP), g8, s_cap[tid]); stg32<double>(PA(EV2G_PS_TOT), g8, s_tot[tid]); stg32<double>(PA(EV2G_PS_PREV), g8, s_prev[tid]);
+            if (log_soc) stg32<double>(PA(EV2G_PS_ABSE), g8, s_abse[tid]);
         }
     }
 }
