@@ -626,10 +626,13 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
     }
     if (h->wave_path) {
         const V2P *pp = (const V2P *)h->d_v2p;
+        const DevState &st = h->st;
+        const WaveArgs wa{s.P, s.T, s.E, s.D, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
+                          st.env_acc, s.cs_imax, s.cs_dmax_abs, s.cs_imin, s.cs_dmin, s.cs_maxp, s.cs_minp};
 #define EV2G_WAVE_CASE(SK, RK)                                                                                         \
     case SK * 3 + RK:                                                                                                  \
         hipLaunchKernelGGL((ev2g_step_wave<SK, RK>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, \
-                           pp, io, t0, k, auto_reset);                                                                 \
+                           pp, io, t0, k, auto_reset, wa);                                                             \
         break;
         switch (s.state_kind * 3 + s.reward_kind) {
             EV2G_WAVE_CASE(0, 0) EV2G_WAVE_CASE(0, 1) EV2G_WAVE_CASE(0, 2)

@@ -62,19 +62,34 @@ template <class B> __device__ __forceinline__ SessRec ldg32_rec(B base, unsigned
     return u.r;
 }
 
+// What the launch prologue needs, BY VALUE: with it the first data loads depend on one fetch (the kernarg segment)
+// instead of two (kernarg -> parameter block).  A launch starts with cold caches, so every dependent fetch in the
+// prologue is a full memory round trip -- paid per step by single-step launches.
+struct WaveArgs {
+    int P, T, E, D;
+    char *slab_port; unsigned long long slab_port_slice;
+    double *slab_hist; unsigned long long hist_slice;
+    double *env_acc;
+    const double *cs_imax, *cs_dmax_abs, *cs_imin, *cs_dmin, *cs_maxp, *cs_minp;
+};
+
 template <int SK, int RK>
 __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
-                                                                     int k_steps, int auto_reset) {
+                                                                     int k_steps, int auto_reset, WaveArgs wa) {
     extern __shared__ double lds[];
+#if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
+    const unsigned long long pt_k0 = __builtin_readcyclecounter();   // slot 7 := prologue, slot 6 := epilogue (tools/phase_timing.py --outer)
+#endif
     typedef const V2P __attribute__((address_space(4))) *ParamPtr;
     ParamPtr S = (ParamPtr)(unsigned long long)params;
     constexpr int NS = EV2G_WAVE_BLOCK;
-    const int P = S->P, T = S->T, E = S->E, D = S->D;
+    const int P = wa.P, T = wa.T, E = wa.E, D = wa.D;
     // state slabs (ev2g_device.h): every [E*P] array is slabP + k * PS8, the three [T,E] histories slabH + k * HS8, the
     // two per-session result arrays slabS + k * SS8 -- scalar adds on three base pointers instead of one pointer fetch
     // from the parameter block per array and use
-    const gptr slabP = (gptr)S->slab_port, slabH = (gptr)S->slab_hist, slabS = (gptr)S->slab_sess;
-    const unsigned long long PS8 = S->slab_port_slice, HS8 = S->hist_slice, SS8 = S->sess_slice;
+    const gptr slabP = (gptr)wa.slab_port, slabH = (gptr)wa.slab_hist, slabS = (gptr)S->slab_sess;
+    const unsigned long long PS8 = wa.slab_port_slice, HS8 = wa.hist_slice, SS8 = S->sess_slice;
+    const gptr env_acc = (gptr)wa.env_acc;
 #define PA(k) (slabP + PS8 * (unsigned long long)(k))
     const int EPW = 64 / P;   // envs per wavefront
     const int G = (EV2G_WAVE_BLOCK / 64) * EPW;    // envs per workgroup
@@ -107,44 +122,66 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     const int g = valid ? e * P + q : 0;
     const int ocol = (SK == 1) ? 3 + 3 * q : (SK == 0 ? 62 + 2 * q : 22 + 2 * q);
     const int cs = valid ? q : 0;
-    const double c_imax = S->cs_imax[cs], c_dmaxabs = S->cs_dmax_abs[cs];
-    if (tid < P) {
-        s_cst[0 * 64 + tid] = S->cs_imin[tid] - 0.01; s_cst[1 * 64 + tid] = S->cs_dmin[tid];
-        s_cst[2 * 64 + tid] = S->cs_maxp[tid]; s_cst[3 * 64 + tid] = S->cs_minp[tid];
-    }
     int t = t0;
-    if (valid) {
-        const unsigned g8 = (unsigned)g * 8u;
-        const i2v w = ldg32<i2v>(PA(EV2G_PS_WIN), g8);
-        const i2v sc = ldg32<i2v>(PA(EV2G_PS_SC), g8);
-        s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = sc.x; s_cyc[tid] = sc.y;
-        // s_dirty: bits 0,1 = what the epilogue must write back; bits 8.. = 1 + efficiency-table id of the attached EV, so
-        // that the battery maths can issue the table look-up together with (not behind) the session-record load
-        s_dirty[tid] = (ldg32<int>(PA(EV2G_PS_LUT), g8 >> 1) + 1) << 8;
-        if (w.x <= t && t <= w.y) {
-            s_cap[tid] = ldg32<double>(PA(EV2G_PS_CAP), g8); s_tot[tid] = ldg32<double>(PA(EV2G_PS_TOT), g8);
-            s_prev[tid] = ldg32<double>(PA(EV2G_PS_PREV), g8);
-            s_bcap[tid] = ldg32<double>(PA(EV2G_PS_BCAP), g8); s_potc[tid] = ldg32<double>(PA(EV2G_PS_POTC), g8);
-            s_abse[tid] = log_soc ? ldg32<double>(PA(EV2G_PS_ABSE), g8) : 0.0;
-        } else {
-            s_cap[tid] = 0.0; s_tot[tid] = 0.0; s_prev[tid] = 0.0; s_bcap[tid] = 1.0; s_potc[tid] = 0.0; s_abse[tid] = 0.0;
-        }
-    }
     const bool head = valid && q == 0;   // one lane per env: env-level scalars
     const int elg = wv * EPW + elw;      // env inside the workgroup
-    if (head) {   // episode accumulators and charge_power_potential[t] live in LDS (only head lanes use them)
-        for (int i = 0; i < 5; i++) eacc[elg * 6 + i] = 0.0;
-        eacc[elg * 6 + 5] = (t < T) ? S->pot_hist[t * E + e] : 0.0;
+    // ---- launch prologue.  A single-step launch (the RL loop with a policy between steps) pays it every step, with
+    // cold caches: occupancy windows, charger constants, the first action and the env accumulators are fetched in one
+    // round trip (unconditional, clamped loads), the per-EV state in a second one, only where an EV is attached.
+    double c_imax, c_dmaxabs, a_next;
+    {
+        const unsigned g8 = (unsigned)g * 8u, c8 = (unsigned)cs * 8u, cp8 = (unsigned)min(tid, P - 1) * 8u;
+        const unsigned ec = (unsigned)(valid ? e : e0);
+        i2v w = ldg32<i2v>(PA(EV2G_PS_WIN), g8), sc = ldg32<i2v>(PA(EV2G_PS_SC), g8);
+        int lut0 = ldg32<int>(PA(EV2G_PS_LUT), g8 >> 1);
+        c_imax = ldg32<double>(wa.cs_imax, c8); c_dmaxabs = ldg32<double>(wa.cs_dmax_abs, c8);
+        double k_imin = ldg32<double>(wa.cs_imin, cp8), k_dmin = ldg32<double>(wa.cs_dmin, cp8);
+        double k_maxp = ldg32<double>(wa.cs_maxp, cp8), k_minp = ldg32<double>(wa.cs_minp, cp8);
+        a_next = ldg32<double>(io.actions, (unsigned)(valid ? g : e0 * P) * 8u);
+        double l_pot = ldg32<double>(slabH + HS8, ((unsigned)min(t, T - 1) * (unsigned)E + ec) * 8u);
+        d2v acc01 = ldg32<d2v>(env_acc, ec * 64u), acc23 = ldg32<d2v>(env_acc, ec * 64u + 16u);
+        double acc4 = ldg32<double>(env_acc, ec * 64u + 32u);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w), "+v"(sc), "+v"(lut0), "+v"(c_imax), "+v"(c_dmaxabs), "+v"(k_imin), "+v"(k_dmin),
+                     "+v"(k_maxp), "+v"(k_minp), "+v"(a_next), "+v"(l_pot), "+v"(acc01), "+v"(acc23), "+v"(acc4));
+        if (tid < P) {
+            s_cst[0 * 64 + tid] = k_imin - 0.01; s_cst[1 * 64 + tid] = k_dmin;
+            s_cst[2 * 64 + tid] = k_maxp; s_cst[3 * 64 + tid] = k_minp;
+        }
+        if (valid) {
+            s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = sc.x; s_cyc[tid] = sc.y;
+            // s_dirty: bits 0,1 = what the epilogue must write back; bits 8.. = 1 + efficiency-table id of the attached EV,
+            // so that the battery maths can issue the table look-up together with (not behind) the session-record load
+            s_dirty[tid] = (lut0 + 1) << 8;
+            // the per-EV state is fetched only where an EV is attached (a launch starts with cold caches: bytes count)
+            if (w.x <= t && t <= w.y) {
+                s_cap[tid] = ldg32<double>(PA(EV2G_PS_CAP), g8); s_tot[tid] = ldg32<double>(PA(EV2G_PS_TOT), g8);
+                s_prev[tid] = ldg32<double>(PA(EV2G_PS_PREV), g8);
+                s_bcap[tid] = ldg32<double>(PA(EV2G_PS_BCAP), g8); s_potc[tid] = ldg32<double>(PA(EV2G_PS_POTC), g8);
+                s_abse[tid] = log_soc ? ldg32<double>(PA(EV2G_PS_ABSE), g8) : 0.0;
+            } else {
+                s_cap[tid] = 0.0; s_tot[tid] = 0.0; s_prev[tid] = 0.0; s_bcap[tid] = 1.0; s_potc[tid] = 0.0; s_abse[tid] = 0.0;
+            }
+        }
+        if (head) {   // episode accumulators (continued from global memory) and charge_power_potential[t], in LDS
+            double *ea = eacc + elg * 6;
+            ea[0] = acc01.x; ea[1] = acc01.y; ea[2] = acc23.x; ea[3] = acc23.y; ea[4] = acc4;
+            ea[5] = (t < T) ? l_pot : 0.0;
+        }
     }
     if (tid < 4) cnt[tid] = 0;
     for (int k = 0; k < EV2G_NQ; k++) stage[k * NS + tid] = 0.0;
-    double a_next = ldg32<double>(io.actions, (unsigned)(valid ? g : e0 * P) * 8u);
     __syncthreads();
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_next));   // the first action has landed: a plain value for the loop
 
     PT_DECL
+#if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
+    pt_acc[7] += pt_last - pt_k0;
+#endif
     for (int kk = 0; kk < k_steps; kk++) {
+#if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
+        PT_MARK(5)
+#else
         PT_MARK(7)
+#endif
         asm volatile("" : "+s"(S));
         int tid_l = tid, g_l = g, e_l = e, q_l = q, lane_l = lane;
         asm volatile("" : "+v"(tid_l), "+v"(g_l), "+v"(e_l), "+v"(q_l), "+v"(lane_l));
@@ -161,7 +198,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 stg32<int>(PA(EV2G_PS_SERVED), g8 >> 1, 0);
             }
             if (head) {
-                for (int i = 0; i < 8; i++) S->env_acc[e_l * 8 + i] = 0.0;
+                for (int i = 0; i < 8; i++) stg32<double>(env_acc, (unsigned)e_l * 64u + (unsigned)i * 8u, 0.0);
                 for (int i = 0; i < 6; i++) eacc[elg * 6 + i] = 0.0;
             }
             t = 0;
@@ -232,7 +269,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 if (u == 0) pf_ob0 = v; else if (u == 1) pf_ob1 = v; else pf_ob2 = v;
             }
         }
+#if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
+        PT_MARK(0)
+#else
         PT_MARK(6)
+#endif
         lds_barrier();
         PT_MARK(1)
         if (tid_l < 2) cnt[2 * ((kk + 1) & 1) + tid_l] = 0;   // next step's counters (last used two barriers ago)
@@ -441,12 +482,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             ea[0] += reward; ea[1] += costs; ea[2] += esum[4]; ea[3] += esum[5]; ea[4] += esum[6];
             if (io.reward) stg32<double>(io.reward + (long long)kk * io.r_stride, e8, reward);
             if (io.done) stg32<uint8_t>(io.done + (long long)kk * io.d_stride, (unsigned)e_l, (sstep >= T) ? 1 : 0);
-            if (sstep >= T || last_step) {  // flush the episode accumulators (get_statistics reads them)
-                for (int i = 0; i < 5; i++) {
-                    const unsigned a8 = (unsigned)e_l * 64u + (unsigned)i * 8u;
-                    stg32<double>(S->env_acc, a8, ldg32<double>(S->env_acc, a8) + ea[i]);
-                    ea[i] = 0.0;
-                }
+            if (sstep >= T || last_step) {  // publish the running episode totals (get_statistics reads them)
+                const unsigned a8 = (unsigned)e_l * 64u;
+                stg32<d2v>(env_acc, a8, (d2v){ea[0], ea[1]});
+                stg32<d2v>(env_acc, a8 + 16u, (d2v){ea[2], ea[3]});
+                stg32<double>(env_acc, a8 + 32u, ea[4]);
             }
         }
         if (valid && obs) {
@@ -476,7 +516,6 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // wavefront finished reading them (program order); other wavefronts never touch these slots outside phase B,
         // which is fenced by the two barriers.
     }
-    PT_FLUSH
     __syncthreads();
     if (valid) {
         const int d = s_dirty[tid];
@@ -488,4 +527,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             if (log_soc) stg32<double>(PA(EV2G_PS_ABSE), g8, s_abse[tid]);
         }
     }
+#if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PT_MARK(6)
+#endif
+    PT_FLUSH
 }

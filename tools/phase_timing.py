@@ -8,7 +8,9 @@ sys.path.insert(0, ROOT)
 from ev2gym_amd import build, engine, _abi
 so = os.path.join(ROOT, "gpurun_out", "libev2g_hip_pt.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call([build.hipcc()] + build.FLAGS + ["-DEV2G_PHASE_TIMING", "-o", so, build.SRC])
+OUTER = "--outer" in sys.argv
+if OUTER: sys.argv.remove("--outer")
+subprocess.check_call([build.hipcc()] + build.FLAGS + ["-DEV2G_PHASE_TIMING"] + (["-DEV2G_PT_OUTER"] if OUTER else []) + ["-o", so, build.SRC])
 engine._LIB_PATH = so
 L = engine.load_library(so)
 from bench import WORKLOADS
@@ -22,6 +24,7 @@ P, D, T = eng.P, eng.D, eng.T
 acts = eng.empty((T, E, P)); eng.fill_uniform(acts, T * E * P, 1, wl["lo"], 1.0)
 obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
 names = ["A home/charger", "barrier waits", "B battery maths", "C home", "D reduce", "E env-level", "prefetch issue", "loop top"]
+if OUTER: names[6], names[7] = "EPILOGUE (state write-back)", "PROLOGUE (state load)"
 for persistent in (True, False):
     eng.reset(obs)
     eng.step_n(T, acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=persistent)
