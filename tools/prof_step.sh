@@ -21,6 +21,6 @@ print("## PMC, average per dispatch of the step kernel")
 for d in ['pmc1','pmc2','pmc3','pmc4']:
     try:
         con=sqlite3.connect(f'gpurun_out/prof/{d}/{d}_results.db')
-        for r in con.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection where kernel_name like '%step%' group by kernel_name, counter_name"): print("PMC |", r[0][:28], "|", r[1], "|", round(r[2],1), "| n =", r[3])
+        for r in con.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection where kernel_name like '%ev2g_step_%' group by kernel_name, counter_name"): print("PMC |", r[0][:28], "|", r[1], "|", round(r[2],1), "| n =", r[3])
     except Exception as e: print(d,'ERR',e)
 P
