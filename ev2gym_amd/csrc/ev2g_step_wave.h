@@ -20,7 +20,7 @@
 
 __host__ __device__ inline size_t ev2g_wave_lds_bytes(int envs_per_group) {
     const size_t NS = EV2G_WAVE_BLOCK;
-    return sizeof(double) * ((EV2G_NQ + 7) * NS + 6 * (size_t)envs_per_group + 4 * 64) + sizeof(int) * (6 * NS + 8);
+    return sizeof(double) * (EV2G_NQ * (NS + 8) + 7 * NS + 6 * (size_t)envs_per_group + 4 * 64) + sizeof(int) * (6 * NS + 8);
 }
 
 // xor-butterfly partners inside 8-lane groups through DPP (VALU cross-lane moves, a few cycles) instead of
@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     typedef const V2P __attribute__((address_space(4))) *ParamPtr;
     ParamPtr S = (ParamPtr)(unsigned long long)params;
     constexpr int NS = EV2G_WAVE_BLOCK;
+    constexpr int RS = NS + 8;   // stage row stride: +16 banks per row, so the 8 rows one reduction read touches spread over all banks
     const int P = wa.P, T = wa.T, E = wa.E, D = wa.D;
     // state slabs (ev2g_device.h): every [E*P] array is slabP + k * PS8, the three [T,E] histories slabH + k * HS8, the
     // two per-session result arrays slabS + k * SS8 -- scalar adds on three base pointers instead of one pointer fetch
@@ -99,8 +100,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         grp = (nb & 7) == 0 ? (b & 7) * per + (b >> 3) : b;
     }
     const int e0 = grp * G;
-    double *stage = lds;                                   // [NQ][NS] per-port step results, by home index (= tid)
-    double *s_cap = stage + (size_t)EV2G_NQ * NS;
+    double *stage = lds;                                   // [NQ][RS] per-port step results, by home index (= tid)
+    double *s_cap = stage + (size_t)EV2G_NQ * RS;
     double *s_tot = s_cap + NS, *s_prev = s_tot + NS, *s_bcap = s_prev + NS, *s_potc = s_bcap + NS;
     double *s_amps = s_potc + NS, *s_abse = s_amps + NS;
     double *eacc = s_abse + NS;                            // [G][6] episode accumulators + charge_power_potential[t], per env
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         }
     }
     if (tid < 4) cnt[tid] = 0;
-    for (int k = 0; k < EV2G_NQ; k++) stage[k * NS + tid] = 0.0;
+    for (int k = 0; k < EV2G_NQ; k++) stage[k * RS + tid] = 0.0;
     __syncthreads();
 
     PT_DECL
@@ -227,11 +228,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 else if (x < 0.0) { const double c_dmin = s_cst[1 * 64 + q_l]; amps = x * c_dmaxabs; if (amps > c_dmin - 0.01) amps = c_dmin; }
             }
             s_amps[tid_l] = amps;
-            stage[0 * NS + tid_l] = 0.0;
-            stage[4 * NS + tid_l] = 0.0;
-            stage[5 * NS + tid_l] = 0.0;
-            stage[6 * NS + tid_l] = 0.0;
-            stage[7 * NS + tid_l] = 0.0;
+            stage[0 * RS + tid_l] = 0.0;
+            stage[4 * RS + tid_l] = 0.0;
+            stage[5 * RS + tid_l] = 0.0;
+            stage[6 * RS + tid_l] = 0.0;
+            stage[7 * RS + tid_l] = 0.0;
             if (amps != 0.0) items[(amps > 0.0) ? atomicAdd(&cntk[0], 1) : NS - 1 - atomicAdd(&cntk[1], 1)] = tid_l;
         }
         PT_MARK(0)
@@ -306,10 +307,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     s_cyc[h] = o.cycles;
                     s_amps[h] = o.energy;
                     if (log_soc) s_abse[h] += fabs(o.energy);
-                    stage[0 * NS + h] = o.energy * 60.0 / dtd;
-                    stage[(i < nch ? 4 : 5) * NS + h] = fabs(o.energy);
-                    stage[6 * NS + h] = (double)o.emerg;
-                    stage[7 * NS + h] = o.current;
+                    stage[0 * RS + h] = o.energy * 60.0 / dtd;
+                    stage[(i < nch ? 4 : 5) * RS + h] = fabs(o.energy);
+                    stage[6 * RS + h] = (double)o.emerg;
+                    stage[7 * RS + h] = o.current;
                 }
             }
         }
@@ -330,10 +331,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             double cap = s_cap[tid_l];
             if (occ) {
                 const double energy = s_amps[tid_l];
-                const double current = stage[7 * NS + tid_l];
+                const double current = stage[7 * RS + tid_l];
                 if (energy != 0.0) {  // profit by the sign of the ACTION (ev_charger.py:178,194), staged under 4 / 5
-                    const double ech = stage[4 * NS + tid_l];
-                    profit = (ech != 0.0) ? ech * pf_pch : stage[5 * NS + tid_l] * pf_pdis;
+                    const double ech = stage[4 * RS + tid_l];
+                    profit = (ech != 0.0) ? ech * pf_pch : stage[5 * RS + tid_l] * pf_pdis;
                 }
                 if (current - 0.0001 > c_imax) stg32<int>(S->env_fault, (unsigned)e_l * 4u, 1);  // ev_charger.py:203-205
                 if (last_step) { stg32<double>(PA(EV2G_PS_PENERGY), g8, energy); stg32<double>(PA(EV2G_PS_PCURRENT), g8, current); }
@@ -396,9 +397,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 stg32<double>(obs, o8 + 8u, o1);
                 if (SK == 1) stg32<double>(obs, o8 + 16u, o2);
             }
-            stage[1 * NS + tid_l] = profit;
-            stage[2 * NS + tid_l] = satpen;
-            stage[3 * NS + tid_l] = pot;
+            stage[1 * RS + tid_l] = profit;
+            stage[2 * RS + tid_l] = satpen;
+            stage[3 * RS + tid_l] = pot;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wavefront's LDS writes are visible to itself
         PT_MARK(3)
@@ -413,7 +414,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         {
             const int k = lane_l >> 3, j = lane_l & 7;
             const int wbase = (tid_l & ~63);
-            const double *row = stage + k * NS;
+            const double *row = stage + k * RS;
 #pragma unroll 1
             for (int w = 0; w < EPW; w++) {
                 const int a = wbase + w * P, b = a + P;
@@ -432,13 +433,13 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 acc += xor1_f64(acc);
                 acc += xor2_f64(acc);
                 acc += xor4_f64(acc);
-                if (j == 0) stage[k * NS + a] = acc;
+                if (j == 0) stage[k * RS + a] = acc;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         double esum[EV2G_NQ];
 #pragma unroll
-        for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = stage[kq * NS + tid_l];   // meaningful in head lanes only
+        for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = stage[kq * RS + tid_l];   // meaningful in head lanes only
 
         PT_MARK(4)
         // ---------------- E: per env (head lane) + observation head (the env's lanes) ----------------
