@@ -324,6 +324,11 @@ def main():
     cases.append(("v2gppl_c10r3_mixed_s14", r3, *PPL, 14, "mixed", None))
     big = _yaml_variant(ppl, {"number_of_charging_stations": 1000, "number_of_transformers": 50}, "v2gppl_c1000_r50")
     cases.append(("v2gppl_c1000r50_rand_s15", big, *PPL, 15, "rand", 16))
+    # other timescales: 60/dt = 12 (not a power of two -> the engine's division path) and 2 (multiplication path)
+    ts5 = _yaml_variant(ppl, {"timescale": 5}, "v2gppl_ts5")
+    cases.append(("v2gppl_ts5_rand_s16", ts5, *PPL, 16, "rand", None))
+    ts30 = _yaml_variant(pst, {"timescale": 30}, "pst_ts30")
+    cases.append(("pst_ts30_rand_s17", ts30, *PST, 17, "rand", None))
     for c in cases:
         if only and c[0] not in only:
             continue

@@ -92,7 +92,8 @@ def _tiled(name, E):
 
 @pytest.mark.parametrize("name,E,lo", [("v2gppl_c50_rand_s9", 333, -1.0), ("pst_rand_s2", 517, 0.0),
                                        ("v2gppl_c60r5_rand_s13", 97, -1.0), ("v2gppl_p2_rand_s11", 130, -1.3),
-                                       ("pst_p3_rand_s12", 77, 0.0), ("v2gppl_c1000r50_rand_s15", 9, -1.0)])
+                                       ("pst_p3_rand_s12", 77, 0.0), ("v2gppl_c1000r50_rand_s15", 9, -1.0),
+                                       ("v2gppl_ts5_rand_s16", 64, -1.0), ("pst_ts30_rand_s17", 65, 0.0)])   # 60/dt = 12, 2
 def test_engine_matches_oracle_batched(name, E, lo):
     """Many envs per launch, a different action stream per env: engine == CPU oracle at every step."""
     from ev2gym_amd.engine import host_uniform
