@@ -18,7 +18,7 @@ def _same_25cs():
     for f in GOLDEN_FILES:
         if os.path.basename(f).startswith("v2gppl_") and "_s" in f:
             z, b, rk, sk = load_golden(f)
-            if b.n_chargers == 25 and b.ports_per_charger == 1 and b.arrays["cs_min_charge_current"][0] == 0:
+            if b.n_chargers == 25 and b.ports_per_charger == 1 and b.timescale == 15 and b.arrays["cs_min_charge_current"][0] == 0:
                 out.append(b)
     return out
 
