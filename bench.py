@@ -172,7 +172,10 @@ def main():
     done = torch.empty((E,), dtype=torch.uint8, device=dev)
     mask = torch.empty((E, P), dtype=torch.uint8, device=dev)
     stats = torch.empty((E, _abi.N_STATS), dtype=torch.float64, device=dev)
-    gathered = torch.empty((world * E, _abi.N_STATS), dtype=torch.float64, device=dev) if world > 1 else None
+    gath = None
+    if world > 1:   # double-buffered asynchronous all-gather: the statistics travel while the next episode steps
+        from ev2gym_amd.dist import AsyncStatsGather
+        gath = AsyncStatsGather(E, world, dev)
 
     actor = None
     if args.actor == "mlp":
@@ -202,12 +205,16 @@ def main():
                 timing.append((eng.last_step_n_kernel_ms(), k))
             left -= k
             if eng.current_step >= T:
-                eng.stats(out=stats)
-                if world > 1:
-                    dist.all_gather_into_tensor(gathered, stats)
+                if gath is None:
+                    eng.stats(out=stats)
+                else:
+                    eng.stats(out=gath.buffer())
+                    gath.launch()
                 eng.reset(obs)
 
     def barrier():
+        if gath is not None:
+            gath.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -255,7 +262,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": E, "chargers": C_,
                    "transformers": R_, "steps_per_episode": T, "obs_dim": D, "occupancy_phi": round(phi, 4), "soc_log": not args.no_soc_log,
-                   "launch": best, "actor": args.actor, "parallelism": f"env-sharded x{world}, RCCL all_gather of episode stats only"},
+                   "launch": best, "actor": args.actor, "parallelism": f"env-sharded x{world}, RCCL all_gather of episode stats only (asynchronous, overlaps the next episode)"},
         "port_steps_per_s": value * P,
         "wall_s_by_launch_mode": {m: round(w, 6) for m, w in wall.items()},
         "env_steps_per_s_by_launch_mode": {m: env_steps_total / w for m, w in wall.items()},
@@ -272,6 +279,7 @@ def main():
         out["cpu_baseline"] = None
     eng.close()
     if world > 1:
+        gath.finish()
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -49,3 +49,48 @@ def gather_stats(vec_env, group=None):
     else:
         st = torch.from_numpy(np.ascontiguousarray(vec_env.engine.stats()))
     return gather_stats_tensor(st, group)
+
+
+class AsyncStatsGather:
+    """Per-episode statistics all-gather that overlaps with the next episode (equal env counts per rank).
+
+    Two [E,17] send buffers and two [world*E,17] receive buffers alternate.  `buffer()` hands out the send buffer of
+    the current episode (first waiting, on the device, for the gather that used it two episodes ago); `launch()`
+    starts the all-gather asynchronously -- the collective is ordered after the kernels already queued on the
+    current stream, and the current stream does not wait for it, so the next episode's step kernels run while the
+    statistics travel over xGMI; `finish()` waits for everything outstanding and returns the last result.
+    """
+
+    def __init__(self, n_envs: int, world: int, device, dtype=None, group=None):
+        import torch
+        dtype = dtype or torch.float64
+        self.group, self.world = group, world
+        self.send = [torch.zeros((n_envs, _abi.N_STATS), dtype=dtype, device=device) for _ in range(2)]
+        self.recv = [torch.zeros((world * n_envs, _abi.N_STATS), dtype=dtype, device=device) for _ in range(2)]
+        self.work = [None, None]
+        self.i = 0
+        self.launched = 0
+
+    def buffer(self):
+        w = self.work[self.i]
+        if w is not None:
+            w.wait()
+            self.work[self.i] = None
+        return self.send[self.i]
+
+    def launch(self):
+        import torch.distributed as dist
+        if self.world > 1:
+            self.work[self.i] = dist.all_gather_into_tensor(self.recv[self.i], self.send[self.i], group=self.group, async_op=True)
+        else:
+            self.recv[self.i].copy_(self.send[self.i])
+        self.last = self.i
+        self.i ^= 1
+        self.launched += 1
+
+    def finish(self):
+        for k in (0, 1):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
+        return self.recv[self.last] if self.launched else None

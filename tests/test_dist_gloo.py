@@ -59,3 +59,42 @@ def test_two_rank_shards_plus_gather_equal_single_process(tmp_path):
     want = ora.stats()
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.array_equal(np.nan_to_num(got), np.nan_to_num(want)), "sharded + gathered statistics must equal the single-process run bit for bit"
+
+
+def _async_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from ev2gym_amd import _abi
+    from ev2gym_amd.dist import AsyncStatsGather
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    E = 6
+    g = AsyncStatsGather(E, world, "cpu")
+    seen = []
+    for ep in range(5):   # five "episodes": the buffers alternate, every gather must carry that episode's values
+        buf = g.buffer()
+        buf.copy_(torch.full((E, _abi.N_STATS), float(100 * ep + rank), dtype=torch.float64)
+                  + torch.arange(E, dtype=torch.float64)[:, None])
+        g.launch()
+        if ep >= 1:       # the previous episode's result is complete once its work was waited on in buffer()/finish()
+            pass
+    out = g.finish()
+    seen.append(out.clone())
+    want = torch.cat([torch.full((E, _abi.N_STATS), float(100 * 4 + r), dtype=torch.float64)
+                      + torch.arange(E, dtype=torch.float64)[:, None] for r in range(world)], 0)
+    assert torch.equal(out, want), (rank, out[:, 0], want[:, 0])
+    # the other receive buffer still holds the episode before (nothing overwrote it out of order)
+    prev = g.recv[g.last ^ 1]
+    wantp = torch.cat([torch.full((E, _abi.N_STATS), float(100 * 3 + r), dtype=torch.float64)
+                       + torch.arange(E, dtype=torch.float64)[:, None] for r in range(world)], 0)
+    assert torch.equal(prev, wantp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_async_double_buffered_stats_gather_two_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_async_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
