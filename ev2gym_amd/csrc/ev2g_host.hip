@@ -249,6 +249,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     std::vector<int> sess_port((size_t)S), host_to_dev((size_t)S);
     std::vector<long long> dev_to_host((size_t)S);
     std::vector<int> port_first((size_t)E * P, -1);
+    std::vector<int> port_end((size_t)E * P, -1);   // one past the port's last session (device order: a port's sessions are consecutive)
     std::vector<int2> port_first_win((size_t)E * P, make_int2(EV2G_INT_MAX, EV2G_INT_MAX));
     {
         std::vector<int> free_at((size_t)C * npc);
@@ -291,6 +292,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
                     port_first[g] = (int)d;
                     port_first_win[g] = make_int2(b->ev_t_arr[kv.second], b->ev_t_dep[kv.second]);
                 }
+                port_end[g] = (int)d + 1;
                 d++;
             }
         }
@@ -373,7 +375,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         const unsigned long long lim = 1ull << 32;
         const unsigned long long biggest = std::max({(unsigned long long)E * P * 8, (unsigned long long)E * D * 8,
                                                      (unsigned long long)E * (T + 1) * 60 * 8, (unsigned long long)S * sizeof(SessRec),
-                                                     (unsigned long long)E * T * 64});
+                                                     (unsigned long long)E * T * 64, (unsigned long long)E * P * T * 8});
         if (biggest >= lim) h->wave_path = false;
     }
     if (h->wave_path) s.G = (EV2G_WAVE_BLOCK / 64) * (64 / P);   // wave-aligned: 64/P envs per wavefront
@@ -493,6 +495,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     double *d_lut_eta = nullptr;
     UP(d_lut_eta, lut_eta)
     UP(ip, port_first) s.port_first = ip;
+    UP(ip, port_end) s.port_end = ip;
     UP(i2p, port_first_win) s.port_first_win = i2p;
     UP(dp, ss_afap) h->d_ss_afap = dp;
     { SessRec *rp; UP(rp, recs) s.rec = rp; }
@@ -589,9 +592,8 @@ int ev2g_reset(ev2g_handle *h, double *obs) {
     if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_reset: no scenarios loaded");
     (void)hipSetDevice(h->device);
     const DevScn &s = h->scn;
-    HIPCHK(h, hipMemsetAsync(h->st.usage_hist, 0, sizeof(double) * (size_t)s.T * s.E, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->st.pot_hist, 0, sizeof(double) * (size_t)s.T * s.E, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->st.over_hist, 0, sizeof(double) * (size_t)s.T * s.E * s.R, h->stream));
+    // usage | potential | overload histories are one slab: one fill
+    HIPCHK(h, hipMemsetAsync(h->st.slab_hist, 0, sizeof(double) * (size_t)s.T * s.E * (2 + s.R), h->stream));
     if (h->st.cs_power_hist) {
         HIPCHK(h, hipMemsetAsync(h->st.cs_power_hist, 0, sizeof(double) * (size_t)s.T * s.E * s.C, h->stream));
         HIPCHK(h, hipMemsetAsync(h->st.cs_cur_hist, 0, sizeof(double) * (size_t)s.T * s.E * s.C, h->stream));
