@@ -828,9 +828,24 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, c
                 double hs = 0.0, fs = 0.0;
                 int n = 0, nf = 0;
                 // historic_soc / active_steps (sign bit set = inactive step).  The log is [T, E*P]: consecutive steps of a
-                // port are E*P*8 bytes apart, every read is its own cache line, so the loop is bound by memory latency --
-                // eight unconditional (clamped) loads are issued before any is consumed; accumulation order unchanged.
-                for (int t = ta; t <= tend; t += 8) {
+                // port are E*P*8 bytes apart, every read is its own 32-byte sector -- the kernel is bound by that sector
+                // traffic.  The first NK steps of a session are fetched by unconditional (clamped) loads issued together
+                // and KEPT in registers for the second pass; only the tail of longer sessions is read twice, in batches
+                // of eight.  Accumulation order is the sequential one.
+                constexpr int NK = 24;
+                double xk[NK];
+#pragma unroll
+                for (int u = 0; u < NK; u++) xk[u] = st.soc_log[(long long)min(ta + u, tend) * EP + g];
+#pragma unroll
+                for (int u = 0; u < NK; u++) {
+                    if (ta + u <= tend) {
+                        const double soc = fabs(xk[u]) / B;
+                        hs += soc; n++;
+                        if (__double_as_longlong(xk[u]) >= 0) { fs += soc; nf++; }
+                    }
+                    if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four divisions in flight, not NK (registers)
+                }
+                for (int t = ta + NK; t <= tend; t += 8) {
                     double x[8];
 #pragma unroll
                     for (int u = 0; u < 8; u++) x[u] = st.soc_log[(long long)min(t + u, tend) * EP + g];
@@ -847,7 +862,12 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, c
                 fs += soc_f; nf++;
                 const double avg_soc = hs / n, avg_f = fs / nf;
                 double mad = 0.0;
-                for (int t = ta; t <= tend; t += 8) {
+#pragma unroll
+                for (int u = 0; u < NK; u++) {
+                    if (ta + u <= tend && __double_as_longlong(xk[u]) >= 0) mad += fabs(avg_f - fabs(xk[u]) / B);
+                    if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+                for (int t = ta + NK; t <= tend; t += 8) {
                     double x[8];
 #pragma unroll
                     for (int u = 0; u < 8; u++) x[u] = st.soc_log[(long long)min(t + u, tend) * EP + g];
