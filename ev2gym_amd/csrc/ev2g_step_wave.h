@@ -446,6 +446,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const double usage = esum[0];
         if (head) {
             double *ea = eacc + elg * 6;
+            // all six accumulator words are read up front (one LDS wait) and written back together at the end; reading
+            // each one next to its update made every update wait for its own LDS round trip
+            const double ea0 = ea[0], ea1 = ea[1], ea2 = ea[2], ea3 = ea[3], ea4 = ea[4], ea5 = ea[5];
             const unsigned e8 = (unsigned)e_l * 8u;
             double over100 = 0.0;
             if (RK == 0) {  // Transformer.reset + step + get_how_overloaded (transformer.py:258-302)
@@ -470,7 +473,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             const double costs = esum[1];
             double reward;
             if (RK == 1) {  // SquaredTrackingErrorReward reward.py:7-14
-                const double pp = ea[5];
+                const double pp = ea5;
                 const double m = (pp < pf_sp) ? pp : pf_sp;
                 const double d = m - usage;
                 reward = -(d * d);
@@ -479,15 +482,15 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
                 reward = costs - over100 - esum[2];
             }
-            ea[5] = potn;
-            ea[0] += reward; ea[1] += costs; ea[2] += esum[4]; ea[3] += esum[5]; ea[4] += esum[6];
+            const double n0 = ea0 + reward, n1 = ea1 + costs, n2 = ea2 + esum[4], n3 = ea3 + esum[5], n4 = ea4 + esum[6];
+            ea[0] = n0; ea[1] = n1; ea[2] = n2; ea[3] = n3; ea[4] = n4; ea[5] = potn;
             if (io.reward) stg32<double>(io.reward + (long long)kk * io.r_stride, e8, reward);
             if (io.done) stg32<uint8_t>(io.done + (long long)kk * io.d_stride, (unsigned)e_l, (sstep >= T) ? 1 : 0);
             if (sstep >= T || last_step) {  // publish the running episode totals (get_statistics reads them)
                 const unsigned a8 = (unsigned)e_l * 64u;
-                stg32<d2v>(env_acc, a8, (d2v){ea[0], ea[1]});
-                stg32<d2v>(env_acc, a8 + 16u, (d2v){ea[2], ea[3]});
-                stg32<double>(env_acc, a8 + 32u, ea[4]);
+                stg32<d2v>(env_acc, a8, (d2v){n0, n1});
+                stg32<d2v>(env_acc, a8 + 16u, (d2v){n2, n3});
+                stg32<double>(env_acc, a8 + 32u, n4);
             }
         }
         if (valid && obs) {
