@@ -50,6 +50,8 @@ def kernel_name(batch, sk, rk):
     """Which step kernel ev2g_load_scenarios() selects for this shape (ev2gym_amd/csrc/ev2g_host.hip)."""
     P, R, npc = batch.n_ports, batch.n_transformers, batch.ports_per_charger
     k = os.environ.get("EV2G_KERNEL", "")
+    if P <= 64 and R == 1 and npc == 1 and k == "pipe":
+        return f"ev2g_step_pipe<{sk},{rk}>"
     if P <= 64 and R == 1 and npc == 1 and k != "v2":
         return (f"ev2g_step_list<{sk},{rk},{256 if k == 'list256' else 128}>" if k in ("list", "list256") and P >= 4
                 else f"ev2g_step_wave<{sk},{rk}>")

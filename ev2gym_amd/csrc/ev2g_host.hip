@@ -18,6 +18,7 @@
 #include "ev2g_step_v2.h"
 #include "ev2g_step_wave.h"
 #include "ev2g_step_list.h"
+#include "ev2g_step_pipe.h"
 #include <cstdlib>
 
 static thread_local std::string g_create_error;
@@ -44,6 +45,7 @@ struct ev2g_handle {
     V2P *d_v2p = nullptr;                       // device copy of the v2 kernel's parameter block
     int block = 0;                              // 256/512/1024: v2 kernel; 0: generic kernel (P > 1024)
     bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
+    bool pipe_path = false;                     // ev2g_step_pipe: wave path with dedicated battery-maths wavefronts (EV2G_KERNEL=pipe)
     bool list_path = false;                     // ev2g_step_list: same shape, 4 <= P (work proportional to occupied ports)
     int list_wb = 128;                          // workgroup size of the list kernel (128 or 256)
     int current_step = 0;
@@ -388,6 +390,8 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         if (kn && std::string(kn) == "v2") { h->wave_path = h->list_path = false; s.G = std::min(std::max(1, blk / P), E); }
         h->list_wb = (kn && std::string(kn) == "list256") ? 256 : 128;
         if (h->list_path) s.G = (h->list_wb / 64) * (64 / P);
+        h->pipe_path = h->wave_path && !h->list_path && kn && std::string(kn) == "pipe";
+        if (h->pipe_path) s.G = EV2G_PIPE_ENVW * (64 / P);
     }
     {
         int gs = 4;
@@ -399,6 +403,8 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     s.dt_over_60 = (double)b->timescale / 60.0;
     if (h->list_path)
         h->lds_bytes = ev2g_list_lds_bytes(h->list_wb);
+    else if (h->pipe_path)
+        h->lds_bytes = ev2g_pipe_lds_bytes(s.G);
     else if (h->wave_path)
         h->lds_bytes = ev2g_wave_lds_bytes(s.G);
     else if (h->block)
@@ -413,6 +419,12 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
                          : h->block == 1024 ? (const void *)ev2g_step_v2<1024> : (const void *)ev2g_step_kernel;
         if (h->lds_bytes > 48 * 1024)
             HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        if (h->pipe_path) {
+#define EV2G_PIPE_ATTR(SK, RK) HIPCHK(h, hipFuncSetAttribute((const void *)ev2g_step_pipe<SK, RK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+            EV2G_PIPE_ATTR(0, 0) EV2G_PIPE_ATTR(0, 1) EV2G_PIPE_ATTR(0, 2) EV2G_PIPE_ATTR(1, 0) EV2G_PIPE_ATTR(1, 1) EV2G_PIPE_ATTR(1, 2)
+            EV2G_PIPE_ATTR(2, 0) EV2G_PIPE_ATTR(2, 1) EV2G_PIPE_ATTR(2, 2)
+#undef EV2G_PIPE_ATTR
+        }
     }
     // AoS session records (one cache line each) for the v2 kernel
     std::vector<SessRec> recs((size_t)std::max<long long>(S, 1));
@@ -623,6 +635,25 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
             EV2G_LIST_CASE(2, 0) EV2G_LIST_CASE(2, 1) EV2G_LIST_CASE(2, 2)
         }
 #undef EV2G_LIST_CASE
+        HIPCHK(h, hipGetLastError());
+        return EV2G_OK;
+    }
+    if (h->pipe_path) {
+        const V2P *pp = (const V2P *)h->d_v2p;
+        const DevState &st = h->st;
+        const WaveArgs wa{s.P, s.T, s.E, s.D, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
+                          st.env_acc, s.cs_imax, s.cs_dmax_abs, s.cs_imin, s.cs_dmin, s.cs_maxp, s.cs_minp};
+#define EV2G_PIPE_CASE(SK, RK)                                                                                         \
+    case SK * 3 + RK:                                                                                                  \
+        hipLaunchKernelGGL((ev2g_step_pipe<SK, RK>), dim3(s.n_groups), dim3(EV2G_PIPE_BLOCK), h->lds_bytes, h->stream, \
+                           pp, io, t0, k, auto_reset, wa);                                                             \
+        break;
+        switch (s.state_kind * 3 + s.reward_kind) {
+            EV2G_PIPE_CASE(0, 0) EV2G_PIPE_CASE(0, 1) EV2G_PIPE_CASE(0, 2)
+            EV2G_PIPE_CASE(1, 0) EV2G_PIPE_CASE(1, 1) EV2G_PIPE_CASE(1, 2)
+            EV2G_PIPE_CASE(2, 0) EV2G_PIPE_CASE(2, 1) EV2G_PIPE_CASE(2, 2)
+        }
+#undef EV2G_PIPE_CASE
         HIPCHK(h, hipGetLastError());
         return EV2G_OK;
     }

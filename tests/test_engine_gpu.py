@@ -179,7 +179,7 @@ def test_engine_is_deterministic():
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
-@pytest.mark.parametrize("kernel", ["wave", "list", "list256", "v2"])
+@pytest.mark.parametrize("kernel", ["wave", "pipe", "list", "list256", "v2"])
 @pytest.mark.parametrize("name,E,lo", [("v2gppl_c50_rand_s9", 131, -1.0), ("pst_rand_s2", 203, 0.0)])
 def test_every_kernel_variant_matches_oracle(kernel, name, E, lo, monkeypatch):
     """The common shape (P <= 64, one transformer, single-port chargers) has three kernels: the wave-aligned default,
