@@ -280,6 +280,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         if (tid_l < 2) cnt[2 * ((kk + 1) & 1) + tid_l] = 0;   // next step's counters (last used two barriers ago)
 
         // ---------------- B: worker lanes, battery maths on the compact list ----------------
+        // The wavefronts that hold list items are the critical path of the whole workgroup (the others wait at the next
+        // barrier): they issue at raised priority until their items are done.
+        __builtin_amdgcn_s_setprio(3);
         {
             const int nch = cntk[0], ndis = cntk[1];
             const int nchp = (nch + 63) & ~63;
@@ -314,6 +317,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         PT_MARK(2)
         lds_barrier();
         PT_MARK(1)
