@@ -385,6 +385,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
         PT_MARK(1)
 
         // ---------------- B: worker lanes, battery maths on the compact list ----------------
+        __builtin_amdgcn_s_setprio(3);   // the wavefronts holding list items are the workgroup's critical path
         {
             const int nch = cnt[0], ndis = cnt[1];
             const int nchp = (nch + 63) & ~63;  // discharge items start on a wavefront boundary
@@ -414,6 +415,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         PT_MARK(2)
         lds_barrier();
         PT_MARK(1)
