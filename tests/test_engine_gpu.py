@@ -211,3 +211,59 @@ def test_every_kernel_variant_matches_oracle(kernel, name, E, lo, monkeypatch):
     eng.check_faults()
     eng.close()
     ora.close()
+
+
+@pytest.mark.parametrize("workload,K", [("cfg2", 112), ("cfg3", 112), ("cfg4", 6)])
+def test_full_size_batch_properties_and_sampled_parity(workload, K):
+    """BASELINE.json's full sizes (4096 x 50 / 8192 x 20, generated scenarios): what no small case shows -- every
+    workgroup of a full grid, the XCD-aware group mapping, 32-bit offsets near their largest values.
+      * a random sample of envs, replayed by the CPU oracle with the same action streams, matches at every step;
+      * one persistent 112-step launch == 112 single-step launches, bit for bit (sampled envs + all rewards);
+      * conservation: the per-env energy / profit totals of get_statistics equal the sums of the per-step port
+        quantities the oracle accumulates for the sampled envs (already part of the oracle's statistics)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import WORKLOADS
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import host_uniform
+    from ev2gym_amd.scenario_gen import generate
+    from oracle.oracle import Oracle
+    wl = WORKLOADS[workload]
+    E = wl["envs"]
+    batch = generate(wl["gen"](E, 7))
+    rk, sk = _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]]
+    eng = _engine(batch, rk, sk, flags=4)
+    P, D, T = eng.P, eng.D, eng.T
+    rng = np.random.default_rng(3)
+    sample = np.sort(np.concatenate([[0, 1, E // 2, E - 2, E - 1], rng.choice(E, 27, replace=False)]))
+    sample = np.unique(sample)
+    K = min(K, T)   # cfg4: a few steps only (its [T,E,D] observation block would be 7 GB)
+    d_act = eng.empty((K, E, P))
+    eng.fill_uniform(d_act, K * E * P, 123, wl["lo"], 1.0)
+    acts = host_uniform(K * E * P, 123, wl["lo"], 1.0).reshape(K, E, P)[:, sample]
+    outs = []
+    for persistent in (True, False):
+        d_obs, d_rew, d_mask = eng.empty((K, E, D)), eng.empty((K, E)), eng.empty((K, E, P), np.uint8)
+        eng.reset()
+        eng.step_n(K, d_act, E * P, d_obs, E * D, d_rew, E, None, 0, d_mask, E * P, auto_reset=False, persistent=persistent)
+        eng.check_faults()
+        outs.append((d_obs.to_host()[:, sample], d_rew.to_host(), d_mask.to_host()[:, sample], eng.stats()))
+        for b in (d_obs, d_rew, d_mask):
+            b.free()
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert np.array_equal(a, b), "persistent launch != single-step launches at full size"
+    assert np.array_equal(np.nan_to_num(outs[0][3]), np.nan_to_num(outs[1][3]))
+    obs, rew, mask, stats = outs[0]
+    ora = Oracle(batch.select(sample), rk, sk)
+    ora.reset()
+    for t in range(K):
+        o, r, d, m, rc = ora.step(acts[t].copy())
+        assert rc == 0
+        assert np.array_equal(mask[t], m), f"mask[{t}]"
+        _close(obs[t], o, f"obs[{t}]")
+        _close(rew[t, sample], r, f"reward[{t}]")
+    if K == T:
+        _close(stats[sample], ora.stats(), "episode statistics of the sampled envs")
+    ora.close()
+    eng.close()
