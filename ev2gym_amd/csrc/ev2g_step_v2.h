@@ -193,7 +193,7 @@ inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
 // LDS carve-up for ev2g_step_v2 (doubles first, then ints); NS = G*P, NT = G*R
 __host__ __device__ inline size_t ev2g_v2_lds_bytes(int NS, int NT, int G, int R) {
     return sizeof(double) * ((size_t)(EV2G_NQ + 7) * NS + (size_t)EV2G_NQ * NT + (size_t)EV2G_NQ * G + (size_t)NT +
-                             (size_t)G * 6) +
+                             (size_t)G * 7) +
            sizeof(int) * (6 * (size_t)NS + 2 * (size_t)R + 1 + 4);
 }
 
@@ -224,7 +224,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     double *over_l = esum + (size_t)EV2G_NQ * G;           // [NT] 100 * overload of each (env, transformer)
     double *eacc = over_l + NT;                            // [G][5] episode accumulators
     double *pot_prev = eacc + (size_t)G * 5;               // [G] charge_power_potential[t]
-    int *s_ta = (int *)(pot_prev + G);                     // window {t_arr, t_dep} of the attached-or-next session
+    double *osum = pot_prev + G;                           // [G] sum of 100 * overload over the env's transformers
+    int *s_ta = (int *)(osum + G);                     // window {t_arr, t_dep} of the attached-or-next session
     int *s_td = s_ta + NS, *s_ss = s_td + NS, *s_cyc = s_ss + NS;  // session index, charging_cycles
     int *s_dirty = s_cyc + NS;                             // bit0: cap/tot/prev/cycles changed, bit1: window changed
     int *items = s_dirty + NS, *seg = items + NS, *trobs = seg + R + 1, *cnt = trobs + R;  // cnt[0] charge, cnt[1] discharge
@@ -571,14 +572,28 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             over_l[tid_l] = 100.0 * over;
         }
         if (R > 1) {
-            for (int i = tid_l; i < ne * EV2G_NQ; i += BLOCK) {
-                const int tel = i / EV2G_NQ, k = i - tel * EV2G_NQ;
+            // (env, quantity) sums over the env's R transformers: one wavefront per sum, lanes strided over the
+            // transformers, fixed xor tree (a single lane adding R values is an R-long chain of LDS round trips)
+            const int wave = tid_l >> 6, ln = tid_l & 63;
+            for (int task = wave; task < ne * EV2G_NQ; task += (BLOCK >> 6)) {
+                const int tel = task / EV2G_NQ, k = task - tel * EV2G_NQ;
                 double v = 0.0;
-                for (int r = 0; r < R; r++) v += tsum[k * NT + tel * R + r];
-                esum[k * G + tel] = v;
+                for (int r = ln; r < R; r += 64) v += tsum[k * NT + tel * R + r];
+                v = wave_sum(v);
+                if (ln == 0) esum[k * G + tel] = v;
             }
         }
         lds_barrier();
+        if (R > 1) {   // the overload penalties of E1 are visible now: their per-env sum, same scheme
+            const int wave = tid_l >> 6, ln = tid_l & 63;
+            for (int tel = wave; tel < ne; tel += (BLOCK >> 6)) {
+                double v = 0.0;
+                for (int r = ln; r < R; r += 64) v += over_l[tel * R + r];
+                v = wave_sum(v);
+                if (ln == 0) osum[tel] = v;
+            }
+            lds_barrier();
+        }
         const double *es = (R > 1) ? esum : tsum;
         const int esn = (R > 1) ? G : NT;
 
@@ -586,8 +601,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
         if (env_lane) {
             const double usage = es[0 * esn + pel_l];
             if (pl_l == 0) {
-                double over_sum = 0.0;
-                for (int r = 0; r < R; r++) over_sum += over_l[pel_l * R + r];
+                const double over_sum = (R > 1) ? osum[pel_l] : over_l[pel_l];
                 S->usage_hist[t * E + pe_l] = usage;
                 const double potn = es[3 * esn + pel_l];
                 if (sstep < T) S->pot_hist[sstep * E + pe_l] = potn;
