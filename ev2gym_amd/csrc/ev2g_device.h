@@ -133,6 +133,20 @@ __device__ __forceinline__ double div_int_by_const(double n, double b, double rb
 __device__ __forceinline__ double ceil2_x(double a) { return div_int_by_const(ceil(a * 100.0), 100.0, 1.0 / 100.0, 2.0e7); }
 __device__ __forceinline__ double rnd5_x(double x) { return div_int_by_const(rint(x * 100000.0), 100000.0, 1.0 / 100000.0, 2.0e5); }
 
+// xor-butterfly partners inside 8-lane groups through DPP (VALU cross-lane moves, a few cycles) instead of
+// ds_bpermute (an LDS crossbar round trip per step): quad_perm [1,0,3,2], quad_perm [2,3,0,1], and
+// quad_perm [3,2,1,0] followed by row_half_mirror (i -> 3-i in the quad, then 7-i in the half row = i ^ 4).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double xor1_f64(double v) { return dpp_mov_f64<0xB1>(v); }
+__device__ __forceinline__ double xor2_f64(double v) { return dpp_mov_f64<0x4E>(v); }
+__device__ __forceinline__ double xor4_f64(double v) { return dpp_mov_f64<0x141>(dpp_mov_f64<0x1B>(v)); }
+
 // dict.get(np.round(amps), 1): integer keys 0..100 exist, anything else -> 1   (ev.py:287-290, :375-379)
 __device__ __forceinline__ double lut_get(const double *__restrict__ lut, int id, double key) {
     if (key >= 0.0 && key <= 100.0) return lut[id * 101 + (int)key];

@@ -551,9 +551,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 for (; i + 8 < b; i += 16) { acc += stage[k * NS + i]; acc2 += stage[k * NS + i + 8]; }
                 if (i < b) acc += stage[k * NS + i];
                 acc += acc2;
-                acc += __shfl_xor(acc, 1, 64);
-                acc += __shfl_xor(acc, 2, 64);
-                acc += __shfl_xor(acc, 4, 64);
+                acc += xor1_f64(acc);   // DPP cross-lane moves (ev2g_device.h), not LDS-crossbar shuffles
+                acc += xor2_f64(acc);
+                acc += xor4_f64(acc);
                 if (j == 0) tsum[k * NT + task] = acc;
             }
         }

@@ -23,20 +23,6 @@ __host__ __device__ inline size_t ev2g_wave_lds_bytes(int envs_per_group) {
     return sizeof(double) * (EV2G_NQ * (NS + 8) + 7 * NS + 6 * (size_t)envs_per_group + 4 * 64) + sizeof(int) * (6 * NS + 8);
 }
 
-// xor-butterfly partners inside 8-lane groups through DPP (VALU cross-lane moves, a few cycles) instead of
-// ds_bpermute (an LDS crossbar round trip per step): quad_perm [1,0,3,2], quad_perm [2,3,0,1], and
-// quad_perm [3,2,1,0] followed by row_half_mirror (i -> 3-i in the quad, then 7-i in the half row = i ^ 4).
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double xor1_f64(double v) { return dpp_mov_f64<0xB1>(v); }
-__device__ __forceinline__ double xor2_f64(double v) { return dpp_mov_f64<0x4E>(v); }
-__device__ __forceinline__ double xor4_f64(double v) { return dpp_mov_f64<0x141>(dpp_mov_f64<0x1B>(v)); }
-
 // Global accesses as  uniform base (an SGPR pair) + 32-bit unsigned BYTE offset (one VGPR):  the
 // `global_load/store v, v_off, s[base:base+1]` form.  Indexing a pointer with a (sign-extended) int instead makes every
 // access carry a 64-bit VALU address computation (v_ashrrev + v_lshl_add_u64, an address VGPR pair each).  The host
