@@ -39,6 +39,35 @@ def SimpleReward(env, *args):
     return -(env.power_setpoints[t] - env.current_power_usage[t]) ** 2
 
 
+def _tracking_gap(env, *limits):
+    """(min(setpoint, potential, *limits) - usage) at the step that was just simulated."""
+    t = env.current_step - 1
+    return min(env.power_setpoints[t], env.charge_power_potential[t], *limits) - env.current_power_usage[t]
+
+
+def SqTrError_TrPenalty_UserIncentives(env, _, user_satisfaction_list, *args):
+    """reward.py:16-32 (host-evaluated): tracking error capped by transformer 0's limit, overload and dissatisfaction penalties"""
+    gap = _tracking_gap(env, env.transformers[0].max_power[env.current_step - 1])
+    penalty = sum(100 * tr.get_how_overloaded() for tr in env.transformers)
+    penalty += sum(1000 * (1 - score) for score in user_satisfaction_list)
+    return -gap ** 2 - penalty
+
+
+def SquaredTrackingErrorRewardWithPenalty(env, *args):
+    """reward.py:46-58 (host-evaluated): an extra -100 when nothing was delivered although there was potential the step before"""
+    t = env.current_step - 1
+    idle = env.current_power_usage[t] == 0 and env.charge_power_potential[t - 1] != 0
+    return -_tracking_gap(env) ** 2 - (100 if idle else 0)
+
+
+def MinimizeTrackerSurplusWithChargeRewards(env, *args):
+    """reward.py:67-76 (host-evaluated): quadratic penalty on exceeding the setpoint, linear bonus for delivered power"""
+    t = env.current_step - 1
+    usage, sp = env.current_power_usage[t], env.power_setpoints[t]
+    surplus = usage - sp
+    return (-(surplus ** 2) if sp < usage else 0) + usage
+
+
 ProfitMax_TrPenalty_UserIncentives._ev2g_kind = 0
 SquaredTrackingErrorReward._ev2g_kind = 1
 profit_maximization._ev2g_kind = 2

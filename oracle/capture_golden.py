@@ -333,6 +333,14 @@ def main():
         if only and c[0] not in only:
             continue
         run_case(*c)
+    # reward plugins that are not fused in the kernel (evaluated on the host through the facade): plugin_*.npz
+    for c in [("plugin_pst_sqtr_rand_s23", pst, "PublicPST", "SqTrError_TrPenalty_UserIncentives", 23, "rand", None),
+              ("plugin_pst_surplus_rand_s24", pst, "PublicPST", "MinimizeTrackerSurplusWithChargeRewards", 24, "rand", None),
+              ("plugin_pst_idlepen_mixed_s25", pst, "PublicPST", "SquaredTrackingErrorRewardWithPenalty", 25, "mixed", None),
+              ("plugin_v2gppl_sqtr_rand_s26", ppl, "V2G_profit_max_loads", "SqTrError_TrPenalty_UserIncentives", 26, "rand", None)]:
+        if only and c[0] not in only:
+            continue
+        run_case(*c)
     # replay files: the reference's on-disk scenario format
     for c in [("replay_v2gppl_p2_rand_s21", p2, *PPL, 21, "rand"), ("replay_pst_rand_s22", pst, *PST, 22, "rand")]:
         if only and c[0] not in only:

@@ -196,3 +196,30 @@ def test_facade_from_replay_file_reproduces_reference_episode(name, tmp_path):
     _close(o[0], z["trj_obs"][1], "vec obs[0]")
     _close(r[1], z["trj_reward"][0], "vec reward[0]")
     venv.close()
+
+
+@pytest.mark.parametrize("name", ["plugin_pst_sqtr_rand_s23", "plugin_pst_surplus_rand_s24", "plugin_pst_idlepen_mixed_s25",
+                                  "plugin_v2gppl_sqtr_rand_s26"])
+def test_unfused_builtin_rewards_through_the_facade(name):
+    """Reference reward functions that are not fused in the kernel are host-evaluated plugins here: the facade feeds
+    them the same env attributes the reference does, so the reference's reward trajectory is reproduced."""
+    from ev2gym_amd.env import EV2Gym
+    from ev2gym_amd.rl_agent import cost as C, reward as R, state as S
+    from ev2gym_amd.scenario import ScenarioBatch
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    batch = ScenarioBatch.from_single(z)
+    rf = getattr(R, str(z["case"][3]))
+    assert getattr(rf, "_ev2g_kind", None) is None
+    env = EV2Gym(scenario=batch, state_function=getattr(S, str(z["case"][2])), reward_function=rf,
+                 cost_function=C.transformer_overload_usrpenalty_cost)
+    obs, _ = env.reset()
+    _close(obs, z["trj_obs"][0], "reset obs")
+    for t in range(len(z["act"])):
+        obs, rew, done, trunc, info = env.step(z["act"][t].copy())
+        _close(obs, z["trj_obs"][t + 1], f"obs[{t}]")
+        _close(rew, z["trj_reward"][t], f"reward[{t}]")
+        # cost.py:8-18 == what ProfitMax_TrPenalty_UserIncentives subtracts: overload + dissatisfaction penalties
+        want_cost = 100 * z["trj_tr_overload"][t].sum() + sum(100 * np.exp(-10 * s) for s in z["trj_dep_score"][t][:z["trj_n_departed"][t]])
+        _close(env.cost if done else info["cost"], want_cost, f"cost[{t}]")
+    _close(info["total_reward"], z["trj_stats"][16], "total_reward")
+    env.close()
