@@ -32,6 +32,11 @@ typedef char __attribute__((address_space(1))) *gptr;
 template <class T, class B> __device__ __forceinline__ T ldg32(B base, unsigned boff) {
     return *(const T __attribute__((address_space(1))) *)((gcptr)base + boff);
 }
+// streaming variant: read once per step and never again by this CU -- keep it from displacing the session records and
+// efficiency tables (re-read every step) in the vector L1
+template <class T, class B> __device__ __forceinline__ T ldg32_nt(B base, unsigned boff) {
+    return __builtin_nontemporal_load((const T __attribute__((address_space(1))) *)((gcptr)base + boff));
+}
 template <class T, class B> __device__ __forceinline__ void stg32(B base, unsigned boff, T v) {
     *(T __attribute__((address_space(1))) *)((gptr)base + boff) = v;
 }
@@ -229,22 +234,22 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
         const int ec = valid ? e_l : e0;   // clamped env for idle lanes
         const int gc = valid ? g_l : e0 * P;
-        a_next = ldg32<double>(io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride, (unsigned)gc * 8u);
+        a_next = ldg32_nt<double>(io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride, (unsigned)gc * 8u);
         const unsigned eT64 = (unsigned)(ec * T) * 64u;   // this env's rows in the [E,T,8] step table
         const unsigned et64 = eT64 + (unsigned)t * 64u;
-        const d2v st0 = ldg32<d2v>(S->step_tab, et64);                                  // charge price, discharge price
+        const d2v st0 = ldg32_nt<d2v>(S->step_tab, et64);                                  // charge price, discharge price
         double pf_pch = st0.x, pf_pdis = st0.y;
         double pf_base = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
         if (RK == 0) {
-            const d2v st1 = ldg32<d2v>(S->step_tab, et64 + 16u);                        // inflexible + solar, max_power
-            pf_base = st1.x; pf_maxp = st1.y; pf_minp = ldg32<double>(S->step_tab, et64 + 32u);
+            const d2v st1 = ldg32_nt<d2v>(S->step_tab, et64 + 16u);                        // inflexible + solar, max_power
+            pf_base = st1.x; pf_maxp = st1.y; pf_minp = ldg32_nt<double>(S->step_tab, et64 + 32u);
         }
-        if (RK == 1) pf_sp = ldg32<double>(S->step_tab, et64 + 40u);
+        if (RK == 1) pf_sp = ldg32_nt<double>(S->step_tab, et64 + 40u);
         // observation head columns of this env, distributed over its P lanes: column c = q, q+P, q+2P
         double pf_ob0 = 0.0, pf_ob1 = 0.0, pf_ob2 = 0.0;
         constexpr int NHEAD = (SK == 1) ? 0 : (SK == 0 ? 60 : 20);   // 20 prices (+ 40 window columns)
         if (SK == 1) {
-            pf_ob0 = ldg32<double>(S->step_tab, eT64 + (unsigned)min(sstep, T - 1) * 64u + 40u);   // next setpoint; head lane only, masked by sstep < T
+            pf_ob0 = ldg32_nt<double>(S->step_tab, eT64 + (unsigned)min(sstep, T - 1) * 64u + 40u);   // next setpoint; head lane only, masked by sstep < T
         } else {
             // observation head table [E, T+1, NHEAD]: |charge price| window (zero-padded) + load/PV/limit window, exactly
             // the values of columns 2..2+NHEAD of the observation emitted at the end of step sstep-1 (state.py:65-83, :108-135)
@@ -252,7 +257,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
 #pragma unroll
             for (int u = 0; u < 3; u++) {
                 const int c = q_l + u * P;
-                const double v = ldg32<double>(S->head_tab, h8 + (unsigned)min(c, NHEAD - 1) * 8u);
+                const double v = ldg32_nt<double>(S->head_tab, h8 + (unsigned)min(c, NHEAD - 1) * 8u);
                 if (u == 0) pf_ob0 = v; else if (u == 1) pf_ob1 = v; else pf_ob2 = v;
             }
         }
