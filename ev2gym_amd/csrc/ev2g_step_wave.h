@@ -388,8 +388,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
             if (obs) {
                 const unsigned o8 = (unsigned)(e_l * D + ocol) * 8u;
-                stg32<double>(obs, o8, o0);
-                stg32<double>(obs, o8 + 8u, o1);
+                stg32<d2v>(obs, o8, (d2v){o0, o1});   // one 16-byte store (D and the column offset are even for SK != 1)
                 if (SK == 1) stg32<double>(obs, o8 + 16u, o2);
             }
             stage[1 * RS + tid_l] = profit;
