@@ -245,21 +245,19 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             pf_base = st1.x; pf_maxp = st1.y; pf_minp = ldg32_nt<double>(S->step_tab, et64 + 32u);
         }
         if (RK == 1) pf_sp = ldg32_nt<double>(S->step_tab, et64 + 40u);
-        // observation head columns of this env, distributed over its P lanes: column c = q, q+P, q+2P
-        double pf_ob0 = 0.0, pf_ob1 = 0.0, pf_ob2 = 0.0;
+        // observation head columns of this env, distributed over its P lanes as 16-byte column PAIRS: pair q, q+P
+        double pf_ob0 = 0.0;
+        d2v pf_h0 = {0.0, 0.0}, pf_h1 = {0.0, 0.0};
         constexpr int NHEAD = (SK == 1) ? 0 : (SK == 0 ? 60 : 20);   // 20 prices (+ 40 window columns)
+        constexpr int NPAIR = NHEAD / 2;
         if (SK == 1) {
             pf_ob0 = ldg32_nt<double>(S->step_tab, eT64 + (unsigned)min(sstep, T - 1) * 64u + 40u);   // next setpoint; head lane only, masked by sstep < T
         } else {
             // observation head table [E, T+1, NHEAD]: |charge price| window (zero-padded) + load/PV/limit window, exactly
             // the values of columns 2..2+NHEAD of the observation emitted at the end of step sstep-1 (state.py:65-83, :108-135)
             const unsigned h8 = (unsigned)((ec * (T + 1) + sstep) * NHEAD) * 8u;
-#pragma unroll
-            for (int u = 0; u < 3; u++) {
-                const int c = q_l + u * P;
-                const double v = ldg32_nt<double>(S->head_tab, h8 + (unsigned)min(c, NHEAD - 1) * 8u);
-                if (u == 0) pf_ob0 = v; else if (u == 1) pf_ob1 = v; else pf_ob2 = v;
-            }
+            pf_h0 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l, NPAIR - 1) * 16u);
+            pf_h1 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l + P, NPAIR - 1) * 16u);
         }
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
         PT_MARK(0)
@@ -319,7 +317,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // prefetched registers are plain values from here on, so their later uses -- after this phase's stores, and
         // across the loop back-edge for the next action -- no longer cost a conservative vmcnt(0) drain
         asm volatile("" : "+v"(a_next), "+v"(pf_pch), "+v"(pf_pdis), "+v"(pf_base), "+v"(pf_maxp), "+v"(pf_minp),
-                     "+v"(pf_sp), "+v"(pf_ob0), "+v"(pf_ob1), "+v"(pf_ob2));
+                     "+v"(pf_sp), "+v"(pf_ob0), "+v"(pf_h0), "+v"(pf_h1));
         if (valid) {
             double profit = 0.0, satpen = 0.0, pot = 0.0;
             int ta = s_ta[tid_l], td = s_td[tid_l];
@@ -496,16 +494,12 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     stg32<double>(obs, o8 + 16u, usage);
                 }
             } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135: columns 2.. are a copy of the head table row
-                if (q_l == 0) { stg32<double>(obs, o8, (double)sstep); stg32<double>(obs, o8 + 8u, usage); }
-                int c = q_l;
-                if (c < NHEAD) stg32<double>(obs, o8 + (unsigned)(2 + c) * 8u, pf_ob0);
-                c = q_l + P;
-                if (c < NHEAD) stg32<double>(obs, o8 + (unsigned)(2 + c) * 8u, pf_ob1);
-                c = q_l + 2 * P;
-                if (c < NHEAD) stg32<double>(obs, o8 + (unsigned)(2 + c) * 8u, pf_ob2);
+                if (q_l == 0) stg32<d2v>(obs, o8, (d2v){(double)sstep, usage});
+                if (q_l < NPAIR) stg32<d2v>(obs, o8 + 16u + (unsigned)q_l * 16u, pf_h0);
+                if (q_l + P < NPAIR) stg32<d2v>(obs, o8 + 16u + (unsigned)(q_l + P) * 16u, pf_h1);
                 const unsigned h8 = (unsigned)((e_l * (T + 1) + sstep) * NHEAD) * 8u;
-                for (c = q_l + 3 * P; c < NHEAD; c += P)    // tiny envs (P < 20): the remaining columns, unprefetched
-                    stg32<double>(obs, o8 + (unsigned)(2 + c) * 8u, ldg32<double>(S->head_tab, h8 + (unsigned)c * 8u));
+                for (int pi = q_l + 2 * P; pi < NPAIR; pi += P)    // tiny envs (P < 15): the remaining pairs, unprefetched
+                    stg32<d2v>(obs, o8 + 16u + (unsigned)pi * 16u, ldg32<d2v>(S->head_tab, h8 + (unsigned)pi * 16u));
             }
         }
         PT_MARK(5)
