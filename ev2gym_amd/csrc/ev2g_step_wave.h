@@ -239,12 +239,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const unsigned et64 = eT64 + (unsigned)t * 64u;
         const d2v st0 = ldg32_nt<d2v>(S->step_tab, et64);                                  // charge price, discharge price
         double pf_pch = st0.x, pf_pdis = st0.y;
-        double pf_base = 0.0, pf_maxp = 0.0, pf_minp = 0.0, pf_sp = 0.0;
-        if (RK == 0) {
-            const d2v st1 = ldg32_nt<d2v>(S->step_tab, et64 + 16u);                        // inflexible + solar, max_power
-            pf_base = st1.x; pf_maxp = st1.y; pf_minp = ldg32_nt<double>(S->step_tab, et64 + 32u);
-        }
-        if (RK == 1) pf_sp = ldg32_nt<double>(S->step_tab, et64 + 40u);
+        // the transformer scalars only the head lane needs: ONE more load in which the head lane (q == 0) takes
+        // {inflexible + solar, max_power} and its neighbour takes {min_power, setpoint}; the head lane picks the
+        // neighbour's pair up with a DPP wave shift in phase E
+        d2v pf_tr = ldg32_nt<d2v>(S->step_tab, et64 + ((q_l == 0) ? 16u : 32u));
         // observation head columns of this env, distributed over its P lanes as 16-byte column PAIRS: pair q, q+P
         double pf_ob0 = 0.0;
         d2v pf_h0 = {0.0, 0.0}, pf_h1 = {0.0, 0.0};
@@ -316,8 +314,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // ... and make that visible to the compiler's wait-count tracking: as outputs of this (empty) asm the
         // prefetched registers are plain values from here on, so their later uses -- after this phase's stores, and
         // across the loop back-edge for the next action -- no longer cost a conservative vmcnt(0) drain
-        asm volatile("" : "+v"(a_next), "+v"(pf_pch), "+v"(pf_pdis), "+v"(pf_base), "+v"(pf_maxp), "+v"(pf_minp),
-                     "+v"(pf_sp), "+v"(pf_ob0), "+v"(pf_h0), "+v"(pf_h1));
+        asm volatile("" : "+v"(a_next), "+v"(pf_pch), "+v"(pf_pdis), "+v"(pf_tr), "+v"(pf_ob0), "+v"(pf_h0), "+v"(pf_h1));
         if (valid) {
             double profit = 0.0, satpen = 0.0, pot = 0.0;
             int ta = s_ta[tid_l], td = s_td[tid_l];
@@ -436,6 +433,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         PT_MARK(4)
         // ---------------- E: per env (head lane) + observation head (the env's lanes) ----------------
         const double usage = esum[0];
+        // {min_power, setpoint} from the next lane (wave_shl:1 -- the head lane's neighbour always belongs to the same env)
+        const double pf_base = pf_tr.x, pf_maxp = pf_tr.y;
+        const double pf_minp = dpp_mov_f64<0x130>(pf_tr.x), pf_sp = dpp_mov_f64<0x130>(pf_tr.y);
         if (head) {
             double *ea = eacc + elg * 6;
             // all six accumulator words are read up front (one LDS wait) and written back together at the end; reading
@@ -451,10 +451,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 if (last_step) stg32<double>(S->tr_power_now, e8, ptr);
                 over100 = 100.0 * over;
             } else {
-                const unsigned erT64 = (unsigned)(e_l * T + t) * 64u;
-                double ptr = ldg32<double>(S->step_tab, erT64 + 16u);
+                double ptr = pf_base;
                 ptr += usage;
-                const double mx = ldg32<double>(S->step_tab, erT64 + 24u), mn = ldg32<double>(S->step_tab, erT64 + 32u);
+                const double mx = pf_maxp, mn = pf_minp;
                 const double over = (ptr > mx + 0.0001 || ptr < mn - 0.0001) ? fabs(ptr - mx) : 0.0;
                 stg32<double>((slabH + 2 * HS8) + (long long)t * E * 8, e8, over);
                 if (last_step) stg32<double>(S->tr_power_now, e8, ptr);
