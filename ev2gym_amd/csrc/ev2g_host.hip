@@ -377,7 +377,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         const unsigned long long lim = 1ull << 32;
         const unsigned long long biggest = std::max({(unsigned long long)E * P * 8, (unsigned long long)E * D * 8,
                                                      (unsigned long long)E * (T + 1) * 60 * 8, (unsigned long long)S * sizeof(SessRec),
-                                                     (unsigned long long)E * T * 64, (unsigned long long)E * P * T * 8});
+                                                     (unsigned long long)E * T * 64, (unsigned long long)E * T * 8 * 3});
         if (biggest >= lim) h->wave_path = false;
     }
     if (h->wave_path) s.G = (EV2G_WAVE_BLOCK / 64) * (64 / P);   // wave-aligned: 64/P envs per wavefront

@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         double esum[EV2G_NQ];
 #pragma unroll
-        for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = stage[kq * RS + tid_l];   // meaningful in head lanes only
+        for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = stage[kq * RS + (tid_l - q_l)];   // the env's sums (its head slot), every lane
 
         PT_MARK(4)
         // ---------------- E: per env (head lane) + observation head (the env's lanes) ----------------
@@ -436,6 +436,20 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // {min_power, setpoint} from the next lane (wave_shl:1 -- the head lane's neighbour always belongs to the same env)
         const double pf_base = pf_tr.x, pf_maxp = pf_tr.y;
         const double pf_minp = dpp_mov_f64<0x130>(pf_tr.x), pf_sp = dpp_mov_f64<0x130>(pf_tr.y);
+        // Transformer.reset + step + get_how_overloaded (transformer.py:258-302), evaluated wave-wide (meaningful in head lanes)
+        const double tr_power = pf_base + usage;   // inflexible_load[t] + solar_power[t] + sum of the charger powers
+        const double over = (tr_power > pf_maxp + 0.0001 || tr_power < pf_minp - 0.0001) ? fabs(tr_power - pf_maxp) : 0.0;
+        if (P >= 3) {
+            // the three history entries of the step in ONE store: lane 0 of the env writes usage[t], lane 1 the overload
+            // (handed over by a DPP wave shift), lane 2 potential[t+1] -- not three stores with one active lane each
+            const double over_n = dpp_mov_f64<0x138>(over);   // wave_shr:1: lane L takes lane L-1's value
+            if (valid && q_l < 3 && (q_l != 2 || sstep < T)) {
+                const double hv = (q_l == 0) ? usage : ((q_l == 1) ? over_n : esum[3]);
+                const unsigned hoff = (q_l == 0) ? 0u : ((q_l == 1) ? 2u * (unsigned)HS8 : (unsigned)HS8);
+                const unsigned hstep = (q_l == 2) ? (unsigned)sstep : (unsigned)t;
+                stg32<double>(slabH, hoff + (hstep * (unsigned)E + (unsigned)e_l) * 8u, hv);
+            }
+        }
         if (head) {
             double *ea = eacc + elg * 6;
             // all six accumulator words are read up front (one LDS wait) and written back together at the end; reading
@@ -443,24 +457,14 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             const double ea0 = ea[0], ea1 = ea[1], ea2 = ea[2], ea3 = ea[3], ea4 = ea[4], ea5 = ea[5];
             const unsigned e8 = (unsigned)e_l * 8u;
             double over100 = 0.0;
-            if (RK == 0) {  // Transformer.reset + step + get_how_overloaded (transformer.py:258-302)
-                double ptr = pf_base;   // inflexible_load[t] + solar_power[t]
-                ptr += usage;
-                const double over = (ptr > pf_maxp + 0.0001 || ptr < pf_minp - 0.0001) ? fabs(ptr - pf_maxp) : 0.0;
-                stg32<double>((slabH + 2 * HS8) + (long long)t * E * 8, e8, over);
-                if (last_step) stg32<double>(S->tr_power_now, e8, ptr);
-                over100 = 100.0 * over;
-            } else {
-                double ptr = pf_base;
-                ptr += usage;
-                const double mx = pf_maxp, mn = pf_minp;
-                const double over = (ptr > mx + 0.0001 || ptr < mn - 0.0001) ? fabs(ptr - mx) : 0.0;
-                stg32<double>((slabH + 2 * HS8) + (long long)t * E * 8, e8, over);
-                if (last_step) stg32<double>(S->tr_power_now, e8, ptr);
-            }
-            stg32<double>(slabH + (long long)t * E * 8, e8, usage);
+            if (RK == 0) over100 = 100.0 * over;
+            if (last_step) stg32<double>(S->tr_power_now, e8, tr_power);
             const double potn = esum[3];
-            if (sstep < T) stg32<double>((slabH + HS8) + (long long)sstep * E * 8, e8, potn);
+            if (P < 3) {   // two-port envs: no third lane to share the history stores with
+                stg32<double>((slabH + 2 * HS8) + (long long)t * E * 8, e8, over);
+                stg32<double>(slabH + (long long)t * E * 8, e8, usage);
+                if (sstep < T) stg32<double>((slabH + HS8) + (long long)sstep * E * 8, e8, potn);
+            }
             const double costs = esum[1];
             double reward;
             if (RK == 1) {  // SquaredTrackingErrorReward reward.py:7-14
