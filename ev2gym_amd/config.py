@@ -37,6 +37,7 @@ def gen_config_from_yaml(cfg, n_envs: int, seed: int = 0) -> GenConfig:
         demand_response=bool(c["demand_response"]["include"]),
         heterogeneous_ev_specs=bool(c["heterogeneous_ev_specs"]),
         fleet_with_efficiency_tables=("v2g_enabled2024" in specs),
+        fleet=("ev_plus_phev" if "phev" in specs else "v2g2024"),
         transformer_max_power=float(c["transformer"]["max_power"]),
         cs_min_charge_current=float(cs["min_charge_current"]), cs_max_charge_current=float(cs["max_charge_current"]),
         cs_min_discharge_current=float(cs["min_discharge_current"]),

@@ -41,6 +41,14 @@ _FLEET_V2G = [
 ]
 
 
+# A mixed BEV / plug-in-hybrid fleet (the PublicPST configuration): (share, battery kWh, max AC kW).  Representative
+# classes fitted to the capacity distribution the reference draws for that config (39 % below 20 kWh, mean 39.7 kWh).
+_FLEET_EV_PHEV = [
+    (0.26, 8.0, 3.7), (0.10, 14.5, 3.7), (0.03, 39.0, 3.6), (0.045, 46.3, 7.4), (0.035, 52.0, 22.0),
+    (0.32, 57.7, 11.0), (0.12, 64.5, 11.0), (0.07, 76.0, 11.0),
+]
+
+
 def _lut_from_levels(levels, values):
     """Nearest-non-zero fill of a {current level -> efficiency %} map over 0..100 A (utils.py:279-288)."""
     tab = np.zeros(_abi.LUT_LEN)
@@ -71,6 +79,7 @@ class GenConfig:
     demand_response: bool = True
     heterogeneous_ev_specs: bool = True
     fleet_with_efficiency_tables: bool = True   # ev_specs_v2g_enabled2024-like; False = scalar eta in [0.95,1]
+    fleet: str = "v2g2024"                      # "v2g2024" | "ev_plus_phev" (mixed BEV / plug-in hybrids, PublicPST)
     transformer_max_power: float = 100.0
     cs_min_charge_current: float = 0.0
     cs_max_charge_current: float = 32.0
@@ -102,33 +111,50 @@ class GenConfig:
     @staticmethod
     def public_pst(n_envs, n_chargers=20, seed=0, **kw):
         d = dict(scenario="public", v2g_enabled=False, power_setpoint_enabled=True, inflexible_loads=False,
-                 solar_power=False, demand_response=False, fleet_with_efficiency_tables=False,
+                 solar_power=False, demand_response=False, fleet_with_efficiency_tables=False, fleet="ev_plus_phev",
                  cs_max_charge_current=16.0, cs_max_discharge_current=0.0, ev_min_time_of_stay=60)
         d.update(kw)
         return GenConfig(n_envs=n_envs, number_of_charging_stations=n_chargers, seed=seed, **d)
 
 
+# Hour-of-day tables of the spawner (the role of the reference's distribution-of-arrival / time-of-connection /
+# energy-demand data, utils.py:177-345): arrivals per port per hour in percent, mean stay in hours, mean required energy
+# in kWh -- for an EV arriving in that hour.  Fitted (tools/calibrate_generator.py) so that scenarios drawn with the
+# shipped YAMLs reproduce the reference's summary statistics (tests/golden/spawn_stats.json: arrivals per hour, stay by
+# arrival time, required energy, sessions per port, occupancy); linear interpolation between the hours.
+_HOURLY = {
+    "workplace": dict(
+        rate=np.array([0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.023, 1.241, 4.008, 8.163, 3.732, 1.516, 1.371, 1.463, 1.412, 0.945, 0.716,
+                       0.568, 0.215, 0.091, 0.0, 0.0, 0.0, 0.0]),
+        stay=np.array([8.0, 8.0, 8.0, 8.0, 8.0, 7.93, 7.93, 8.63, 8.63, 7.35, 6.75, 4.34, 4.04, 3.56, 3.36, 2.41, 2.41, 2.51, 2.51,
+                       2.62, 2.62, 3.0, 3.0, 3.0]),
+        energy=np.full(24, 14.35)),
+    "public": dict(
+        rate=np.array([0.153, 0.153, 0.153, 0.153, 0.153, 0.041, 0.05, 0.156, 0.86, 2.444, 1.525, 1.113, 1.251, 1.322, 1.261, 1.221,
+                       1.221, 1.272, 1.731, 2.13, 1.883, 0.649, 0.741, 0.934]),
+        stay=np.array([8.0, 8.0, 8.0, 8.0, 8.0, 5.51, 5.51, 5.31, 5.31, 4.44, 4.44, 2.86, 2.86, 2.98, 2.98, 2.92, 2.92, 8.4, 8.4,
+                       11.77, 11.77, 10.91, 9.91, 10.96]),
+        energy=np.full(24, 14.11)),
+}
+
+
+def _hourly(scenario, key, hours):
+    tab = _HOURLY[scenario][key]
+    h = np.asarray(hours, float) % 24.0
+    return np.interp(h, np.arange(25), np.append(tab, tab[0]))
+
+
 def _arrival_rate(scenario, hours):
-    """Arrivals per port per hour in percent (the role of distribution-of-arrival.csv), by hour of day."""
-    h = np.asarray(hours, float)
-    if scenario == "workplace":
-        r = 7.4 * np.exp(-0.5 * ((h - 8.3) / 1.1) ** 2) + 1.2 * np.exp(-0.5 * ((h - 13.0) / 1.5) ** 2)
-        r = np.where((h < 6) | (h > 18), 0.0, r)
-    else:  # public
-        r = 0.25 + 1.7 * np.exp(-0.5 * ((h - 9.5) / 2.5) ** 2) + 1.9 * np.exp(-0.5 * ((h - 17.0) / 3.0) ** 2)
-    return r
+    """Arrivals per port per hour in percent, by hour of day."""
+    return _hourly(scenario, "rate", hours)
 
 
 def _mean_stay_hours(scenario, hours):
-    h = np.asarray(hours, float)
-    if scenario == "workplace":
-        return np.clip(9.0 - 0.75 * (h - 7.0), 2.0, 9.5)
-    return np.clip(4.5 - 0.12 * (h - 8.0), 1.5, 6.0)
+    return _hourly(scenario, "stay", hours)
 
 
 def _mean_energy_kwh(scenario, hours):
-    h = np.asarray(hours, float)
-    return 22.0 + 6.0 * np.cos((h - 9.0) / 24.0 * 2 * np.pi) if scenario == "workplace" else 20.0 + 4.0 * np.cos((h - 12.0) / 24.0 * 2 * np.pi)
+    return _hourly(scenario, "energy", hours)
 
 
 def generate(cfg: GenConfig) -> ScenarioBatch:
@@ -165,10 +191,11 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
     stay_mean = _mean_stay_hours(cfg.scenario, hod)
     energy_mean = _mean_energy_kwh(cfg.scenario, hod)
     if cfg.heterogeneous_ev_specs:
-        share = np.array([f[0] for f in _FLEET_V2G])
+        fleet = _FLEET_V2G if (cfg.fleet_with_efficiency_tables or cfg.fleet != "ev_plus_phev") else _FLEET_EV_PHEV
+        share = np.array([f[0] for f in fleet])
         share = share / share.sum()
-        fleet_B = np.array([f[1] for f in _FLEET_V2G])
-        fleet_pac = np.array([f[2] for f in _FLEET_V2G])
+        fleet_B = np.array([f[1] for f in fleet])
+        fleet_pac = np.array([f[2] for f in fleet])
     se, sp, st_, sB, spac, scap0, stdep, smodel = [], [], [], [], [], [], [], []
     for t in range(2, T - min_stay_steps - 1):
         u = rng.random((E, P)) * 100.0
