@@ -5,8 +5,11 @@ The reference builds one scenario per `reset()` with Python loops and pandas loo
 transformer.py:80-256, load_electricity_prices loaders.py:392-461, generate_power_setpoints
 utils.py:664-757), which costs 0.16-1.2 s per env and would dominate a GPU-resident
 step engine.  This module draws the same *kind* of scenario -- same structure, same constraints,
-statistically comparable (not bit-identical: the reference's RNG streams and CSV data sets are not
-reproduced) -- for thousands of envs with numpy array operations:
+statistically matched (not bit-identical: the reference's RNG streams and CSV data sets are not
+reproduced; the hour-of-day tables and fleet classes below are FITTED to summary statistics of the
+reference's own resets, tests/golden/spawn_stats.json, and tests/test_host_logic.py keeps them there:
+occupancy, sessions per port, stay and arrival-SoC quantiles, required energy, arrival histogram) --
+for thousands of envs with numpy array operations:
 
   * arrivals: a Bernoulli trial per (port, step) against a time-of-day rate, with the reference's
     "port must have been empty for 3 steps" rule and the end-of-simulation cut-off;
