@@ -315,6 +315,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // prefetched registers are plain values from here on, so their later uses -- after this phase's stores, and
         // across the loop back-edge for the next action -- no longer cost a conservative vmcnt(0) drain
         asm volatile("" : "+v"(a_next), "+v"(pf_pch), "+v"(pf_pdis), "+v"(pf_tr), "+v"(pf_ob0), "+v"(pf_h0), "+v"(pf_h1));
+        bool occ_any = false;   // an EV on this port before or after the step
         if (valid) {
             double profit = 0.0, satpen = 0.0, pot = 0.0;
             int ta = s_ta[tid_l], td = s_td[tid_l];
@@ -369,6 +370,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 s_dirty[tid_l] = (s_dirty[tid_l] & 3) | 1 | ((lut_new + 1) << 8);
             }
             const bool occ_after = (ta <= sstep) && (sstep <= td);
+            occ_any = occ || occ_after;
             if (mask) stg32<uint8_t>(mask, (unsigned)g_l, occ_after ? 1 : 0);
             double o0 = 0.0, o1 = 0.0, o2 = 0.0;
             if (occ_after) {
@@ -400,6 +402,12 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // (stage[k][first port of env w]; only this lane ever reads that slot in this phase), where the head lane --
         // the only consumer of env-level sums -- picks all eight up below.  LDS operations of one wavefront execute in
         // order, so no barrier is involved.
+        // A wavefront whose envs hold no EV before or after this step (the night half of a workplace episode, the early
+        // morning) has nothing to add up: every staged value of its ports is an exact +0.0.
+        double esum[EV2G_NQ];
+#pragma unroll
+        for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = 0.0;
+        if (__ballot(occ_any) != 0ull) {   // (uniform)
         {
             const int k = lane_l >> 3, j = lane_l & 7;
             const int wbase = (tid_l & ~63);
@@ -426,9 +434,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        double esum[EV2G_NQ];
 #pragma unroll
         for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = stage[kq * RS + (tid_l - q_l)];   // the env's sums (its head slot), every lane
+        }
 
         PT_MARK(4)
         // ---------------- E: per env (head lane) + observation head (the env's lanes) ----------------
