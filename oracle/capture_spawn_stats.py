@@ -25,9 +25,14 @@ def stats_for(config, n_resets, state_fn, reward_fn):
                  generate_rnd_game=True)
     T, P = env.simulation_length, env.number_of_ports
     occ, nsess, stay, soc0, bcap, tarr = [], [], [], [], [], []
+    sp_ratio, sp_max, sp_nz, sp_mean = [], [], [], []
     for seed in range(n_resets):
         env.reset(seed=seed)
         evs = env.EVs_profiles
+        sp = np.array(env.power_setpoints, float)
+        need = sum(ev.battery_capacity - ev.battery_capacity_at_arrival for ev in evs)
+        if sp.any() and need > 0:   # generate_power_setpoints (utils.py:664-757): energy of the setpoint curve vs the energy the EVs need
+            sp_ratio.append(sp.sum() * env.timescale / 60 / need); sp_max.append(sp.max()); sp_nz.append((sp > 0).mean()); sp_mean.append(sp.mean())
         nsess.append(len(evs) / P)
         m = np.zeros((T + 1, P), bool)
         for ev in evs:
@@ -56,7 +61,11 @@ def stats_for(config, n_resets, state_fn, reward_fn):
                 arrival_share_per_hour=[float(x) for x in hourly], stay_mean_by_2h_arrival_bin=stay_by_2h,
                 required_energy_mean=float(req.mean()), required_energy_q10=q(req, .1), required_energy_q50=q(req, .5),
                 required_energy_q90=q(req, .9), stay_q05=q(stay, .05), stay_q25=q(stay, .25), stay_q75=q(stay, .75),
-                stay_q95=q(stay, .95), small_battery_share=float((np.array(bcap) < 20).mean()))
+                stay_q95=q(stay, .95), small_battery_share=float((np.array(bcap) < 20).mean()),
+                setpoint_energy_ratio_mean=float(np.mean(sp_ratio)) if sp_ratio else None,
+                setpoint_max_mean=float(np.mean(sp_max)) if sp_max else None,
+                setpoint_nonzero_fraction=float(np.mean(sp_nz)) if sp_nz else None,
+                setpoint_mean_kw=float(np.mean(sp_mean)) if sp_mean else None)
 
 
 def main():

@@ -156,3 +156,25 @@ def test_generator_reproduces_the_reference_spawn_statistics(name, yaml_file):
     near((a["ev_B"] < 20).mean(), "small_battery_share", abs_=0.06)
     hist = np.histogram(a["ev_t_arr"], bins=np.linspace(0, T, 8))[0] / len(stay)
     assert np.abs(hist - np.array(ref["arrival_hist_7bins"])).max() <= 0.04, (hist, ref["arrival_hist_7bins"])
+
+
+def test_generated_power_setpoints_resemble_the_reference_ones():
+    """generate_power_setpoints (utils.py:664-757) is re-implemented vectorised and simplified: its output must still
+    carry about the same energy relative to what the EVs need, peak, duty and level as the reference's (PublicPST)."""
+    import json
+    from ev2gym_amd.config import gen_config_from_yaml, load_yaml
+    from ev2gym_amd.scenario_gen import generate
+    ref = json.load(open(os.path.join(GOLDEN_DIR, "spawn_stats.json")))["PublicPST"]
+    cfg_dir = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "ev2gym_amd", "example_config_files")
+    b = generate(gen_config_from_yaml(load_yaml(os.path.join(cfg_dir, "PublicPST.yaml")), 300, 5))
+    a, st, dt = b.arrays, b.arrays["env_session_start"], b.timescale
+    ratio, peak, duty, level = [], [], [], []
+    for e in range(b.n_envs):
+        sp = a["power_setpoints"][e]
+        need = (a["ev_B"][st[e]:st[e + 1]] - a["ev_cap0"][st[e]:st[e + 1]]).sum()
+        if sp.any() and need > 0:
+            ratio.append(sp.sum() * dt / 60 / need); peak.append(sp.max()); duty.append((sp > 0).mean()); level.append(sp.mean())
+    assert abs(np.mean(ratio) - ref["setpoint_energy_ratio_mean"]) <= 0.12 * ref["setpoint_energy_ratio_mean"]
+    assert abs(np.mean(peak) - ref["setpoint_max_mean"]) <= 0.25 * ref["setpoint_max_mean"]
+    assert abs(np.mean(duty) - ref["setpoint_nonzero_fraction"]) <= 0.08
+    assert abs(np.mean(level) - ref["setpoint_mean_kw"]) <= 0.15 * ref["setpoint_mean_kw"]
