@@ -267,3 +267,54 @@ def test_full_size_batch_properties_and_sampled_parity(workload, K):
         _close(stats[sample], ora.stats(), "episode statistics of the sampled envs")
     ora.close()
     eng.close()
+
+
+@pytest.mark.parametrize("P", [2, 3, 5, 8, 13, 16, 21, 31, 32, 33, 47, 64])
+@pytest.mark.parametrize("kind", ["v2gppl", "pst"])
+def test_fast_path_for_every_env_width(P, kind):
+    """The wave-aligned kernel packs 64 // P envs into a wavefront and splits the observation head, the history
+    stores and the reduction over the env's lanes: every width class (1, 2, 3, 4, ... 32 envs per wavefront; fewer lanes
+    than head-column pairs; two-port envs) against the oracle, a whole episode, persistent and single-step launches."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import host_uniform
+    from ev2gym_amd.scenario_gen import GenConfig, generate
+    from oracle.oracle import Oracle
+    E = 37 if P > 8 else 150
+    if kind == "v2gppl":
+        batch = generate(GenConfig.v2g_profit_plus_loads(E, P, 1, seed=100 + P))
+        rk, sk, lo = _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"], -1.0
+    else:
+        batch = generate(GenConfig.public_pst(E, P, seed=200 + P))
+        rk, sk, lo = _abi.REWARD_KINDS["SquaredTrackingErrorReward"], _abi.STATE_KINDS["PublicPST"], 0.0
+    eng = _engine(batch, rk, sk, flags=4)
+    ora = Oracle(batch, rk, sk)
+    D, T = eng.D, eng.T
+    d_act = eng.empty((T, E, P))
+    eng.fill_uniform(d_act, T * E * P, 9, lo, 1.0)
+    acts = host_uniform(T * E * P, 9, lo, 1.0).reshape(T, E, P)
+    outs = []
+    for persistent in (True, False):
+        d_obs, d_rew, d_mask = eng.empty((T, E, D)), eng.empty((T, E)), eng.empty((T, E, P), np.uint8)
+        eng.reset()
+        eng.step_n(T, d_act, E * P, d_obs, E * D, d_rew, E, None, 0, d_mask, E * P, auto_reset=False, persistent=persistent)
+        eng.check_faults()
+        outs.append((d_obs.to_host(), d_rew.to_host(), d_mask.to_host(), eng.stats()))
+        for b in (d_obs, d_rew, d_mask):
+            b.free()
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert np.array_equal(a, b)
+    obs, rew, mask, stats = outs[0]
+    ora.reset()
+    for t in range(T):
+        o, r, d, m, rc = ora.step(acts[t].copy())
+        assert rc == 0 and np.array_equal(mask[t], m), f"mask[{t}]"
+        _close(obs[t], o, f"obs[{t}]")
+        _close(rew[t], r, f"reward[{t}]")
+    _close(stats, ora.stats(), "episode statistics")
+    for e in (0, E - 1):
+        pk, po = eng.peek(e), ora.peek(e)
+        _close(pk["power_usage"], po["usage"], "usage history")
+        _close(pk["power_potential"], po["potential"], "potential history")
+        _close(pk["tr_overload"], po["tr_overload"], "overload history")
+    eng.close()
+    ora.close()
