@@ -318,3 +318,46 @@ def test_fast_path_for_every_env_width(P, kind):
         _close(pk["tr_overload"], po["tr_overload"], "overload history")
     eng.close()
     ora.close()
+
+
+@pytest.mark.parametrize("C,npc,R", [(6, 2, 1), (7, 3, 2), (30, 1, 4), (130, 2, 5), (520, 1, 7), (1100, 1, 11), (700, 2, 50)])
+def test_general_kernels_for_multi_port_and_multi_transformer_shapes(C, npc, R):
+    """Shapes outside the fast path: multi-port chargers (action normalisation, first-free ports), several transformers
+    (segmented reduction, round-robin charger map), 256 / 512 / 1024-thread workgroups of ev2g_step_v2 and, above 1024
+    ports per env, the generic ev2g_step_kernel -- generated scenarios against the oracle, persistent == single-step."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import host_uniform
+    from ev2gym_amd.scenario_gen import GenConfig, generate
+    from oracle.oracle import Oracle
+    E = 9 if C * npc <= 300 else 4
+    batch = generate(GenConfig.v2g_profit_plus_loads(E, C, R, seed=C + R, number_of_ports_per_cs=npc))
+    rk, sk = _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"]
+    eng = _engine(batch, rk, sk, flags=4)
+    ora = Oracle(batch, rk, sk)
+    P, D, T = eng.P, eng.D, eng.T
+    assert P == C * npc
+    K = T if P <= 300 else 40
+    d_act = eng.empty((K, E, P))
+    eng.fill_uniform(d_act, K * E * P, 17, -1.4, 1.4)      # beyond the action box: normalisation / clamp paths
+    acts = host_uniform(K * E * P, 17, -1.4, 1.4).reshape(K, E, P)
+    outs = []
+    for persistent in (True, False):
+        d_obs, d_rew, d_mask = eng.empty((K, E, D)), eng.empty((K, E)), eng.empty((K, E, P), np.uint8)
+        eng.reset()
+        eng.step_n(K, d_act, E * P, d_obs, E * D, d_rew, E, None, 0, d_mask, E * P, auto_reset=False, persistent=persistent)
+        outs.append((d_obs.to_host(), d_rew.to_host(), d_mask.to_host()))
+        for b in (d_obs, d_rew, d_mask):
+            b.free()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    obs, rew, mask = outs[0]
+    ora.reset()
+    for t in range(K):
+        o, r, d, m, rc = ora.step(acts[t].copy())
+        assert np.array_equal(mask[t], m), f"mask[{t}]"
+        _close(obs[t], o, f"obs[{t}]")
+        _close(rew[t], r, f"reward[{t}]")
+    if K == T:
+        _close(eng.stats(), ora.stats(), "episode statistics")
+    eng.close()
+    ora.close()
