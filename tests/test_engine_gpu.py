@@ -270,7 +270,7 @@ def test_full_size_batch_properties_and_sampled_parity(workload, K):
 
 
 @pytest.mark.parametrize("P", [2, 3, 5, 8, 13, 16, 21, 31, 32, 33, 47, 64])
-@pytest.mark.parametrize("kind", ["v2gppl", "pst"])
+@pytest.mark.parametrize("kind", ["v2gppl", "pst", "v2gmax"])
 def test_fast_path_for_every_env_width(P, kind):
     """The wave-aligned kernel packs 64 // P envs into a wavefront and splits the observation head, the history
     stores and the reduction over the env's lanes: every width class (1, 2, 3, 4, ... 32 envs per wavefront; fewer lanes
@@ -283,6 +283,9 @@ def test_fast_path_for_every_env_width(P, kind):
     if kind == "v2gppl":
         batch = generate(GenConfig.v2g_profit_plus_loads(E, P, 1, seed=100 + P))
         rk, sk, lo = _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"], -1.0
+    elif kind == "v2gmax":   # the third fused pair (20-column observation head, no transformer penalty)
+        batch = generate(GenConfig.v2g_profit_plus_loads(E, P, 1, seed=300 + P))
+        rk, sk, lo = _abi.REWARD_KINDS["profit_maximization"], _abi.STATE_KINDS["V2G_profit_max"], -1.0
     else:
         batch = generate(GenConfig.public_pst(E, P, seed=200 + P))
         rk, sk, lo = _abi.REWARD_KINDS["SquaredTrackingErrorReward"], _abi.STATE_KINDS["PublicPST"], 0.0
