@@ -364,3 +364,31 @@ def test_general_kernels_for_multi_port_and_multi_transformer_shapes(C, npc, R):
         _close(eng.stats(), ora.stats(), "episode statistics")
     eng.close()
     ora.close()
+
+
+@pytest.mark.parametrize("sk", [0, 1, 2])
+@pytest.mark.parametrize("rk", [0, 1, 2])
+def test_all_nine_fused_plugin_pairs(sk, rk):
+    """The step kernels are specialised on (state, reward): every combination, not only the three shipped pairings."""
+    from ev2gym_amd.engine import host_uniform
+    from ev2gym_amd.scenario_gen import GenConfig, generate
+    from oracle.oracle import Oracle
+    E, P = 21, 20
+    batch = generate(GenConfig.v2g_profit_plus_loads(E, P, 1, seed=40 + 3 * sk + rk, power_setpoint_enabled=True))
+    eng = _engine(batch, rk, sk, flags=4)
+    ora = Oracle(batch, rk, sk)
+    D, T = eng.D, eng.T
+    d_act, d_obs, d_rew = eng.empty((T, E, P)), eng.empty((T, E, D)), eng.empty((T, E))
+    eng.fill_uniform(d_act, T * E * P, 3, -1.0, 1.0)
+    acts = host_uniform(T * E * P, 3, -1.0, 1.0).reshape(T, E, P)
+    eng.reset()
+    eng.step_n(T, d_act, E * P, d_obs, E * D, d_rew, E, None, 0, None, 0, auto_reset=False, persistent=True)
+    obs, rew = d_obs.to_host(), d_rew.to_host()
+    ora.reset()
+    for t in range(T):
+        o, r, d, m, rc = ora.step(acts[t].copy())
+        _close(obs[t], o, f"obs[{t}]")
+        _close(rew[t], r, f"reward[{t}]")
+    _close(eng.stats(), ora.stats(), "episode statistics")
+    eng.close()
+    ora.close()
