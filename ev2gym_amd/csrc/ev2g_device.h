@@ -352,6 +352,11 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_reset_kernel(DevScn s, DevSta
         if (st.cs_profits) { st.cs_profits[g] = 0.0; st.cs_e_ch[g] = 0.0; st.cs_e_dis[g] = 0.0; st.cs_power_now[g] = 0.0; st.cs_cur_now[g] = 0.0; }
     }
     for (int idx = threadIdx.x; idx < ne * 8; idx += EV2G_BLOCK) st.env_acc[(long long)e0 * 8 + idx] = 0.0;
+    {   // usage | potential | overload histories (one slab): cleared here, grid-strided, instead of by a separate fill launch
+        const long long n = (long long)s.T * s.E * (2 + s.R);
+        for (long long i = (long long)blockIdx.x * EV2G_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * EV2G_BLOCK)
+            st.slab_hist[i] = 0.0;
+    }
     for (int idx = threadIdx.x; idx < ne; idx += EV2G_BLOCK) st.env_fault[e0 + idx] = 0;
     for (int idx = threadIdx.x; idx < ne * s.R; idx += EV2G_BLOCK) st.tr_power_now[(long long)e0 * s.R + idx] = 0.0;
     if (obs) {

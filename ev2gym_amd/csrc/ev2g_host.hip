@@ -604,8 +604,7 @@ int ev2g_reset(ev2g_handle *h, double *obs) {
     if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_reset: no scenarios loaded");
     (void)hipSetDevice(h->device);
     const DevScn &s = h->scn;
-    // usage | potential | overload histories are one slab: one fill
-    HIPCHK(h, hipMemsetAsync(h->st.slab_hist, 0, sizeof(double) * (size_t)s.T * s.E * (2 + s.R), h->stream));
+    // (the usage | potential | overload history slab is cleared by the reset kernel itself)
     if (h->st.cs_power_hist) {
         HIPCHK(h, hipMemsetAsync(h->st.cs_power_hist, 0, sizeof(double) * (size_t)s.T * s.E * s.C, h->stream));
         HIPCHK(h, hipMemsetAsync(h->st.cs_cur_hist, 0, sizeof(double) * (size_t)s.T * s.E * s.C, h->stream));
