@@ -250,8 +250,6 @@ class EV2Gym:
         else:
             self.config, self.seed = None, seed
             assert scenario.n_envs == 1
-        self._batch = scenario
-        self._arr = scenario.arrays
         self.state_function, self.reward_function, self.cost_function = state_function, reward_function, cost_function
         sk = _kind(state_function, _abi.STATE_KINDS, "state_function")
         rk = _kind(reward_function, _abi.REWARD_KINDS, "reward_function")
@@ -260,6 +258,21 @@ class EV2Gym:
         flags = _abi.FLAG_LOG_CS_HISTORY if (log_cs_history or self._host_reward or cost_function) else 0
         flags |= _abi.FLAG_LOG_SOC
         self.engine = Engine(scenario, rk if rk is not None else 2, sk if sk is not None else 2, device=device, flags=flags)
+        self._d = None
+        self._bind_scenario(scenario)
+        low = -1.0 if self.v2g_enabled else 0.0
+        self.action_space = Box(low, 1.0, (self.engine.P,))
+        self.departing_evs = []
+        self.total_reward = 0.0
+        self._scenario_seed = self.seed if self.config is not None else None
+        self.reset()
+        self.observation_space = Box(-np.inf, np.inf, (len(self._last_obs),))
+        self.observation_mask = np.zeros(self.engine.P)
+
+    def _bind_scenario(self, scenario):
+        """Everything the facade derives from the loaded scenario (also after reset(seed=...) drew a new one)."""
+        self._batch = scenario
+        self._arr = scenario.arrays
         e = self.engine
         self.simulation_length, self.timescale = e.T, scenario.timescale
         self.cs, self.number_of_ports, self.number_of_ports_per_cs = e.C, e.P, scenario.ports_per_charger
@@ -273,15 +286,9 @@ class EV2Gym:
         self.transformers = [TransformerView(self, r) for r in range(e.R)]
         self._evs = {}
         self.EVs_profiles = [self._ev(k) for k in range(scenario.n_sessions)]
-        self._d = dict(act=e.empty((1, e.P)), obs=e.empty((1, e.D)), rew=e.empty((1,)), done=e.empty((1,), np.uint8),
-                       mask=e.empty((1, e.P), np.uint8))
-        low = -1.0 if self.v2g_enabled else 0.0
-        self.action_space = Box(low, 1.0, (e.P,))
-        self.departing_evs = []
-        self.total_reward = 0.0
-        self.reset(seed=seed)
-        self.observation_space = Box(-np.inf, np.inf, (len(self._last_obs),))
-        self.observation_mask = np.zeros(e.P)
+        if self._d is None:
+            self._d = dict(act=e.empty((1, e.P)), obs=e.empty((1, e.D)), rew=e.empty((1,)), done=e.empty((1,), np.uint8),
+                           mask=e.empty((1, e.P), np.uint8))
 
     # ---- snapshot plumbing ------------------------------------------------------------------------
     def _ev(self, k):
@@ -316,6 +323,14 @@ class EV2Gym:
 
     # ---- gym surface --------------------------------------------------------------------------------
     def reset(self, seed=None, options=None, **kwargs):
+        """`reset()` re-arms the loaded scenario; `reset(seed=s)` on an env built from a config file draws the scenario of
+        seed s first, like the reference's reset (ev2gym_env.py:243-331: new EV profiles, prices, loads per reset)."""
+        if seed is not None and self.config is not None and seed != self._scenario_seed:
+            self.seed = seed
+            new = generate(gen_config_from_yaml(self.config, 1, seed))
+            self.engine.load(new)
+            self._bind_scenario(new)
+            self._scenario_seed = seed
         self.engine.reset(self._d["obs"])
         self._snapshot = None
         self._max_obs_step = 0

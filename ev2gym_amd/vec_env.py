@@ -153,7 +153,16 @@ class EV2GymVec:
         return self.engine.current_step
 
     def reset(self, seed=None, options=None, **kwargs):
-        """Re-arms every env on its scenario (state-init part of EV2Gym.reset, ev2gym_env.py:298-331)."""
+        """Re-arms every env on its scenario (state-init part of EV2Gym.reset, ev2gym_env.py:298-331).  With a `seed`
+        different from the loaded one (and a config file to draw from) a NEW batch of scenarios is generated and loaded
+        first -- the reference's per-reset scenario draw (ev2gym_env.py:243-296); the host generation + upload takes
+        ~1 s per 4096 x 50 envs, so per-episode resampling is for evaluation, not for the inner training loop."""
+        if seed is not None and self.config is not None and int(seed) != self.seed:
+            self.seed = int(seed)
+            total = self.num_envs * self.world_size
+            full = generate(gen_config_from_yaml(self.config, total, self.seed))
+            self.scenarios = full.shard(self.rank, self.world_size) if self.world_size > 1 else full
+            self.engine.load(self.scenarios)
         self.engine.reset(self._obs)
         self.stats = None
         return self._out(self._obs), {}

@@ -223,3 +223,33 @@ def test_unfused_builtin_rewards_through_the_facade(name):
         _close(env.cost if done else info["cost"], want_cost, f"cost[{t}]")
     _close(info["total_reward"], z["trj_stats"][16], "total_reward")
     env.close()
+
+
+def test_reset_with_a_seed_draws_that_seeds_scenarios():
+    """reset(seed=s) == constructing with seed s (the reference draws its scenario inside reset, ev2gym_env.py:243-296);
+    reset() without a seed re-arms what is loaded."""
+    from ev2gym_amd.env import EV2Gym
+    from ev2gym_amd.vec_env import EV2GymVec
+    cfg = os.path.join(CFG, "V2GProfitPlusLoads.yaml")
+    kw = dict(state_function="V2G_profit_max_loads", reward_function="ProfitMax_TrPenalty_UserIncentives")
+    a = EV2Gym(config_file=cfg, seed=5, **kw)
+    b = EV2Gym(config_file=cfg, seed=9, **kw)
+    assert not np.array_equal(a._arr["ev_t_arr"], b._arr["ev_t_arr"]) or not np.array_equal(a._arr["charge_price"], b._arr["charge_price"])
+    ob, _ = b.reset(seed=5)
+    oa, _ = a.reset()
+    assert np.array_equal(oa, ob) and len(a.EVs_profiles) == len(b.EVs_profiles)
+    rng = np.random.default_rng(0)
+    for t in range(40):
+        act = rng.uniform(-1, 1, a.number_of_ports)
+        ra, rb = a.step(act.copy()), b.step(act.copy())
+        assert np.array_equal(ra[0], rb[0]) and ra[1] == rb[1]
+    a.close(); b.close()
+    v1 = EV2GymVec(config_file=cfg, num_envs=16, seed=3, use_torch=False, **kw)
+    v2 = EV2GymVec(config_file=cfg, num_envs=16, seed=4, use_torch=False, **kw)
+    o2, _ = v2.reset(seed=3)
+    o1, _ = v1.reset()
+    assert np.array_equal(o1, o2)
+    act = rng.uniform(-1, 1, (16, v1.number_of_ports))
+    s1, s2 = v1.step(act), v2.step(act)
+    assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[1], s2[1])
+    v1.close(); v2.close()
