@@ -259,6 +259,12 @@ class EV2Gym:
         flags |= _abi.FLAG_LOG_SOC
         self.engine = Engine(scenario, rk if rk is not None else 2, sk if sk is not None else 2, device=device, flags=flags)
         self._d = None
+        # the reference keeps a calendar date for plots / week-day logic (ev2gym_env.py:262-296); scenarios here carry none,
+        # so the date is the reference's base day at the configured start hour
+        import datetime
+        c = self.config or {}
+        self.sim_starting_date = datetime.datetime(2022, 1, 1, int(c.get("hour", 5)), int(c.get("minute", 0)))
+        self.sim_date = self.sim_starting_date
         self._bind_scenario(scenario)
         low = -1.0 if self.v2g_enabled else 0.0
         self.action_space = Box(low, 1.0, (self.engine.P,))
