@@ -156,7 +156,8 @@ class EV2GymVec:
         """Re-arms every env on its scenario (state-init part of EV2Gym.reset, ev2gym_env.py:298-331).  With a `seed`
         different from the loaded one (and a config file to draw from) a NEW batch of scenarios is generated and loaded
         first -- the reference's per-reset scenario draw (ev2gym_env.py:243-296); the host generation + upload takes
-        ~1 s per 4096 x 50 envs, so per-episode resampling is for evaluation, not for the inner training loop."""
+        0.16 s for 4096 x 50 envs (tools/reseed_timing.py) against 0.16 ms for a plain reset(): resample every so many
+        episodes rather than every one."""
         if seed is not None and self.config is not None and int(seed) != self.seed:
             self.seed = int(seed)
             total = self.num_envs * self.world_size
