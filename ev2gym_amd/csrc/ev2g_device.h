@@ -25,10 +25,13 @@
 
 // One EV session, 128 bytes = one cache line: everything the per-step battery maths needs (ev.py:68-113).
 struct __attribute__((aligned(128))) SessRec {
-    double B, cap0, des, minB, emerg, pacmax, pdismax, ts, tsm, eta_ch, eta_dis;
+    // the first 96 bytes are what the battery maths reads every step (the fast path fetches only those six 16-byte chunks) ...
+    double B, minB, emerg, pacmax, pdismax, ts, tsm, eta_ch, eta_dis;
     double gate_ch;   // min_ac_charge_power*1000/(voltage*sqrt(charger phases))   (ev.py:151)
     double gate_dis;  // min_discharge_power*1000/(voltage*sqrt(charger phases))   (ev.py:153)
     double v;         // voltage*sqrt(min(charger phases, ev_phases))              (ev.py:169,279,365)
+    // ... the rest is read on arrival / departure only
+    double cap0, des;    // battery_capacity_at_arrival, desired_capacity
     int nt_arr, nt_dep;  // window of the next session on the same port (EV2G_INT_MAX = none)
     int lut, pad;        // efficiency table id or -1
 };

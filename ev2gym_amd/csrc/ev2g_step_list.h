@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(WB, 4) ev2g_step_list(const V2P *__restrict__ 
                         if (r.lut >= 0) { const int li = ev_lut_index(r.lut, amps); if (li >= 0) lutv = S->lut[li]; }
                         const double prev0 = s_prev[h];
                         const int cyc0 = s_cyc[h];
-                        const EvRes o = ev_math(r, lutv, amps, cap, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt);
+                        const EvRes o = ev_math(r, lutv, amps, cap, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt, r.lut >= 0);
                         dirty = (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap || o.prev_power != prev0);
                         cap = o.cap;
                         s_prev[h] = o.prev_power;

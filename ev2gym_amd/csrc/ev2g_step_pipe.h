@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(EV2G_PIPE_BLOCK, 5) ev2g_step_pipe(const V2P *
                 const double cap0 = s_cap[h], prev0 = s_prev[h];                                                         \
                 const int cyc0 = s_cyc[h];                                                                               \
                 const double lutv = (li >= 0) ? lut_raw : 1.0 / 100.0;                                                   \
-                const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt); \
+                const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt, lut_id >= 0); \
                 if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;     \
                 s_cap[h] = o.cap;                                                                                        \
                 s_prev[h] = o.prev_power;                                                                                \

@@ -67,7 +67,7 @@ __device__ __forceinline__ int ev_lut_index(int lut, double amps) {
 //   * the final `ceil(cap*100)/100` goes through div_int_by_const (exhaustively verified range).
 __device__ __forceinline__ EvRes ev_math(const SessRec &r, double lutv, double amps, double cap,
                                          double prev_power, double tot_e, int cycles, double sixty_over_dt,
-                                         double dt_over_60, double dt, bool pow2_dt) {
+                                         double dt_over_60, double dt, bool pow2_dt, bool has_lut) {
     EvRes o;
     o.cap = cap; o.prev_power = prev_power; o.tot_e = tot_e; o.energy = 0.0; o.current = 0.0; o.cycles = cycles; o.emerg = 0;
     if (amps > 0.0 && amps < r.gate_ch) amps = 0.0;
@@ -76,7 +76,7 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, double lutv, double a
     if (prev_power == 0.0 || ((prev_power < 0.0) != (amps < 0.0))) o.cycles = cycles + 1;
     const double B = r.B, v = r.v;
     if (amps > 0.0) {
-        const double eta = (r.lut >= 0) ? lutv : r.eta_ch;
+        const double eta = has_lut ? lutv : r.eta_ch;
         const double pd0 = eta * amps * v / 1000.0 / B, md0 = eta * r.pacmax / B;
         double pilot_dsoc = pow2_dt ? pd0 * dt_over_60 : pd0 / sixty_over_dt;
         const double max_dsoc = pow2_dt ? md0 * dt_over_60 : md0 / sixty_over_dt;
@@ -105,7 +105,7 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, double lutv, double a
     } else {
         double given_power = amps * v / 1000.0;
         if (fabs(given_power) > fabs(r.pdismax)) given_power = r.pdismax;
-        const double eta = (r.lut >= 0) ? lutv : r.eta_dis;
+        const double eta = has_lut ? lutv : r.eta_dis;
         double given_energy = given_power * eta * dt / 60.0;
         if (cap + given_energy < r.minB) {
             if (cap > r.minB) { o.energy = -(cap - r.minB); given_energy = o.energy; }
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                     const double amps_h = s_amps[h];
                     double lutv = 1.0 / 100.0;
                     if (r.lut >= 0) { const int li = ev_lut_index(r.lut, amps_h); if (li >= 0) lutv = S->lut[li]; }
-                    const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt);
+                    const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt, r.lut >= 0);
                     if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
                     s_cap[h] = o.cap;
                     s_prev[h] = o.prev_power;

@@ -42,14 +42,16 @@ template <class T, class B> __device__ __forceinline__ void stg32(B base, unsign
 }
 typedef double d2v __attribute__((ext_vector_type(2)));   // builtin vectors: loadable from any address space
 typedef int i2v __attribute__((ext_vector_type(2)));
-// The whole record in one memory round trip: 8 x 16-byte loads issued back to back, then pinned by an empty asm so
+// The battery-maths part of the record (its first 96 bytes) in one memory round trip: 6 x 16-byte loads issued back to back, then pinned by an empty asm so
 // that the compiler cannot sink the ones a later branch does not need behind that branch (it otherwise loads the
 // two gate fields first and the rest only after testing them: two dependent round trips).
 template <class B> __device__ __forceinline__ SessRec ldg32_rec(B base, unsigned boff) {
     union { SessRec r; d2v v[sizeof(SessRec) / 16]; } u;
+    static_assert(offsetof(SessRec, cap0) == 96, "the battery maths reads the first six 16-byte chunks");
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(SessRec) / 16); i++) u.v[i] = ldg32<d2v>(base, boff + 16u * i);
-    asm volatile("" : "+v"(u.v[0]), "+v"(u.v[1]), "+v"(u.v[2]), "+v"(u.v[3]), "+v"(u.v[4]), "+v"(u.v[5]), "+v"(u.v[6]), "+v"(u.v[7]));
+    for (int i = 0; i < 6; i++) u.v[i] = ldg32<d2v>(base, boff + 16u * i);
+    asm volatile("" : "+v"(u.v[0]), "+v"(u.v[1]), "+v"(u.v[2]), "+v"(u.v[3]), "+v"(u.v[4]), "+v"(u.v[5]));
+    u.v[6] = (d2v){0.0, 0.0}; u.v[7] = (d2v){0.0, 0.0};   // arrival / departure fields: not read by ev_math
     return u.r;
 }
 
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
                     const double lutv = (li >= 0) ? lut_raw : 1.0 / 100.0;
-                    const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt);
+                    const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt, lut_id >= 0);
                     if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
                     s_cap[h] = o.cap;
                     s_prev[h] = o.prev_power;
