@@ -329,6 +329,16 @@ def main():
     cases.append(("v2gppl_ts5_rand_s16", ts5, *PPL, 16, "rand", None))
     ts30 = _yaml_variant(pst, {"timescale": 30}, "pst_ts30")
     cases.append(("pst_ts30_rand_s17", ts30, *PST, 17, "rand", None))
+    # combinations the single-feature cases above do not cross: multi-port chargers x several transformers x other timescales
+    x1 = _yaml_variant(pst, {"number_of_charging_stations": 12, "number_of_ports_per_cs": 3, "number_of_transformers": 2,
+                             "timescale": 5, "heterogeneous_ev_specs": False}, "pst_c12p3r2_ts5")
+    cases.append(("pst_c12p3r2ts5_rand_s31", x1, *PST, 31, "rand", None))
+    x2 = _yaml_variant(ppl, {"number_of_charging_stations": 9, "number_of_ports_per_cs": 3, "number_of_transformers": 3},
+                       "v2gppl_c9p3r3")
+    cases.append(("v2gppl_c9p3r3_wild_s32", x2, *PPL, 32, "wild", None))
+    x3 = _yaml_variant(vmax, {"number_of_charging_stations": 28, "number_of_ports_per_cs": 2, "number_of_transformers": 3,
+                              "timescale": 30}, "v2gmax_c28p2r3_ts30")
+    cases.append(("v2gmax_c28p2r3ts30_rand_s33", x3, *VMX, 33, "rand", None))
     for c in cases:
         if only and c[0] not in only:
             continue
