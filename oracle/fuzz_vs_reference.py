@@ -29,7 +29,7 @@ def main(n_cases):
     from ev2gym_amd.scenario import ScenarioBatch
     from oracle import Oracle
     base = "ev2gym/example_config_files/"
-    rng = np.random.default_rng(2026)
+    rng = np.random.default_rng(int(os.environ.get("EV2G_FUZZ_SEED", "2026")))
     worst = 0.0
     for case in range(n_cases):
         kind = case % 3
@@ -54,16 +54,24 @@ def main(n_cases):
         lo = -1.0 if env.config["v2g_enabled"] else 0.0
         pol = rng.choice(["rand", "wild", "mixed"])
         info = None
+        faulted = False
         for t in range(T):
             a = rng.uniform(lo, 1.0, P) if pol == "rand" else (rng.uniform(-1.6 if lo < 0 else 0, 1.6, P) if pol == "wild"
                                                                  else rng.uniform(lo, 1.0, P) * (rng.random(P) < 0.7))
-            ro, rr, rd, _, info = env.step(a.copy())
+            try:
+                ro, rr, rd, _, info = env.step(a.copy())
+            except Exception as ex:   # the reference's over-current exception (ev_charger.py:203-205): the oracle must flag the same step
+                assert "sum of amps" in str(ex), ex
+                oo, orr, od, om, rc = ora.step(a[None].copy())
+                assert rc != 0, (case, t, "reference raised over-current, oracle did not")
+                faulted = True
+                break
             oo, orr, od, om, rc = ora.step(a[None].copy())
             assert rc == 0 and bool(od[0]) == bool(rd), (case, t)
             assert np.array_equal(om[0].astype(float), np.asarray(info["action_mask"], float)), (case, t, "mask")
             err = max(err, np.abs(oo[0] - ro).max() / max(1.0, np.abs(ro).max()), abs(orr[0] - rr) / max(1.0, abs(rr)))
         st = ora.stats()[0]
-        for i, k in enumerate(cg.STAT_KEYS):
+        for i, k in enumerate(cg.STAT_KEYS if not faulted else []):
             rv = float(info[k])
             if np.isnan(rv) and np.isnan(st[i]):
                 continue
@@ -71,7 +79,7 @@ def main(n_cases):
         ora.close()
         worst = max(worst, err)
         print(f"case {case:3d} {sf:22s} C={over['number_of_charging_stations']:2d} npc={over['number_of_ports_per_cs']} R={over['number_of_transformers']} "
-              f"dt={over['timescale']:2d} het={int(over['heterogeneous_ev_specs'])} {pol:5s} max rel err {err:.2e}", flush=True)
+              f"dt={over['timescale']:2d} het={int(over['heterogeneous_ev_specs'])} {pol:5s} max rel err {err:.2e}" + (" (over-current fault at the same step)" if faulted else ""), flush=True)
         assert err < 1e-9, "oracle and reference disagree"
     print(f"{n_cases} cases, worst relative error {worst:.2e}")
 
