@@ -46,18 +46,6 @@ WORKLOADS = {
 }
 
 
-def kernel_name(batch, sk, rk):
-    """Which step kernel ev2g_load_scenarios() selects for this shape (ev2gym_amd/csrc/ev2g_host.hip)."""
-    P, R, npc = batch.n_ports, batch.n_transformers, batch.ports_per_charger
-    k = os.environ.get("EV2G_KERNEL", "")
-    if P <= 64 and R == 1 and npc == 1 and k == "pipe":
-        return f"ev2g_step_pipe<{sk},{rk}>"
-    if P <= 64 and R == 1 and npc == 1 and k != "v2":
-        return (f"ev2g_step_list<{sk},{rk},{256 if k == 'list256' else 128}>" if k in ("list", "list256") and P >= 4
-                else f"ev2g_step_wave<{sk},{rk}>")
-    return f"ev2g_step_v2<{256 if P <= 256 else 512 if P <= 512 else 1024}>" if P <= 1024 else "ev2g_step_kernel"
-
-
 def measured_traffic(workload, launch, steps_per_launch, envs):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes (profiles/r01_hbm_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH doubled per the gfx950 note in
@@ -76,8 +64,8 @@ def cpu_baseline(batch, rk, sk, lo, budget_s=12.0):
     cores, single thread, on whole episodes of a prefix of the same env batch."""
     from oracle.oracle import Oracle
     from ev2gym_amd.engine import host_uniform
-    n = min(batch.n_envs, 512)
-    sub = batch.select(np.arange(n))
+    n = batch.n_envs
+    sub = batch
     ora = Oracle(sub, rk, sk)
     E, P, T = sub.n_envs, sub.n_ports, sub.n_steps
     acts = host_uniform(T * E * P, 12345, lo, 1.0).reshape(T, E, P)
@@ -122,6 +110,50 @@ def cpu_baseline(batch, rk, sk, lo, budget_s=12.0):
                        f"reference CPython step() measured at build time: 1075 env-steps/s/core at 50 chargers (BASELINE.md)")
 
 
+class RolloutLoop:
+    """The stepping loop the benchmark times (and tests/test_dist_gloo.py drives on CPU with a stub engine): whole
+    episodes where possible; at every episode end the statistics kernel, the (asynchronous) gather of the statistics over
+    the ranks and a reset onto the next window of the resident scenario pool."""
+
+    def __init__(self, eng, E, P, T, M, acts, obs, rew, done, mask, stats, gath=None, actor=None):
+        self.eng, self.E, self.P, self.T, self.M = eng, E, P, T, M
+        self.acts, self.obs, self.rew, self.done, self.mask, self.stats = acts, obs, rew, done, mask, stats
+        self.gath, self.actor = gath, actor
+        self.offset = 0
+        self.episodes = 0
+
+    def reset(self):
+        self.offset = (self.offset + self.E) % self.M   # fresh scenarios every episode (E <= M: no env shares one)
+        self.eng.reset(self.obs, offset=self.offset)
+
+    def episode_end(self):
+        if self.gath is None:
+            self.eng.stats(out=self.stats)
+        else:
+            self.eng.stats(out=self.gath.buffer())
+            self.gath.launch()
+        self.episodes += 1
+        self.reset()
+
+    def run(self, n_steps, persistent, timing=None):
+        eng, T = self.eng, self.T
+        left = n_steps
+        while left > 0:
+            t = eng.current_step
+            if self.actor is not None:
+                k = 1
+                self.actor.step(self)
+            else:
+                k = min(left, T - t)
+                eng.step_n(k, self.acts[t], self.E * self.P, self.obs, 0, self.rew, 0, self.done, 0, self.mask, 0,
+                           auto_reset=False, persistent=persistent)
+            if timing is not None:
+                timing.append((eng.last_step_n_kernel_ms(), k))
+            left -= k
+            if eng.current_step >= T:
+                self.episode_end()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +161,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=112)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
+    ap.add_argument("--pool", type=int, default=0, help="scenario pool size as a multiple of --envs (default 8; cfg4: 2): every "
+                    "episode steps a fresh window of the resident pool (the per-reset scenario draw of the reference)")
     ap.add_argument("--launch", default="auto", choices=["auto", "per_step", "persistent"])
+    ap.add_argument("--min-time", type=float, default=0.25, help="repeat the --steps-sized timed region until this many seconds "
+                    "have been measured per launch mode (median over the repetitions is reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-soc-log", action="store_true", help="skip the SoC log that the battery-degradation statistics need")
     ap.add_argument("--actor", default="none", choices=["none", "mlp"],
@@ -157,14 +193,16 @@ def main():
     from ev2gym_amd.engine import Engine
     wl = WORKLOADS[args.workload]
     E = args.envs or wl["envs"]            # per GPU: weak scaling
+    pool = args.pool or (2 if args.workload == "cfg4" else 8)
+    M = E * pool
     rk, sk = _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]]
-    batch = generate(wl["gen"](E, args.seed * 1000 + rank))   # every rank draws its own shard of scenarios
+    batch = generate(wl["gen"](M, args.seed * 1000 + rank))   # every rank draws its own pool of scenarios
     phi = occupancy_fraction(batch)
     # engine kernels, torch allocations and the RCCL gather all run on ONE explicit (non-default) stream
     tstream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(tstream)
     eng = Engine(batch, rk, sk, device=local_rank, stream=tstream.cuda_stream,
-                 flags=0 if args.no_soc_log else _abi.FLAG_LOG_SOC)
+                 flags=0 if args.no_soc_log else _abi.FLAG_LOG_SOC, n_active_envs=E)
     P, D, T = eng.P, eng.D, eng.T
     dev = torch.device("cuda", local_rank)
     acts = torch.empty((T, E, P), dtype=torch.float64, device=dev)
@@ -181,38 +219,10 @@ def main():
 
     actor = None
     if args.actor == "mlp":
-        torch.manual_seed(1234 + rank)
-        lo_a = wl["lo"]
-        net = torch.nn.Sequential(torch.nn.Linear(D, 400), torch.nn.ReLU(), torch.nn.Linear(400, 300), torch.nn.ReLU(),
-                                  torch.nn.Linear(300, P), torch.nn.Tanh()).to(dev)
-        a_buf = torch.empty((E, P), dtype=torch.float64, device=dev)
+        from ev2gym_amd.actor import make_actor
+        actor = make_actor(eng, E, P, D, wl["lo"], dev, seed=1234 + rank)
 
-        @torch.no_grad()
-        def actor(o):
-            a = net(o.to(torch.float32))
-            if lo_a == 0.0:
-                a = a * 0.5 + 0.5
-            a_buf.copy_(a)
-            return a_buf
-
-    def run(n_steps, persistent, timing=None):
-        """n_steps batched steps; whole episodes where possible; stats (+gather) and reset at episode ends."""
-        left = n_steps
-        while left > 0:
-            t = eng.current_step
-            k = 1 if actor is not None else min(left, T - t)
-            a_src = actor(obs) if actor is not None else acts[t]
-            eng.step_n(k, a_src, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=persistent)
-            if timing is not None:
-                timing.append((eng.last_step_n_kernel_ms(), k))
-            left -= k
-            if eng.current_step >= T:
-                if gath is None:
-                    eng.stats(out=stats)
-                else:
-                    eng.stats(out=gath.buffer())
-                    gath.launch()
-                eng.reset(obs)
+    loop = RolloutLoop(eng, E, P, T, M, acts, obs, rew, done, mask, stats, gath, actor)
 
     def barrier():
         if gath is not None:
@@ -223,60 +233,113 @@ def main():
         torch.cuda.synchronize()
 
     def timed(persistent):
-        eng.reset(obs)
-        run(args.warmup, persistent)
-        eng.reset(obs)
+        """Median over repetitions of the --steps-sized region.  One repetition = a chain of whole --steps regions long
+        enough to out-weigh the launch / synchronisation edges (>= 20 ms), bracketed by barrier + synchronize; episode ends
+        (statistics kernel, gather, reset onto fresh scenarios) fall where they fall inside the chain."""
+        loop.reset()
+        loop.run(args.warmup, persistent)
+        loop.reset()
         barrier()
         t0 = time.perf_counter()
-        run(args.steps, persistent)
+        loop.run(args.steps, persistent)
         barrier()
-        dt_ = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt_], dtype=torch.float64, device=dev)
+        one = time.perf_counter() - t0
+        inner = max(1, int(np.ceil(0.02 / max(one, 1e-6))))
+        if world > 1:   # every rank must run the same number of steps
+            tt = torch.tensor([inner], dtype=torch.int64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt_ = float(tt.item())
-        return dt_
+            inner = int(tt.item())
+        samples, spent = [], 0.0
+        while spent < args.min_time or len(samples) < 3:
+            barrier()
+            t0 = time.perf_counter()
+            loop.run(args.steps * inner, persistent)
+            barrier()
+            dt_ = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([dt_], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt_ = float(tt.item())
+            samples.append(dt_ / inner)
+            spent += dt_
+            if len(samples) >= 200:
+                break
+        return float(np.median(samples)), len(samples), inner, samples
 
     modes = ["per_step", "persistent"] if args.launch == "auto" else [args.launch]
-    wall = {m: timed(m == "persistent") for m in modes}
+    res = {m: timed(m == "persistent") for m in modes}
+    wall = {m: r[0] for m, r in res.items()}
     best = min(wall, key=wall.get)
-    # kernel-only duration of the chosen mode, HIP events on the launch stream (separate, untimed pass)
-    eng.reset(obs)
-    tim = []
-    run(min(args.steps, 2 * T), best == "persistent", timing=tim)
-    torch.cuda.synchronize()
-    kern_ms = sum(x for x, _ in tim)
-    kern_steps = sum(k for _, k in tim)
-    n_launch = kern_steps if best == "per_step" else len(tim)
-    eng.check_faults()
+
+    # whole episodes, the RL-free upper bound of the path: one 112-step persistent launch + statistics + reset per episode
+    full_ep = None
+    if actor is None:
+        loop.reset()
+        loop.run(T, True)
+        barrier()
+        n_ep = 0
+        t0 = time.perf_counter()
+        while n_ep < 3 or time.perf_counter() - t0 < 0.1:
+            loop.reset() if loop.eng.current_step else None
+            loop.run(T, True)
+            n_ep += 1
+        barrier()
+        ep_s = (time.perf_counter() - t0) / n_ep
+        full_ep = {"episodes": n_ep, "ms_per_episode": ep_s * 1e3, "env_steps_per_s": world * E * T / ep_s,
+                   "contains": "112-step persistent launch + statistics kernel + reset onto fresh scenarios"}
 
     C_, R_ = batch.n_chargers, batch.n_transformers
     bytes_env_step = P * (phi * wl["b_occ"] + (1 - phi) * wl["b_empty"]) + R_ * wl["b_tr"] + wl["b_env"]
+
+    def roofline(mode):
+        # kernel-only duration, HIP events on the launch stream around every ev2g_step_n of an untimed pass
+        loop.reset()
+        tim = []
+        loop.run(max(min(args.steps, 2 * T), T), mode == "persistent", timing=tim)
+        torch.cuda.synchronize()
+        kern_ms = sum(x for x, _ in tim)
+        kern_steps = sum(k for _, k in tim)
+        n_launch = kern_steps if mode == "per_step" else len(tim)
+        launch_s = kern_ms / 1e3 / n_launch
+        bytes_per_launch = bytes_env_step * E * (kern_steps / n_launch)
+        achieved = bytes_per_launch / launch_s / 1e9
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": measured_traffic(args.workload, mode, kern_steps / n_launch, E),
+                "kernel": eng.kernel_name, "avg_launch_us": launch_s * 1e6, "steps_per_launch": kern_steps / n_launch,
+                "algorithmic_bytes_per_env_step": bytes_env_step}
+
+    roof = {m: roofline(m) for m in modes}
+    eng.check_faults()
+
     env_steps_total = world * E * args.steps
     value = env_steps_total / wall[best]
-    launch_s = kern_ms / 1e3 / n_launch
-    bytes_per_launch = bytes_env_step * E * (kern_steps / n_launch)
-    achieved = bytes_per_launch / launch_s / 1e9
+    per_rank = None
+    if world > 1:   # what every rank measured itself (the driver computes scaling efficiency from `value`)
+        mine = torch.tensor([E * args.steps / float(np.median(res[best][3]))], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank = [float(v.item()) for v in allv]
     out = {
         "metric": "env-steps/sec (envs x chargers x steps); % HBM roofline",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall[best] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": E, "chargers": C_,
+        "reps": res[best][1], "regions_per_rep": res[best][2], "timing": "median over reps of (chain of `regions_per_rep` x `steps`-step regions) / regions_per_rep",
+        "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": E, "scenario_pool_per_gpu": M, "chargers": C_,
                    "transformers": R_, "steps_per_episode": T, "obs_dim": D, "occupancy_phi": round(phi, 4), "soc_log": not args.no_soc_log,
-                   "launch": best, "actor": args.actor, "parallelism": f"env-sharded x{world}, RCCL all_gather of episode stats only (asynchronous, overlaps the next episode)"},
+                   "launch": best, "actor": args.actor if actor is None else actor.describe,
+                   "parallelism": f"env-sharded x{world}, RCCL all_gather of episode stats only (asynchronous, overlaps the next episode)"},
         "port_steps_per_s": value * P,
         "wall_s_by_launch_mode": {m: round(w, 6) for m, w in wall.items()},
         "env_steps_per_s_by_launch_mode": {m: env_steps_total / w for m, w in wall.items()},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.workload, best, kern_steps / n_launch, E),
-                     "kernel": kernel_name(batch, sk, rk),
-                     "avg_launch_us": launch_s * 1e6,
-                     "steps_per_launch": kern_steps / n_launch,
-                     "algorithmic_bytes_per_env_step": bytes_env_step},
+        "full_episode": full_ep,
+        "roofline": roof[best],
+        "roofline_by_launch_mode": roof,
+        "rccl_ranks_seen": (world if world > 1 else None), "per_rank_env_steps_per_s": per_rank,
+        "rccl_collectives_issued": (gath.collectives if gath is not None else 0),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(batch, rk, sk, wl["lo"])
+        out["cpu_baseline"] = cpu_baseline(batch.select(np.arange(min(E, 512))), rk, sk, wl["lo"])
     elif rank == 0:
         out["cpu_baseline"] = None
     eng.close()

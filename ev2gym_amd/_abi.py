@@ -1,7 +1,7 @@
 """ctypes mirrors of include/ev2g.h (the C-ABI structs).  Keep in sync with the header."""
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 LUT_LEN = 101
 N_STATS = 17
 
@@ -26,6 +26,13 @@ STAT_NAMES = [  # get_statistics(), utilities/utils.py:84-101
 # grid-simulation keys of the same dict (utils.py:103-112): constant 0 because simulate_grid is out of scope
 GRID_STAT_ZEROS = ('saved_grid_energy', 'voltage_violation', 'voltage_violation_counter',
                    'voltage_violation_counter_per_step')
+
+COST_KINDS = {
+    "transformer_overload_usrpenalty_cost": 1,         # rl_agent/cost.py:8-18
+    "ProfitMax_TrPenalty_UserIncentives_safety": 2,    # rl_agent/cost.py:22-27
+}
+AUTO_RESET_SAME = 1
+AUTO_RESET_NEXT = 2
 
 ERR_DONE = -4
 ERR_OVERCURRENT = -5
@@ -66,7 +73,12 @@ class ScenarioBatchC(C.Structure):
 
 class ConfigC(C.Structure):
     _fields_ = [("device", C.c_int32), ("reward_kind", C.c_int32), ("state_kind", C.c_int32),
-                ("flags", C.c_int32), ("stream", C.c_void_p)]
+                ("flags", C.c_int32), ("stream", C.c_void_p), ("cost_kind", C.c_int32), ("n_active_envs", C.c_int32)]
+
+
+class StepExtrasC(C.Structure):
+    _fields_ = [("cost", C.c_void_p), ("cost_step_stride", C.c_int64), ("obs_f32", C.c_void_p),
+                ("obs_f32_step_stride", C.c_int64), ("actions_f32", C.c_void_p)]
 
 
 class EnvViewC(C.Structure):

@@ -37,8 +37,10 @@ struct __attribute__((aligned(128))) SessRec {
 };
 
 struct DevScn {  // read-only scenario + layout, device pointers
-    int E, T, C, npc, P, R, D, ND, dt;
-    int reward_kind, state_kind, flags;
+    int E;        // envs stepped concurrently (state arrays are [E, ...])
+    int M;        // scenarios resident in the pool (scenario arrays are [M, ...]); env e runs scenario (e + off) mod M
+    int T, C, npc, P, R, D, ND, dt;
+    int reward_kind, state_kind, flags, cost_kind;
     int n_lut;    // number of efficiency tables
     int G;        // envs per workgroup
     int gs;       // lanes per reduction group (power of two, 4..64)
@@ -114,7 +116,26 @@ struct StepIO {
     double *reward;        long long r_stride;
     uint8_t *done;         long long d_stride;
     uint8_t *mask;         long long m_stride;
+    // scenario pool window of this launch: env e runs scenario (e + scn_off) mod M; an in-launch auto-reset advances the
+    // offset by scn_stride (0: re-arm the same scenarios)
+    int scn_off, scn_stride;
+    int step0;   // index of this launch's first step inside the caller's ev2g_step_n run (offsets the extras' step strides)
 };
+
+// optional extra step outputs / inputs (ev2g_set_step_extras), device-resident next to the kernel parameter block: they are
+// sticky and rarely used, so they do not occupy kernel-argument SGPRs
+struct StepExtras {
+    double *cost;          long long c_stride;     // cost_function value [E]
+    float *obs32;          long long o32_stride;   // float32 observation copy [E,D]
+    const float *act32;                            // float32 actions [E,P], used when StepIO::actions is null; step stride a_stride
+};
+
+// scenario of env e under pool offset `off` (0 <= off < M, e < E <= M)
+__host__ __device__ __forceinline__ int ev2g_scn(int e, int off, int M) { const int s = e + off; return s >= M ? s - M : s; }
+// action of (env-port element i) from whichever action array the caller supplied; widened to float64 on entry
+__device__ __forceinline__ double ev2g_action(const StepIO &io, const float *act32, long long step_off, long long i) {
+    return io.actions ? io.actions[step_off + i] : (double)act32[step_off + i];
+}
 
 #define EV2G_INT_MAX 0x7fffffff
 
@@ -290,14 +311,15 @@ __device__ __forceinline__ double group_sum(double v, int gs) {
 
 // Observation columns that do not belong to a port: head + per-transformer windows, for env `e` at step
 // counter `sstep` (= current_step after the increment), written cooperatively by `nl` lanes (lane id `l`).
-__device__ __forceinline__ void write_obs_env(const DevScn &s, double *__restrict__ obs_e, int e, int sstep,
+template <class OT>
+__device__ __forceinline__ void write_obs_env(const DevScn &s, OT *__restrict__ obs_e, int e /* scenario index */, int sstep,
                                               double usage_prev, int l, int nl) {
     const int T = s.T;
     if (s.state_kind == 1) {  // PublicPST state.py:6-35
         if (l == 0) {
-            obs_e[0] = (double)sstep / (double)T;
-            obs_e[1] = (sstep < T) ? s.setpoint[(long long)e * T + sstep] : 0.0;
-            obs_e[2] = usage_prev;
+            obs_e[0] = (OT)((double)sstep / (double)T);
+            obs_e[1] = (OT)((sstep < T) ? s.setpoint[(long long)e * T + sstep] : 0.0);
+            obs_e[2] = (OT)usage_prev;
         }
         return;
     }
@@ -310,7 +332,7 @@ __device__ __forceinline__ void write_obs_env(const DevScn &s, double *__restric
             const int k = sstep + (c - 2);
             v = (k < T) ? fabs(s.price_ch[(long long)e * T + k]) : 0.0;
         }
-        obs_e[c] = v;
+        obs_e[c] = (OT)v;
     }
     if (s.state_kind == 0) {
         const int n = s.R * 40;
@@ -318,14 +340,15 @@ __device__ __forceinline__ void write_obs_env(const DevScn &s, double *__restric
             const int r = i / 40, j = i - r * 40;
             const int er = e * s.R + r;
             double v = (j < 20) ? load_minus_pv_at(s, (long long)er * T, sstep, j) : power_limit_at(s, er, sstep, j - 20);
-            obs_e[s.tr_obs[r] + j] = v;
+            obs_e[s.tr_obs[r] + j] = (OT)v;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // reset: EV2Gym.reset() state-init part (ev2gym_env.py:298-306,329-331; utils.py:794-861; ev_charger.py:96-112)
-__global__ void __launch_bounds__(EV2G_BLOCK) ev2g_reset_kernel(DevScn s, DevState st, double *__restrict__ obs) {
+__global__ void __launch_bounds__(EV2G_BLOCK) ev2g_reset_kernel(DevScn s, DevState st, double *__restrict__ obs,
+                                                                float *__restrict__ obs32, int scn_off) {
     const int grp = blockIdx.x;
     const int e0 = grp * s.G;
     const int ne = min(s.G, s.E - e0);
@@ -334,8 +357,11 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_reset_kernel(DevScn s, DevSta
         const int el = idx / P, q = idx - el * P;
         const int e = e0 + el;
         const long long g = (long long)e * P + q;
-        st.win[g] = s.port_first_win[g];
-        st.sc[g] = make_int2(s.port_first[g], 0);
+        const long long gs = (long long)ev2g_scn(e, scn_off, s.M) * P + q;   // this env's scenario for the coming episode
+        const int2 w = s.port_first_win[gs];
+        const int first = s.port_first[gs];
+        st.win[g] = w;
+        st.sc[g] = make_int2(first, 0);
         st.cap[g] = 0.0;
         st.tot_e[g] = 0.0;
         st.prev_power[g] = 0.0;
@@ -346,6 +372,12 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_reset_kernel(DevScn s, DevSta
             o[0] = 0.0;
             o[1] = 0.0;
             if (s.state_kind == 1) o[2] = 0.0;
+        }
+        if (obs32) {
+            float *o = obs32 + (long long)e * s.D + s.slot_obs[q];
+            o[0] = 0.f;
+            o[1] = 0.f;
+            if (s.state_kind == 1) o[2] = 0.f;
         }
     }
     for (int idx = threadIdx.x; idx < ne * s.C; idx += EV2G_BLOCK) {
@@ -362,17 +394,25 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_reset_kernel(DevScn s, DevSta
     }
     for (int idx = threadIdx.x; idx < ne; idx += EV2G_BLOCK) st.env_fault[e0 + idx] = 0;
     for (int idx = threadIdx.x; idx < ne * s.R; idx += EV2G_BLOCK) st.tr_power_now[(long long)e0 * s.R + idx] = 0.0;
-    if (obs) {
+    if (obs || obs32) {
         const int lpe = EV2G_BLOCK / ne;  // lanes per env
         const int el = threadIdx.x / lpe;
-        if (el < ne) write_obs_env(s, obs + (long long)(e0 + el) * s.D, e0 + el, 0, 0.0, threadIdx.x - el * lpe, lpe);
+        if (el < ne) {
+            const int scn = ev2g_scn(e0 + el, scn_off, s.M);
+            if (obs) write_obs_env(s, obs + (long long)(e0 + el) * s.D, scn, 0, 0.0, threadIdx.x - el * lpe, lpe);
+            if (obs32) write_obs_env(s, obs32 + (long long)(e0 + el) * s.D, scn, 0, 0.0, threadIdx.x - el * lpe, lpe);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// step: EV2Gym.step() for the envs of this workgroup, k_steps consecutive timesteps starting at t0.
-// Dynamic LDS: double stage[EV2G_NQ][N] ; double tsum[EV2G_NQ][G*R] ; double esum[EV2G_NQ][G]   (N = G*P)
-__global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevState st, StepIO io, int t0, int k_steps,
+// step: EV2Gym.step() for the envs of this workgroup, k_steps consecutive timesteps starting at t0.  The generic
+// kernel: ports looped per thread, any P that fits the LDS staging (used above 1024 ports per env).
+// Dynamic LDS: double stage[EV2G_NQ][N] ; tsum[EV2G_NQ][G*R] ; esum[EV2G_NQ][G] ; amask[N] (multi-port chargers)   (N = G*P)
+__host__ __device__ inline size_t ev2g_generic_lds_bytes(int G, int P, int R, int npc) {
+    return sizeof(double) * ((size_t)EV2G_NQ * G * P + (size_t)EV2G_NQ * G * R + (size_t)EV2G_NQ * G + (npc > 1 ? (size_t)G * P : 0));
+}
+__global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevState st, StepIO io, StepExtras xt, int t0, int k_steps,
                                                                int auto_reset) {
     extern __shared__ double lds[];
     // XCD-aware env-group mapping: workgroup b runs on XCD b % 8 (observed dispatch order); give every XCD a
@@ -391,18 +431,23 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
     double *stage = lds;
     double *tsum = lds + (size_t)EV2G_NQ * NS;
     double *esum = tsum + (size_t)EV2G_NQ * s.G * R;
+    double *amask = esum + (size_t)EV2G_NQ * s.G;   // [NS] this step's action of every port, 0 where the port is empty (npc > 1)
     const int tid = threadIdx.x;
     const bool log_cs = st.cs_profits != nullptr;
+    int off = io.scn_off;
 
     int t = t0;
     for (int kk = 0; kk < k_steps; kk++) {
         if (t >= T) {  // episode finished inside a fused run
             if (!auto_reset) break;
+            off = ev2g_scn(off, io.scn_stride, s.M);
             // in-kernel ev2g_reset for this workgroup's envs
             for (int idx = tid; idx < N; idx += EV2G_BLOCK) {
+                const int el = idx / P, q = idx - el * P;
                 const long long g = (long long)e0 * P + idx;
-                st.win[g] = s.port_first_win[g];
-                st.sc[g] = make_int2(s.port_first[g], 0);
+                const long long gs = (long long)ev2g_scn(e0 + el, off, s.M) * P + q;
+                st.win[g] = s.port_first_win[gs];
+                st.sc[g] = make_int2(s.port_first[gs], 0);
                 st.port_energy[g] = 0.0;
                 st.port_current[g] = 0.0;
             }
@@ -417,34 +462,46 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
             t = 0;
             __syncthreads();
         }
-        const double *__restrict__ actions = io.actions + (long long)kk * io.a_stride;
+        const long long a_off = (long long)kk * io.a_stride + (io.actions ? 0 : (long long)io.step0 * io.a_stride);
         double *__restrict__ obs = io.obs ? io.obs + (long long)kk * io.o_stride : nullptr;
+        float *__restrict__ obs32 = xt.obs32 ? xt.obs32 + (long long)(io.step0 + kk) * xt.o32_stride : nullptr;
         uint8_t *__restrict__ mask = io.mask ? io.mask + (long long)kk * io.m_stride : nullptr;
         const int sstep = t + 1;
+
+        // ---------------- phase 0 (multi-port chargers): the actions the normalisation sums, ev_charger.py:137-149 ----------------
+        // Snapshot BEFORE any window changes: phase 1 frees departing ports, and a charger's ports may sit in different
+        // wavefronts / loop iterations -- the sum must see this step's occupancy, not the post-departure one.
+        if (npc > 1) {
+            for (int idx = tid; idx < N; idx += EV2G_BLOCK) {
+                const int el = idx / P, q = idx - el * P;
+                const int e = e0 + el;
+                const int2 w = st.win[(long long)e * P + q];
+                const bool occ = (w.x <= t) && (t <= w.y);
+                amask[idx] = occ ? ev2g_action(io, xt.act32, a_off, (long long)e * P + s.slot_port[q]) : 0.0;
+            }
+            __syncthreads();
+        }
 
         // ---------------- phase 1: per port ----------------
         for (int idx = tid; idx < N; idx += EV2G_BLOCK) {
             const int el = idx / P, q = idx - el * P;
             const int e = e0 + el;
+            const int scn = ev2g_scn(e, off, s.M);
             const long long g = (long long)e * P + q;
             const int cs = s.slot_cs[q];
             const int pref = s.slot_port[q];
             int2 w = st.win[g];
             const bool occ = (w.x <= t) && (t <= w.y);
-            double a = actions[(long long)e * P + pref];
-            if (!occ) a = 0.0;  // ev_charger.py:137-140
+            double a;
             if (npc == 1) {     // ev_charger.py:143-149 with one port: a/a
+                a = occ ? ev2g_action(io, xt.act32, a_off, (long long)e * P + pref) : 0.0;  // ev_charger.py:137-140
                 if (a > 1.0) a = a / a;
                 else if (a < -1.0) a = -a / a;
             } else {
-                const int j0 = q - (pref - cs * npc);  // slot of the charger's port 0 (ports of a charger are adjacent)
+                a = amask[idx];
+                const int j0 = idx - (pref - cs * npc);  // slot of the charger's port 0 (ports of a charger are adjacent, in port order)
                 double S = 0.0;
-                for (int j = 0; j < npc; j++) {
-                    const int2 wj = st.win[g - q + j0 + j];
-                    const bool oj = (wj.x <= t) && (t <= wj.y);
-                    const double aj = oj ? actions[(long long)e * P + cs * npc + j] : 0.0;
-                    S = S + aj;
-                }
+                for (int j = 0; j < npc; j++) S = S + amask[j0 + j];   // sequential python sum()
                 if (S > 1.0) a = a / S;
                 else if (S < -1.0) a = -a / S;
             }
@@ -475,8 +532,8 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                     current = o.current;
                     emerg = (double)o.emerg;
                     const double ae = fabs(energy);
-                    if (x > 0.0) { profit = ae * s.price_ch[(long long)e * T + t]; e_ch = ae; }
-                    else         { profit = ae * s.price_dis[(long long)e * T + t]; e_dis = ae; }
+                    if (x > 0.0) { profit = ae * s.price_ch[(long long)scn * T + t]; e_ch = ae; }
+                    else         { profit = ae * s.price_dis[(long long)scn * T + t]; e_dis = ae; }
                     if (o.active) {
                         st.cap[g] = cap;
                         st.tot_e[g] = tot_e;
@@ -494,7 +551,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 if (t >= w.y) {
                     const double des = s.ss_des[ss];
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
-                    if (s.reward_kind != 1) satpen = 100.0 * exp(-10.0 * score);
+                    if (s.reward_kind != 1 || s.cost_kind == 1) satpen = 100.0 * exp(-10.0 * score);
                     const long long gc = (long long)e * C + cs;
                     if (npc == 1) {
                         st.cs_served[gc] += 1;
@@ -551,6 +608,12 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 o[0] = o0;
                 o[1] = o1;
                 if (s.state_kind == 1) o[2] = o2;
+            }
+            if (obs32) {
+                float *o = obs32 + (long long)e * s.D + s.slot_obs[q];
+                o[0] = (float)o0;
+                o[1] = (float)o1;
+                if (s.state_kind == 1) o[2] = (float)o2;
             }
             stage[0 * NS + idx] = energy * 60.0 / (double)s.dt;  // contribution to current_power_output
             stage[1 * NS + idx] = current;
@@ -654,12 +717,13 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
             const int el = tid / lpe, l = tid - el * lpe;
             if (el < ne) {
                 const int e = e0 + el;
+                const int scn = ev2g_scn(e, off, s.M);
                 const double usage = esum[0 * s.G + el];
                 // transformers: Transformer.reset + step + get_how_overloaded (transformer.py:258-302)
                 double over_sum = 0.0;  // only lane 0 uses it
                 if (l == 0) {
                     for (int r = 0; r < R; r++) {
-                        const long long erT = ((long long)e * R + r) * T + t;
+                        const long long erT = ((long long)scn * R + r) * T + t;
                         double ptr = s.tr_infl[erT] + s.tr_solar[erT];
                         ptr += tsum[0 * (s.G * R) + el * R + r];
                         const double mx = s.tr_maxp[erT], mn = s.tr_minp[erT];
@@ -674,7 +738,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                     double reward;
                     const double costs = esum[2 * s.G + el];
                     if (s.reward_kind == 1) {  // SquaredTrackingErrorReward reward.py:7-14
-                        const double sp = s.setpoint[(long long)e * T + t];
+                        const double sp = s.setpoint[(long long)scn * T + t];
                         const double pp = st.pot_hist[(long long)t * s.E + e];
                         const double m = (pp < sp) ? pp : sp;
                         const double d = m - usage;
@@ -692,8 +756,11 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                     acc[4] += esum[7 * s.G + el];
                     if (io.reward) io.reward[(long long)kk * io.r_stride + e] = reward;
                     if (io.done) io.done[(long long)kk * io.d_stride + e] = (sstep >= T) ? 1 : 0;
+                    if (xt.cost)   // cost_function (rl_agent/cost.py:8-27)
+                        xt.cost[(long long)(io.step0 + kk) * xt.c_stride + e] = (s.cost_kind == 2) ? costs : over_sum + esum[3 * s.G + el];
                 }
-                if (obs) write_obs_env(s, obs + (long long)e * s.D, e, sstep, usage, l, lpe);
+                if (obs) write_obs_env(s, obs + (long long)e * s.D, scn, sstep, usage, l, lpe);
+                if (obs32) write_obs_env(s, obs32 + (long long)e * s.D, scn, sstep, usage, l, lpe);
             }
         }
         t += 1;
@@ -705,7 +772,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
 // [ (loads - pv)[20] | power_limits[20] ] (transformer.py:142-188) so that the step kernel streams it with
 // one coalesced load per lane instead of re-deriving it through dependent gathers every step.
 __global__ void ev2g_build_window_table_kernel(DevScn s, double *__restrict__ tab) {
-    const long long n = (long long)s.E * s.R * (s.T + 1) * 40;
+    const long long n = (long long)s.M * s.R * (s.T + 1) * 40;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(i % 40);
         const long long k = i / 40;
@@ -737,7 +804,7 @@ __global__ void ev2g_build_head_table_kernel(const double *__restrict__ price_ch
 // Per (env, step) scalars of the one-transformer fast path, interleaved so that one base pointer and three 16-byte
 // loads fetch them: {charge price, discharge price, inflexible+solar, max_power, min_power, setpoint, 0, 0}.
 __global__ void ev2g_build_step_table_kernel(DevScn s, double *__restrict__ tab) {
-    const long long n = (long long)s.E * s.T;
+    const long long n = (long long)s.M * s.T;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         double *o = tab + i * 8;
         o[0] = s.price_ch[i]; o[1] = s.price_dis[i]; o[2] = s.tr_base[i]; o[3] = s.tr_maxp[i]; o[4] = s.tr_minp[i];
@@ -771,27 +838,28 @@ __device__ __forceinline__ double wave_min(double v) {
 }
 
 // sessions [first, last) of port g have been spawned; `attached`: the last of them is still on the port
-__device__ __forceinline__ void port_sessions(const DevScn &s, const DevState &st, long long g, int cur_step, int &first,
+__device__ __forceinline__ void port_sessions(const DevScn &s, const DevState &st, long long g, long long gs, int cur_step, int &first,
                                               int &last, bool &attached) {
-    first = s.port_first[g];
+    first = s.port_first[gs];   // gs: the port in the scenario pool, g: the port in the env state
     last = first;
     attached = false;
     if (first < 0) return;
     const int2 w = st.win[g];
     const int cur = st.sc[g].x;  // attached-or-next session, -1 when the port's list is exhausted
     if (cur < 0) {
-        last = s.port_end[g];
+        last = s.port_end[gs];
     } else {
         attached = (w.x <= cur_step);  // spawned at the end of step t_arr-1
         last = attached ? cur + 1 : cur;
     }
 }
 
-__global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, const long long *__restrict__ unused,
+__global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, int scn_off,
                                                         const double *__restrict__ ss_afap, int cur_step,
                                                         double *__restrict__ out) {
     const int e = blockIdx.x, lane = threadIdx.x;
     if (e >= s.E) return;
+    const int scn = ev2g_scn(e, scn_off, s.M);
     const int T = s.T, C = s.C, R = s.R, P = s.P;
     double served = 0.0, sat = 0.0, nsat = 0.0;
     for (int c = lane; c < C; c += 64) {
@@ -803,7 +871,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, c
     double over = 0.0, te = 0.0, ete = 0.0, ptv = 0.0;
     for (int t = lane; t < T; t += 64) {
         for (int r = 0; r < R; r++) over += st.over_hist[((long long)t * s.E + e) * R + r];
-        const double sp = s.setpoint[(long long)e * T + t], u = st.usage_hist[(long long)t * s.E + e];
+        const double sp = s.setpoint[(long long)scn * T + t], u = st.usage_hist[(long long)t * s.E + e];
         const double d = sp - u;
         te += d * d;
         ete += fabs(d);
@@ -826,10 +894,10 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, c
     double vkeep[6];
     int nkeep = 0;
     for (int q = lane; q < P; q += 64) {
-        const long long g = (long long)e * P + q;
+        const long long g = (long long)e * P + q, gs = (long long)scn * P + q;
         int first, last;
         bool attached;
-        port_sessions(s, st, g, cur_step, first, last, attached);
+        port_sessions(s, st, g, gs, cur_step, first, last, attached);
         for (int k = first; k < last; k++) {
             const bool live = attached && k == last - 1;
             const double capk = live ? st.cap[g] : st.sess_final_cap[k];
@@ -922,10 +990,10 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, c
             for (int u = 0; u < 6; u++) if (u < nkeep) { const double v = vkeep[u] - mean; var += v * v; }
         } else {
             for (int q = lane; q < P; q += 64) {
-                const long long g = (long long)e * P + q;
+                const long long g = (long long)e * P + q, gs = (long long)scn * P + q;
                 int first, last;
                 bool attached;
-                port_sessions(s, st, g, cur_step, first, last, attached);
+                port_sessions(s, st, g, gs, cur_step, first, last, attached);
                 for (int k = first; k < last; k++) {
                     const double capk = (attached && k == last - 1) ? st.cap[g] : st.sess_final_cap[k];
                     const double v = capk / ss_afap[k] * 100.0 - mean;

@@ -17,8 +17,6 @@
 #include "ev2g_device.h"
 #include "ev2g_step_v2.h"
 #include "ev2g_step_wave.h"
-#include "ev2g_step_list.h"
-#include "ev2g_step_pipe.h"
 #include <cstdlib>
 
 static thread_local std::string g_create_error;
@@ -33,7 +31,9 @@ struct ev2g_handle {
     DevState st{};
     std::vector<void *> scn_allocs, st_allocs, user_allocs;
     // host mirrors for peek / stats
-    int E = 0, T = 0, C = 0, npc = 0, P = 0, R = 0, D = 0;
+    int E = 0, M = 0, T = 0, C = 0, npc = 0, P = 0, R = 0, D = 0;   // E envs stepped concurrently, M scenarios in the pool
+    long long scn_off = 0;                      // env e runs scenario (e + scn_off) mod M
+    ev2g_step_extras extras{};
     long long S = 0;
     std::vector<int> slot_port, port_slot;
     std::vector<long long> env_sess_start;      // [E+1] host order
@@ -45,9 +45,8 @@ struct ev2g_handle {
     V2P *d_v2p = nullptr;                       // device copy of the v2 kernel's parameter block
     int block = 0;                              // 256/512/1024: v2 kernel; 0: generic kernel (P > 1024)
     bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
-    bool pipe_path = false;                     // ev2g_step_pipe: wave path with dedicated battery-maths wavefronts (EV2G_KERNEL=pipe)
-    bool list_path = false;                     // ev2g_step_list: same shape, 4 <= P (work proportional to occupied ports)
-    int list_wb = 128;                          // workgroup size of the list kernel (128 or 256)
+    std::string kernel_name;                    // the step kernel ev2g_load_scenarios selected (ev2g_kernel_name)
+    std::string fallback_reason;                // why the common-shape fast path was NOT taken ("" when it was / does not apply)
     int current_step = 0;
     size_t lds_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -152,6 +151,8 @@ int ev2g_n_ports(const ev2g_handle *h) { return h ? h->P : 0; }
 int ev2g_obs_dim(const ev2g_handle *h) { return h ? h->D : 0; }
 int ev2g_n_steps(const ev2g_handle *h) { return h ? h->T : 0; }
 int ev2g_current_step(const ev2g_handle *h) { return h ? h->current_step : 0; }
+const char *ev2g_kernel_name(const ev2g_handle *h) { return (h && h->loaded) ? h->kernel_name.c_str() : ""; }
+const char *ev2g_fallback_reason(const ev2g_handle *h) { return (h && h->loaded) ? h->fallback_reason.c_str() : ""; }
 
 static const char *kStatNames[EV2G_N_STATS] = {
     "total_ev_served", "total_profits", "total_energy_charged", "total_energy_discharged",
@@ -184,22 +185,33 @@ static double afap_energy(const ev2g_scenario_batch *b, long long s, double max_
     return x;
 }
 
-int ev2g_reset(ev2g_handle *h, double *obs);
+int ev2g_reset_ex(ev2g_handle *h, double *obs, int64_t scenario_offset);
 
 int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     if (!h || !b) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: null argument");
     (void)hipSetDevice(h->device);
-    const int E = b->n_envs, T = b->n_steps, C = b->n_chargers, npc = b->ports_per_charger, R = b->n_transformers;
+    const int M = b->n_envs, T = b->n_steps, C = b->n_chargers, npc = b->ports_per_charger, R = b->n_transformers;
     const int ND = std::max(b->n_dr_max, 0);
-    if (E <= 0 || T <= 0 || C <= 0 || npc <= 0 || R <= 0 || b->timescale <= 0)
+    const int E = h->cfg.n_active_envs > 0 ? h->cfg.n_active_envs : M;   // envs stepped concurrently
+    if (E > M) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: n_active_envs exceeds the number of scenarios in the batch");
+    if (M <= 0 || T <= 0 || C <= 0 || npc <= 0 || R <= 0 || b->timescale <= 0)
         return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: non-positive size");
     if (b->horizon != 20) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: horizon must be 20 (state.py:119,129-132)");
     if (npc > 32) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: more than 32 ports per charger unsupported");
     const int P = C * npc;
-    const long long S = b->env_session_start[E];
+    const long long S = b->env_session_start[M];
     if (S != b->n_sessions || b->env_session_start[0] != 0)
         return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: env_session_start inconsistent with n_sessions");
     if (S > 0x7ffffff0LL) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: too many sessions for 32-bit indices");
+    {   // the kernels index with 32-bit ints: every element offset they form must stay below 2^31
+        const long long lim = 0x7fffffffLL, Pq = (long long)C * npc;
+        const long long Dq = 3 + 3 * Pq > 22 + 40LL * R + 2 * Pq ? 3 + 3 * Pq : 22 + 40LL * R + 2 * Pq;
+        const bool log_cs = (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) != 0;
+        if ((long long)M * Pq > lim || (long long)M * Dq > lim || (long long)M * R * (T + 1) * 40 > lim ||
+            (log_cs && (long long)T * M * std::max<long long>(C, Pq) > lim) || (long long)M * T * 8 > lim)
+            return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: batch too large for 32-bit element offsets "
+                                         "(need M*P, M*D, M*R*(T+1)*40, T*M*C < 2^31): split it over more handles / GPUs");
+    }
     for (int c = 0; c < C; c++) {
         if (b->cs_transformer[c] < 0 || b->cs_transformer[c] >= R)
             return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: cs_transformer out of range");
@@ -250,14 +262,14 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     // ---- resolve ports (first-free replay, ev_charger.py:266-286) and order sessions by (env, slot, arrival) ----
     std::vector<int> sess_port((size_t)S), host_to_dev((size_t)S);
     std::vector<long long> dev_to_host((size_t)S);
-    std::vector<int> port_first((size_t)E * P, -1);
-    std::vector<int> port_end((size_t)E * P, -1);   // one past the port's last session (device order: a port's sessions are consecutive)
-    std::vector<int2> port_first_win((size_t)E * P, make_int2(EV2G_INT_MAX, EV2G_INT_MAX));
+    std::vector<int> port_first((size_t)M * P, -1);
+    std::vector<int> port_end((size_t)M * P, -1);   // one past the port's last session (device order: a port's sessions are consecutive)
+    std::vector<int2> port_first_win((size_t)M * P, make_int2(EV2G_INT_MAX, EV2G_INT_MAX));
     {
         std::vector<int> free_at((size_t)C * npc);
         std::vector<std::pair<long long, long long>> keyed;  // (slot, host idx)
         long long d = 0;
-        for (int e = 0; e < E; e++) {
+        for (int e = 0; e < M; e++) {
             std::fill(free_at.begin(), free_at.end(), 0);
             const long long s0 = b->env_session_start[e], s1 = b->env_session_start[e + 1];
             if (s1 < s0) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: env_session_start not monotone");
@@ -330,8 +342,8 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         {
             // env of a host session: binary search in env_session_start
             const int64_t *st = b->env_session_start;
-            const int64_t *ua = std::upper_bound(st, st + E + 1, (int64_t)a);
-            const int64_t *uc = std::upper_bound(st, st + E + 1, (int64_t)c);
+            const int64_t *ua = std::upper_bound(st, st + M + 1, (int64_t)a);
+            const int64_t *uc = std::upper_bound(st, st + M + 1, (int64_t)c);
             same_env = (ua == uc);
         }
         if (same_env && sess_port[a] == sess_port[c]) {
@@ -355,8 +367,8 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         sess_afap_host[s] = afap_energy(b, s, mp);
         ss_afap[host_to_dev[s]] = sess_afap_host[s];
     }
-    std::vector<double> tr_peak((size_t)E * R);
-    for (size_t er = 0; er < (size_t)E * R; er++) {
+    std::vector<double> tr_peak((size_t)M * R);
+    for (size_t er = 0; er < (size_t)M * R; er++) {
         double m = b->tr_max_power[er * T];
         for (int t = 1; t < T; t++) m = std::max(m, b->tr_max_power[er * T + t]);
         tr_peak[er] = m;
@@ -365,33 +377,41 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     // ---- launch geometry ----
     DevScn &s = h->scn;
     s = DevScn{};
-    s.E = E; s.T = T; s.C = C; s.npc = npc; s.P = P; s.R = R; s.D = D; s.ND = std::max(ND, 1); s.dt = b->timescale;
-    s.reward_kind = h->cfg.reward_kind; s.state_kind = sk; s.flags = h->cfg.flags; s.n_lut = b->n_lut;
+    s.E = E; s.M = M; s.T = T; s.C = C; s.npc = npc; s.P = P; s.R = R; s.D = D; s.ND = std::max(ND, 1); s.dt = b->timescale;
+    s.reward_kind = h->cfg.reward_kind; s.state_kind = sk; s.flags = h->cfg.flags; s.cost_kind = h->cfg.cost_kind; s.n_lut = b->n_lut;
     // v2 kernel: one home lane per port, BLOCK >= P; the generic kernel handles larger envs
     h->block = (P <= 256) ? 256 : (P <= 512) ? 512 : (P <= 1024) ? 1024 : 0;
     const int blk = h->block ? h->block : EV2G_BLOCK;
     s.G = std::max(1, blk / P);
     s.G = std::min(s.G, E);
-    h->wave_path = (P >= 2 && P <= 64 && R == 1 && npc == 1 && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY));
-    {   // ev2g_step_wave addresses every array as base + 32-bit byte offset: all of them must stay below 4 GiB
+    // fast path (ev2g_step_wave): the common shape.  Anything else runs the general kernels; which one was chosen, and why the
+    // fast path was not, is reported by ev2g_kernel_name() / ev2g_fallback_reason() -- routing is never silent.
+    h->fallback_reason.clear();
+    if (P < 2 || P > 64) h->fallback_reason = "ports per env outside 2..64";
+    else if (R != 1) h->fallback_reason = "more than one transformer";
+    else if (npc != 1) h->fallback_reason = "multi-port chargers";
+    h->wave_path = h->fallback_reason.empty();
+    if (h->wave_path) {   // ev2g_step_wave addresses every array as base + 32-bit byte offset: all of them must stay below 4 GiB
         const unsigned long long lim = 1ull << 32;
         const unsigned long long biggest = std::max({(unsigned long long)E * P * 8, (unsigned long long)E * D * 8,
-                                                     (unsigned long long)E * (T + 1) * 60 * 8, (unsigned long long)S * sizeof(SessRec),
-                                                     (unsigned long long)E * T * 64, (unsigned long long)E * T * 8 * 3});
-        if (biggest >= lim) h->wave_path = false;
+                                                     (unsigned long long)M * (T + 1) * 60 * 8, (unsigned long long)S * sizeof(SessRec),
+                                                     (unsigned long long)M * T * 64, (unsigned long long)E * T * 8 * 3, (unsigned long long)M * P * 8,
+                                                     (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) ? (unsigned long long)T * E * C * 8 : 0ull});
+        if (biggest >= lim) { h->wave_path = false; h->fallback_reason = "an array of the batch reaches 4 GiB (32-bit byte offsets)"; }
     }
     if (h->wave_path) s.G = (EV2G_WAVE_BLOCK / 64) * (64 / P);   // wave-aligned: 64/P envs per wavefront
-    {
-        // Kernel choice for the common shape.  Default: ev2g_step_wave (fastest measured).  EV2G_KERNEL
-        // selects the alternatives that are kept and parity-tested: "list" / "list256" (attached-list kernel, work
-        // proportional to occupied ports) and "v2" (the generic port-per-lane kernel).
+    {   // EV2G_KERNEL=v2 forces the general kernel on the common shape (parity tests compare the two)
         const char *kn = std::getenv("EV2G_KERNEL");
-        h->list_path = h->wave_path && P >= 4 && kn && (std::string(kn) == "list" || std::string(kn) == "list256");
-        if (kn && std::string(kn) == "v2") { h->wave_path = h->list_path = false; s.G = std::min(std::max(1, blk / P), E); }
-        h->list_wb = (kn && std::string(kn) == "list256") ? 256 : 128;
-        if (h->list_path) s.G = (h->list_wb / 64) * (64 / P);
-        h->pipe_path = h->wave_path && !h->list_path && kn && std::string(kn) == "pipe";
-        if (h->pipe_path) s.G = EV2G_PIPE_ENVW * (64 / P);
+        if (h->wave_path && kn && std::string(kn) == "v2") {
+            h->wave_path = false; h->fallback_reason = "EV2G_KERNEL=v2"; s.G = std::min(std::max(1, blk / P), E);
+        }
+    }
+    {
+        char nm[64];
+        if (h->wave_path) std::snprintf(nm, sizeof nm, "ev2g_step_wave<%d,%d>", sk, h->cfg.reward_kind);
+        else if (h->block) std::snprintf(nm, sizeof nm, "ev2g_step_v2<%d>", h->block);
+        else std::snprintf(nm, sizeof nm, "ev2g_step_kernel");
+        h->kernel_name = nm;
     }
     {
         int gs = 4;
@@ -401,16 +421,12 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     s.n_groups = (E + s.G - 1) / s.G;
     s.sixty_over_dt = 60.0 / (double)b->timescale;
     s.dt_over_60 = (double)b->timescale / 60.0;
-    if (h->list_path)
-        h->lds_bytes = ev2g_list_lds_bytes(h->list_wb);
-    else if (h->pipe_path)
-        h->lds_bytes = ev2g_pipe_lds_bytes(s.G);
-    else if (h->wave_path)
+    if (h->wave_path)
         h->lds_bytes = ev2g_wave_lds_bytes(s.G);
     else if (h->block)
         h->lds_bytes = ev2g_v2_lds_bytes(s.G * P, s.G * R, s.G, R);
     else
-        h->lds_bytes = sizeof(double) * ((size_t)EV2G_NQ * s.G * P + (size_t)EV2G_NQ * s.G * R + (size_t)EV2G_NQ * s.G);
+        h->lds_bytes = ev2g_generic_lds_bytes(s.G, P, R, npc);
     if (h->lds_bytes > 160 * 1024)
         return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: ports per env exceed the LDS staging capacity (P <= ~2400)");
     {
@@ -419,12 +435,6 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
                          : h->block == 1024 ? (const void *)ev2g_step_v2<1024> : (const void *)ev2g_step_kernel;
         if (h->lds_bytes > 48 * 1024)
             HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-        if (h->pipe_path) {
-#define EV2G_PIPE_ATTR(SK, RK) HIPCHK(h, hipFuncSetAttribute((const void *)ev2g_step_pipe<SK, RK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-            EV2G_PIPE_ATTR(0, 0) EV2G_PIPE_ATTR(0, 1) EV2G_PIPE_ATTR(0, 2) EV2G_PIPE_ATTR(1, 0) EV2G_PIPE_ATTR(1, 1) EV2G_PIPE_ATTR(1, 2)
-            EV2G_PIPE_ATTR(2, 0) EV2G_PIPE_ATTR(2, 1) EV2G_PIPE_ATTR(2, 2)
-#undef EV2G_PIPE_ATTR
-        }
     }
     // AoS session records (one cache line each) for the v2 kernel
     std::vector<SessRec> recs((size_t)std::max<long long>(S, 1));
@@ -463,24 +473,24 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     UPP(ip, b->cs_phases, C) s.cs_ph = ip;
     UP(ip, tr_seg) s.tr_seg = ip;
     UP(ip, tr_obs) s.tr_obs = ip;
-    UPP(dp, b->charge_price, (size_t)E * T) s.price_ch = dp;
-    UPP(dp, b->discharge_price, (size_t)E * T) s.price_dis = dp;
-    UPP(dp, b->power_setpoints, (size_t)E * T) s.setpoint = dp;
-    UPP(dp, b->tr_max_power, (size_t)E * R * T) s.tr_maxp = dp;
-    UPP(dp, b->tr_min_power, (size_t)E * R * T) s.tr_minp = dp;
-    UPP(dp, b->tr_inflexible_load, (size_t)E * R * T) s.tr_infl = dp;
-    UPP(dp, b->tr_solar_power, (size_t)E * R * T) s.tr_solar = dp;
-    UPP(dp, b->tr_load_forecast, (size_t)E * R * T) s.tr_lf = dp;
-    UPP(dp, b->tr_pv_forecast, (size_t)E * R * T) s.tr_pvf = dp;
+    UPP(dp, b->charge_price, (size_t)M * T) s.price_ch = dp;
+    UPP(dp, b->discharge_price, (size_t)M * T) s.price_dis = dp;
+    UPP(dp, b->power_setpoints, (size_t)M * T) s.setpoint = dp;
+    UPP(dp, b->tr_max_power, (size_t)M * R * T) s.tr_maxp = dp;
+    UPP(dp, b->tr_min_power, (size_t)M * R * T) s.tr_minp = dp;
+    UPP(dp, b->tr_inflexible_load, (size_t)M * R * T) s.tr_infl = dp;
+    UPP(dp, b->tr_solar_power, (size_t)M * R * T) s.tr_solar = dp;
+    UPP(dp, b->tr_load_forecast, (size_t)M * R * T) s.tr_lf = dp;
+    UPP(dp, b->tr_pv_forecast, (size_t)M * R * T) s.tr_pvf = dp;
     UP(dp, tr_peak) s.tr_peak = dp;
     {
-        std::vector<double> tr_base((size_t)E * R * T);
+        std::vector<double> tr_base((size_t)M * R * T);
         for (size_t i = 0; i < tr_base.size(); i++) tr_base[i] = b->tr_inflexible_load[i] + b->tr_solar_power[i];
         UP(dp, tr_base) s.tr_base = dp;
     }
-    UPP(dp, b->tr_dr, (size_t)E * R * ND * 3) s.tr_dr = dp;
-    UPP(ip, b->tr_n_dr, (size_t)E * R) s.tr_ndr = ip;
-    UPP(ip, b->tr_steps_ahead, (size_t)E * R) s.tr_ahead = ip;
+    UPP(dp, b->tr_dr, (size_t)M * R * ND * 3) s.tr_dr = dp;
+    UPP(ip, b->tr_n_dr, (size_t)M * R) s.tr_ndr = ip;
+    UPP(ip, b->tr_steps_ahead, (size_t)M * R) s.tr_ahead = ip;
     UP(ip, ss_tarr) s.ss_tarr = ip;
     UP(ip, ss_tdep) s.ss_tdep = ip;
     UP(ip, ss_ntarr) s.ss_ntarr = ip;
@@ -516,7 +526,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     s.win_tab = nullptr;
     if (sk == EV2G_STATE_V2G_PROFIT_MAX_LOADS && h->block) {
         double *tab = nullptr;
-        const size_t n = (size_t)E * R * (T + 1) * 40;
+        const size_t n = (size_t)M * R * (T + 1) * 40;
         HIPCHK(h, hipMalloc((void **)&tab, n * sizeof(double)));
         pool.push_back(tab);
         const int nb = (int)std::min<size_t>((n + 255) / 256, 4096);
@@ -525,22 +535,22 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         s.win_tab = tab;
     }
     double *d_step_tab = nullptr;
-    if (h->wave_path || h->list_path) {   // R == 1: [E,T] series interleaved per (env, step)
-        const size_t n = (size_t)E * T * 8;
+    if (h->wave_path) {   // R == 1: [M,T] series interleaved per (env, step)
+        const size_t n = (size_t)M * T * 8;
         HIPCHK(h, hipMalloc((void **)&d_step_tab, n * sizeof(double)));
         pool.push_back(d_step_tab);
-        const int nb = (int)std::min<size_t>(((size_t)E * T + 255) / 256, 4096);
+        const int nb = (int)std::min<size_t>(((size_t)M * T + 255) / 256, 4096);
         hipLaunchKernelGGL(ev2g_build_step_table_kernel, dim3(nb), dim3(256), 0, h->stream, s, d_step_tab);
         HIPCHK(h, hipGetLastError());
     }
     double *d_head_tab = nullptr;
-    if ((h->wave_path || h->list_path) && sk != EV2G_STATE_PUBLIC_PST) {
+    if (h->wave_path && sk != EV2G_STATE_PUBLIC_PST) {
         const int NH = (sk == EV2G_STATE_V2G_PROFIT_MAX_LOADS) ? 60 : 20;
-        const size_t n = (size_t)E * (T + 1) * NH;
+        const size_t n = (size_t)M * (T + 1) * NH;
         HIPCHK(h, hipMalloc((void **)&d_head_tab, n * sizeof(double)));
         pool.push_back(d_head_tab);
         const int nb = (int)std::min<size_t>((n + 255) / 256, 4096);
-        hipLaunchKernelGGL(ev2g_build_head_table_kernel, dim3(nb), dim3(256), 0, h->stream, s.price_ch, s.win_tab, E, T, NH, d_head_tab);
+        hipLaunchKernelGGL(ev2g_build_head_table_kernel, dim3(nb), dim3(256), 0, h->stream, s.price_ch, s.win_tab, M, T, NH, d_head_tab);
         HIPCHK(h, hipGetLastError());
     }
     // ---- state ----
@@ -574,7 +584,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     AL(tr_power_now, (size_t)E * R)
     if (h->cfg.flags & EV2G_FLAG_LOG_SOC) { AL(soc_log, (size_t)T * EP) st.sess_abs_e = st.slab_sess + (size_t)std::max<long long>(S, 1); }
 #ifdef EV2G_PHASE_TIMING
-    AL(dbg, (size_t)s.n_groups * 8)
+    AL(dbg, (size_t)s.n_groups * 18)
 #endif
 #undef AL
     {
@@ -589,87 +599,102 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
 
-    h->E = E; h->T = T; h->C = C; h->npc = npc; h->P = P; h->R = R; h->D = D; h->S = S;
+    h->E = E; h->M = M; h->scn_off = 0; h->T = T; h->C = C; h->npc = npc; h->P = P; h->R = R; h->D = D; h->S = S;
     h->slot_port = slot_port;
     h->port_slot = port_slot;
-    h->env_sess_start.assign(b->env_session_start, b->env_session_start + E + 1);
+    h->env_sess_start.assign(b->env_session_start, b->env_session_start + M + 1);
     h->host_to_dev = host_to_dev;
     h->sess_port = sess_port;
     h->sess_afap = sess_afap_host;
     h->loaded = true;
-    return ev2g_reset(h, nullptr);
+    if (h->extras.cost || h->extras.obs_f32 || h->extras.actions_f32) {
+        const ev2g_step_extras keep = h->extras;
+        if ((rc = ev2g_set_step_extras(h, &keep))) return rc;
+    }
+    return ev2g_reset_ex(h, nullptr, 0);
 }
 
-int ev2g_reset(ev2g_handle *h, double *obs) {
+int ev2g_reset_ex(ev2g_handle *h, double *obs, int64_t scenario_offset) {
     if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_reset: no scenarios loaded");
     (void)hipSetDevice(h->device);
     const DevScn &s = h->scn;
+    long long off = scenario_offset % (long long)s.M;
+    if (off < 0) off += s.M;
+    h->scn_off = off;
     // (the usage | potential | overload history slab is cleared by the reset kernel itself)
     if (h->st.cs_power_hist) {
         HIPCHK(h, hipMemsetAsync(h->st.cs_power_hist, 0, sizeof(double) * (size_t)s.T * s.E * s.C, h->stream));
         HIPCHK(h, hipMemsetAsync(h->st.cs_cur_hist, 0, sizeof(double) * (size_t)s.T * s.E * s.C, h->stream));
     }
-    hipLaunchKernelGGL(ev2g_reset_kernel, dim3(s.n_groups), dim3(EV2G_BLOCK), 0, h->stream, s, h->st, obs);
+    hipLaunchKernelGGL(ev2g_reset_kernel, dim3(s.n_groups), dim3(EV2G_BLOCK), 0, h->stream, s, h->st, obs, h->extras.obs_f32, (int)off);
     HIPCHK(h, hipGetLastError());
     h->current_step = 0;
     return EV2G_OK;
 }
 
+int ev2g_reset(ev2g_handle *h, double *obs) { return ev2g_reset_ex(h, obs, h ? h->scn_off : 0); }
+int64_t ev2g_scenario_offset(const ev2g_handle *h) { return h ? h->scn_off : 0; }
+int ev2g_n_scenarios(const ev2g_handle *h) { return h ? h->M : 0; }
+
+int ev2g_set_step_extras(ev2g_handle *h, const ev2g_step_extras *x) {
+    if (!h) return EV2G_ERR_ARG;
+    if (x && x->cost && h->cfg.cost_kind == EV2G_COST_NONE)
+        return fail(h, EV2G_ERR_ARG, "ev2g_set_step_extras: a cost buffer needs ev2g_config.cost_kind != EV2G_COST_NONE");
+    h->extras = x ? *x : ev2g_step_extras{};
+    if (h->loaded && h->d_v2p) {   // refresh the extras inside the device-resident parameter block (stream-ordered)
+        (void)hipSetDevice(h->device);
+        struct { void *cost; long long cs; void *o32; long long os; const void *a32; } blk{
+            h->extras.cost, h->extras.cost_step_stride, h->extras.obs_f32, h->extras.obs_f32_step_stride, h->extras.actions_f32};
+        static_assert(sizeof(blk) == sizeof(V2P) - offsetof(V2P, x_cost), "StepExtras block is the tail of V2P");
+        HIPCHK(h, hipMemcpyAsync((char *)h->d_v2p + offsetof(V2P, x_cost), &blk, sizeof blk, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // `blk` is a stack temporary
+    }
+    return EV2G_OK;
+}
+
+// StepIO of one call: the caller's buffers plus the scenario-pool window; step0 offsets the sticky extras' step strides
+static StepIO make_io(const ev2g_handle *h, const double *actions, long long a_stride, double *obs, long long o_stride,
+                      double *reward, long long r_stride, uint8_t *done, long long d_stride, uint8_t *mask, long long m_stride,
+                      long long step0, int auto_reset) {
+    StepIO io{};
+    io.actions = actions; io.a_stride = a_stride;
+    io.obs = obs; io.o_stride = o_stride;
+    io.reward = reward; io.r_stride = r_stride;
+    io.done = done; io.d_stride = d_stride;
+    io.mask = mask; io.m_stride = m_stride;
+    io.scn_off = (int)h->scn_off;
+    io.scn_stride = (auto_reset == EV2G_AUTO_RESET_NEXT) ? h->E % h->M : 0;
+    io.step0 = (int)step0;
+    return io;
+}
+
 static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int auto_reset) {
     const DevScn &s = h->scn;
-    if (h->list_path) {
-        const V2P *pp = (const V2P *)h->d_v2p;
-#define EV2G_LIST_CASE(SK, RK)                                                                                        \
-    case SK * 3 + RK:                                                                                                 \
-        if (h->list_wb == 128)                                                                                        \
-            hipLaunchKernelGGL((ev2g_step_list<SK, RK, 128>), dim3(s.n_groups), dim3(128), h->lds_bytes, h->stream,   \
-                               pp, io, t0, k, auto_reset);                                                            \
-        else                                                                                                          \
-            hipLaunchKernelGGL((ev2g_step_list<SK, RK, 256>), dim3(s.n_groups), dim3(256), h->lds_bytes, h->stream,   \
-                               pp, io, t0, k, auto_reset);                                                            \
-        break;
-        switch (s.state_kind * 3 + s.reward_kind) {
-            EV2G_LIST_CASE(0, 0) EV2G_LIST_CASE(0, 1) EV2G_LIST_CASE(0, 2)
-            EV2G_LIST_CASE(1, 0) EV2G_LIST_CASE(1, 1) EV2G_LIST_CASE(1, 2)
-            EV2G_LIST_CASE(2, 0) EV2G_LIST_CASE(2, 1) EV2G_LIST_CASE(2, 2)
-        }
-#undef EV2G_LIST_CASE
-        HIPCHK(h, hipGetLastError());
-        return EV2G_OK;
-    }
-    if (h->pipe_path) {
-        const V2P *pp = (const V2P *)h->d_v2p;
-        const DevState &st = h->st;
-        const WaveArgs wa{s.P, s.T, s.E, s.D, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
-                          st.env_acc, s.cs_imax, s.cs_dmax_abs, s.cs_imin, s.cs_dmin, s.cs_maxp, s.cs_minp};
-#define EV2G_PIPE_CASE(SK, RK)                                                                                         \
-    case SK * 3 + RK:                                                                                                  \
-        hipLaunchKernelGGL((ev2g_step_pipe<SK, RK>), dim3(s.n_groups), dim3(EV2G_PIPE_BLOCK), h->lds_bytes, h->stream, \
-                           pp, io, t0, k, auto_reset, wa);                                                             \
-        break;
-        switch (s.state_kind * 3 + s.reward_kind) {
-            EV2G_PIPE_CASE(0, 0) EV2G_PIPE_CASE(0, 1) EV2G_PIPE_CASE(0, 2)
-            EV2G_PIPE_CASE(1, 0) EV2G_PIPE_CASE(1, 1) EV2G_PIPE_CASE(1, 2)
-            EV2G_PIPE_CASE(2, 0) EV2G_PIPE_CASE(2, 1) EV2G_PIPE_CASE(2, 2)
-        }
-#undef EV2G_PIPE_CASE
-        HIPCHK(h, hipGetLastError());
-        return EV2G_OK;
-    }
     if (h->wave_path) {
         const V2P *pp = (const V2P *)h->d_v2p;
         const DevState &st = h->st;
-        const WaveArgs wa{s.P, s.T, s.E, s.D, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
+        const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
                           st.env_acc, s.cs_imax, s.cs_dmax_abs, s.cs_imin, s.cs_dmin, s.cs_maxp, s.cs_minp};
-#define EV2G_WAVE_CASE(SK, RK)                                                                                         \
-    case SK * 3 + RK:                                                                                                  \
-        hipLaunchKernelGGL((ev2g_step_wave<SK, RK>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, \
-                           pp, io, t0, k, auto_reset, wa);                                                             \
+#define EV2G_WAVE_CASE(SK, RK)                                                                                              \
+    case SK * 3 + RK:                                                                                                       \
+        if (!io.actions)                                                                                                    \
+            hipLaunchKernelGGL((ev2g_step_wave<SK, RK, true>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes,       \
+                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
+        else                                                                                                                \
+            hipLaunchKernelGGL((ev2g_step_wave<SK, RK, false>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes,      \
+                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
         break;
         switch (s.state_kind * 3 + s.reward_kind) {
+#ifdef EV2G_ONLY_00   /* tuning builds (tools/): one specialisation, seconds to compile */
+            case 0:
+                hipLaunchKernelGGL((ev2g_step_wave<0, 0, false>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
+                break;
+            default: return fail(h, EV2G_ERR_ARG, "EV2G_ONLY_00 build: only the cfg2 specialisation exists");
+#else
             EV2G_WAVE_CASE(0, 0) EV2G_WAVE_CASE(0, 1) EV2G_WAVE_CASE(0, 2)
             EV2G_WAVE_CASE(1, 0) EV2G_WAVE_CASE(1, 1) EV2G_WAVE_CASE(1, 2)
             EV2G_WAVE_CASE(2, 0) EV2G_WAVE_CASE(2, 1) EV2G_WAVE_CASE(2, 2)
+#endif
         }
 #undef EV2G_WAVE_CASE
         HIPCHK(h, hipGetLastError());
@@ -686,7 +711,9 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         hipLaunchKernelGGL(ev2g_step_v2<1024>, dim3(s.n_groups), dim3(1024), h->lds_bytes, h->stream, (const V2P *)h->d_v2p, io, t0, k, auto_reset);
         break;
     default:
-        hipLaunchKernelGGL(ev2g_step_kernel, dim3(s.n_groups), dim3(EV2G_BLOCK), h->lds_bytes, h->stream, s, h->st, io, t0, k, auto_reset);
+        hipLaunchKernelGGL(ev2g_step_kernel, dim3(s.n_groups), dim3(EV2G_BLOCK), h->lds_bytes, h->stream, s, h->st, io,
+                           StepExtras{h->extras.cost, h->extras.cost_step_stride, h->extras.obs_f32, h->extras.obs_f32_step_stride, h->extras.actions_f32},
+                           t0, k, auto_reset);
     }
     HIPCHK(h, hipGetLastError());
     return EV2G_OK;
@@ -694,11 +721,11 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
 
 int ev2g_step(ev2g_handle *h, const double *actions, double *obs, double *reward, uint8_t *done, uint8_t *action_mask) {
     if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_step: no scenarios loaded");
-    if (!actions) return fail(h, EV2G_ERR_ARG, "ev2g_step: actions is null");
+    if (!actions && !h->extras.actions_f32) return fail(h, EV2G_ERR_ARG, "ev2g_step: actions is null (and no float32 actions are set)");
     if (h->current_step >= h->T)
         return fail(h, EV2G_ERR_DONE, "ev2g_step: episode is done, reset the environment (ev2gym_env.py:343)");
     (void)hipSetDevice(h->device);
-    StepIO io{actions, 0, obs, 0, reward, 0, done, 0, action_mask, 0};
+    const StepIO io = make_io(h, actions, 0, obs, 0, reward, 0, done, 0, action_mask, 0, 0, 0);
     int rc = launch_steps(h, io, h->current_step, 1, 0);
     if (rc) return rc;
     h->current_step += 1;
@@ -710,20 +737,21 @@ int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, in
                 int64_t o_stride, double *reward, int64_t r_stride, uint8_t *done, int64_t d_stride, uint8_t *mask,
                 int64_t m_stride, int auto_reset) {
     if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_step_n: no scenarios loaded");
-    if (!actions || k_steps < 0) return fail(h, EV2G_ERR_ARG, "ev2g_step_n: bad arguments");
+    if ((!actions && !h->extras.actions_f32) || k_steps < 0) return fail(h, EV2G_ERR_ARG, "ev2g_step_n: bad arguments");
     (void)hipSetDevice(h->device);
     int rc = EV2G_OK;
+    const long long adv = (auto_reset == EV2G_AUTO_RESET_NEXT) ? h->E % h->M : 0;   // pool offset advance per in-run reset
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (mode == EV2G_STEPN_PERSISTENT) {
         int k = k_steps;
         if (!auto_reset) k = std::min(k, h->T - h->current_step);
-        StepIO io{actions, a_stride, obs, o_stride, reward, r_stride, done, d_stride, mask, m_stride};
+        const StepIO io = make_io(h, actions, a_stride, obs, o_stride, reward, r_stride, done, d_stride, mask, m_stride, 0, auto_reset);
         if (k > 0) rc = launch_steps(h, io, h->current_step, k, auto_reset);
         if (rc) return rc;
         if (auto_reset) {
             // replay the step counter on the host: reset happens lazily before the step that follows a terminal one
             int t = h->current_step;
-            for (int i = 0; i < k; i++) { if (t >= h->T) t = 0; t++; }
+            for (int i = 0; i < k; i++) { if (t >= h->T) { t = 0; h->scn_off = (h->scn_off + adv) % h->M; } t++; }
             h->current_step = t;
         } else {
             h->current_step += k;
@@ -733,14 +761,14 @@ int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, in
         for (int i = 0; i < k_steps; i++) {
             if (h->current_step >= h->T) {
                 if (!auto_reset) { rc = fail(h, EV2G_ERR_DONE, "ev2g_step_n: episode finished before k_steps (auto_reset off)"); break; }
-                int r2 = ev2g_reset(h, nullptr);
+                int r2 = ev2g_reset_ex(h, nullptr, h->scn_off + adv);
                 if (r2) return r2;
             }
-            StepIO io{actions + (long long)i * a_stride, 0,
-                      obs ? obs + (long long)i * o_stride : nullptr, 0,
-                      reward ? reward + (long long)i * r_stride : nullptr, 0,
-                      done ? done + (long long)i * d_stride : nullptr, 0,
-                      mask ? mask + (long long)i * m_stride : nullptr, 0};
+            const StepIO io = make_io(h, actions ? actions + (long long)i * a_stride : nullptr, a_stride,   // (float32 actions: the kernel applies step0 * a_stride)
+                                      obs ? obs + (long long)i * o_stride : nullptr, 0,
+                                      reward ? reward + (long long)i * r_stride : nullptr, 0,
+                                      done ? done + (long long)i * d_stride : nullptr, 0,
+                                      mask ? mask + (long long)i * m_stride : nullptr, 0, i, 0);
             int r2 = launch_steps(h, io, h->current_step, 1, 0);
             if (r2) return r2;
             h->current_step += 1;
@@ -777,7 +805,7 @@ int ev2g_get_stats(ev2g_handle *h, double *stats) {
     if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_get_stats: no scenarios loaded");
     if (!stats) return fail(h, EV2G_ERR_ARG, "ev2g_get_stats: null output");
     (void)hipSetDevice(h->device);
-    hipLaunchKernelGGL(ev2g_stats_kernel, dim3(h->E), dim3(64), 0, h->stream, h->scn, h->st, (const long long *)nullptr,
+    hipLaunchKernelGGL(ev2g_stats_kernel, dim3(h->E), dim3(64), 0, h->stream, h->scn, h->st, (int)h->scn_off,
                        (const double *)h->d_ss_afap, h->current_step, stats);
     HIPCHK(h, hipGetLastError());
     return EV2G_OK;
@@ -824,7 +852,8 @@ int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *v) {
     const int t = h->current_step;
     v->current_step = t;
     v->n_ports = P; v->n_chargers = C; v->n_transformers = R; v->n_steps = T;
-    const long long s0 = h->env_sess_start[env], s1 = h->env_sess_start[env + 1];
+    const long long scn = ((long long)env + h->scn_off) % h->M;   // the scenario this env is running
+    const long long s0 = h->env_sess_start[scn], s1 = h->env_sess_start[scn + 1];
     std::vector<int> dev_to_local;  // device idx -> env-local host idx
     if (v->port_session) {
         // inverse map restricted to this env
@@ -879,10 +908,10 @@ int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *v) {
 }
 
 #ifdef EV2G_PHASE_TIMING
-int ev2g_debug_phase_ticks(ev2g_handle *h, unsigned long long *out8) {
-    std::vector<unsigned long long> v((size_t)h->scn.n_groups * 8);
+int ev2g_debug_phase_ticks(ev2g_handle *h, unsigned long long *out18) {
+    std::vector<unsigned long long> v((size_t)h->scn.n_groups * 18);
     HIPCHK(h, hipMemcpy(v.data(), h->st.dbg, v.size() * 8, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; i++) { out8[i] = 0; for (int b = 0; b < h->scn.n_groups; b++) out8[i] += v[(size_t)b * 8 + i]; }
+    for (int i = 0; i < 18; i++) { out18[i] = 0; for (int b = 0; b < h->scn.n_groups; b++) out18[i] += v[(size_t)b * 18 + i]; }
     HIPCHK(h, hipMemset(h->st.dbg, 0, v.size() * 8));
     return 0;
 }

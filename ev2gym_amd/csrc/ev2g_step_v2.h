@@ -24,16 +24,21 @@
 // Optional per-phase cycle accounting (tools/phase_timing.py builds a private .so with -DEV2G_PHASE_TIMING;
 // the product library never has it).  dbg[block][phase] accumulates s_memtime ticks seen by wave 0 lane 0.
 #ifdef EV2G_PHASE_TIMING
-#define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(); unsigned long long pt_acc[8] = {0,0,0,0,0,0,0,0};
-#define PT_MARK(i) { unsigned long long n_ = __builtin_readcyclecounter(); pt_acc[i] += n_ - pt_last; pt_last = n_; }
-#define PT_FLUSH if (threadIdx.x == 0 && S->dbg) { for (int i_ = 0; i_ < 8; i_++) S->dbg[(size_t)blockIdx.x * 8 + i_] += pt_acc[i_]; }
+// slots 0..7: steps in which the workgroup had battery-maths items; 8..15: steps without any (empty nights, idle EVs);
+// slot 16 / 17: number of such workgroup-steps
+#define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(); unsigned long long pt_acc[18] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long pt_cur[8] = {0,0,0,0,0,0,0,0};
+#define PT_MARK(i) { unsigned long long n_ = __builtin_readcyclecounter(); pt_cur[i] += n_ - pt_last; pt_last = n_; }
+#define PT_STEP_END(empty) { const int o_ = (empty) ? 8 : 0; for (int i_ = 0; i_ < 8; i_++) { pt_acc[o_ + i_] += pt_cur[i_]; pt_cur[i_] = 0; } pt_acc[16 + ((empty) ? 1 : 0)] += 1; }
+#define PT_FLUSH if (threadIdx.x == 0 && S->dbg) { for (int i_ = 0; i_ < 8; i_++) pt_acc[i_] += pt_cur[i_]; for (int i_ = 0; i_ < 18; i_++) S->dbg[(size_t)blockIdx.x * 18 + i_] += pt_acc[i_]; }
 #elif defined(EV2G_PHASE_MARKERS)   /* ISA analysis only: phase boundaries as comments in the -S output */
 #define PT_DECL
 #define PT_MARK(i) asm volatile("; PHASE_MARK " #i);
+#define PT_STEP_END(empty)
 #define PT_FLUSH
 #else
 #define PT_DECL
 #define PT_MARK(i)
+#define PT_STEP_END(empty)
 #define PT_FLUSH
 #endif
 
@@ -139,7 +144,7 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, double lutv, double a
 // as by-value kernel arguments made LLVM hoist all of them above the loop and spill >200 SGPRs to VGPR lanes,
 // which was 40 % of the VALU instruction stream.
 struct V2P {
-    int E, T, C, npc, P, R, D, G, dt, reward_kind, state_kind, n_lut, pow2_dt;
+    int E, M, T, C, npc, P, R, D, G, dt, reward_kind, state_kind, cost_kind, n_lut, pow2_dt;
     double sixty_over_dt, dt_over_60;
     EV2G_GP(const int) slot_cs; EV2G_GP(const int) slot_port; EV2G_GP(const int) slot_obs;
     EV2G_GP(const int) tr_seg; EV2G_GP(const int) tr_obs; EV2G_GP(const int) port_first;
@@ -164,12 +169,18 @@ struct V2P {
     EV2G_GP(double) sess_final_cap; EV2G_GP(double) port_energy; EV2G_GP(double) port_current; EV2G_GP(int) port_lut;
     EV2G_GP(double) soc_log; EV2G_GP(double) abs_e; EV2G_GP(double) sess_abs_e;
     EV2G_GP(unsigned long long) dbg;
+    // StepExtras (ev2g_set_step_extras), refreshed in place when they change
+    EV2G_GP(double) x_cost; long long x_c_stride;
+    EV2G_GP(float) x_obs32; long long x_o32_stride;
+    EV2G_GP(const float) x_act32;
 };
 
 inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
-    p.E = s.E; p.T = s.T; p.C = s.C; p.npc = s.npc; p.P = s.P; p.R = s.R; p.D = s.D; p.G = s.G; p.dt = s.dt;
+    p.E = s.E; p.M = s.M; p.cost_kind = s.cost_kind; p.T = s.T; p.C = s.C; p.npc = s.npc; p.P = s.P; p.R = s.R; p.D = s.D; p.G = s.G; p.dt = s.dt;
     p.reward_kind = s.reward_kind; p.state_kind = s.state_kind; p.n_lut = s.n_lut;
     p.sixty_over_dt = s.sixty_over_dt; p.dt_over_60 = s.dt_over_60;
+    EV2G_SETP(p.x_cost, (double *)nullptr); EV2G_SETP(p.x_obs32, (float *)nullptr); EV2G_SETP(p.x_act32, (const float *)nullptr);
+    p.x_c_stride = 0; p.x_o32_stride = 0;
     p.pow2_dt = 0; EV2G_SETP(p.head_tab, (const double *)nullptr);
     EV2G_SETP(p.step_tab, (const double *)nullptr);
     EV2G_SETP(p.slab_port, st.slab_port); p.slab_port_slice = st.slab_port_slice;
@@ -203,7 +214,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     extern __shared__ double lds[];
     typedef const V2P __attribute__((address_space(4))) *ParamPtr;  // constant address space: scalar loads
     ParamPtr S = (ParamPtr)(unsigned long long)params;
-    const int P = S->P, R = S->R, T = S->T, C = S->C, npc = S->npc, E = S->E, D = S->D, G = S->G;
+    const int P = S->P, R = S->R, T = S->T, C = S->C, npc = S->npc, E = S->E, D = S->D, G = S->G, M = S->M;
+    int off = io.scn_off;   // scenario-pool window: env e runs scenario (e + off) mod M
     int grp;
     {   // XCD-aware mapping: workgroup b runs on XCD b % 8; give each XCD a contiguous range of env groups
         const int nb = gridDim.x, b = blockIdx.x, per = nb >> 3;
@@ -269,7 +281,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     for (int i = tid; i < R; i += BLOCK) trobs[i] = S->tr_obs[i];
     for (int i = tid; i < ne * 5; i += BLOCK) eacc[i] = 0.0;
     for (int i = tid; i < ne; i += BLOCK) pot_prev[i] = (t < T) ? S->pot_hist[t * E + e0 + i] : 0.0;
-    double a_next = io.actions[valid ? e * P + pref : e0 * P];
+    const float *act32 = (const float *)S->x_act32;   // float32 actions (StepExtras), used when io.actions is null
+    const long long a_base = io.actions ? 0 : (long long)io.step0 * io.a_stride;
+    double a_next = ev2g_action(io, act32, a_base, valid ? e * P + pref : e0 * P);
     __syncthreads();
 
     PT_DECL
@@ -283,9 +297,11 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
         asm volatile("" : "+v"(tid_l), "+v"(g_l), "+v"(e_l), "+v"(cs_l), "+v"(pref_l), "+v"(ocol_l), "+v"(pe_l), "+v"(pl_l), "+v"(pel_l));
         if (t >= T) {  // episode finished inside a fused run: in-kernel ev2g_reset for this workgroup
             if (!auto_reset) break;
+            off = ev2g_scn(off, io.scn_stride, M);
             if (valid) {
-                const int2 w = S->port_first_win[g_l];
-                s_ta[tid_l] = w.x; s_td[tid_l] = w.y; s_ss[tid_l] = S->port_first[g_l]; s_cyc[tid_l] = 0;
+                const int gs = ev2g_scn(e_l, off, M) * P + (g_l - e_l * P);
+                const int2 w = S->port_first_win[gs];
+                s_ta[tid_l] = w.x; s_td[tid_l] = w.y; s_ss[tid_l] = S->port_first[gs]; s_cyc[tid_l] = 0;
                 s_cap[tid_l] = 0.0; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_abse[tid_l] = 0.0; s_dirty[tid_l] = 3;
                 S->port_energy[g_l] = 0.0;
                 S->port_current[g_l] = 0.0;
@@ -303,6 +319,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             lds_barrier();
         }
         double *__restrict__ obs = io.obs ? io.obs + (long long)kk * io.o_stride : nullptr;
+        float *__restrict__ obs32 = S->x_obs32 ? (float *)S->x_obs32 + (long long)(io.step0 + kk) * S->x_o32_stride : nullptr;
         uint8_t *__restrict__ mask = io.mask ? io.mask + (long long)kk * io.m_stride : nullptr;
         const int sstep = t + 1;
         const bool last_step = (kk == k_steps - 1) || (sstep >= T && !auto_reset);
@@ -319,12 +336,12 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 if (a > 1.0) a = a / a;
                 else if (a < -1.0) a = -a / a;
             } else {
-                const double *__restrict__ actions = io.actions + (long long)kk * io.a_stride;
+                const long long a_off = a_base + (long long)kk * io.a_stride;
                 const int j0 = tid_l - (pref_l - cs_l * npc);
                 double Ssum = 0.0;
                 for (int j = 0; j < npc; j++) {  // sequential python sum() over the charger's ports
                     const bool oj = (s_ta[j0 + j] <= t) && (t <= s_td[j0 + j]);
-                    Ssum = Ssum + (oj ? actions[e_l * P + cs_l * npc + j] : 0.0);
+                    Ssum = Ssum + (oj ? ev2g_action(io, act32, a_off, e_l * P + cs_l * npc + j) : 0.0);
                 }
                 if (Ssum > 1.0) a = a / Ssum;
                 else if (Ssum < -1.0) a = -a / Ssum;
@@ -349,16 +366,17 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
         //      phase A never waits on them; the loads stay in flight across the LDS-only barriers) ----
         {
             const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
-            a_next = (io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride)[valid ? e_l * P + pref_l : e0 * P];
+            a_next = ev2g_action(io, act32, a_base + (long long)(more ? kk + 1 : kk) * io.a_stride, valid ? e_l * P + pref_l : e0 * P);
         }
         // Every prefetch is ONE unconditional load from a clamped (always valid) address; the conditions are applied where
         // the value is consumed.  A load in a divergent branch whose result merges with a default makes the compiler
         // serialise on the destination register (write-after-write) with a full vmcnt(0) drain.
-        const int erT = (e0 * R + min(tid_l, ne * R - 1)) * T + t;
+        const int trl = min(tid_l, ne * R - 1), trl_e = trl / R;   // this lane's (env, transformer) role
+        const int erT = (ev2g_scn(e0 + trl_e, off, M) * R + (trl - trl_e * R)) * T + t;
         const double pf_infl = S->tr_infl[erT], pf_solar = S->tr_solar[erT], pf_maxp = S->tr_maxp[erT], pf_minp = S->tr_minp[erT];
-        const int pec = e0 + min(pel_l, ne - 1);       // clamped env of this lane's env-level role
+        const int pec = ev2g_scn(e0 + min(pel_l, ne - 1), off, M);   // scenario of the (clamped) env of this lane's env-level role
         const double pf_sp = S->setpoint[pec * T + t];
-        const int evc = valid ? e_l : e0;              // clamped env of this lane's home role
+        const int evc = ev2g_scn(valid ? e_l : e0, off, M);   // scenario of the (clamped) env of this lane's home role
         const double pf_pch = S->price_ch[evc * T + t], pf_pdis = S->price_dis[evc * T + t];
         // head / window columns of the observation this step emits (step counter sstep): one coalesced load per lane
         double pf_ob0 = 0.0, pf_ob1 = 0.0;
@@ -450,7 +468,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                     const SessRec &r = *(const SessRec *)(S->rec + ss);
                     const double des = r.des;
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
-                    if (S->reward_kind != 1) satpen = 100.0 * exp(-10.0 * score);
+                    if (S->reward_kind != 1 || S->cost_kind == 1) satpen = 100.0 * exp(-10.0 * score);
                     const int gc = e_l * C + cs_l;
                     // fire-and-forget device atomics (no returned value => no memory round trip on this path)
                     __hip_atomic_fetch_add(&S->cs_served[gc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -493,6 +511,12 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 o[0] = o0;
                 o[1] = o1;
                 if (S->state_kind == 1) o[2] = o2;
+            }
+            if (obs32) {
+                float *o = obs32 + (e_l * D + ocol_l);
+                o[0] = (float)o0;
+                o[1] = (float)o1;
+                if (S->state_kind == 1) o[2] = (float)o2;
             }
             stage[1 * NS + tid_l] = profit;
             stage[2 * NS + tid_l] = satpen;
@@ -626,32 +650,38 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 acc[4] += es[6 * esn + pel_l];
                 if (io.reward) io.reward[(long long)kk * io.r_stride + pe_l] = reward;
                 if (io.done) io.done[(long long)kk * io.d_stride + pe_l] = (sstep >= T) ? 1 : 0;
+                if (S->x_cost)   // cost_function (rl_agent/cost.py:8-27)
+                    S->x_cost[(long long)(io.step0 + kk) * S->x_c_stride + pe_l] = (S->cost_kind == 2) ? costs : over_sum + es[2 * esn + pel_l];
                 if (sstep >= T || last_step) {  // flush the episode accumulators (get_statistics reads them)
                     auto ga = S->env_acc + pe_l * 8;
                     for (int i = 0; i < 5; i++) { ga[i] += acc[i]; acc[i] = 0.0; }
                 }
             }
-            if (obs) {
-                double *o = obs + pe_l * D;
+            if (obs || obs32) {
+                double *o = obs ? obs + pe_l * D : nullptr;
+                float *o32 = obs32 ? obs32 + pe_l * D : nullptr;
+#define EV2G_OBS_PUT(col, val) { const double v_ = (val); if (o) o[col] = v_; if (o32) o32[col] = (float)v_; }
                 if (S->state_kind == 1) {  // PublicPST state.py:6-35
-                    if (pl_l == 0) { o[0] = (double)sstep / (double)T; o[1] = (sstep < T) ? pf_ob0 : 0.0; o[2] = usage; }
+                    if (pl_l == 0) { EV2G_OBS_PUT(0, (double)sstep / (double)T) EV2G_OBS_PUT(1, (sstep < T) ? pf_ob0 : 0.0) EV2G_OBS_PUT(2, usage) }
                 } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135
-                    if (pl_l == 0) { o[0] = (double)sstep; o[1] = usage; }
+                    if (pl_l == 0) { EV2G_OBS_PUT(0, (double)sstep) EV2G_OBS_PUT(1, usage) }
                     int c = pl_l;
-                    if (c < 20) o[2 + c] = (sstep + c < T) ? fabs(pf_ob0) : 0.0;
-                    else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; o[trobs[r] + j] = pf_ob0; }
+                    if (c < 20) EV2G_OBS_PUT(2 + c, (sstep + c < T) ? fabs(pf_ob0) : 0.0)
+                    else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; EV2G_OBS_PUT(trobs[r] + j, pf_ob0) }
                     c = pl_l + lpe;
-                    if (c < 20) o[2 + c] = (sstep + c < T) ? fabs(pf_ob1) : 0.0;
-                    else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; o[trobs[r] + j] = pf_ob1; }
+                    if (c < 20) EV2G_OBS_PUT(2 + c, (sstep + c < T) ? fabs(pf_ob1) : 0.0)
+                    else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; EV2G_OBS_PUT(trobs[r] + j, pf_ob1) }
                     // envs with more head columns than two passes of their lanes (many transformers): the rest, unprefetched
                     for (c = pl_l + 2 * lpe; c < nhead; c += lpe) {
                         const int i = c - 20, r = i / 40, j = i - r * 40;
-                        o[trobs[r] + j] = S->win_tab[(((long long)pe_l * R + r) * (T + 1) + sstep) * 40 + j];
+                        EV2G_OBS_PUT(trobs[r] + j, S->win_tab[(((long long)pec * R + r) * (T + 1) + sstep) * 40 + j])
                     }
                 }
+#undef EV2G_OBS_PUT
             }
         }
         PT_MARK(5)
+        PT_STEP_END(false)
         t += 1;
         // no barrier needed here: the next step's phase A only touches stage[0,4..7], s_amps, items and cnt, none
         // of which phase E reads; tsum/esum/over_l are rewritten only after three more barriers.

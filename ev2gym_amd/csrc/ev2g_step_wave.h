@@ -42,6 +42,7 @@ template <class T, class B> __device__ __forceinline__ void stg32(B base, unsign
 }
 typedef double d2v __attribute__((ext_vector_type(2)));   // builtin vectors: loadable from any address space
 typedef int i2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 // The battery-maths part of the record (its first 96 bytes) in one memory round trip: 6 x 16-byte loads issued back to back, then pinned by an empty asm so
 // that the compiler cannot sink the ones a later branch does not need behind that branch (it otherwise loads the
 // two gate fields first and the rest only after testing them: two dependent round trips).
@@ -59,14 +60,16 @@ template <class B> __device__ __forceinline__ SessRec ldg32_rec(B base, unsigned
 // instead of two (kernarg -> parameter block).  A launch starts with cold caches, so every dependent fetch in the
 // prologue is a full memory round trip -- paid per step by single-step launches.
 struct WaveArgs {
-    int P, T, E, D;
+    int P, T, E, D, M;
     char *slab_port; unsigned long long slab_port_slice;
     double *slab_hist; unsigned long long hist_slice;
     double *env_acc;
     const double *cs_imax, *cs_dmax_abs, *cs_imin, *cs_dmin, *cs_maxp, *cs_minp;
 };
 
-template <int SK, int RK>
+// IO32: the actions are float32 (StepIO::act32) -- the policy-network interface; float32 observations (StepIO::obs32) are
+// written whenever that pointer is set, in either instantiation.
+template <int SK, int RK, bool IO32>
 __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
                                                                      int k_steps, int auto_reset, WaveArgs wa) {
     extern __shared__ double lds[];
@@ -77,7 +80,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     ParamPtr S = (ParamPtr)(unsigned long long)params;
     constexpr int NS = EV2G_WAVE_BLOCK;
     constexpr int RS = NS + 8;   // stage row stride: +16 banks per row, so the 8 rows one reduction read touches spread over all banks
-    const int P = wa.P, T = wa.T, E = wa.E, D = wa.D;
+    const int P = wa.P, T = wa.T, E = wa.E, D = wa.D, M = wa.M;
+    int off = io.scn_off;   // scenario-pool window: env e runs scenario (e + off) mod M
     // state slabs (ev2g_device.h): every [E*P] array is slabP + k * PS8, the three [T,E] histories slabH + k * HS8, the
     // two per-session result arrays slabS + k * SS8 -- scalar adds on three base pointers instead of one pointer fetch
     // from the parameter block per array and use
@@ -105,6 +109,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     int *cnt = items + NS;  // cnt[2*(kk&1) + {0 charge, 1 discharge}]
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const bool log_soc = S->soc_log != nullptr;
+    const bool log_cs = S->cs_profits != nullptr;   // EV2G_FLAG_LOG_CS_HISTORY: charger-level accumulators and histories (ev2gym_env.py:533-535)
     const double dtd = (double)S->dt, sixty_over_dt = S->sixty_over_dt, dt_over_60 = S->dt_over_60;
     const bool pow2_dt = S->pow2_dt != 0;
 
@@ -131,7 +136,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         c_imax = ldg32<double>(wa.cs_imax, c8); c_dmaxabs = ldg32<double>(wa.cs_dmax_abs, c8);
         double k_imin = ldg32<double>(wa.cs_imin, cp8), k_dmin = ldg32<double>(wa.cs_dmin, cp8);
         double k_maxp = ldg32<double>(wa.cs_maxp, cp8), k_minp = ldg32<double>(wa.cs_minp, cp8);
-        a_next = ldg32<double>(io.actions, (unsigned)(valid ? g : e0 * P) * 8u);
+        a_next = IO32 ? (double)ldg32<float>(S->x_act32 + (long long)io.step0 * io.a_stride, (unsigned)(valid ? g : e0 * P) * 4u)
+                      : ldg32<double>(io.actions, (unsigned)(valid ? g : e0 * P) * 8u);
         double l_pot = ldg32<double>(slabH + HS8, ((unsigned)min(t, T - 1) * (unsigned)E + ec) * 8u);
         d2v acc01 = ldg32<d2v>(env_acc, ec * 64u), acc23 = ldg32<d2v>(env_acc, ec * 64u + 16u);
         double acc4 = ldg32<double>(env_acc, ec * 64u + 32u);
@@ -168,7 +174,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
 
     PT_DECL
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
-    pt_acc[7] += pt_last - pt_k0;
+    pt_cur[7] += pt_last - pt_k0;
 #endif
     for (int kk = 0; kk < k_steps; kk++) {
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
@@ -182,14 +188,19 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const unsigned g8 = (unsigned)g_l * 8u;   // byte offset of this port in every [E*P] float64 / int2 array
         if (t >= T) {  // episode finished inside a fused run: in-kernel ev2g_reset for this workgroup
             if (!auto_reset) break;
+            off = ev2g_scn(off, io.scn_stride, M);
             if (valid) {
-                const i2v w = ldg32<i2v>(S->port_first_win, g8);
-                s_ta[tid_l] = w.x; s_td[tid_l] = w.y; s_ss[tid_l] = ldg32<int>(S->port_first, g8 >> 1); s_cyc[tid_l] = 0;
+                const unsigned gs8 = (unsigned)(ev2g_scn(e_l, off, M) * P + q_l) * 8u;   // this port in the scenario pool
+                const i2v w = ldg32<i2v>(S->port_first_win, gs8);
+                s_ta[tid_l] = w.x; s_td[tid_l] = w.y; s_ss[tid_l] = ldg32<int>(S->port_first, gs8 >> 1); s_cyc[tid_l] = 0;
                 s_cap[tid_l] = 0.0; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_abse[tid_l] = 0.0; s_dirty[tid_l] = 3;
                 stg32<double>(PA(EV2G_PS_PENERGY), g8, 0.0);
                 stg32<double>(PA(EV2G_PS_PCURRENT), g8, 0.0);
                 stg32<double>(PA(EV2G_PS_SATSUM), g8, 0.0);   // single-port chargers: charger index == port index
                 stg32<int>(PA(EV2G_PS_SERVED), g8 >> 1, 0);
+                if (log_cs) {   // single-port chargers: charger index == port index
+                    stg32<double>(S->cs_profits, g8, 0.0); stg32<double>(S->cs_e_ch, g8, 0.0); stg32<double>(S->cs_e_dis, g8, 0.0);
+                }
             }
             if (head) {
                 for (int i = 0; i < 8; i++) stg32<double>(env_acc, (unsigned)e_l * 64u + (unsigned)i * 8u, 0.0);
@@ -198,6 +209,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             t = 0;
         }
         double *obs = io.obs ? io.obs + (long long)kk * io.o_stride : nullptr;       // uniform bases (scalar arithmetic)
+        float *obs32 = S->x_obs32 ? (float *)S->x_obs32 + (long long)(io.step0 + kk) * S->x_o32_stride : nullptr;
         uint8_t *mask = io.mask ? io.mask + (long long)kk * io.m_stride : nullptr;
         const int sstep = t + 1;
         const bool last_step = (kk == k_steps - 1) || (sstep >= T && !auto_reset);
@@ -236,8 +248,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
         const int ec = valid ? e_l : e0;   // clamped env for idle lanes
         const int gc = valid ? g_l : e0 * P;
-        a_next = ldg32_nt<double>(io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride, (unsigned)gc * 8u);
-        const unsigned eT64 = (unsigned)(ec * T) * 64u;   // this env's rows in the [E,T,8] step table
+        a_next = IO32 ? (double)ldg32_nt<float>(S->x_act32 + (long long)(io.step0 + (more ? kk + 1 : kk)) * io.a_stride, (unsigned)gc * 4u)
+                      : ldg32_nt<double>(io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride, (unsigned)gc * 8u);
+        const int scn = ev2g_scn(ec, off, M);             // this env's scenario in the resident pool
+        const unsigned eT64 = (unsigned)(scn * T) * 64u;  // its rows in the [M,T,8] step table
         const unsigned et64 = eT64 + (unsigned)t * 64u;
         const d2v st0 = ldg32_nt<d2v>(S->step_tab, et64);                                  // charge price, discharge price
         double pf_pch = st0.x, pf_pdis = st0.y;
@@ -255,7 +269,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         } else {
             // observation head table [E, T+1, NHEAD]: |charge price| window (zero-padded) + load/PV/limit window, exactly
             // the values of columns 2..2+NHEAD of the observation emitted at the end of step sstep-1 (state.py:65-83, :108-135)
-            const unsigned h8 = (unsigned)((ec * (T + 1) + sstep) * NHEAD) * 8u;
+            const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
             pf_h0 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l, NPAIR - 1) * 16u);
             if (P < NPAIR) pf_h1 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l + P, NPAIR - 1) * 16u);   // (uniform)
         }
@@ -329,6 +343,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     const double ech = stage[4 * RS + tid_l];
                     profit = (ech != 0.0) ? ech * pf_pch : stage[5 * RS + tid_l] * pf_pdis;
                 }
+                if (log_cs && energy != 0.0) {   // charger accumulators (ev_charger.py:178-181,194-197): one lane per charger and step
+                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_profits + g8), profit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_e_ch + g8), stage[4 * RS + tid_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_e_dis + g8), stage[5 * RS + tid_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 if (current - 0.0001 > c_imax) stg32<int>(S->env_fault, (unsigned)e_l * 4u, 1);  // ev_charger.py:203-205
                 if (last_step) { stg32<double>(PA(EV2G_PS_PENERGY), g8, energy); stg32<double>(PA(EV2G_PS_PCURRENT), g8, current); }
                 if (log_soc) stg32<double>(S->soc_log + (long long)t * E * P, g8, (current != 0.0) ? cap_before : -cap_before);
@@ -337,7 +356,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     const unsigned r8 = (unsigned)ss * (unsigned)sizeof(SessRec);
                     const double des = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, des));
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
-                    if (RK != 1) satpen = 100.0 * exp(-10.0 * score);
+                    if (RK != 1 || S->cost_kind == 1) satpen = 100.0 * exp(-10.0 * score);
                     // fire-and-forget device atomics (no returned value => no memory round trip on this path); exactly one
                     // lane updates a given charger per step, so the result does not depend on any ordering
                     __hip_atomic_fetch_add((int __attribute__((address_space(1))) *)(PA(EV2G_PS_SERVED) + (g8 >> 1)), 1,
@@ -389,6 +408,17 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 const unsigned o8 = (unsigned)(e_l * D + ocol) * 8u;
                 stg32<d2v>(obs, o8, (d2v){o0, o1});   // one 16-byte store (D and the column offset are even for SK != 1)
                 if (SK == 1) stg32<double>(obs, o8 + 16u, o2);
+            }
+            if (obs32) {
+                const unsigned o4 = (unsigned)(e_l * D + ocol) * 4u;
+                if (SK == 1) { stg32<float>(obs32, o4, (float)o0); stg32<float>(obs32, o4 + 4u, (float)o1); stg32<float>(obs32, o4 + 8u, (float)o2); }
+                else stg32<f2v>(obs32, o4, (f2v){(float)o0, (float)o1});
+            }
+            if (log_cs) {   // cs_power / cs_current of the step (ev2gym_env.py:533-535) and the chargers' current_power_output / current_total_amps
+                const double pw = occ ? stage[0 * RS + tid_l] : 0.0, cur = occ ? stage[7 * RS + tid_l] : 0.0;
+                const unsigned hc8 = ((unsigned)(t * E + e_l) * (unsigned)P + (unsigned)q_l) * 8u;
+                stg32<double>(S->cs_power_hist, hc8, pw); stg32<double>(S->cs_cur_hist, hc8, cur);
+                if (last_step) { stg32<double>(S->cs_power_now, g8, pw); stg32<double>(S->cs_cur_now, g8, cur); }
             }
             stage[1 * RS + tid_l] = profit;
             stage[2 * RS + tid_l] = satpen;
@@ -491,11 +521,32 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             ea[0] = n0; ea[1] = n1; ea[2] = n2; ea[3] = n3; ea[4] = n4; ea[5] = potn;
             if (io.reward) stg32<double>(io.reward + (long long)kk * io.r_stride, e8, reward);
             if (io.done) stg32<uint8_t>(io.done + (long long)kk * io.d_stride, (unsigned)e_l, (sstep >= T) ? 1 : 0);
+            if (S->x_cost)   // cost_function (rl_agent/cost.py:8-27); the overload weight is applied here when the reward does not carry it
+                stg32<double>(S->x_cost + (long long)(io.step0 + kk) * S->x_c_stride, e8, (S->cost_kind == 2) ? costs : 100.0 * over + esum[2]);
             if (sstep >= T || last_step) {  // publish the running episode totals (get_statistics reads them)
                 const unsigned a8 = (unsigned)e_l * 64u;
                 stg32<d2v>(env_acc, a8, (d2v){n0, n1});
                 stg32<d2v>(env_acc, a8 + 16u, (d2v){n2, n3});
                 stg32<double>(env_acc, a8 + 32u, n4);
+            }
+        }
+        if (valid && obs32) {
+            const unsigned o4 = (unsigned)(e_l * D) * 4u;
+            if (SK == 1) {
+                if (q_l == 0) {
+                    stg32<float>(obs32, o4, (float)((double)sstep / (double)T));
+                    stg32<float>(obs32, o4 + 4u, (float)((sstep < T) ? pf_ob0 : 0.0));
+                    stg32<float>(obs32, o4 + 8u, (float)usage);
+                }
+            } else {
+                if (q_l == 0) stg32<f2v>(obs32, o4, (f2v){(float)sstep, (float)usage});
+                if (q_l < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)q_l * 8u, (f2v){(float)pf_h0.x, (float)pf_h0.y});
+                if (q_l + P < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)(q_l + P) * 8u, (f2v){(float)pf_h1.x, (float)pf_h1.y});
+                const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
+                for (int pi = q_l + 2 * P; pi < NPAIR; pi += P) {
+                    const d2v hv = ldg32<d2v>(S->head_tab, h8 + (unsigned)pi * 16u);
+                    stg32<f2v>(obs32, o4 + 8u + (unsigned)pi * 8u, (f2v){(float)hv.x, (float)hv.y});
+                }
             }
         }
         if (valid && obs) {
@@ -510,12 +561,13 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 if (q_l == 0) stg32<d2v>(obs, o8, (d2v){(double)sstep, usage});
                 if (q_l < NPAIR) stg32<d2v>(obs, o8 + 16u + (unsigned)q_l * 16u, pf_h0);
                 if (q_l + P < NPAIR) stg32<d2v>(obs, o8 + 16u + (unsigned)(q_l + P) * 16u, pf_h1);
-                const unsigned h8 = (unsigned)((e_l * (T + 1) + sstep) * NHEAD) * 8u;
+                const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
                 for (int pi = q_l + 2 * P; pi < NPAIR; pi += P)    // tiny envs (P < 15): the remaining pairs, unprefetched
                     stg32<d2v>(obs, o8 + 16u + (unsigned)pi * 16u, ldg32<d2v>(S->head_tab, h8 + (unsigned)pi * 16u));
             }
         }
         PT_MARK(5)
+        PT_STEP_END(cntk[0] + cntk[1] == 0)
         t += 1;
         // The next step's phase A rewrites stage[0,4..7] / s_amps of this wavefront's own lanes only after this
         // wavefront finished reading them (program order); other wavefronts never touch these slots outside phase B,

@@ -70,6 +70,7 @@ class AsyncStatsGather:
         self.work = [None, None]
         self.i = 0
         self.launched = 0
+        self.collectives = 0   # all-gathers actually issued on the process group
 
     def buffer(self):
         w = self.work[self.i]
@@ -80,8 +81,9 @@ class AsyncStatsGather:
 
     def launch(self):
         import torch.distributed as dist
-        if self.world > 1:
+        if dist.is_available() and dist.is_initialized():   # also at world size 1: the same RCCL call, one rank
             self.work[self.i] = dist.all_gather_into_tensor(self.recv[self.i], self.send[self.i], group=self.group, async_op=True)
+            self.collectives += 1
         else:
             self.recv[self.i].copy_(self.send[self.i])
         self.last = self.i

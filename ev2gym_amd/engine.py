@@ -50,9 +50,14 @@ def load_library(path: Optional[str] = None):
         "ev2g_destroy": (None, [vp]),
         "ev2g_last_error": (C.c_char_p, [vp]),
         "ev2g_load_scenarios": (C.c_int, [vp, C.POINTER(_abi.ScenarioBatchC)]),
-        "ev2g_n_envs": (C.c_int, [vp]), "ev2g_n_ports": (C.c_int, [vp]), "ev2g_obs_dim": (C.c_int, [vp]),
+        "ev2g_n_envs": (C.c_int, [vp]), "ev2g_n_scenarios": (C.c_int, [vp]), "ev2g_n_ports": (C.c_int, [vp]), "ev2g_obs_dim": (C.c_int, [vp]),
         "ev2g_n_steps": (C.c_int, [vp]), "ev2g_current_step": (C.c_int, [vp]),
         "ev2g_reset": (C.c_int, [vp, vp]),
+        "ev2g_reset_ex": (C.c_int, [vp, vp, i64]),
+        "ev2g_scenario_offset": (i64, [vp]),
+        "ev2g_set_step_extras": (C.c_int, [vp, C.POINTER(_abi.StepExtrasC)]),
+        "ev2g_kernel_name": (C.c_char_p, [vp]),
+        "ev2g_fallback_reason": (C.c_char_p, [vp]),
         "ev2g_step": (C.c_int, [vp, vp, vp, vp, vp, vp]),
         "ev2g_step_n": (C.c_int, [vp, C.c_int, C.c_int, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, C.c_int]),
         "ev2g_check_faults": (C.c_int, [vp, C.POINTER(i32)]),
@@ -80,7 +85,8 @@ def load_library(path: Optional[str] = None):
 
 EXPORTED_SYMBOLS = [
     "ev2g_abi_version", "ev2g_create", "ev2g_destroy", "ev2g_last_error", "ev2g_load_scenarios", "ev2g_n_envs",
-    "ev2g_n_ports", "ev2g_obs_dim", "ev2g_n_steps", "ev2g_current_step", "ev2g_reset", "ev2g_step", "ev2g_step_n",
+    "ev2g_n_scenarios", "ev2g_n_ports", "ev2g_obs_dim", "ev2g_n_steps", "ev2g_current_step", "ev2g_reset", "ev2g_reset_ex",
+    "ev2g_scenario_offset", "ev2g_set_step_extras", "ev2g_kernel_name", "ev2g_fallback_reason", "ev2g_step", "ev2g_step_n",
     "ev2g_check_faults", "ev2g_get_stats", "ev2g_stat_name", "ev2g_peek", "ev2g_malloc", "ev2g_free",
     "ev2g_memcpy_h2d", "ev2g_memcpy_d2h", "ev2g_synchronize", "ev2g_fill_uniform", "ev2g_host_uniform",
     "ev2g_last_step_n_kernel_ms"]
@@ -133,10 +139,12 @@ class Engine:
     """One handle = one GPU = one HIP stream; E envs resident in HBM."""
 
     def __init__(self, batch: ScenarioBatch, reward_kind: int, state_kind: int, device: int = 0, flags: int = 0,
-                 stream: Optional[int] = None):
+                 stream: Optional[int] = None, cost_kind: int = 0, n_active_envs: int = 0):
+        """`batch` is the resident scenario pool (M scenarios); `n_active_envs` (default: all of them) envs are stepped
+        per call, each reset choosing which window of the pool they run (`reset(offset=...)`)."""
         self._lib = load_library()
         self._h = None
-        cfg = _abi.ConfigC(int(device), int(reward_kind), int(state_kind), int(flags), stream)
+        cfg = _abi.ConfigC(int(device), int(reward_kind), int(state_kind), int(flags), stream, int(cost_kind), int(n_active_envs))
         h = C.c_void_p()
         rc = self._lib.ev2g_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -151,10 +159,34 @@ class Engine:
         self._check(self._lib.ev2g_load_scenarios(self._h, C.byref(cb)))
         self.batch = batch
         self.E = self._lib.ev2g_n_envs(self._h)
+        self.M = self._lib.ev2g_n_scenarios(self._h)
         self.P = self._lib.ev2g_n_ports(self._h)
         self.D = self._lib.ev2g_obs_dim(self._h)
         self.T = self._lib.ev2g_n_steps(self._h)
         self.C, self.R = batch.n_chargers, batch.n_transformers
+        why = self.fallback_reason
+        if why and self.P <= 64:   # a shape of the common size that did not get the fast-path kernel: say so, once per cause
+            import warnings
+            warnings.warn(f"ev2gym_amd: step kernel {self.kernel_name} selected instead of the fast path ({why})", stacklevel=2)
+
+    @property
+    def kernel_name(self) -> str:
+        """The step kernel ev2g_load_scenarios selected for the loaded shape (routing is never silent)."""
+        return (self._lib.ev2g_kernel_name(self._h) or b"").decode()
+
+    @property
+    def fallback_reason(self) -> str:
+        return (self._lib.ev2g_fallback_reason(self._h) or b"").decode()
+
+    @property
+    def scenario_offset(self) -> int:
+        return int(self._lib.ev2g_scenario_offset(self._h))
+
+    def set_extras(self, cost=None, cost_stride=0, obs_f32=None, obs_f32_stride=0, actions_f32=None):
+        """Optional sticky step outputs / inputs (include/ev2g.h ev2g_step_extras); all None clears them."""
+        self._extras_keep = (cost, obs_f32, actions_f32)   # keep the buffers alive
+        x = _abi.StepExtrasC(_ptr(cost), int(cost_stride), _ptr(obs_f32), int(obs_f32_stride), _ptr(actions_f32))
+        self._check(self._lib.ev2g_set_step_extras(self._h, C.byref(x)))
 
     # ---- plumbing ------------------------------------------------------------------------------
     def last_error(self) -> str:
@@ -175,8 +207,13 @@ class Engine:
         return self._lib.ev2g_current_step(self._h)
 
     # ---- hot path ------------------------------------------------------------------------------
-    def reset(self, obs=None):
-        self._check(self._lib.ev2g_reset(self._h, _ptr(obs)))
+    def reset(self, obs=None, offset: Optional[int] = None):
+        """Re-arm every env; `offset` first draws the scenarios of the coming episode: env e runs scenario
+        (e + offset) mod M of the resident pool (None: the same scenarios as before)."""
+        if offset is None:
+            self._check(self._lib.ev2g_reset(self._h, _ptr(obs)))
+        else:
+            self._check(self._lib.ev2g_reset_ex(self._h, _ptr(obs), int(offset)))
 
     def step(self, actions, obs=None, reward=None, done=None, mask=None):
         self._check(self._lib.ev2g_step(self._h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(mask)))
@@ -185,7 +222,7 @@ class Engine:
                mask=None, m_stride=0, auto_reset=True, persistent=False):
         rc = self._lib.ev2g_step_n(self._h, int(k), 1 if persistent else 0, _ptr(actions), int(a_stride), _ptr(obs),
                                    int(o_stride), _ptr(reward), int(r_stride), _ptr(done), int(d_stride), _ptr(mask),
-                                   int(m_stride), 1 if auto_reset else 0)
+                                   int(m_stride), int(auto_reset))   # 0 / AUTO_RESET_SAME (True) / AUTO_RESET_NEXT
         self._check(rc)
 
     def last_step_n_kernel_ms(self) -> float:
@@ -217,7 +254,8 @@ class Engine:
         """Host copy of one env's state in the reference's port order (feeds the EV2Gym facade)."""
         P, Cn, R, T = self.P, self.C, self.R, self.T
         st = self.batch.arrays["env_session_start"]
-        S = int(st[env + 1] - st[env])
+        scn = (env + self.scenario_offset) % self.M   # the scenario this env is running
+        S = int(st[scn + 1] - st[scn])
         f8 = lambda *s: np.empty(s, np.float64)  # noqa: E731
         i4 = lambda *s: np.empty(s, np.int32)  # noqa: E731
         d = dict(port_capacity=f8(P), port_energy=f8(P), port_current=f8(P), port_total_energy=f8(P),

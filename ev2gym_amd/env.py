@@ -271,6 +271,9 @@ class EV2Gym:
         self.departing_evs = []
         self.total_reward = 0.0
         self._scenario_seed = self.seed if self.config is not None else None
+        self._episodes = 0
+        self.resample_on_reset = True     # False: reset() re-arms the current scenario (round-1 behaviour)
+        self._seed_rng = np.random.default_rng(self.seed if isinstance(self.seed, (int, np.integer)) else None)
         self.reset()
         self.observation_space = Box(-np.inf, np.inf, (len(self._last_obs),))
         self.observation_mask = np.zeros(self.engine.P)
@@ -329,14 +332,20 @@ class EV2Gym:
 
     # ---- gym surface --------------------------------------------------------------------------------
     def reset(self, seed=None, options=None, **kwargs):
-        """`reset()` re-arms the loaded scenario; `reset(seed=s)` on an env built from a config file draws the scenario of
-        seed s first, like the reference's reset (ev2gym_env.py:243-331: new EV profiles, prices, loads per reset)."""
-        if seed is not None and self.config is not None and seed != self._scenario_seed:
-            self.seed = seed
-            new = generate(gen_config_from_yaml(self.config, 1, seed))
-            self.engine.load(new)
-            self._bind_scenario(new)
-            self._scenario_seed = seed
+        """EV2Gym.reset() (ev2gym_env.py:243-331).  Built from a config file, every reset draws a NEW scenario like the
+        reference does (new EV profiles, prices, loads, PV, demand-response events): `reset(seed=s)` the scenario of seed s,
+        `reset()` the next seed of the env's own generator (itself seeded by the constructor's `seed`).  Built from explicit
+        scenario tensors or a replay file, reset() re-arms that scenario (the reference's replay behaviour, :102-116)."""
+        if self.config is not None:
+            if seed is None and self._episodes > 0 and self.resample_on_reset:
+                seed = int(self._seed_rng.integers(0, 1000000))    # ev2gym_env.py:250-253 draws its seed the same way
+            if seed is not None and seed != self._scenario_seed:
+                self.seed = seed
+                new = generate(gen_config_from_yaml(self.config, 1, seed))
+                self.engine.load(new)
+                self._bind_scenario(new)
+                self._scenario_seed = seed
+        self._episodes += 1
         self.engine.reset(self._d["obs"])
         self._snapshot = None
         self._max_obs_step = 0

@@ -105,6 +105,11 @@ class EV2GymSB3VecEnv(_SB3VecEnv):
         self.vec.close()
 
     def seed(self, seed: Optional[int] = None) -> Sequence[Optional[int]]:
+        """SB3 seeds its envs once before training: re-seed the generator the per-episode scenario draws come from and
+        start from the window of the pool that `seed` selects (EV2GymVec.reset(seed=...))."""
+        if seed is not None:
+            self.vec._rng = np.random.default_rng(int(seed))
+            self.vec.reset(seed=int(seed))
         return [None if seed is None else seed + i for i in range(self.num_envs)]
 
     def _indices(self, indices):

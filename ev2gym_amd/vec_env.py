@@ -8,6 +8,13 @@ Keeps the reference's surface (ev2gym/models/ev2gym_env.py: constructor kwargs :
     obs, _ = env.reset()                       # [E, D]
     obs, reward, done, truncated, info = env.step(actions)   # actions [E, P] in [-1, 1]
 
+Scenario draw: the reference draws a new scenario in every `reset()` (ev2gym_env.py:243-296).  Here a POOL of
+`pool_factor x num_envs` scenarios is generated once and stays resident in HBM; every `reset()` picks, at no cost, which
+window of the pool the envs run next (env e <- scenario (e + offset) mod M, offset drawn from the env's seeded generator;
+`reset(seed=s)` maps s to an offset reproducibly), so consecutive episodes differ and auto-resetting rollouts never
+replay a fixed set of `num_envs` episodes.  `resample_every=N` additionally re-draws the whole pool on the host every N
+episodes.
+
 Arrays are torch CUDA tensors when torch sees the GPU (zero-copy: the engine writes through `data_ptr()` on
 torch's current stream -- the SB3 path), otherwise engine-owned device buffers mirrored to numpy.
 Only the fused built-in state / reward functions run here; arbitrary Python callables need the single-env
@@ -61,7 +68,7 @@ class EV2GymVec:
                  reward_function="SquaredTrackingErrorReward", cost_function=None, seed: Optional[int] = None,
                  scenarios: Optional[ScenarioBatch] = None, auto_reset: bool = False, log_cs_history: bool = False, log_soc: bool = True,
                  use_torch: Optional[bool] = None, rank: int = 0, world_size: int = 1, verbose: bool = False,
-                 load_from_replay_path=None, **unused):
+                 load_from_replay_path=None, pool_factor: int = 8, resample_every: Optional[int] = None, **unused):
         self.state_kind = _kind(state_function, _abi.STATE_KINDS, "state_function")
         self.reward_kind = _kind(reward_function, _abi.REWARD_KINDS, "reward_function")
         if self.state_kind is None or self.reward_kind is None:
@@ -69,9 +76,18 @@ class EV2GymVec:
                 "EV2GymVec fuses only the built-in state/reward functions "
                 f"({sorted(_abi.STATE_KINDS)} / {sorted(_abi.REWARD_KINDS)}); "
                 "user-defined callables run through the single-env facade ev2gym_amd.env.EV2Gym")
+        self.cost_kind = 0
         if cost_function is not None:
-            raise NotImplementedError("cost_function is evaluated by the single-env facade only")
+            self.cost_kind = _kind(cost_function, _abi.COST_KINDS, "cost_function")
+            if self.cost_kind is None:
+                raise NotImplementedError(f"EV2GymVec fuses only the built-in cost functions ({sorted(_abi.COST_KINDS)}); "
+                                          "user-defined callables run through the single-env facade ev2gym_amd.env.EV2Gym")
         self.seed = 0 if seed is None else int(seed)
+        self._rng = np.random.default_rng(self.seed)     # the stream reset() draws scenario offsets from
+        self.pool_factor = max(1, int(pool_factor))
+        self.resample_every = resample_every
+        self._episodes = 0
+        self._pool_generation = 0
         if scenarios is None and load_from_replay_path is not None:
             # one replay file, or a list of them recorded with the same config: one env per file (ev2gym_env.py:102-116)
             from .replay import load_replay
@@ -81,12 +97,12 @@ class EV2GymVec:
             if config_file is None:
                 raise AssertionError("Please provide a config file!!!")   # ev2gym_env.py:64
             self.config = load_yaml(config_file)
-            total = int(num_envs) * int(world_size)
-            gen = gen_config_from_yaml(self.config, total, self.seed)
-            full = generate(gen)
-            scenarios = full.shard(rank, world_size) if world_size > 1 else full
+            self._n_req, self._world = int(num_envs), int(world_size)
+            scenarios = self._draw_pool(rank, world_size)
+            n_active = int(num_envs)
         else:
             self.config = None
+            n_active = min(int(num_envs), scenarios.n_envs) if num_envs and int(num_envs) > 1 else scenarios.n_envs
         self.scenarios = scenarios
         self.rank, self.world_size = rank, world_size
         if use_torch is None:
@@ -107,7 +123,8 @@ class EV2GymVec:
             flags |= _abi.FLAG_LOG_SOC   # battery-degradation statistics need the SoC log (ev.py:442-521)
         if use_torch and stream is None:
             flags |= _abi.FLAG_NULL_STREAM   # torch's current stream is the default stream: share it
-        self.engine = Engine(scenarios, self.reward_kind, self.state_kind, device=device, flags=flags, stream=stream)
+        self.engine = Engine(scenarios, self.reward_kind, self.state_kind, device=device, flags=flags, stream=stream,
+                             cost_kind=self.cost_kind, n_active_envs=n_active)
         e = self.engine
         self.num_envs, self.number_of_ports, self.obs_dim = e.E, e.P, e.D
         self.simulation_length = e.T
@@ -122,8 +139,20 @@ class EV2GymVec:
         self._done = self._alloc((e.E,), np.uint8)
         self._mask = self._alloc((e.E, e.P), np.uint8)
         self._act = self._alloc((e.E, e.P))
+        self._cost = None
+        if self.cost_kind:
+            self._cost = self._alloc((e.E,))
+            e.set_extras(cost=self._cost)
         self.stats = None
-        self.reset()
+        self.reset(seed=self.seed)
+
+    def _draw_pool(self, rank, world_size):
+        """pool_factor x num_envs scenarios per rank from the vectorised generator (statistically matched to the
+        reference's per-reset draw, scenario_gen.py); generation `g` of the pool uses the seed (seed, g)."""
+        total = self._n_req * self.pool_factor * world_size
+        gen_seed = self.seed if self._pool_generation == 0 else int(np.random.SeedSequence([self.seed, self._pool_generation]).generate_state(1)[0])
+        full = generate(gen_config_from_yaml(self.config, total, gen_seed))
+        return full.shard(rank, world_size) if world_size > 1 else full
 
     # ---- buffers ---------------------------------------------------------------------------------
     def _alloc(self, shape, dtype=np.float64):
@@ -153,18 +182,22 @@ class EV2GymVec:
         return self.engine.current_step
 
     def reset(self, seed=None, options=None, **kwargs):
-        """Re-arms every env on its scenario (state-init part of EV2Gym.reset, ev2gym_env.py:298-331).  With a `seed`
-        different from the loaded one (and a config file to draw from) a NEW batch of scenarios is generated and loaded
-        first -- the reference's per-reset scenario draw (ev2gym_env.py:243-296); the host generation + upload takes
-        0.16 s for 4096 x 50 envs (tools/reseed_timing.py) against 0.16 ms for a plain reset(): resample every so many
-        episodes rather than every one."""
-        if seed is not None and self.config is not None and int(seed) != self.seed:
-            self.seed = int(seed)
-            total = self.num_envs * self.world_size
-            full = generate(gen_config_from_yaml(self.config, total, self.seed))
-            self.scenarios = full.shard(self.rank, self.world_size) if self.world_size > 1 else full
+        """EV2Gym.reset() (ev2gym_env.py:243-331) for every env: draws the scenarios of the coming episode -- a window of the
+        resident pool: with `seed` reproducibly (same seed, same episode), without it the next draw of the env's generator,
+        so consecutive episodes differ -- and re-arms the state.  O(1) on the host, one small kernel on the device; with
+        `resample_every=N` the whole pool is regenerated on the host every N episodes (0.16 s per 4096 x 50 scenarios)."""
+        M = self.engine.M
+        if (self.resample_every and self.config is not None and self._episodes
+                and self._episodes % int(self.resample_every) == 0 and seed is None):
+            self._pool_generation += 1
+            self.scenarios = self._draw_pool(self.rank, self.world_size)
             self.engine.load(self.scenarios)
-        self.engine.reset(self._obs)
+        if seed is not None:
+            offset = int(np.random.default_rng(int(seed)).integers(0, M)) if M > self.num_envs else 0
+        else:
+            offset = int(self._rng.integers(0, M)) if M > self.num_envs else 0
+        self.engine.reset(self._obs, offset=offset)
+        self._episodes += 1
         self.stats = None
         return self._out(self._obs), {}
 
@@ -190,7 +223,7 @@ class EV2GymVec:
             raise AssertionError("Episode is done, please reset the environment")   # ev2gym_env.py:343
         a = self._as_device_actions(actions)
         self.engine.step(a, self._obs, self._rew, self._done, self._mask)
-        info = {"action_mask": self._out(self._mask), "cost": None}
+        info = {"action_mask": self._out(self._mask), "cost": self._out(self._cost) if self._cost is not None else None}
         finished = self.engine.current_step >= self.simulation_length
         if finished:
             self.engine.check_faults()
@@ -201,7 +234,9 @@ class EV2GymVec:
                 rew, done = self._out(self._rew), self._out(self._done)
                 if self._torch is not None:
                     rew, done = rew.clone(), done.clone()
-                self.engine.reset(self._obs)
+                if self._cost is not None and self._torch is not None:
+                    info["cost"] = info["cost"].clone()
+                self.reset()   # the next episode's scenarios: a fresh window of the pool
                 return self._out(self._obs), rew, done, self._false(), info
         return self._out(self._obs), self._out(self._rew), self._out(self._done), self._false(), info
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define EV2G_ABI_VERSION 1
+#define EV2G_ABI_VERSION 2
 
 /* reward_function built-ins (rl_agent/reward.py) */
 #define EV2G_REWARD_PROFITMAX_TRPENALTY_USERINCENTIVES 0 /* reward.py:34-44  */
@@ -38,6 +38,11 @@ extern "C" {
 #define EV2G_STATE_V2G_PROFIT_MAX_LOADS 0 /* state.py:108-155, D = 2+H + 2H*R + 2P */
 #define EV2G_STATE_PUBLIC_PST 1           /* state.py:6-63,    D = 3 + 3P          */
 #define EV2G_STATE_V2G_PROFIT_MAX 2       /* state.py:65-106,  D = 2+H + 2P        */
+
+/* cost_function built-ins (rl_agent/cost.py), evaluated next to the reward (ev2gym_env.py:434-438) */
+#define EV2G_COST_NONE 0
+#define EV2G_COST_TR_OVERLOAD_USRPENALTY 1 /* cost.py:8-18: 100*sum(overload) + 100*sum(exp(-10*score))  */
+#define EV2G_COST_PROFIT_ONLY 2            /* cost.py:22-27 (ProfitMax_TrPenalty_UserIncentives_safety): total_costs */
 
 #define EV2G_OK 0
 #define EV2G_ERR_ARG -1       /* bad argument / inconsistent scenario                         */
@@ -64,6 +69,11 @@ typedef struct ev2g_config {
     int32_t flags;       /* EV2G_FLAG_*                                                          */
     void *stream;        /* hipStream_t to launch on; NULL = a stream owned by the handle (or the
                             default stream with EV2G_FLAG_NULL_STREAM)                          */
+    int32_t cost_kind;   /* EV2G_COST_*    -- replaces the `cost_function` ctor kwarg (:48)      */
+    int32_t n_active_envs; /* E: envs stepped concurrently.  0 = as many as the loaded scenario pool holds.  With
+                            E < pool size M the pool is a device-resident reservoir of scenarios and every reset
+                            picks which M-cyclic window of it the E envs run (ev2g_reset_ex) -- the per-episode
+                            scenario draw of EV2Gym.reset() (ev2gym_env.py:243-296) without a host round trip */
 } ev2g_config;
 
 /*
@@ -149,7 +159,8 @@ const char *ev2g_last_error(const ev2g_handle *h); /* h may be NULL: last create
 int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b);
 
 /* shapes */
-int ev2g_n_envs(const ev2g_handle *h);
+int ev2g_n_envs(const ev2g_handle *h);      /* E: envs stepped per call (n_active_envs)            */
+int ev2g_n_scenarios(const ev2g_handle *h); /* M: scenarios resident in the pool (batch->n_envs)   */
 int ev2g_n_ports(const ev2g_handle *h); /* P */
 int ev2g_obs_dim(const ev2g_handle *h); /* D */
 int ev2g_n_steps(const ev2g_handle *h); /* T */
@@ -159,6 +170,12 @@ int ev2g_n_steps(const ev2g_handle *h); /* T */
  * utils.py:794-861; EV_Charger.reset ev_charger.py:96-112) for every env of the batch, on the same
  * scenarios.  obs [E,D] may be NULL. */
 int ev2g_reset(ev2g_handle *h, double *obs);
+/* The same, preceded by the scenario draw of EV2Gym.reset() (ev2gym_env.py:243-296: new EV sessions, prices, loads,
+ * PV, demand-response events, setpoints): env e runs scenario (e + scenario_offset) mod M of the resident pool for
+ * the coming episode.  Distinct envs always run distinct scenarios (E <= M).  ev2g_reset() keeps the current offset
+ * (re-arms the same scenarios); the host picks offsets (seeded, or fresh per episode).  O(1): nothing is copied. */
+int ev2g_reset_ex(ev2g_handle *h, double *obs, int64_t scenario_offset);
+int64_t ev2g_scenario_offset(const ev2g_handle *h);
 
 /* EV2Gym.step(actions) for all E envs (ev2gym_env.py:333-447).
  *   actions     [E,P] float64, read-only here (the reference zeroes empty ports in the caller's
@@ -177,9 +194,12 @@ int ev2g_step(ev2g_handle *h, const double *actions, double *obs, double *reward
  *   mode 0  one kernel launch per step, enqueued back to back from C;
  *   mode 1  ONE persistent launch: every workgroup loops over the K steps of its own envs (envs are
  *           independent, so no grid-wide synchronisation is needed).
- * If the episode ends inside the K steps: with auto_reset != 0 the envs are reset (ev2g_reset
- * semantics, same scenarios) before the next step -- the terminal step still reports its own obs --
- * otherwise stepping stops there and EV2G_ERR_DONE is returned. */
+ * If the episode ends inside the K steps: with auto_reset != 0 the envs are reset before the next step -- the
+ * terminal step still reports its own obs -- otherwise stepping stops there and EV2G_ERR_DONE is returned.
+ * auto_reset == 1 re-arms the same scenarios (ev2g_reset); auto_reset == 2 moves on to the next E scenarios of
+ * the pool (ev2g_reset_ex with scenario_offset + E), inside the persistent launch as well. */
+#define EV2G_AUTO_RESET_SAME 1
+#define EV2G_AUTO_RESET_NEXT 2
 #define EV2G_STEPN_PER_STEP_LAUNCH 0
 #define EV2G_STEPN_PERSISTENT 1
 int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, int64_t action_step_stride,
@@ -187,7 +207,26 @@ int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, in
                 uint8_t *done, int64_t done_step_stride, uint8_t *action_mask,
                 int64_t mask_step_stride, int auto_reset);
 
+/* Optional extra step outputs / inputs, sticky until changed (all-NULL = off, the default).  DEVICE pointers.
+ *   cost        [E] float64: cost_function value of the step (config.cost_kind must not be EV2G_COST_NONE)
+ *   obs_f32     [E,D] float32 copy of the observation, written next to `obs` (which may then be NULL): policy
+ *               networks take float32, this saves them a conversion pass over the largest stream of the path
+ *   actions_f32 [E,P] float32 actions, read (and widened to float64 on entry, as every action is) when the
+ *               `actions` argument of ev2g_step / ev2g_step_n is NULL; its step stride is action_step_stride */
+typedef struct ev2g_step_extras {
+    double *cost;
+    int64_t cost_step_stride;
+    float *obs_f32;
+    int64_t obs_f32_step_stride;
+    const float *actions_f32;
+} ev2g_step_extras;
+int ev2g_set_step_extras(ev2g_handle *h, const ev2g_step_extras *x); /* x == NULL clears */
+
 int ev2g_current_step(const ev2g_handle *h);
+/* Which step kernel ev2g_load_scenarios selected for the loaded shape ("ev2g_step_wave<0,0>", "ev2g_step_v2<1024>",
+ * "ev2g_step_kernel"), and -- when the common-shape fast path was not taken -- why ("" otherwise). */
+const char *ev2g_kernel_name(const ev2g_handle *h);
+const char *ev2g_fallback_reason(const ev2g_handle *h);
 /* data-dependent faults recorded since the last reset (per-env flag word, device side):
  * returns 0 or EV2G_ERR_OVERCURRENT; synchronises the stream. */
 int ev2g_check_faults(ev2g_handle *h, int32_t *first_bad_env);

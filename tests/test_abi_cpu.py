@@ -24,7 +24,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(L, name), f"{name} declared in include/ev2g.h but not exported"
     assert set(engine.EXPORTED_SYMBOLS) == set(decl)
-    assert L.ev2g_abi_version() == 1
+    from ev2gym_amd import _abi
+    assert L.ev2g_abi_version() == _abi.ABI_VERSION == 2
 
 
 def test_struct_mirrors_match_header_field_order():
@@ -38,6 +39,11 @@ def test_struct_mirrors_match_header_field_order():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = [n for part in re.findall(r"(?:int32_t|double)\s+([^;]+);", body) for n in re.split(r"[,\s\*]+", part) if n]
     assert names == [f[0] for f in _abi.EnvViewC._fields_]
+    for cname, mirror in (("ev2g_config", _abi.ConfigC), ("ev2g_step_extras", _abi.StepExtrasC)):
+        body = txt[txt.index("typedef struct %s {" % cname):txt.index("} %s;" % cname)]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = [n for part in re.findall(r"(?:int32_t|int64_t|double|float|void|const float)\s+([^;]+);", body) for n in re.split(r"[,\s\*]+", part) if n]
+        assert names == [f[0] for f in mirror._fields_], cname
 
 
 @pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")

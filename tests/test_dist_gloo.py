@@ -98,3 +98,92 @@ def test_async_double_buffered_stats_gather_two_ranks(tmp_path):
     import torch.multiprocessing as mp
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_async_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+
+class _OracleEngine:
+    """Stand-in for ev2gym_amd.engine.Engine on a box without a GPU: the same calls bench.RolloutLoop makes, served by the
+    CPU oracle on the current window of the scenario pool."""
+
+    def __init__(self, pool, E, rk, sk):
+        from oracle.oracle import Oracle
+        self._Oracle, self.pool, self.E, self.M, self.rk, self.sk = Oracle, pool, E, pool.n_envs, rk, sk
+        self.T, self.P = pool.n_steps, pool.n_ports
+        self.ora, self.current_step, self.offsets, self.all_acts = None, 0, [], None
+
+    def reset(self, obs=None, offset=0):
+        if self.ora is not None:
+            self.ora.close()
+        self.offsets.append(offset)
+        self.ora = self._Oracle(self.pool.select((np.arange(self.E) + offset) % self.M), self.rk, self.sk)
+        self.ora.reset()
+        self.current_step = 0
+
+    def step_n(self, k, acts, a_stride, obs, o_stride, rew, r_stride, done, d_stride, mask, m_stride, auto_reset=False, persistent=False):
+        for i in range(k):   # `acts` is the device address of step current_step's actions, a_stride apart: here the host array
+            self.ora.step(self.all_acts[self.current_step].numpy().copy())
+            self.current_step += 1
+
+    def last_step_n_kernel_ms(self):
+        return 0.0
+
+    def stats(self, out=None):
+        import torch
+        out.copy_(torch.from_numpy(np.nan_to_num(self.ora.stats())))
+        return out
+
+
+def _loop_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from bench import RolloutLoop
+    from ev2gym_amd import _abi
+    from ev2gym_amd.dist import AsyncStatsGather
+    from ev2gym_amd.engine import host_uniform
+    from ev2gym_amd.scenario_gen import GenConfig, generate
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    E, M = 5, 15
+    pool = generate(GenConfig.v2g_profit_plus_loads(M, 10, seed=300 + rank))   # every rank draws its own pool, like bench.py
+    eng = _OracleEngine(pool, E, 0, 0)
+    T, P = eng.T, eng.P
+    acts = torch.from_numpy(host_uniform(T * E * P, 50 + rank, -1.0, 1.0).reshape(T, E, P))
+    eng.all_acts = acts
+    gath = AsyncStatsGather(E, world, "cpu")
+    loop = RolloutLoop(eng, E, P, T, M, acts, None, None, None, None, None, gath=gath, actor=None)
+    loop.reset()
+    loop.run(2 * T + 40, persistent=True)       # two whole episodes and the start of a third, in uneven pieces ...
+    loop.run(T - 40, persistent=False)          # ... the third one finished by a second call
+    out = gath.finish()
+    assert loop.episodes == 3 and gath.collectives == 3 and eng.offsets == [5, 10, 0, 5]
+    if rank == 0:
+        np.save(os.path.join(out_dir, "loop_gathered.npy"), out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_bench_rollout_loop_over_two_ranks(tmp_path):
+    """bench.py's stepping loop (episode boundaries inside and between run() calls, statistics -> asynchronous gather ->
+    reset onto the next window of the scenario pool, finish()) on two gloo ranks, the CPU oracle standing in for the HIP
+    engine: the last gathered block equals what each rank's third episode produces on its own."""
+    import torch.multiprocessing as mp
+    from ev2gym_amd.engine import host_uniform
+    from ev2gym_amd.scenario_gen import GenConfig, generate
+    from oracle.oracle import Oracle
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_loop_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "loop_gathered.npy")
+    E, M = 5, 15
+    want = []
+    for rank in range(2):
+        pool = generate(GenConfig.v2g_profit_plus_loads(M, 10, seed=300 + rank))
+        T, P = pool.n_steps, pool.n_ports
+        acts = host_uniform(T * E * P, 50 + rank, -1.0, 1.0).reshape(T, E, P)
+        ora = Oracle(pool.select((np.arange(E) + 0) % M), 0, 0)    # third episode: offset (5 + 2*5) % 15 = 0
+        ora.reset()
+        for t in range(T):
+            ora.step(acts[t].copy())
+        want.append(np.nan_to_num(ora.stats()))
+        ora.close()
+    assert np.array_equal(got, np.concatenate(want, 0))

@@ -25,15 +25,29 @@ def _close(a, b, what, tol=RTOL):
     assert err.max(initial=0.0) <= tol, f"{what}: max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
 
 
-def _engine(batch, rk, sk, flags=1 | 4):
+def _engine(batch, rk, sk, flags=1 | 4, **kw):
     from ev2gym_amd.engine import Engine
-    return Engine(batch, rk, sk, device=0, flags=flags)
+    return Engine(batch, rk, sk, device=0, flags=flags, **kw)
 
 
+def _expected_kernel(batch, sk, rk, forced_v2=False):
+    """The routing rule of ev2g_load_scenarios, restated: the common shape gets the fast path, with or without the
+    charger-history flag."""
+    P, R, npc = batch.n_ports, batch.n_transformers, batch.ports_per_charger
+    if 2 <= P <= 64 and R == 1 and npc == 1 and not forced_v2:
+        return f"ev2g_step_wave<{sk},{rk}>"
+    return f"ev2g_step_v2<{256 if P <= 256 else 512 if P <= 512 else 1024}>" if P <= 1024 else "ev2g_step_kernel"
+
+
+@pytest.mark.parametrize("flags", [4, 1 | 4], ids=["soclog", "cshist+soclog"])
 @pytest.mark.parametrize("path", GOLDEN_FILES, ids=GOLDEN_IDS)
-def test_engine_matches_reference_golden(path):
+def test_engine_matches_reference_golden(path, flags):
+    """Every reference fixture through the kernel the engine routes its shape to -- for the single-port, one-transformer
+    fixtures that is ev2g_step_wave, the benchmarked kernel, with and without the charger-history flag."""
     z, batch, rk, sk = load_golden(path)
-    eng = _engine(batch, rk, sk)
+    eng = _engine(batch, rk, sk, flags=flags)
+    assert eng.kernel_name == _expected_kernel(batch, sk, rk), (eng.kernel_name, eng.fallback_reason)
+    log_cs = bool(flags & 1)
     E, P, D = eng.E, eng.P, eng.D
     assert D == z["trj_obs"].shape[1]
     d_act, d_obs = eng.empty((E, P)), eng.empty((E, D))
@@ -55,11 +69,12 @@ def test_engine_matches_reference_golden(path):
         _close(pk["port_total_energy"], z["trj_tot_e"][t], f"tot_e[{t}]")
         _close(pk["port_prev_power"], z["trj_prev_power"][t], f"prev_power[{t}]")
         assert (pk["port_cycles"] == z["trj_cycles"][t]).all(), f"cycles[{t}]"
-        _close(pk["cs_power"], z["trj_cs_power"][t], f"cs_power[{t}]")
-        _close(pk["cs_amps"], z["trj_cs_amps"][t], f"cs_amps[{t}]")
-        _close(pk["cs_profits"], z["trj_cs_profits"][t], f"cs_profits[{t}]")
-        _close(pk["cs_energy_charged"], z["trj_cs_e_ch"][t], f"cs_e_ch[{t}]")
-        _close(pk["cs_energy_discharged"], z["trj_cs_e_dis"][t], f"cs_e_dis[{t}]")
+        if log_cs:
+            _close(pk["cs_power"], z["trj_cs_power"][t], f"cs_power[{t}]")
+            _close(pk["cs_amps"], z["trj_cs_amps"][t], f"cs_amps[{t}]")
+            _close(pk["cs_profits"], z["trj_cs_profits"][t], f"cs_profits[{t}]")
+            _close(pk["cs_energy_charged"], z["trj_cs_e_ch"][t], f"cs_e_ch[{t}]")
+            _close(pk["cs_energy_discharged"], z["trj_cs_e_dis"][t], f"cs_e_dis[{t}]")
         _close(pk["tr_power"], z["trj_tr_power"][t], f"tr_power[{t}]")
     pk = eng.peek(0)
     _close(pk["power_usage"][:nT], z["trj_usage"], "current_power_usage")
@@ -179,16 +194,17 @@ def test_engine_is_deterministic():
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
-@pytest.mark.parametrize("kernel", ["wave", "pipe", "list", "list256", "v2"])
+@pytest.mark.parametrize("kernel", ["wave", "v2"])
 @pytest.mark.parametrize("name,E,lo", [("v2gppl_c50_rand_s9", 131, -1.0), ("pst_rand_s2", 203, 0.0)])
 def test_every_kernel_variant_matches_oracle(kernel, name, E, lo, monkeypatch):
-    """The common shape (P <= 64, one transformer, single-port chargers) has three kernels: the wave-aligned default,
-    the attached-list kernel and the generic one.  All of them must reproduce the oracle, persistent launch included."""
+    """The common shape (P <= 64, one transformer, single-port chargers) can run on two kernels: the wave-aligned default
+    and (EV2G_KERNEL=v2) the general one.  Both must reproduce the oracle, persistent launch included."""
     from ev2gym_amd.engine import host_uniform
     from oracle.oracle import Oracle
     monkeypatch.setenv("EV2G_KERNEL", kernel)
     batch, rk, sk = _tiled(name, E)
     eng = _engine(batch, rk, sk, flags=4)
+    assert eng.kernel_name == _expected_kernel(batch, sk, rk, forced_v2=(kernel == "v2"))
     ora = Oracle(batch, rk, sk)
     P, D, T = eng.P, eng.D, eng.T
     K = T
