@@ -17,12 +17,7 @@ import sqlite3, sys
 out = sys.argv[1]
 con=sqlite3.connect(f'{out}/kt/kt_results.db')
 print("## kernel trace (--kernel-trace --stats): name | calls | total us | avg us | %")
-for r in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 8"): print("KT |", r[0][:70], "|", r[1], "|", round(r[2]/1e3,1), "|", round(r[3]/1e3,3), "|", round(r[4],2))
-# the step kernel's launches by grid-size / duration class (persistent 112-step launches vs single steps share one name)
-try:
-    rows = list(con.execute("select (end-start) from kernels k join rocpd_info_kernel_symbol s on k.kernel_id = s.id where s.kernel_name like '%ev2g_step_%'"))
-except Exception:
-    rows = []
+for r in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 8"): print("KT |", r[0][:70], "|", r[1], "|", round(r[2],1), "|", round(r[3],3), "|", round(r[4],2))
 print("## PMC, average per dispatch of the step kernel")
 for d in ['pmc1','pmc2','pmc3','pmc4']:
     try:
