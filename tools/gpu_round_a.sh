@@ -18,9 +18,6 @@ except Exception as e: print('ERR',e); print(open(sys.argv[1].replace('.json','.
 P
 done
 bash tools/prof_step.sh cfg2_persistent --launch persistent > $O/prof_cfg2_persistent.txt 2>&1
-bash tools/prof_step.sh cfg2_per_step --launch per_step > $O/prof_cfg2_per_step.txt 2>&1
-bash tools/prof_step.sh cfg3 --workload cfg3 --launch persistent > $O/prof_cfg3.txt 2>&1
-bash tools/prof_step.sh cfg4 --workload cfg4 --launch persistent --steps 224 --warmup 28 > $O/prof_cfg4.txt 2>&1
 python tools/phase_timing.py cfg2 > $O/phase_cfg2.txt 2>&1
 python tools/phase_timing.py cfg2 --outer > $O/phase_cfg2_outer.txt 2>&1
 tail -30 $O/phase_cfg2.txt
