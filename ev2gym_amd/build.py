@@ -9,7 +9,10 @@ SRC = os.path.join(HERE, "csrc", "ev2g_host.hip")
 DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("ev2g_device.h", "ev2g_step_v2.h", "ev2g_step_wave.h")] + [
     os.path.join(HERE, "..", "include", "ev2g.h")]
 # -ffp-contract=off: the reference's operation order must survive (EV.my_ceil, ev.py:188-189)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# -disable-machine-licm: the step kernels sit at the 128-VGPR / 4-waves-per-SIMD boundary; machine LICM hoists the constant
+#   materialisations of the inlined float64 exp / division sequences out of the step loop and the register allocator then
+#   spills them to scratch and reloads them inside the dependent chain of the battery maths (measured: DESIGN.md §3)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-mllvm", "-disable-machine-licm"]
 
 
 def hipcc():
@@ -19,6 +22,10 @@ def hipcc():
     raise RuntimeError("hipcc not found: the EV2Gym step engine is HIP-only (gfx950)")
 
 
+def extra_drop(extra):
+    return [f[len("--drop="):] for f in extra if f.startswith("--drop=")]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -26,7 +33,12 @@ def needs_build():
     return any(os.path.getmtime(d) > m for d in DEPS)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, out=None, extra=()):
+    """Build the library in-tree; `out` / `extra` produce A/B variants (tools/ab_bench.py) next to it."""
+    if out is not None:
+        cmd = [hipcc()] + [f for f in FLAGS if f not in extra_drop(extra)] + [f for f in extra if not f.startswith("--drop=")] + ["-o", out, SRC]
+        subprocess.check_call(cmd)
+        return out
     if force or needs_build():
         cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC]
         if verbose:

@@ -120,6 +120,8 @@ struct StepIO {
     // offset by scn_stride (0: re-arm the same scenarios)
     int scn_off, scn_stride;
     int step0;   // index of this launch's first step inside the caller's ev2g_step_n run (offsets the extras' step strides)
+    int log_soc; // EV2G_FLAG_LOG_SOC (the fast path's prologue reads it from here: no parameter-block fetch on its first round trip)
+    const float *act32;   // StepExtras::act32 when `actions` is null (same reason)
 };
 
 // optional extra step outputs / inputs (ev2g_set_step_extras), device-resident next to the kernel parameter block: they are

@@ -42,6 +42,7 @@ struct ev2g_handle {
     std::vector<double> sess_afap;              // [S] host order
     long long *d_env_sess = nullptr;            // unused placeholder for the stats kernel signature
     double *d_ss_afap = nullptr;                // [S] device order
+    double *d_step_tab = nullptr;               // [M,T,8] (fast path)
     V2P *d_v2p = nullptr;                       // device copy of the v2 kernel's parameter block
     int block = 0;                              // 256/512/1024: v2 kernel; 0: generic kernel (P > 1024)
     bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
@@ -535,6 +536,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         s.win_tab = tab;
     }
     double *d_step_tab = nullptr;
+    h->d_step_tab = nullptr;
     if (h->wave_path) {   // R == 1: [M,T] series interleaved per (env, step)
         const size_t n = (size_t)M * T * 8;
         HIPCHK(h, hipMalloc((void **)&d_step_tab, n * sizeof(double)));
@@ -542,6 +544,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         const int nb = (int)std::min<size_t>(((size_t)M * T + 255) / 256, 4096);
         hipLaunchKernelGGL(ev2g_build_step_table_kernel, dim3(nb), dim3(256), 0, h->stream, s, d_step_tab);
         HIPCHK(h, hipGetLastError());
+        h->d_step_tab = d_step_tab;
     }
     double *d_head_tab = nullptr;
     if (h->wave_path && sk != EV2G_STATE_PUBLIC_PST) {
@@ -665,16 +668,25 @@ static StepIO make_io(const ev2g_handle *h, const double *actions, long long a_s
     io.scn_off = (int)h->scn_off;
     io.scn_stride = (auto_reset == EV2G_AUTO_RESET_NEXT) ? h->E % h->M : 0;
     io.step0 = (int)step0;
+    io.log_soc = (h->cfg.flags & EV2G_FLAG_LOG_SOC) ? 1 : 0;
+    io.act32 = actions ? nullptr : h->extras.actions_f32;
     return io;
 }
 
 static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int auto_reset) {
     const DevScn &s = h->scn;
     if (h->wave_path) {
+        // the fast path advances its output pointers by 32-bit byte strides
+        const long long lim = 1ll << 32;
+        const ev2g_step_extras &x = h->extras;
+        if (io.a_stride * 8 >= lim || io.o_stride * 8 >= lim || io.r_stride * 8 >= lim || io.d_stride >= lim || io.m_stride >= lim ||
+            x.cost_step_stride * 8 >= lim || x.obs_f32_step_stride * 4 >= lim || io.a_stride < 0 || io.o_stride < 0 || io.r_stride < 0 ||
+            io.d_stride < 0 || io.m_stride < 0 || x.cost_step_stride < 0 || x.obs_f32_step_stride < 0)
+            return fail(h, EV2G_ERR_ARG, "ev2g_step_n: a step stride is negative or reaches 4 GiB (unsupported by the fast-path kernel)");
         const V2P *pp = (const V2P *)h->d_v2p;
         const DevState &st = h->st;
         const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
-                          st.env_acc, s.cs_imax, s.cs_dmax_abs, s.cs_imin, s.cs_dmin, s.cs_maxp, s.cs_minp};
+                          st.env_acc, s.cs_imax, s.cs_dmax_abs, s.cs_imin, s.cs_dmin, s.cs_maxp, s.cs_minp, h->d_step_tab};
 #define EV2G_WAVE_CASE(SK, RK)                                                                                              \
     case SK * 3 + RK:                                                                                                       \
         if (!io.actions)                                                                                                    \

@@ -30,7 +30,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or _LIB_PATH
+    path = path or os.environ.get("EV2G_LIB") or _LIB_PATH   # EV2G_LIB: A/B builds of the library (tools/ab_bench.py)
     # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME).  If ours were loaded
     # first from /opt/rocm, torch would later bring up a second runtime and fail with "No HIP GPUs are available";
     # importing torch first makes the dynamic linker resolve our DT_NEEDED libamdhip64.so.7 to torch's copy.

@@ -11,6 +11,12 @@ pytestmark = pytest.mark.gpu
 CFG = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "ev2gym_amd", "example_config_files")
 
 
+def _window(env):
+    """The scenarios the envs of an EV2GymVec are running right now: a window of its resident pool."""
+    e = env.engine
+    return env.scenarios.select((np.arange(e.E) + e.scenario_offset) % e.M)
+
+
 def _close(a, b, what, tol=1e-9):
     a, b = np.asarray(a, float), np.asarray(b, float)
     err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
@@ -87,8 +93,8 @@ def test_vec_env_from_yaml_matches_oracle(cfg, sf, rf, use_torch):
     from oracle.oracle import Oracle
     env = EV2GymVec(config_file=os.path.join(CFG, cfg), num_envs=96, state_function=sf, reward_function=rf, seed=3,
                     auto_reset=True, use_torch=use_torch)
-    ora = Oracle(env.scenarios, _abi.REWARD_KINDS[rf], _abi.STATE_KINDS[sf])
     obs, _ = env.reset()
+    ora = Oracle(_window(env), _abi.REWARD_KINDS[rf], _abi.STATE_KINDS[sf])
     to_np = lambda x: x.cpu().numpy() if hasattr(x, "cpu") else (x.to_host() if hasattr(x, "to_host") else np.asarray(x))  # noqa: E731
     _close(to_np(obs), ora.reset(), "reset obs")
     agent = RandomAgent(seed=5)
@@ -108,7 +114,8 @@ def test_vec_env_from_yaml_matches_oracle(cfg, sf, rf, use_torch):
     # auto_reset: the terminal step returns the reset observation, the terminal one rides in info, stats are per env
     _close(to_np(info["terminal_observation"]), o_obs, "terminal obs")
     st = ora.stats()
-    _close(to_np(obs), ora.reset(), "obs after auto-reset")
+    ora2 = Oracle(_window(env), _abi.REWARD_KINDS[rf], _abi.STATE_KINDS[sf])   # the auto-reset drew fresh scenarios from the pool
+    _close(to_np(obs), ora2.reset(), "obs after auto-reset")
     _close(info["total_profits"], st[:, 1], "total_profits")
     _close(info["total_reward"], st[:, 16], "total_reward")
     assert env.current_step == 0
@@ -130,11 +137,11 @@ def test_sb3_vec_env_protocol_matches_oracle(use_torch):
     sf, rf = "V2G_profit_max_loads", "ProfitMax_TrPenalty_UserIncentives"
     venv = EV2GymSB3VecEnv(config_file=os.path.join(CFG, "V2GProfitPlusLoads.yaml"), num_envs=24, state_function=sf,
                            reward_function=rf, seed=9, use_torch=use_torch, obs_dtype=np.float64)
-    ora = Oracle(venv.vec.scenarios, _abi.REWARD_KINDS[rf], _abi.STATE_KINDS[sf])
     E, P, T = venv.num_envs, venv.vec.number_of_ports, venv.vec.simulation_length
     assert venv.observation_space.shape == (venv.vec.obs_dim,) and venv.action_space.shape == (P,)
     assert venv.env_is_wrapped(object) == [False] * E and venv.get_attr("simulation_length", 0) == [T]
     obs = venv.reset()
+    ora = Oracle(_window(venv.vec), _abi.REWARD_KINDS[rf], _abi.STATE_KINDS[sf])
     assert isinstance(obs, np.ndarray) and obs.shape == (E, venv.vec.obs_dim)
     _close(obs, ora.reset(), "reset obs")
     rng = np.random.default_rng(4)
@@ -157,6 +164,8 @@ def test_sb3_vec_env_protocol_matches_oracle(use_torch):
             _close(np.array([i["total_profits"] for i in infos]), st[:, 1], "total_profits")
             _close(np.array([i["episode"]["r"] for i in infos]), ret, "episode return")
             assert all(i["episode"]["l"] == T and i["TimeLimit.truncated"] is False for i in infos)
+            ora.close()   # the reset inside step_wait drew fresh scenarios from the pool
+            ora = Oracle(_window(venv.vec), _abi.REWARD_KINDS[rf], _abi.STATE_KINDS[sf])
             _close(obs, ora.reset(), "obs after reset inside step_wait")
         else:
             assert "terminal_observation" not in infos[0]
@@ -226,30 +235,44 @@ def test_unfused_builtin_rewards_through_the_facade(name):
 
 
 def test_reset_with_a_seed_draws_that_seeds_scenarios():
-    """reset(seed=s) == constructing with seed s (the reference draws its scenario inside reset, ev2gym_env.py:243-296);
-    reset() without a seed re-arms what is loaded."""
+    """The reference draws a scenario inside every reset (ev2gym_env.py:243-296).  Facade: reset(seed=s) == constructing with
+    seed s; reset() moves on to a new scenario, reproducibly for equal constructor seeds.  EV2GymVec: reset(seed=s) selects a
+    window of the resident pool, reproducibly for equal constructor seeds."""
     from ev2gym_amd.env import EV2Gym
     from ev2gym_amd.vec_env import EV2GymVec
     cfg = os.path.join(CFG, "V2GProfitPlusLoads.yaml")
     kw = dict(state_function="V2G_profit_max_loads", reward_function="ProfitMax_TrPenalty_UserIncentives")
     a = EV2Gym(config_file=cfg, seed=5, **kw)
     b = EV2Gym(config_file=cfg, seed=9, **kw)
+    first_a = a._arr["charge_price"].copy()
     assert not np.array_equal(a._arr["ev_t_arr"], b._arr["ev_t_arr"]) or not np.array_equal(a._arr["charge_price"], b._arr["charge_price"])
     ob, _ = b.reset(seed=5)
-    oa, _ = a.reset()
-    assert np.array_equal(oa, ob) and len(a.EVs_profiles) == len(b.EVs_profiles)
+    oa, _ = a.reset(seed=5)
+    assert np.array_equal(oa, ob) and len(a.EVs_profiles) == len(b.EVs_profiles) and np.array_equal(a._arr["charge_price"], first_a)
     rng = np.random.default_rng(0)
     for t in range(40):
         act = rng.uniform(-1, 1, a.number_of_ports)
         ra, rb = a.step(act.copy()), b.step(act.copy())
         assert np.array_equal(ra[0], rb[0]) and ra[1] == rb[1]
-    a.close(); b.close()
+    # reset() without a seed: a NEW scenario (the reference's behaviour), the same one for envs built with the same seed
+    c = EV2Gym(config_file=cfg, seed=5, **kw)
+    a.reset(seed=5)
+    a.reset(); c.reset()
+    assert not np.array_equal(a._arr["charge_price"], first_a) or len(a.EVs_profiles) != len(b.EVs_profiles)
+    assert np.array_equal(a._arr["charge_price"], c._arr["charge_price"]) and np.array_equal(a._arr["ev_t_arr"], c._arr["ev_t_arr"])
+    a.resample_on_reset = False     # opt out: reset() re-arms the current scenario
+    cur = a._arr["charge_price"].copy()
+    a.reset()
+    assert np.array_equal(a._arr["charge_price"], cur)
+    a.close(); b.close(); c.close()
     v1 = EV2GymVec(config_file=cfg, num_envs=16, seed=3, use_torch=False, **kw)
-    v2 = EV2GymVec(config_file=cfg, num_envs=16, seed=4, use_torch=False, **kw)
-    o2, _ = v2.reset(seed=3)
-    o1, _ = v1.reset()
-    assert np.array_equal(o1, o2)
+    v2 = EV2GymVec(config_file=cfg, num_envs=16, seed=3, use_torch=False, **kw)
+    o2, _ = v2.reset(seed=11)
+    o1, _ = v1.reset(seed=11)
+    assert np.array_equal(o1, o2) and v1.engine.scenario_offset == v2.engine.scenario_offset
     act = rng.uniform(-1, 1, (16, v1.number_of_ports))
     s1, s2 = v1.step(act), v2.step(act)
     assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[1], s2[1])
+    offs = {v1.reset(seed=k) and v1.engine.scenario_offset for k in range(12)}
+    assert len(offs) > 6, "different seeds select different windows of the pool"
     v1.close(); v2.close()

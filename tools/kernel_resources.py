@@ -11,8 +11,9 @@ SRC = os.path.join(ROOT, "ev2gym_amd", "csrc", "ev2g_host.hip")
 
 def main():
     extra = sys.argv[1:]
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/_ev2g_res.so", SRC] + extra
+    sys.path.insert(0, ROOT)
+    from ev2gym_amd import build
+    cmd = [build.hipcc()] + build.FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/_ev2g_res.so", SRC] + extra
     out = subprocess.run(cmd, capture_output=True, text=True).stderr
     rows, cur = [], None
     for line in out.splitlines():
