@@ -686,7 +686,7 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         const V2P *pp = (const V2P *)h->d_v2p;
         const DevState &st = h->st;
         const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
-                          st.env_acc, s.cs_imax, s.cs_dmax_abs, s.cs_imin, s.cs_dmin, s.cs_maxp, s.cs_minp, h->d_step_tab};
+                          st.env_acc, s.cs_imax, s.cs_dmax_abs, s.cs_imin, s.cs_dmin, s.cs_maxp, s.cs_minp};
 #define EV2G_WAVE_CASE(SK, RK)                                                                                              \
     case SK * 3 + RK:                                                                                                       \
         if (!io.actions)                                                                                                    \

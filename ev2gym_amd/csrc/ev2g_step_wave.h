@@ -1,7 +1,7 @@
 // ev2g_step_wave.h -- fast path of the step kernel for the common shape: P <= 64 ports per env, one transformer,
 // single-port chargers (BASELINE cfg2 / cfg3 / cfg5 and the reference's shipped YAML files).
 //
-// Same phases and the same arithmetic as ev2g_step_v2 (ev2g_step_v2.h), with these structural differences:
+// Same phases and the same arithmetic as ev2g_step_v2 (ev2g_step_v2.h), with two structural differences:
 //   * WAVE-ALIGNED envs: a wavefront owns EPW = 64 / P whole envs (lanes [0, EPW*P)).  Everything that concerns one
 //     env after the battery maths -- departures / arrivals, observation columns, the per-env reduction, transformer
 //     overload, reward, observation head -- then happens inside ONE wavefront, ordered by s_waitcnt only.  Only the
@@ -9,12 +9,6 @@
 //     barriers instead of five or six.
 //   * specialised at compile time on the fused (state, reward) plugin pair, so the plugin branches, their loads and
 //     their registers disappear.
-//   * QUIET STEPS: while no port of the workgroup holds an EV or is about to receive one (nights: ~40 % of a workplace
-//     episode, at the same steps in every env) a step is only its env-level part -- no list, no battery maths, no
-//     reduction, no barrier (see the loop).
-//   * uniform bookkeeping is kept scalar and cheap: every per-step output address is a running pointer (one 64-bit scalar
-//     add per step), optional outputs are one flag word, rarely used base pointers are fetched from the parameter block in
-//     the rare branch that needs them.
 // The reduction is still LDS-staged and fixed-order (8 quantities x 8 lanes, two chains, 3 xor steps), i.e.
 // bit-reproducible, and identical in value to the generic kernel's (same tree).
 #pragma once
@@ -23,13 +17,10 @@
 #ifndef EV2G_WAVE_BLOCK
 #define EV2G_WAVE_BLOCK 256
 #endif
-#ifndef EV2G_ABLATE   /* tuning builds only (tools/ab_bench.py): bit mask of phases whose work is skipped to read their marginal cost */
-#define EV2G_ABLATE 0
-#endif
 
 __host__ __device__ inline size_t ev2g_wave_lds_bytes(int envs_per_group) {
     const size_t NS = EV2G_WAVE_BLOCK;
-    return sizeof(double) * (EV2G_NQ * (NS + 8) + 7 * NS + 8 * (size_t)envs_per_group + 6 * 64) + sizeof(int) * (6 * NS + 8);
+    return sizeof(double) * (EV2G_NQ * (NS + 8) + 7 * NS + 6 * (size_t)envs_per_group + 4 * 64) + sizeof(int) * (6 * NS + 8);
 }
 
 // Global accesses as  uniform base (an SGPR pair) + 32-bit unsigned BYTE offset (one VGPR):  the
@@ -52,7 +43,6 @@ template <class T, class B> __device__ __forceinline__ void stg32(B base, unsign
 typedef double d2v __attribute__((ext_vector_type(2)));   // builtin vectors: loadable from any address space
 typedef int i2v __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
-typedef int i4v __attribute__((ext_vector_type(4)));
 // The battery-maths part of the record (its first 96 bytes) in one memory round trip: 6 x 16-byte loads issued back to back, then pinned by an empty asm so
 // that the compiler cannot sink the ones a later branch does not need behind that branch (it otherwise loads the
 // two gate fields first and the rest only after testing them: two dependent round trips).
@@ -66,19 +56,6 @@ template <class B> __device__ __forceinline__ SessRec ldg32_rec(B base, unsigned
     return u.r;
 }
 
-// Minimum of a 32-bit value over the 64 lanes of the wavefront (every lane must execute it), returned uniform: three DPP
-// butterflies inside each 8-lane group, a row mirror for the 16-lane rows (VALU cross-lane moves), then the four row results
-// through readlane + scalar min.  (An LDS atomic min from all lanes is one instruction, but the LDS serialises its 64
-// same-address updates.)
-__device__ __forceinline__ int wave_min_i32(int v) {
-    v = min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));   // row_half_mirror
-    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));   // row_mirror
-    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-
 // What the launch prologue needs, BY VALUE: with it the first data loads depend on one fetch (the kernarg segment)
 // instead of two (kernarg -> parameter block).  A launch starts with cold caches, so every dependent fetch in the
 // prologue is a full memory round trip -- paid per step by single-step launches.
@@ -88,15 +65,10 @@ struct WaveArgs {
     double *slab_hist; unsigned long long hist_slice;
     double *env_acc;
     const double *cs_imax, *cs_dmax_abs, *cs_imin, *cs_dmin, *cs_maxp, *cs_minp;
-    const double *step_tab;   // [M,T,8] per (scenario, step) scalars: the first step's prices are part of the prologue's round trip
 };
 
-// optional outputs / modes of a launch, one uniform word (tested with scalar bit compares)
-enum { WF_OBS = 1, WF_OBS32 = 2, WF_MASK = 4, WF_REW = 8, WF_DONE = 16, WF_COST = 32, WF_LOGSOC = 64, WF_LOGCS = 128,
-       WF_COST_PROFIT = 256, WF_SATPEN = 512 };
-
-// IO32: the actions are float32 (StepExtras::act32) -- the policy-network interface; float32 observations (StepExtras::obs32)
-// are written whenever that pointer is set, in either instantiation.
+// IO32: the actions are float32 (StepIO::act32) -- the policy-network interface; float32 observations (StepIO::obs32) are
+// written whenever that pointer is set, in either instantiation.
 template <int SK, int RK, bool IO32>
 __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
                                                                      int k_steps, int auto_reset, WaveArgs wa) {
@@ -108,16 +80,15 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     ParamPtr S = (ParamPtr)(unsigned long long)params;
     constexpr int NS = EV2G_WAVE_BLOCK;
     constexpr int RS = NS + 8;   // stage row stride: +16 banks per row, so the 8 rows one reduction read touches spread over all banks
-    constexpr int NHEAD = (SK == 1) ? 0 : (SK == 0 ? 60 : 20);   // observation head: 20 prices (+ 40 window columns)
-    constexpr int NPAIR = NHEAD / 2;
     const int P = wa.P, T = wa.T, E = wa.E, D = wa.D, M = wa.M;
     int off = io.scn_off;   // scenario-pool window: env e runs scenario (e + off) mod M
-    // state slabs (ev2g_device.h): every [E*P] array is slabP + k * PS8, the three [T,E] histories slabH + k * HS8 -- used by
-    // the prologue / epilogue and by rare branches only; inside the step loop they are re-read from the parameter block
-    const gptr slabP = (gptr)wa.slab_port;
-    const unsigned long long PS8 = wa.slab_port_slice;
+    // state slabs (ev2g_device.h): every [E*P] array is slabP + k * PS8, the three [T,E] histories slabH + k * HS8, the
+    // two per-session result arrays slabS + k * SS8 -- scalar adds on three base pointers instead of one pointer fetch
+    // from the parameter block per array and use
+    const gptr slabP = (gptr)wa.slab_port, slabH = (gptr)wa.slab_hist, slabS = (gptr)S->slab_sess;
+    const unsigned long long PS8 = wa.slab_port_slice, HS8 = wa.hist_slice, SS8 = S->sess_slice;
+    const gptr env_acc = (gptr)wa.env_acc;
 #define PA(k) (slabP + PS8 * (unsigned long long)(k))
-#define PAS(k) ((gptr)S->slab_port + S->slab_port_slice * (unsigned long long)(k))   /* the same, fetched where a rare branch needs it */
     const int EPW = 64 / P;   // envs per wavefront
     const int G = (EV2G_WAVE_BLOCK / 64) * EPW;    // envs per workgroup
     int grp;
@@ -130,15 +101,15 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     double *s_cap = stage + (size_t)EV2G_NQ * RS;
     double *s_tot = s_cap + NS, *s_prev = s_tot + NS, *s_bcap = s_prev + NS, *s_potc = s_bcap + NS;
     double *s_amps = s_potc + NS, *s_abse = s_amps + NS;
-    double *eacc = s_abse + NS;                            // [G][8] per env: episode accumulators, charge_power_potential[t],
-                                                           // and (6,7) this step's {charge, discharge} price for the battery-maths lanes
-    double *s_cst = eacc + 8 * G;                          // [6][64] per-charger gates, clamps and current limits (launch constants
-                                                           // kept out of the register file): imin-0.01, dmin, max power, min power, imax, |dmax|
-    int *s_ta = (int *)(s_cst + 6 * 64);
+    double *eacc = s_abse + NS;                            // [G][6] episode accumulators + charge_power_potential[t], per env
+    double *s_cst = eacc + 6 * G;                          // [4][64] per-charger gates and clamps (rarely changing operands
+                                                           // kept out of the register file): imin-0.01, dmin, max power, min power
+    int *s_ta = (int *)(s_cst + 4 * 64);
     int *s_td = s_ta + NS, *s_ss = s_td + NS, *s_cyc = s_ss + NS, *s_dirty = s_cyc + NS, *items = s_dirty + NS;
     int *cnt = items + NS;  // cnt[2*(kk&1) + {0 charge, 1 discharge}]
-    int *wq = cnt + 4;      // [4] per wavefront: the first step at which one of its ports needs a full step (see "quiet steps")
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const bool log_soc = S->soc_log != nullptr;
+    const bool log_cs = S->cs_profits != nullptr;   // EV2G_FLAG_LOG_CS_HISTORY: charger-level accumulators and histories (ev2gym_env.py:533-535)
     const double dtd = (double)S->dt, sixty_over_dt = S->sixty_over_dt, dt_over_60 = S->dt_over_60;
     const bool pow2_dt = S->pow2_dt != 0;
 
@@ -149,44 +120,32 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     const bool valid = (elw < EPW) && (e < E);
     const int g = valid ? e * P + q : 0;
     const int ocol = (SK == 1) ? 3 + 3 * q : (SK == 0 ? 62 + 2 * q : 22 + 2 * q);
+    const int cs = valid ? q : 0;
     int t = t0;
     const bool head = valid && q == 0;   // one lane per env: env-level scalars
     const int elg = wv * EPW + elw;      // env inside the workgroup
     // ---- launch prologue.  A single-step launch (the RL loop with a policy between steps) pays it every step, with
     // cold caches: occupancy windows, charger constants, the first action and the env accumulators are fetched in one
     // round trip (unconditional, clamped loads), the per-EV state in a second one, only where an EV is attached.
-    double a_next;   // this lane's action of the coming step and
-    d2v pf_price;    // its env's {charge, discharge} price: both fetched one step ahead (phase C of the step before, or the prologue)
+    double c_imax, c_dmaxabs, a_next;
     {
-        const unsigned g8 = (unsigned)g * 8u, cp8 = (unsigned)min(tid, P - 1) * 8u;
+        const unsigned g8 = (unsigned)g * 8u, c8 = (unsigned)cs * 8u, cp8 = (unsigned)min(tid, P - 1) * 8u;
         const unsigned ec = (unsigned)(valid ? e : e0);
-        const gptr slabH = (gptr)wa.slab_hist, env_acc = (gptr)wa.env_acc;
         i2v w = ldg32<i2v>(PA(EV2G_PS_WIN), g8), sc = ldg32<i2v>(PA(EV2G_PS_SC), g8);
         int lut0 = ldg32<int>(PA(EV2G_PS_LUT), g8 >> 1);
-        double k_imax = ldg32<double>(wa.cs_imax, cp8), k_dmaxabs = ldg32<double>(wa.cs_dmax_abs, cp8);
+        c_imax = ldg32<double>(wa.cs_imax, c8); c_dmaxabs = ldg32<double>(wa.cs_dmax_abs, c8);
         double k_imin = ldg32<double>(wa.cs_imin, cp8), k_dmin = ldg32<double>(wa.cs_dmin, cp8);
         double k_maxp = ldg32<double>(wa.cs_maxp, cp8), k_minp = ldg32<double>(wa.cs_minp, cp8);
-        // (everything this first round trip reads is addressed from kernel arguments alone: no parameter-block fetch ahead of it)
-        a_next = IO32 ? (double)ldg32<float>((gcptr)io.act32 + (unsigned long long)(unsigned)io.step0 * ((unsigned)io.a_stride * 4u), (unsigned)(valid ? g : e0 * P) * 4u)
+        a_next = IO32 ? (double)ldg32<float>(S->x_act32 + (long long)io.step0 * io.a_stride, (unsigned)(valid ? g : e0 * P) * 4u)
                       : ldg32<double>(io.actions, (unsigned)(valid ? g : e0 * P) * 8u);
-        d2v pr0 = ldg32<d2v>(wa.step_tab, ((unsigned)(ev2g_scn((int)ec, off, M) * T) + (unsigned)min(t, T - 1)) * 64u);
-        double l_pot = ldg32<double>(slabH + wa.hist_slice, ((unsigned)min(t, T - 1) * (unsigned)E + ec) * 8u);
+        double l_pot = ldg32<double>(slabH + HS8, ((unsigned)min(t, T - 1) * (unsigned)E + ec) * 8u);
         d2v acc01 = ldg32<d2v>(env_acc, ec * 64u), acc23 = ldg32<d2v>(env_acc, ec * 64u + 16u);
         double acc4 = ldg32<double>(env_acc, ec * 64u + 32u);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w), "+v"(sc), "+v"(lut0), "+v"(k_imax), "+v"(k_dmaxabs), "+v"(k_imin), "+v"(k_dmin),
-                     "+v"(k_maxp), "+v"(k_minp), "+v"(a_next), "+v"(l_pot), "+v"(acc01), "+v"(acc23), "+v"(acc4), "+v"(pr0));
-        pf_price = pr0;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w), "+v"(sc), "+v"(lut0), "+v"(c_imax), "+v"(c_dmaxabs), "+v"(k_imin), "+v"(k_dmin),
+                     "+v"(k_maxp), "+v"(k_minp), "+v"(a_next), "+v"(l_pot), "+v"(acc01), "+v"(acc23), "+v"(acc4));
         if (tid < P) {
             s_cst[0 * 64 + tid] = k_imin - 0.01; s_cst[1 * 64 + tid] = k_dmin;
             s_cst[2 * 64 + tid] = k_maxp; s_cst[3 * 64 + tid] = k_minp;
-            s_cst[4 * 64 + tid] = k_imax; s_cst[5 * 64 + tid] = k_dmaxabs;
-        }
-        // quiet steps: the first step at which a port needs more than the env-level part of a step -- 0 while an EV is attached,
-        // t_arr - 1 (the step at whose end it arrives) while one is expected, never otherwise.  Minimum per wavefront, published
-        // in LDS; every wavefront reads all four after the next barrier.
-        {
-            const int m = wave_min_i32(valid ? ((w.x <= t && t <= w.y) ? 0 : w.x - 1) : EV2G_INT_MAX);
-            if (lane == 0) wq[wv] = m;
         }
         if (valid) {
             s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = sc.x; s_cyc[tid] = sc.y;
@@ -198,13 +157,13 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 s_cap[tid] = ldg32<double>(PA(EV2G_PS_CAP), g8); s_tot[tid] = ldg32<double>(PA(EV2G_PS_TOT), g8);
                 s_prev[tid] = ldg32<double>(PA(EV2G_PS_PREV), g8);
                 s_bcap[tid] = ldg32<double>(PA(EV2G_PS_BCAP), g8); s_potc[tid] = ldg32<double>(PA(EV2G_PS_POTC), g8);
-                s_abse[tid] = io.log_soc ? ldg32<double>(PA(EV2G_PS_ABSE), g8) : 0.0;
+                s_abse[tid] = log_soc ? ldg32<double>(PA(EV2G_PS_ABSE), g8) : 0.0;
             } else {
                 s_cap[tid] = 0.0; s_tot[tid] = 0.0; s_prev[tid] = 0.0; s_bcap[tid] = 1.0; s_potc[tid] = 0.0; s_abse[tid] = 0.0;
             }
         }
         if (head) {   // episode accumulators (continued from global memory) and charge_power_potential[t], in LDS
-            double *ea = eacc + elg * 8;
+            double *ea = eacc + elg * 6;
             ea[0] = acc01.x; ea[1] = acc01.y; ea[2] = acc23.x; ea[3] = acc23.y; ea[4] = acc4;
             ea[5] = (t < T) ? l_pot : 0.0;
         }
@@ -212,138 +171,6 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     if (tid < 4) cnt[tid] = 0;
     for (int k = 0; k < EV2G_NQ; k++) stage[k * RS + tid] = 0.0;
     __syncthreads();
-
-    // ---- uniform launch state: flags, running output pointers (advanced by one scalar add per step) ----
-    unsigned wf = 0;
-    gptr obs_p = (gptr)io.obs, mask_p = (gptr)io.mask, rew_p = (gptr)io.reward, done_p = (gptr)io.done;
-    gptr o32_p = (gptr)S->x_obs32, cost_p = (gptr)S->x_cost, soc_p = (gptr)S->soc_log;
-    gcptr act_p = IO32 ? (gcptr)io.act32 : (gcptr)io.actions;
-    // byte strides per step; the host admits this kernel only while each of them fits 32 bits
-    const unsigned o_sb = (unsigned)io.o_stride * 8u, m_sb = (unsigned)io.m_stride, r_sb = (unsigned)io.r_stride * 8u, d_sb = (unsigned)io.d_stride;
-    const unsigned a_sb = (unsigned)io.a_stride * (IO32 ? 4u : 8u);
-    const unsigned o32_sb = (unsigned)S->x_o32_stride * 4u, c_sb = (unsigned)S->x_c_stride * 8u;
-    const unsigned soc_sb = (unsigned)(E * P) * 8u;
-    {
-        if (obs_p) wf |= WF_OBS;
-        if (o32_p) wf |= WF_OBS32;
-        if (mask_p) wf |= WF_MASK;
-        if (rew_p) wf |= WF_REW;
-        if (done_p) wf |= WF_DONE;
-        if (cost_p) wf |= WF_COST;
-        if (soc_p) wf |= WF_LOGSOC;
-        if (S->cs_profits) wf |= WF_LOGCS;   // EV2G_FLAG_LOG_CS_HISTORY: charger-level accumulators and histories (ev2gym_env.py:533-535)
-        if (S->cost_kind == 2) wf |= WF_COST_PROFIT;
-        if (RK != 1 || S->cost_kind == 1) wf |= WF_SATPEN;
-        const unsigned s0 = (unsigned)io.step0;   // extras count their steps from the start of the caller's ev2g_step_n run
-        o32_p += (unsigned long long)s0 * o32_sb; cost_p += (unsigned long long)s0 * c_sb;
-        if (IO32) act_p += (unsigned long long)s0 * a_sb;
-        soc_p += (unsigned long long)(unsigned)t0 * soc_sb;
-    }
-    const bool log_soc = (wf & WF_LOGSOC) != 0;
-
-
-    // ---- env-level part of a step (phase E): Transformer.reset + step + get_how_overloaded (transformer.py:258-302), reward,
-    // histories, accumulators, observation head.  `usage .. emg` are the env's reduced quantities (all +0.0 in a quiet step);
-    // n0..n4 / pp the env's episode accumulators and charge_power_potential[t], kept by the caller.
-    auto env_level = [&](const int tt, const bool last, const int e_l, const int q_l, const int scn, const double usage,
-                         const double costs, const double satsum, const double potn, const double ech, const double edis,
-                         const double emg, const d2v tr, const double ob0, const d2v h0v, const d2v h1v, double &n0, double &n1,
-                         double &n2, double &n3, double &n4, double &pp) __attribute__((always_inline)) {
-        const int ss_ = tt + 1;
-        const gptr slabH = (gptr)wa.slab_hist;
-        const unsigned HS8 = (unsigned)wa.hist_slice;
-        const double pf_base = tr.x, pf_maxp = tr.y;
-        // {min_power, setpoint} from the next lane (wave_shl:1 -- the head lane's neighbour always belongs to the same env)
-        const double pf_minp = dpp_mov_f64<0x130>(tr.x), pf_sp = dpp_mov_f64<0x130>(tr.y);
-        const double tr_power = pf_base + usage;   // inflexible_load[t] + solar_power[t] + sum of the charger powers
-        const double over = (tr_power > pf_maxp + 0.0001 || tr_power < pf_minp - 0.0001) ? fabs(tr_power - pf_maxp) : 0.0;
-        if (P >= 3) {
-            // the three history entries of the step in ONE store: lane 0 of the env writes usage[t], lane 1 the overload
-            // (handed over by a DPP wave shift), lane 2 potential[t+1] -- not three stores with one active lane each
-            const double over_n = dpp_mov_f64<0x138>(over);   // wave_shr:1: lane L takes lane L-1's value
-            if (valid && q_l < 3 && (q_l != 2 || ss_ < T)) {
-                const double hv = (q_l == 0) ? usage : ((q_l == 1) ? over_n : potn);
-                const unsigned hoff = (q_l == 0) ? 0u : ((q_l == 1) ? 2u * HS8 : HS8);
-                const unsigned hstep = (q_l == 2) ? (unsigned)ss_ : (unsigned)tt;
-                stg32<double>(slabH, hoff + (hstep * (unsigned)E + (unsigned)e_l) * 8u, hv);
-            }
-        }
-        if (head) {
-            const unsigned e8 = (unsigned)e_l * 8u;
-            if (last) stg32<double>(S->tr_power_now, e8, tr_power);
-            if (P < 3) {   // two-port envs: no third lane to share the history stores with
-                stg32<double>(slabH, 2u * HS8 + ((unsigned)tt * (unsigned)E) * 8u + e8, over);
-                stg32<double>(slabH, ((unsigned)tt * (unsigned)E) * 8u + e8, usage);
-                if (ss_ < T) stg32<double>(slabH, HS8 + ((unsigned)ss_ * (unsigned)E) * 8u + e8, potn);
-            }
-            double reward;
-            if (RK == 1) {  // SquaredTrackingErrorReward reward.py:7-14
-                const double m = (pp < pf_sp) ? pp : pf_sp;
-                const double d = m - usage;
-                reward = -(d * d);
-            } else if (RK == 2) {  // profit_maximization reward.py:78-87
-                reward = costs - satsum;
-            } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
-                reward = costs - 100.0 * over - satsum;
-            }
-            n0 += reward; n1 += costs; n2 += ech; n3 += edis; n4 += emg; pp = potn;
-            if (wf & WF_REW) stg32<double>(rew_p, e8, reward);
-            if (wf & WF_DONE) stg32<uint8_t>(done_p, (unsigned)e_l, (ss_ >= T) ? 1 : 0);
-            if (wf & WF_COST)   // cost_function (rl_agent/cost.py:8-27)
-                stg32<double>(cost_p, e8, (wf & WF_COST_PROFIT) ? costs : 100.0 * over + satsum);
-            if (ss_ >= T || last) {  // publish the running episode totals (get_statistics reads them)
-                const gptr env_acc = (gptr)wa.env_acc;
-                const unsigned a8 = (unsigned)e_l * 64u;
-                stg32<d2v>(env_acc, a8, (d2v){n0, n1});
-                stg32<d2v>(env_acc, a8 + 16u, (d2v){n2, n3});
-                stg32<double>(env_acc, a8 + 32u, n4);
-            }
-        }
-        if (valid && (wf & WF_OBS)) {
-            const unsigned o8 = (unsigned)(e_l * D) * 8u;
-            if (SK == 1) {  // PublicPST state.py:6-35
-                if (q_l == 0) {
-                    stg32<double>(obs_p, o8, (double)ss_ / (double)T);
-                    stg32<double>(obs_p, o8 + 8u, (ss_ < T) ? ob0 : 0.0);
-                    stg32<double>(obs_p, o8 + 16u, usage);
-                }
-            } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135: columns 2.. are a copy of the head table row
-                if (q_l == 0) stg32<d2v>(obs_p, o8, (d2v){(double)ss_, usage});
-                if (q_l < NPAIR) stg32<d2v>(obs_p, o8 + 16u + (unsigned)q_l * 16u, h0v);
-                if (q_l + P < NPAIR) stg32<d2v>(obs_p, o8 + 16u + (unsigned)(q_l + P) * 16u, h1v);
-                if (2 * P < NPAIR) {   // tiny envs (P < 15): the remaining pairs, unprefetched
-                    const unsigned h8 = (unsigned)((scn * (T + 1) + ss_) * NHEAD) * 8u;
-                    for (int pi = q_l + 2 * P; pi < NPAIR; pi += P)
-                        stg32<d2v>(obs_p, o8 + 16u + (unsigned)pi * 16u, ldg32<d2v>(S->head_tab, h8 + (unsigned)pi * 16u));
-                }
-            }
-        }
-        if (valid && (wf & WF_OBS32)) {
-            const unsigned o4 = (unsigned)(e_l * D) * 4u;
-            if (SK == 1) {
-                if (q_l == 0) {
-                    stg32<float>(o32_p, o4, (float)((double)ss_ / (double)T));
-                    stg32<float>(o32_p, o4 + 4u, (float)((ss_ < T) ? ob0 : 0.0));
-                    stg32<float>(o32_p, o4 + 8u, (float)usage);
-                }
-            } else {
-                if (q_l == 0) stg32<f2v>(o32_p, o4, (f2v){(float)ss_, (float)usage});
-                if (q_l < NPAIR) stg32<f2v>(o32_p, o4 + 8u + (unsigned)q_l * 8u, (f2v){(float)h0v.x, (float)h0v.y});
-                if (q_l + P < NPAIR) stg32<f2v>(o32_p, o4 + 8u + (unsigned)(q_l + P) * 8u, (f2v){(float)h1v.x, (float)h1v.y});
-                if (2 * P < NPAIR) {
-                    const unsigned h8 = (unsigned)((scn * (T + 1) + ss_) * NHEAD) * 8u;
-                    for (int pi = q_l + 2 * P; pi < NPAIR; pi += P) {
-                        const d2v hv = ldg32<d2v>(S->head_tab, h8 + (unsigned)pi * 16u);
-                        stg32<f2v>(o32_p, o4 + 8u + (unsigned)pi * 8u, (f2v){(float)hv.x, (float)hv.y});
-                    }
-                }
-            }
-        }
-    };
-    // one scalar add per running pointer and step
-    auto advance = [&]() __attribute__((always_inline)) {
-        obs_p += o_sb; o32_p += o32_sb; mask_p += m_sb; rew_p += r_sb; done_p += d_sb; cost_p += c_sb; soc_p += soc_sb;
-    };
 
     PT_DECL
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
@@ -362,42 +189,39 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         if (t >= T) {  // episode finished inside a fused run: in-kernel ev2g_reset for this workgroup
             if (!auto_reset) break;
             off = ev2g_scn(off, io.scn_stride, M);
-            soc_p = (gptr)S->soc_log;
-            int attn_l = EV2G_INT_MAX;
             if (valid) {
                 const unsigned gs8 = (unsigned)(ev2g_scn(e_l, off, M) * P + q_l) * 8u;   // this port in the scenario pool
                 const i2v w = ldg32<i2v>(S->port_first_win, gs8);
-                attn_l = w.x - 1;
                 s_ta[tid_l] = w.x; s_td[tid_l] = w.y; s_ss[tid_l] = ldg32<int>(S->port_first, gs8 >> 1); s_cyc[tid_l] = 0;
                 s_cap[tid_l] = 0.0; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_abse[tid_l] = 0.0; s_dirty[tid_l] = 3;
-                stg32<double>(PAS(EV2G_PS_PENERGY), g8, 0.0);
-                stg32<double>(PAS(EV2G_PS_PCURRENT), g8, 0.0);
-                stg32<double>(PAS(EV2G_PS_SATSUM), g8, 0.0);   // single-port chargers: charger index == port index
-                stg32<int>(PAS(EV2G_PS_SERVED), g8 >> 1, 0);
-                if (wf & WF_LOGCS) {
+                stg32<double>(PA(EV2G_PS_PENERGY), g8, 0.0);
+                stg32<double>(PA(EV2G_PS_PCURRENT), g8, 0.0);
+                stg32<double>(PA(EV2G_PS_SATSUM), g8, 0.0);   // single-port chargers: charger index == port index
+                stg32<int>(PA(EV2G_PS_SERVED), g8 >> 1, 0);
+                if (log_cs) {   // single-port chargers: charger index == port index
                     stg32<double>(S->cs_profits, g8, 0.0); stg32<double>(S->cs_e_ch, g8, 0.0); stg32<double>(S->cs_e_dis, g8, 0.0);
                 }
             }
             if (head) {
-                for (int i = 0; i < 8; i++) stg32<double>(S->env_acc, (unsigned)e_l * 64u + (unsigned)i * 8u, 0.0);
-                for (int i = 0; i < 6; i++) eacc[elg * 8 + i] = 0.0;
-            }
-            {
-                const int m = wave_min_i32(attn_l);
-                if (lane_l == 0) wq[tid_l >> 6] = m;
+                for (int i = 0; i < 8; i++) stg32<double>(env_acc, (unsigned)e_l * 64u + (unsigned)i * 8u, 0.0);
+                for (int i = 0; i < 6; i++) eacc[elg * 6 + i] = 0.0;
             }
             t = 0;
         }
+        double *obs = io.obs ? io.obs + (long long)kk * io.o_stride : nullptr;       // uniform bases (scalar arithmetic)
+        float *obs32 = S->x_obs32 ? (float *)S->x_obs32 + (long long)(io.step0 + kk) * S->x_o32_stride : nullptr;
+        uint8_t *mask = io.mask ? io.mask + (long long)kk * io.m_stride : nullptr;
         const int sstep = t + 1;
         const bool last_step = (kk == k_steps - 1) || (sstep >= T && !auto_reset);
         int *cntk = cnt + 2 * (kk & 1);
 
         // ---------------- A: home lanes, charger level (ev_charger.py:137-186) ----------------
-        bool occ = false, item = false;
-        if (head) *(d2v *)(eacc + elg * 8 + 6) = pf_price;   // the step's prices, for the lanes that do this env's battery maths
-        if (valid && !(EV2G_ABLATE & 16)) {
+        bool occ = false;
+        double cap_before = 0.0;
+        if (valid) {
             const int ta = s_ta[tid_l], td = s_td[tid_l];
             occ = (ta <= t) && (t <= td);
+            if (log_soc && occ) cap_before = s_cap[tid_l];
             double a = occ ? a_next : 0.0;
             // one port per charger: a / sum(a) = a / a, which is exactly +-1 for every finite action (ev_charger.py:143-149)
             if (a > 1.0) a = 1.0;
@@ -405,23 +229,50 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             double amps = 0.0;
             if (occ) {
                 const double x = rnd5_x(a);
-                if (x > 0.0) { amps = x * s_cst[4 * 64 + q_l]; if (amps < s_cst[0 * 64 + q_l]) amps = 0.0; }
-                else if (x < 0.0) { const double c_dmin = s_cst[1 * 64 + q_l]; amps = x * s_cst[5 * 64 + q_l]; if (amps > c_dmin - 0.01) amps = c_dmin; }
+                if (x > 0.0) { amps = x * c_imax; if (amps < s_cst[0 * 64 + q_l]) amps = 0.0; }
+                else if (x < 0.0) { const double c_dmin = s_cst[1 * 64 + q_l]; amps = x * c_dmaxabs; if (amps > c_dmin - 0.01) amps = c_dmin; }
             }
             s_amps[tid_l] = amps;
             stage[0 * RS + tid_l] = 0.0;
-            stage[1 * RS + tid_l] = 0.0;
             stage[4 * RS + tid_l] = 0.0;
             stage[5 * RS + tid_l] = 0.0;
             stage[6 * RS + tid_l] = 0.0;
             stage[7 * RS + tid_l] = 0.0;
-            item = amps != 0.0;   // list entry: home lane | env inside the workgroup << 8
-            if (item) items[(amps > 0.0) ? atomicAdd(&cntk[0], 1) : NS - 1 - atomicAdd(&cntk[1], 1)] = tid_l | (elg << 8);
+            if (amps != 0.0) items[(amps > 0.0) ? atomicAdd(&cntk[0], 1) : NS - 1 - atomicAdd(&cntk[1], 1)] = tid_l;
         }
         PT_MARK(0)
+        // ---- prefetch what the rest of this step needs (collected before the stores of phase C) ----
+        // Every prefetch is ONE unconditional load from a clamped (always valid) address; the conditions are applied
+        // where the value is consumed.  A load inside a divergent branch whose result merges with a default makes the
+        // compiler serialise on the destination register (write-after-write) with a full vmcnt(0) drain.
+        const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
         const int ec = valid ? e_l : e0;   // clamped env for idle lanes
+        const int gc = valid ? g_l : e0 * P;
+        a_next = IO32 ? (double)ldg32_nt<float>(S->x_act32 + (long long)(io.step0 + (more ? kk + 1 : kk)) * io.a_stride, (unsigned)gc * 4u)
+                      : ldg32_nt<double>(io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride, (unsigned)gc * 8u);
         const int scn = ev2g_scn(ec, off, M);             // this env's scenario in the resident pool
         const unsigned eT64 = (unsigned)(scn * T) * 64u;  // its rows in the [M,T,8] step table
+        const unsigned et64 = eT64 + (unsigned)t * 64u;
+        const d2v st0 = ldg32_nt<d2v>(S->step_tab, et64);                                  // charge price, discharge price
+        double pf_pch = st0.x, pf_pdis = st0.y;
+        // the transformer scalars only the head lane needs: ONE more load in which the head lane (q == 0) takes
+        // {inflexible + solar, max_power} and its neighbour takes {min_power, setpoint}; the head lane picks the
+        // neighbour's pair up with a DPP wave shift in phase E
+        d2v pf_tr = ldg32_nt<d2v>(S->step_tab, et64 + ((q_l == 0) ? 16u : 32u));
+        // observation head columns of this env, distributed over its P lanes as 16-byte column PAIRS: pair q, q+P
+        double pf_ob0 = 0.0;
+        d2v pf_h0 = {0.0, 0.0}, pf_h1 = {0.0, 0.0};
+        constexpr int NHEAD = (SK == 1) ? 0 : (SK == 0 ? 60 : 20);   // 20 prices (+ 40 window columns)
+        constexpr int NPAIR = NHEAD / 2;
+        if (SK == 1) {
+            pf_ob0 = ldg32_nt<double>(S->step_tab, eT64 + (unsigned)min(sstep, T - 1) * 64u + 40u);   // next setpoint; head lane only, masked by sstep < T
+        } else {
+            // observation head table [E, T+1, NHEAD]: |charge price| window (zero-padded) + load/PV/limit window, exactly
+            // the values of columns 2..2+NHEAD of the observation emitted at the end of step sstep-1 (state.py:65-83, :108-135)
+            const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
+            pf_h0 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l, NPAIR - 1) * 16u);
+            if (P < NPAIR) pf_h1 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l + P, NPAIR - 1) * 16u);   // (uniform)
+        }
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
         PT_MARK(0)
 #else
@@ -431,157 +282,6 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         PT_MARK(1)
         if (tid_l < 2) cnt[2 * ((kk + 1) & 1) + tid_l] = 0;   // next step's counters (last used two barriers ago)
 
-        // ---------------- quiet steps ----------------
-        // While no port of this workgroup holds an EV or is about to receive one (workplace nights and early mornings:
-        // ~40 % of an episode, at the same steps in every env of a config) a step is its env-level part only: transformer
-        // overload, reward, histories, the observation head and zero port columns.  All four wavefronts read the same four
-        // attention steps after the same barrier, so they take this branch together and meet again at the next barrier;
-        // inside, nothing crosses wavefronts: no list, no battery maths, no reduction, no barrier.
-#ifndef EV2G_NO_QUIET
-        {
-            const i4v wqv = *(const i4v *)wq;
-            const int attn = __builtin_amdgcn_readfirstlane(min(min(wqv.x, wqv.y), min(wqv.z, wqv.w)));
-            if (t < attn) {   // (uniform)
-                const int nq = min(min(attn, T) - t, k_steps - kk);
-                double *ea = eacc + elg * 8;
-                double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0, n4 = 0.0, pp = 0.0;
-                if (head) { n0 = ea[0]; n1 = ea[1]; n2 = ea[2]; n3 = ea[3]; n4 = ea[4]; pp = ea[5]; }
-                // A quiet step is a few dozen instructions -- far shorter than a memory round trip -- and loads and stores retire
-                // through ONE in-order counter: a step that waits for its own table rows also waits for the stores of the step
-                // before it.  So the steps go in BATCHES: the rows of QB steps are fetched together, collected by one wait,
-                // then the QB steps' stores are issued back to back from registers.
-                constexpr int QB = 4;
-                auto q_emit = [&](const int tj, const d2v tr, const double ob0, const d2v h0v) __attribute__((always_inline)) {
-                    // the env-level part (phase E, env_level above) with every port sum an exact +0.0, zero port columns, mask 0
-                    const int sj = tj + 1;
-                    const bool lastj = (kk + (tj - t) == k_steps - 1) || (sj >= T && !auto_reset);
-                    const gptr slabH = (gptr)wa.slab_hist;
-                    const unsigned HS8 = (unsigned)wa.hist_slice;
-                    const double pf_minp = dpp_mov_f64<0x130>(tr.x), pf_sp = dpp_mov_f64<0x130>(tr.y);
-                    const double tr_power = tr.x + 0.0;
-                    const double over = (tr_power > tr.y + 0.0001 || tr_power < pf_minp - 0.0001) ? fabs(tr_power - tr.y) : 0.0;
-                    const double over_n = dpp_mov_f64<0x138>(over);
-                    if (valid && q_l < 3 && (q_l != 2 || sj < T)) {   // usage[t] = 0 | overload[t] | potential[t+1] = 0
-                        const unsigned hoff = (q_l == 0) ? 0u : ((q_l == 1) ? 2u * HS8 : HS8);
-                        const unsigned hstep = (q_l == 2) ? (unsigned)sj : (unsigned)tj;
-                        stg32<double>(slabH, hoff + (hstep * (unsigned)E + (unsigned)e_l) * 8u, (q_l == 1) ? over_n : 0.0);
-                    }
-                    if (head) {
-                        const unsigned e8 = (unsigned)e_l * 8u;
-                        if (lastj) stg32<double>(S->tr_power_now, e8, tr_power);
-                        double reward;
-                        if (RK == 1) { const double m = (pp < pf_sp) ? pp : pf_sp; const double d = m - 0.0; reward = -(d * d); }
-                        else if (RK == 2) reward = 0.0 - 0.0;
-                        else reward = 0.0 - 100.0 * over - 0.0;
-                        n0 += reward; pp = 0.0;
-                        if (wf & WF_REW) stg32<double>(rew_p, e8, reward);
-                        if (wf & WF_DONE) stg32<uint8_t>(done_p, (unsigned)e_l, (sj >= T) ? 1 : 0);
-                        if (wf & WF_COST) stg32<double>(cost_p, e8, (wf & WF_COST_PROFIT) ? 0.0 : 100.0 * over + 0.0);
-                        if (sj >= T || lastj) {
-                            const gptr env_acc = (gptr)wa.env_acc;
-                            const unsigned a8 = (unsigned)e_l * 64u;
-                            stg32<d2v>(env_acc, a8, (d2v){n0, n1});
-                            stg32<d2v>(env_acc, a8 + 16u, (d2v){n2, n3});
-                            stg32<double>(env_acc, a8 + 32u, n4);
-                        }
-                    }
-                    if (valid) {
-                        if (wf & WF_MASK) stg32<uint8_t>(mask_p, (unsigned)g_l, 0);
-                        if (wf & WF_OBS) {
-                            const unsigned o8 = (unsigned)(e_l * D + ocol) * 8u, hd8 = (unsigned)(e_l * D) * 8u;
-                            stg32<d2v>(obs_p, o8, (d2v){0.0, 0.0});
-                            if (SK == 1) {
-                                stg32<double>(obs_p, o8 + 16u, 0.0);
-                                if (q_l == 0) {
-                                    stg32<double>(obs_p, hd8, (double)sj / (double)T);
-                                    stg32<double>(obs_p, hd8 + 8u, (sj < T) ? ob0 : 0.0);
-                                    stg32<double>(obs_p, hd8 + 16u, 0.0);
-                                }
-                            } else {
-                                if (q_l == 0) stg32<d2v>(obs_p, hd8, (d2v){(double)sj, 0.0});
-                                if (q_l < NPAIR) stg32<d2v>(obs_p, hd8 + 16u + (unsigned)q_l * 16u, h0v);
-                            }
-                        }
-                        if (wf & WF_OBS32) {
-                            const unsigned o4 = (unsigned)(e_l * D + ocol) * 4u, hd4 = (unsigned)(e_l * D) * 4u;
-                            stg32<f2v>(o32_p, o4, (f2v){0.f, 0.f});
-                            if (SK == 1) {
-                                stg32<float>(o32_p, o4 + 8u, 0.f);
-                                if (q_l == 0) {
-                                    stg32<float>(o32_p, hd4, (float)((double)sj / (double)T));
-                                    stg32<float>(o32_p, hd4 + 4u, (float)((sj < T) ? ob0 : 0.0));
-                                    stg32<float>(o32_p, hd4 + 8u, 0.f);
-                                }
-                            } else {
-                                if (q_l == 0) stg32<f2v>(o32_p, hd4, (f2v){(float)sj, 0.f});
-                                if (q_l < NPAIR) stg32<f2v>(o32_p, hd4 + 8u + (unsigned)q_l * 8u, (f2v){(float)h0v.x, (float)h0v.y});
-                            }
-                        }
-                        if (wf & WF_LOGCS) {
-                            const unsigned hc8 = ((unsigned)(tj * E + e_l) * (unsigned)P + (unsigned)q_l) * 8u;
-                            stg32<double>(S->cs_power_hist, hc8, 0.0); stg32<double>(S->cs_cur_hist, hc8, 0.0);
-                            if (lastj) { stg32<double>(S->cs_power_now, g8, 0.0); stg32<double>(S->cs_cur_now, g8, 0.0); }
-                        }
-                    }
-                    advance();
-                    PT_MARK(5)
-                    PT_STEP_END(true)
-                };
-                if (SK == 1 || P >= NPAIR) {   // (uniform) every head-column pair has its own lane: the batched form
-                    for (int j = 0; j < nq; j += QB) {
-                        d2v b_tr[QB], b_h0[QB];
-                        double b_ob[QB];
-#pragma unroll
-                        for (int u = 0; u < QB; u++) {   // rows of steps t+j+u (clamped addresses: steps past the run are never used)
-                            const int tj = t + j + u, sj = tj + 1;
-                            b_tr[u] = ldg32_nt<d2v>(S->step_tab, eT64 + (unsigned)min(tj, T - 1) * 64u + ((q_l == 0) ? 16u : 32u));
-                            b_ob[u] = 0.0; b_h0[u] = (d2v){0.0, 0.0};
-                            if (SK == 1) b_ob[u] = ldg32_nt<double>(S->step_tab, eT64 + (unsigned)min(sj, T - 1) * 64u + 40u);
-                            else b_h0[u] = ldg32_nt<d2v>(S->head_tab, (unsigned)((scn * (T + 1) + min(sj, T)) * NHEAD) * 8u + (unsigned)min(q_l, NPAIR - 1) * 16u);
-                        }
-                        // ONE wait per batch, made visible to the compiler's wait-count tracking (the registers are plain values from here on)
-                        __builtin_amdgcn_s_waitcnt(0x0F70);
-#pragma unroll
-                        for (int u = 0; u < QB; u++) asm volatile("" : "+v"(b_tr[u]), "+v"(b_h0[u]), "+v"(b_ob[u]));
-#pragma unroll
-                        for (int u = 0; u < QB; u++)
-                            if (j + u < nq) q_emit(t + j + u, b_tr[u], b_ob[u], b_h0[u]);
-                    }
-                } else {   // small envs whose lanes copy several head-column pairs each: step by step through the general form
-                    for (int j = 0; j < nq; j++) {
-                        const int tj = t + j, sj = tj + 1;
-                        const bool lastj = (kk + j == k_steps - 1) || (sj >= T && !auto_reset);
-                        const d2v q_tr = ldg32_nt<d2v>(S->step_tab, eT64 + (unsigned)tj * 64u + ((q_l == 0) ? 16u : 32u));
-                        const unsigned h8q = (unsigned)((scn * (T + 1) + sj) * NHEAD) * 8u;
-                        const d2v q_h0 = ldg32_nt<d2v>(S->head_tab, h8q + (unsigned)min(q_l, NPAIR - 1) * 16u);
-                        const d2v q_h1 = ldg32_nt<d2v>(S->head_tab, h8q + (unsigned)min(q_l + P, NPAIR - 1) * 16u);
-                        env_level(tj, lastj, e_l, q_l, scn, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, q_tr, 0.0, q_h0, q_h1, n0, n1, n2, n3, n4, pp);
-                        if (valid) {
-                            if (wf & WF_MASK) stg32<uint8_t>(mask_p, (unsigned)g_l, 0);
-                            if (wf & WF_OBS) stg32<d2v>(obs_p, (unsigned)(e_l * D + ocol) * 8u, (d2v){0.0, 0.0});
-                            if (wf & WF_OBS32) stg32<f2v>(o32_p, (unsigned)(e_l * D + ocol) * 4u, (f2v){0.f, 0.f});
-                            if (wf & WF_LOGCS) {
-                                const unsigned hc8 = ((unsigned)(tj * E + e_l) * (unsigned)P + (unsigned)q_l) * 8u;
-                                stg32<double>(S->cs_power_hist, hc8, 0.0); stg32<double>(S->cs_cur_hist, hc8, 0.0);
-                                if (lastj) { stg32<double>(S->cs_power_now, g8, 0.0); stg32<double>(S->cs_cur_now, g8, 0.0); }
-                            }
-                        }
-                        advance();
-                        PT_MARK(5)
-                        PT_STEP_END(true)
-                    }
-                }
-                if (head) { ea[0] = n0; ea[1] = n1; ea[2] = n2; ea[3] = n3; ea[4] = n4; ea[5] = pp; }
-                // the actions and prices of the quiet steps are never read, nor are those of the first full step after them (no
-                // port is occupied during it); that step's phase C fetches the ones after it
-                act_p += (unsigned long long)a_sb * (unsigned)nq;
-                t += nq;
-                kk += nq - 1;
-                continue;
-            }
-        }
-#endif
-
         // ---------------- B: worker lanes, battery maths on the compact list ----------------
         // The wavefronts that hold list items are the critical path of the whole workgroup (the others wait at the next
         // barrier): they issue at raised priority until their items are done.
@@ -589,13 +289,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         {
             const int nch = cntk[0], ndis = cntk[1];
             const int nchp = (nch + 63) & ~63;
-            for (int i = tid_l; i < ((EV2G_ABLATE & 1) ? 0 : nchp + ndis); i += EV2G_WAVE_BLOCK) {
+            for (int i = tid_l; i < nchp + ndis; i += EV2G_WAVE_BLOCK) {
                 int h = -1;
                 if (i < nch) h = items[i];
                 else if (i >= nchp) h = items[NS - 1 - (i - nchp)];
                 if (h >= 0) {
-                    const int elg_h = h >> 8;
-                    h &= 255;
                     const double amps_h = s_amps[h];
                     const int lut_id = (s_dirty[h] >> 8) - 1;
                     // table entry and session record are independent loads: one memory round trip, not two.  The look-up
@@ -606,7 +304,6 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     asm volatile("" : "+v"(lut_raw));
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
-                    const d2v price = *(const d2v *)(eacc + elg_h * 8 + 6);
                     const double lutv = (li >= 0) ? lut_raw : 1.0 / 100.0;
                     const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt, lut_id >= 0);
                     if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
@@ -617,13 +314,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     s_amps[h] = o.energy;
                     if (log_soc) s_abse[h] += fabs(o.energy);
                     stage[0 * RS + h] = o.energy * 60.0 / dtd;
-                    // profit += |E| * price by the sign of the ACTION (ev_charger.py:178,194): the charge price is negative
-                    stage[1 * RS + h] = fabs(o.energy) * (i < nch ? price.x : price.y);
                     stage[(i < nch ? 4 : 5) * RS + h] = fabs(o.energy);
                     stage[6 * RS + h] = (double)o.emerg;
                     stage[7 * RS + h] = o.current;
-                    if (log_soc)   // historic_soc / active_steps (ev.py:156,162,185): the capacity before the step, negated if the step was inactive
-                        stg32<double>(soc_p, (unsigned)((e0 * P) + (h >> 6) * (EPW * P) + (h & 63)) * 8u, (o.current != 0.0) ? cap0 : -cap0);
                 }
             }
         }
@@ -633,69 +326,45 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         PT_MARK(1)
 
         // ---------------- C: home lanes (from here on everything of one env lives in one wavefront) ----------------
-        // ---- prefetch, issued HERE (not before the battery maths: nothing fetched ahead occupies registers across it):
-        //   for phase E of this step: the transformer scalars and the observation head row;
-        //   for phase A of the next step: its actions and prices.
-        // Every prefetch is ONE unconditional load from a clamped (always valid) address; the conditions are applied
-        // where the value is consumed.  Phases C and D (thousands of cycles) cover the round trip; they are collected by one
-        // s_waitcnt vmcnt(0) before phase E.
-        const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
-        const int gc = valid ? g_l : e0 * P;
-        if (more) act_p += a_sb;           // the next step's actions (a run's last step re-reads its own: the value is not used)
-        a_next = IO32 ? (double)ldg32_nt<float>(act_p, (unsigned)gc * 4u) : ldg32_nt<double>(act_p, (unsigned)gc * 8u);
-        const unsigned et64 = eT64 + (unsigned)t * 64u;
-        pf_price = ldg32_nt<d2v>(S->step_tab, eT64 + (unsigned)min(sstep, T - 1) * 64u);   // {charge, discharge} price of step t+1
-        // the transformer scalars only the head lane needs: ONE load in which the head lane (q == 0) takes
-        // {inflexible + solar, max_power} and its neighbour takes {min_power, setpoint}; the head lane picks the
-        // neighbour's pair up with a DPP wave shift in phase E
-        d2v pf_tr = ldg32_nt<d2v>(S->step_tab, et64 + ((q_l == 0) ? 16u : 32u));
-        // observation head columns of this env, distributed over its P lanes as 16-byte column PAIRS: pair q, q+P
-        double pf_ob0 = 0.0;
-        d2v pf_h0 = {0.0, 0.0}, pf_h1 = {0.0, 0.0};
-        if (SK == 1) {
-            pf_ob0 = ldg32_nt<double>(S->step_tab, eT64 + (unsigned)min(sstep, T - 1) * 64u + 40u);   // next setpoint; head lane only, masked by sstep < T
-        } else {
-            // observation head table [M, T+1, NHEAD]: |charge price| window (zero-padded) + load/PV/limit window, exactly
-            // the values of columns 2..2+NHEAD of the observation emitted at the end of step sstep-1 (state.py:65-83, :108-135)
-            const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
-            pf_h0 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l, NPAIR - 1) * 16u);
-            if (P < NPAIR) pf_h1 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l + P, NPAIR - 1) * 16u);   // (uniform)
-        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // collect the prefetches before this phase issues stores (vmcnt(0))
+        // ... and make that visible to the compiler's wait-count tracking: as outputs of this (empty) asm the
+        // prefetched registers are plain values from here on, so their later uses -- after this phase's stores, and
+        // across the loop back-edge for the next action -- no longer cost a conservative vmcnt(0) drain
+        asm volatile("" : "+v"(a_next), "+v"(pf_pch), "+v"(pf_pdis), "+v"(pf_tr), "+v"(pf_ob0), "+v"(pf_h0), "+v"(pf_h1));
         bool occ_any = false;   // an EV on this port before or after the step
-        int attn_l = EV2G_INT_MAX;   // the step at which this port next needs a full step (quiet steps)
-        // this port's observation columns and action-mask bit: computed here, stored with phase E's outputs -- after the
-        // prefetched rows have been collected, so that waiting for those never waits for these stores
-        double o0 = 0.0, o1 = 0.0, o2 = 0.0, cs_pw = 0.0, cs_cur = 0.0;
-        bool occ_aft = false;
-        if (valid && !(EV2G_ABLATE & 2)) {
-            double satpen = 0.0, pot = 0.0;
+        if (valid) {
+            double profit = 0.0, satpen = 0.0, pot = 0.0;
             int ta = s_ta[tid_l], td = s_td[tid_l];
             double cap = s_cap[tid_l];
             if (occ) {
                 const double energy = s_amps[tid_l];
                 const double current = stage[7 * RS + tid_l];
-                if ((wf & WF_LOGCS) && energy != 0.0) {   // charger accumulators (ev_charger.py:178-181,194-197): one lane per charger and step
-                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_profits + g8), stage[1 * RS + tid_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (energy != 0.0) {  // profit by the sign of the ACTION (ev_charger.py:178,194), staged under 4 / 5
+                    const double ech = stage[4 * RS + tid_l];
+                    profit = (ech != 0.0) ? ech * pf_pch : stage[5 * RS + tid_l] * pf_pdis;
+                }
+                if (log_cs && energy != 0.0) {   // charger accumulators (ev_charger.py:178-181,194-197): one lane per charger and step
+                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_profits + g8), profit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_e_ch + g8), stage[4 * RS + tid_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_e_dis + g8), stage[5 * RS + tid_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (current - 0.0001 > s_cst[4 * 64 + q_l]) stg32<int>(S->env_fault, (unsigned)e_l * 4u, 1);  // ev_charger.py:203-205
-                if (last_step) { stg32<double>(PAS(EV2G_PS_PENERGY), g8, energy); stg32<double>(PAS(EV2G_PS_PCURRENT), g8, current); }
-                if (log_soc && !item) stg32<double>(soc_p, g8, -cap);   // an idle EV's step is inactive, its capacity unchanged (the battery-maths lanes log the others)
+                if (current - 0.0001 > c_imax) stg32<int>(S->env_fault, (unsigned)e_l * 4u, 1);  // ev_charger.py:203-205
+                if (last_step) { stg32<double>(PA(EV2G_PS_PENERGY), g8, energy); stg32<double>(PA(EV2G_PS_PCURRENT), g8, current); }
+                if (log_soc) stg32<double>(S->soc_log + (long long)t * E * P, g8, (current != 0.0) ? cap_before : -cap_before);
                 if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
                     const int ss = s_ss[tid_l];
                     const unsigned r8 = (unsigned)ss * (unsigned)sizeof(SessRec);
                     const double des = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, des));
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
-                    if (wf & WF_SATPEN) satpen = 100.0 * exp(-10.0 * score);
+                    if (RK != 1 || S->cost_kind == 1) satpen = 100.0 * exp(-10.0 * score);
                     // fire-and-forget device atomics (no returned value => no memory round trip on this path); exactly one
                     // lane updates a given charger per step, so the result does not depend on any ordering
-                    __hip_atomic_fetch_add((int __attribute__((address_space(1))) *)(PAS(EV2G_PS_SERVED) + (g8 >> 1)), 1,
+                    __hip_atomic_fetch_add((int __attribute__((address_space(1))) *)(PA(EV2G_PS_SERVED) + (g8 >> 1)), 1,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)(PAS(EV2G_PS_SATSUM) + g8), score,
+                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)(PA(EV2G_PS_SATSUM) + g8), score,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    stg32<double>(S->slab_sess, (unsigned)ss * 8u, cap);
-                    if (log_soc) stg32<double>((gptr)S->slab_sess + S->sess_slice, (unsigned)ss * 8u, s_abse[tid_l]);
+                    stg32<double>(slabS, (unsigned)ss * 8u, cap);
+                    if (log_soc) stg32<double>((slabS + SS8), (unsigned)ss * 8u, s_abse[tid_l]);
                     const i2v nx = ldg32<i2v>(S->rec, r8 + (unsigned)offsetof(SessRec, nt_arr));
                     ta = nx.x; td = nx.y;
                     s_ta[tid_l] = ta; s_td[tid_l] = td;
@@ -710,22 +379,21 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 const double B = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, B));
                 const double v = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, v));
                 const double evc = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, pacmax)) * 1000.0 / v;            // utils.py:773-777
-                const double c_imax = s_cst[4 * 64 + q_l];
                 const double potc = v * ((evc < c_imax) ? evc : c_imax) / 1000.0;
                 s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
                 s_abse[tid_l] = 0.0;
                 const int lut_new = ldg32<int>(S->rec, r8 + (unsigned)offsetof(SessRec, lut));
-                stg32<int>(PAS(EV2G_PS_LUT), g8 >> 1, lut_new);
-                stg32<double>(PAS(EV2G_PS_BCAP), g8, B);
-                stg32<double>(PAS(EV2G_PS_POTC), g8, potc);
-                stg32<double>(PAS(EV2G_PS_PENERGY), g8, 0.0);
-                stg32<double>(PAS(EV2G_PS_PCURRENT), g8, 0.0);
+                stg32<int>(PA(EV2G_PS_LUT), g8 >> 1, lut_new);
+                stg32<double>(PA(EV2G_PS_BCAP), g8, B);
+                stg32<double>(PA(EV2G_PS_POTC), g8, potc);
+                stg32<double>(PA(EV2G_PS_PENERGY), g8, 0.0);
+                stg32<double>(PA(EV2G_PS_PCURRENT), g8, 0.0);
                 s_dirty[tid_l] = (s_dirty[tid_l] & 3) | 1 | ((lut_new + 1) << 8);
             }
             const bool occ_after = (ta <= sstep) && (sstep <= td);
             occ_any = occ || occ_after;
-            attn_l = occ_after ? 0 : ta - 1;
-            occ_aft = occ_after;
+            if (mask) stg32<uint8_t>(mask, (unsigned)g_l, occ_after ? 1 : 0);
+            double o0 = 0.0, o1 = 0.0, o2 = 0.0;
             if (occ_after) {
                 const double soc = cap / s_bcap[tid_l];
                 if (SK == 1) { o0 = (soc == 1.0) ? 1.0 : 0.5; o1 = s_tot[tid_l]; o2 = (double)(sstep - ta); }
@@ -736,13 +404,25 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 const double c_maxp = s_cst[2 * 64 + q_l], c_minp = s_cst[3 * 64 + q_l];
                 pot = (pot > c_maxp) ? c_maxp : ((pot < c_minp) ? 0.0 : pot);
             }
-            if (wf & WF_LOGCS) { cs_pw = occ ? stage[0 * RS + tid_l] : 0.0; cs_cur = occ ? stage[7 * RS + tid_l] : 0.0; }
+            if (obs) {
+                const unsigned o8 = (unsigned)(e_l * D + ocol) * 8u;
+                stg32<d2v>(obs, o8, (d2v){o0, o1});   // one 16-byte store (D and the column offset are even for SK != 1)
+                if (SK == 1) stg32<double>(obs, o8 + 16u, o2);
+            }
+            if (obs32) {
+                const unsigned o4 = (unsigned)(e_l * D + ocol) * 4u;
+                if (SK == 1) { stg32<float>(obs32, o4, (float)o0); stg32<float>(obs32, o4 + 4u, (float)o1); stg32<float>(obs32, o4 + 8u, (float)o2); }
+                else stg32<f2v>(obs32, o4, (f2v){(float)o0, (float)o1});
+            }
+            if (log_cs) {   // cs_power / cs_current of the step (ev2gym_env.py:533-535) and the chargers' current_power_output / current_total_amps
+                const double pw = occ ? stage[0 * RS + tid_l] : 0.0, cur = occ ? stage[7 * RS + tid_l] : 0.0;
+                const unsigned hc8 = ((unsigned)(t * E + e_l) * (unsigned)P + (unsigned)q_l) * 8u;
+                stg32<double>(S->cs_power_hist, hc8, pw); stg32<double>(S->cs_cur_hist, hc8, cur);
+                if (last_step) { stg32<double>(S->cs_power_now, g8, pw); stg32<double>(S->cs_cur_now, g8, cur); }
+            }
+            stage[1 * RS + tid_l] = profit;
             stage[2 * RS + tid_l] = satpen;
             stage[3 * RS + tid_l] = pot;
-        }
-        {   // this wavefront's attention step for the coming steps (its own LDS slot: read by the others after the next barrier)
-            const int m = wave_min_i32(attn_l);
-            if (lane_l == 0) wq[tid_l >> 6] = m;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wavefront's LDS writes are visible to itself
         PT_MARK(3)
@@ -754,12 +434,12 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // (stage[k][first port of env w]; only this lane ever reads that slot in this phase), where the head lane --
         // the only consumer of env-level sums -- picks all eight up below.  LDS operations of one wavefront execute in
         // order, so no barrier is involved.
-        // A wavefront whose envs hold no EV before or after this step has nothing to add up: every staged value of its
-        // ports is an exact +0.0.
+        // A wavefront whose envs hold no EV before or after this step (the night half of a workplace episode, the early
+        // morning) has nothing to add up: every staged value of its ports is an exact +0.0.
         double esum[EV2G_NQ];
 #pragma unroll
         for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = 0.0;
-        if (__ballot(occ_any) != 0ull && !(EV2G_ABLATE & 4)) {   // (uniform)
+        if (__ballot(occ_any) != 0ull) {   // (uniform)
         {
             const int k = lane_l >> 3, j = lane_l & 7;
             const int wbase = (tid_l & ~63);
@@ -792,39 +472,100 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
 
         PT_MARK(4)
         // ---------------- E: per env (head lane) + observation head (the env's lanes) ----------------
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // collect phase C's prefetches (vmcnt(0)) ...
-        // ... and make that visible to the compiler's wait-count tracking: as outputs of this (empty) asm the prefetched
-        // registers are plain values from here on (their later uses -- across the loop back-edge -- cost no further drain)
-        asm volatile("" : "+v"(a_next), "+v"(pf_price), "+v"(pf_tr), "+v"(pf_ob0), "+v"(pf_h0), "+v"(pf_h1));
-        {
-            double *ea = eacc + elg * 8;
+        const double usage = esum[0];
+        // {min_power, setpoint} from the next lane (wave_shl:1 -- the head lane's neighbour always belongs to the same env)
+        const double pf_base = pf_tr.x, pf_maxp = pf_tr.y;
+        const double pf_minp = dpp_mov_f64<0x130>(pf_tr.x), pf_sp = dpp_mov_f64<0x130>(pf_tr.y);
+        // Transformer.reset + step + get_how_overloaded (transformer.py:258-302), evaluated wave-wide (meaningful in head lanes)
+        const double tr_power = pf_base + usage;   // inflexible_load[t] + solar_power[t] + sum of the charger powers
+        const double over = (tr_power > pf_maxp + 0.0001 || tr_power < pf_minp - 0.0001) ? fabs(tr_power - pf_maxp) : 0.0;
+        if (P >= 3) {
+            // the three history entries of the step in ONE store: lane 0 of the env writes usage[t], lane 1 the overload
+            // (handed over by a DPP wave shift), lane 2 potential[t+1] -- not three stores with one active lane each
+            const double over_n = dpp_mov_f64<0x138>(over);   // wave_shr:1: lane L takes lane L-1's value
+            if (valid && q_l < 3 && (q_l != 2 || sstep < T)) {
+                const double hv = (q_l == 0) ? usage : ((q_l == 1) ? over_n : esum[3]);
+                const unsigned hoff = (q_l == 0) ? 0u : ((q_l == 1) ? 2u * (unsigned)HS8 : (unsigned)HS8);
+                const unsigned hstep = (q_l == 2) ? (unsigned)sstep : (unsigned)t;
+                stg32<double>(slabH, hoff + (hstep * (unsigned)E + (unsigned)e_l) * 8u, hv);
+            }
+        }
+        if (head) {
+            double *ea = eacc + elg * 6;
             // all six accumulator words are read up front (one LDS wait) and written back together at the end; reading
             // each one next to its update made every update wait for its own LDS round trip
-            double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0, n4 = 0.0, pp = 0.0;
-            if (head) { n0 = ea[0]; n1 = ea[1]; n2 = ea[2]; n3 = ea[3]; n4 = ea[4]; pp = ea[5]; }
-            if (valid && !(EV2G_ABLATE & 2)) {   // phase C's port-level outputs
-                if (wf & WF_MASK) stg32<uint8_t>(mask_p, (unsigned)g_l, occ_aft ? 1 : 0);
-                if (wf & WF_OBS) {
-                    const unsigned o8 = (unsigned)(e_l * D + ocol) * 8u;
-                    stg32<d2v>(obs_p, o8, (d2v){o0, o1});   // one 16-byte store (D and the column offset are even for SK != 1)
-                    if (SK == 1) stg32<double>(obs_p, o8 + 16u, o2);
+            const double ea0 = ea[0], ea1 = ea[1], ea2 = ea[2], ea3 = ea[3], ea4 = ea[4], ea5 = ea[5];
+            const unsigned e8 = (unsigned)e_l * 8u;
+            double over100 = 0.0;
+            if (RK == 0) over100 = 100.0 * over;
+            if (last_step) stg32<double>(S->tr_power_now, e8, tr_power);
+            const double potn = esum[3];
+            if (P < 3) {   // two-port envs: no third lane to share the history stores with
+                stg32<double>((slabH + 2 * HS8) + (long long)t * E * 8, e8, over);
+                stg32<double>(slabH + (long long)t * E * 8, e8, usage);
+                if (sstep < T) stg32<double>((slabH + HS8) + (long long)sstep * E * 8, e8, potn);
+            }
+            const double costs = esum[1];
+            double reward;
+            if (RK == 1) {  // SquaredTrackingErrorReward reward.py:7-14
+                const double pp = ea5;
+                const double m = (pp < pf_sp) ? pp : pf_sp;
+                const double d = m - usage;
+                reward = -(d * d);
+            } else if (RK == 2) {  // profit_maximization reward.py:78-87
+                reward = costs - esum[2];
+            } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
+                reward = costs - over100 - esum[2];
+            }
+            const double n0 = ea0 + reward, n1 = ea1 + costs, n2 = ea2 + esum[4], n3 = ea3 + esum[5], n4 = ea4 + esum[6];
+            ea[0] = n0; ea[1] = n1; ea[2] = n2; ea[3] = n3; ea[4] = n4; ea[5] = potn;
+            if (io.reward) stg32<double>(io.reward + (long long)kk * io.r_stride, e8, reward);
+            if (io.done) stg32<uint8_t>(io.done + (long long)kk * io.d_stride, (unsigned)e_l, (sstep >= T) ? 1 : 0);
+            if (S->x_cost)   // cost_function (rl_agent/cost.py:8-27); the overload weight is applied here when the reward does not carry it
+                stg32<double>(S->x_cost + (long long)(io.step0 + kk) * S->x_c_stride, e8, (S->cost_kind == 2) ? costs : 100.0 * over + esum[2]);
+            if (sstep >= T || last_step) {  // publish the running episode totals (get_statistics reads them)
+                const unsigned a8 = (unsigned)e_l * 64u;
+                stg32<d2v>(env_acc, a8, (d2v){n0, n1});
+                stg32<d2v>(env_acc, a8 + 16u, (d2v){n2, n3});
+                stg32<double>(env_acc, a8 + 32u, n4);
+            }
+        }
+        if (valid && obs32) {
+            const unsigned o4 = (unsigned)(e_l * D) * 4u;
+            if (SK == 1) {
+                if (q_l == 0) {
+                    stg32<float>(obs32, o4, (float)((double)sstep / (double)T));
+                    stg32<float>(obs32, o4 + 4u, (float)((sstep < T) ? pf_ob0 : 0.0));
+                    stg32<float>(obs32, o4 + 8u, (float)usage);
                 }
-                if (wf & WF_OBS32) {
-                    const unsigned o4 = (unsigned)(e_l * D + ocol) * 4u;
-                    if (SK == 1) { stg32<float>(o32_p, o4, (float)o0); stg32<float>(o32_p, o4 + 4u, (float)o1); stg32<float>(o32_p, o4 + 8u, (float)o2); }
-                    else stg32<f2v>(o32_p, o4, (f2v){(float)o0, (float)o1});
-                }
-                if (wf & WF_LOGCS) {   // cs_power / cs_current of the step (ev2gym_env.py:533-535) and the chargers' current_power_output / current_total_amps
-                    const unsigned hc8 = ((unsigned)(t * E + e_l) * (unsigned)P + (unsigned)q_l) * 8u;
-                    stg32<double>(S->cs_power_hist, hc8, cs_pw); stg32<double>(S->cs_cur_hist, hc8, cs_cur);
-                    if (last_step) { stg32<double>(S->cs_power_now, g8, cs_pw); stg32<double>(S->cs_cur_now, g8, cs_cur); }
+            } else {
+                if (q_l == 0) stg32<f2v>(obs32, o4, (f2v){(float)sstep, (float)usage});
+                if (q_l < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)q_l * 8u, (f2v){(float)pf_h0.x, (float)pf_h0.y});
+                if (q_l + P < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)(q_l + P) * 8u, (f2v){(float)pf_h1.x, (float)pf_h1.y});
+                const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
+                for (int pi = q_l + 2 * P; pi < NPAIR; pi += P) {
+                    const d2v hv = ldg32<d2v>(S->head_tab, h8 + (unsigned)pi * 16u);
+                    stg32<f2v>(obs32, o4 + 8u + (unsigned)pi * 8u, (f2v){(float)hv.x, (float)hv.y});
                 }
             }
-            if (!(EV2G_ABLATE & 8)) env_level(t, last_step, e_l, q_l, scn, esum[0], esum[1], esum[2], esum[3], esum[4], esum[5], esum[6], pf_tr, pf_ob0, pf_h0,
-                      pf_h1, n0, n1, n2, n3, n4, pp);
-            if (head) { ea[0] = n0; ea[1] = n1; ea[2] = n2; ea[3] = n3; ea[4] = n4; ea[5] = pp; }
         }
-        advance();
+        if (valid && obs) {
+            const unsigned o8 = (unsigned)(e_l * D) * 8u;
+            if (SK == 1) {  // PublicPST state.py:6-35
+                if (q_l == 0) {
+                    stg32<double>(obs, o8, (double)sstep / (double)T);
+                    stg32<double>(obs, o8 + 8u, (sstep < T) ? pf_ob0 : 0.0);
+                    stg32<double>(obs, o8 + 16u, usage);
+                }
+            } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135: columns 2.. are a copy of the head table row
+                if (q_l == 0) stg32<d2v>(obs, o8, (d2v){(double)sstep, usage});
+                if (q_l < NPAIR) stg32<d2v>(obs, o8 + 16u + (unsigned)q_l * 16u, pf_h0);
+                if (q_l + P < NPAIR) stg32<d2v>(obs, o8 + 16u + (unsigned)(q_l + P) * 16u, pf_h1);
+                const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
+                for (int pi = q_l + 2 * P; pi < NPAIR; pi += P)    // tiny envs (P < 15): the remaining pairs, unprefetched
+                    stg32<d2v>(obs, o8 + 16u + (unsigned)pi * 16u, ldg32<d2v>(S->head_tab, h8 + (unsigned)pi * 16u));
+            }
+        }
         PT_MARK(5)
         PT_STEP_END(cntk[0] + cntk[1] == 0)
         t += 1;
@@ -848,6 +589,4 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     PT_MARK(6)
 #endif
     PT_FLUSH
-#undef PA
-#undef PAS
 }
