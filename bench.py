@@ -140,11 +140,10 @@ class RolloutLoop:
         left = n_steps
         while left > 0:
             t = eng.current_step
+            k = min(left, T - t)
             if self.actor is not None:
-                k = 1
-                self.actor.step(self)
+                self.actor.run(self, k)   # k x (policy forward -> env step)
             else:
-                k = min(left, T - t)
                 eng.step_n(k, self.acts[t], self.E * self.P, self.obs, 0, self.rew, 0, self.done, 0, self.mask, 0,
                            auto_reset=False, persistent=persistent)
             if timing is not None:
@@ -168,9 +167,10 @@ def main():
                     "have been measured per launch mode (median over the repetitions is reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-soc-log", action="store_true", help="skip the SoC log that the battery-degradation statistics need")
-    ap.add_argument("--actor", default="none", choices=["none", "mlp"],
-                    help="mlp: BASELINE configs[4]-shaped rollout -- a torch actor (obs->400->300->P, tanh; SB3-DDPG shape, "
-                         "random weights, fp32) produces the actions on the device between steps (forces per_step launches)")
+    ap.add_argument("--actor", default="none", choices=["none", "mlp", "mlp_torch"],
+                    help="BASELINE configs[4]-shaped rollout: an actor (obs->400->300->P, tanh; SB3-DDPG shape, random weights) "
+                         "produces the actions on the device between steps (forces per_step launches).  mlp: the fused one-kernel "
+                         "forward of the library (bf16 MFMA); mlp_torch: the same network through torch.nn (fp32)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     if args.actor != "none":
@@ -218,9 +218,9 @@ def main():
         gath = AsyncStatsGather(E, world, dev)
 
     actor = None
-    if args.actor == "mlp":
+    if args.actor != "none":
         from ev2gym_amd.actor import make_actor
-        actor = make_actor(eng, E, P, D, wl["lo"], dev, seed=1234 + rank)
+        actor = make_actor(eng, E, P, D, wl["lo"], dev, seed=1234 + rank, kind="fused" if args.actor == "mlp" else "torch")
 
     loop = RolloutLoop(eng, E, P, T, M, acts, obs, rew, done, mask, stats, gath, actor)
 

@@ -17,6 +17,7 @@
 #include "ev2g_device.h"
 #include "ev2g_step_v2.h"
 #include "ev2g_step_wave.h"
+#include "ev2g_mlp.h"
 #include <cstdlib>
 
 static thread_local std::string g_create_error;
@@ -785,6 +786,137 @@ int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, in
             if (r2) return r2;
             h->current_step += 1;
         }
+    }
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return rc;
+}
+
+// ---- policy in the loop -------------------------------------------------------------------------------------------
+struct ev2g_mlp {
+    MlpDev dev{};
+    std::vector<void *> allocs;
+    size_t lds = 0;
+    const void *fn = nullptr;   // the kernel for this shape
+};
+
+// the fixed-shape kernels exist for the layer widths of the shipped configs (obs 162 / 63 -> 400 -> 300 -> ports); anything else
+// runs the generic one
+static const void *mlp_kernel_for(const MlpDev &d) {
+    const int k1 = d.k1 / 16, k2 = d.n1 / 16, k3 = d.n2 / 16;
+    // (the fixed kernels unroll over at most 4 / 3 / 1 column tiles per wavefront: 400 -> 13 tiles, 300 -> 10, ports <= 128)
+    if (d.n1 / 32 > 16 || d.n2 / 32 > 12 || d.n3 / 32 > 4) return (const void *)ev2g_mlp3_any;
+    if (k1 == 11 && k2 == 26 && k3 == 20) return (const void *)ev2g_mlp3_fixed<11, 26, 20>;
+    if (k1 == 4 && k2 == 26 && k3 == 20) return (const void *)ev2g_mlp3_fixed<4, 26, 20>;
+    return (const void *)ev2g_mlp3_any;
+}
+
+static uint16_t host_bf16(float f) {   // round to nearest even (same as the kernel's)
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// torch.nn.Linear weight W[n_out, n_in] -> MFMA B-fragment order [n_tile][k_step][lane][8] (bf16, zero padded):
+// lane l of tile (nt, ks) holds B[k][j] = W[j][k] for j = nt*32 + (l & 31), k = ks*16 + (l >> 5)*8 + 0..7
+static std::vector<uint16_t> pack_linear(const float *W, int n_out, int n_in, int N, int K) {
+    const int NT = N / 32, KS = K / 16;
+    std::vector<uint16_t> p((size_t)NT * KS * 64 * 8, 0);
+    for (int nt = 0; nt < NT; nt++)
+        for (int ks = 0; ks < KS; ks++)
+            for (int l = 0; l < 64; l++) {
+                const int j = nt * 32 + (l & 31);
+                for (int i = 0; i < 8; i++) {
+                    const int k = ks * 16 + (l >> 5) * 8 + i;
+                    if (j < n_out && k < n_in) p[(((size_t)nt * KS + ks) * 64 + l) * 8 + i] = host_bf16(W[(size_t)j * n_in + k]);
+                }
+            }
+    return p;
+}
+
+int ev2g_mlp_create(ev2g_handle *h, int d_in, int h1, int h2, int d_out, const float *W1, const float *b1, const float *W2,
+                    const float *b2, const float *W3, const float *b3, float out_lo, ev2g_mlp **out) {
+    if (!h || !out || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || d_in <= 0 || h1 <= 0 || h2 <= 0 || d_out <= 0)
+        return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create: bad arguments");
+    if (out_lo != -1.0f && out_lo != 0.0f) return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create: out_lo must be -1 or 0");
+    (void)hipSetDevice(h->device);
+    auto up = [](int x, int m) { return (x + m - 1) / m * m; };
+    ev2g_mlp *m = new ev2g_mlp();
+    MlpDev &d = m->dev;
+    d.d_in = d_in; d.h1 = h1; d.h2 = h2; d.d_out = d_out;
+    d.k1 = up(d_in, 16); d.n1 = up(h1, 32); d.n2 = up(h2, 32); d.n3 = up(d_out, 32);
+    d.out_lo = out_lo;
+    d.dbg = nullptr;
+#ifdef EV2G_MLP_TIMING
+    { unsigned long long *p; if (dalloc(h, m->allocs, 8, &p)) { delete m; return EV2G_ERR_HIP; } d.dbg = p; }
+#endif
+    m->lds = ev2g_mlp_lds_bytes(d);
+    if (m->lds > 160 * 1024) { delete m; return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create: layers too wide for the LDS-resident activations"); }
+    int rc = 0;
+    auto upw = [&](const std::vector<uint16_t> &v, const uint16_t **dst) { uint16_t *p; rc = upload(h, m->allocs, v.data(), v.size(), &p); *dst = p; return rc; };
+    auto upb = [&](const float *b, int n, int N, const float **dst) { std::vector<float> v((size_t)N, 0.f); std::copy(b, b + n, v.begin()); float *p; rc = upload(h, m->allocs, v.data(), v.size(), &p); *dst = p; return rc; };
+    if (upw(pack_linear(W1, h1, d_in, d.n1, d.k1), &d.w1) || upw(pack_linear(W2, h2, h1, d.n2, d.n1), &d.w2) ||
+        upw(pack_linear(W3, d_out, h2, d.n3, d.n2), &d.w3) || upb(b1, h1, d.n1, &d.b1) || upb(b2, h2, d.n2, &d.b2) || upb(b3, d_out, d.n3, &d.b3)) {
+        free_pool(m->allocs); delete m; return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // the staging vectors are temporaries
+    m->fn = mlp_kernel_for(d);
+    if (m->lds > 48 * 1024) HIPCHK(h, hipFuncSetAttribute(m->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds));
+    *out = m;
+    return EV2G_OK;
+}
+
+void ev2g_mlp_destroy(ev2g_handle *h, ev2g_mlp *m) {
+    if (!m) return;
+    if (h) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); }
+    free_pool(m->allocs);
+    delete m;
+}
+
+int ev2g_mlp_forward(ev2g_handle *h, const ev2g_mlp *m, const float *x, float *y, int n_rows) {
+    if (!h || !m || !x || !y || n_rows <= 0) return fail(h, EV2G_ERR_ARG, "ev2g_mlp_forward: bad arguments");
+    (void)hipSetDevice(h->device);
+    MlpDev dev = m->dev;
+    void *args[] = {&dev, &x, &y, &n_rows};
+    HIPCHK(h, hipLaunchKernel(m->fn, dim3((n_rows + EV2G_MLP_ROWS - 1) / EV2G_MLP_ROWS), dim3(EV2G_MLP_BLOCK), args, m->lds, h->stream));
+    return EV2G_OK;
+}
+
+#ifdef EV2G_MLP_TIMING
+int ev2g_mlp_debug_stamps(ev2g_handle *h, const ev2g_mlp *m, unsigned long long *out8) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out8, m->dev.dbg, 64, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+
+int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward, int64_t r_stride, uint8_t *done, int64_t d_stride,
+                 uint8_t *mask, int64_t m_stride, int auto_reset) {
+    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_rollout: no scenarios loaded");
+    if (!m || k_steps < 0) return fail(h, EV2G_ERR_ARG, "ev2g_rollout: bad arguments");
+    const ev2g_step_extras &x = h->extras;
+    if (!x.obs_f32 || !x.actions_f32 || x.obs_f32_step_stride != 0)
+        return fail(h, EV2G_ERR_ARG, "ev2g_rollout: register float32 observation (step stride 0) and action buffers with ev2g_set_step_extras first");
+    if (m->dev.d_in != h->D || m->dev.d_out != h->P) return fail(h, EV2G_ERR_ARG, "ev2g_rollout: actor shape != (obs dim, ports)");
+    (void)hipSetDevice(h->device);
+    const long long adv = (auto_reset == EV2G_AUTO_RESET_NEXT) ? h->E % h->M : 0;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    int rc = EV2G_OK;
+    for (int i = 0; i < k_steps; i++) {
+        if (h->current_step >= h->T) {
+            if (!auto_reset) { rc = fail(h, EV2G_ERR_DONE, "ev2g_rollout: episode finished before k_steps (auto_reset off)"); break; }
+            int r2 = ev2g_reset_ex(h, nullptr, h->scn_off + adv);
+            if (r2) return r2;
+        }
+        int r2 = ev2g_mlp_forward(h, m, x.obs_f32, (float *)x.actions_f32, h->E);
+        if (r2) return r2;
+        StepIO io = make_io(h, nullptr, 0, nullptr, 0, reward ? reward + (long long)i * r_stride : nullptr, 0,
+                            done ? done + (long long)i * d_stride : nullptr, 0, mask ? mask + (long long)i * m_stride : nullptr, 0, 0, 0);
+        if (x.cost) io.step0 = i;   // (a cost buffer may record every step; the float32 buffers do not advance)
+        r2 = launch_steps(h, io, h->current_step, 1, 0);
+        if (r2) return r2;
+        h->current_step += 1;
     }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     h->timed = true;

@@ -72,6 +72,10 @@ def load_library(path: Optional[str] = None):
         "ev2g_fill_uniform": (C.c_int, [vp, vp, i64, C.c_uint64, dbl, dbl]),
         "ev2g_host_uniform": (None, [vp, i64, C.c_uint64, dbl, dbl]),
         "ev2g_last_step_n_kernel_ms": (dbl, [vp]),
+        "ev2g_mlp_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, C.POINTER(vp)]),
+        "ev2g_mlp_destroy": (None, [vp, vp]),
+        "ev2g_mlp_forward": (C.c_int, [vp, vp, vp, vp, C.c_int]),
+        "ev2g_rollout": (C.c_int, [vp, vp, C.c_int, vp, i64, vp, i64, vp, i64, C.c_int]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(L, name)  # AttributeError here = the .so does not export what include/ev2g.h declares
@@ -89,7 +93,7 @@ EXPORTED_SYMBOLS = [
     "ev2g_scenario_offset", "ev2g_set_step_extras", "ev2g_kernel_name", "ev2g_fallback_reason", "ev2g_step", "ev2g_step_n",
     "ev2g_check_faults", "ev2g_get_stats", "ev2g_stat_name", "ev2g_peek", "ev2g_malloc", "ev2g_free",
     "ev2g_memcpy_h2d", "ev2g_memcpy_d2h", "ev2g_synchronize", "ev2g_fill_uniform", "ev2g_host_uniform",
-    "ev2g_last_step_n_kernel_ms"]
+    "ev2g_last_step_n_kernel_ms", "ev2g_mlp_create", "ev2g_mlp_destroy", "ev2g_mlp_forward", "ev2g_rollout"]
 
 
 def _ptr(x):
@@ -224,6 +228,29 @@ class Engine:
                                    int(o_stride), _ptr(reward), int(r_stride), _ptr(done), int(d_stride), _ptr(mask),
                                    int(m_stride), int(auto_reset))   # 0 / AUTO_RESET_SAME (True) / AUTO_RESET_NEXT
         self._check(rc)
+
+    # ---- policy in the loop ----------------------------------------------------------------------
+    def mlp_create(self, W1, b1, W2, b2, W3, b3, out_lo=-1.0):
+        """Three-layer actor (torch.nn.Linear layout: W[out,in], b[out]; host float32 arrays) evaluated by one fused kernel."""
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (W1, b1, W2, b2, W3, b3)]
+        h1, d_in = arrs[0].shape
+        h2, d_out = arrs[2].shape[0], arrs[4].shape[0]
+        assert arrs[2].shape == (h2, h1) and arrs[4].shape == (d_out, h2) and arrs[1].shape == (h1,) and arrs[3].shape == (h2,) and arrs[5].shape == (d_out,)
+        m = C.c_void_p()
+        self._check(self._lib.ev2g_mlp_create(self._h, d_in, h1, h2, d_out, *[a.ctypes.data for a in arrs], float(out_lo), C.byref(m)))
+        return m
+
+    def mlp_destroy(self, m):
+        if self._h:
+            self._lib.ev2g_mlp_destroy(self._h, m)
+
+    def mlp_forward(self, m, x, y, n_rows):
+        self._check(self._lib.ev2g_mlp_forward(self._h, m, _ptr(x), _ptr(y), int(n_rows)))
+
+    def rollout(self, m, k, reward=None, r_stride=0, done=None, d_stride=0, mask=None, m_stride=0, auto_reset=0):
+        """k x (actor forward on the registered float32 observation -> float32 actions -> env step), one C call."""
+        self._check(self._lib.ev2g_rollout(self._h, m, int(k), _ptr(reward), int(r_stride), _ptr(done), int(d_stride), _ptr(mask),
+                                           int(m_stride), int(auto_reset)))
 
     def last_step_n_kernel_ms(self) -> float:
         return float(self._lib.ev2g_last_step_n_kernel_ms(self._h))

@@ -265,6 +265,23 @@ typedef struct ev2g_env_view {
 } ev2g_env_view;
 int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *view);
 
+/* ---- policy in the loop (BASELINE configs[4]: an SB3-MlpPolicy-shaped actor produces the actions between steps) ------ */
+/* A three-layer MLP actor  obs[E,d_in] -> ReLU(h1) -> ReLU(h2) -> tanh(d_out)  evaluated by ONE kernel (bf16 MFMA, fp32
+ * accumulation).  Weights are HOST pointers in torch.nn.Linear layout (W[out,in] row-major, b[out]), copied and packed once.
+ * out_lo = -1: actions in [-1,1] (tanh); out_lo = 0: (tanh + 1) / 2, the action box of configs without V2G (ev2gym_env.py:226-231).
+ * The reference has no counterpart: its agents are SB3 objects stepping one CPU env (train_stable_baselines.py:62-130). */
+typedef struct ev2g_mlp ev2g_mlp;
+int ev2g_mlp_create(ev2g_handle *h, int d_in, int h1, int h2, int d_out, const float *W1, const float *b1, const float *W2,
+                    const float *b2, const float *W3, const float *b3, float out_lo, ev2g_mlp **out);
+void ev2g_mlp_destroy(ev2g_handle *h, ev2g_mlp *m);
+/* y[n_rows,d_out] = actor(x[n_rows,d_in]); float32 DEVICE pointers; asynchronous on the handle's stream. */
+int ev2g_mlp_forward(ev2g_handle *h, const ev2g_mlp *m, const float *x, float *y, int n_rows);
+/* K rollout steps enqueued by one call: actor(obs_f32) -> actions_f32 -> EV2Gym.step, K times (the float32 buffers are the ones
+ * registered with ev2g_set_step_extras, obs_f32_step_stride 0; d_in == obs dim, d_out == ports).  reward / done /
+ * action_mask as in ev2g_step_n (mode EV2G_STEPN_PER_STEP_LAUNCH); auto_reset as there. */
+int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward, int64_t reward_step_stride, uint8_t *done,
+                 int64_t done_step_stride, uint8_t *action_mask, int64_t mask_step_stride, int auto_reset);
+
 /* ---- plain device-memory helpers so a ctypes host needs no other HIP binding --------------- */
 void *ev2g_malloc(ev2g_handle *h, size_t bytes);
 void ev2g_free(ev2g_handle *h, void *p);
