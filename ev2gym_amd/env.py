@@ -11,6 +11,7 @@ this facade as its `env` argument -- an explicit slow path, never a silent one.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import numpy as np
@@ -236,8 +237,10 @@ class EV2Gym:
                  lightweight_plots=False, empty_ports_at_end_of_simulation=True, extra_sim_name=None, verbose=False,
                  render_mode=None, scenario: Optional[ScenarioBatch] = None, device: int = 0,
                  log_cs_history: bool = True):
-        if save_replay or save_plots or render_mode:
-            raise NotImplementedError("writing replay pickles, plots and rendering are outside the accelerated path (SURVEY.md §2)")
+        if save_plots or render_mode:
+            raise NotImplementedError("plots and rendering are outside the accelerated path (SURVEY.md §2)")
+        self.save_replay, self.replay_path, self.extra_sim_name = bool(save_replay), replay_save_path, extra_sim_name
+        self.load_from_replay_path = load_from_replay_path
         if scenario is None and load_from_replay_path is not None:   # ev2gym_env.py:102-116
             from .replay import load_replay
             v2g = bool(load_yaml(config_file)["v2g_enabled"]) if config_file is not None else None
@@ -265,6 +268,11 @@ class EV2Gym:
         c = self.config or {}
         self.sim_starting_date = datetime.datetime(2022, 1, 1, int(c.get("hour", 5)), int(c.get("minute", 0)))
         self.sim_date = self.sim_starting_date
+        self.sim_name = (extra_sim_name or "") + "sim_" + datetime.datetime.now().strftime("%Y_%m_%d_%f")   # ev2gym_env.py:163-189
+        if load_from_replay_path is not None:                                 # ev2gym_env.py:106-108
+            self.sim_name = os.path.basename(str(load_from_replay_path)).split("replay_")[-1].split(".")[0] + "_replay"
+        if self.save_replay:
+            os.makedirs(self.replay_path, exist_ok=True)                      # ev2gym_env.py:213-214
         self._bind_scenario(scenario)
         low = -1.0 if self.v2g_enabled else 0.0
         self.action_space = Box(low, 1.0, (self.engine.P,))
@@ -402,8 +410,23 @@ class EV2Gym:
                 self.stats["total_reward"] = self.total_reward
             self.stats["action_mask"] = mask
             self.cost = cost
+            if self.save_replay:
+                self._save_sim_replay()
             return self._last_obs, reward, True, False, self.stats
         return self._last_obs, reward, False, False, {"cost": cost, "action_mask": mask}
+
+    def _save_sim_replay(self):
+        """ev2gym_env.py:503-510: the finished episode as `<replay_save_path>/replay_<sim_name>.pkl`, an EvCityReplay pickle
+        the reference's `EV2Gym(load_from_replay_path=...)` (and this class) loads."""
+        from .replay import write_replay
+        c = self.config or {}
+        path = os.path.join(self.replay_path, f"replay_{self.sim_name}.pkl")
+        stats = {k: v for k, v in (self.stats or {}).items() if k != "action_mask"}
+        write_replay(path, self._batch, 0, run=self._snap(), stats=stats, sim_date=self.sim_starting_date,
+                     scenario=str(c.get("scenario", "workplace")), heterogeneous_specs=bool(c.get("heterogeneous_ev_specs", True)),
+                     sim_name=self.sim_name, replay_path=self.replay_path)
+        print(f"Saving replay file at {path}")
+        return path
 
     def set_cost_function(self, cost_function):
         self.cost_function = cost_function

@@ -76,3 +76,45 @@ def test_replay_object_fields_and_restricted_unpickler():
         read_replay_object(pickle.dumps(Evil()))
     with pytest.raises(pickle.UnpicklingError):
         read_replay_object(b"cbuiltins\neval\n.")
+
+
+# ---- writing (ev2gym_env.py:503-510) -------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", CASES)
+def test_written_replay_round_trips_and_has_the_reference_layout(name, tmp_path):
+    """write_replay -> load_replay gives the same scenario, and the file is a pickle of the reference's own classes with
+    the attribute sets of the file the reference wrote (oracle/check_replay_write.py has the live reference load it and
+    reproduce the fixture trajectory bit-exactly; run in the build container, it needs /root/reference)."""
+    import pickletools
+    from ev2gym_amd.replay import write_replay
+    g = load_golden(name)
+    batch = load_replay(bytes(g["replay_pkl"]))
+    path = write_replay(str(tmp_path / "replay_sim_x.pkl"), batch, scenario="public", sim_name="sim_x")
+    back = load_replay(path)
+    for k, _ in _abi.BATCH_ARRAYS:
+        assert np.array_equal(back.arrays[k], batch.arrays[k], equal_nan=True), k
+    globs = {str(arg) for op, arg, _ in pickletools.genops(open(path, "rb").read()) if op.name in ("GLOBAL", "STACK_GLOBAL")}
+    assert {"ev2gym.models.replay EvCityReplay", "ev2gym.models.ev EV", "ev2gym.models.ev_charger EV_Charger",
+            "ev2gym.models.transformer Transformer"} <= globs
+    assert not any("ev2gym_amd" in s for s in globs)
+    ref, mine = read_replay_object(bytes(g["replay_pkl"])), read_replay_object(path)
+    assert mine.replay_path.split("replay_")[-1].split(".")[0] == "sim_x"       # ev2gym_env.py:106-108 derives sim_name so
+    for a, b in ((ref, mine), (ref.EVs[0], mine.EVs[0]), (ref.charging_stations[0], mine.charging_stations[0]),
+                 (ref.transformers[0], mine.transformers[0])):
+        assert set(a.__dict__) == set(b.__dict__)
+    for k in ("u", "ev_arrival", "t_dep", "energy_at_arrival", "ev_max_energy", "ev_max_ch_power", "ev_max_dis_power",
+              "ev_des_energy", "tra_min_amps", "voltages", "cs_transformer", "charge_prices", "discharge_prices", "power_setpoints"):
+        assert np.array_equal(np.asarray(getattr(mine, k), float), np.asarray(getattr(ref, k), float)), k
+    for k in ("sim_length", "n_cs", "n_transformers", "timescale", "max_n_ports", "cs_transformers", "simulate_grid"):
+        assert getattr(mine, k) == getattr(ref, k), k
+
+
+def test_replay_reader_refuses_classes_outside_its_whitelist():
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    with pytest.raises(pickle.UnpicklingError):
+        read_replay_object(pickle.dumps(Evil()))
+    with pytest.raises(pickle.UnpicklingError):   # a numpy name that is not one of the reconstruction helpers
+        read_replay_object(b"cnumpy\nload\n.")
+    with pytest.raises(pickle.UnpicklingError):   # an ev2gym name that is not a replay class
+        read_replay_object(b"cev2gym.utilities.utils\nprint_statistics\n.")
