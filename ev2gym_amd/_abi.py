@@ -48,7 +48,7 @@ _pl = C.POINTER(C.c_int64)
 BATCH_ARRAYS = [
     ("cs_min_charge_current", C.c_double), ("cs_max_charge_current", C.c_double),
     ("cs_min_discharge_current", C.c_double), ("cs_max_discharge_current", C.c_double),
-    ("cs_voltage", C.c_double), ("cs_phases", C.c_int32), ("cs_transformer", C.c_int32),
+    ("cs_voltage", C.c_double), ("cs_phases", C.c_int32), ("cs_transformer", C.c_int32), ("cs_n_ports", C.c_int32),
     ("charge_price", C.c_double), ("discharge_price", C.c_double), ("power_setpoints", C.c_double),
     ("tr_max_power", C.c_double), ("tr_min_power", C.c_double), ("tr_inflexible_load", C.c_double),
     ("tr_solar_power", C.c_double), ("tr_load_forecast", C.c_double), ("tr_pv_forecast", C.c_double),

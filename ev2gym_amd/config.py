@@ -2,6 +2,11 @@
 keys read in ev2gym_env.py:65-166, loaders.py, utils.py, transformer.py)."""
 from __future__ import annotations
 
+import json
+import os
+import warnings
+
+import numpy as np
 import yaml
 
 from .scenario_gen import GenConfig
@@ -14,22 +19,79 @@ def load_yaml(path_or_dict) -> dict:
         return yaml.load(f, Loader=yaml.FullLoader)
 
 
+def load_topology(path, search_dirs=()) -> dict:
+    """A charging_network_topology JSON (example_config_files/charging_topology_10.json; parsed by the reference in
+    loaders.py:259-276 for the transformers and :312-340 for the chargers) as the generator's per-charger arrays.  Chargers
+    are numbered in file order, a charger's transformer is the index of the transformer entry it sits under."""
+    cands = [path] + [os.path.join(d, os.path.basename(path)) for d in search_dirs]
+    found = next((p for p in cands if os.path.isfile(p)), None)
+    if found is None:
+        raise FileNotFoundError(path)
+    with open(found) as f:
+        topo = json.load(f)
+    keys = ("min_charge_current", "max_charge_current", "min_discharge_current", "max_discharge_current", "voltage", "phases", "n_ports")
+    out = {k: [] for k in keys}
+    out.update(transformer=[], tr_max_power=[])
+    for i, tr in enumerate(topo.values()):
+        out["tr_max_power"].append(float(tr["max_power"]))
+        for ch in tr["charging_stations"].values():
+            if str(ch.get("charger_type", "AC")) != "AC":
+                raise NotImplementedError("DC chargers are outside the accelerated path (EV.step's DC branch, ev.py:165-167)")
+            for k in keys:
+                out[k].append(ch[k])
+            out["transformer"].append(i)
+    return {k: np.asarray(v) for k, v in out.items()}
+
+
+# YAML keys that select real-world data by calendar date in the reference (prices, loads, PV of that day; weekday / weekend
+# arrival tables).  The scenario generator here is synthetic and calendar-free, so they have no counterpart.
+_CALENDAR_KEYS = ("year", "month", "day")
+
+
 def gen_config_from_yaml(cfg, n_envs: int, seed: int = 0) -> GenConfig:
-    """Map the reference YAML keys onto the vectorised generator's config."""
+    """Map the reference YAML keys onto the vectorised generator's config.  Every key of the reference's schema is either
+    passed through, irrelevant off the grid-simulation path, or reported (warning / error) -- none is dropped silently."""
     c = load_yaml(cfg)
-    topo = c.get("charging_network_topology", "None")
-    if topo not in (None, "None"):
-        raise NotImplementedError("charging_network_topology files (heterogeneous chargers) are not supported yet")
     if c.get("simulate_grid", False):
         raise NotImplementedError("simulate_grid: True is outside the accelerated path (SURVEY.md §2 row 14)")
+    if c["scenario"] not in ("workplace", "public"):
+        raise ValueError(f"scenario: '{c['scenario']}' -- the scenario generator has arrival / stay / energy tables for 'workplace' and "
+                         "'public' (the reference's 'private' scenario is not fitted)")
+    if str(c.get("simulation_days", "weekdays")) != "weekdays" and c["scenario"] != "workplace":
+        raise NotImplementedError(f"simulation_days: {c['simulation_days']} -- the generator's tables are fitted on weekdays only")
+    if not c.get("random_day", True):
+        warnings.warn("random_day: False asks for the data of the calendar day " + "-".join(str(c.get(k)) for k in _CALENDAR_KEYS) +
+                      "; the scenario generator is synthetic and calendar-free, so every reset still draws a new day", stacklevel=2)
+    topology = None
+    topo = c.get("charging_network_topology", "None")
+    if topo not in (None, "None"):
+        dirs = [os.path.dirname(cfg)] if isinstance(cfg, str) else []
+        try:
+            topology = load_topology(str(topo), dirs)
+        except FileNotFoundError:      # ev2gym_env.py:182-186 prints this and carries on with the YAML's uniform chargers
+            warnings.warn(f"Did not find file {topo}: using the YAML's number_of_charging_stations / charging_station keys", stacklevel=2)
     cs, ev = c["charging_station"], c["ev"]
+    il, pv, dr = c["inflexible_loads"], c["solar_power"], c["demand_response"]
     specs = str(c.get("ev_specs_file", ""))
     return GenConfig(
         n_envs=n_envs, simulation_length=int(c["simulation_length"]), timescale=int(c["timescale"]),
         number_of_charging_stations=int(c["number_of_charging_stations"]),
         number_of_ports_per_cs=int(c["number_of_ports_per_cs"]),
         number_of_transformers=int(c["number_of_transformers"]), scenario=c["scenario"],
-        spawn_multiplier=float(c["spawn_multiplier"]), hour=int(c["hour"]), v2g_enabled=bool(c["v2g_enabled"]),
+        spawn_multiplier=float(c["spawn_multiplier"]), hour=int(c["hour"]), minute=int(c.get("minute", 0)),
+        random_hour=bool(c.get("random_day", True) and c.get("random_hour", False)), v2g_enabled=bool(c["v2g_enabled"]),
+        topology=topology, tr_seed=int(c.get("tr_seed", -1)),
+        inflexible_loads_capacity_multiplier_mean=float(il.get("inflexible_loads_capacity_multiplier_mean", 1)),
+        inflexible_loads_forecast_mean=float(il.get("forecast_mean", 30)), inflexible_loads_forecast_std=float(il.get("forecast_std", 5)),
+        solar_power_capacity_multiplier_mean=float(pv.get("solar_power_capacity_multiplier_mean", 1)),
+        solar_power_forecast_mean=float(pv.get("forecast_mean", 20)), solar_power_forecast_std=float(pv.get("forecast_std", 5)),
+        dr_events_per_day=int(dr.get("events_per_day", 1)),
+        dr_event_capacity_percentage_mean=float(dr.get("event_capacity_percentage_mean", 35)),
+        dr_event_capacity_percentage_std=float(dr.get("event_capacity_percentage_std", 5)),
+        dr_event_length_minutes_min=int(dr.get("event_length_minutes_min", 60)),
+        dr_event_length_minutes_max=int(dr.get("event_length_minutes_max", 60)),
+        dr_event_start_hour_mean=float(dr.get("event_start_hour_mean", 12)), dr_event_start_hour_std=float(dr.get("event_start_hour_std", 2)),
+        dr_notification_of_event_minutes=int(dr.get("notification_of_event_minutes", 60)),
         discharge_price_factor=float(c["discharge_price_factor"]),
         power_setpoint_enabled=bool(c["power_setpoint_enabled"]),
         power_setpoint_flexiblity=float(c["power_setpoint_flexiblity"]),

@@ -49,6 +49,10 @@ struct DevScn {  // read-only scenario + layout, device pointers
     double dt_over_60;     // timescale / 60   (ev.py:355)
     // slot tables [P] (slot = transformer-major port order)
     const int *slot_port, *slot_cs, *slot_obs, *slot_tr;
+    // chargers whose port counts differ (topology file; generic kernel only): ports [C] and first port [C+1] of every charger, and per
+    // slot the action-mask entry the reference sets for it, i*cs.n_ports + j (ev2gym_env.py:452-457) -- the port itself when counts are equal
+    const int *cs_np, *cs_pbase, *slot_mask;
+    int het;
     // chargers [C]
     const double *cs_imin, *cs_imax, *cs_dmin, *cs_dmax_abs, *cs_volt, *cs_maxp, *cs_minp;
     const double *cs_vk;  // [C,4] voltage*sqrt(k), k = 0..3
@@ -480,6 +484,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 const int2 w = st.win[(long long)e * P + q];
                 const bool occ = (w.x <= t) && (t <= w.y);
                 amask[idx] = occ ? ev2g_action(io, xt.act32, a_off, (long long)e * P + s.slot_port[q]) : 0.0;
+                if (s.het && mask) mask[(long long)e * P + q] = 0;   // entries are OR-ed below: two ports can share one (ev2gym_env.py:452-457)
             }
             __syncthreads();
         }
@@ -501,9 +506,10 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 else if (a < -1.0) a = -a / a;
             } else {
                 a = amask[idx];
-                const int j0 = idx - (pref - cs * npc);  // slot of the charger's port 0 (ports of a charger are adjacent, in port order)
+                const int j0 = idx - (pref - s.cs_pbase[cs]);  // slot of the charger's port 0 (ports of a charger are adjacent, in port order)
+                const int np = s.cs_np[cs];
                 double S = 0.0;
-                for (int j = 0; j < npc; j++) S = S + amask[j0 + j];   // sequential python sum()
+                for (int j = 0; j < np; j++) S = S + amask[j0 + j];   // sequential python sum()
                 if (S > 1.0) a = a / S;
                 else if (S < -1.0) a = -a / S;
             }
@@ -583,7 +589,10 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 st.port_energy[g] = 0.0;
                 st.port_current[g] = 0.0;
             }
-            if (mask) mask[(long long)e * P + pref] = occ_after ? 1 : 0;
+            if (mask) {
+                if (!s.het) mask[(long long)e * P + pref] = occ_after ? 1 : 0;
+                else if (occ_after) mask[(long long)e * P + s.slot_mask[q]] = 1;
+            }
             // per-port observation columns + charge power potential (state.py, utils.py:760-791)
             double o0 = 0.0, o1 = 0.0, o2 = 0.0;
             if (occ_after) {
@@ -634,11 +643,12 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 const int el = idx / P, q = idx - el * P;
                 const int cs = s.slot_cs[q];
                 const int pref = s.slot_port[q];
-                if (pref != cs * npc) continue;  // leader = port 0 of the charger
+                if (pref != s.cs_pbase[cs]) continue;  // leader = port 0 of the charger
+                const int np = s.cs_np[cs];
                 const int e = e0 + el;
                 double pw = 0.0, cur = 0.0, pr = 0.0, ec = 0.0, ed = 0.0, pp = 0.0;
                 bool fault = false;
-                for (int j = 0; j < npc; j++) {  // sequential, port order (ev_charger.py:155-205)
+                for (int j = 0; j < np; j++) {  // sequential, port order (ev_charger.py:155-205)
                     pw += stage[0 * NS + idx + j];
                     cur += stage[1 * NS + idx + j];
                     pr += stage[2 * NS + idx + j];
@@ -652,7 +662,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                     const double mx = s.cs_maxp[cs], mn = s.cs_minp[cs];
                     pp = (pp > mx) ? mx : ((pp < mn) ? 0.0 : pp);
                     stage[4 * NS + idx] = pp;
-                    for (int j = 1; j < npc; j++) stage[4 * NS + idx + j] = 0.0;
+                    for (int j = 1; j < np; j++) stage[4 * NS + idx + j] = 0.0;
                 }
                 if (log_cs) {
                     const long long gc = (long long)e * C + cs;

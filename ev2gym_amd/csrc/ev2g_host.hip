@@ -200,13 +200,33 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: non-positive size");
     if (b->horizon != 20) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: horizon must be 20 (state.py:119,129-132)");
     if (npc > 32) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: more than 32 ports per charger unsupported");
-    const int P = C * npc;
+    // ports of each charger: uniform, or per charger from a topology file (loaders.py:312-340); numbered cumulatively in charger
+    // order like the reference's port_counter (ev2gym_env.py:364-385)
+    std::vector<int> np_of(C, npc), pbase(C + 1, 0);
+    bool het = false;
+    if (b->cs_n_ports) {
+        int mx = 0;
+        for (int c = 0; c < C; c++) {
+            np_of[c] = b->cs_n_ports[c];
+            if (np_of[c] < 1) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: cs_n_ports must be >= 1");
+            mx = std::max(mx, np_of[c]);
+            het = het || np_of[c] != npc;
+        }
+        if (mx != npc) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: ports_per_charger must be the maximum of cs_n_ports");
+    }
+    for (int c = 0; c < C; c++) pbase[c + 1] = pbase[c] + np_of[c];
+    const int P = pbase[C];
+    if (het)   // the reference's action mask is indexed i*cs.n_ports + j (ev2gym_env.py:452-457): past the array it raises IndexError
+        for (int c = 0; c < C; c++)
+            if (c * np_of[c] + np_of[c] > P)
+                return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: this charger order makes the reference's action mask index "
+                                             "i*n_ports+j leave the mask array (ev2gym_env.py:457 raises IndexError); order the chargers by falling port count");
     const long long S = b->env_session_start[M];
     if (S != b->n_sessions || b->env_session_start[0] != 0)
         return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: env_session_start inconsistent with n_sessions");
     if (S > 0x7ffffff0LL) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: too many sessions for 32-bit indices");
     {   // the kernels index with 32-bit ints: every element offset they form must stay below 2^31
-        const long long lim = 0x7fffffffLL, Pq = (long long)C * npc;
+        const long long lim = 0x7fffffffLL, Pq = P;
         const long long Dq = 3 + 3 * Pq > 22 + 40LL * R + 2 * Pq ? 3 + 3 * Pq : 22 + 40LL * R + 2 * Pq;
         const bool log_cs = (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) != 0;
         if ((long long)M * Pq > lim || (long long)M * Dq > lim || (long long)M * R * (T + 1) * 40 > lim ||
@@ -226,18 +246,19 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     h->loaded = false;
 
     // ---- slot order: transformer-major, chargers in id order inside a transformer, ports adjacent ----
-    std::vector<int> slot_port(P), slot_cs(P), slot_tr(P), slot_obs(P), port_slot(P), tr_seg(R + 1, 0), tr_obs(R);
+    std::vector<int> slot_port(P), slot_cs(P), slot_tr(P), slot_obs(P), slot_mask(P), port_slot(P), tr_seg(R + 1, 0), tr_obs(R);
     {
         int q = 0;
         for (int r = 0; r < R; r++) {
             tr_seg[r] = q;
             for (int c = 0; c < C; c++)
                 if (b->cs_transformer[c] == r)
-                    for (int j = 0; j < npc; j++) {
-                        slot_port[q] = c * npc + j;
+                    for (int j = 0; j < np_of[c]; j++) {
+                        slot_port[q] = pbase[c] + j;
+                        slot_mask[q] = c * np_of[c] + j;   // where the reference sets this port's action-mask entry (ev2gym_env.py:457)
                         slot_cs[q] = c;
                         slot_tr[q] = r;
-                        port_slot[c * npc + j] = q;
+                        port_slot[pbase[c] + j] = q;
                         q++;
                     }
         }
@@ -287,7 +308,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
                 if (b->ev_lut[s] >= b->n_lut) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: ev_lut out of range");
                 prev_arr = ta;
                 int slot = -1;
-                for (int j = 0; j < npc; j++)
+                for (int j = 0; j < np_of[cs]; j++)
                     if (free_at[(size_t)cs * npc + j] <= ta - 1) {  // attached at the end of step ta-1
                         slot = j;
                         break;
@@ -295,8 +316,8 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
                 if (slot < 0)
                     return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: no free port for a session (assert n_evs_connected < n_ports, ev_charger.py:271)");
                 free_at[(size_t)cs * npc + slot] = td;  // freed inside step td, before that step's spawns
-                sess_port[s] = cs * npc + slot;
-                keyed.emplace_back((long long)port_slot[cs * npc + slot], s);
+                sess_port[s] = pbase[cs] + slot;
+                keyed.emplace_back((long long)port_slot[pbase[cs] + slot], s);
             }
             std::stable_sort(keyed.begin(), keyed.end(),
                              [](const auto &x, const auto &y) { return x.first < y.first; });
@@ -382,7 +403,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     s.E = E; s.M = M; s.T = T; s.C = C; s.npc = npc; s.P = P; s.R = R; s.D = D; s.ND = std::max(ND, 1); s.dt = b->timescale;
     s.reward_kind = h->cfg.reward_kind; s.state_kind = sk; s.flags = h->cfg.flags; s.cost_kind = h->cfg.cost_kind; s.n_lut = b->n_lut;
     // v2 kernel: one home lane per port, BLOCK >= P; the generic kernel handles larger envs
-    h->block = (P <= 256) ? 256 : (P <= 512) ? 512 : (P <= 1024) ? 1024 : 0;
+    h->block = het ? 0 : (P <= 256) ? 256 : (P <= 512) ? 512 : (P <= 1024) ? 1024 : 0;   // different port counts per charger: generic kernel
     const int blk = h->block ? h->block : EV2G_BLOCK;
     s.G = std::max(1, blk / P);
     s.G = std::min(s.G, E);
@@ -392,6 +413,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     if (P < 2 || P > 64) h->fallback_reason = "ports per env outside 2..64";
     else if (R != 1) h->fallback_reason = "more than one transformer";
     else if (npc != 1) h->fallback_reason = "multi-port chargers";
+    if (het) h->fallback_reason = "chargers with different port counts (topology file)";
     h->wave_path = h->fallback_reason.empty();
     if (h->wave_path) {   // ev2g_step_wave addresses every array as base + 32-bit byte offset: all of them must stay below 4 GiB
         const unsigned long long lim = 1ull << 32;
@@ -464,6 +486,10 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     UP(ip, slot_cs) s.slot_cs = ip;
     UP(ip, slot_obs) s.slot_obs = ip;
     UP(ip, slot_tr) s.slot_tr = ip;
+    UP(ip, slot_mask) s.slot_mask = ip;
+    UP(ip, np_of) s.cs_np = ip;
+    UP(ip, pbase) s.cs_pbase = ip;
+    s.het = het ? 1 : 0;
     UPP(dp, b->cs_min_charge_current, C) s.cs_imin = dp;
     UPP(dp, b->cs_max_charge_current, C) s.cs_imax = dp;
     UPP(dp, b->cs_min_discharge_current, C) s.cs_dmin = dp;

@@ -60,7 +60,7 @@ class EVView:
 
     @property
     def id(self):
-        return self._port() % self._env.number_of_ports_per_cs
+        return self._port() - int(self._env._port_base[self.location])
 
     def _dyn(self, key, default=0.0):
         s = self._env._snap()
@@ -110,7 +110,8 @@ class ChargerView:
     def __init__(self, env, i):
         a = env._arr
         self._env, self.id = env, i
-        self.n_ports = env.number_of_ports_per_cs
+        self.n_ports = int(a["cs_n_ports"][i])
+        self._base = int(env._port_base[i])
         self.connected_transformer = int(a["cs_transformer"][i])
         self.connected_bus = self.connected_transformer
         self.min_charge_current = float(a["cs_min_charge_current"][i])
@@ -127,7 +128,7 @@ class ChargerView:
         s = self._env._snap()
         out = []
         for j in range(self.n_ports):
-            k = int(s["port_session"][self.id * self.n_ports + j])
+            k = int(s["port_session"][self._base + j])
             out.append(self._env._ev(k) if k >= 0 else None)
         return out
 
@@ -293,6 +294,7 @@ class EV2Gym:
         e = self.engine
         self.simulation_length, self.timescale = e.T, scenario.timescale
         self.cs, self.number_of_ports, self.number_of_ports_per_cs = e.C, e.P, scenario.ports_per_charger
+        self._port_base = scenario.port_base          # cumulative port numbering (ev2gym_env.py:364-385)
         self.number_of_transformers = e.R
         self.v2g_enabled = scenario.v2g_enabled
         self.cs_transformers = [int(x) for x in self._arr["cs_transformer"]]

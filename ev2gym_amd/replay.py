@@ -81,9 +81,7 @@ def objects_to_scenario(transformers: Sequence, charging_stations: Sequence, ev_
     transformer.py:38-78) into a one-env `ScenarioBatch`."""
     T = int(simulation_length)
     cs, trs, evs = list(charging_stations), list(transformers), list(ev_profiles)
-    npc = {int(c.n_ports) for c in cs}
-    if len(npc) != 1:
-        raise NotImplementedError("chargers with different port counts (topology JSON) are out of scope")
+    n_ports = np.array([int(c.n_ports) for c in cs], np.int32)
     cp, dp = np.asarray(charge_prices, float), np.asarray(discharge_prices, float)
     if cp.ndim == 2:
         if not (cp == cp[0]).all() or not (dp == dp[0]).all():
@@ -138,7 +136,8 @@ def objects_to_scenario(transformers: Sequence, charging_stations: Sequence, ev_
                scn_lut=np.array(luts, float).reshape(-1, _abi.LUT_LEN) if luts else np.zeros((0, _abi.LUT_LEN)))
     if v2g_enabled is None:   # the flag lives in the YAML, not in the replay; it only selects the action-space low bound
         v2g_enabled = bool(np.any(rec["scn_cs_max_discharge_current"] != 0))
-    rec["scn_meta"] = np.array([T, int(timescale), len(cs), npc.pop(), R, int(bool(v2g_enabled)), int(horizon)], np.int64)
+    rec["scn_cs_n_ports"] = n_ports
+    rec["scn_meta"] = np.array([T, int(timescale), len(cs), int(n_ports.max()), R, int(bool(v2g_enabled)), int(horizon)], np.int64)
     return ScenarioBatch.from_single(rec)
 
 
@@ -158,12 +157,12 @@ def replay_tensors(batch: ScenarioBatch, env: int = 0) -> Dict[str, np.ndarray]:
     the scenario, and is not produced.)  Ports are the ones EVs actually occupy (first-free rule)."""
     b = batch.select(np.array([env])) if batch.n_envs > 1 else batch
     a, T, C, npc = b.arrays, b.n_steps, b.n_chargers, b.ports_per_charger
-    port = resolve_ports(b)          # [S] port within the charger, -1 = never admitted
+    port = resolve_ports(b) - b.port_base[a["ev_cs"]]          # [S] port within the charger
     z = lambda: np.zeros((npc, C, T))  # noqa: E731
     out = {k: z() for k in ("u", "ev_arrival", "t_dep", "energy_at_arrival", "ev_max_energy", "ev_max_ch_power",
                             "ev_max_dis_power", "ev_des_energy")}
     for s in range(len(a["ev_cs"])):
-        p, c, ta, td0 = int(port[s]) % npc if port[s] >= 0 else -1, int(a["ev_cs"][s]), int(a["ev_t_arr"][s]), int(a["ev_t_dep"][s])
+        p, c, ta, td0 = int(port[s]), int(a["ev_cs"][s]), int(a["ev_t_arr"][s]), int(a["ev_t_dep"][s])
         if p < 0 or ta >= T:
             continue
         td = min(td0, T)
@@ -228,7 +227,7 @@ def replay_objects(batch: ScenarioBatch, env: int = 0, run: Optional[dict] = Non
     b = batch.select(np.array([env])) if batch.n_envs > 1 else batch
     a, T, C, npc, R, dt = b.arrays, b.n_steps, b.n_chargers, b.ports_per_charger, b.n_transformers, b.timescale
     run = run or {}
-    port = resolve_ports(b)
+    port = resolve_ports(b) - b.port_base[a["ev_cs"]]     # port within the charger
     sim_date = sim_date or datetime.datetime(2022, 1, 1, 5, 0)
     sim_name = sim_name or ("sim_" + sim_date.strftime("%Y_%m_%d") + "_000000")
     volt_cfg = float(a["cs_voltage"][0]) * float(np.sqrt(a["cs_phases"][0]))   # Transformer.voltage: config voltage * sqrt(phases) (transformer.py:39-40)
@@ -248,10 +247,10 @@ def replay_objects(batch: ScenarioBatch, env: int = 0, run: Optional[dict] = Non
     css = []
     for c in range(C):
         css.append(_new("EV_Charger", id=c, connected_bus=0, connected_transformer=int(a["cs_transformer"][c]), geo_location=None,
-                        n_ports=npc, charger_type="AC", timescale=dt, min_charge_current=float(a["cs_min_charge_current"][c]),
+                        n_ports=int(a["cs_n_ports"][c]), charger_type="AC", timescale=dt, min_charge_current=float(a["cs_min_charge_current"][c]),
                         max_charge_current=float(a["cs_max_charge_current"][c]), min_discharge_current=float(a["cs_min_discharge_current"][c]),
                         max_discharge_current=float(a["cs_max_discharge_current"][c]), phases=int(a["cs_phases"][c]),
-                        voltage=float(a["cs_voltage"][c]), current_power_output=0, evs_connected=[None] * npc, n_evs_connected=0,
+                        voltage=float(a["cs_voltage"][c]), current_power_output=0, evs_connected=[None] * int(a["cs_n_ports"][c]), n_evs_connected=0,
                         current_step=int(run.get("current_step", 0)), current_charge_price=0, current_discharge_price=0,
                         current_total_amps=0, current_signal=[], total_energy_charged=float(run.get("cs_energy_charged", zC)[c]),
                         total_energy_discharged=float(run.get("cs_energy_discharged", zC)[c]), total_profits=float(run.get("cs_profits", zC)[c]),
@@ -263,7 +262,7 @@ def replay_objects(batch: ScenarioBatch, env: int = 0, run: Optional[dict] = Non
         eff_c = {i: float(lut[lid, i]) for i in range(_abi.LUT_LEN)} if lid >= 0 else float(a["ev_eta_ch"][s])
         eff_d = dict(eff_c) if lid >= 0 else float(a["ev_eta_dis"][s])
         cap0, B = float(a["ev_cap0"][s]), float(a["ev_B"][s])
-        evs.append(_new("EV", id=(int(port[s]) % npc if port[s] >= 0 else 0), location=int(a["ev_cs"][s]), timescale=dt,
+        evs.append(_new("EV", id=int(port[s]), location=int(a["ev_cs"][s]), timescale=dt,
                         time_of_arrival=int(a["ev_t_arr"][s]), time_of_departure=int(a["ev_t_dep"][s]), desired_capacity=float(a["ev_desired"][s]),
                         battery_capacity_at_arrival=cap0, battery_capacity=B, min_battery_capacity=float(a["ev_minB"][s]),
                         min_emergency_battery_capacity=float(a["ev_min_emerg"][s]), max_ac_charge_power=float(a["ev_pac_max"][s]),
@@ -301,9 +300,9 @@ def replay_objects(batch: ScenarioBatch, env: int = 0, run: Optional[dict] = Non
     if fin is not None:
         for s in range(len(a["ev_cs"])):
             td0, ta = int(a["ev_t_dep"][s]), int(a["ev_t_arr"][s])
-            if port[s] < 0 or ta >= T or not np.isfinite(fin[s]):
+            if ta >= T or not np.isfinite(fin[s]):
                 continue
-            mead[int(port[s]) % npc, int(a["ev_cs"][s]), td0 if td0 < T else T - 1] = min(float(fin[s]), float(a["ev_B"][s]))
+            mead[int(port[s]), int(a["ev_cs"][s]), td0 if td0 < T else T - 1] = min(float(fin[s]), float(a["ev_B"][s]))
     rep.max_energy_at_departure = mead
     return rep
 

@@ -47,7 +47,21 @@ class ScenarioBatch:
     # ---- derived sizes -----------------------------------------------------------------
     @property
     def n_ports(self) -> int:
-        return self.n_chargers * self.ports_per_charger
+        """Ports of one env: sum of the chargers' n_ports (ev2gym_env.py:201-202)."""
+        n = self.arrays.get("cs_n_ports")
+        return int(np.sum(n)) if n is not None else self.n_chargers * self.ports_per_charger
+
+    @property
+    def port_base(self) -> np.ndarray:
+        """[C+1] first port of every charger in the cumulative numbering (ev2gym_env.py:364-385)."""
+        n = self.arrays.get("cs_n_ports")
+        n = np.full(self.n_chargers, self.ports_per_charger) if n is None else n
+        return np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+
+    @property
+    def uniform_ports(self) -> bool:
+        n = self.arrays.get("cs_n_ports")
+        return n is None or bool((np.asarray(n) == self.ports_per_charger).all())
 
     @property
     def n_sessions(self) -> int:
@@ -79,6 +93,8 @@ class ScenarioBatch:
     def finalize(self) -> "ScenarioBatch":
         E, T, Cn, R = self.n_envs, self.n_steps, self.n_chargers, self.n_transformers
         a = self.arrays
+        if "cs_n_ports" not in a:      # no topology file: every charger has ports_per_charger ports
+            a["cs_n_ports"] = np.full(Cn, self.ports_per_charger, np.int32)
         for name, ct in _abi.BATCH_ARRAYS:
             if name not in a:
                 raise ValueError(f"scenario batch lacks '{name}'")
@@ -106,6 +122,8 @@ class ScenarioBatch:
             raise ValueError("cs_transformer out of range")
         if self.horizon != 20:
             raise ValueError("horizon must be 20 (state.py:119,129-132)")
+        if (a["cs_n_ports"] < 1).any() or int(a["cs_n_ports"].max()) != self.ports_per_charger:
+            raise ValueError("cs_n_ports must be >= 1 with ports_per_charger as their maximum")
         return self
 
     # ---- C view ----------------------------------------------------------------------------
@@ -128,7 +146,7 @@ class ScenarioBatch:
         T, ts, Cn, npc, R, v2g, H = [int(x) for x in g("meta")]
         a = {}
         for n, _ in _abi.BATCH_ARRAYS:
-            if n.startswith("cs_"):
+            if n.startswith("cs_") and ("scn_" + n) in rec:
                 a[n] = g(n)
         a["charge_price"] = g("charge_price")[None]
         a["discharge_price"] = g("discharge_price")[None]
@@ -242,18 +260,19 @@ class ScenarioBatch:
     def load(path: str) -> "ScenarioBatch":
         z = np.load(path)
         m = [int(x) for x in z["batch_meta"]]
-        a = {n: z[n] for n, _ in _abi.BATCH_ARRAYS}
+        a = {n: z[n] for n, _ in _abi.BATCH_ARRAYS if n in z}
         return ScenarioBatch(m[0], m[1], m[2], m[3], m[4], m[5], bool(m[6]), m[7], a).finalize()
 
 
 def resolve_ports(batch: ScenarioBatch) -> np.ndarray:
-    """Port index (charger*ports_per_charger + slot) of every session, by replaying
+    """Port index (first port of the charger + slot) of every session, by replaying
     EV_Charger.spawn_ev's first-free rule (ev_charger.py:266-286).  Occupancy does not depend on the
     actions: an EV attached at the end of step t_arr-1 leaves at the end of step t_dep
     (ev_charger.py:209-229, ev.py:191-202), and departures of a step precede its arrivals
     (ev2gym_env.py:363-417).  Host-side mirror of what ev2g_load_scenarios() does natively."""
     a = batch.arrays
-    npc = batch.ports_per_charger
+    npc, base = batch.ports_per_charger, batch.port_base
+    n_of = np.diff(base)
     out = np.full(batch.n_sessions, -1, np.int32)
     st = a["env_session_start"]
     for e in range(batch.n_envs):
@@ -262,12 +281,12 @@ def resolve_ports(batch: ScenarioBatch) -> np.ndarray:
             cs, ta, td = int(a["ev_cs"][s]), int(a["ev_t_arr"][s]), int(a["ev_t_dep"][s])
             # attached at end of step ta-1; slot busy through step td (freed inside step td before spawns)
             slot = -1
-            for j in range(npc):
+            for j in range(int(n_of[cs])):
                 if free_at[cs, j] <= ta - 1:
                     slot = j
                     break
             if slot < 0:
                 raise ValueError(f"env {e}: no free port on charger {cs} at step {ta}")
             free_at[cs, slot] = td
-            out[s] = cs * npc + slot
+            out[s] = base[cs] + slot
     return out

@@ -73,6 +73,8 @@ class GenConfig:
     scenario: str = "workplace"          # workplace | public
     spawn_multiplier: float = 5.0
     hour: int = 5
+    minute: int = 0
+    random_hour: bool = False             # ev2gym_env.py:131-133: start hour drawn from 5..15 (here: once per drawn batch)
     v2g_enabled: bool = True
     discharge_price_factor: float = 1.0
     power_setpoint_enabled: bool = False
@@ -80,6 +82,22 @@ class GenConfig:
     inflexible_loads: bool = True
     solar_power: bool = True
     demand_response: bool = True
+    # transformer.py:85-93,192-256 (the YAML's inflexible_loads / solar_power / demand_response sub-keys)
+    inflexible_loads_capacity_multiplier_mean: float = 1.0
+    inflexible_loads_forecast_mean: float = 30.0
+    inflexible_loads_forecast_std: float = 5.0
+    solar_power_capacity_multiplier_mean: float = 1.0
+    solar_power_forecast_mean: float = 20.0
+    solar_power_forecast_std: float = 5.0
+    dr_events_per_day: int = 1
+    dr_event_capacity_percentage_mean: float = 35.0
+    dr_event_capacity_percentage_std: float = 5.0
+    dr_event_length_minutes_min: int = 60
+    dr_event_length_minutes_max: int = 60
+    dr_event_start_hour_mean: float = 12.0
+    dr_event_start_hour_std: float = 2.0
+    dr_notification_of_event_minutes: int = 60
+    tr_seed: int = -1                     # != -1: transformer loads / PV / events come from their own generator (ev2gym_env.py:97-100)
     heterogeneous_ev_specs: bool = True
     fleet_with_efficiency_tables: bool = True   # ev_specs_v2g_enabled2024-like; False = scalar eta in [0.95,1]
     fleet: str = "v2g2024"                      # "v2g2024" | "ev_plus_phev" (mixed BEV / plug-in hybrids, PublicPST)
@@ -105,6 +123,10 @@ class GenConfig:
     ev_min_emergency_battery_capacity: float = 25.0
     ev_desired_capacity: float = 1.0
     seed: int = 0
+    # charging_network_topology file (ev2gym_env.py:176-186; loaders.py:259-276,312-340): per-charger arrays "n_ports",
+    # "transformer", "min_charge_current", "max_charge_current", "min_discharge_current", "max_discharge_current", "voltage",
+    # "phases" [C] and "tr_max_power" [R]; overrides the number_of_* / charging_station / transformer keys above
+    topology: Optional[dict] = None
 
     @staticmethod
     def v2g_profit_plus_loads(n_envs, n_chargers=50, n_transformers=1, seed=0, **kw):
@@ -164,18 +186,38 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
     rng = np.random.default_rng(cfg.seed)
     E, T, dt = cfg.n_envs, cfg.simulation_length, cfg.timescale
     Cn, npc, R = cfg.number_of_charging_stations, cfg.number_of_ports_per_cs, cfg.number_of_transformers
-    P = Cn * npc
     a = {}
-    # ---- chargers (load_ev_charger_profiles loaders.py:342-365; load_grid :494-498) ----
-    a["cs_min_charge_current"] = np.full(Cn, cfg.cs_min_charge_current)
-    a["cs_max_charge_current"] = np.full(Cn, cfg.cs_max_charge_current)
-    a["cs_min_discharge_current"] = np.full(Cn, cfg.cs_min_discharge_current if cfg.v2g_enabled else 0.0)
-    a["cs_max_discharge_current"] = np.full(Cn, cfg.cs_max_discharge_current if cfg.v2g_enabled else 0.0)
-    a["cs_voltage"] = np.full(Cn, cfg.cs_voltage)
-    a["cs_phases"] = np.full(Cn, cfg.cs_phases, np.int32)
-    a["cs_transformer"] = (np.arange(Cn) % R).astype(np.int32)
+    if cfg.topology is None:
+        # ---- chargers (load_ev_charger_profiles loaders.py:342-365; load_grid :494-498) ----
+        a["cs_min_charge_current"] = np.full(Cn, cfg.cs_min_charge_current)
+        a["cs_max_charge_current"] = np.full(Cn, cfg.cs_max_charge_current)
+        a["cs_min_discharge_current"] = np.full(Cn, cfg.cs_min_discharge_current if cfg.v2g_enabled else 0.0)
+        a["cs_max_discharge_current"] = np.full(Cn, cfg.cs_max_discharge_current if cfg.v2g_enabled else 0.0)
+        a["cs_voltage"] = np.full(Cn, cfg.cs_voltage)
+        a["cs_phases"] = np.full(Cn, cfg.cs_phases, np.int32)
+        a["cs_transformer"] = (np.arange(Cn) % R).astype(np.int32)
+        a["cs_n_ports"] = np.full(Cn, npc, np.int32)
+        tr_cap = np.full(R, cfg.transformer_max_power)
+    else:
+        # ---- chargers and transformers from the topology file (loaders.py:259-276, 312-340): values as written, v2g_enabled not consulted ----
+        tp = cfg.topology
+        Cn, R = len(tp["n_ports"]), len(tp["tr_max_power"])
+        for k in ("min_charge_current", "max_charge_current", "min_discharge_current", "max_discharge_current", "voltage"):
+            a["cs_" + k] = np.asarray(tp[k], float)
+        a["cs_phases"] = np.asarray(tp["phases"], np.int32)
+        a["cs_transformer"] = np.asarray(tp["transformer"], np.int32)
+        a["cs_n_ports"] = np.asarray(tp["n_ports"], np.int32)
+        npc = int(a["cs_n_ports"].max())
+        tr_cap = np.asarray(tp["tr_max_power"], float)
+    port_cs = np.repeat(np.arange(Cn), a["cs_n_ports"])    # charger of every port, ports numbered cumulatively (ev2gym_env.py:364-385)
+    P = len(port_cs)
+    tr_cap = tr_cap[None, :, None]
 
-    step_hours = cfg.hour + np.arange(T + 24) * dt / 60.0          # hour-of-day (unwrapped) of every step
+    if cfg.scenario not in _HOURLY:
+        raise ValueError(f"scenario '{cfg.scenario}': the spawner has tables for {sorted(_HOURLY)} "
+                         "(the reference's 'private' scenario is not fitted)")
+    hour = int(rng.integers(5, 16)) if cfg.random_hour else cfg.hour
+    step_hours = hour + cfg.minute / 60.0 + np.arange(T + 24) * dt / 60.0          # hour-of-day (unwrapped) of every step
     hod = step_hours % 24.0
 
     # ---- prices (load_electricity_prices loaders.py:392-461): hourly, EUR/MWh -> EUR/kWh ----
@@ -239,7 +281,7 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
     se, sp, st_, sB, spac, scap0, stdep, smodel = [x[order] for x in (se, sp, st_, sB, spac, scap0, stdep, smodel)]
     S = len(se)
     a["env_session_start"] = np.concatenate([[0], np.cumsum(np.bincount(se, minlength=E))]).astype(np.int64)
-    a["ev_cs"] = (sp // npc).astype(np.int32)
+    a["ev_cs"] = port_cs[sp].astype(np.int32)
     a["ev_t_arr"] = st_.astype(np.int32)
     a["ev_t_dep"] = stdep.astype(np.int32)
     a["ev_cap0"] = scap0.astype(float)
@@ -278,44 +320,51 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
         a["ev_eta_dis"] = np.full(S, cfg.ev_discharge_efficiency)
 
     # ---- transformers (loaders.py:227-296, transformer.py:38-256) ----
-    maxp = np.full((E, R, T), cfg.transformer_max_power)
+    if cfg.tr_seed != -1:
+        rng = np.random.default_rng(cfg.tr_seed)    # the reference's tr_rng: the same loads / PV / events every episode
+    maxp = np.broadcast_to(tr_cap, (E, R, T)).copy()
     minp = -maxp.copy()
     tod = (hod[:T])[None, None, :]
     if cfg.inflexible_loads:
         shape = 0.35 + 0.25 * np.sin((tod / 24.0 - 0.3) * 2 * np.pi) ** 2 + 0.5 * np.exp(-((tod / 24.0 - 0.8) / 0.08) ** 2)
         infl = shape * rng.uniform(0.6, 1.4, (E, R, 1)) + rng.normal(0, 0.03, (E, R, T))
         infl = np.abs(infl)
-        mult = rng.normal(1.0, 0.1, (E, R, 1))
-        infl = infl * mult * (cfg.transformer_max_power / infl.max(axis=2, keepdims=True) + 0.0000001)
+        mult = rng.normal(cfg.inflexible_loads_capacity_multiplier_mean, 0.1, (E, R, 1))
+        infl = infl * mult * (tr_cap / infl.max(axis=2, keepdims=True) + 0.0000001)
         infl = np.clip(infl, minp, maxp)
     else:
         infl = np.zeros((E, R, T))
     if cfg.solar_power:
         sun = np.clip(np.sin((tod - 6.5) / 13.0 * np.pi), 0, None) ** 1.5 * rng.uniform(0.3, 1.0, (E, 1, 1))
-        solar = -(sun * rng.uniform(0.9, 1.1, (E, R, 1))) * rng.normal(1.0, 0.1, (E, R, 1)) * cfg.transformer_max_power
+        solar = -(sun * rng.uniform(0.9, 1.1, (E, R, 1))) * rng.normal(cfg.solar_power_capacity_multiplier_mean, 0.1, (E, R, 1)) * tr_cap
         solar = np.where(tod < 24, solar, solar)
     else:
         solar = np.zeros((E, R, T))
-    steps_ahead = 60 // dt
-    dr = np.zeros((E, R, 1, 3))
+    steps_ahead = cfg.dr_notification_of_event_minutes // dt
+    n_ev = max(int(cfg.dr_events_per_day), 1) if cfg.demand_response else 1
+    dr = np.zeros((E, R, n_ev, 3))
     ndr = np.zeros((E, R), np.int32)
     if cfg.demand_response:
-        start_min = np.clip(rng.normal(12 * 60, 2 * 60, (E, R)), 0, 23 * 60)
-        es = (start_min // dt - (cfg.hour * 60) // dt).astype(int)
-        ee = es + 60 // dt
-        cap = np.clip(rng.normal(35, 5, (E, R)), 0, 100)
         tt = np.arange(T)[None, None, :]
-        inside = (tt >= es[..., None]) & (tt < ee[..., None])
-        maxp = np.where(inside, maxp - maxp * cap[..., None] / 100, maxp)
-        # if the load exceeds the reduced limit inside the event, the limit is lifted to the load's maximum
-        over = (inside & (infl > maxp)).any(axis=2)
-        load_max = np.where(inside, infl, -np.inf).max(axis=2)
-        maxp = np.where(inside & over[..., None], load_max[..., None], maxp)
-        cap = np.where(over, 100 * (1 - load_max / maxp.max(axis=2)), cap)
-        dr[:, :, 0, 0], dr[:, :, 0, 1], dr[:, :, 0, 2] = es, ee, cap
-        ndr[:] = 1
-    lf = np.clip(rng.normal(0.30 * infl, np.abs(0.05 * infl)), minp, maxp) if cfg.inflexible_loads else np.zeros((E, R, T))
-    pvf = rng.normal(0.20 * solar, np.abs(0.05 * solar)) if cfg.solar_power else np.zeros((E, R, T))
+        for k in range(int(cfg.dr_events_per_day)):      # generate_demand_response_events transformer.py:80-140, one event after the other
+            length = rng.integers(cfg.dr_event_length_minutes_min, cfg.dr_event_length_minutes_max + 1, (E, R))
+            start_min = np.clip(rng.normal(cfg.dr_event_start_hour_mean * 60, cfg.dr_event_start_hour_std * 60, (E, R)), 0, 23 * 60)
+            es = (start_min // dt - (hour * 60 + cfg.minute) // dt).astype(int)
+            ee = es + length // dt
+            cap = np.clip(rng.normal(cfg.dr_event_capacity_percentage_mean, cfg.dr_event_capacity_percentage_std, (E, R)), 0, 100)
+            inside = (tt >= es[..., None]) & (tt < ee[..., None])
+            maxp = np.where(inside, maxp - maxp * cap[..., None] / 100, maxp)
+            # if the load exceeds the reduced limit inside the event, the limit is lifted to the load's maximum
+            over = (inside & (infl > maxp)).any(axis=2)
+            load_max = np.where(inside, infl, -np.inf).max(axis=2)
+            maxp = np.where(inside & over[..., None], load_max[..., None], maxp)
+            cap = np.where(over, 100 * (1 - load_max / maxp.max(axis=2)), cap)
+            dr[:, :, k, 0], dr[:, :, k, 1], dr[:, :, k, 2] = es, ee, cap
+        ndr[:] = int(cfg.dr_events_per_day)
+    fm, fs = cfg.inflexible_loads_forecast_mean / 100, cfg.inflexible_loads_forecast_std / 100
+    lf = np.clip(rng.normal(fm * infl, np.abs(fs * infl)), minp, maxp) if cfg.inflexible_loads else np.zeros((E, R, T))
+    fm, fs = cfg.solar_power_forecast_mean / 100, cfg.solar_power_forecast_std / 100
+    pvf = rng.normal(fm * solar, np.abs(fs * solar)) if cfg.solar_power else np.zeros((E, R, T))
     # reset() already observed step 0 (transformer.py:178-180)
     lf[:, :, 0] = infl[:, :, 0]
     pvf[:, :, 0] = solar[:, :, 0]
@@ -329,9 +378,9 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
     if cfg.power_setpoint_enabled and S:
         pr = np.abs(a["charge_price"])
         pr = pr / pr.max(axis=1, keepdims=True)
-        sq = np.sqrt(cfg.cs_phases)
-        min_cs = cfg.cs_min_charge_current * cfg.cs_voltage * sq / 1000
-        max_cs = cfg.cs_max_charge_current * cfg.cs_voltage * sq / 1000
+        sq = np.sqrt(a["cs_phases"][a["ev_cs"]])     # limits of each session's charger
+        min_cs = a["cs_min_charge_current"][a["ev_cs"]] * a["cs_voltage"][a["ev_cs"]] * sq / 1000
+        max_cs = a["cs_max_charge_current"][a["ev_cs"]] * a["cs_voltage"][a["ev_cs"]] * sq / 1000
         tt = np.arange(T)[None, :]
         win = (tt >= (a["ev_t_arr"][:, None] + 1)) & (tt < a["ev_t_dep"][:, None])     # steps t+2 .. t_dep-1
         w = np.abs(rng.normal(1 - pr[se], np.maximum(pr[se].min(axis=1, keepdims=True), 1e-3))) * win

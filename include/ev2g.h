@@ -88,7 +88,7 @@ typedef struct ev2g_scenario_batch {
     int32_t n_steps;           /* T  = simulation_length                                  */
     int32_t timescale;         /* minutes per step                                        */
     int32_t n_chargers;        /* C                                                       */
-    int32_t ports_per_charger; /* uniform n_ports                                         */
+    int32_t ports_per_charger; /* n_ports of every charger; with cs_n_ports: their maximum */
     int32_t n_transformers;    /* R                                                       */
     int32_t horizon;           /* H, must be 20                                           */
     int32_t n_dr_max;          /* ND: slots per transformer in tr_dr                      */
@@ -104,6 +104,9 @@ typedef struct ev2g_scenario_batch {
     const double *cs_voltage;
     const int32_t *cs_phases;
     const int32_t *cs_transformer; /* connected_transformer, loaders.py:494-498 */
+    /* n_ports of each charger when a topology file gives them different counts (loaders.py:312-340), or NULL: every
+       charger has ports_per_charger ports.  Ports are numbered cumulatively in charger order (ev2gym_env.py:364-385). */
+    const int32_t *cs_n_ports;
 
     /* per env [E,T]: row 0 of charge_prices / discharge_prices (identical for all chargers,
        loaders.py:423-424,439-442; charge price is negative) and power_setpoints */

@@ -55,16 +55,34 @@ def _yaml_variant(base, overrides, name):
     return p
 
 
+def _topology_file(name, transformers):
+    """Write a charging_network_topology JSON in the layout of example_config_files/charging_topology_10.json:
+    transformers = [(max_power, [(n_ports, max_charge_current, max_discharge_current, voltage, phases), ...]), ...]."""
+    import json
+    topo, k = {}, 0
+    for i, (max_power, chargers) in enumerate(transformers):
+        chs = {}
+        for n_ports, imax, dmax, volt, ph in chargers:
+            chs[f"charger_{k + 1}"] = dict(id=k, min_charge_current=6, max_charge_current=imax, min_discharge_current=0,
+                                           max_discharge_current=dmax, voltage=volt, n_ports=n_ports, charger_type="AC", phases=ph)
+            k += 1
+        topo[f"transformer_{i + 1}"] = dict(id=i + 1, max_power=max_power, charging_stations=chs)
+    os.makedirs("/tmp/ev2g_cfg", exist_ok=True)
+    p = f"/tmp/ev2g_cfg/topology_{name}.json"
+    json.dump(topo, open(p, "w"), indent=1)
+    return p
+
+
 def extract_scenario(env):
     """Flatten the reference object graph into this repo's scenario schema."""
     T = env.simulation_length
     cs = env.charging_stations
     C = len(cs)
-    nports = {c.n_ports for c in cs}
-    assert len(nports) == 1, "uniform ports per charger only"
     R = len(env.transformers)
     s = {}
-    s["scn_meta"] = np.array([T, env.timescale, C, cs[0].n_ports, R,
+    if len({c.n_ports for c in cs}) > 1:     # topology file with different port counts (loaders.py:312-340)
+        s["scn_cs_n_ports"] = np.array([c.n_ports for c in cs], np.int32)
+    s["scn_meta"] = np.array([T, env.timescale, C, max(c.n_ports for c in cs), R,
                               int(bool(env.config['v2g_enabled'])), 20], dtype=np.int64)
     s["scn_cs_min_charge_current"] = np.array([c.min_charge_current for c in cs], float)
     s["scn_cs_max_charge_current"] = np.array([c.max_charge_current for c in cs], float)
@@ -154,7 +172,7 @@ def run_case(name, config, state_fn, reward_fn, seed, policy, steps=None, env=No
     P = env.number_of_ports
     C = len(env.charging_stations)
     R = len(env.transformers)
-    npc = env.charging_stations[0].n_ports
+    base = np.concatenate([[0], np.cumsum([c.n_ports for c in env.charging_stations])])   # cumulative port numbering (ev2gym_env.py:364-385)
     rng = np.random.default_rng(1000 + seed)
     lo = -1.0 if env.config['v2g_enabled'] else 0.0
     if policy == "ones":
@@ -203,7 +221,7 @@ def run_case(name, config, state_fn, reward_fn, seed, policy, steps=None, env=No
             trj["trj_cs_e_dis"][t, i] = cs.total_energy_discharged
             for j, ev in enumerate(cs.evs_connected):
                 if ev is not None:
-                    p = i * npc + j
+                    p = base[i] + j
                     trj["trj_cap"][t, p] = ev.current_capacity
                     trj["trj_energy"][t, p] = ev.current_energy
                     trj["trj_current"][t, p] = ev.actual_current
@@ -217,7 +235,7 @@ def run_case(name, config, state_fn, reward_fn, seed, policy, steps=None, env=No
             trj["trj_tr_overload"][t, i] = env.tr_overload[i, t]
         trj["trj_n_departed"][t] = len(env.departing_evs)
         for k, ev in enumerate(env.departing_evs):
-            trj["trj_dep_port"][t, k] = ev.location * npc + ev.id
+            trj["trj_dep_port"][t, k] = base[ev.location] + ev.id
             trj["trj_dep_score"][t, k] = ev.get_user_satisfaction()
             trj["trj_sat_sum"][t] += ev.get_user_satisfaction()
     trj["trj_usage"] = np.array(env.current_power_usage[:nT])
@@ -228,7 +246,7 @@ def run_case(name, config, state_fn, reward_fn, seed, policy, steps=None, env=No
     trj["trj_ev_final_cap"] = np.full(S_, np.nan)
     trj["trj_ev_afap"] = np.full(S_, np.nan)
     for k, ev in enumerate(env.EVs):
-        trj["trj_ev_port"][k] = ev.location * npc + ev.id
+        trj["trj_ev_port"][k] = base[ev.location] + ev.id
         trj["trj_ev_final_cap"][k] = ev.current_capacity
         trj["trj_ev_afap"][k] = ev.max_energy_AFAP
     if nT == T:
@@ -339,6 +357,15 @@ def main():
     x3 = _yaml_variant(vmax, {"number_of_charging_stations": 28, "number_of_ports_per_cs": 2, "number_of_transformers": 3,
                               "timescale": 30}, "v2gmax_c28p2r3_ts30")
     cases.append(("v2gmax_c28p2r3ts30_rand_s33", x3, *VMX, 33, "rand", None))
+    # topology files (loaders.py:259-276, 312-340): chargers with their own port counts, current limits, voltage and phases
+    tp1 = _topology_file("het_a", [(60, [(3, 32, -32, 400, 3), (2, 16, -16, 230, 3)]),
+                                   (40, [(2, 32, -32, 400, 1), (1, 16, -16, 230, 3), (1, 32, -32, 400, 3)])])
+    t1 = _yaml_variant(ppl, {"charging_network_topology": tp1, "spawn_multiplier": 10}, "v2gppl_topo_het_a")
+    cases.append(("topo_v2gppl_het_rand_s41", t1, *PPL, 41, "rand", None))
+    cases.append(("topo_v2gppl_het_wild_s42", t1, *PPL, 42, "wild", None))
+    tp2 = _topology_file("het_b", [(100, [(4, 32, 0, 400, 3), (2, 16, 0, 230, 1), (2, 32, 0, 400, 3), (1, 16, 0, 400, 3), (1, 32, 0, 400, 3), (1, 32, 0, 230, 3)])])
+    t2 = _yaml_variant(pst, {"charging_network_topology": tp2, "spawn_multiplier": 10}, "pst_topo_het_b")
+    cases.append(("topo_pst_het_mixed_s43", t2, *PST, 43, "mixed", None))
     for c in cases:
         if only and c[0] not in only:
             continue

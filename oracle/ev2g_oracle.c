@@ -590,7 +590,14 @@ static void env_step(Env *env, double *actions, double *obs, double *reward_out,
         for (int p = 0; p < env->P; p++) mask[p] = 0;
         for (int i = 0; i < env->C; i++)
             for (int j = 0; j < env->cs[i].n_ports; j++)
-                if (env->cs[i].evs_connected[j] != NULL) mask[i * env->cs[i].n_ports + j] = 1;
+                if (env->cs[i].evs_connected[j] != NULL) {
+                    /* the reference indexes i*cs.n_ports + j, not the cumulative port number (ev2gym_env.py:452-457): the same
+                       thing for equal port counts; with a topology file the entries collide or fall outside the array, where
+                       numpy raises IndexError */
+                    const int m = i * env->cs[i].n_ports + j;
+                    if (m < env->P) mask[m] = 1;
+                    else env->fault = EV2G_ERR_ARG;
+                }
     }
     if (env->current_step >= env->T) env->done = 1;
     if (obs) get_observation(env, obs);
@@ -723,6 +730,7 @@ void *ev2g_oracle_create(const ev2g_scenario_batch *bin, int reward_kind, int st
     DUP(cs_voltage, C, double);
     DUP(cs_phases, C, int32_t);
     DUP(cs_transformer, C, int32_t);
+    if (bin->cs_n_ports) DUP(cs_n_ports, C, int32_t);
     DUP(charge_price, (size_t)E * T, double);
     DUP(discharge_price, (size_t)E * T, double);
     DUP(power_setpoints, (size_t)E * T, double);
@@ -765,7 +773,8 @@ void *ev2g_oracle_create(const ev2g_scenario_batch *bin, int reward_kind, int st
         env->timescale = b->timescale;
         env->C = C;
         env->npc = npc;
-        env->P = C * npc;
+        env->P = 0;
+        for (int c = 0; c < C; c++) env->P += b->cs_n_ports ? b->cs_n_ports[c] : npc;   /* ev2gym_env.py:201-202 */
         env->R = R;
         env->H = b->horizon;
         env->ND = ND;
@@ -783,7 +792,7 @@ void *ev2g_oracle_create(const ev2g_scenario_batch *bin, int reward_kind, int st
         for (int c = 0; c < C; c++) {
             Charger *cs = &env->cs[c];
             cs->id = c;
-            cs->n_ports = npc;
+            cs->n_ports = b->cs_n_ports ? b->cs_n_ports[c] : npc;   /* topology file: per charger (loaders.py:330-331) */
             cs->phases = b->cs_phases[c];
             cs->connected_transformer = b->cs_transformer[c];
             cs->min_charge_current = b->cs_min_charge_current[c];
@@ -791,7 +800,7 @@ void *ev2g_oracle_create(const ev2g_scenario_batch *bin, int reward_kind, int st
             cs->min_discharge_current = b->cs_min_discharge_current[c];
             cs->max_discharge_current = b->cs_max_discharge_current[c];
             cs->voltage = b->cs_voltage[c];
-            cs->evs_connected = (EV **)calloc(npc, sizeof(EV *));
+            cs->evs_connected = (EV **)calloc(cs->n_ports, sizeof(EV *));
         }
         env->tr = (Transformer *)calloc(R, sizeof(Transformer));
         for (int t = 0; t < R; t++) {
@@ -899,6 +908,7 @@ void ev2g_oracle_peek(void *h, int e, double *cap, double *energy, double *curre
                       double *session_cap) {
     Oracle *o = (Oracle *)h;
     Env *env = &o->env[e];
+    int base = 0;   /* first port of charger c in the cumulative numbering */
     for (int c = 0; c < env->C; c++) {
         Charger *cs = &env->cs[c];
         if (cs_power) cs_power[c] = cs->current_power_output;
@@ -907,7 +917,7 @@ void ev2g_oracle_peek(void *h, int e, double *cap, double *energy, double *curre
         if (cs_e_ch) cs_e_ch[c] = cs->total_energy_charged;
         if (cs_e_dis) cs_e_dis[c] = cs->total_energy_discharged;
         for (int j = 0; j < cs->n_ports; j++) {
-            int p = c * cs->n_ports + j;
+            int p = base + j;
             EV *ev = cs->evs_connected[j];
             if (cap) cap[p] = ev ? ev->current_capacity : NAN;
             if (energy) energy[p] = ev ? ev->current_energy : NAN;
@@ -918,6 +928,7 @@ void ev2g_oracle_peek(void *h, int e, double *cap, double *energy, double *curre
             if (cycles) cycles[p] = ev ? ev->charging_cycles : -1;
             if (session) session[p] = ev ? ev->session : -1;
         }
+        base += cs->n_ports;
     }
     for (int t = 0; t < env->R; t++) {
         if (tr_power) tr_power[t] = env->tr[t].current_power;
@@ -928,7 +939,11 @@ void ev2g_oracle_peek(void *h, int e, double *cap, double *energy, double *curre
     if (potential) memcpy(potential, env->charge_power_potential, sizeof(double) * env->T);
     for (int k = 0; k < env->n_profiles; k++) {
         int spawned = k < env->n_evs;
-        if (session_port) session_port[k] = spawned ? env->evs[k].location * env->npc + env->evs[k].id : -1;
+        if (session_port && spawned) {
+            int pb = 0;
+            for (int c = 0; c < env->evs[k].location; c++) pb += env->cs[c].n_ports;
+            session_port[k] = pb + env->evs[k].id;
+        } else if (session_port) session_port[k] = -1;
         if (session_afap) session_afap[k] = spawned ? env->evs[k].max_energy_AFAP : NAN;
         if (session_cap) session_cap[k] = spawned ? env->evs[k].current_capacity : NAN;
     }

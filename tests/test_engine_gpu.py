@@ -34,6 +34,8 @@ def _expected_kernel(batch, sk, rk, forced_v2=False):
     """The routing rule of ev2g_load_scenarios, restated: the common shape gets the fast path, with or without the
     charger-history flag."""
     P, R, npc = batch.n_ports, batch.n_transformers, batch.ports_per_charger
+    if not batch.uniform_ports:     # topology file with different port counts per charger
+        return "ev2g_step_kernel"
     if 2 <= P <= 64 and R == 1 and npc == 1 and not forced_v2:
         return f"ev2g_step_wave<{sk},{rk}>"
     return f"ev2g_step_v2<{256 if P <= 256 else 512 if P <= 512 else 1024}>" if P <= 1024 else "ev2g_step_kernel"

@@ -39,11 +39,20 @@ def _shape(kind, M, seed):
     if kind == "generic":         # ev2g_step_kernel (P > 1024), multi-port chargers whose ports straddle wavefronts
         return (generate(GenConfig.v2g_profit_plus_loads(M, 400, 2, seed=seed, number_of_ports_per_cs=3)),
                 RK["ProfitMax_TrPenalty_UserIncentives"], SK["V2G_profit_max_loads"], -1.3)
+    if kind == "topo_het":        # ev2g_step_kernel: a topology file's chargers, each with its own port count / limits / voltage / phases
+        n_ports = np.array([4, 3, 3, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1])
+        C = len(n_ports)
+        topo = dict(n_ports=n_ports, transformer=np.arange(C) % 3, min_charge_current=np.full(C, 6.0),
+                    max_charge_current=np.where(np.arange(C) % 2, 16.0, 32.0), min_discharge_current=np.zeros(C),
+                    max_discharge_current=np.where(np.arange(C) % 2, -16.0, -32.0), voltage=np.where(np.arange(C) % 3, 400.0, 230.0),
+                    phases=np.where(np.arange(C) % 4 == 1, 1, 3), tr_max_power=np.array([90.0, 60.0, 45.0]))
+        return (generate(GenConfig.v2g_profit_plus_loads(M, seed=seed, topology=topo, spawn_multiplier=9.0)),
+                RK["ProfitMax_TrPenalty_UserIncentives"], SK["V2G_profit_max_loads"], -1.3)
     raise ValueError(kind)
 
 
 @pytest.mark.parametrize("kind,M,E,K", [("wave_v2gppl", 41, 12, 112), ("wave_pst", 50, 17, 112), ("v2_multi", 23, 9, 112),
-                                        ("generic", 7, 3, 30)])
+                                        ("generic", 7, 3, 30), ("topo_het", 37, 21, 112)])
 def test_scenario_pool_window_matches_oracle(kind, M, E, K):
     """E envs stepping a window of an M-scenario pool == the oracle on exactly those scenarios, for windows that start
     anywhere in the pool (including ones that wrap around its end); statistics and peeks follow the window."""
@@ -52,6 +61,8 @@ def test_scenario_pool_window_matches_oracle(kind, M, E, K):
     pool, rk, sk, lo = _shape(kind, M, seed=5)
     eng = Engine(pool, rk, sk, device=0, flags=4, n_active_envs=E)
     assert (eng.E, eng.M) == (E, M)
+    if kind == "topo_het":
+        assert eng.kernel_name == "ev2g_step_kernel" and "port counts" in eng.fallback_reason and eng.P == 25
     P, D, T = eng.P, eng.D, eng.T
     K = min(K, T)
     d_act = eng.empty((K, E, P))
@@ -83,7 +94,7 @@ def test_scenario_pool_window_matches_oracle(kind, M, E, K):
     eng.close()
 
 
-@pytest.mark.parametrize("kind,M,E", [("wave_v2gppl", 30, 8), ("v2_multi", 20, 6)])
+@pytest.mark.parametrize("kind,M,E", [("wave_v2gppl", 30, 8), ("v2_multi", 20, 6), ("topo_het", 19, 7)])
 @pytest.mark.parametrize("persistent", [True, False])
 def test_auto_reset_moves_to_the_next_scenarios_of_the_pool(kind, M, E, persistent):
     """ev2g_step_n(auto_reset = NEXT): when the episode ends inside a fused run -- inside ONE persistent launch too -- the

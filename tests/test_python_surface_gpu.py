@@ -24,7 +24,7 @@ def _close(a, b, what, tol=1e-9):
 
 
 @pytest.mark.parametrize("name", ["v2gppl_rand_s2", "pst_rand_s2", "v2gmax_het_rand_s3", "v2gppl_p2_rand_s11",
-                                  "v2gppl_c10r3_mixed_s14"])
+                                  "v2gppl_c10r3_mixed_s14", "topo_v2gppl_het_rand_s41", "topo_pst_het_mixed_s43"])
 @pytest.mark.parametrize("host_plugins", [False, True], ids=["fused", "host_plugins"])
 def test_facade_reproduces_reference_episode(name, host_plugins):
     """EV2Gym facade == reference trajectory, with the plugins fused in the kernel and evaluated on the host."""

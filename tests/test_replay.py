@@ -118,3 +118,23 @@ def test_replay_reader_refuses_classes_outside_its_whitelist():
         read_replay_object(b"cnumpy\nload\n.")
     with pytest.raises(pickle.UnpicklingError):   # an ev2gym name that is not a replay class
         read_replay_object(b"cev2gym.utilities.utils\nprint_statistics\n.")
+
+
+def test_replay_of_a_topology_scenario_keeps_per_charger_ports(tmp_path):
+    """Chargers with different port counts (topology file): n_ports per EV_Charger, [max_n_ports, n_cs, T] tensors, round trip."""
+    from ev2gym_amd.replay import write_replay
+    g = load_golden("topo_v2gppl_het_rand_s41")
+    batch = ScenarioBatch.from_single(g)
+    assert batch.arrays["cs_n_ports"].tolist() == [3, 2, 2, 1, 1]
+    path = write_replay(str(tmp_path / "replay_sim_t.pkl"), batch)
+    rep = read_replay_object(path)
+    assert [c.n_ports for c in rep.charging_stations] == [3, 2, 2, 1, 1] and rep.max_n_ports == 3
+    assert rep.u.shape == (3, 5, batch.n_steps) and rep.u[1:, 3:].sum() == 0     # one-port chargers only ever use port 0
+    back = load_replay(path)
+    for k, _ in _abi.BATCH_ARRAYS:
+        assert np.array_equal(back.arrays[k], batch.arrays[k], equal_nan=True), k
+    # the EV ids are the ports the first-free rule gives them in the reference's run (trj_ev_port is cumulative)
+    base = batch.port_base
+    for k, ev in enumerate(rep.EVs):
+        if g["trj_ev_port"][k] >= 0:
+            assert base[ev.location] + ev.id == g["trj_ev_port"][k]
