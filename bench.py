@@ -311,6 +311,26 @@ def main():
     roof = {m: roofline(m) for m in modes}
     eng.check_faults()
 
+    # outside the timed regions: the C-ABI's own RCCL gather (ev2g_comm_init / ev2g_gather_stats, the path of hosts without
+    # torch.distributed) next to torch's, on the same statistics
+    c_gather = None
+    if world > 1:
+        try:
+            from ev2gym_amd.dist import gather_stats_tensor
+            ids = [Engine.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            eng.comm_init(ids[0], rank, world)
+            st_all = torch.empty((world * E, _abi.N_STATS), dtype=torch.float64, device=dev)
+            eng.gather_stats(st_all)
+            st_loc = torch.empty((E, _abi.N_STATS), dtype=torch.float64, device=dev)
+            eng.stats(out=st_loc)
+            want = gather_stats_tensor(st_loc)
+            torch.cuda.synchronize()
+            c_gather = {"ranks": eng.comm_world_size, "rows": int(st_all.shape[0]),
+                        "equals_torch_all_gather": bool(torch.equal(torch.nan_to_num(st_all, nan=-7.0), torch.nan_to_num(want, nan=-7.0)))}
+        except Exception as ex:   # reported, never fatal for the measurement
+            c_gather = {"error": f"{type(ex).__name__}: {ex}"}
+
     env_steps_total = world * E * args.steps
     value = env_steps_total / wall[best]
     per_rank = None
@@ -337,6 +357,7 @@ def main():
         "roofline_by_launch_mode": roof,
         "rccl_ranks_seen": (world if world > 1 else None), "per_rank_env_steps_per_s": per_rank,
         "rccl_collectives_issued": (gath.collectives if gath is not None else 0),
+        "c_abi_rccl_gather": c_gather,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(batch.select(np.arange(min(E, 512))), rk, sk, wl["lo"])

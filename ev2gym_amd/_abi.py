@@ -2,6 +2,7 @@
 import ctypes as C
 
 ABI_VERSION = 2
+COMM_ID_BYTES = 128   # EV2G_COMM_ID_BYTES = sizeof(ncclUniqueId)
 LUT_LEN = 101
 N_STATS = 17
 

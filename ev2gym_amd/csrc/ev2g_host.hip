@@ -18,6 +18,7 @@
 #include "ev2g_step_v2.h"
 #include "ev2g_step_wave.h"
 #include "ev2g_mlp.h"
+#include "ev2g_comm.h"
 #include <cstdlib>
 
 static thread_local std::string g_create_error;
@@ -54,6 +55,7 @@ struct ev2g_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     std::string err;
+    CommState comm;                             // RCCL communicator of the statistics exchange (ev2g_comm_init), if any
 };
 
 #define HIPCHK(h, call)                                                                              \
@@ -142,6 +144,7 @@ void ev2g_destroy(ev2g_handle *h) {
     free_pool(h->scn_allocs);
     free_pool(h->st_allocs);
     free_pool(h->user_allocs);
+    ev2g_comm_destroy(h);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -978,6 +981,65 @@ int ev2g_get_stats(ev2g_handle *h, double *stats) {
     hipLaunchKernelGGL(ev2g_stats_kernel, dim3(h->E), dim3(64), 0, h->stream, h->scn, h->st, (int)h->scn_off,
                        (const double *)h->d_ss_afap, h->current_step, stats);
     HIPCHK(h, hipGetLastError());
+    return EV2G_OK;
+}
+
+// ---- multi-GPU statistics exchange (RCCL) --------------------------------------------------------------------------------
+int ev2g_comm_get_unique_id(void *id) {
+    RcclApi *api = rccl_api();
+    if (!api->lib) return fail(nullptr, EV2G_ERR_STATE, "ev2g_comm_get_unique_id: " + api->err);
+    if (!id) return fail(nullptr, EV2G_ERR_ARG, "ev2g_comm_get_unique_id: null output");
+    static_assert(sizeof(ncclUniqueId) == EV2G_COMM_ID_BYTES, "EV2G_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+    ncclUniqueId u;
+    const ncclResult_t r = api->GetUniqueId(&u);
+    if (r != ncclSuccess) return fail(nullptr, EV2G_ERR_HIP, std::string("ncclGetUniqueId: ") + api->GetErrorString(r));
+    std::memcpy(id, &u, sizeof u);
+    return EV2G_OK;
+}
+
+int ev2g_comm_init(ev2g_handle *h, const void *id, int rank, int world_size) {
+    if (!h) return fail(h, EV2G_ERR_ARG, "ev2g_comm_init: null handle");
+    if (!id || world_size < 1 || rank < 0 || rank >= world_size) return fail(h, EV2G_ERR_ARG, "ev2g_comm_init: bad arguments");
+    RcclApi *api = rccl_api();
+    if (!api->lib) return fail(h, EV2G_ERR_STATE, "ev2g_comm_init: " + api->err);
+    ev2g_comm_destroy(h);
+    (void)hipSetDevice(h->device);
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    const ncclResult_t r = api->CommInitRank(&h->comm.comm, world_size, u, rank);
+    if (r != ncclSuccess) { h->comm.comm = nullptr; return fail(h, EV2G_ERR_HIP, std::string("ncclCommInitRank: ") + api->GetErrorString(r)); }
+    h->comm.rank = rank; h->comm.world = world_size;
+    return EV2G_OK;
+}
+
+void ev2g_comm_destroy(ev2g_handle *h) {
+    if (!h || !h->comm.comm) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    rccl_api()->CommDestroy(h->comm.comm);
+    if (h->comm.d_send) (void)hipFree(h->comm.d_send);
+    h->comm = CommState{};
+}
+
+int ev2g_comm_world_size(const ev2g_handle *h) { return (h && h->comm.comm) ? h->comm.world : 0; }
+long long ev2g_comm_gathers(const ev2g_handle *h) { return h ? h->comm.gathers : 0; }
+
+int ev2g_gather_stats(ev2g_handle *h, double *stats_all) {
+    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_gather_stats: no scenarios loaded");
+    if (!h->comm.comm) return fail(h, EV2G_ERR_STATE, "ev2g_gather_stats: no communicator (call ev2g_comm_init on every rank first)");
+    if (!stats_all) return fail(h, EV2G_ERR_ARG, "ev2g_gather_stats: null output");
+    (void)hipSetDevice(h->device);
+    if (h->comm.send_envs != h->E) {
+        if (h->comm.d_send) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->comm.d_send); h->comm.d_send = nullptr; }
+        HIPCHK(h, hipMalloc((void **)&h->comm.d_send, sizeof(double) * (size_t)h->E * EV2G_N_STATS));
+        h->comm.send_envs = h->E;
+    }
+    const int rc = ev2g_get_stats(h, h->comm.d_send);
+    if (rc) return rc;
+    RcclApi *api = rccl_api();
+    const ncclResult_t r = api->AllGather(h->comm.d_send, stats_all, (size_t)h->E * EV2G_N_STATS, ncclDouble, h->comm.comm, h->stream);
+    if (r != ncclSuccess) return fail(h, EV2G_ERR_HIP, std::string("ncclAllGather: ") + api->GetErrorString(r));
+    h->comm.gathers++;
     return EV2G_OK;
 }
 

@@ -76,6 +76,12 @@ def load_library(path: Optional[str] = None):
         "ev2g_mlp_destroy": (None, [vp, vp]),
         "ev2g_mlp_forward": (C.c_int, [vp, vp, vp, vp, C.c_int]),
         "ev2g_rollout": (C.c_int, [vp, vp, C.c_int, vp, i64, vp, i64, vp, i64, C.c_int]),
+        "ev2g_comm_get_unique_id": (C.c_int, [vp]),
+        "ev2g_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+        "ev2g_comm_destroy": (None, [vp]),
+        "ev2g_comm_world_size": (C.c_int, [vp]),
+        "ev2g_comm_gathers": (C.c_longlong, [vp]),
+        "ev2g_gather_stats": (C.c_int, [vp, vp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(L, name)  # AttributeError here = the .so does not export what include/ev2g.h declares
@@ -93,7 +99,8 @@ EXPORTED_SYMBOLS = [
     "ev2g_scenario_offset", "ev2g_set_step_extras", "ev2g_kernel_name", "ev2g_fallback_reason", "ev2g_step", "ev2g_step_n",
     "ev2g_check_faults", "ev2g_get_stats", "ev2g_stat_name", "ev2g_peek", "ev2g_malloc", "ev2g_free",
     "ev2g_memcpy_h2d", "ev2g_memcpy_d2h", "ev2g_synchronize", "ev2g_fill_uniform", "ev2g_host_uniform",
-    "ev2g_last_step_n_kernel_ms", "ev2g_mlp_create", "ev2g_mlp_destroy", "ev2g_mlp_forward", "ev2g_rollout"]
+    "ev2g_last_step_n_kernel_ms", "ev2g_mlp_create", "ev2g_mlp_destroy", "ev2g_mlp_forward", "ev2g_rollout",
+    "ev2g_comm_get_unique_id", "ev2g_comm_init", "ev2g_comm_destroy", "ev2g_comm_world_size", "ev2g_comm_gathers", "ev2g_gather_stats"]
 
 
 def _ptr(x):
@@ -273,6 +280,42 @@ class Engine:
         buf = self.empty((self.E, _abi.N_STATS))
         try:
             self._check(self._lib.ev2g_get_stats(self._h, buf.ptr))
+            return buf.to_host()
+        finally:
+            buf.free()
+
+    # ---- multi-GPU statistics exchange over RCCL (include/ev2g.h: ev2g_comm_*, ev2g_gather_stats) ----
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0: the communicator id to hand to every rank's comm_init (128 bytes; ship them by any host-side channel)."""
+        buf = C.create_string_buffer(_abi.COMM_ID_BYTES)
+        rc = load_library().ev2g_comm_get_unique_id(C.cast(buf, C.c_void_p))
+        if rc:
+            raise EngineError(rc, (load_library().ev2g_last_error(None) or b"").decode())
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world_size: int):
+        assert len(unique_id) == _abi.COMM_ID_BYTES
+        buf = C.create_string_buffer(unique_id, _abi.COMM_ID_BYTES)
+        self._check(self._lib.ev2g_comm_init(self._h, C.cast(buf, C.c_void_p), int(rank), int(world_size)))
+
+    @property
+    def comm_world_size(self) -> int:
+        return int(self._lib.ev2g_comm_world_size(self._h))
+
+    @property
+    def comm_gathers(self) -> int:
+        return int(self._lib.ev2g_comm_gathers(self._h))
+
+    def gather_stats(self, out=None) -> np.ndarray:
+        """Episode statistics of every rank, [world*E,17] rank-major: this rank's statistics kernel followed by ncclAllGather on the
+        engine's stream.  Into the device array `out` (asynchronous), or returned as a host array."""
+        if out is not None:
+            self._check(self._lib.ev2g_gather_stats(self._h, _ptr(out)))
+            return out
+        buf = self.empty((self.comm_world_size * self.E, _abi.N_STATS))
+        try:
+            self._check(self._lib.ev2g_gather_stats(self._h, buf.ptr))
             return buf.to_host()
         finally:
             buf.free()

@@ -239,6 +239,22 @@ int ev2g_check_faults(ev2g_handle *h, int32_t *first_bad_env);
 int ev2g_get_stats(ev2g_handle *h, double *stats);
 const char *ev2g_stat_name(int i);
 
+/* ---- multi-GPU: one process per GPU, envs sharded, statistics gathered over RCCL ---------------
+ * The reference has no multi-process path (one env, one process).  Sharding envs over GPUs needs no data-path collective;
+ * the only exchange is this per-episode statistics block.  For hosts without torch.distributed: rank 0 obtains an id,
+ * ships its EV2G_COMM_ID_BYTES bytes to the other ranks by any host-side means, every rank calls ev2g_comm_init, and
+ * ev2g_gather_stats then computes this rank's statistics and all-gathers them with ncclAllGather on the handle's stream
+ * (stream-ordered, asynchronous to the host).  Every rank must hold the same number of envs.  librccl is opened on first
+ * use; without it these calls fail with EV2G_ERR_STATE and the step path is unaffected. */
+#define EV2G_COMM_ID_BYTES 128
+int ev2g_comm_get_unique_id(void *id_out);
+int ev2g_comm_init(ev2g_handle *h, const void *id, int rank, int world_size);
+void ev2g_comm_destroy(ev2g_handle *h);
+int ev2g_comm_world_size(const ev2g_handle *h);   /* 0: no communicator */
+long long ev2g_comm_gathers(const ev2g_handle *h); /* all-gathers issued so far */
+/* stats_all: DEVICE [world_size * E, EV2G_N_STATS] float64, rank-major */
+int ev2g_gather_stats(ev2g_handle *h, double *stats_all);
+
 /* ---- inspection (feeds the read-only Python facade of the reference object graph) ----------- */
 /* HOST output buffers; any may be NULL.  Synchronises.  Port arrays are in reference port order;
  * empty ports are NaN / -1.  */

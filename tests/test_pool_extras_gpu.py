@@ -322,3 +322,29 @@ def test_rccl_statistics_gather_runs_on_the_device():
             env.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_c_abi_rccl_gather_for_hosts_without_torch():
+    """ev2g_comm_get_unique_id / ev2g_comm_init / ev2g_gather_stats: the statistics all-gather issued by the library itself
+    through librccl on the engine's stream (world size 1 on this box; bench.py --gpus N runs it across ranks)."""
+    from ev2gym_amd.engine import Engine, EngineError
+    pool, rk, sk, lo = _shape("wave_v2gppl", 24, seed=3)
+    eng = Engine(pool, rk, sk, device=0, flags=4, n_active_envs=16)
+    E, P, T = eng.E, eng.P, eng.T
+    d_act = eng.empty((T, E, P))
+    eng.fill_uniform(d_act, T * E * P, 8, lo, 1.0)
+    eng.reset(offset=5)
+    eng.step_n(T, d_act, E * P, None, 0, None, 0, None, 0, None, 0, auto_reset=False, persistent=True)
+    with pytest.raises(EngineError, match="communicator"):
+        eng.gather_stats()
+    uid = Engine.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng.comm_init(uid, 0, 1)
+    assert eng.comm_world_size == 1
+    want = eng.stats()
+    got = eng.gather_stats()
+    assert got.shape == (E, 17) and np.array_equal(got, want, equal_nan=True) and eng.comm_gathers == 1
+    out = eng.empty((E, 17))
+    eng.gather_stats(out)                       # device output, stream-ordered
+    assert np.array_equal(out.to_host(), want, equal_nan=True) and eng.comm_gathers == 2
+    eng.close()
