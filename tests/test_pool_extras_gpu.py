@@ -78,8 +78,10 @@ def test_scenario_pool_window_matches_oracle(kind, M, E, K):
         _close(d_obs0.to_host(), ora.reset(), f"reset obs, offset {off}")
         eng.step_n(K, d_act, E * P, d_obs, E * D, d_rew, E, None, 0, d_mask, E * P, auto_reset=False, persistent=(off != 0))
         obs, rew, mask = d_obs.to_host(), d_rew.to_host(), d_mask.to_host()
+        faulted = False
         for t in range(K):
             o, r, d, m, rc = ora.step(acts[t].copy())
+            faulted = faulted or rc != 0
             assert np.array_equal(mask[t], m), f"mask[{t}], offset {off}"
             _close(obs[t], o, f"obs[{t}], offset {off}")
             _close(rew[t], r, f"reward[{t}], offset {off}")
@@ -89,7 +91,13 @@ def test_scenario_pool_window_matches_oracle(kind, M, E, K):
             pk, po = eng.peek(e), ora.peek(e)
             _close(pk["port_capacity"], po["cap"], "capacity")
             assert (pk["port_session"] == po["session"]).all()
-        eng.check_faults()
+        # the reference raises when the running sum of a charger's currents passes its limit (ev_charger.py:203-205; with several V2G ports
+        # and actions beyond the box that happens): the engine flags exactly the runs the oracle flags
+        if faulted:
+            with pytest.raises(Exception, match="over-current"):
+                eng.check_faults()
+        else:
+            eng.check_faults()
         ora.close()
     eng.close()
 

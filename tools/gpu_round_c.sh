@@ -1,5 +1,4 @@
 #!/bin/bash
-# GPU round C: parity suite after replay-write / topology / RCCL entry points, cfg4 profile for the general-kernel work.
+# GPU round C: parity suite after replay-write / topology / RCCL entry points.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r2c; mkdir -p $O
-( time python -m pytest tests -m gpu -q -x ) > $O/pytest.log 2>&1; tail -6 $O/pytest.log
-bash tools/prof_step.sh cfg4 --workload cfg4 --steps 224 --warmup 28 > $O/prof_cfg4.txt 2>&1; tail -40 $O/prof_cfg4.txt
+( time python -m pytest tests -m gpu -q ) > $O/pytest.log 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" $O/pytest.log | tail; grep -B5 -A40 "^___" $O/pytest.log | head -150
