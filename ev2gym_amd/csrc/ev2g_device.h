@@ -176,6 +176,20 @@ __device__ __forceinline__ double dpp_mov_f64(double v) {
 __device__ __forceinline__ double xor1_f64(double v) { return dpp_mov_f64<0xB1>(v); }
 __device__ __forceinline__ double xor2_f64(double v) { return dpp_mov_f64<0x4E>(v); }
 __device__ __forceinline__ double xor4_f64(double v) { return dpp_mov_f64<0x141>(dpp_mov_f64<0x1B>(v)); }
+// Sum over the 64 lanes of a wavefront without touching the LDS crossbar: three DPP butterflies inside 8-lane groups, row_ror:8
+// for the 16-lane rows, then the four row sums through v_readlane.  The result is wave-uniform; fixed order (bit-reproducible).
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += xor1_f64(v);
+    v += xor2_f64(v);
+    v += xor4_f64(v);
+    v += dpp_mov_f64<0x128>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 
 // dict.get(np.round(amps), 1): integer keys 0..100 exist, anything else -> 1   (ev.py:287-290, :375-379)
 __device__ __forceinline__ double lut_get(const double *__restrict__ lut, int id, double key) {

@@ -281,6 +281,21 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     for (int i = tid; i < R; i += BLOCK) trobs[i] = S->tr_obs[i];
     for (int i = tid; i < ne * 5; i += BLOCK) eacc[i] = 0.0;
     for (int i = tid; i < ne; i += BLOCK) pot_prev[i] = (t < T) ? S->pot_hist[t * E + e0 + i] : 0.0;
+    // observation-head role of this lane (columns pl and pl + lpe of the env it serves at env level), fixed for the launch:
+    // destination column, and where the value comes from -- charge price `hsrc` steps ahead (hsrc < 20), or entry hsrc - 20 of the
+    // env's window table row block (then + sstep*40 per step); hdst < 0: no column
+    int hdst0 = -1, hsrc0 = 0, hdst1 = -1, hsrc1 = 0;
+    {
+        const int nhead0 = (S->state_kind == 1) ? 0 : 20 + ((S->state_kind == 0) ? 40 * R : 0);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int c = pl + u * lpe;
+            int dst = -1, src = 0;
+            if (c < 20 && c < nhead0) { dst = 2 + c; src = c; }
+            else if (c < nhead0) { const int i = c - 20, r = i / 40, j = i - r * 40; dst = S->tr_obs[r] + j; src = 20 + r * (T + 1) * 40 + j; }
+            if (u == 0) { hdst0 = dst; hsrc0 = src; } else { hdst1 = dst; hsrc1 = src; }
+        }
+    }
     const float *act32 = (const float *)S->x_act32;   // float32 actions (StepExtras), used when io.actions is null
     const long long a_base = io.actions ? 0 : (long long)io.step0 * io.a_stride;
     double a_next = ev2g_action(io, act32, a_base, valid ? e * P + pref : e0 * P);
@@ -295,6 +310,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
         asm volatile("" : "+s"(S));  // parameters are (re)loaded through the scalar cache where they are used
         int tid_l = tid, g_l = g, e_l = e, cs_l = cs, pref_l = pref, ocol_l = ocol, pe_l = pe, pl_l = pl, pel_l = pel;
         asm volatile("" : "+v"(tid_l), "+v"(g_l), "+v"(e_l), "+v"(cs_l), "+v"(pref_l), "+v"(ocol_l), "+v"(pe_l), "+v"(pl_l), "+v"(pel_l));
+        int hdst0_l = hdst0, hsrc0_l = hsrc0, hdst1_l = hdst1, hsrc1_l = hsrc1;
+        asm volatile("" : "+v"(hdst0_l), "+v"(hsrc0_l), "+v"(hdst1_l), "+v"(hsrc1_l));
         if (t >= T) {  // episode finished inside a fused run: in-kernel ev2g_reset for this workgroup
             if (!auto_reset) break;
             off = ev2g_scn(off, io.scn_stride, M);
@@ -327,6 +344,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
         // ---------------- A: home lanes, charger level (ev_charger.py:137-186) ----------------
         bool occ = false;
         double cap_before = 0.0;
+        double amps = 0.0;
         if (valid) {
             const int ta = s_ta[tid_l], td = s_td[tid_l];
             occ = (ta <= t) && (t <= td);
@@ -346,7 +364,6 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 if (Ssum > 1.0) a = a / Ssum;
                 else if (Ssum < -1.0) a = -a / Ssum;
             }
-            double amps = 0.0;
             if (occ) {
                 const double x = rnd5_x(a);
                 if (x > 0.0) { amps = x * c_imax; if (amps < c_thr_ch) amps = 0.0; }
@@ -358,9 +375,21 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             stage[5 * NS + tid_l] = 0.0;
             stage[6 * NS + tid_l] = 0.0;
             stage[7 * NS + tid_l] = 0.0;
-            if (amps != 0.0) items[(amps > 0.0) ? atomicAdd(&cnt[0], 1) : NS - 1 - atomicAdd(&cnt[1], 1)] = tid_l;
-            // next step's action: issued now, consumed after the barriers of this step
-
+        }
+        {   // compact the ports that have battery maths to do: charging items from the front of `items`, discharging ones from its
+            // back.  One LDS atomic per wavefront and list (ballot + lane prefix count); an atomic per item serialises on the
+            // two counters -- ~200 same-address atomics per step at 1000 ports.
+            const unsigned long long mch = __ballot(amps > 0.0), mdis = __ballot(amps < 0.0);
+            const int lane = tid & 63;
+            int bch = 0, bdis = 0;
+            if (lane == 0) {
+                if (mch) bch = atomicAdd(&cnt[0], __popcll(mch));
+                if (mdis) bdis = atomicAdd(&cnt[1], __popcll(mdis));
+            }
+            bch = __shfl(bch, 0, 64);
+            bdis = __shfl(bdis, 0, 64);
+            if (amps > 0.0) items[bch + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mch >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mch, 0u))] = tid_l;
+            else if (amps < 0.0) items[NS - 1 - (bdis + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mdis >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mdis, 0u)))] = tid_l;
         }
         // ---- prefetch what phases C-E of this step need (issued AFTER phase A consumed its own operands, so that
         //      phase A never waits on them; the loads stay in flight across the LDS-only barriers) ----
@@ -385,15 +414,11 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             pf_ob0 = S->setpoint[pec * T + min(sstep, T - 1)];   // consumed by pl == 0, masked by sstep < T
         } else {
             const double *pprice = (const double *)S->price_ch + pec * T;
+            const double *pwin = (const double *)S->win_tab + ((long long)pec * R * (T + 1) + sstep) * 40 - 20;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const int c = pl_l + u * lpe;
-                const double *pa = pprice;
-                if (c < 20) pa = pprice + min(sstep + c, T - 1);
-                else if (c < nhead) {
-                    const int i = c - 20, r = i / 40, j = i - r * 40;
-                    pa = (const double *)S->win_tab + (((long long)pec * R + r) * (T + 1) + sstep) * 40 + j;
-                }
+                const int src = u ? hsrc1_l : hsrc0_l;
+                const double *pa = (src < 20) ? pprice + min(sstep + src, T - 1) : pwin + src;
                 const double v = *pa;
                 if (u == 0) pf_ob0 = v; else pf_ob1 = v;
             }
@@ -563,7 +588,33 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
         }
 
         // ---------------- D: LDS-staged segmented reduction, one wavefront per (env, transformer) ----------------
-        {
+        const bool one_env = (BLOCK >= 512) && (G == 1) && (R > 1) && (R <= 64);   // a big env owns the whole workgroup (P > 256), several transformers
+        if (one_env) {
+            // Only quantity 0 (power) is needed per transformer; the other seven are needed per ENV.  Power: 8 lanes per
+            // transformer segment, DPP butterfly.  Totals: BLOCK/8 lanes per quantity read the whole row with unit stride
+            // (bank-conflict free), one butterfly per wavefront, per-wavefront partials into the unused rows 1..7 of tsum.
+            if (tid_l < R * 8) {
+                const int r = tid_l >> 3, j = tid_l & 7;
+                const int b = seg[r + 1];
+                double acc = 0.0;
+                for (int i = seg[r] + j; i < b; i += 8) acc += stage[i];
+                acc += xor1_f64(acc);
+                acc += xor2_f64(acc);
+                acc += xor4_f64(acc);
+                if (j == 0) tsum[r] = acc;
+            }
+            constexpr int LPK = BLOCK / 8;          // lanes per quantity
+            const int k = 1 + tid_l / LPK, c = tid_l - (k - 1) * LPK;
+            if (k < EV2G_NQ) {
+                const double *sp = stage + k * NS;
+                double c0 = 0.0, c1 = 0.0;
+                int i = c;
+                for (; i + LPK < P; i += 2 * LPK) { c0 += sp[i]; c1 += sp[i + LPK]; }
+                if (i < P) c0 += sp[i];
+                const double v = wave_sum_dpp(c0 + c1);
+                if ((tid_l & 63) == 0) tsum[k * NT + (c >> 6)] = v;
+            }
+        } else {
             const int wv = tid_l >> 6, lane = tid_l & 63, nw = BLOCK >> 6;
             const int k = lane >> 3, j = lane & 7;
             const int ntask = ne * R;
@@ -586,6 +637,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
         PT_MARK(1)
 
         // ---------------- E1: per (env, transformer): Transformer.reset + step + get_how_overloaded ----------------
+        double over100 = 0.0;
         if (tid_l < ne * R) {  // transformer.py:258-302
             double ptr = pf_infl + pf_solar;
             ptr += tsum[0 * NT + tid_l];
@@ -593,9 +645,22 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             const int tel = tid_l / R, r = tid_l - tel * R;
             S->over_hist[(t * E + e0 + tel) * R + r] = over;
             if (last_step) S->tr_power_now[(e0 + tel) * R + r] = ptr;
-            over_l[tid_l] = 100.0 * over;
+            over100 = 100.0 * over;
+            over_l[tid_l] = over100;
         }
-        if (R > 1) {
+        if (one_env && tid_l < 64) {
+            // all transformer lanes sit in wavefront 0: the env's overload sum and total power with in-register butterflies, and the
+            // other totals from the per-wavefront partials of phase D -- no second pass over tsum, no extra barriers
+            const double ov = wave_sum_dpp(over100);
+            const double pw = wave_sum_dpp((tid_l < R) ? tsum[tid_l] : 0.0);
+            if (tid_l == 0) { osum[0] = ov; esum[0] = pw; }
+            else if (tid_l < EV2G_NQ) {
+                double v = 0.0;
+                for (int w = 0; w < BLOCK / 8 / 64; w++) v += tsum[tid_l * NT + w];
+                esum[tid_l * G] = v;
+            }
+        }
+        if (R > 1 && !one_env) {
             // (env, quantity) sums over the env's R transformers: one wavefront per sum, lanes strided over the
             // transformers, fixed xor tree (a single lane adding R values is an R-long chain of LDS round trips)
             const int wave = tid_l >> 6, ln = tid_l & 63;
@@ -608,7 +673,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             }
         }
         lds_barrier();
-        if (R > 1) {   // the overload penalties of E1 are visible now: their per-env sum, same scheme
+        if (R > 1 && !one_env) {   // the overload penalties of E1 are visible now: their per-env sum, same scheme
             const int wave = tid_l >> 6, ln = tid_l & 63;
             for (int tel = wave; tel < ne; tel += (BLOCK >> 6)) {
                 double v = 0.0;
@@ -665,14 +730,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                     if (pl_l == 0) { EV2G_OBS_PUT(0, (double)sstep / (double)T) EV2G_OBS_PUT(1, (sstep < T) ? pf_ob0 : 0.0) EV2G_OBS_PUT(2, usage) }
                 } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135
                     if (pl_l == 0) { EV2G_OBS_PUT(0, (double)sstep) EV2G_OBS_PUT(1, usage) }
-                    int c = pl_l;
-                    if (c < 20) EV2G_OBS_PUT(2 + c, (sstep + c < T) ? fabs(pf_ob0) : 0.0)
-                    else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; EV2G_OBS_PUT(trobs[r] + j, pf_ob0) }
-                    c = pl_l + lpe;
-                    if (c < 20) EV2G_OBS_PUT(2 + c, (sstep + c < T) ? fabs(pf_ob1) : 0.0)
-                    else if (c < nhead) { const int i = c - 20, r = i / 40, j = i - r * 40; EV2G_OBS_PUT(trobs[r] + j, pf_ob1) }
+                    if (hdst0_l >= 0) EV2G_OBS_PUT(hdst0_l, (hsrc0_l < 20) ? ((sstep + hsrc0_l < T) ? fabs(pf_ob0) : 0.0) : pf_ob0)
+                    if (hdst1_l >= 0) EV2G_OBS_PUT(hdst1_l, (hsrc1_l < 20) ? ((sstep + hsrc1_l < T) ? fabs(pf_ob1) : 0.0) : pf_ob1)
                     // envs with more head columns than two passes of their lanes (many transformers): the rest, unprefetched
-                    for (c = pl_l + 2 * lpe; c < nhead; c += lpe) {
+                    for (int c = pl_l + 2 * lpe; c < nhead; c += lpe) {
                         const int i = c - 20, r = i / 40, j = i - r * 40;
                         EV2G_OBS_PUT(trobs[r] + j, S->win_tab[(((long long)pec * R + r) * (T + 1) + sstep) * 40 + j])
                     }
