@@ -176,6 +176,9 @@ __device__ __forceinline__ double dpp_mov_f64(double v) {
 __device__ __forceinline__ double xor1_f64(double v) { return dpp_mov_f64<0xB1>(v); }
 __device__ __forceinline__ double xor2_f64(double v) { return dpp_mov_f64<0x4E>(v); }
 __device__ __forceinline__ double xor4_f64(double v) { return dpp_mov_f64<0x141>(dpp_mov_f64<0x1B>(v)); }
+__device__ __forceinline__ double readlane_f64(double v, int lane) {   // wave-uniform copy of lane `lane` (a compile-time constant)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 // Sum over the 64 lanes of a wavefront without touching the LDS crossbar: three DPP butterflies inside 8-lane groups, row_ror:8
 // for the 16-lane rows, then the four row sums through v_readlane.  The result is wave-uniform; fixed order (bit-reproducible).
 __device__ __forceinline__ double wave_sum_dpp(double v) {

@@ -648,77 +648,96 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             over100 = 100.0 * over;
             over_l[tid_l] = over100;
         }
-        if (one_env && tid_l < 64) {
-            // all transformer lanes sit in wavefront 0: the env's overload sum and total power with in-register butterflies, and the
-            // other totals from the per-wavefront partials of phase D -- no second pass over tsum, no extra barriers
-            const double ov = wave_sum_dpp(over100);
-            const double pw = wave_sum_dpp((tid_l < R) ? tsum[tid_l] : 0.0);
-            if (tid_l == 0) { osum[0] = ov; esum[0] = pw; }
-            else if (tid_l < EV2G_NQ) {
-                double v = 0.0;
-                for (int w = 0; w < BLOCK / 8 / 64; w++) v += tsum[tid_l * NT + w];
-                esum[tid_l * G] = v;
+        // env-level quantities of this step, as the lane that owns the env (pl == 0) needs them
+        double q_usage = 0.0, q_costs = 0.0, q_sat = 0.0, q_pot = 0.0, q_ech = 0.0, q_edis = 0.0, q_emerg = 0.0, q_over = 0.0;
+        if (one_env) {
+            // All transformer lanes sit in wavefront 0, which also holds the env's owner lane: overload sum and total power by
+            // in-register butterflies, the other totals from phase D's per-wavefront partials (lane k sums quantity k) handed to
+            // the owner through v_readlane.  No pass over tsum, no LDS hand-off, NO barrier: the other wavefronts go straight from
+            // their observation-head stores into the next step.
+            if (tid_l < 64) {
+                q_over = wave_sum_dpp(over100);
+                q_usage = wave_sum_dpp((tid_l < R) ? tsum[tid_l] : 0.0);
+                double tot = 0.0;
+                if (tid_l >= 1 && tid_l < EV2G_NQ)
+                    for (int w = 0; w < BLOCK / 8 / 64; w++) tot += tsum[tid_l * NT + w];
+                q_costs = readlane_f64(tot, 1); q_sat = readlane_f64(tot, 2); q_pot = readlane_f64(tot, 3);
+                q_ech = readlane_f64(tot, 4); q_edis = readlane_f64(tot, 5); q_emerg = readlane_f64(tot, 6);
             }
-        }
-        if (R > 1 && !one_env) {
-            // (env, quantity) sums over the env's R transformers: one wavefront per sum, lanes strided over the
-            // transformers, fixed xor tree (a single lane adding R values is an R-long chain of LDS round trips)
-            const int wave = tid_l >> 6, ln = tid_l & 63;
-            for (int task = wave; task < ne * EV2G_NQ; task += (BLOCK >> 6)) {
-                const int tel = task / EV2G_NQ, k = task - tel * EV2G_NQ;
-                double v = 0.0;
-                for (int r = ln; r < R; r += 64) v += tsum[k * NT + tel * R + r];
-                v = wave_sum(v);
-                if (ln == 0) esum[k * G + tel] = v;
-            }
-        }
-        lds_barrier();
-        if (R > 1 && !one_env) {   // the overload penalties of E1 are visible now: their per-env sum, same scheme
-            const int wave = tid_l >> 6, ln = tid_l & 63;
-            for (int tel = wave; tel < ne; tel += (BLOCK >> 6)) {
-                double v = 0.0;
-                for (int r = ln; r < R; r += 64) v += over_l[tel * R + r];
-                v = wave_sum(v);
-                if (ln == 0) osum[tel] = v;
+        } else {
+            if (R > 1) {
+                // (env, quantity) sums over the env's R transformers: one wavefront per sum, lanes strided over the
+                // transformers, fixed xor tree (a single lane adding R values is an R-long chain of LDS round trips)
+                const int wave = tid_l >> 6, ln = tid_l & 63;
+                for (int task = wave; task < ne * EV2G_NQ; task += (BLOCK >> 6)) {
+                    const int tel = task / EV2G_NQ, k = task - tel * EV2G_NQ;
+                    double v = 0.0;
+                    for (int r = ln; r < R; r += 64) v += tsum[k * NT + tel * R + r];
+                    v = wave_sum(v);
+                    if (ln == 0) esum[k * G + tel] = v;
+                }
             }
             lds_barrier();
+            if (R > 1) {   // the overload penalties of E1 are visible now: their per-env sum, same scheme
+                const int wave = tid_l >> 6, ln = tid_l & 63;
+                for (int tel = wave; tel < ne; tel += (BLOCK >> 6)) {
+                    double v = 0.0;
+                    for (int r = ln; r < R; r += 64) v += over_l[tel * R + r];
+                    v = wave_sum(v);
+                    if (ln == 0) osum[tel] = v;
+                }
+                lds_barrier();
+            }
+            const double *es = (R > 1) ? esum : tsum;
+            const int esn = (R > 1) ? G : NT;
+            if (env_lane) {
+                q_usage = es[0 * esn + pel_l];
+                if (pl_l == 0) {
+                    q_over = (R > 1) ? osum[pel_l] : over_l[pel_l];
+                    q_costs = es[1 * esn + pel_l]; q_sat = es[2 * esn + pel_l]; q_pot = es[3 * esn + pel_l];
+                    q_ech = es[4 * esn + pel_l]; q_edis = es[5 * esn + pel_l]; q_emerg = es[6 * esn + pel_l];
+                }
+            }
         }
-        const double *es = (R > 1) ? esum : tsum;
-        const int esn = (R > 1) ? G : NT;
 
         // ---------------- E2: per env: reward, histories, observation head ----------------
+        // the parameters the owner lane's chain needs, fetched in ONE scalar-load batch (one wait) instead of a round trip per use
+        double *const p_usage = (double *)S->usage_hist, *const p_pot = (double *)S->pot_hist, *const p_cost = (double *)S->x_cost;
+        double *const p_acc = (double *)S->env_acc;
+        const long long c_stride = S->x_c_stride;
+        const int rkind = S->reward_kind, ckind = S->cost_kind;
         if (env_lane) {
-            const double usage = es[0 * esn + pel_l];
+            const double usage = q_usage;
             if (pl_l == 0) {
-                const double over_sum = (R > 1) ? osum[pel_l] : over_l[pel_l];
-                S->usage_hist[t * E + pe_l] = usage;
-                const double potn = es[3 * esn + pel_l];
-                if (sstep < T) S->pot_hist[sstep * E + pe_l] = potn;
-                const double costs = es[1 * esn + pel_l];
+                const double over_sum = q_over;
+                p_usage[t * E + pe_l] = usage;
+                const double potn = q_pot;
+                if (sstep < T) p_pot[sstep * E + pe_l] = potn;
+                const double costs = q_costs;
                 double reward;
-                if (S->reward_kind == 1) {  // SquaredTrackingErrorReward reward.py:7-14
+                if (rkind == 1) {  // SquaredTrackingErrorReward reward.py:7-14
                     const double pp = pot_prev[pel_l];
                     const double m = (pp < pf_sp) ? pp : pf_sp;
                     const double d = m - usage;
                     reward = -(d * d);
-                } else if (S->reward_kind == 2) {  // profit_maximization reward.py:78-87
-                    reward = costs - es[2 * esn + pel_l];
+                } else if (rkind == 2) {  // profit_maximization reward.py:78-87
+                    reward = costs - q_sat;
                 } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
-                    reward = costs - over_sum - es[2 * esn + pel_l];
+                    reward = costs - over_sum - q_sat;
                 }
                 pot_prev[pel_l] = potn;
                 double *acc = eacc + pel_l * 5;
                 acc[0] += reward;
                 acc[1] += costs;
-                acc[2] += es[4 * esn + pel_l];
-                acc[3] += es[5 * esn + pel_l];
-                acc[4] += es[6 * esn + pel_l];
+                acc[2] += q_ech;
+                acc[3] += q_edis;
+                acc[4] += q_emerg;
                 if (io.reward) io.reward[(long long)kk * io.r_stride + pe_l] = reward;
                 if (io.done) io.done[(long long)kk * io.d_stride + pe_l] = (sstep >= T) ? 1 : 0;
-                if (S->x_cost)   // cost_function (rl_agent/cost.py:8-27)
-                    S->x_cost[(long long)(io.step0 + kk) * S->x_c_stride + pe_l] = (S->cost_kind == 2) ? costs : over_sum + es[2 * esn + pel_l];
+                if (p_cost)   // cost_function (rl_agent/cost.py:8-27)
+                    p_cost[(long long)(io.step0 + kk) * c_stride + pe_l] = (ckind == 2) ? costs : over_sum + q_sat;
                 if (sstep >= T || last_step) {  // flush the episode accumulators (get_statistics reads them)
-                    auto ga = S->env_acc + pe_l * 8;
+                    double *ga = p_acc + pe_l * 8;
                     for (int i = 0; i < 5; i++) { ga[i] += acc[i]; acc[i] = 0.0; }
                 }
             }
@@ -745,7 +764,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
         PT_STEP_END(false)
         t += 1;
         // no barrier needed here: the next step's phase A only touches stage[0,4..7], s_amps, items and cnt, none
-        // of which phase E reads; tsum/esum/over_l are rewritten only after three more barriers.
+        // of which phase E reads; tsum/esum/over_l are rewritten only after three more barriers (in the one-env scheme wavefront 0
+        // may still be in phase E while the others start the next step: same argument).
     }
     PT_FLUSH
     // ---- write the LDS-resident port state back ----
