@@ -153,6 +153,31 @@ class RolloutLoop:
                 self.episode_end()
 
 
+class PipelinedLoops:
+    """Several RolloutLoops over disjoint env groups of one GPU, each with its own engine handle and HIP stream, fed by one host
+    thread per group.  With a policy in the loop every step is a chain of two dependent kernels (actor forward -> env step); two
+    groups let the GPU run one group's actor forward next to the other group's env step, and hide the launch gaps of both."""
+
+    def __init__(self, loops):
+        from concurrent.futures import ThreadPoolExecutor
+        self.loops = loops
+        self.eng, self.T = loops[0].eng, loops[0].T
+        self.pool = ThreadPoolExecutor(len(loops))
+
+    def reset(self):
+        for l in self.loops:
+            l.reset()
+
+    @property
+    def episodes(self):
+        return self.loops[0].episodes
+
+    def run(self, n_steps, persistent, timing=None):
+        futs = [self.pool.submit(l.run, n_steps, persistent, timing if i == 0 else None) for i, l in enumerate(self.loops)]
+        for f in futs:
+            f.result()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,6 +192,9 @@ def main():
                     "have been measured per launch mode (median over the repetitions is reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-soc-log", action="store_true", help="skip the SoC log that the battery-degradation statistics need")
+    ap.add_argument("--actor-groups", type=int, default=1, help="with --actor mlp: split the envs of a GPU into this many independently "
+                    "pipelined groups (own engine handle + HIP stream each); 1 = one chain of dependent kernels.  Measured on MI355X: "
+                    "1 -> 147 M, 2 -> 148-149 M, 4 -> 143-145 M env-steps/s (the gaps between dependent kernels are GPU-side)")
     ap.add_argument("--actor", default="none", choices=["none", "mlp", "mlp_torch"],
                     help="BASELINE configs[4]-shaped rollout: an actor (obs->400->300->P, tanh; SB3-DDPG shape, random weights) "
                          "produces the actions on the device between steps (forces per_step launches).  mlp: the fused one-kernel "
@@ -199,30 +227,41 @@ def main():
     batch = generate(wl["gen"](M, args.seed * 1000 + rank))   # every rank draws its own pool of scenarios
     phi = occupancy_fraction(batch)
     # engine kernels, torch allocations and the RCCL gather all run on ONE explicit (non-default) stream
-    tstream = torch.cuda.Stream(device=local_rank)
-    torch.cuda.set_stream(tstream)
-    eng = Engine(batch, rk, sk, device=local_rank, stream=tstream.cuda_stream,
-                 flags=0 if args.no_soc_log else _abi.FLAG_LOG_SOC, n_active_envs=E)
-    P, D, T = eng.P, eng.D, eng.T
     dev = torch.device("cuda", local_rank)
-    acts = torch.empty((T, E, P), dtype=torch.float64, device=dev)
-    eng.fill_uniform(acts, T * E * P, 999 + rank, wl["lo"], 1.0)
-    obs = torch.empty((E, D), dtype=torch.float64, device=dev)
-    rew = torch.empty((E,), dtype=torch.float64, device=dev)
-    done = torch.empty((E,), dtype=torch.uint8, device=dev)
-    mask = torch.empty((E, P), dtype=torch.uint8, device=dev)
-    stats = torch.empty((E, _abi.N_STATS), dtype=torch.float64, device=dev)
+    n_groups = args.actor_groups if (args.actor == "mlp" and args.actor_groups > 1 and E % args.actor_groups == 0) else 1
+    Eg, Mg = E // n_groups, M // n_groups
     gath = None
     if world > 1:   # double-buffered asynchronous all-gather: the statistics travel while the next episode steps
         from ev2gym_amd.dist import AsyncStatsGather
         gath = AsyncStatsGather(E, world, dev)
-
-    actor = None
-    if args.actor != "none":
-        from ev2gym_amd.actor import make_actor
-        actor = make_actor(eng, E, P, D, wl["lo"], dev, seed=1234 + rank, kind="fused" if args.actor == "mlp" else "torch")
-
-    loop = RolloutLoop(eng, E, P, T, M, acts, obs, rew, done, mask, stats, gath, actor)
+    loops, engines, actor = [], [], None
+    for gi in range(n_groups):
+        # engine kernels, torch allocations and the RCCL gather of a group all run on ONE explicit (non-default) stream
+        tstream = torch.cuda.Stream(device=local_rank)
+        if gi == 0:
+            torch.cuda.set_stream(tstream)
+        gb = batch if n_groups == 1 else batch.select(np.arange(gi * Mg, (gi + 1) * Mg))
+        eng = Engine(gb, rk, sk, device=local_rank, stream=tstream.cuda_stream,
+                     flags=0 if args.no_soc_log else _abi.FLAG_LOG_SOC, n_active_envs=Eg)
+        P, D, T = eng.P, eng.D, eng.T
+        acts = None
+        if args.actor == "none":
+            acts = torch.empty((T, Eg, P), dtype=torch.float64, device=dev)
+            eng.fill_uniform(acts, T * Eg * P, 999 + rank, wl["lo"], 1.0)
+        obs = torch.empty((Eg, D), dtype=torch.float64, device=dev)
+        rew = torch.empty((Eg,), dtype=torch.float64, device=dev)
+        done = torch.empty((Eg,), dtype=torch.uint8, device=dev)
+        mask = torch.empty((Eg, P), dtype=torch.uint8, device=dev)
+        stats = torch.empty((Eg, _abi.N_STATS), dtype=torch.float64, device=dev)
+        g_actor = None
+        if args.actor != "none":
+            from ev2gym_amd.actor import make_actor
+            g_actor = make_actor(eng, Eg, P, D, wl["lo"], dev, seed=1234 + rank, kind="fused" if args.actor == "mlp" else "torch")
+            actor = actor or g_actor
+        loops.append(RolloutLoop(eng, Eg, P, T, Mg, acts, obs, rew, done, mask, stats, gath if n_groups == 1 else None, g_actor))
+        engines.append(eng)
+    eng = engines[0]
+    loop = loops[0] if n_groups == 1 else PipelinedLoops(loops)
 
     def barrier():
         if gath is not None:
@@ -301,15 +340,16 @@ def main():
         kern_steps = sum(k for _, k in tim)
         n_launch = kern_steps if mode == "per_step" else len(tim)
         launch_s = kern_ms / 1e3 / n_launch
-        bytes_per_launch = bytes_env_step * E * (kern_steps / n_launch)
+        bytes_per_launch = bytes_env_step * Eg * (kern_steps / n_launch)   # (the timed launches are those of env group 0)
         achieved = bytes_per_launch / launch_s / 1e9
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": measured_traffic(args.workload, mode, kern_steps / n_launch, E),
+                "traffic": measured_traffic(args.workload, mode, kern_steps / n_launch, Eg),
                 "kernel": eng.kernel_name, "avg_launch_us": launch_s * 1e6, "steps_per_launch": kern_steps / n_launch,
                 "algorithmic_bytes_per_env_step": bytes_env_step}
 
     roof = {m: roofline(m) for m in modes}
-    eng.check_faults()
+    for e_ in engines:
+        e_.check_faults()
 
     # outside the timed regions: the C-ABI's own RCCL gather (ev2g_comm_init / ev2g_gather_stats, the path of hosts without
     # torch.distributed) next to torch's, on the same statistics
@@ -320,9 +360,9 @@ def main():
             ids = [Engine.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             eng.comm_init(ids[0], rank, world)
-            st_all = torch.empty((world * E, _abi.N_STATS), dtype=torch.float64, device=dev)
+            st_all = torch.empty((world * eng.E, _abi.N_STATS), dtype=torch.float64, device=dev)
             eng.gather_stats(st_all)
-            st_loc = torch.empty((E, _abi.N_STATS), dtype=torch.float64, device=dev)
+            st_loc = torch.empty((eng.E, _abi.N_STATS), dtype=torch.float64, device=dev)
             eng.stats(out=st_loc)
             want = gather_stats_tensor(st_loc)
             torch.cuda.synchronize()
@@ -348,6 +388,7 @@ def main():
         "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": E, "scenario_pool_per_gpu": M, "chargers": C_,
                    "transformers": R_, "steps_per_episode": T, "obs_dim": D, "occupancy_phi": round(phi, 4), "soc_log": not args.no_soc_log,
                    "launch": best, "actor": args.actor if actor is None else actor.describe,
+                   "actor_env_groups": (n_groups if actor is not None else None),
                    "parallelism": f"env-sharded x{world}, RCCL all_gather of episode stats only (asynchronous, overlaps the next episode)"},
         "port_steps_per_s": value * P,
         "wall_s_by_launch_mode": {m: round(w, 6) for m, w in wall.items()},
@@ -363,7 +404,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(batch.select(np.arange(min(E, 512))), rk, sk, wl["lo"])
     elif rank == 0:
         out["cpu_baseline"] = None
-    eng.close()
+    for e_ in engines:
+        e_.close()
     if world > 1:
         gath.finish()
         dist.barrier()

@@ -56,6 +56,14 @@ struct ev2g_handle {
     bool timed = false;
     std::string err;
     CommState comm;                             // RCCL communicator of the statistics exchange (ev2g_comm_init), if any
+    // ev2g_rollout segments captured as HIP graphs: a policy-in-the-loop step is two short dependent kernels, so the enqueue cost
+    // of 2k launches (and the gaps between them) is comparable to the kernels; a segment with the same signature is replayed
+    struct RolloutGraph {
+        const void *mlp; int k, t0; long long scn_off; const void *rew, *done, *mask; long long rs, ds, ms;
+        ev2g_step_extras x; hipGraphExec_t exec;
+    };
+    std::vector<RolloutGraph> rollout_graphs;
+    long long graph_launches = 0;
 };
 
 #define HIPCHK(h, call)                                                                              \
@@ -145,6 +153,7 @@ void ev2g_destroy(ev2g_handle *h) {
     free_pool(h->st_allocs);
     free_pool(h->user_allocs);
     ev2g_comm_destroy(h);
+    for (auto &g : h->rollout_graphs) (void)hipGraphExecDestroy(g.exec);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -930,27 +939,66 @@ int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward,
     if (m->dev.d_in != h->D || m->dev.d_out != h->P) return fail(h, EV2G_ERR_ARG, "ev2g_rollout: actor shape != (obs dim, ports)");
     (void)hipSetDevice(h->device);
     const long long adv = (auto_reset == EV2G_AUTO_RESET_NEXT) ? h->E % h->M : 0;
+    // the k x (actor forward, env step) launches; `capturing`: no host-side reset inside (the caller made sure none is needed)
+    auto enqueue = [&](int k) -> int {
+        for (int i = 0; i < k; i++) {
+            if (h->current_step >= h->T) {
+                if (!auto_reset) return fail(h, EV2G_ERR_DONE, "ev2g_rollout: episode finished before k_steps (auto_reset off)");
+                int r2 = ev2g_reset_ex(h, nullptr, h->scn_off + adv);
+                if (r2) return r2;
+            }
+            int r2 = ev2g_mlp_forward(h, m, x.obs_f32, (float *)x.actions_f32, h->E);
+            if (r2) return r2;
+            StepIO io = make_io(h, nullptr, 0, nullptr, 0, reward ? reward + (long long)i * r_stride : nullptr, 0,
+                                done ? done + (long long)i * d_stride : nullptr, 0, mask ? mask + (long long)i * m_stride : nullptr, 0, 0, 0);
+            if (x.cost) io.step0 = i;   // (a cost buffer may record every step; the float32 buffers do not advance)
+            r2 = launch_steps(h, io, h->current_step, 1, 0);
+            if (r2) return r2;
+            h->current_step += 1;
+        }
+        return EV2G_OK;
+    };
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     int rc = EV2G_OK;
-    for (int i = 0; i < k_steps; i++) {
-        if (h->current_step >= h->T) {
-            if (!auto_reset) { rc = fail(h, EV2G_ERR_DONE, "ev2g_rollout: episode finished before k_steps (auto_reset off)"); break; }
-            int r2 = ev2g_reset_ex(h, nullptr, h->scn_off + adv);
-            if (r2) return r2;
+    static const bool use_graphs = [] { const char *e = std::getenv("EV2G_ROLLOUT_GRAPHS"); return !(e && e[0] == '0'); }();
+    const bool whole = h->current_step + k_steps <= h->T;   // no episode end inside the segment: nothing but kernel launches
+    if (use_graphs && whole && k_steps >= 4) {
+        ev2g_handle::RolloutGraph *hit = nullptr;
+        for (auto &g : h->rollout_graphs)
+            if (g.mlp == m && g.k == k_steps && g.t0 == h->current_step && g.scn_off == h->scn_off && g.rew == reward && g.done == done &&
+                g.mask == mask && g.rs == r_stride && g.ds == d_stride && g.ms == m_stride && std::memcmp(&g.x, &x, sizeof x) == 0) { hit = &g; break; }
+        if (!hit) {
+            const int t_before = h->current_step;
+            hipGraph_t graph = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue(k_steps);
+            const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+            h->current_step = t_before;
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (ce != hipSuccess) return fail(h, EV2G_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+            hipGraphExec_t exec = nullptr;
+            const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) return fail(h, EV2G_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+            if (h->rollout_graphs.size() >= 64) {   // bounded cache: drop the oldest
+                (void)hipGraphExecDestroy(h->rollout_graphs.front().exec);
+                h->rollout_graphs.erase(h->rollout_graphs.begin());
+            }
+            h->rollout_graphs.push_back({m, k_steps, t_before, h->scn_off, reward, done, mask, r_stride, d_stride, m_stride, x, exec});
+            hit = &h->rollout_graphs.back();
         }
-        int r2 = ev2g_mlp_forward(h, m, x.obs_f32, (float *)x.actions_f32, h->E);
-        if (r2) return r2;
-        StepIO io = make_io(h, nullptr, 0, nullptr, 0, reward ? reward + (long long)i * r_stride : nullptr, 0,
-                            done ? done + (long long)i * d_stride : nullptr, 0, mask ? mask + (long long)i * m_stride : nullptr, 0, 0, 0);
-        if (x.cost) io.step0 = i;   // (a cost buffer may record every step; the float32 buffers do not advance)
-        r2 = launch_steps(h, io, h->current_step, 1, 0);
-        if (r2) return r2;
-        h->current_step += 1;
+        HIPCHK(h, hipGraphLaunch(hit->exec, h->stream));
+        h->current_step += k_steps;
+        h->graph_launches++;
+    } else {
+        rc = enqueue(k_steps);
     }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return rc;
 }
+
+long long ev2g_rollout_graph_launches(const ev2g_handle *h) { return h ? h->graph_launches : 0; }
 
 double ev2g_last_step_n_kernel_ms(ev2g_handle *h) {
     if (!h || !h->timed) return -1.0;

@@ -76,6 +76,7 @@ def load_library(path: Optional[str] = None):
         "ev2g_mlp_destroy": (None, [vp, vp]),
         "ev2g_mlp_forward": (C.c_int, [vp, vp, vp, vp, C.c_int]),
         "ev2g_rollout": (C.c_int, [vp, vp, C.c_int, vp, i64, vp, i64, vp, i64, C.c_int]),
+        "ev2g_rollout_graph_launches": (C.c_longlong, [vp]),
         "ev2g_comm_get_unique_id": (C.c_int, [vp]),
         "ev2g_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
         "ev2g_comm_destroy": (None, [vp]),
@@ -100,7 +101,7 @@ EXPORTED_SYMBOLS = [
     "ev2g_check_faults", "ev2g_get_stats", "ev2g_stat_name", "ev2g_peek", "ev2g_malloc", "ev2g_free",
     "ev2g_memcpy_h2d", "ev2g_memcpy_d2h", "ev2g_synchronize", "ev2g_fill_uniform", "ev2g_host_uniform",
     "ev2g_last_step_n_kernel_ms", "ev2g_mlp_create", "ev2g_mlp_destroy", "ev2g_mlp_forward", "ev2g_rollout",
-    "ev2g_comm_get_unique_id", "ev2g_comm_init", "ev2g_comm_destroy", "ev2g_comm_world_size", "ev2g_comm_gathers", "ev2g_gather_stats"]
+    "ev2g_rollout_graph_launches", "ev2g_comm_get_unique_id", "ev2g_comm_init", "ev2g_comm_destroy", "ev2g_comm_world_size", "ev2g_comm_gathers", "ev2g_gather_stats"]
 
 
 def _ptr(x):
@@ -258,6 +259,10 @@ class Engine:
         """k x (actor forward on the registered float32 observation -> float32 actions -> env step), one C call."""
         self._check(self._lib.ev2g_rollout(self._h, m, int(k), _ptr(reward), int(r_stride), _ptr(done), int(d_stride), _ptr(mask),
                                            int(m_stride), int(auto_reset)))
+
+    @property
+    def rollout_graph_launches(self) -> int:
+        return int(self._lib.ev2g_rollout_graph_launches(self._h))
 
     def last_step_n_kernel_ms(self) -> float:
         return float(self._lib.ev2g_last_step_n_kernel_ms(self._h))

@@ -300,6 +300,9 @@ int ev2g_mlp_forward(ev2g_handle *h, const ev2g_mlp *m, const float *x, float *y
  * action_mask as in ev2g_step_n (mode EV2G_STEPN_PER_STEP_LAUNCH); auto_reset as there. */
 int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward, int64_t reward_step_stride, uint8_t *done,
                  int64_t done_step_stride, uint8_t *action_mask, int64_t mask_step_stride, int auto_reset);
+/* Segments that contain no episode end are captured once as a HIP graph (keyed by their full launch signature) and replayed;
+ * EV2G_ROLLOUT_GRAPHS=0 in the environment falls back to plain launches.  Number of graph replays so far: */
+long long ev2g_rollout_graph_launches(const ev2g_handle *h);
 
 /* ---- plain device-memory helpers so a ctypes host needs no other HIP binding --------------- */
 void *ev2g_malloc(ev2g_handle *h, size_t bytes);
