@@ -47,14 +47,17 @@ WORKLOADS = {
 
 
 def measured_traffic(workload, launch, steps_per_launch, envs):
-    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes (profiles/r01_hbm_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH doubled per the gfx950 note in
-    MI355X_MICROARCH.md), or None when this workload / launch shape was not profiled."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))[workload][launch]
-    except Exception:
-        return None
-    if abs(t["steps_per_launch"] - steps_per_launch) > 1e-9 or envs != WORKLOADS[workload]["envs"]:
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes (profiles/r02_hbm_traffic.json, written by
+    tools/prof_step.sh + tools/collect_evidence.py: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH doubled per
+    the gfx950 note in MI355X_MICROARCH.md), or None when this workload / launch shape was not profiled."""
+    t = None
+    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))[workload][launch]
+            break
+        except Exception:
+            continue
+    if t is None or abs(t["steps_per_launch"] - steps_per_launch) > 1e-9 or envs != WORKLOADS[workload]["envs"]:
         return None
     return (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
 
