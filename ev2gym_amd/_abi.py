@@ -10,6 +10,12 @@ REWARD_KINDS = {
     "ProfitMax_TrPenalty_UserIncentives": 0,   # rl_agent/reward.py:34-44
     "SquaredTrackingErrorReward": 1,           # rl_agent/reward.py:7-14
     "profit_maximization": 2,                  # rl_agent/reward.py:78-87
+    "SqTrError_TrPenalty_UserIncentives": 3,   # rl_agent/reward.py:16-32
+    "SquaredTrackingErrorRewardWithPenalty": 4,  # rl_agent/reward.py:46-58
+    "SimpleReward": 5,                         # rl_agent/reward.py:60-65
+    "MinimizeTrackerSurplusWithChargeRewards": 6,  # rl_agent/reward.py:67-76
+    "V2G_costs_simple": 7,                     # rl_agent/reward.py:151-154
+    "V2G_profitmax": 8,                        # rl_agent/reward.py:120-148
 }
 STATE_KINDS = {
     "V2G_profit_max_loads": 0,                 # rl_agent/state.py:108-155

@@ -326,6 +326,42 @@ __device__ __forceinline__ double load_minus_pv_at(const DevScn &s, long long er
     return l - p;
 }
 
+// ---- reward plugins (rl_agent/reward.py) -----------------------------------------------------------------------------
+// What a departing EV contributes to the step's "user" sum (staged per port, summed per env): the term of the reward in use,
+// or -- for rewards without one -- of the transformer_overload_usrpenalty cost (cost.py:8-20) when that is enabled.
+__device__ __forceinline__ double ev2g_departure_term(int reward_kind, int cost_kind, double score, double cap, double des) {
+    if (reward_kind == 3) return 1000.0 * (1.0 - score);                           // SqTrError_TrPenalty_UserIncentives :30-31
+    if (reward_kind == 8) return (des > cap) ? 100.0 * (des - cap) : 0.0;          // V2G_profitmax :130-136
+    if (reward_kind == 0 || reward_kind == 2 || cost_kind == 1) return 100.0 * exp(-10.0 * score);   // :41-42, :84-86, cost.py:17-18
+    return 0.0;
+}
+// The reward of a step from its env-level quantities.  costs: total profit of the step; usage: current_power_usage[t]; sp:
+// power_setpoints[t]; pot_t / pot_tm1: charge_power_potential[t] / [t-1] (0 before the episode's first entry); over100: sum over
+// the transformers of 100 * get_how_overloaded(); user: sum of ev2g_departure_term; tr0_maxp: transformers[0].max_power[t].
+struct RewardIn { double costs, usage, sp, pot_t, pot_tm1, over100, user, tr0_maxp; };
+__device__ __forceinline__ double ev2g_reward(int kind, const RewardIn &x) {
+    switch (kind) {
+    case 1: { const double m = (x.pot_t < x.sp) ? x.pot_t : x.sp; const double d = m - x.usage; return -(d * d); }   // reward.py:7-14
+    case 2: return x.costs - x.user;                                                                                 // :78-87
+    case 3: {                                                                                                        // :16-32
+        double m = x.sp;
+        if (x.pot_t < m) m = x.pot_t;
+        if (x.tr0_maxp < m) m = x.tr0_maxp;
+        const double d = m - x.usage;
+        return -(d * d) - x.over100 - x.user;
+    }
+    case 4: {                                                                                                        // :46-58
+        const double m = (x.pot_t < x.sp) ? x.pot_t : x.sp; const double d = m - x.usage;
+        return (x.usage == 0.0 && x.pot_tm1 != 0.0) ? -(d * d) - 100.0 : -(d * d);
+    }
+    case 5: { const double d = x.sp - x.usage; return -(d * d); }                                                    // :60-65
+    case 6: { double r = 0.0; if (x.sp < x.usage) r -= (x.usage - x.sp) * (x.usage - x.sp); return r + x.usage; }   // :67-76
+    case 7: return x.costs;                                                                                          // :151-154
+    case 8: return x.costs + (-x.user);                                                                              // :120-148
+    default: return x.costs - x.over100 - x.user;                                                                    // :34-44
+    }
+}
+
 // butterfly sum over aligned lane groups of width gs (power of two <= 64): fixed tree, deterministic
 __device__ __forceinline__ double group_sum(double v, int gs) {
     for (int d = gs >> 1; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -576,7 +612,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 if (t >= w.y) {
                     const double des = s.ss_des[ss];
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
-                    if (s.reward_kind != 1 || s.cost_kind == 1) satpen = 100.0 * exp(-10.0 * score);
+                    satpen = ev2g_departure_term(s.reward_kind, s.cost_kind, score, cap, des);
                     const long long gc = (long long)e * C + cs;
                     if (npc == 1) {
                         st.cs_served[gc] += 1;
@@ -764,19 +800,14 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                     st.usage_hist[(long long)t * s.E + e] = usage;
                     const double pot = esum[4 * s.G + el];
                     if (sstep < T) st.pot_hist[(long long)sstep * s.E + e] = pot;
-                    double reward;
                     const double costs = esum[2 * s.G + el];
-                    if (s.reward_kind == 1) {  // SquaredTrackingErrorReward reward.py:7-14
-                        const double sp = s.setpoint[(long long)scn * T + t];
-                        const double pp = st.pot_hist[(long long)t * s.E + e];
-                        const double m = (pp < sp) ? pp : sp;
-                        const double d = m - usage;
-                        reward = -(d * d);
-                    } else if (s.reward_kind == 2) {  // profit_maximization reward.py:78-87
-                        reward = costs - esum[3 * s.G + el];
-                    } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
-                        reward = costs - over_sum - esum[3 * s.G + el];
-                    }
+                    RewardIn ri;
+                    ri.costs = costs; ri.usage = usage; ri.over100 = over_sum; ri.user = esum[3 * s.G + el];
+                    ri.sp = s.setpoint[(long long)scn * T + t];
+                    ri.pot_t = st.pot_hist[(long long)t * s.E + e];
+                    ri.pot_tm1 = (t > 0) ? st.pot_hist[(long long)(t - 1) * s.E + e] : 0.0;
+                    ri.tr0_maxp = s.tr_maxp[(long long)scn * R * T + t];
+                    const double reward = ev2g_reward(s.reward_kind, ri);
                     double *acc = st.env_acc + (long long)e * 8;
                     acc[0] += reward;
                     acc[1] += costs;

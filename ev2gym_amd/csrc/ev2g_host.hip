@@ -114,8 +114,12 @@ const char *ev2g_last_error(const ev2g_handle *h) { return h ? h->err.c_str() : 
 
 int ev2g_create(const ev2g_config *cfg, ev2g_handle **out) {
     if (!cfg || !out) return fail(nullptr, EV2G_ERR_ARG, "ev2g_create: null argument");
-    if (cfg->reward_kind < 0 || cfg->reward_kind > 2 || cfg->state_kind < 0 || cfg->state_kind > 2)
+    if (cfg->reward_kind < 0 || cfg->reward_kind >= EV2G_N_REWARDS || cfg->state_kind < 0 || cfg->state_kind > 2)
         return fail(nullptr, EV2G_ERR_ARG, "ev2g_create: unknown reward_kind/state_kind");
+    if (cfg->cost_kind == EV2G_COST_TR_OVERLOAD_USRPENALTY &&
+        (cfg->reward_kind == EV2G_REWARD_SQTR_TRPENALTY_USERINCENTIVES || cfg->reward_kind == EV2G_REWARD_V2G_PROFITMAX))
+        return fail(nullptr, EV2G_ERR_ARG, "ev2g_create: the fused transformer_overload_usrpenalty cost shares its per-departure staging slot with "
+                                           "the user term of this reward (SqTrError_TrPenalty_UserIncentives / V2G_profitmax): evaluate one of the two on the host");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0)
@@ -444,7 +448,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     }
     {
         char nm[64];
-        if (h->wave_path) std::snprintf(nm, sizeof nm, "ev2g_step_wave<%d,%d>", sk, h->cfg.reward_kind);
+        if (h->wave_path) std::snprintf(nm, sizeof nm, "ev2g_step_wave<%d,%d>", sk, std::min(h->cfg.reward_kind, 3));
         else if (h->block) std::snprintf(nm, sizeof nm, "ev2g_step_v2<%d>", h->block);
         else std::snprintf(nm, sizeof nm, "ev2g_step_kernel");
         h->kernel_name = nm;
@@ -727,7 +731,7 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
                           st.env_acc, s.cs_imax, s.cs_dmax_abs, s.cs_imin, s.cs_dmin, s.cs_maxp, s.cs_minp};
 #define EV2G_WAVE_CASE(SK, RK)                                                                                              \
-    case SK * 3 + RK:                                                                                                       \
+    case SK * 4 + RK:                                                                                                       \
         if (!io.actions)                                                                                                    \
             hipLaunchKernelGGL((ev2g_step_wave<SK, RK, true>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes,       \
                                h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
@@ -735,16 +739,16 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
             hipLaunchKernelGGL((ev2g_step_wave<SK, RK, false>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes,      \
                                h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
         break;
-        switch (s.state_kind * 3 + s.reward_kind) {
+        switch (s.state_kind * 4 + std::min(s.reward_kind, 3)) {   // rewards beyond the three compiled-in ones share instantiation 3
 #ifdef EV2G_ONLY_00   /* tuning builds (tools/): one specialisation, seconds to compile */
             case 0:
                 hipLaunchKernelGGL((ev2g_step_wave<0, 0, false>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
                 break;
             default: return fail(h, EV2G_ERR_ARG, "EV2G_ONLY_00 build: only the cfg2 specialisation exists");
 #else
-            EV2G_WAVE_CASE(0, 0) EV2G_WAVE_CASE(0, 1) EV2G_WAVE_CASE(0, 2)
-            EV2G_WAVE_CASE(1, 0) EV2G_WAVE_CASE(1, 1) EV2G_WAVE_CASE(1, 2)
-            EV2G_WAVE_CASE(2, 0) EV2G_WAVE_CASE(2, 1) EV2G_WAVE_CASE(2, 2)
+            EV2G_WAVE_CASE(0, 0) EV2G_WAVE_CASE(0, 1) EV2G_WAVE_CASE(0, 2) EV2G_WAVE_CASE(0, 3)
+            EV2G_WAVE_CASE(1, 0) EV2G_WAVE_CASE(1, 1) EV2G_WAVE_CASE(1, 2) EV2G_WAVE_CASE(1, 3)
+            EV2G_WAVE_CASE(2, 0) EV2G_WAVE_CASE(2, 1) EV2G_WAVE_CASE(2, 2) EV2G_WAVE_CASE(2, 3)
 #endif
         }
 #undef EV2G_WAVE_CASE

@@ -204,7 +204,7 @@ inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
 // LDS carve-up for ev2g_step_v2 (doubles first, then ints); NS = G*P, NT = G*R
 __host__ __device__ inline size_t ev2g_v2_lds_bytes(int NS, int NT, int G, int R) {
     return sizeof(double) * ((size_t)(EV2G_NQ + 7) * NS + (size_t)EV2G_NQ * NT + (size_t)EV2G_NQ * G + (size_t)NT +
-                             (size_t)G * 7) +
+                             (size_t)G * 9) +
            sizeof(int) * (6 * (size_t)NS + 2 * (size_t)R + 1 + 4);
 }
 
@@ -237,7 +237,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     double *eacc = over_l + NT;                            // [G][5] episode accumulators
     double *pot_prev = eacc + (size_t)G * 5;               // [G] charge_power_potential[t]
     double *osum = pot_prev + G;                           // [G] sum of 100 * overload over the env's transformers
-    int *s_ta = (int *)(osum + G);                     // window {t_arr, t_dep} of the attached-or-next session
+    double *pot_prev2 = osum + G;                          // [G] charge_power_potential[t-1] (SquaredTrackingErrorRewardWithPenalty)
+    double *tr0max = pot_prev2 + G;                        // [G] transformers[0].max_power[t] (SqTrError_TrPenalty_UserIncentives)
+    int *s_ta = (int *)(tr0max + G);                   // window {t_arr, t_dep} of the attached-or-next session
     int *s_td = s_ta + NS, *s_ss = s_td + NS, *s_cyc = s_ss + NS;  // session index, charging_cycles
     int *s_dirty = s_cyc + NS;                             // bit0: cap/tot/prev/cycles changed, bit1: window changed
     int *items = s_dirty + NS, *seg = items + NS, *trobs = seg + R + 1, *cnt = trobs + R;  // cnt[0] charge, cnt[1] discharge
@@ -280,7 +282,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     for (int i = tid; i <= R; i += BLOCK) seg[i] = S->tr_seg[i];
     for (int i = tid; i < R; i += BLOCK) trobs[i] = S->tr_obs[i];
     for (int i = tid; i < ne * 5; i += BLOCK) eacc[i] = 0.0;
-    for (int i = tid; i < ne; i += BLOCK) pot_prev[i] = (t < T) ? S->pot_hist[t * E + e0 + i] : 0.0;
+    for (int i = tid; i < ne; i += BLOCK) {
+        pot_prev[i] = (t < T) ? S->pot_hist[t * E + e0 + i] : 0.0;
+        pot_prev2[i] = (t > 0 && t <= T) ? S->pot_hist[(t - 1) * E + e0 + i] : 0.0;
+    }
     // observation-head role of this lane (columns pl and pl + lpe of the env it serves at env level), fixed for the launch:
     // destination column, and where the value comes from -- charge price `hsrc` steps ahead (hsrc < 20), or entry hsrc - 20 of the
     // env's window table row block (then + sstep*40 per step); hdst < 0: no column
@@ -331,7 +336,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             }
             for (int i = tid_l; i < ne * 8; i += BLOCK) S->env_acc[e0 * 8 + i] = 0.0;
             for (int i = tid_l; i < ne * 5; i += BLOCK) eacc[i] = 0.0;
-            for (int i = tid_l; i < ne; i += BLOCK) pot_prev[i] = 0.0;
+            for (int i = tid_l; i < ne; i += BLOCK) { pot_prev[i] = 0.0; pot_prev2[i] = 0.0; }
             t = 0;
             lds_barrier();
         }
@@ -493,7 +498,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                     const SessRec &r = *(const SessRec *)(S->rec + ss);
                     const double des = r.des;
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
-                    if (S->reward_kind != 1 || S->cost_kind == 1) satpen = 100.0 * exp(-10.0 * score);
+                    satpen = ev2g_departure_term(S->reward_kind, S->cost_kind, score, cap, des);
                     const int gc = e_l * C + cs_l;
                     // fire-and-forget device atomics (no returned value => no memory round trip on this path)
                     __hip_atomic_fetch_add(&S->cs_served[gc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -647,6 +652,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             if (last_step) S->tr_power_now[(e0 + tel) * R + r] = ptr;
             over100 = 100.0 * over;
             over_l[tid_l] = over100;
+            if (r == 0) tr0max[tel] = pf_maxp;   // (its only reader is the env's owner lane: after the barrier, or -- one-env scheme -- this very lane)
         }
         // env-level quantities of this step, as the lane that owns the env (pl == 0) needs them
         double q_usage = 0.0, q_costs = 0.0, q_sat = 0.0, q_pot = 0.0, q_ech = 0.0, q_edis = 0.0, q_emerg = 0.0, q_over = 0.0;
@@ -714,17 +720,11 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 const double potn = q_pot;
                 if (sstep < T) p_pot[sstep * E + pe_l] = potn;
                 const double costs = q_costs;
-                double reward;
-                if (rkind == 1) {  // SquaredTrackingErrorReward reward.py:7-14
-                    const double pp = pot_prev[pel_l];
-                    const double m = (pp < pf_sp) ? pp : pf_sp;
-                    const double d = m - usage;
-                    reward = -(d * d);
-                } else if (rkind == 2) {  // profit_maximization reward.py:78-87
-                    reward = costs - q_sat;
-                } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
-                    reward = costs - over_sum - q_sat;
-                }
+                RewardIn ri;
+                ri.costs = costs; ri.usage = usage; ri.sp = pf_sp; ri.over100 = over_sum; ri.user = q_sat;
+                ri.pot_t = pot_prev[pel_l]; ri.pot_tm1 = pot_prev2[pel_l]; ri.tr0_maxp = tr0max[pel_l];
+                const double reward = ev2g_reward(rkind, ri);
+                pot_prev2[pel_l] = ri.pot_t;
                 pot_prev[pel_l] = potn;
                 double *acc = eacc + pel_l * 5;
                 acc[0] += reward;

@@ -20,7 +20,7 @@
 
 __host__ __device__ inline size_t ev2g_wave_lds_bytes(int envs_per_group) {
     const size_t NS = EV2G_WAVE_BLOCK;
-    return sizeof(double) * (EV2G_NQ * (NS + 8) + 7 * NS + 6 * (size_t)envs_per_group + 4 * 64) + sizeof(int) * (6 * NS + 8);
+    return sizeof(double) * (EV2G_NQ * (NS + 8) + 7 * NS + 7 * (size_t)envs_per_group + 4 * 64) + sizeof(int) * (6 * NS + 8);
 }
 
 // Global accesses as  uniform base (an SGPR pair) + 32-bit unsigned BYTE offset (one VGPR):  the
@@ -69,6 +69,8 @@ struct WaveArgs {
 
 // IO32: the actions are float32 (StepIO::act32) -- the policy-network interface; float32 observations (StepIO::obs32) are
 // written whenever that pointer is set, in either instantiation.
+// RK: 0..2 = the reward of the three shipped configs, compiled in; 3 = any other fused reward, selected at run time by
+// V2P::reward_kind (ev2g_reward / ev2g_departure_term in ev2g_device.h).
 template <int SK, int RK, bool IO32>
 __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
                                                                      int k_steps, int auto_reset, WaveArgs wa) {
@@ -101,8 +103,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     double *s_cap = stage + (size_t)EV2G_NQ * RS;
     double *s_tot = s_cap + NS, *s_prev = s_tot + NS, *s_bcap = s_prev + NS, *s_potc = s_bcap + NS;
     double *s_amps = s_potc + NS, *s_abse = s_amps + NS;
-    double *eacc = s_abse + NS;                            // [G][6] episode accumulators + charge_power_potential[t], per env
-    double *s_cst = eacc + 6 * G;                          // [4][64] per-charger gates and clamps (rarely changing operands
+    double *eacc = s_abse + NS;                            // [G][7] episode accumulators + charge_power_potential[t], [t-1], per env
+    double *s_cst = eacc + 7 * G;                          // [4][64] per-charger gates and clamps (rarely changing operands
                                                            // kept out of the register file): imin-0.01, dmin, max power, min power
     int *s_ta = (int *)(s_cst + 4 * 64);
     int *s_td = s_ta + NS, *s_ss = s_td + NS, *s_cyc = s_ss + NS, *s_dirty = s_cyc + NS, *items = s_dirty + NS;
@@ -139,10 +141,12 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         a_next = IO32 ? (double)ldg32<float>(S->x_act32 + (long long)io.step0 * io.a_stride, (unsigned)(valid ? g : e0 * P) * 4u)
                       : ldg32<double>(io.actions, (unsigned)(valid ? g : e0 * P) * 8u);
         double l_pot = ldg32<double>(slabH + HS8, ((unsigned)min(t, T - 1) * (unsigned)E + ec) * 8u);
+        double l_pot2 = 0.0;   // charge_power_potential[t-1]: only SquaredTrackingErrorRewardWithPenalty (a run-time reward) reads it
+        if (RK == 3) l_pot2 = ldg32<double>(slabH + HS8, ((unsigned)min(max(t - 1, 0), T - 1) * (unsigned)E + ec) * 8u);
         d2v acc01 = ldg32<d2v>(env_acc, ec * 64u), acc23 = ldg32<d2v>(env_acc, ec * 64u + 16u);
         double acc4 = ldg32<double>(env_acc, ec * 64u + 32u);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(w), "+v"(sc), "+v"(lut0), "+v"(c_imax), "+v"(c_dmaxabs), "+v"(k_imin), "+v"(k_dmin),
-                     "+v"(k_maxp), "+v"(k_minp), "+v"(a_next), "+v"(l_pot), "+v"(acc01), "+v"(acc23), "+v"(acc4));
+                     "+v"(k_maxp), "+v"(k_minp), "+v"(a_next), "+v"(l_pot), "+v"(l_pot2), "+v"(acc01), "+v"(acc23), "+v"(acc4));
         if (tid < P) {
             s_cst[0 * 64 + tid] = k_imin - 0.01; s_cst[1 * 64 + tid] = k_dmin;
             s_cst[2 * 64 + tid] = k_maxp; s_cst[3 * 64 + tid] = k_minp;
@@ -163,9 +167,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
         }
         if (head) {   // episode accumulators (continued from global memory) and charge_power_potential[t], in LDS
-            double *ea = eacc + elg * 6;
+            double *ea = eacc + elg * 7;
             ea[0] = acc01.x; ea[1] = acc01.y; ea[2] = acc23.x; ea[3] = acc23.y; ea[4] = acc4;
             ea[5] = (t < T) ? l_pot : 0.0;
+            ea[6] = (t > 0 && t <= T) ? l_pot2 : 0.0;
         }
     }
     if (tid < 4) cnt[tid] = 0;
@@ -204,7 +209,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
             if (head) {
                 for (int i = 0; i < 8; i++) stg32<double>(env_acc, (unsigned)e_l * 64u + (unsigned)i * 8u, 0.0);
-                for (int i = 0; i < 6; i++) eacc[elg * 6 + i] = 0.0;
+                for (int i = 0; i < 7; i++) eacc[elg * 7 + i] = 0.0;
             }
             t = 0;
         }
@@ -356,7 +361,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     const unsigned r8 = (unsigned)ss * (unsigned)sizeof(SessRec);
                     const double des = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, des));
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
-                    if (RK != 1 || S->cost_kind == 1) satpen = 100.0 * exp(-10.0 * score);
+                    if (RK == 3) satpen = ev2g_departure_term(S->reward_kind, S->cost_kind, score, cap, des);
+                    else if (RK != 1 || S->cost_kind == 1) satpen = 100.0 * exp(-10.0 * score);
                     // fire-and-forget device atomics (no returned value => no memory round trip on this path); exactly one
                     // lane updates a given charger per step, so the result does not depend on any ordering
                     __hip_atomic_fetch_add((int __attribute__((address_space(1))) *)(PA(EV2G_PS_SERVED) + (g8 >> 1)), 1,
@@ -491,13 +497,14 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
         }
         if (head) {
-            double *ea = eacc + elg * 6;
+            double *ea = eacc + elg * 7;
             // all six accumulator words are read up front (one LDS wait) and written back together at the end; reading
             // each one next to its update made every update wait for its own LDS round trip
             const double ea0 = ea[0], ea1 = ea[1], ea2 = ea[2], ea3 = ea[3], ea4 = ea[4], ea5 = ea[5];
+            const double ea6 = (RK == 3) ? ea[6] : 0.0;
             const unsigned e8 = (unsigned)e_l * 8u;
             double over100 = 0.0;
-            if (RK == 0) over100 = 100.0 * over;
+            if (RK == 0 || RK == 3) over100 = 100.0 * over;
             if (last_step) stg32<double>(S->tr_power_now, e8, tr_power);
             const double potn = esum[3];
             if (P < 3) {   // two-port envs: no third lane to share the history stores with
@@ -514,11 +521,17 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 reward = -(d * d);
             } else if (RK == 2) {  // profit_maximization reward.py:78-87
                 reward = costs - esum[2];
+            } else if (RK == 3) {  // the other fused rewards, by V2P::reward_kind
+                RewardIn ri;
+                ri.costs = costs; ri.usage = usage; ri.sp = pf_sp; ri.pot_t = ea5; ri.pot_tm1 = ea6; ri.over100 = over100;
+                ri.user = esum[2]; ri.tr0_maxp = pf_maxp;
+                reward = ev2g_reward(S->reward_kind, ri);
             } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
                 reward = costs - over100 - esum[2];
             }
             const double n0 = ea0 + reward, n1 = ea1 + costs, n2 = ea2 + esum[4], n3 = ea3 + esum[5], n4 = ea4 + esum[6];
             ea[0] = n0; ea[1] = n1; ea[2] = n2; ea[3] = n3; ea[4] = n4; ea[5] = potn;
+            if (RK == 3) ea[6] = ea5;
             if (io.reward) stg32<double>(io.reward + (long long)kk * io.r_stride, e8, reward);
             if (io.done) stg32<uint8_t>(io.done + (long long)kk * io.d_stride, (unsigned)e_l, (sstep >= T) ? 1 : 0);
             if (S->x_cost)   // cost_function (rl_agent/cost.py:8-27); the overload weight is applied here when the reward does not carry it

@@ -34,7 +34,7 @@ def profit_maximization(env, total_costs, user_satisfaction_list, *args):
 
 
 def SimpleReward(env, *args):
-    """reward.py:60-65 (host-evaluated plugin: not fused)"""
+    """reward.py:60-65 """
     t = env.current_step - 1
     return -(env.power_setpoints[t] - env.current_power_usage[t]) ** 2
 
@@ -46,7 +46,7 @@ def _tracking_gap(env, *limits):
 
 
 def SqTrError_TrPenalty_UserIncentives(env, _, user_satisfaction_list, *args):
-    """reward.py:16-32 (host-evaluated): tracking error capped by transformer 0's limit, overload and dissatisfaction penalties"""
+    """reward.py:16-32: tracking error capped by transformer 0's limit, overload and dissatisfaction penalties"""
     gap = _tracking_gap(env, env.transformers[0].max_power[env.current_step - 1])
     penalty = sum(100 * tr.get_how_overloaded() for tr in env.transformers)
     penalty += sum(1000 * (1 - score) for score in user_satisfaction_list)
@@ -54,20 +54,38 @@ def SqTrError_TrPenalty_UserIncentives(env, _, user_satisfaction_list, *args):
 
 
 def SquaredTrackingErrorRewardWithPenalty(env, *args):
-    """reward.py:46-58 (host-evaluated): an extra -100 when nothing was delivered although there was potential the step before"""
+    """reward.py:46-58: an extra -100 when nothing was delivered although there was potential the step before"""
     t = env.current_step - 1
     idle = env.current_power_usage[t] == 0 and env.charge_power_potential[t - 1] != 0
     return -_tracking_gap(env) ** 2 - (100 if idle else 0)
 
 
 def MinimizeTrackerSurplusWithChargeRewards(env, *args):
-    """reward.py:67-76 (host-evaluated): quadratic penalty on exceeding the setpoint, linear bonus for delivered power"""
+    """reward.py:67-76: quadratic penalty on exceeding the setpoint, linear bonus for delivered power"""
     t = env.current_step - 1
     usage, sp = env.current_power_usage[t], env.power_setpoints[t]
     surplus = usage - sp
     return (-(surplus ** 2) if sp < usage else 0) + usage
 
 
+def V2G_costs_simple(env, total_costs, user_satisfaction_list, *args):
+    """reward.py:151-154"""
+    return total_costs
+
+
+def V2G_profitmax(env, total_costs, user_satisfaction_list, *args):
+    """reward.py:120-148: profit minus 100 per kWh that a departing EV is short of its desired capacity"""
+    short = sum(100 * (ev.desired_capacity - ev.current_capacity) for ev in env.departing_evs
+                if ev.desired_capacity > ev.current_capacity)
+    return total_costs - short
+
+
 ProfitMax_TrPenalty_UserIncentives._ev2g_kind = 0
 SquaredTrackingErrorReward._ev2g_kind = 1
 profit_maximization._ev2g_kind = 2
+SqTrError_TrPenalty_UserIncentives._ev2g_kind = 3
+SquaredTrackingErrorRewardWithPenalty._ev2g_kind = 4
+SimpleReward._ev2g_kind = 5
+MinimizeTrackerSurplusWithChargeRewards._ev2g_kind = 6
+V2G_costs_simple._ev2g_kind = 7
+V2G_profitmax._ev2g_kind = 8

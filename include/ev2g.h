@@ -34,6 +34,16 @@ extern "C" {
 #define EV2G_REWARD_PROFITMAX_TRPENALTY_USERINCENTIVES 0 /* reward.py:34-44  */
 #define EV2G_REWARD_SQUARED_TRACKING_ERROR 1             /* reward.py:7-14   */
 #define EV2G_REWARD_PROFIT_MAXIMIZATION 2                /* reward.py:78-87  */
+#define EV2G_REWARD_SQTR_TRPENALTY_USERINCENTIVES 3      /* reward.py:16-32: SqTrError_TrPenalty_UserIncentives        */
+#define EV2G_REWARD_SQUARED_TRACKING_ERROR_PENALTY 4     /* reward.py:46-58: SquaredTrackingErrorRewardWithPenalty     */
+#define EV2G_REWARD_SIMPLE 5                             /* reward.py:60-65: SimpleReward                              */
+#define EV2G_REWARD_MINIMIZE_TRACKER_SURPLUS 6           /* reward.py:67-76: MinimizeTrackerSurplusWithChargeRewards   */
+#define EV2G_REWARD_V2G_COSTS_SIMPLE 7                   /* reward.py:151-154: V2G_costs_simple                        */
+#define EV2G_REWARD_V2G_PROFITMAX 8                      /* reward.py:120-148: V2G_profitmax                           */
+#define EV2G_N_REWARDS 9
+/* Kinds 3 and 8 carry their own per-departure user term; the fused transformer_overload_usrpenalty cost (EV2G_COST_TR_OVERLOAD_
+ * USRPENALTY) shares that staging slot and cannot be combined with them (ev2g_create refuses the pair).  The reference's other
+ * reward built-ins need the grid simulation (V2G_grid_*) or are host-evaluated plugins through the Python facade. */
 /* state_function built-ins (rl_agent/state.py) */
 #define EV2G_STATE_V2G_PROFIT_MAX_LOADS 0 /* state.py:108-155, D = 2+H + 2H*R + 2P */
 #define EV2G_STATE_PUBLIC_PST 1           /* state.py:6-63,    D = 3 + 3P          */

@@ -374,7 +374,13 @@ def main():
     for c in [("plugin_pst_sqtr_rand_s23", pst, "PublicPST", "SqTrError_TrPenalty_UserIncentives", 23, "rand", None),
               ("plugin_pst_surplus_rand_s24", pst, "PublicPST", "MinimizeTrackerSurplusWithChargeRewards", 24, "rand", None),
               ("plugin_pst_idlepen_mixed_s25", pst, "PublicPST", "SquaredTrackingErrorRewardWithPenalty", 25, "mixed", None),
-              ("plugin_v2gppl_sqtr_rand_s26", ppl, "V2G_profit_max_loads", "SqTrError_TrPenalty_UserIncentives", 26, "rand", None)]:
+              ("plugin_v2gppl_sqtr_rand_s26", ppl, "V2G_profit_max_loads", "SqTrError_TrPenalty_UserIncentives", 26, "rand", None),
+              ("plugin_pst_simple_rand_s27", pst, "PublicPST", "SimpleReward", 27, "rand", None),
+              ("plugin_v2gppl_costs_rand_s28", ppl, "V2G_profit_max_loads", "V2G_costs_simple", 28, "rand", None),
+              ("plugin_v2gppl_profitmax_rand_s29", ppl, "V2G_profit_max_loads", "V2G_profitmax", 29, "rand", None),
+              ("plugin_v2gmax_profitmax_neg_s30", vmax, "V2G_profit_max", "V2G_profitmax", 30, "neg", None),
+              ("plugin_v2gppl_c10r3_sqtr_mixed_s31", r3, "V2G_profit_max_loads", "SqTrError_TrPenalty_UserIncentives", 31, "mixed", None),
+              ("plugin_pst_p3_idlepen_mixed_s32", p3, "PublicPST", "SquaredTrackingErrorRewardWithPenalty", 32, "mixed", None)]:
         if only and c[0] not in only:
             continue
         run_case(*c)

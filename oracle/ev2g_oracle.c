@@ -73,6 +73,7 @@ typedef struct {
     double *cs_power, *cs_current;                             /* [C,T] */
     /* per-step scratch: departing EVs */
     double *sat_list;
+    double *short_list; /* per departing EV of the step: 100 * (desired - capacity) when short, else 0 */
     int n_sat;
     const double *lut; /* [NL,101] */
     int n_lut;
@@ -306,6 +307,8 @@ static void cs_step(Env *env, Charger *cs, double *actions, double charge_price,
             cs->total_evs_served += 1;
             double sat = ev_get_user_satisfaction(ev);
             cs->total_user_satisfaction += sat;
+            /* what V2G_profitmax charges a departing EV (reward.py:130-136), next to its satisfaction score */
+            env->short_list[env->n_sat] = (ev->desired > ev->current_capacity) ? 100 * (ev->desired - ev->current_capacity) : 0.0;
             env->sat_list[env->n_sat++] = sat;
         }
     }
@@ -468,6 +471,46 @@ static double calculate_reward(Env *env, double total_costs) {
         reward = total_costs;
         for (int k = 0; k < env->n_sat; k++) reward -= 100 * exp(-10 * env->sat_list[k]);
         break;
+    case EV2G_REWARD_SQTR_TRPENALTY_USERINCENTIVES: { /* reward.py:16-32; python min(a,b,c) keeps the first of equal values */
+        double m = env->setpoints[t1];
+        if (env->charge_power_potential[t1] < m) m = env->charge_power_potential[t1];
+        if (env->tr[0].max_power[t1] < m) m = env->tr[0].max_power[t1];
+        double d = m - env->current_power_usage[t1];
+        reward = -(d * d);
+        for (int t = 0; t < env->R; t++) reward -= 100 * tr_get_how_overloaded(&env->tr[t]);
+        for (int k = 0; k < env->n_sat; k++) reward -= 1000 * (1 - env->sat_list[k]);
+        break;
+    }
+    case EV2G_REWARD_SQUARED_TRACKING_ERROR_PENALTY: { /* reward.py:46-58; index current_step-2 wraps like a python list */
+        double a = env->setpoints[t1], b = env->charge_power_potential[t1];
+        double m = (b < a) ? b : a;
+        double d = m - env->current_power_usage[t1];
+        int t2 = t1 - 1 < 0 ? env->T - 1 : t1 - 1;
+        reward = -(d * d);
+        if (env->current_power_usage[t1] == 0 && env->charge_power_potential[t2] != 0) reward -= 100;
+        break;
+    }
+    case EV2G_REWARD_SIMPLE: { /* reward.py:60-65 */
+        double d = env->setpoints[t1] - env->current_power_usage[t1];
+        reward = -(d * d);
+        break;
+    }
+    case EV2G_REWARD_MINIMIZE_TRACKER_SURPLUS: { /* reward.py:67-76 */
+        double u = env->current_power_usage[t1], sp = env->setpoints[t1];
+        reward = 0;
+        if (sp < u) reward -= (u - sp) * (u - sp);
+        reward += u;
+        break;
+    }
+    case EV2G_REWARD_V2G_COSTS_SIMPLE: /* reward.py:151-154 */
+        reward = total_costs;
+        break;
+    case EV2G_REWARD_V2G_PROFITMAX: { /* reward.py:120-148 */
+        double user_costs = 0;
+        for (int k = 0; k < env->n_sat; k++) user_costs += -env->short_list[k];
+        reward = total_costs + user_costs;
+        break;
+    }
     default: /* ProfitMax_TrPenalty_UserIncentives reward.py:34-44 */
         reward = total_costs;
         for (int t = 0; t < env->R; t++) reward -= 100 * tr_get_how_overloaded(&env->tr[t]);
@@ -855,6 +898,7 @@ void *ev2g_oracle_create(const ev2g_scenario_batch *bin, int reward_kind, int st
         env->cs_power = (double *)calloc((size_t)T * C, sizeof(double));
         env->cs_current = (double *)calloc((size_t)T * C, sizeof(double));
         env->sat_list = (double *)calloc(env->P + 1, sizeof(double));
+        env->short_list = (double *)calloc(env->P + 1, sizeof(double));
         env_reset(o, env, e, NULL);
     }
     return o;
@@ -978,6 +1022,7 @@ void ev2g_oracle_destroy(void *h) {
         free(env->cs_power);
         free(env->cs_current);
         free(env->sat_list);
+        free(env->short_list);
     }
     for (int i = 0; i < o->n_owned; i++) free(o->owned[i]);
     free(o->owned);

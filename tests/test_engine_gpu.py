@@ -37,7 +37,7 @@ def _expected_kernel(batch, sk, rk, forced_v2=False):
     if not batch.uniform_ports:     # topology file with different port counts per charger
         return "ev2g_step_kernel"
     if 2 <= P <= 64 and R == 1 and npc == 1 and not forced_v2:
-        return f"ev2g_step_wave<{sk},{rk}>"
+        return f"ev2g_step_wave<{sk},{min(rk, 3)}>"
     return f"ev2g_step_v2<{256 if P <= 256 else 512 if P <= 512 else 1024}>" if P <= 1024 else "ev2g_step_kernel"
 
 
@@ -385,15 +385,21 @@ def test_general_kernels_for_multi_port_and_multi_transformer_shapes(C, npc, R):
 
 
 @pytest.mark.parametrize("sk", [0, 1, 2])
-@pytest.mark.parametrize("rk", [0, 1, 2])
-def test_all_nine_fused_plugin_pairs(sk, rk):
-    """The step kernels are specialised on (state, reward): every combination, not only the three shipped pairings."""
+@pytest.mark.parametrize("rk", range(9))
+@pytest.mark.parametrize("shape", ["wave", "v2_multi_tr"])
+def test_all_fused_plugin_pairs(sk, rk, shape):
+    """Every (state, reward) combination, not only the three shipped pairings: the fast path (rewards 0..2 compiled in, 3..8
+    selected at run time) and the general kernel (several transformers: the transformer-0 limit and the overload sum differ)."""
     from ev2gym_amd.engine import host_uniform
     from ev2gym_amd.scenario_gen import GenConfig, generate
     from oracle.oracle import Oracle
     E, P = 21, 20
-    batch = generate(GenConfig.v2g_profit_plus_loads(E, P, 1, seed=40 + 3 * sk + rk, power_setpoint_enabled=True))
+    if shape == "v2_multi_tr" and rk < 3 and sk != 0:
+        pytest.skip("covered by the general-kernel shapes test")
+    batch = generate(GenConfig.v2g_profit_plus_loads(E, P, 1 if shape == "wave" else 3, seed=40 + 3 * sk + rk, power_setpoint_enabled=True,
+                                                     transformer_max_power=60.0))
     eng = _engine(batch, rk, sk, flags=4)
+    assert eng.kernel_name == _expected_kernel(batch, sk, rk)
     ora = Oracle(batch, rk, sk)
     D, T = eng.D, eng.T
     d_act, d_obs, d_rew = eng.empty((T, E, P)), eng.empty((T, E, D)), eng.empty((T, E))
