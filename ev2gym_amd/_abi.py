@@ -16,6 +16,8 @@ REWARD_KINDS = {
     "MinimizeTrackerSurplusWithChargeRewards": 6,  # rl_agent/reward.py:67-76
     "V2G_costs_simple": 7,                     # rl_agent/reward.py:151-154
     "V2G_profitmax": 8,                        # rl_agent/reward.py:120-148
+    "V2G_profitmaxV2": 9,                      # rl_agent/reward.py:156-211
+    "pst_V2G_profitmaxV2": 10,                 # rl_agent/reward.py:278-339
 }
 STATE_KINDS = {
     "V2G_profit_max_loads": 0,                 # rl_agent/state.py:108-155

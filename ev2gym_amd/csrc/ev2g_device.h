@@ -332,7 +332,19 @@ __device__ __forceinline__ double load_minus_pv_at(const DevScn &s, long long er
 __device__ __forceinline__ double ev2g_departure_term(int reward_kind, int cost_kind, double score, double cap, double des) {
     if (reward_kind == 3) return 1000.0 * (1.0 - score);                           // SqTrError_TrPenalty_UserIncentives :30-31
     if (reward_kind == 8) return (des > cap) ? 100.0 * (des - cap) : 0.0;          // V2G_profitmax :130-136
+    if (reward_kind >= 9) return (des > cap) ? 0.05 * ((des - cap) * (des - cap)) : 0.0;   // (pst_)V2G_profitmaxV2 :197-207
     if (reward_kind == 0 || reward_kind == 2 || cost_kind == 1) return 100.0 * exp(-10.0 * score);   // :41-42, :84-86, cost.py:17-18
+    return 0.0;
+}
+// (pst_)V2G_profitmaxV2 also charge every EV that is connected AFTER the step's departures and arrivals and can no longer reach its
+// desired capacity at full power (reward.py:173-195); sstep = env.current_step after its increment.  Staged with the departure terms.
+__device__ __forceinline__ double ev2g_connected_term(double des, double cap, double pacmax, double sixty_over_dt, int t_dep, int sstep) {
+    const double min_steps_to_full = (des - cap) / (pacmax / sixty_over_dt);
+    const double departing_step = (double)(t_dep - sstep);
+    if (min_steps_to_full > departing_step) {
+        const double gap = (des - ((departing_step + 1.0) * pacmax / sixty_over_dt)) - cap;
+        return 0.05 * (gap * gap);
+    }
     return 0.0;
 }
 // The reward of a step from its env-level quantities.  costs: total profit of the step; usage: current_power_usage[t]; sp:
@@ -358,6 +370,8 @@ __device__ __forceinline__ double ev2g_reward(int kind, const RewardIn &x) {
     case 6: { double r = 0.0; if (x.sp < x.usage) r -= (x.usage - x.sp) * (x.usage - x.sp); return r + x.usage; }   // :67-76
     case 7: return x.costs;                                                                                          // :151-154
     case 8: return x.costs + (-x.user);                                                                              // :120-148
+    case 9: return x.costs + (-x.user);                                                                              // :156-211
+    case 10: return (x.costs + (-x.user)) + 1000.0 * ((x.sp < x.usage) ? (x.sp - x.usage) : 0.0);                   // :278-339
     default: return x.costs - x.over100 - x.user;                                                                    // :34-44
     }
 }
@@ -642,6 +656,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 st.port_energy[g] = 0.0;
                 st.port_current[g] = 0.0;
             }
+            if (occ_after && s.reward_kind >= 9) satpen += ev2g_connected_term(s.ss_des[ss], cap, s.ss_pacmax[ss], s.sixty_over_dt, w.y, sstep);
             if (mask) {
                 if (!s.het) mask[(long long)e * P + pref] = occ_after ? 1 : 0;
                 else if (occ_after) mask[(long long)e * P + s.slot_mask[q]] = 1;

@@ -117,9 +117,9 @@ int ev2g_create(const ev2g_config *cfg, ev2g_handle **out) {
     if (cfg->reward_kind < 0 || cfg->reward_kind >= EV2G_N_REWARDS || cfg->state_kind < 0 || cfg->state_kind > 2)
         return fail(nullptr, EV2G_ERR_ARG, "ev2g_create: unknown reward_kind/state_kind");
     if (cfg->cost_kind == EV2G_COST_TR_OVERLOAD_USRPENALTY &&
-        (cfg->reward_kind == EV2G_REWARD_SQTR_TRPENALTY_USERINCENTIVES || cfg->reward_kind == EV2G_REWARD_V2G_PROFITMAX))
+        (cfg->reward_kind == EV2G_REWARD_SQTR_TRPENALTY_USERINCENTIVES || cfg->reward_kind >= EV2G_REWARD_V2G_PROFITMAX))
         return fail(nullptr, EV2G_ERR_ARG, "ev2g_create: the fused transformer_overload_usrpenalty cost shares its per-departure staging slot with "
-                                           "the user term of this reward (SqTrError_TrPenalty_UserIncentives / V2G_profitmax): evaluate one of the two on the host");
+                                           "the user term of this reward (SqTrError_TrPenalty_UserIncentives / V2G_profitmax / *V2G_profitmaxV2): evaluate one of the two on the host");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0)

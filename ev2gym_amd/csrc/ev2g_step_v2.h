@@ -527,6 +527,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 s_dirty[tid_l] |= 1;
             }
             const bool occ_after = (ta <= sstep) && (sstep <= td);
+            if (occ_after && S->reward_kind >= 9) {   // (pst_)V2G_profitmaxV2: every connected EV (reward.py:173-195)
+                const SessRec &r = *(const SessRec *)(S->rec + s_ss[tid_l]);
+                satpen += ev2g_connected_term(r.des, cap, r.pacmax, sixty_over_dt, td, sstep);
+            }
             if (mask) mask[e_l * P + pref_l] = occ_after ? 1 : 0;
             double o0 = 0.0, o1 = 0.0, o2 = 0.0;
             if (occ_after) {

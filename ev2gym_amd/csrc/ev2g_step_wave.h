@@ -397,6 +397,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 s_dirty[tid_l] = (s_dirty[tid_l] & 3) | 1 | ((lut_new + 1) << 8);
             }
             const bool occ_after = (ta <= sstep) && (sstep <= td);
+            if (RK == 3 && occ_after && S->reward_kind >= 9) {   // (pst_)V2G_profitmaxV2: every connected EV (reward.py:173-195)
+                const unsigned r8 = (unsigned)s_ss[tid_l] * (unsigned)sizeof(SessRec);
+                satpen += ev2g_connected_term(ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, des)), cap,
+                                              ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, pacmax)), sixty_over_dt, td, sstep);
+            }
             occ_any = occ || occ_after;
             if (mask) stg32<uint8_t>(mask, (unsigned)g_l, occ_after ? 1 : 0);
             double o0 = 0.0, o1 = 0.0, o2 = 0.0;

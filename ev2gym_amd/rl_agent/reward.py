@@ -80,6 +80,38 @@ def V2G_profitmax(env, total_costs, user_satisfaction_list, *args):
     return total_costs - short
 
 
+def _v2_user_costs(env):
+    """The user term of the *V2 rewards (reward.py:173-207): every connected EV that can no longer reach its desired capacity at
+    full power pays 0.05 * (shortfall at this point of its stay)^2, every departing EV 0.05 * (final shortfall)^2."""
+    user_costs = 0
+    for cs in env.charging_stations:
+        for ev in cs.evs_connected:
+            if ev is not None:
+                min_steps_to_full = (ev.desired_capacity - ev.current_capacity) / (ev.max_ac_charge_power / (60 / env.timescale))
+                departing_step = ev.time_of_departure - env.current_step
+                if min_steps_to_full > departing_step:
+                    min_capacity_at_time = ev.desired_capacity - ((departing_step + 1) * ev.max_ac_charge_power / (60 / env.timescale))
+                    user_costs += -(0.05 * (min_capacity_at_time - ev.current_capacity) ** 2)
+    for ev in env.departing_evs:
+        if ev.desired_capacity > ev.current_capacity:
+            user_costs += -0.05 * (ev.desired_capacity - ev.current_capacity) ** 2
+    return user_costs
+
+
+def V2G_profitmaxV2(env, total_costs, user_satisfaction_list, *args):
+    """reward.py:156-211"""
+    return total_costs + _v2_user_costs(env)
+
+
+def pst_V2G_profitmaxV2(env, total_costs, user_satisfaction_list, *args):
+    """reward.py:278-339: V2G_profitmaxV2 plus 1000 x the (negative) excess of the power over the setpoint"""
+    t = env.current_step - 1
+    pst_violation = 0
+    if env.power_setpoints[t] < env.current_power_usage[t]:
+        pst_violation += env.power_setpoints[t] - env.current_power_usage[t]
+    return total_costs + _v2_user_costs(env) + 1000 * pst_violation
+
+
 ProfitMax_TrPenalty_UserIncentives._ev2g_kind = 0
 SquaredTrackingErrorReward._ev2g_kind = 1
 profit_maximization._ev2g_kind = 2
@@ -89,3 +121,5 @@ SimpleReward._ev2g_kind = 5
 MinimizeTrackerSurplusWithChargeRewards._ev2g_kind = 6
 V2G_costs_simple._ev2g_kind = 7
 V2G_profitmax._ev2g_kind = 8
+V2G_profitmaxV2._ev2g_kind = 9
+pst_V2G_profitmaxV2._ev2g_kind = 10

@@ -40,8 +40,10 @@ extern "C" {
 #define EV2G_REWARD_MINIMIZE_TRACKER_SURPLUS 6           /* reward.py:67-76: MinimizeTrackerSurplusWithChargeRewards   */
 #define EV2G_REWARD_V2G_COSTS_SIMPLE 7                   /* reward.py:151-154: V2G_costs_simple                        */
 #define EV2G_REWARD_V2G_PROFITMAX 8                      /* reward.py:120-148: V2G_profitmax                           */
-#define EV2G_N_REWARDS 9
-/* Kinds 3 and 8 carry their own per-departure user term; the fused transformer_overload_usrpenalty cost (EV2G_COST_TR_OVERLOAD_
+#define EV2G_REWARD_V2G_PROFITMAX_V2 9                   /* reward.py:156-211: V2G_profitmaxV2                         */
+#define EV2G_REWARD_PST_V2G_PROFITMAX_V2 10              /* reward.py:278-339: pst_V2G_profitmaxV2                     */
+#define EV2G_N_REWARDS 11
+/* Kinds 3, 8, 9 and 10 carry their own per-departure user term; the fused transformer_overload_usrpenalty cost (EV2G_COST_TR_OVERLOAD_
  * USRPENALTY) shares that staging slot and cannot be combined with them (ev2g_create refuses the pair).  The reference's other
  * reward built-ins need the grid simulation (V2G_grid_*) or are host-evaluated plugins through the Python facade. */
 /* state_function built-ins (rl_agent/state.py) */

@@ -380,7 +380,11 @@ def main():
               ("plugin_v2gppl_profitmax_rand_s29", ppl, "V2G_profit_max_loads", "V2G_profitmax", 29, "rand", None),
               ("plugin_v2gmax_profitmax_neg_s30", vmax, "V2G_profit_max", "V2G_profitmax", 30, "neg", None),
               ("plugin_v2gppl_c10r3_sqtr_mixed_s31", r3, "V2G_profit_max_loads", "SqTrError_TrPenalty_UserIncentives", 31, "mixed", None),
-              ("plugin_pst_p3_idlepen_mixed_s32", p3, "PublicPST", "SquaredTrackingErrorRewardWithPenalty", 32, "mixed", None)]:
+              ("plugin_pst_p3_idlepen_mixed_s32", p3, "PublicPST", "SquaredTrackingErrorRewardWithPenalty", 32, "mixed", None),
+              ("plugin_v2gppl_pmaxv2_rand_s33", ppl, "V2G_profit_max_loads", "V2G_profitmaxV2", 33, "rand", None),
+              ("plugin_v2gppl_p2_pmaxv2_mixed_s34", p2, "V2G_profit_max_loads", "V2G_profitmaxV2", 34, "mixed", None),
+              ("plugin_pst_pstpmaxv2_rand_s35", pst, "PublicPST", "pst_V2G_profitmaxV2", 35, "rand", None),
+              ("plugin_v2gmax_c28p2r3_pstpmaxv2_s36", x3, "V2G_profit_max", "pst_V2G_profitmaxV2", 36, "rand", None)]:
         if only and c[0] not in only:
             continue
         run_case(*c)

@@ -74,6 +74,7 @@ typedef struct {
     /* per-step scratch: departing EVs */
     double *sat_list;
     double *short_list; /* per departing EV of the step: 100 * (desired - capacity) when short, else 0 */
+    double *short2_list; /* ... and (desired - capacity)^2 when short (the *V2 rewards, reward.py:197-207) */
     int n_sat;
     const double *lut; /* [NL,101] */
     int n_lut;
@@ -309,6 +310,7 @@ static void cs_step(Env *env, Charger *cs, double *actions, double charge_price,
             cs->total_user_satisfaction += sat;
             /* what V2G_profitmax charges a departing EV (reward.py:130-136), next to its satisfaction score */
             env->short_list[env->n_sat] = (ev->desired > ev->current_capacity) ? 100 * (ev->desired - ev->current_capacity) : 0.0;
+            env->short2_list[env->n_sat] = (ev->desired > ev->current_capacity) ? (ev->desired - ev->current_capacity) * (ev->desired - ev->current_capacity) : 0.0;
             env->sat_list[env->n_sat++] = sat;
         }
     }
@@ -509,6 +511,36 @@ static double calculate_reward(Env *env, double total_costs) {
         double user_costs = 0;
         for (int k = 0; k < env->n_sat; k++) user_costs += -env->short_list[k];
         reward = total_costs + user_costs;
+        break;
+    }
+    case EV2G_REWARD_V2G_PROFITMAX_V2:       /* reward.py:156-211 */
+    case EV2G_REWARD_PST_V2G_PROFITMAX_V2: { /* reward.py:278-339 */
+        double user_costs = 0;
+        const double cost_multiplier = 0.05;
+        for (int c = 0; c < env->C; c++) {
+            Charger *cs = &env->cs[c];
+            for (int j = 0; j < cs->n_ports; j++) {
+                EV *ev = cs->evs_connected[j];
+                if (ev == NULL) continue;
+                double spd = 60.0 / env->timescale;
+                double min_steps_to_full = (ev->desired - ev->current_capacity) / (ev->pac_max / spd);
+                double departing_step = (double)(ev->t_dep - env->current_step);
+                if (min_steps_to_full > departing_step) {
+                    /* python: desired - ((departing_step+1) * max_ac_charge_power/(60/timescale)): product first, then the division */
+                    double min_capacity_at_time = ev->desired - ((departing_step + 1) * ev->pac_max / spd);
+                    double gap = min_capacity_at_time - ev->current_capacity;
+                    double cost = cost_multiplier * (gap * gap); /* python: cost_multiplier * (gap)**2 */
+                    user_costs += -cost;
+                }
+            }
+        }
+        for (int k = 0; k < env->n_sat; k++) user_costs += -cost_multiplier * env->short2_list[k];
+        reward = total_costs + user_costs;
+        if (env->reward_kind == EV2G_REWARD_PST_V2G_PROFITMAX_V2) {
+            double pst_violation = 0;
+            if (env->setpoints[t1] < env->current_power_usage[t1]) pst_violation += env->setpoints[t1] - env->current_power_usage[t1];
+            reward = reward + 1000 * pst_violation;
+        }
         break;
     }
     default: /* ProfitMax_TrPenalty_UserIncentives reward.py:34-44 */
@@ -899,6 +931,7 @@ void *ev2g_oracle_create(const ev2g_scenario_batch *bin, int reward_kind, int st
         env->cs_current = (double *)calloc((size_t)T * C, sizeof(double));
         env->sat_list = (double *)calloc(env->P + 1, sizeof(double));
         env->short_list = (double *)calloc(env->P + 1, sizeof(double));
+        env->short2_list = (double *)calloc(env->P + 1, sizeof(double));
         env_reset(o, env, e, NULL);
     }
     return o;
@@ -1023,6 +1056,7 @@ void ev2g_oracle_destroy(void *h) {
         free(env->cs_current);
         free(env->sat_list);
         free(env->short_list);
+        free(env->short2_list);
     }
     for (int i = 0; i < o->n_owned; i++) free(o->owned[i]);
     free(o->owned);

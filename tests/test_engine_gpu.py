@@ -385,10 +385,10 @@ def test_general_kernels_for_multi_port_and_multi_transformer_shapes(C, npc, R):
 
 
 @pytest.mark.parametrize("sk", [0, 1, 2])
-@pytest.mark.parametrize("rk", range(9))
+@pytest.mark.parametrize("rk", range(11))
 @pytest.mark.parametrize("shape", ["wave", "v2_multi_tr"])
 def test_all_fused_plugin_pairs(sk, rk, shape):
-    """Every (state, reward) combination, not only the three shipped pairings: the fast path (rewards 0..2 compiled in, 3..8
+    """Every (state, reward) combination, not only the three shipped pairings: the fast path (rewards 0..2 compiled in, 3..10
     selected at run time) and the general kernel (several transformers: the transformer-0 limit and the overload sum differ)."""
     from ev2gym_amd.engine import host_uniform
     from ev2gym_amd.scenario_gen import GenConfig, generate

@@ -116,7 +116,7 @@ def test_plugin_resolution():
     assert _kind(S.PublicPST, _abi.STATE_KINDS, "s") == 1 and _kind("V2G_profit_max_loads", _abi.STATE_KINDS, "s") == 0
     assert _kind(R.profit_maximization, _abi.REWARD_KINDS, "r") == 2
     assert _kind(R.SimpleReward, _abi.REWARD_KINDS, "r") == 5 and _kind("V2G_profitmax", _abi.REWARD_KINDS, "r") == 8
-    assert sorted(_abi.REWARD_KINDS.values()) == list(range(9))            # every fused reward has a kernel id (include/ev2g.h)
+    assert sorted(_abi.REWARD_KINDS.values()) == list(range(11))           # every fused reward has a kernel id (include/ev2g.h)
     assert _kind(lambda env: 0.0, _abi.REWARD_KINDS, "r") is None
     with pytest.raises(ValueError):
         _kind("NoSuchReward", _abi.REWARD_KINDS, "r")
