@@ -36,12 +36,19 @@ def main(n_cases):
         over = {"number_of_charging_stations": int(rng.integers(3, 40)), "number_of_ports_per_cs": int(rng.choice([1, 1, 2, 3])),
                 "number_of_transformers": int(rng.integers(1, 4)), "timescale": int(rng.choice([5, 15, 15, 30])),
                 "heterogeneous_ev_specs": bool(rng.random() < 0.7)}
-        if kind == 0:
-            cfg, sf, rf = cg._yaml_variant(base + "V2GProfitPlusLoads.yaml", over, f"fuzz{case}"), "V2G_profit_max_loads", "ProfitMax_TrPenalty_UserIncentives"
-        elif kind == 1:
-            cfg, sf, rf = cg._yaml_variant(base + "PublicPST.yaml", over, f"fuzz{case}"), "PublicPST", "SquaredTrackingErrorReward"
-        else:
-            cfg, sf, rf = cg._yaml_variant(base + "V2GProfitMax.yaml", over, f"fuzz{case}"), "V2G_profit_max", "profit_maximization"
+        topo = None
+        if rng.random() < 0.25:   # a topology file: chargers with their own port counts (falling order: the reference's mask index
+            # i*n_ports+j stays inside the array), current limits, voltage and phases (loaders.py:259-276, 312-340)
+            nps = sorted(rng.integers(1, 5, int(rng.integers(3, 9))).tolist(), reverse=True)
+            cut = sorted(rng.choice(np.arange(1, len(nps)), size=min(int(over["number_of_transformers"]) - 1, len(nps) - 1), replace=False).tolist())
+            groups = np.split(np.array(nps), cut)
+            topo = cg._topology_file(f"fuzz{case}", [(float(rng.choice([40, 60, 100])),
+                                                      [(int(n), float(rng.choice([16, 32])), float(rng.choice([0, -16, -32])) if kind != 1 else 0.0,
+                                                        float(rng.choice([230, 400])), int(rng.choice([1, 3]))) for n in g]) for g in groups])
+            over["charging_network_topology"] = topo
+        yaml_file, sf = [("V2GProfitPlusLoads.yaml", "V2G_profit_max_loads"), ("PublicPST.yaml", "PublicPST"), ("V2GProfitMax.yaml", "V2G_profit_max")][kind]
+        rf = str(rng.choice(sorted(_abi.REWARD_KINDS)))      # every fused reward built-in, with every state
+        cfg = cg._yaml_variant(base + yaml_file, over, f"fuzz{case}")
         seed = int(rng.integers(0, 10 ** 6))
         env = EV2Gym(config_file=cfg, seed=seed, state_function=getattr(S, sf), reward_function=getattr(RW, rf), generate_rnd_game=True)
         obs0, _ = env.reset(seed=seed)
@@ -78,7 +85,7 @@ def main(n_cases):
             err = max(err, abs(st[i] - rv) / max(1.0, abs(rv)))
         ora.close()
         worst = max(worst, err)
-        print(f"case {case:3d} {sf:22s} C={over['number_of_charging_stations']:2d} npc={over['number_of_ports_per_cs']} R={over['number_of_transformers']} "
+        print(f"case {case:3d} {sf:22s} {rf:40s} {'topology ' + str([c.n_ports for c in env.charging_stations]) if topo else ''} C={len(env.charging_stations):2d} npc={over['number_of_ports_per_cs']} R={len(env.transformers)} "
               f"dt={over['timescale']:2d} het={int(over['heterogeneous_ev_specs'])} {pol:5s} max rel err {err:.2e}" + (" (over-current fault at the same step)" if faulted else ""), flush=True)
         assert err < 1e-9, "oracle and reference disagree"
     print(f"{n_cases} cases, worst relative error {worst:.2e}")
