@@ -215,8 +215,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
+    # EV2G_BENCH_FORCE_DIST=1: run the multi-process code path (process group, asynchronous gather, C-ABI gather) at any world
+    # size -- under torch.distributed.run with ONE process it exercises, on a single GPU, exactly what the N-GPU launch runs
+    multi = world > 1 or bool(os.environ.get("EV2G_BENCH_FORCE_DIST"))
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -234,7 +237,7 @@ def main():
     n_groups = args.actor_groups if (args.actor == "mlp" and args.actor_groups > 1 and E % args.actor_groups == 0) else 1
     Eg, Mg = E // n_groups, M // n_groups
     gath = None
-    if world > 1:   # double-buffered asynchronous all-gather: the statistics travel while the next episode steps
+    if multi:   # double-buffered asynchronous all-gather: the statistics travel while the next episode steps
         from ev2gym_amd.dist import AsyncStatsGather
         gath = AsyncStatsGather(E, world, dev)
     loops, engines, actor = [], [], None
@@ -270,7 +273,7 @@ def main():
         if gath is not None:
             gath.finish()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -287,7 +290,7 @@ def main():
         barrier()
         one = time.perf_counter() - t0
         inner = max(1, int(np.ceil(0.02 / max(one, 1e-6))))
-        if world > 1:   # every rank must run the same number of steps
+        if multi:   # every rank must run the same number of steps
             tt = torch.tensor([inner], dtype=torch.int64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             inner = int(tt.item())
@@ -298,7 +301,7 @@ def main():
             loop.run(args.steps * inner, persistent)
             barrier()
             dt_ = time.perf_counter() - t0
-            if world > 1:
+            if multi:
                 tt = torch.tensor([dt_], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt_ = float(tt.item())
@@ -357,7 +360,7 @@ def main():
     # outside the timed regions: the C-ABI's own RCCL gather (ev2g_comm_init / ev2g_gather_stats, the path of hosts without
     # torch.distributed) next to torch's, on the same statistics
     c_gather = None
-    if world > 1:
+    if multi:
         try:
             from ev2gym_amd.dist import gather_stats_tensor
             ids = [Engine.comm_unique_id() if rank == 0 else None]
@@ -377,7 +380,7 @@ def main():
     env_steps_total = world * E * args.steps
     value = env_steps_total / wall[best]
     per_rank = None
-    if world > 1:   # what every rank measured itself (the driver computes scaling efficiency from `value`)
+    if multi:   # what every rank measured itself (the driver computes scaling efficiency from `value`)
         mine = torch.tensor([E * args.steps / float(np.median(res[best][3]))], dtype=torch.float64, device=dev)
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
@@ -399,7 +402,7 @@ def main():
         "full_episode": full_ep,
         "roofline": roof[best],
         "roofline_by_launch_mode": roof,
-        "rccl_ranks_seen": (world if world > 1 else None), "per_rank_env_steps_per_s": per_rank,
+        "rccl_ranks_seen": (world if multi else None), "per_rank_env_steps_per_s": per_rank,
         "rccl_collectives_issued": (gath.collectives if gath is not None else 0),
         "c_abi_rccl_gather": c_gather,
     }
@@ -409,7 +412,7 @@ def main():
         out["cpu_baseline"] = None
     for e_ in engines:
         e_.close()
-    if world > 1:
+    if multi:
         gath.finish()
         dist.barrier()
         dist.destroy_process_group()
