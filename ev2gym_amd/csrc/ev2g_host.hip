@@ -149,6 +149,12 @@ int ev2g_create(const ev2g_config *cfg, ev2g_handle **out) {
     return EV2G_OK;
 }
 
+// captured rollout segments hold kernel arguments (device pointers, shapes, actor weights) of the moment they were recorded
+static void drop_rollout_graphs(ev2g_handle *h) {
+    for (auto &g : h->rollout_graphs) (void)hipGraphExecDestroy(g.exec);
+    h->rollout_graphs.clear();
+}
+
 void ev2g_destroy(ev2g_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
@@ -157,7 +163,7 @@ void ev2g_destroy(ev2g_handle *h) {
     free_pool(h->st_allocs);
     free_pool(h->user_allocs);
     ev2g_comm_destroy(h);
-    for (auto &g : h->rollout_graphs) (void)hipGraphExecDestroy(g.exec);
+    drop_rollout_graphs(h);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -257,6 +263,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
             return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: cs_phases must be 1..3");
     }
     (void)hipStreamSynchronize(h->stream);
+    drop_rollout_graphs(h);
     free_pool(h->scn_allocs);
     free_pool(h->st_allocs);
     h->loaded = false;
@@ -911,7 +918,7 @@ int ev2g_mlp_create(ev2g_handle *h, int d_in, int h1, int h2, int d_out, const f
 
 void ev2g_mlp_destroy(ev2g_handle *h, ev2g_mlp *m) {
     if (!m) return;
-    if (h) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); }
+    if (h) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); drop_rollout_graphs(h); }
     free_pool(m->allocs);
     delete m;
 }

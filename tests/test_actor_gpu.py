@@ -80,3 +80,46 @@ def test_rollout_with_the_fused_actor_matches_oracle(kind):
         eng.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert np.array_equal(np.nan_to_num(res[0][2]), np.nan_to_num(res[1][2]))
+
+
+def test_rollout_graphs_follow_a_reload_and_a_new_actor():
+    """ev2g_rollout replays captured HIP graphs; a scenario reload or a new actor must not replay stale ones: after either, the
+    rollout equals the step-by-step execution again, and the segments are still replayed (graph launches keep counting)."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.actor import FusedMLPActor
+    from ev2gym_amd.engine import Engine
+    E = 40
+    pool, rk, sk, lo = _pool("v2gppl", E, seed=1)
+    eng = Engine(pool, rk, sk, device=0, flags=4)
+    T, P, D = eng.T, eng.P, eng.D
+    d_rew = eng.empty((T, E))
+
+    def both_ways(actor):
+        eng.reset()
+        eng.rollout(actor.mlp, T, d_rew, E)
+        fused = (actor.obs32.to_host().copy(), d_rew.to_host().copy())
+        eng.reset()
+        for t in range(T):
+            eng.mlp_forward(actor.mlp, actor.obs32, actor.act32, E)
+            eng.step_n(1, None, 0, None, 0, d_rew.at(t * E), 0, None, 0, None, 0, auto_reset=False, persistent=False)
+        assert np.array_equal(fused[0], actor.obs32.to_host()) and np.array_equal(fused[1], d_rew.to_host())
+        return fused
+
+    a1 = FusedMLPActor(eng, E, P, D, lo, seed=1)
+    r1 = both_ways(a1)
+    n1 = eng.rollout_graph_launches
+    assert n1 >= 1
+    r1b = both_ways(a1)                       # same signature again: replayed, same result
+    assert eng.rollout_graph_launches > n1 and np.array_equal(r1[1], r1b[1])
+    a1.close()
+    a2 = FusedMLPActor(eng, E, P, D, lo, seed=2)      # another actor (its weights may land where the old ones were)
+    r2 = both_ways(a2)
+    assert not np.array_equal(r1[1], r2[1])
+    pool2, _, _, _ = _pool("v2gppl", E, seed=7)         # reload: same shapes, other scenarios
+    eng.load(pool2)
+    a2.close()
+    a3 = FusedMLPActor(eng, E, P, D, lo, seed=2)
+    r3 = both_ways(a3)
+    assert not np.array_equal(r2[1], r3[1])
+    a3.close()
+    eng.close()

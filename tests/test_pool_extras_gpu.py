@@ -169,13 +169,17 @@ def test_fused_cost_matches_reference_fixture(name, cost_kind):
     eng.close()
 
 
-@pytest.mark.parametrize("kind", ["wave_v2gppl", "wave_pst", "v2_multi"])
+@pytest.mark.parametrize("kind", ["wave_v2gppl", "wave_pst", "v2_multi", "wave_v2gppl:pst_V2G_profitmaxV2", "wave_pst:SquaredTrackingErrorRewardWithPenalty"])
 def test_float32_actions_and_observations(kind):
     """The policy-network interface: float32 actions are widened on entry exactly like float64 ones holding the same
     values, and the float32 observation is the float64 one rounded once."""
     from ev2gym_amd.engine import Engine, host_uniform
+    from ev2gym_amd import _abi
     E = 33
+    kind, _, reward = kind.partition(":")
     pool, rk, sk, lo = _shape(kind, E, seed=3)
+    if reward:   # the run-time-selected reward instantiation of the fast path, float32 flavour
+        rk = _abi.REWARD_KINDS[reward]
     P, T = pool.n_ports, pool.n_steps
     K = 60
     a32 = host_uniform(K * E * P, 8, lo, 1.0).astype(np.float32).reshape(K, E, P)
