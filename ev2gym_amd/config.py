@@ -54,9 +54,9 @@ def gen_config_from_yaml(cfg, n_envs: int, seed: int = 0) -> GenConfig:
     c = load_yaml(cfg)
     if c.get("simulate_grid", False):
         raise NotImplementedError("simulate_grid: True is outside the accelerated path (SURVEY.md §2 row 14)")
-    if c["scenario"] not in ("workplace", "public"):
-        raise ValueError(f"scenario: '{c['scenario']}' -- the scenario generator has arrival / stay / energy tables for 'workplace' and "
-                         "'public' (the reference's 'private' scenario is not fitted)")
+    if c["scenario"] not in ("workplace", "public", "private"):
+        raise ValueError(f"scenario: '{c['scenario']}' -- the scenario generator has arrival / stay / energy tables for 'workplace', "
+                         "'public' and 'private' (the reference's three, utils.py:492-528)")
     if str(c.get("simulation_days", "weekdays")) != "weekdays" and c["scenario"] != "workplace":
         raise NotImplementedError(f"simulation_days: {c['simulation_days']} -- the generator's tables are fitted on weekdays only")
     if not c.get("random_day", True):

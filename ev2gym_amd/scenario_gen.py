@@ -154,6 +154,12 @@ _HOURLY = {
         stay=np.array([8.0, 8.0, 8.0, 8.0, 8.0, 7.93, 7.93, 8.63, 8.63, 7.35, 6.75, 4.34, 4.04, 3.56, 3.36, 2.41, 2.41, 2.51, 2.51,
                        2.62, 2.62, 3.0, 3.0, 3.0]),
         energy=np.full(24, 14.35)),
+    "private": dict(   # home charging: evening arrivals, overnight stays
+        rate=np.array([0.166, 0.166, 0.166, 0.166, 0.166, 0.03, 0.018, 0.079, 0.113, 0.426, 0.277, 0.307, 0.387, 0.587, 0.627, 0.639, 0.495,
+                       0.69, 2.806, 3.265, 2.131, 1.17, 1.69, 1.514]),
+        stay=np.array([8.0, 8.0, 8.0, 8.0, 8.0, 5.32, 5.32, 4.32, 4.32, 3.16, 3.66, 2.48, 4.48, 3.69, 4.69, 10.58, 10.58, 13.9, 13.4,
+                       13.07, 12.07, 11.09, 10.59, 8.91]),
+        energy=np.full(24, 22.0)),
     "public": dict(
         rate=np.array([0.153, 0.153, 0.153, 0.153, 0.153, 0.041, 0.05, 0.156, 0.86, 2.444, 1.525, 1.113, 1.251, 1.322, 1.261, 1.221,
                        1.221, 1.272, 1.731, 2.13, 1.883, 0.649, 0.741, 0.934]),
@@ -215,7 +221,7 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
 
     if cfg.scenario not in _HOURLY:
         raise ValueError(f"scenario '{cfg.scenario}': the spawner has tables for {sorted(_HOURLY)} "
-                         "(the reference's 'private' scenario is not fitted)")
+                         "")
     hour = int(rng.integers(5, 16)) if cfg.random_hour else cfg.hour
     step_hours = hour + cfg.minute / 60.0 + np.arange(T + 24) * dt / 60.0          # hour-of-day (unwrapped) of every step
     hod = step_hours % 24.0

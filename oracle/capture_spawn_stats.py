@@ -70,12 +70,21 @@ def stats_for(config, n_resets, state_fn, reward_fn):
 
 def main():
     import_reference()
+    from capture_golden import _yaml_variant
     base = "ev2gym/example_config_files/"
-    out = {"V2GProfitPlusLoads": stats_for(base + "V2GProfitPlusLoads.yaml", 300, "V2G_profit_max_loads", "ProfitMax_TrPenalty_UserIncentives"),
-           "PublicPST": stats_for(base + "PublicPST.yaml", 300, "PublicPST", "SquaredTrackingErrorReward")}
+    jobs = {"V2GProfitPlusLoads": lambda: stats_for(base + "V2GProfitPlusLoads.yaml", 300, "V2G_profit_max_loads", "ProfitMax_TrPenalty_UserIncentives"),
+            "PublicPST": lambda: stats_for(base + "PublicPST.yaml", 300, "PublicPST", "SquaredTrackingErrorReward"),
+            # the third scenario kind of the reference's arrival / stay / energy distributions ('private': home charging), on the V2GPPL config
+            "PrivateV2GPPL": lambda: stats_for(_yaml_variant(base + "V2GProfitPlusLoads.yaml", {"scenario": "private"}, "v2gppl_private"), 300,
+                                               "V2G_profit_max_loads", "ProfitMax_TrPenalty_UserIncentives")}
     path = os.path.join(os.path.dirname(HERE), "tests", "golden", "spawn_stats.json")
+    only = set(sys.argv[1:]) or set(jobs)
+    out = json.load(open(path)) if os.path.exists(path) else {}   # entries that were not asked for are kept as committed
+    for k in jobs:
+        if k in only:
+            out[k] = jobs[k]()
     json.dump(out, open(path, "w"), indent=1)
-    print(json.dumps(out, indent=1))
+    print(json.dumps({k: out[k] for k in only}, indent=1))
 
 
 if __name__ == "__main__":

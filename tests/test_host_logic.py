@@ -122,7 +122,8 @@ def test_plugin_resolution():
         _kind("NoSuchReward", _abi.REWARD_KINDS, "r")
 
 
-@pytest.mark.parametrize("name,yaml_file", [("V2GProfitPlusLoads", "V2GProfitPlusLoads.yaml"), ("PublicPST", "PublicPST.yaml")])
+@pytest.mark.parametrize("name,yaml_file", [("V2GProfitPlusLoads", "V2GProfitPlusLoads.yaml"), ("PublicPST", "PublicPST.yaml"),
+                                            ("PrivateV2GPPL", "V2GProfitPlusLoads.yaml")])
 def test_generator_reproduces_the_reference_spawn_statistics(name, yaml_file):
     """Statistical parity of the vectorised scenario generator with the reference's EV_spawner / spawn_single_EV
     (SURVEY.md §8f-1): tests/golden/spawn_stats.json holds summary statistics of 300 reference resets per config
@@ -133,7 +134,8 @@ def test_generator_reproduces_the_reference_spawn_statistics(name, yaml_file):
     from ev2gym_amd.scenario_gen import generate, occupancy_fraction
     ref = json.load(open(os.path.join(GOLDEN_DIR, "spawn_stats.json")))[name]
     cfg_dir = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "ev2gym_amd", "example_config_files")
-    b = generate(gen_config_from_yaml(load_yaml(os.path.join(cfg_dir, yaml_file)), 300, 11))
+    over = {"scenario": "private"} if name.startswith("Private") else {}
+    b = generate(gen_config_from_yaml({**load_yaml(os.path.join(cfg_dir, yaml_file)), **over}, 300, 11))
     a, T, P = b.arrays, b.n_steps, b.n_ports
     st = a["env_session_start"]
     stay = a["ev_t_dep"] - a["ev_t_arr"]
@@ -253,7 +255,7 @@ def test_yaml_keys_are_passed_through_or_reported():
     assert np.array_equal(b2.arrays["tr_inflexible_load"], a["tr_inflexible_load"]) and np.array_equal(b2.arrays["tr_dr"], a["tr_dr"])
     assert not np.array_equal(b2.arrays["ev_t_arr"][:20], a["ev_t_arr"][:20])
     with pytest.raises(ValueError, match="scenario"):
-        gen_config_from_yaml(_yaml("V2GProfitPlusLoads.yaml", scenario="private"), 2)
+        gen_config_from_yaml(_yaml("V2GProfitPlusLoads.yaml", scenario="campus"), 2)
     with pytest.raises(ValueError, match="scenario"):
         generate(GenConfig(n_envs=2, scenario="campus"))
     with pytest.raises(NotImplementedError, match="simulation_days"):

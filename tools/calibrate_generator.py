@@ -24,9 +24,13 @@ def measure(batch):
     return dict(hourly=hourly, stay2h=s2, req=req.mean(), spp=(st[1:] - st[:-1]).mean() / P, occ=G.occupancy_fraction(batch))
 
 
-for name, yaml in [("V2GProfitPlusLoads", "V2GProfitPlusLoads.yaml"), ("PublicPST", "PublicPST.yaml")]:
+want = set(sys.argv[1:])
+for name, yaml, over in [("V2GProfitPlusLoads", "V2GProfitPlusLoads.yaml", {}), ("PublicPST", "PublicPST.yaml", {}),
+                         ("PrivateV2GPPL", "V2GProfitPlusLoads.yaml", {"scenario": "private"})]:
+    if want and name not in want:
+        continue
     r = ref[name]
-    cfg = gen_config_from_yaml(load_yaml(os.path.join(ROOT, "ev2gym_amd", "example_config_files", yaml)), 400, 1)
+    cfg = gen_config_from_yaml({**load_yaml(os.path.join(ROOT, "ev2gym_amd", "example_config_files", yaml)), **over}, 400, 1)
     sc = cfg.scenario
     rh = np.array(r["arrival_share_per_hour"]); rs = np.array([x if x is not None else np.nan for x in r["stay_mean_by_2h_arrival_bin"]])
     for it in range(12):
