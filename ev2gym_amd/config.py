@@ -57,8 +57,6 @@ def gen_config_from_yaml(cfg, n_envs: int, seed: int = 0) -> GenConfig:
     if c["scenario"] not in ("workplace", "public", "private"):
         raise ValueError(f"scenario: '{c['scenario']}' -- the scenario generator has arrival / stay / energy tables for 'workplace', "
                          "'public' and 'private' (the reference's three, utils.py:492-528)")
-    if str(c.get("simulation_days", "weekdays")) != "weekdays" and c["scenario"] != "workplace":
-        raise NotImplementedError(f"simulation_days: {c['simulation_days']} -- the generator's tables are fitted on weekdays only")
     if not c.get("random_day", True):
         warnings.warn("random_day: False asks for the data of the calendar day " + "-".join(str(c.get(k)) for k in _CALENDAR_KEYS) +
                       "; the scenario generator is synthetic and calendar-free, so every reset still draws a new day", stacklevel=2)
@@ -78,6 +76,7 @@ def gen_config_from_yaml(cfg, n_envs: int, seed: int = 0) -> GenConfig:
         number_of_charging_stations=int(c["number_of_charging_stations"]),
         number_of_ports_per_cs=int(c["number_of_ports_per_cs"]),
         number_of_transformers=int(c["number_of_transformers"]), scenario=c["scenario"],
+        simulation_days=str(c.get("simulation_days", "weekdays")),
         spawn_multiplier=float(c["spawn_multiplier"]), hour=int(c["hour"]), minute=int(c.get("minute", 0)),
         random_hour=bool(c.get("random_day", True) and c.get("random_hour", False)), v2g_enabled=bool(c["v2g_enabled"]),
         topology=topology, tr_seed=int(c.get("tr_seed", -1)),

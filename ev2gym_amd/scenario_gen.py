@@ -70,7 +70,8 @@ class GenConfig:
     number_of_charging_stations: int = 25
     number_of_ports_per_cs: int = 1
     number_of_transformers: int = 1
-    scenario: str = "workplace"          # workplace | public
+    scenario: str = "workplace"          # workplace | public | private
+    simulation_days: str = "weekdays"    # weekdays | weekends | both (ev2gym_env.py:147-154); workplaces see no weekend arrivals (utils.py:519-521)
     spawn_multiplier: float = 5.0
     hour: int = 5
     minute: int = 0
@@ -160,6 +161,19 @@ _HOURLY = {
         stay=np.array([8.0, 8.0, 8.0, 8.0, 8.0, 5.32, 5.32, 4.32, 4.32, 3.16, 3.66, 2.48, 4.48, 3.69, 4.69, 10.58, 10.58, 13.9, 13.4,
                        13.07, 12.07, 11.09, 10.59, 8.91]),
         energy=np.full(24, 22.0)),
+    # weekend days (distribution-of-arrival-weekend.csv, the *_weekend stay / energy distributions; utils.py:366-382,519-528)
+    "private_weekend": dict(
+        rate=np.array([0.214, 0.214, 0.214, 0.214, 0.214, 0.021, 0.029, 0.08, 0.081, 0.231, 0.486, 0.731, 1.396, 1.606, 1.679, 1.604, 0.916,
+                       1.576, 2.605, 1.286, 1.485, 1.02, 1.231, 0.526]),
+        stay=np.array([8.0, 8.0, 8.0, 8.0, 8.0, 4.35, 4.35, 4.31, 4.31, 3.41, 3.41, 3.16, 4.16, 3.72, 4.72, 9.71, 10.71, 14.4, 14.4, 13.11,
+                       12.11, 11.47, 10.47, 8.3]),
+        energy=np.full(24, 19.37)),
+    "public_weekend": dict(
+        rate=np.array([0.163, 0.163, 0.163, 0.163, 0.163, 0.035, 0.053, 0.083, 0.11, 0.541, 0.957, 1.38, 1.952, 1.951, 2.029, 2.049, 2.025,
+                       1.987, 1.515, 1.608, 1.253, 0.895, 0.638, 1.424]),
+        stay=np.array([8.0, 8.0, 8.0, 8.0, 8.0, 5.33, 5.33, 5.63, 5.63, 4.2, 4.2, 2.86, 2.86, 3.01, 3.01, 2.82, 3.32, 7.28, 8.28, 12.0,
+                       12.0, 10.83, 9.83, 12.11]),
+        energy=np.full(24, 13.9)),
     "public": dict(
         rate=np.array([0.153, 0.153, 0.153, 0.153, 0.153, 0.041, 0.05, 0.156, 0.86, 2.444, 1.525, 1.113, 1.251, 1.322, 1.261, 1.221,
                        1.221, 1.272, 1.731, 2.13, 1.883, 0.649, 0.741, 0.934]),
@@ -219,9 +233,10 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
     P = len(port_cs)
     tr_cap = tr_cap[None, :, None]
 
-    if cfg.scenario not in _HOURLY:
-        raise ValueError(f"scenario '{cfg.scenario}': the spawner has tables for {sorted(_HOURLY)} "
-                         "")
+    if cfg.scenario not in ("workplace", "public", "private"):
+        raise ValueError(f"scenario '{cfg.scenario}': the spawner has tables for 'workplace', 'public' and 'private'")
+    if cfg.simulation_days not in ("weekdays", "weekends", "both"):
+        raise ValueError(f"simulation_days '{cfg.simulation_days}': weekdays, weekends or both")
     hour = int(rng.integers(5, 16)) if cfg.random_hour else cfg.hour
     step_hours = hour + cfg.minute / 60.0 + np.arange(T + 24) * dt / 60.0          # hour-of-day (unwrapped) of every step
     hod = step_hours % 24.0
@@ -238,9 +253,23 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
     # ---- EV sessions (EV_spawner utils.py:477-557) ----
     min_stay_steps = cfg.ev_min_time_of_stay // dt
     free_from = np.zeros((E, P), np.int64)       # first spawn step t at which the port passes the 3-step-empty rule
-    rate = _arrival_rate(cfg.scenario, hod) * (dt / 60.0) * cfg.spawn_multiplier   # percent per step
-    stay_mean = _mean_stay_hours(cfg.scenario, hod)
-    energy_mean = _mean_energy_kwh(cfg.scenario, hod)
+    # weekday or weekend tables per env: the reference's date decides (workplaces are always simulated on weekdays, ev2gym_env.py:141-145;
+    # 'both' = a uniformly random day: two in seven are weekend days)
+    if cfg.scenario == "workplace" or cfg.simulation_days == "weekdays":
+        weekend = np.zeros(E, bool)
+    elif cfg.simulation_days == "weekends":
+        weekend = np.ones(E, bool)
+    else:
+        weekend = rng.random(E) < 2.0 / 7.0
+
+    def table(fn):   # [E, len(hod)]
+        wd = fn(cfg.scenario, hod)
+        if not weekend.any():
+            return np.broadcast_to(wd, (E, len(hod)))
+        return np.where(weekend[:, None], fn(cfg.scenario + "_weekend", hod)[None, :], wd[None, :])
+    rate = table(_arrival_rate) * (dt / 60.0) * cfg.spawn_multiplier   # percent per step
+    stay_mean = table(_mean_stay_hours)
+    energy_mean = table(_mean_energy_kwh)
     if cfg.heterogeneous_ev_specs:
         fleet = _FLEET_V2G if (cfg.fleet_with_efficiency_tables or cfg.fleet != "ev_plus_phev") else _FLEET_EV_PHEV
         share = np.array([f[0] for f in fleet])
@@ -250,12 +279,12 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
     se, sp, st_, sB, spac, scap0, stdep, smodel = [], [], [], [], [], [], [], []
     for t in range(2, T - min_stay_steps - 1):
         u = rng.random((E, P)) * 100.0
-        spawn = (free_from <= t) & (u < rate[t])
+        spawn = (free_from <= t) & (u < rate[:, t, None])
         if not spawn.any():
             continue
         e_idx, p_idx = np.nonzero(spawn)
         n = len(e_idx)
-        req = rng.normal(energy_mean[t], 0.5 * energy_mean[t], n)
+        req = rng.normal(energy_mean[e_idx, t], 0.5 * energy_mean[e_idx, t], n)
         req = np.where(req < 5, rng.integers(5, 10, n), req)
         if cfg.heterogeneous_ev_specs:
             model = rng.choice(len(share), n, p=share)
@@ -269,7 +298,7 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
         cap0 = np.where(cap0 > cfg.ev_desired_capacity * B, rng.integers(1, np.maximum(B.astype(int), 2), n), cap0)
         cap0 = np.where((cap0 < cfg.ev_min_battery_capacity) & (B > 2 * cfg.ev_min_battery_capacity),
                         cfg.ev_min_battery_capacity, cap0)
-        stay = rng.normal(stay_mean[t], 0.2 * stay_mean[t], n) * 60.0 / dt + 1
+        stay = rng.normal(stay_mean[e_idx, t], 0.2 * stay_mean[e_idx, t], n) * 60.0 / dt + 1
         stay = np.maximum(stay, min_stay_steps)
         keep = ~(stay + t + 4 >= T)          # empty_ports_at_end_of_simulation (utils.py:254-256)
         e_idx, p_idx, B, pac, cap0, stay, model = e_idx[keep], p_idx[keep], B[keep], pac[keep], cap0[keep], stay[keep], model[keep]

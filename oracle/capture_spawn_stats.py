@@ -76,7 +76,12 @@ def main():
             "PublicPST": lambda: stats_for(base + "PublicPST.yaml", 300, "PublicPST", "SquaredTrackingErrorReward"),
             # the third scenario kind of the reference's arrival / stay / energy distributions ('private': home charging), on the V2GPPL config
             "PrivateV2GPPL": lambda: stats_for(_yaml_variant(base + "V2GProfitPlusLoads.yaml", {"scenario": "private"}, "v2gppl_private"), 300,
-                                               "V2G_profit_max_loads", "ProfitMax_TrPenalty_UserIncentives")}
+                                               "V2G_profit_max_loads", "ProfitMax_TrPenalty_UserIncentives"),
+            # weekend days (simulation_days: weekends; ev2gym_env.py:151-154, utils.py:366-382,519-528) of the two scenarios that have them
+            "PublicPSTWeekend": lambda: stats_for(_yaml_variant(base + "PublicPST.yaml", {"simulation_days": "weekends"}, "pst_weekend"), 300,
+                                                  "PublicPST", "SquaredTrackingErrorReward"),
+            "PrivateV2GPPLWeekend": lambda: stats_for(_yaml_variant(base + "V2GProfitPlusLoads.yaml", {"scenario": "private", "simulation_days": "weekends"},
+                                                                    "v2gppl_private_weekend"), 300, "V2G_profit_max_loads", "ProfitMax_TrPenalty_UserIncentives")}
     path = os.path.join(os.path.dirname(HERE), "tests", "golden", "spawn_stats.json")
     only = set(sys.argv[1:]) or set(jobs)
     out = json.load(open(path)) if os.path.exists(path) else {}   # entries that were not asked for are kept as committed

@@ -123,7 +123,8 @@ def test_plugin_resolution():
 
 
 @pytest.mark.parametrize("name,yaml_file", [("V2GProfitPlusLoads", "V2GProfitPlusLoads.yaml"), ("PublicPST", "PublicPST.yaml"),
-                                            ("PrivateV2GPPL", "V2GProfitPlusLoads.yaml")])
+                                            ("PrivateV2GPPL", "V2GProfitPlusLoads.yaml"), ("PublicPSTWeekend", "PublicPST.yaml"),
+                                            ("PrivateV2GPPLWeekend", "V2GProfitPlusLoads.yaml")])
 def test_generator_reproduces_the_reference_spawn_statistics(name, yaml_file):
     """Statistical parity of the vectorised scenario generator with the reference's EV_spawner / spawn_single_EV
     (SURVEY.md §8f-1): tests/golden/spawn_stats.json holds summary statistics of 300 reference resets per config
@@ -135,6 +136,8 @@ def test_generator_reproduces_the_reference_spawn_statistics(name, yaml_file):
     ref = json.load(open(os.path.join(GOLDEN_DIR, "spawn_stats.json")))[name]
     cfg_dir = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "ev2gym_amd", "example_config_files")
     over = {"scenario": "private"} if name.startswith("Private") else {}
+    if name.endswith("Weekend"):
+        over["simulation_days"] = "weekends"
     b = generate(gen_config_from_yaml({**load_yaml(os.path.join(cfg_dir, yaml_file)), **over}, 300, 11))
     a, T, P = b.arrays, b.n_steps, b.n_ports
     st = a["env_session_start"]
@@ -258,8 +261,13 @@ def test_yaml_keys_are_passed_through_or_reported():
         gen_config_from_yaml(_yaml("V2GProfitPlusLoads.yaml", scenario="campus"), 2)
     with pytest.raises(ValueError, match="scenario"):
         generate(GenConfig(n_envs=2, scenario="campus"))
-    with pytest.raises(NotImplementedError, match="simulation_days"):
-        gen_config_from_yaml(_yaml("PublicPST.yaml", simulation_days="weekends"), 2)
+    with pytest.raises(ValueError, match="simulation_days"):
+        generate(gen_config_from_yaml(_yaml("PublicPST.yaml", simulation_days="sundays"), 2))
+    wk = generate(gen_config_from_yaml(_yaml("V2GProfitPlusLoads.yaml", simulation_days="weekends"), 4, seed=3))   # workplaces: weekdays anyway
+    wd = generate(gen_config_from_yaml(_yaml("V2GProfitPlusLoads.yaml"), 4, seed=3))
+    assert np.array_equal(wk.arrays["ev_t_arr"], wd.arrays["ev_t_arr"])
+    both = generate(gen_config_from_yaml(_yaml("PublicPST.yaml", simulation_days="both"), 64, seed=3))
+    assert both.n_sessions > 0
     with pytest.raises(NotImplementedError, match="simulate_grid"):
         gen_config_from_yaml(_yaml("PublicPST.yaml", simulate_grid=True), 2)
     with pytest.warns(UserWarning, match="calendar"):

@@ -26,12 +26,14 @@ def measure(batch):
 
 want = set(sys.argv[1:])
 for name, yaml, over in [("V2GProfitPlusLoads", "V2GProfitPlusLoads.yaml", {}), ("PublicPST", "PublicPST.yaml", {}),
-                         ("PrivateV2GPPL", "V2GProfitPlusLoads.yaml", {"scenario": "private"})]:
+                         ("PrivateV2GPPL", "V2GProfitPlusLoads.yaml", {"scenario": "private"}),
+                         ("PublicPSTWeekend", "PublicPST.yaml", {"simulation_days": "weekends"}),
+                         ("PrivateV2GPPLWeekend", "V2GProfitPlusLoads.yaml", {"scenario": "private", "simulation_days": "weekends"})]:
     if want and name not in want:
         continue
     r = ref[name]
     cfg = gen_config_from_yaml({**load_yaml(os.path.join(ROOT, "ev2gym_amd", "example_config_files", yaml)), **over}, 400, 1)
-    sc = cfg.scenario
+    sc = cfg.scenario + ("_weekend" if cfg.simulation_days == "weekends" else "")
     rh = np.array(r["arrival_share_per_hour"]); rs = np.array([x if x is not None else np.nan for x in r["stay_mean_by_2h_arrival_bin"]])
     for it in range(12):
         m = measure(G.generate(cfg))
