@@ -36,7 +36,7 @@ def load_topology(path, search_dirs=()) -> dict:
         out["tr_max_power"].append(float(tr["max_power"]))
         for ch in tr["charging_stations"].values():
             if str(ch.get("charger_type", "AC")) != "AC":
-                raise NotImplementedError("DC chargers are outside the accelerated path (EV.step's DC branch, ev.py:165-167)")
+                raise NotImplementedError("charger_type 'DC': the reference's EV.step raises NotImplementedError for DC chargers too (ev.py:148-149)")
             for k in keys:
                 out[k].append(ch[k])
             out["transformer"].append(i)
