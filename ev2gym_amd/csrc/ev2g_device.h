@@ -105,8 +105,9 @@ struct DevState {  // mutable engine state, device pointers
     double *over_hist;                 // [T,E,R] env.tr_overload
     double *tr_power_now;              // [E,R]  Transformer.current_power of the last step
     double *sess_final_cap;            // [S] capacity at departure
-    double *soc_log;                   // [T,E*P] (EV2G_FLAG_LOG_SOC; time-major: the step kernel's writes of one step are contiguous -- a port-major log made the
-                                       // statistics kernel 20 % faster and the step kernel 13 % slower) capacity before each EV.step, negated when the step was inactive
+    double *soc_log;                   // [E,T,P] (EV2G_FLAG_LOG_SOC; env-major blocks, time-major inside: the step kernel's writes of one env-step are
+                                       // contiguous and the statistics kernel reads an env's block with neighbouring sectors; a PORT-major log made
+                                       // the statistics kernel 20 % faster and the step kernel 13 % slower) capacity before each EV.step, negated when the step was inactive
     double *abs_e;                     // [E*P]  (flag) EV.abs_total_energy_exchanged of the attached session
     double *sess_abs_e;                // [S]    (flag) the same, frozen at departure
     double *port_energy, *port_current;  // [E*P] EV.current_energy / actual_current of the last step
@@ -619,7 +620,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 st.port_energy[g] = energy;
                 st.port_current[g] = current;
                 if (st.soc_log) {  // historic_soc / active_steps (ev.py:156,162,185) and abs_total_energy_exchanged (:180)
-                    st.soc_log[(long long)t * s.E * P + g] = (current != 0.0) ? cap_before : -cap_before;
+                    st.soc_log[((long long)e * T + t) * P + q] = (current != 0.0) ? cap_before : -cap_before;
                     if (energy != 0.0) st.abs_e[g] += fabs(energy);
                 }
                 // departure (ev_charger.py:209-229, ev.py:191-214)
@@ -961,7 +962,6 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
     // per-session constants of get_battery_degradation, evaluated once (same operations, same values)
     const double k_arrh = exp(-e2 / theta), k_age = pow(b_age, 0.25);
     const double Q_acc = 2 * (b_age * (d_dist / 365) * G_ * b_cap_ah) / b_cap_kwh, k_qacc = pow(Q_acc, 0.5);
-    const long long EP = (long long)s.E * P;
     const bool log_soc = st.soc_log != nullptr;
     double sum = 0.0, mn = INFINITY, cnt = 0.0, deg_cal = 0.0, deg_cyc = 0.0;
     // the satisfaction values of this lane's first port (the only one when P <= 64; a port has at most 6 sessions,
@@ -986,21 +986,22 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                 nkeep = k - first + 1;
             }
             if (log_soc) {
+                const double *__restrict__ slog = st.soc_log + (long long)e * T * P + q;   // this port's column of the env's [T, P] block
                 const double B = s.ss_B[k];
                 const int ta = s.ss_tarr[k], td = s.ss_tdep[k];
                 const int tend = min(td, cur_step - 1);
                 const double soc_f = capk / B;
                 double hs = 0.0, fs = 0.0;
                 int n = 0, nf = 0;
-                // historic_soc / active_steps (sign bit set = inactive step).  The log is [T, E*P]: consecutive steps of a
-                // port are E*P*8 bytes apart, every read is its own 32-byte sector -- the kernel is bound by that sector
-                // traffic.  The first NK steps of a session are fetched by unconditional (clamped) loads issued together
+                // historic_soc / active_steps (sign bit set = inactive step).  The log is [E, T, P]: an env's block is contiguous
+                // (T*P*8 bytes, 45 KB at cfg2), consecutive steps of a port are P*8 bytes apart, so the sectors the lanes of this
+                // wavefront touch lie next to each other and are shared between neighbouring ports.  The first NK steps of a session are fetched by unconditional (clamped) loads issued together
                 // and KEPT in registers for the second pass; only the tail of longer sessions is read twice, in batches
                 // of eight.  Accumulation order is the sequential one.
                 constexpr int NK = 24;
                 double xk[NK];
 #pragma unroll
-                for (int u = 0; u < NK; u++) xk[u] = st.soc_log[(long long)min(ta + u, tend) * EP + g];
+                for (int u = 0; u < NK; u++) xk[u] = slog[(long long)min(ta + u, tend) * P];
 #pragma unroll
                 for (int u = 0; u < NK; u++) {
                     if (ta + u <= tend) {
@@ -1013,7 +1014,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                 for (int t = ta + NK; t <= tend; t += 8) {
                     double x[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) x[u] = st.soc_log[(long long)min(t + u, tend) * EP + g];
+                    for (int u = 0; u < 8; u++) x[u] = slog[(long long)min(t + u, tend) * P];
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         if (t + u <= tend) {
@@ -1035,7 +1036,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                 for (int t = ta + NK; t <= tend; t += 8) {
                     double x[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) x[u] = st.soc_log[(long long)min(t + u, tend) * EP + g];
+                    for (int u = 0; u < 8; u++) x[u] = slog[(long long)min(t + u, tend) * P];
 #pragma unroll
                     for (int u = 0; u < 8; u++)
                         if (t + u <= tend && __double_as_longlong(x[u]) >= 0) mad += fabs(avg_f - fabs(x[u]) / B);

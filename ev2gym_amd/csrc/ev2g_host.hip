@@ -443,6 +443,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         const unsigned long long biggest = std::max({(unsigned long long)E * P * 8, (unsigned long long)E * D * 8,
                                                      (unsigned long long)M * (T + 1) * 60 * 8, (unsigned long long)S * sizeof(SessRec),
                                                      (unsigned long long)M * T * 64, (unsigned long long)E * T * 8 * 3, (unsigned long long)M * P * 8,
+                                                     (h->cfg.flags & EV2G_FLAG_LOG_SOC) ? (unsigned long long)E * T * P * 8 : 0ull,
                                                      (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) ? (unsigned long long)T * E * C * 8 : 0ull});
         if (biggest >= lim) { h->wave_path = false; h->fallback_reason = "an array of the batch reaches 4 GiB (32-bit byte offsets)"; }
     }

@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 if (npc == 1 && current - 0.0001 > c_imax) S->env_fault[e_l] = 1;  // ev_charger.py:203-205
                 if (last_step) { S->port_energy[g_l] = energy; S->port_current[g_l] = current; }
                 if (log_soc)  // historic_soc / active_steps (ev.py:156,162,185): capacity before the step, negated if inactive
-                    S->soc_log[(long long)t * E * P + g_l] = (current != 0.0) ? cap_before : -cap_before;
+                    S->soc_log[((long long)e_l * T + t) * P + (g_l - e_l * P)] = (current != 0.0) ? cap_before : -cap_before;
                 if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
                     const int ss = s_ss[tid_l];
                     const SessRec &r = *(const SessRec *)(S->rec + ss);

@@ -14,3 +14,11 @@ python - $O/bench_actor.json <<'P'
 import json,sys
 d=json.loads(open(sys.argv[1]).read()); print("actor rollout", round(d['value']/1e6,2), "M env-steps/s", round(d['ms_per_step']*1e3,2), "us/step")
 P
+# kernel-trace averages of the step / statistics / reset kernels at cfg2 and cfg3 (persistent launches)
+for w in cfg2 cfg3; do rm -rf $O/kt_$w; rocprofv3 --kernel-trace --stats -d $O/kt_$w -o kt -- python bench.py --workload $w --launch persistent --no-cpu-baseline --min-time 0.1 > /dev/null 2>&1
+python - $O/kt_$w/kt_results.db $w <<'P'
+import sqlite3, sys
+con=sqlite3.connect(sys.argv[1])
+for r in con.execute("select name,total_calls,average from top_kernels limit 3"): print(sys.argv[2], "KT |", r[0][:60], "|", r[1], "|", round(r[2],2))
+P
+rm -rf $O/kt_$w; done
