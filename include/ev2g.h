@@ -7,10 +7,11 @@
  * interface it replaces.  Everything is `extern "C"`, plain pointers and sizes, no torch types.
  *
  * Conventions
- *   E envs, C chargers/env, P = C * ports_per_charger ports/env, R transformers/env, T steps/episode,
- *   H = 20 observation horizon (state.py:119,129-132).  All floating point is IEEE float64.
- *   Port index p = charger * ports_per_charger + port  (the reference action / action_mask order,
- *   ev2gym_env.py:363-385, :452-457).
+ *   E envs stepped out of M >= E resident scenarios, C chargers/env, P = sum of the chargers' n_ports
+ *   (C * ports_per_charger when they are equal), R transformers/env, T steps/episode, H = 20 observation
+ *   horizon (state.py:119,129-132).  All floating point is IEEE float64 (float32 hand-over optional).
+ *   Port index p = first port of the charger + port: cumulative in charger order, the reference's action
+ *   order (ev2gym_env.py:363-385); the action mask follows the reference's own index i*n_ports+j (:452-457).
  *   Return value: 0 = ok, negative = EV2G_ERR_*; ev2g_last_error() returns a message.
  *   A handle is bound to one GPU and one HIP stream and is not thread-safe; distinct handles may be
  *   driven from distinct threads / processes (one process per GPU).
