@@ -998,7 +998,10 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                 // wavefront touch lie next to each other and are shared between neighbouring ports.  The first NK steps of a session are fetched by unconditional (clamped) loads issued together
                 // and KEPT in registers for the second pass; only the tail of longer sessions is read twice, in batches
                 // of eight.  Accumulation order is the sequential one.
-                constexpr int NK = 24;
+#ifndef EV2G_STATS_NK
+#define EV2G_STATS_NK 24
+#endif
+                constexpr int NK = EV2G_STATS_NK;
                 double xk[NK];
 #pragma unroll
                 for (int u = 0; u < NK; u++) xk[u] = slog[(long long)min(ta + u, tend) * P];
