@@ -62,7 +62,7 @@ def measured_traffic(workload, launch, steps_per_launch, envs):
     return (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
 
 
-def cpu_baseline(batch, rk, sk, lo, budget_s=12.0):
+def cpu_baseline(batch, rk, sk, lo, budget_s=float(os.environ.get("EV2G_BENCH_CPU_BUDGET", "12.0"))):
     """The C oracle (a scalar port of the reference step(), oracle/ev2g_oracle.c) timed on this box's host
     cores, single thread, on whole episodes of a prefix of the same env batch."""
     from oracle.oracle import Oracle

@@ -1,0 +1,34 @@
+"""bench.py's one-line JSON contract (the driver parses it): a small run on the GPU, keys and types checked."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("extra", [[], ["--workload", "cfg3"], ["--actor", "mlp"]], ids=["cfg2", "cfg3", "actor"])
+def test_bench_line_contract(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--envs", "512", "--steps", "20", "--warmup", "5", "--min-time", "0.02"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env={**os.environ, "EV2G_BENCH_CPU_BUDGET": "1.5"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict)):
+        assert isinstance(d[k], t), (k, d[k])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["value"] > 1e6 and abs(d["value"] - 512 * 20 / (d["ms_per_step"] * 20 / 1e3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    if not extra or extra[0] == "--workload":
+        cb = d["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
