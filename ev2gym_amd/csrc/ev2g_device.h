@@ -74,6 +74,8 @@ struct DevScn {  // read-only scenario + layout, device pointers
     // per port [E*P]: first session (or -1) and its window
     const int *port_first;
     const int *port_end;   // one past the port's last session
+    const int *ss_slot;    // [S] port slot of every session; const int *scn_sess: [M+1] session range of every scenario (statistics kernel)
+    const int *scn_sess;
     const int2 *port_first_win;
     const SessRec *rec;  // [S] AoS twin of the ss_* arrays (v2 kernels)
     const double *win_tab;  // [E,R,T+1,40] precomputed (loads-pv)[20] | power_limits[20] per observation step, or nullptr
@@ -964,27 +966,27 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
     const double Q_acc = 2 * (b_age * (d_dist / 365) * G_ * b_cap_ah) / b_cap_kwh, k_qacc = pow(Q_acc, 0.5);
     const bool log_soc = st.soc_log != nullptr;
     double sum = 0.0, mn = INFINITY, cnt = 0.0, deg_cal = 0.0, deg_cyc = 0.0;
-    // the satisfaction values of this lane's first port (the only one when P <= 64; a port has at most 6 sessions,
-    // utils.py:318,534-552) are kept for the variance pass below instead of being fetched again
-    double vkeep[6];
+    // One SESSION per lane (an env has ~0.7 sessions per port: 35 at cfg2): every lane's chain is the two or three memory round
+    // trips of ONE session's SoC log.  With a lane per port the wavefront waited for its busiest port (up to six sessions in a row).
+    // The satisfaction values of a lane's first two sessions are kept for the variance pass below instead of being fetched again.
+    double vkeep[2];
     int nkeep = 0;
-    for (int q = lane; q < P; q += 64) {
+    const int d0 = s.scn_sess[scn], d1 = s.scn_sess[scn + 1];
+    for (int k = d0 + lane; k < d1; k += 64) {
+        const int q = s.ss_slot[k];
         const long long g = (long long)e * P + q, gs = (long long)scn * P + q;
         int first, last;
         bool attached;
         port_sessions(s, st, g, gs, cur_step, first, last, attached);
-        for (int k = first; k < last; k++) {
+        if (k >= first && k < last) {   // spawned so far
             const bool live = attached && k == last - 1;
             const double capk = live ? st.cap[g] : st.sess_final_cap[k];
             const double v = capk / ss_afap[k] * 100.0;
             sum += v;
             mn = fmin(mn, v);
             cnt += 1.0;
-            if (q == lane) {
-#pragma unroll
-                for (int u = 0; u < 6; u++) if (u == k - first) vkeep[u] = v;
-                nkeep = k - first + 1;
-            }
+            if (nkeep < 2) vkeep[nkeep] = v;
+            nkeep++;
             if (log_soc) {
                 const double *__restrict__ slog = st.soc_log + (long long)e * T * P + q;   // this port's column of the env's [T, P] block
                 const double B = s.ss_B[k];
@@ -1064,16 +1066,17 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
     if (cnt > 0.0) {
         mean = sum / cnt;
         double var = 0.0;
-        if (P <= 64 && __all(nkeep <= 6)) {   // every lane kept all of its values
-#pragma unroll
-            for (int u = 0; u < 6; u++) if (u < nkeep) { const double v = vkeep[u] - mean; var += v * v; }
+        if (__all(nkeep <= 2)) {   // every lane kept all of its values (an env with at most 128 spawned sessions)
+            if (nkeep > 0) { const double v = vkeep[0] - mean; var += v * v; }
+            if (nkeep > 1) { const double v = vkeep[1] - mean; var += v * v; }
         } else {
-            for (int q = lane; q < P; q += 64) {
+            for (int k = d0 + lane; k < d1; k += 64) {
+                const int q = s.ss_slot[k];
                 const long long g = (long long)e * P + q, gs = (long long)scn * P + q;
                 int first, last;
                 bool attached;
                 port_sessions(s, st, g, gs, cur_step, first, last, attached);
-                for (int k = first; k < last; k++) {
+                if (k >= first && k < last) {
                     const double capk = (attached && k == last - 1) ? st.cap[g] : st.sess_final_cap[k];
                     const double v = capk / ss_afap[k] * 100.0 - mean;
                     var += v * v;

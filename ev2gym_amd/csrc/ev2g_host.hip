@@ -306,7 +306,9 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     for (int r = 0; r < R; r++) max_seg = std::max(max_seg, tr_seg[r + 1] - tr_seg[r]);
 
     // ---- resolve ports (first-free replay, ev_charger.py:266-286) and order sessions by (env, slot, arrival) ----
-    std::vector<int> sess_port((size_t)S), host_to_dev((size_t)S);
+    std::vector<int> sess_port((size_t)S), host_to_dev((size_t)S), ss_slot((size_t)std::max<long long>(S, 1));   // ss_slot: port slot of a session, device order
+    std::vector<int> scn_sess((size_t)M + 1);   // device sessions of scenario m: [scn_sess[m], scn_sess[m+1]) (device order is scenario-major)
+    for (int m = 0; m <= M; m++) scn_sess[(size_t)m] = (int)b->env_session_start[m];
     std::vector<long long> dev_to_host((size_t)S);
     std::vector<int> port_first((size_t)M * P, -1);
     std::vector<int> port_end((size_t)M * P, -1);   // one past the port's last session (device order: a port's sessions are consecutive)
@@ -347,6 +349,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
             for (auto &kv : keyed) {
                 host_to_dev[kv.second] = (int)d;
                 dev_to_host[d] = kv.second;
+                ss_slot[(size_t)d] = (int)kv.first;
                 const size_t g = (size_t)e * P + kv.first;
                 if (port_first[g] < 0) {
                     port_first[g] = (int)d;
@@ -570,6 +573,8 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     UP(d_lut_eta, lut_eta)
     UP(ip, port_first) s.port_first = ip;
     UP(ip, port_end) s.port_end = ip;
+    UP(ip, ss_slot) s.ss_slot = ip;
+    UP(ip, scn_sess) s.scn_sess = ip;
     UP(i2p, port_first_win) s.port_first_win = i2p;
     UP(dp, ss_afap) h->d_ss_afap = dp;
     { SessRec *rp; UP(rp, recs) s.rec = rp; }
