@@ -133,8 +133,12 @@ class DeviceBuffer:
         self.engine._check(self.engine._lib.ev2g_memcpy_h2d(self.engine._h, self.ptr, arr.ctypes.data, self.nbytes))
         return self
 
-    def to_host(self):
-        out = np.empty(self.shape, self.dtype)
+    def to_host(self, out=None):
+        """Copy to the host: into a new array, or into `out` (same shape / dtype, C-contiguous) so that views of it stay valid."""
+        if out is None:
+            out = np.empty(self.shape, self.dtype)
+        else:
+            assert out.dtype == self.dtype and out.nbytes == self.nbytes and out.flags.c_contiguous
         self.engine._check(self.engine._lib.ev2g_memcpy_d2h(self.engine._h, out.ctypes.data, self.ptr, self.nbytes))
         return out
 

@@ -59,6 +59,18 @@ class EV2GymSB3VecEnv(_SB3VecEnv):
         self.render_mode = None
         self.reset_infos: List[dict] = [{} for _ in range(self.num_envs)]
         self._actions = None
+        # Fast path (engine-owned buffers, float32 observations): the policy-side types cross the boundary directly -- float32 actions
+        # up, float32 observations down (the kernel widens / rounds once; no float64 copies or host conversions), and the per-env
+        # info dicts of non-terminal steps are PERSISTENT: their "action_mask" entries are views of one host array refreshed in
+        # place every step (consumers that keep infos across steps must copy them; terminal infos are fresh objects).
+        self._fast = hasattr(vec, "engine") and getattr(vec, "_torch", 0) is None and self.obs_dtype == np.float32
+        if self._fast:
+            eng, E, P, D = vec.engine, vec.num_envs, vec.number_of_ports, vec.engine.D
+            self._d_obs32, self._d_act32 = eng.empty((E, D), np.float32), eng.empty((E, P), np.float32)
+            eng.set_extras(cost=vec._cost, obs_f32=self._d_obs32, obs_f32_stride=0, actions_f32=self._d_act32)
+            self._h_obs, self._h_mask = np.empty((E, D), np.float32), np.zeros((E, P), np.uint8)
+            self._h_rew, self._h_done = np.empty(E, np.float64), np.empty(E, np.uint8)
+            self._infos = [{"action_mask": self._h_mask[i]} for i in range(E)]
         self._ep_return = np.zeros(self.num_envs)
         self._seeds = [None] * self.num_envs
         self._options = [{} for _ in range(self.num_envs)]
@@ -71,12 +83,45 @@ class EV2GymSB3VecEnv(_SB3VecEnv):
         obs, _ = self.vec.reset()
         self._ep_return[:] = 0.0
         self.reset_infos = [{} for _ in range(self.num_envs)]
+        if self._fast:
+            return self._d_obs32.to_host().astype(self.obs_dtype, copy=False)
         return self._host(obs).astype(self.obs_dtype, copy=False)
 
     def step_async(self, actions) -> None:
-        self._actions = np.asarray(actions, np.float64)
+        self._actions = np.ascontiguousarray(actions, np.float32 if self._fast else np.float64)
+
+    def _step_wait_fast(self):
+        vec, eng = self.vec, self.vec.engine
+        if eng.current_step >= vec.simulation_length:
+            raise AssertionError("Episode is done, please reset the environment")   # ev2gym_env.py:343
+        assert self._actions.shape == (self.num_envs, vec.number_of_ports), self._actions.shape
+        self._d_act32.upload(self._actions)
+        eng.step(None, None, vec._rew, vec._done, vec._mask)     # float32 actions in, float32 observations out (the extras)
+        obs = self._d_obs32.to_host(self._h_obs)
+        rew = vec._rew.to_host(self._h_rew)
+        done = vec._done.to_host(self._h_done).astype(bool)
+        vec._mask.to_host(self._h_mask)
+        self._ep_return += rew
+        infos = self._infos
+        if eng.current_step >= vec.simulation_length:
+            eng.check_faults()
+            vec.stats = stats = vec.get_statistics()
+            T = vec.simulation_length
+            term, mask = obs.copy(), self._h_mask.copy()
+            infos = []
+            for i in range(self.num_envs):
+                d = {k: float(v[i]) for k, v in stats.items()}
+                d.update({"action_mask": mask[i], "terminal_observation": term[i], "TimeLimit.truncated": False,
+                          "episode": {"r": float(self._ep_return[i]), "l": T}})
+                infos.append(d)
+            vec.reset()
+            obs = self._d_obs32.to_host(self._h_obs)
+            self._ep_return[:] = 0.0
+        return obs.copy(), rew.astype(np.float32), done, infos
 
     def step_wait(self):
+        if self._fast:
+            return self._step_wait_fast()
         obs, rew, done, _trunc, info = self.vec.step(self._actions)
         rew = self._host(rew).astype(np.float64)
         done = self._host(done).astype(bool)

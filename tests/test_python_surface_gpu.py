@@ -128,22 +128,26 @@ def test_vec_env_rejects_unfused_plugins():
         EV2GymVec(config_file=os.path.join(CFG, "PublicPST.yaml"), num_envs=4, state_function=lambda env: None)
 
 
-@pytest.mark.parametrize("use_torch", [False, True], ids=["ctypes_buffers", "torch_tensors"])
-def test_sb3_vec_env_protocol_matches_oracle(use_torch):
-    """SB3 VecEnv protocol (step_async/step_wait, reset at episode end with terminal_observation, numpy out)."""
+@pytest.mark.parametrize("use_torch,obs_dtype", [(False, np.float64), (True, np.float64), (False, np.float32)],
+                         ids=["ctypes_buffers", "torch_tensors", "float32_fast_path"])
+def test_sb3_vec_env_protocol_matches_oracle(use_torch, obs_dtype):
+    """SB3 VecEnv protocol (step_async/step_wait, reset at episode end with terminal_observation, numpy out); with float32
+    observations and engine-owned buffers the adapter hands float32 over in both directions (its fast path)."""
     from ev2gym_amd import _abi
     from ev2gym_amd.sb3_vec_env import EV2GymSB3VecEnv
     from oracle.oracle import Oracle
     sf, rf = "V2G_profit_max_loads", "ProfitMax_TrPenalty_UserIncentives"
     venv = EV2GymSB3VecEnv(config_file=os.path.join(CFG, "V2GProfitPlusLoads.yaml"), num_envs=24, state_function=sf,
-                           reward_function=rf, seed=9, use_torch=use_torch, obs_dtype=np.float64)
+                           reward_function=rf, seed=9, use_torch=use_torch, obs_dtype=obs_dtype)
+    otol = 1e-9 if obs_dtype == np.float64 else 2e-7     # float32 observations: one rounding
+    assert venv._fast == (obs_dtype == np.float32)
     E, P, T = venv.num_envs, venv.vec.number_of_ports, venv.vec.simulation_length
     assert venv.observation_space.shape == (venv.vec.obs_dim,) and venv.action_space.shape == (P,)
     assert venv.env_is_wrapped(object) == [False] * E and venv.get_attr("simulation_length", 0) == [T]
     obs = venv.reset()
     ora = Oracle(_window(venv.vec), _abi.REWARD_KINDS[rf], _abi.STATE_KINDS[sf])
     assert isinstance(obs, np.ndarray) and obs.shape == (E, venv.vec.obs_dim)
-    _close(obs, ora.reset(), "reset obs")
+    _close(obs, ora.reset(), "reset obs", tol=otol)
     rng = np.random.default_rng(4)
     ret = np.zeros(E)
     for t in range(T + 3):            # runs across the episode boundary
@@ -160,16 +164,17 @@ def test_sb3_vec_env_protocol_matches_oracle(use_torch):
         assert all(np.array_equal(infos[i]["action_mask"], o_mask[i]) for i in range(E))
         if done.all():
             st = ora.stats()
-            _close(np.stack([i["terminal_observation"] for i in infos]), o_obs, "terminal obs")
+            _close(np.stack([i["terminal_observation"] for i in infos]), o_obs, "terminal obs", tol=otol)
             _close(np.array([i["total_profits"] for i in infos]), st[:, 1], "total_profits")
             _close(np.array([i["episode"]["r"] for i in infos]), ret, "episode return")
             assert all(i["episode"]["l"] == T and i["TimeLimit.truncated"] is False for i in infos)
             ora.close()   # the reset inside step_wait drew fresh scenarios from the pool
             ora = Oracle(_window(venv.vec), _abi.REWARD_KINDS[rf], _abi.STATE_KINDS[sf])
-            _close(obs, ora.reset(), "obs after reset inside step_wait")
+            _close(obs, ora.reset(), "obs after reset inside step_wait", tol=otol)
         else:
             assert "terminal_observation" not in infos[0]
-            _close(obs, o_obs, f"obs[{t}]")
+            _close(obs, o_obs, f"obs[{t}]", tol=otol)
+            assert obs.dtype == obs_dtype
     venv.close()
 
 
