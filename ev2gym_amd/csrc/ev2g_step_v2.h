@@ -757,8 +757,12 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                     if (hdst1_l >= 0) EV2G_OBS_PUT(hdst1_l, (hsrc1_l < 20) ? ((sstep + hsrc1_l < T) ? fabs(pf_ob1) : 0.0) : pf_ob1)
                     // envs with more head columns than two passes of their lanes (many transformers): the rest, unprefetched
                     for (int c = pl_l + 2 * lpe; c < nhead; c += lpe) {
-                        const int i = c - 20, r = i / 40, j = i - r * 40;
-                        EV2G_OBS_PUT(trobs[r] + j, S->win_tab[(((long long)pec * R + r) * (T + 1) + sstep) * 40 + j])
+                        if (c < 20) {   // (more than 25 envs per workgroup: fewer than ten lanes per env, price columns are left too)
+                            EV2G_OBS_PUT(2 + c, (sstep + c < T) ? fabs(S->price_ch[pec * T + min(sstep + c, T - 1)]) : 0.0)
+                        } else {
+                            const int i = c - 20, r = i / 40, j = i - r * 40;
+                            EV2G_OBS_PUT(trobs[r] + j, S->win_tab[(((long long)pec * R + r) * (T + 1) + sstep) * 40 + j])
+                        }
                     }
                 }
 #undef EV2G_OBS_PUT
