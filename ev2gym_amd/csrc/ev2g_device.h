@@ -948,8 +948,11 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
     served = wave_sum(served); sat = wave_sum(sat); nsat = wave_sum(nsat);
     double over = 0.0, te = 0.0, ete = 0.0, ptv = 0.0;
     for (int t = lane; t < T; t += 64) {
-        for (int r = 0; r < R; r++) over += st.over_hist[((long long)t * s.E + e) * R + r];
-        const double sp = s.setpoint[(long long)scn * T + t], u = st.usage_hist[(long long)t * s.E + e];
+        // steps the running episode has not reached count as zeros (the reference's arrays are zero-initialised at reset); the
+        // history slab may still hold the previous episode's values there after an in-kernel reset of a fused run
+        const bool past = t < cur_step;
+        if (past) for (int r = 0; r < R; r++) over += st.over_hist[((long long)t * s.E + e) * R + r];
+        const double sp = s.setpoint[(long long)scn * T + t], u = past ? st.usage_hist[(long long)t * s.E + e] : 0.0;
         const double d = sp - u;
         te += d * d;
         ete += fabs(d);

@@ -813,6 +813,33 @@ int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, in
     if (mode == EV2G_STEPN_PERSISTENT) {
         int k = k_steps;
         if (!auto_reset) k = std::min(k, h->T - h->current_step);
+        // Per-session results (sess_final_cap, sess_abs_e) are indexed by pool session.  Two envs that run the same scenario inside
+        // ONE launch store to the same slots from different XCDs, whose L2s are written back at the kernel boundary in no defined
+        // order, so a launch covers several AUTO_RESET_NEXT episodes only while their windows are disjoint: (resets + 1) * E <= M.
+        // Otherwise the run is cut at the episode ends (one launch per episode, host-side reset in between).
+        int resets = 0;
+        { int t = h->current_step; for (int i = 0; i < k; i++) { if (t >= h->T) { t = 0; resets++; } t++; } }
+        if (adv != 0 && resets > 0 && (long long)(resets + 1) * h->E > h->M) {
+            for (int i0 = 0; i0 < k;) {
+                if (h->current_step >= h->T) {
+                    int r2 = ev2g_reset_ex(h, nullptr, h->scn_off + adv);
+                    if (r2) return r2;
+                }
+                const int kc = std::min(k - i0, h->T - h->current_step);
+                const StepIO io = make_io(h, actions ? actions + (long long)i0 * a_stride : nullptr, a_stride,
+                                          obs ? obs + (long long)i0 * o_stride : nullptr, o_stride,
+                                          reward ? reward + (long long)i0 * r_stride : nullptr, r_stride,
+                                          done ? done + (long long)i0 * d_stride : nullptr, d_stride,
+                                          mask ? mask + (long long)i0 * m_stride : nullptr, m_stride, i0, 0);
+                int r2 = launch_steps(h, io, h->current_step, kc, 0);
+                if (r2) return r2;
+                h->current_step += kc;
+                i0 += kc;
+            }
+            HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+            h->timed = true;
+            return rc;
+        }
         const StepIO io = make_io(h, actions, a_stride, obs, o_stride, reward, r_stride, done, d_stride, mask, m_stride, 0, auto_reset);
         if (k > 0) rc = launch_steps(h, io, h->current_step, k, auto_reset);
         if (rc) return rc;
@@ -1183,6 +1210,10 @@ int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *v) {
         if (v->cs_energy_charged) v->cs_energy_charged[c] = log_cs ? csv[3 * C + c] : nan;
         if (v->cs_energy_discharged) v->cs_energy_discharged[c] = log_cs ? csv[4 * C + c] : nan;
     }
+    // entries the running episode has not written yet read as zeros (after an in-kernel reset of a fused run the slab still holds the
+    // previous episode's values there); charge_power_potential is written one step ahead (utils.py:760-791)
+    for (int k = t; k < T; k++) { usage[k] = 0.0; for (int r = 0; r < R; r++) over[(size_t)k * R + r] = 0.0; }
+    for (int k = t + 1; k < T; k++) pot[k] = 0.0;
     if (v->tr_power) std::copy(trp.begin(), trp.end(), v->tr_power);
     if (v->tr_overload)
         for (int r = 0; r < R; r++)

@@ -106,3 +106,73 @@ def test_random_configuration_matches_oracle(case):
         eng.check_faults()
     eng.close()
     ora.close()
+
+
+@pytest.mark.parametrize("case", range(40))
+def test_random_fused_runs_across_episode_ends(case):
+    """ev2g_step_n across one or two episode ends with in-run resets (SAME scenarios / NEXT window of the pool), persistent or
+    step by step, float64 or float32 actions, every kernel the drawn shape routes to -- against oracle episodes on the windows the
+    engine reports."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine, host_uniform
+    from ev2gym_amd.scenario_gen import generate
+    from oracle.oracle import Oracle
+    rng, cfg = _draw(500 + case)
+    cfg.n_envs = int(rng.integers(6, 30))
+    if rng.random() < 0.15:     # a big env now and then: the 512 / 1024-thread general kernel and the generic one
+        cfg.topology = None
+        cfg.number_of_charging_stations, cfg.number_of_ports_per_cs, cfg.n_envs = int(rng.choice([300, 700, 1100])), 1, int(rng.integers(3, 6))
+        cfg.number_of_transformers = int(rng.choice([1, 7, 50]))
+    pool = generate(cfg)
+    M = pool.n_envs
+    E = int(rng.integers(max(1, M // 3), M + 1))
+    rk, sk = int(rng.integers(0, 11)), int(rng.integers(0, 3))
+    eng = Engine(pool, rk, sk, device=0, flags=4, n_active_envs=E)
+    P, D, T = eng.P, eng.D, eng.T
+    mode = _abi.AUTO_RESET_NEXT if rng.random() < 0.6 else _abi.AUTO_RESET_SAME
+    persistent = bool(rng.random() < 0.6)
+    f32 = bool(rng.random() < 0.4)
+    K = T + int(rng.integers(1, T + 6))
+    lo = -1.0 if cfg.v2g_enabled else 0.0
+    acts = host_uniform(K * E * P, 700 + case, lo, 1.0).reshape(K, E, P)
+    if f32:
+        acts = acts.astype(np.float32).astype(np.float64)
+        d_act32 = eng.empty((K, E, P), np.float32).upload(acts.astype(np.float32))
+        eng.set_extras(actions_f32=d_act32)
+    d_act = None if f32 else eng.empty((K, E, P)).upload(acts)
+    d_obs, d_rew, d_done, d_mask = eng.empty((K, E, D)), eng.empty((K, E)), eng.empty((K, E), np.uint8), eng.empty((K, E, P), np.uint8)
+    off0 = int(rng.integers(0, M))
+    eng.reset(offset=off0)
+    eng.step_n(K, d_act, E * P, d_obs, E * D, d_rew, E, d_done, E, d_mask, E * P, auto_reset=mode, persistent=persistent)
+    obs, rew, done, mask = d_obs.to_host(), d_rew.to_host(), d_done.to_host(), d_mask.to_host()
+    tag = f"case {case} {eng.kernel_name} rk={rk} sk={sk} P={P} R={eng.R} mode={mode} persistent={persistent} f32={f32}"
+    adv = (E % M) if mode == _abi.AUTO_RESET_NEXT else 0
+    n_ep = (K - 1) // T
+    assert eng.scenario_offset == (off0 + n_ep * adv) % M and eng.current_step == K - n_ep * T, tag
+    k = 0
+    for ep in range(n_ep + 1):
+        ora = Oracle(pool.select((np.arange(E) + off0 + ep * adv) % M), rk, sk)
+        ora.reset()
+        for t in range(min(T, K - k)):
+            o, r, d, m, rc = ora.step(acts[k].copy())
+            assert np.array_equal(mask[k], m), f"{tag}: mask[{k}]"
+            _close(obs[k], o, f"{tag}: obs[{k}]")
+            _close(rew[k], r, f"{tag}: reward[{k}]")
+            assert np.array_equal(done[k], d), f"{tag}: done[{k}]"
+            k += 1
+        if ep == n_ep:   # the running episode: per-env state through the inspection API
+            for e in (0, E - 1):
+                pk, po = eng.peek(e), ora.peek(e)
+                _close(pk["port_capacity"], po["cap"], f"{tag}: capacity")
+                assert (pk["port_session"] == po["session"]).all(), tag
+            se, so = eng.stats(), ora.stats()
+            worst = {}
+            for i, name in enumerate(_abi.STAT_NAMES):
+                x, y = se[:, i], so[:, i]
+                err = np.nan_to_num(np.abs(x - y) / np.maximum(1.0, np.abs(np.nan_to_num(y))))
+                if err.max() > 1e-9 or (np.isnan(x) != np.isnan(y)).any():
+                    j = int(err.argmax())
+                    worst[name] = (float(x[j]), float(y[j]), j)
+            assert not worst, f"{tag}: statistics of the running episode (step {eng.current_step}): {worst}"
+        ora.close()
+    eng.close()
