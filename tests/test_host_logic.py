@@ -186,6 +186,32 @@ def test_generated_power_setpoints_resemble_the_reference_ones():
     assert abs(np.mean(level) - ref["setpoint_mean_kw"]) <= 0.15 * ref["setpoint_mean_kw"]
 
 
+@pytest.mark.parametrize("yaml_file,T,P,R", [("PublicPST.yaml", 112, 20, 1), ("simplePST.yaml", 96, 2, 1), ("V2GProfitMax.yaml", 112, 25, 1),
+                                             ("V2GProfitPlusLoads.yaml", 112, 25, 1), ("V2GProfitPlusLoads_50cs.yaml", 112, 50, 1),
+                                             ("V2GProfitPlusLoads_1000cs_50tr.yaml", 112, 1000, 50)])
+def test_every_shipped_config_generates_a_batch(yaml_file, T, P, R):
+    """The example configs mirror the reference's example_config_files (PublicPST / simplePST / V2GProfitMax / V2GProfitPlusLoads) plus the
+    two BASELINE shapes: each must load, generate and finalise, with the features its switches select."""
+    import warnings
+    from ev2gym_amd.config import gen_config_from_yaml, load_yaml
+    from ev2gym_amd.scenario_gen import generate
+    cfg = load_yaml(os.path.join(CFG, yaml_file))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")   # simplePST pins a calendar day (random_day: False): the generator says its curves are synthetic
+        b = generate(gen_config_from_yaml(cfg, 6, 2))
+    a = b.arrays
+    assert (b.n_envs, b.n_steps, b.n_ports, b.n_transformers) == (6, T, P, R)
+    assert (a["ev_t_arr"] < a["ev_t_dep"]).all() and a["ev_t_arr"].min() >= 0
+    loads = bool(cfg["inflexible_loads"]["include"]); pv = bool(cfg["solar_power"]["include"])
+    assert bool(np.abs(a["tr_inflexible_load"]).sum() > 0) == loads
+    assert bool(np.abs(a["tr_solar_power"]).sum() > 0) == pv
+    assert bool(a["power_setpoints"].any()) == bool(cfg["power_setpoint_enabled"])
+    if not cfg["heterogeneous_ev_specs"]:
+        assert len(np.unique(a["ev_B"])) == 1   # one EV model (ev2gym_env.py:  ev_specs are only read when heterogeneous)
+    if not cfg["v2g_enabled"]:
+        assert not b.v2g_enabled
+
+
 # ---- topology files and the rest of the YAML schema (ADVICE: no key is dropped silently) -----------------------------------
 def _write_topology(path, spec):
     """spec = [(transformer max_power, [n_ports of its chargers])], in the layout of example_config_files/charging_topology_10.json."""
