@@ -26,11 +26,12 @@
 // One EV session, 128 bytes = one cache line: everything the per-step battery maths needs (ev.py:68-113).
 struct __attribute__((aligned(128))) SessRec {
     // the first 96 bytes are what the battery maths reads every step (the fast path fetches only those six 16-byte chunks) ...
-    double B, minB, emerg, pacmax, pdismax, ts, tsm, eta_ch, eta_dis;
+    double minB, emerg, pdismax, ts, tsm, eta_ch, eta_dis;
     double gate_ch;   // min_ac_charge_power*1000/(voltage*sqrt(charger phases))   (ev.py:151)
     double gate_dis;  // min_discharge_power*1000/(voltage*sqrt(charger phases))   (ev.py:153)
+    // ... an arrival reads the LAST four chunks (B .. lut), a departure the last two: the fast path prefetches them as such
+    double B, pacmax;
     double v;         // voltage*sqrt(min(charger phases, ev_phases))              (ev.py:169,279,365)
-    // ... the rest is read on arrival / departure only
     double cap0, des;    // battery_capacity_at_arrival, desired_capacity
     int nt_arr, nt_dep;  // window of the next session on the same port (EV2G_INT_MAX = none)
     int lut, pad;        // efficiency table id or -1
@@ -55,6 +56,7 @@ struct DevScn {  // read-only scenario + layout, device pointers
     int het;
     // chargers [C]
     const double *cs_imin, *cs_imax, *cs_dmin, *cs_dmax_abs, *cs_volt, *cs_maxp, *cs_minp;
+    const double *cs_pack;   // [C][6]: imax, |dmax|, imin, dmin, max power, min power (ev2g_step_wave prologue: 3 loads instead of 6)
     const double *cs_vk;  // [C,4] voltage*sqrt(k), k = 0..3
     const int *cs_ph;
     // transformers: slot segments [R+1], obs column of the 40-wide window block [R]

@@ -525,6 +525,15 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     UP(dp, cs_maxp) s.cs_maxp = dp;
     UP(dp, cs_minp) s.cs_minp = dp;
     UP(dp, cs_vk) s.cs_vk = dp;
+    {   // the six per-charger operands of the fast path side by side: (imax, |dmax|), (imin, dmin), (max power, min power)
+        std::vector<double> cs_pack((size_t)C * 6);
+        for (int c = 0; c < C; c++) {
+            double *r = &cs_pack[(size_t)c * 6];
+            r[0] = b->cs_max_charge_current[c]; r[1] = cs_dmax_abs[c]; r[2] = b->cs_min_charge_current[c];
+            r[3] = b->cs_min_discharge_current[c]; r[4] = cs_maxp[c]; r[5] = cs_minp[c];
+        }
+        UP(dp, cs_pack) s.cs_pack = dp;
+    }
     UPP(ip, b->cs_phases, C) s.cs_ph = ip;
     UP(ip, tr_seg) s.tr_seg = ip;
     UP(ip, tr_obs) s.tr_obs = ip;
@@ -742,7 +751,7 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         const V2P *pp = (const V2P *)h->d_v2p;
         const DevState &st = h->st;
         const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
-                          st.env_acc, s.cs_imax, s.cs_dmax_abs, s.cs_imin, s.cs_dmin, s.cs_maxp, s.cs_minp};
+                          st.env_acc, s.cs_pack};
 #define EV2G_WAVE_CASE(SK, RK)                                                                                              \
     case SK * 4 + RK:                                                                                                       \
         if (!io.actions)                                                                                                    \

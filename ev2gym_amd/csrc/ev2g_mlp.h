@@ -214,6 +214,43 @@ __device__ __forceinline__ void ev2g_mlp_stage_input(const MlpDev &m, const floa
     for (int i = threadIdx.x; i < (EV2G_MLP_ROWS - nr) * m.d_in; i += EV2G_MLP_BLOCK) { const int r = nr + i / m.d_in; bufA[r * sA + (i - (r - nr) * m.d_in)] = 0; }
 }
 
+// The same in two halves for the fixed-shape kernel (one pass: 32 rows x d_in <= EV2G_MLP_NL x 256 lanes x 4 floats, checked by the
+// host when it picks that kernel): request the rows, ... , convert and scatter them.
+#define EV2G_MLP_NL 6
+__device__ __forceinline__ void ev2g_mlp_input_request(const MlpDev &m, const float *__restrict__ x, int row0, int n_rows, float4 (&v)[EV2G_MLP_NL]) {
+    const int nr = min(EV2G_MLP_ROWS, n_rows - row0), total = nr * m.d_in;
+    const float *xs = x + (size_t)row0 * m.d_in;
+    const bool vec = (((size_t)xs) & 15) == 0;
+#pragma unroll
+    for (int it = 0; it < EV2G_MLP_NL; it++) {
+        const int f = (it * EV2G_MLP_BLOCK + (int)threadIdx.x) * 4;
+        if (vec && f + 3 < total) v[it] = *(const float4 *)(xs + f);
+        else {
+            v[it].x = f < total ? xs[f] : 0.f; v[it].y = f + 1 < total ? xs[f + 1] : 0.f;
+            v[it].z = f + 2 < total ? xs[f + 2] : 0.f; v[it].w = f + 3 < total ? xs[f + 3] : 0.f;
+        }
+    }
+}
+__device__ __forceinline__ void ev2g_mlp_input_store(const MlpDev &m, int row0, int n_rows, const float4 (&v)[EV2G_MLP_NL], uint16_t *bufA, int sA) {
+    const int nr = min(EV2G_MLP_ROWS, n_rows - row0), total = nr * m.d_in;
+    const float rdin = 1.0f / (float)m.d_in;
+#pragma unroll
+    for (int it = 0; it < EV2G_MLP_NL; it++) {
+        const int f = (it * EV2G_MLP_BLOCK + (int)threadIdx.x) * 4;
+        const float e[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+        int r = (int)((float)f * rdin), c = f - r * m.d_in;
+        if (c < 0) { r--; c += m.d_in; } else if (c >= m.d_in) { r++; c -= m.d_in; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (f + j < total) bufA[r * sA + c] = ev2g_f32_to_bf16(e[j]);
+            if (++c == m.d_in) { c = 0; r++; }
+        }
+    }
+    const int padc = m.k1 - m.d_in;
+    for (int i = threadIdx.x; i < EV2G_MLP_ROWS * padc; i += EV2G_MLP_BLOCK) { const int r = i / padc; bufA[r * sA + m.d_in + (i - r * padc)] = 0; }
+    for (int i = threadIdx.x; i < (EV2G_MLP_ROWS - nr) * m.d_in; i += EV2G_MLP_BLOCK) { const int r = nr + i / m.d_in; bufA[r * sA + (i - (r - nr) * m.d_in)] = 0; }
+}
+
 // LDS: bufA [32][sA] bf16 (input, then layer-2 output) | bufB [32][sB] bf16 (layer-1 output) | biases (fixed-shape kernel)
 template <int KS1, int KS2, int KS3>
 __global__ void __launch_bounds__(EV2G_MLP_BLOCK) ev2g_mlp3_fixed(MlpDev m, const float *__restrict__ x, float *__restrict__ y, int n_rows) {
@@ -225,11 +262,25 @@ __global__ void __launch_bounds__(EV2G_MLP_BLOCK) ev2g_mlp3_fixed(MlpDev m, cons
     MLP_STAMP(0)
     // register budget per lane (512): F1 4 x KS1 x 4 | F2 2 x KS2 x 4 requested while layer 1 runs | F3 KS3 x 4 while layer 2 runs
     MlpFrags<KS1, 4> F1;
-    F1.first(m.w1, m.n1);   // ALL of this wavefront's layer-1 weight tiles travel together with the input rows and the biases
-    for (int i = threadIdx.x; i < m.n1 + m.n2 + m.n3; i += EV2G_MLP_BLOCK) lb1[i] = i < m.n1 ? m.b1[i] : (i < m.n1 + m.n2 ? m.b2[i - m.n1] : m.b3[i - m.n1 - m.n2]);
-    ev2g_mlp_stage_input(m, x, row0, n_rows, bufA, sA);
-    MLP_STAMP(1)
     MlpFrags<KS2, 2> F2;
+    // vmcnt retires in order: the input rows and the biases are requested FIRST, so that their conversion into LDS overlaps the arrival
+    // of the weight fragments instead of waiting behind all of them
+    float4 xin[EV2G_MLP_NL];
+    ev2g_mlp_input_request(m, x, row0, n_rows, xin);
+    float bv[4];   // n1 + n2 + n3 <= 416 + 320 + 128 <= 4 x 256 for the fixed shapes
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = (int)threadIdx.x + j * EV2G_MLP_BLOCK;
+        bv[j] = i < m.n1 ? m.b1[i] : (i < m.n1 + m.n2 ? m.b2[i - m.n1] : (i < m.n1 + m.n2 + m.n3 ? m.b3[i - m.n1 - m.n2] : 0.f));
+    }
+    F1.first(m.w1, m.n1);   // ALL of this wavefront's layer-1 weight tiles
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = (int)threadIdx.x + j * EV2G_MLP_BLOCK;
+        if (i < m.n1 + m.n2 + m.n3) lb1[i] = bv[j];
+    }
+    ev2g_mlp_input_store(m, row0, n_rows, xin, bufA, sA);
+    MLP_STAMP(1)
     F2.first(m.w2, m.n2);   // layer 2's first two tiles: in flight while layer 1 computes
     __syncthreads();
     MLP_STAMP(2)

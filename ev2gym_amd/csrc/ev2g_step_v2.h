@@ -465,6 +465,20 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        // Departures and arrivals are known before the step (occupancy does not depend on the actions): the session-record fields
+        // phase C needs are requested here, behind this wavefront's battery maths (the register file has no room to hold them across it) and before the
+        // barrier -- wavefronts without items overlap them with the others' maths -- instead of dependently inside that phase's branches.
+        // A lane has at most one of the two events: {B | des}, {cap0 | next window}, pacmax, v -- four 8-byte loads, issued only by
+        // wavefront-steps that have such an event; the other lanes of such a wavefront read record 0.
+        double pf_ra = 0.0, pf_rb = 0.0, pf_rc = 0.0, pf_rd = 0.0;
+        const bool ev_dep = occ && t >= s_td[valid ? tid_l : 0], ev_arr = valid && (s_ta[tid_l] == sstep);   // (the battery maths does not touch the windows)
+        if (__ballot(ev_dep || ev_arr) != 0ull) {   // (uniform)
+            const char *rp = (const char *)((const SessRec *)S->rec + ((ev_dep || ev_arr) ? s_ss[tid_l] : 0));
+            pf_ra = *(const double *)(rp + (ev_arr ? offsetof(SessRec, B) : offsetof(SessRec, des)));
+            pf_rb = *(const double *)(rp + (ev_arr ? offsetof(SessRec, cap0) : offsetof(SessRec, nt_arr)));   // (the window: two ints)
+            pf_rc = *(const double *)(rp + offsetof(SessRec, pacmax));
+            pf_rd = *(const double *)(rp + offsetof(SessRec, v));
+        }
         PT_MARK(2)
         lds_barrier();
         PT_MARK(1)
@@ -480,6 +494,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             double profit = 0.0, satpen = 0.0, pot = 0.0;
             int ta = s_ta[tid_l], td = s_td[tid_l];
             double cap = s_cap[tid_l];
+            bool departed = false;
             if (occ) {
                 const double energy = s_amps[tid_l];  // 0 for idle EVs (phase A stored amps == 0)
                 const double current = stage[7 * NS + tid_l];
@@ -495,8 +510,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                     S->soc_log[((long long)e_l * T + t) * P + (g_l - e_l * P)] = (current != 0.0) ? cap_before : -cap_before;
                 if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
                     const int ss = s_ss[tid_l];
-                    const SessRec &r = *(const SessRec *)(S->rec + ss);
-                    const double des = r.des;
+                    const double des = pf_ra;
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
                     satpen = ev2g_departure_term(S->reward_kind, S->cost_kind, score, cap, des);
                     const int gc = e_l * C + cs_l;
@@ -505,7 +519,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                     __hip_atomic_fetch_add(&S->cs_sat_sum[gc], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     S->sess_final_cap[ss] = cap;
                     if (log_soc) S->sess_abs_e[ss] = s_abse[tid_l];
-                    ta = r.nt_arr; td = r.nt_dep;
+                    ta = __double2loint(pf_rb); td = __double2hiint(pf_rb);   // window of the port's next session
+                    departed = true;
                     s_ta[tid_l] = ta; s_td[tid_l] = td;
                     s_ss[tid_l] = (ta != EV2G_INT_MAX) ? ss + 1 : -1;
                     s_cyc[tid_l] = 0;
@@ -513,10 +528,14 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 }
             }
             if (ta == sstep) {  // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
-                const SessRec &r = *(const SessRec *)(S->rec + s_ss[tid_l]);
-                cap = r.cap0;
-                const double B = r.B, v = r.v;
-                const double evc = r.pacmax * 1000.0 / v;            // utils.py:773-777
+                if (departed) {   // the next session arrives right behind a departure of this very step (the reference's spawner leaves a
+                                  // gap, replayed scenarios need not): its record was not the one prefetched
+                    const SessRec &r = *(const SessRec *)(S->rec + s_ss[tid_l]);
+                    pf_ra = r.B; pf_rb = r.cap0; pf_rc = r.pacmax; pf_rd = r.v;
+                }
+                cap = pf_rb;
+                const double B = pf_ra, v = pf_rd;
+                const double evc = pf_rc * 1000.0 / v;            // utils.py:773-777
                 const double potc = v * ((evc < c_imax) ? evc : c_imax) / 1000.0;
                 s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
                 s_abse[tid_l] = 0.0;

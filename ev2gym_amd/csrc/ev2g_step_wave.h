@@ -42,6 +42,7 @@ template <class T, class B> __device__ __forceinline__ void stg32(B base, unsign
 }
 typedef double d2v __attribute__((ext_vector_type(2)));   // builtin vectors: loadable from any address space
 typedef int i2v __attribute__((ext_vector_type(2)));
+typedef int i4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 // The battery-maths part of the record (its first 96 bytes) in one memory round trip: 6 x 16-byte loads issued back to back, then pinned by an empty asm so
 // that the compiler cannot sink the ones a later branch does not need behind that branch (it otherwise loads the
@@ -64,7 +65,7 @@ struct WaveArgs {
     char *slab_port; unsigned long long slab_port_slice;
     double *slab_hist; unsigned long long hist_slice;
     double *env_acc;
-    const double *cs_imax, *cs_dmax_abs, *cs_imin, *cs_dmin, *cs_maxp, *cs_minp;
+    const double *cs_pack;   // [C][6] imax, |dmax|, imin, dmin, max power, min power
 };
 
 // IO32: the actions are float32 (StepIO::act32) -- the policy-network interface; float32 observations (StepIO::obs32) are
@@ -135,9 +136,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const unsigned ec = (unsigned)(valid ? e : e0);
         i2v w = ldg32<i2v>(PA(EV2G_PS_WIN), g8), sc = ldg32<i2v>(PA(EV2G_PS_SC), g8);
         int lut0 = ldg32<int>(PA(EV2G_PS_LUT), g8 >> 1);
-        c_imax = ldg32<double>(wa.cs_imax, c8); c_dmaxabs = ldg32<double>(wa.cs_dmax_abs, c8);
-        double k_imin = ldg32<double>(wa.cs_imin, cp8), k_dmin = ldg32<double>(wa.cs_dmin, cp8);
-        double k_maxp = ldg32<double>(wa.cs_maxp, cp8), k_minp = ldg32<double>(wa.cs_minp, cp8);
+        const d2v k_max = ldg32<d2v>(wa.cs_pack, c8 * 6u);   // (imax, |dmax|) of this lane's charger
+        d2v k_min = {0.0, 0.0}, k_pow = {0.0, 0.0};            // gates and clamps, staged in LDS by the first P lanes of the workgroup
+        if (tid < 64) { k_min = ldg32<d2v>(wa.cs_pack, cp8 * 6u + 16u); k_pow = ldg32<d2v>(wa.cs_pack, cp8 * 6u + 32u); }   // (wavefront 0 only)
         a_next = IO32 ? (double)ldg32<float>(S->x_act32 + (long long)io.step0 * io.a_stride, (unsigned)(valid ? g : e0 * P) * 4u)
                       : ldg32<double>(io.actions, (unsigned)(valid ? g : e0 * P) * 8u);
         double l_pot = ldg32<double>(slabH + HS8, ((unsigned)min(t, T - 1) * (unsigned)E + ec) * 8u);
@@ -145,11 +146,13 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         if (RK == 3) l_pot2 = ldg32<double>(slabH + HS8, ((unsigned)min(max(t - 1, 0), T - 1) * (unsigned)E + ec) * 8u);
         d2v acc01 = ldg32<d2v>(env_acc, ec * 64u), acc23 = ldg32<d2v>(env_acc, ec * 64u + 16u);
         double acc4 = ldg32<double>(env_acc, ec * 64u + 32u);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w), "+v"(sc), "+v"(lut0), "+v"(c_imax), "+v"(c_dmaxabs), "+v"(k_imin), "+v"(k_dmin),
-                     "+v"(k_maxp), "+v"(k_minp), "+v"(a_next), "+v"(l_pot), "+v"(l_pot2), "+v"(acc01), "+v"(acc23), "+v"(acc4));
+        d2v k_max_w = k_max;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w), "+v"(sc), "+v"(lut0), "+v"(k_max_w), "+v"(k_min), "+v"(k_pow),
+                     "+v"(a_next), "+v"(l_pot), "+v"(l_pot2), "+v"(acc01), "+v"(acc23), "+v"(acc4));
+        c_imax = k_max_w.x; c_dmaxabs = k_max_w.y;
         if (tid < P) {
-            s_cst[0 * 64 + tid] = k_imin - 0.01; s_cst[1 * 64 + tid] = k_dmin;
-            s_cst[2 * 64 + tid] = k_maxp; s_cst[3 * 64 + tid] = k_minp;
+            s_cst[0 * 64 + tid] = k_min.x - 0.01; s_cst[1 * 64 + tid] = k_min.y;
+            s_cst[2 * 64 + tid] = k_pow.x; s_cst[3 * 64 + tid] = k_pow.y;
         }
         if (valid) {
             s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = sc.x; s_cyc[tid] = sc.y;
@@ -223,8 +226,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // ---------------- A: home lanes, charger level (ev_charger.py:137-186) ----------------
         bool occ = false;
         double cap_before = 0.0;
+        int ta_a = EV2G_INT_MAX, td_a = -1;   // this port's window as phase A saw it (idle lanes: no event)
         if (valid) {
             const int ta = s_ta[tid_l], td = s_td[tid_l];
+            ta_a = ta; td_a = td;
             occ = (ta <= t) && (t <= td);
             if (log_soc && occ) cap_before = s_cap[tid_l];
             double a = occ ? a_next : 0.0;
@@ -277,6 +282,20 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
             pf_h0 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l, NPAIR - 1) * 16u);
             if (P < NPAIR) pf_h1 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l + P, NPAIR - 1) * 16u);   // (uniform)
+        }
+        // Departures and arrivals are known before the step (occupancy does not depend on the actions): the fields phase C needs
+        // from the session record -- its last four 16-byte chunks -- travel with the other prefetches instead of being fetched,
+        // dependently, inside that phase's branches.  Only wavefront-steps that have such an event issue them (about half at cfg2);
+        // the other lanes of such a wavefront read record 0.
+        const bool ev_dep = occ && t >= td_a, ev_arr = (ta_a == sstep);
+        d2v pf_r4 = {0.0, 0.0}, pf_r5 = {0.0, 0.0}, pf_r6 = {0.0, 0.0};
+        i4v pf_r7 = {0, 0, 0, 0};
+        if (__ballot(ev_dep || ev_arr) != 0ull) {   // (uniform)
+            const unsigned r8 = (ev_dep || ev_arr) ? (unsigned)s_ss[tid_l] * (unsigned)sizeof(SessRec) : 0u;
+            static_assert(offsetof(SessRec, B) == 72 && offsetof(SessRec, pacmax) == 80 && offsetof(SessRec, v) == 88 && offsetof(SessRec, cap0) == 96 &&
+                          offsetof(SessRec, des) == 104 && offsetof(SessRec, nt_arr) == 112 && offsetof(SessRec, lut) == 120, "SessRec tail layout");
+            pf_r4 = ldg32<d2v>(S->rec, r8 + 64u); pf_r5 = ldg32<d2v>(S->rec, r8 + 80u);
+            pf_r6 = ldg32<d2v>(S->rec, r8 + 96u); pf_r7 = ldg32<i4v>(S->rec, r8 + 112u);
         }
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
         PT_MARK(0)
@@ -336,11 +355,13 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // prefetched registers are plain values from here on, so their later uses -- after this phase's stores, and
         // across the loop back-edge for the next action -- no longer cost a conservative vmcnt(0) drain
         asm volatile("" : "+v"(a_next), "+v"(pf_pch), "+v"(pf_pdis), "+v"(pf_tr), "+v"(pf_ob0), "+v"(pf_h0), "+v"(pf_h1));
+        asm volatile("" : "+v"(pf_r4), "+v"(pf_r5), "+v"(pf_r6), "+v"(pf_r7));
         bool occ_any = false;   // an EV on this port before or after the step
         if (valid) {
             double profit = 0.0, satpen = 0.0, pot = 0.0;
             int ta = s_ta[tid_l], td = s_td[tid_l];
             double cap = s_cap[tid_l];
+            bool departed = false;
             if (occ) {
                 const double energy = s_amps[tid_l];
                 const double current = stage[7 * RS + tid_l];
@@ -358,8 +379,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 if (log_soc) stg32<double>(S->soc_log + (long long)t * P, g8 + (unsigned)e_l * (unsigned)((T - 1) * P * 8), (current != 0.0) ? cap_before : -cap_before);
                 if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
                     const int ss = s_ss[tid_l];
-                    const unsigned r8 = (unsigned)ss * (unsigned)sizeof(SessRec);
-                    const double des = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, des));
+                    const double des = pf_r6.y;
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
                     if (RK == 3) satpen = ev2g_departure_term(S->reward_kind, S->cost_kind, score, cap, des);
                     else if (RK != 1 || S->cost_kind == 1) satpen = 100.0 * exp(-10.0 * score);
@@ -371,8 +391,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     stg32<double>(slabS, (unsigned)ss * 8u, cap);
                     if (log_soc) stg32<double>((slabS + SS8), (unsigned)ss * 8u, s_abse[tid_l]);
-                    const i2v nx = ldg32<i2v>(S->rec, r8 + (unsigned)offsetof(SessRec, nt_arr));
-                    ta = nx.x; td = nx.y;
+                    ta = pf_r7.x; td = pf_r7.y;   // window of the port's next session
+                    departed = true;
                     s_ta[tid_l] = ta; s_td[tid_l] = td;
                     s_ss[tid_l] = (ta != EV2G_INT_MAX) ? ss + 1 : -1;
                     s_cyc[tid_l] = 0;
@@ -380,15 +400,20 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 }
             }
             if (ta == sstep) {  // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
-                const unsigned r8 = (unsigned)s_ss[tid_l] * (unsigned)sizeof(SessRec);
-                cap = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, cap0));
-                const double B = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, B));
-                const double v = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, v));
-                const double evc = ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, pacmax)) * 1000.0 / v;            // utils.py:773-777
+                if (departed) {   // the next session arrives right behind a departure of this very step (the reference's spawner leaves a
+                                  // gap, replayed scenarios need not): its record was not the one prefetched
+                    const unsigned r8 = (unsigned)s_ss[tid_l] * (unsigned)sizeof(SessRec);
+                    pf_r4 = ldg32<d2v>(S->rec, r8 + 64u); pf_r5 = ldg32<d2v>(S->rec, r8 + 80u);
+                    pf_r6 = ldg32<d2v>(S->rec, r8 + 96u); pf_r7 = ldg32<i4v>(S->rec, r8 + 112u);
+                }
+                cap = pf_r6.x;
+                const double B = pf_r4.y;
+                const double v = pf_r5.y;
+                const double evc = pf_r5.x * 1000.0 / v;            // utils.py:773-777
                 const double potc = v * ((evc < c_imax) ? evc : c_imax) / 1000.0;
                 s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
                 s_abse[tid_l] = 0.0;
-                const int lut_new = ldg32<int>(S->rec, r8 + (unsigned)offsetof(SessRec, lut));
+                const int lut_new = pf_r7.z;
                 stg32<int>(PA(EV2G_PS_LUT), g8 >> 1, lut_new);
                 stg32<double>(PA(EV2G_PS_BCAP), g8, B);
                 stg32<double>(PA(EV2G_PS_POTC), g8, potc);

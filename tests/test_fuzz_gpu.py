@@ -44,6 +44,21 @@ def _draw(case):
     return rng, GenConfig(**kw)
 
 
+def _back_to_back(pool):
+    """Extends every stay up to the step before the same port's next arrival: the next EV plugs in at the end of the very step
+    its predecessor leaves in (ev2gym_env.py:363-417 -- departures precede the spawns of a step).  The reference's spawner keeps a gap
+    between sessions of a port, a replayed scenario need not."""
+    from ev2gym_amd.scenario import resolve_ports
+    a, port, st = pool.arrays, resolve_ports(pool), pool.arrays["env_session_start"]
+    for e in range(pool.n_envs):
+        last = {}
+        for s in range(st[e], st[e + 1]):
+            if port[s] in last:
+                a["ev_t_dep"][last[port[s]]] = a["ev_t_arr"][s] - 1
+            last[port[s]] = s
+    assert np.array_equal(resolve_ports(pool), port)
+
+
 @pytest.mark.parametrize("case", range(N_CASES))
 def test_random_configuration_matches_oracle(case):
     from ev2gym_amd import _abi
@@ -52,6 +67,8 @@ def test_random_configuration_matches_oracle(case):
     from oracle.oracle import Oracle
     rng, cfg = _draw(case)
     pool = generate(cfg)
+    if case % 3 == 1:
+        _back_to_back(pool)
     M = pool.n_envs
     E = int(rng.integers(max(1, M // 2), M + 1))
     rk, sk = int(rng.integers(0, 11)), int(rng.integers(0, 3))
