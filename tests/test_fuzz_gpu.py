@@ -3,8 +3,11 @@ modes and pool windows drawn from a fixed seed -- every kernel the routing can p
 import numpy as np
 import pytest
 
+import os
+
 pytestmark = pytest.mark.gpu
 N_CASES = 120
+SEED_OFFSET = int(os.environ.get("EV2G_FUZZ_OFFSET", "0"))   # EV2G_FUZZ_OFFSET=1000 pytest ...: the same sweep over other draws
 
 
 def _close(a, b, what, tol=1e-9):
@@ -15,7 +18,25 @@ def _close(a, b, what, tol=1e-9):
     assert err.max(initial=0.0) <= tol, f"{what}: max rel err {err.max():.3e}"
 
 
+def _close_reward(rk, r_eng, r_ora, ora, t, what):
+    """Rewards to 1e-9 -- except the one DISCONTINUITY among the reference's reward functions: SquaredTrackingErrorRewardWithPenalty
+    (kind 4, reward.py:46-58) subtracts 100 when `current_power_usage == 0`, an exact test on a sum.  With V2G, charging and discharging
+    powers that cancel leave a rounding residue (~1e-15) or an exact zero depending on the ORDER of the sum; the reference adds charger by
+    charger, the engine in a fixed tree (both within 1e-9 of each other, as every float64 output).  Where the oracle's usage is such a residue
+    the two may differ by exactly that 100."""
+    r_eng, r_ora = np.asarray(r_eng, float), np.asarray(r_ora, float)
+    if rk == 4:
+        bad = np.flatnonzero(np.abs(r_eng - r_ora) > 1e-9 * np.maximum(1.0, np.abs(r_ora)))
+        for e in bad:
+            usage = float(np.asarray(ora.peek(int(e))["usage"])[t])
+            assert abs(usage) < 1e-9 and abs(abs(r_eng[e] - r_ora[e]) - 100.0) < 1e-6, f"{what}: env {e}: {r_eng[e]} vs {r_ora[e]} (usage {usage})"
+        r_eng = r_eng.copy()
+        r_eng[bad] = r_ora[bad]
+    _close(r_eng, r_ora, what)
+
+
 def _draw(case):
+    case = case + SEED_OFFSET
     from ev2gym_amd.scenario_gen import GenConfig
     rng = np.random.default_rng(9000 + case)
     v2g = bool(rng.random() < 0.7)
@@ -113,7 +134,7 @@ def test_random_configuration_matches_oracle(case):
         faulted = faulted or rc != 0
         assert np.array_equal(mask[t], m), f"{tag}: mask[{t}]"
         _close(obs[t], o, f"{tag}: obs[{t}]")
-        _close(rew[t], r, f"{tag}: reward[{t}]")
+        _close_reward(rk, rew[t], r, ora, t, f"{tag}: reward[{t}]")
         assert np.array_equal(done[t], d), f"{tag}: done[{t}]"
     _close(eng.stats(), ora.stats(), f"{tag}: statistics")
     if faulted:
@@ -174,7 +195,7 @@ def test_random_fused_runs_across_episode_ends(case):
             o, r, d, m, rc = ora.step(acts[k].copy())
             assert np.array_equal(mask[k], m), f"{tag}: mask[{k}]"
             _close(obs[k], o, f"{tag}: obs[{k}]")
-            _close(rew[k], r, f"{tag}: reward[{k}]")
+            _close_reward(rk, rew[k], r, ora, t, f"{tag}: reward[{k}]")
             assert np.array_equal(done[k], d), f"{tag}: done[{k}]"
             k += 1
         if ep == n_ep:   # the running episode: per-env state through the inspection API
