@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ev2gym_amd import build
 so = os.path.join(ROOT, "gpurun_out", "libev2g_hip_mlpt.so")
-if os.environ.get("EV2G_LIB") != so:
+if not os.environ.get("EV2G_LIB"):   # (a library built elsewhere with -DEV2G_MLP_TIMING is taken as is)
     os.makedirs(os.path.dirname(so), exist_ok=True)
     subprocess.check_call([build.hipcc()] + build.FLAGS + ["-DEV2G_MLP_TIMING", "-DEV2G_ONLY_00", "-o", so, build.SRC])
     os.environ["EV2G_LIB"] = so
