@@ -213,7 +213,10 @@ int ev2g_step(ev2g_handle *h, const double *actions, double *obs, double *reward
  * If the episode ends inside the K steps: with auto_reset != 0 the envs are reset before the next step -- the
  * terminal step still reports its own obs -- otherwise stepping stops there and EV2G_ERR_DONE is returned.
  * auto_reset == 1 re-arms the same scenarios (ev2g_reset); auto_reset == 2 moves on to the next E scenarios of
- * the pool (ev2g_reset_ex with scenario_offset + E), inside the persistent launch as well. */
+ * the pool (ev2g_reset_ex with scenario_offset + E), inside the persistent launch as well -- as long as the windows
+ * the run visits are disjoint ((resets + 1) * E <= M); a run whose windows overlap is issued as one persistent
+ * launch per episode (results are identical: per-session results are indexed by pool scenario, and two envs must
+ * not write one scenario's slots within a single launch). */
 #define EV2G_AUTO_RESET_SAME 1
 #define EV2G_AUTO_RESET_NEXT 2
 #define EV2G_STEPN_PER_STEP_LAUNCH 0
