@@ -100,3 +100,30 @@ class EnvViewC(C.Structure):
         ("cs_energy_discharged", _pd), ("tr_power", _pd), ("tr_overload", _pd), ("power_usage", _pd),
         ("power_potential", _pd), ("session_port", _pi), ("session_afap", _pd), ("session_final_cap", _pd),
     ]
+
+
+# ---- scenario generator (ev2g_gen_config, include/ev2g.h) ----
+GEN_INT_FIELDS = ["simulation_length", "timescale", "number_of_charging_stations", "number_of_ports_per_cs", "number_of_transformers",
+                  "scenario", "simulation_days", "hour", "minute", "random_hour", "v2g_enabled", "power_setpoint_enabled",
+                  "inflexible_loads", "solar_power", "demand_response", "dr_events_per_day", "dr_event_length_minutes_min",
+                  "dr_event_length_minutes_max", "dr_notification_of_event_minutes", "heterogeneous_ev_specs", "fleet_with_efficiency_tables",
+                  "fleet", "cs_phases", "ev_phases", "ev_min_time_of_stay", "reserved0"]
+GEN_DOUBLE_FIELDS = ["spawn_multiplier", "discharge_price_factor", "power_setpoint_flexiblity",
+                     "inflexible_loads_capacity_multiplier_mean", "inflexible_loads_forecast_mean", "inflexible_loads_forecast_std",
+                     "solar_power_capacity_multiplier_mean", "solar_power_forecast_mean", "solar_power_forecast_std",
+                     "dr_event_capacity_percentage_mean", "dr_event_capacity_percentage_std", "dr_event_start_hour_mean", "dr_event_start_hour_std",
+                     "transformer_max_power", "cs_min_charge_current", "cs_max_charge_current", "cs_min_discharge_current",
+                     "cs_max_discharge_current", "cs_voltage", "ev_battery_capacity", "ev_max_ac_charge_power", "ev_min_ac_charge_power",
+                     "ev_max_discharge_power", "ev_min_discharge_power", "ev_charge_efficiency", "ev_discharge_efficiency", "ev_transition_soc",
+                     "ev_transition_soc_multiplier", "ev_min_battery_capacity", "ev_min_emergency_battery_capacity", "ev_desired_capacity"]
+GEN_TOPO_INT = ["topo_n_ports", "topo_transformer", "topo_phases"]
+GEN_TOPO_DOUBLE = ["topo_min_charge_current", "topo_max_charge_current", "topo_min_discharge_current", "topo_max_discharge_current",
+                   "topo_voltage", "topo_tr_max_power"]
+GEN_SCENARIOS = {"workplace": 0, "public": 1, "private": 2}
+GEN_DAYS = {"weekdays": 0, "weekends": 1, "both": 2}
+GEN_FLEETS = {"v2g2024": 0, "ev_plus_phev": 1}
+
+
+class GenConfigC(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in GEN_INT_FIELDS] + [("tr_seed", C.c_int64)] + [(n, C.c_double) for n in GEN_DOUBLE_FIELDS]
+                + [(n, _pi) for n in GEN_TOPO_INT] + [(n, _pd) for n in GEN_TOPO_DOUBLE])

@@ -1,0 +1,231 @@
+// ev2g_gen_host.h -- host driver of the scenario generator (ev2g_generate & co. of include/ev2g.h): slices the scenarios over
+// threads, runs ev2g_gen.h's per-scenario code, and assembles one ev2g_scenario_batch (sessions in CSR order).  Included by ev2g_host.hip.
+#pragma once
+#include <thread>
+
+#include "ev2g_gen.h"
+
+struct ev2g_gen_result {
+    ev2g_scenario_batch b{};
+    std::vector<double> cs_min_c, cs_max_c, cs_min_d, cs_max_d, cs_volt, charge_price, discharge_price, setpoints;
+    std::vector<int32_t> cs_phases, cs_tr, cs_np;
+    std::vector<double> maxp, minp, infl, solar, lf, pvf, dr;
+    std::vector<int32_t> n_dr, steps_ahead;
+    std::vector<int64_t> sess_start;
+    std::vector<int32_t> ev_cs, ev_ta, ev_td, ev_ph, ev_lut;
+    std::vector<double> cap0, B, desired, minB, min_emerg, pac_max, pac_min, pdis_max, pdis_min, ts, tsm, eta_ch, eta_dis, lut;
+};
+
+static int gen_fail(const char *msg) { g_create_error = msg; return EV2G_ERR_ARG; }
+
+static int ev2g_generate_impl(const ev2g_gen_config *cfg, int32_t M, uint64_t seed, int32_t n_threads, ev2g_gen_result **out) {
+    if (out) *out = nullptr;
+    if (!cfg || !out || M < 1) return gen_fail("ev2g_generate: bad arguments");
+    const ev2g_gen_config &c = *cfg;
+    if (c.scenario < 0 || c.scenario > 2) return gen_fail("ev2g_generate: scenario must be 0 workplace, 1 public or 2 private");
+    if (c.simulation_days < 0 || c.simulation_days > 2) return gen_fail("ev2g_generate: simulation_days must be 0 weekdays, 1 weekends or 2 both");
+    if (c.simulation_length < 8 || c.timescale < 1 || c.number_of_charging_stations < 1 || c.number_of_transformers < 1)
+        return gen_fail("ev2g_generate: simulation_length / timescale / number_of_* out of range");
+    const bool topo = c.topo_n_ports != nullptr;
+    if (topo && !(c.topo_transformer && c.topo_phases && c.topo_min_charge_current && c.topo_max_charge_current && c.topo_min_discharge_current &&
+                  c.topo_max_discharge_current && c.topo_voltage && c.topo_tr_max_power))
+        return gen_fail("ev2g_generate: a topology needs all nine topo_* arrays");
+    if (!topo && c.number_of_ports_per_cs < 1) return gen_fail("ev2g_generate: number_of_ports_per_cs < 1");
+    const int T = c.simulation_length, dt = c.timescale, C = c.number_of_charging_stations, R = c.number_of_transformers;
+    auto *res = new ev2g_gen_result();
+    ev2g_gen_result &r = *res;
+    // ---- chargers (load_ev_charger_profiles loaders.py:342-365; load_grid :494-498; topology :259-276,312-340) ----
+    r.cs_min_c.resize(C); r.cs_max_c.resize(C); r.cs_min_d.resize(C); r.cs_max_d.resize(C); r.cs_volt.resize(C);
+    r.cs_phases.resize(C); r.cs_tr.resize(C); r.cs_np.resize(C);
+    std::vector<double> tr_cap(R);
+    int npc_max = 0, P = 0;
+    for (int i = 0; i < C; i++) {
+        if (topo) {
+            r.cs_min_c[i] = c.topo_min_charge_current[i]; r.cs_max_c[i] = c.topo_max_charge_current[i];
+            r.cs_min_d[i] = c.topo_min_discharge_current[i]; r.cs_max_d[i] = c.topo_max_discharge_current[i];   // as written: v2g_enabled not consulted
+            r.cs_volt[i] = c.topo_voltage[i]; r.cs_phases[i] = c.topo_phases[i]; r.cs_tr[i] = c.topo_transformer[i]; r.cs_np[i] = c.topo_n_ports[i];
+            if (r.cs_tr[i] < 0 || r.cs_tr[i] >= R || r.cs_np[i] < 1) { delete res; return gen_fail("ev2g_generate: topology entry out of range"); }
+        } else {
+            r.cs_min_c[i] = c.cs_min_charge_current; r.cs_max_c[i] = c.cs_max_charge_current;
+            r.cs_min_d[i] = c.v2g_enabled ? c.cs_min_discharge_current : 0.0; r.cs_max_d[i] = c.v2g_enabled ? c.cs_max_discharge_current : 0.0;
+            r.cs_volt[i] = c.cs_voltage; r.cs_phases[i] = c.cs_phases; r.cs_tr[i] = i % R; r.cs_np[i] = c.number_of_ports_per_cs;
+        }
+        npc_max = std::max(npc_max, (int)r.cs_np[i]);
+        P += r.cs_np[i];
+    }
+    for (int k = 0; k < R; k++) tr_cap[k] = topo ? c.topo_tr_max_power[k] : c.transformer_max_power;
+    std::vector<int> port_cs(P);
+    std::vector<double> min_cs(P), max_cs(P);   // charger power limits seen by each port (generate_power_setpoints)
+    for (int i = 0, p = 0; i < C; i++)
+        for (int j = 0; j < r.cs_np[i]; j++, p++) {
+            port_cs[p] = i;
+            const double sq = std::sqrt((double)r.cs_phases[i]);
+            min_cs[p] = r.cs_min_c[i] * r.cs_volt[i] * sq / 1000; max_cs[p] = r.cs_max_c[i] * r.cs_volt[i] * sq / 1000;
+        }
+
+    Ev2gGenRun g{};
+    g.c = cfg; g.T = T; g.dt = dt; g.C = C; g.P = P; g.R = R; g.npc_max = npc_max; g.seed = seed;
+    g.hour = c.random_hour ? (int)ev2g_rng(seed, ~0ull).integers(EV2G_RS_HOUR, 0, 0, 5, 16) : c.hour;
+    g.min_stay_steps = c.ev_min_time_of_stay / dt;
+    g.steps_ahead = c.dr_notification_of_event_minutes / dt;
+    g.n_dr = c.demand_response ? std::max(c.dr_events_per_day, 1) : 1;
+    g.lut_fleet = c.heterogeneous_ev_specs && c.fleet_with_efficiency_tables;
+    g.n_fleet = EV2G_GEN_FLEET_MAX;
+    const int ND = g.n_dr;
+
+    r.charge_price.resize((size_t)M * T); r.discharge_price.resize((size_t)M * T); r.setpoints.resize((size_t)M * T);
+    const size_t ert = (size_t)M * R * T;
+    r.maxp.resize(ert); r.minp.resize(ert); r.infl.resize(ert); r.solar.resize(ert); r.lf.resize(ert); r.pvf.resize(ert);
+    r.dr.resize((size_t)M * R * ND * 3); r.n_dr.resize((size_t)M * R); r.steps_ahead.assign((size_t)M * R, g.steps_ahead);
+    r.sess_start.assign((size_t)M + 1, 0);
+
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(nt, (int)M));
+    std::vector<std::vector<Ev2gGenSession>> part(nt);   // the sessions of each thread's slice, scenario after scenario
+    std::vector<int> count(M, 0);
+    bool overflow = false;
+    auto work = [&](int ti) {
+        const int m0 = (int)((long long)M * ti / nt), m1 = (int)((long long)M * (ti + 1) / nt);
+        const int cap = P * 8 + 8;
+        std::vector<Ev2gGenSession> buf(cap);
+        std::vector<int> free_from(P);
+        std::vector<double> w(T), pad(T + 96);
+        for (int m = m0; m < m1; m++) {
+            const Ev2gRng rng = ev2g_rng(seed, (uint64_t)m);
+            const Ev2gRng rng_tr = (c.tr_seed != -1) ? ev2g_rng((uint64_t)c.tr_seed, (uint64_t)m) : rng;
+            double *cp = &r.charge_price[(size_t)m * T], *dp = &r.discharge_price[(size_t)m * T];
+            ev2g_gen_prices(g, rng, cp, dp);
+            // weekday or weekend tables: the reference's date decides; workplaces are always simulated on weekdays (ev2gym_env.py:141-154)
+            const bool weekend = (c.scenario == 0 || c.simulation_days == 0) ? false : (c.simulation_days == 1 ? true : rng.uni(EV2G_RS_WEEKEND, 0, 0) < 2.0 / 7.0);
+            const int n = ev2g_gen_sessions(g, rng, weekend, free_from.data(), buf.data(), cap);
+            if (n > cap) { overflow = true; count[m] = 0; continue; }
+            count[m] = n;
+            part[ti].insert(part[ti].end(), buf.begin(), buf.begin() + n);
+            const double sun = c.solar_power ? rng_tr.uni(EV2G_RS_SOLAR_ENV, 0, 0, 0.3, 1.0) : 0.0;
+            for (int k = 0; k < R; k++) {
+                const size_t o = ((size_t)m * R + k) * T;
+                ev2g_gen_transformer(g, rng_tr, k, tr_cap[k], sun, &r.maxp[o], &r.minp[o], &r.infl[o], &r.solar[o], &r.lf[o], &r.pvf[o],
+                                     &r.dr[((size_t)m * R + k) * ND * 3], &r.n_dr[(size_t)m * R + k]);
+            }
+            ev2g_gen_setpoints(g, rng, cp, buf.data(), n, min_cs.data(), max_cs.data(), c.heterogeneous_ev_specs ? 0.0 : c.ev_min_ac_charge_power,
+                               &r.setpoints[(size_t)m * T], w.data(), pad.data());
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int ti = 1; ti < nt; ti++) th.emplace_back(work, ti);
+        work(0);
+        for (auto &t : th) t.join();
+    }
+    if (overflow) { delete res; return gen_fail("ev2g_generate: session buffer overflow (internal)"); }
+    for (int m = 0; m < M; m++) r.sess_start[m + 1] = r.sess_start[m] + count[m];
+    const size_t S = (size_t)r.sess_start[M];
+    r.ev_cs.resize(S); r.ev_ta.resize(S); r.ev_td.resize(S); r.ev_ph.resize(S); r.ev_lut.resize(S);
+    for (auto *v : {&r.cap0, &r.B, &r.desired, &r.minB, &r.min_emerg, &r.pac_max, &r.pac_min, &r.pdis_max, &r.pdis_min, &r.ts, &r.tsm, &r.eta_ch, &r.eta_dis}) v->resize(S);
+    // per-session fields (spawn_single_EV utils.py:298-345): slice ti's sessions start at sess_start[first scenario of the slice]
+    auto fill = [&](int ti) {
+        const int m0 = (int)((long long)M * ti / nt), m1 = (int)((long long)M * (ti + 1) / nt);
+        size_t k = 0;
+        for (int m = m0; m < m1; m++) {
+            const Ev2gRng rng = ev2g_rng(seed, (uint64_t)m);
+            for (int i = 0; i < count[m]; i++, k++) {
+                const Ev2gGenSession &e = part[ti][k];
+                const size_t s = (size_t)r.sess_start[m] + i;
+                const uint64_t id = (uint64_t)(e.t_arr - 1) * (uint64_t)P + (uint64_t)e.port;   // the spawn trial this session came from
+                r.ev_cs[s] = port_cs[e.port]; r.ev_ta[s] = e.t_arr; r.ev_td[s] = e.t_dep;
+                r.cap0[s] = e.cap0; r.B[s] = e.B; r.desired[s] = c.ev_desired_capacity * e.B; r.minB[s] = c.ev_min_battery_capacity;
+                r.min_emerg[s] = c.ev_min_emergency_battery_capacity > e.B ? 0.7 * e.B : c.ev_min_emergency_battery_capacity;
+                r.pac_max[s] = e.pac; r.tsm[s] = c.ev_transition_soc_multiplier;
+                if (c.heterogeneous_ev_specs) {
+                    r.pac_min[s] = 0.0; r.pdis_max[s] = c.v2g_enabled ? -e.pac : 0.0; r.pdis_min[s] = 0.0; r.ev_ph[s] = 3;
+                    r.ts[s] = ev2g_round_dec(0.9 - (rng.uni(EV2G_RS_SESSION, id, 20) + 0.00001) / 5, 1000.0);
+                    if (c.fleet_with_efficiency_tables) { r.ev_lut[s] = e.model; r.eta_ch[s] = NAN; r.eta_dis[s] = NAN; }
+                    else {
+                        r.ev_lut[s] = -1;
+                        r.eta_ch[s] = ev2g_round_dec(1 - (rng.uni(EV2G_RS_SESSION, id, 21) + 0.00001) / 20, 1000.0);
+                        r.eta_dis[s] = ev2g_round_dec(1 - (rng.uni(EV2G_RS_SESSION, id, 22) + 0.00001) / 20, 1000.0);
+                    }
+                } else {
+                    r.pac_min[s] = c.ev_min_ac_charge_power; r.pdis_max[s] = c.ev_max_discharge_power; r.pdis_min[s] = c.ev_min_discharge_power;
+                    r.ev_ph[s] = c.ev_phases; r.ts[s] = c.ev_transition_soc; r.ev_lut[s] = -1;
+                    r.eta_ch[s] = c.ev_charge_efficiency; r.eta_dis[s] = c.ev_discharge_efficiency;
+                }
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int ti = 1; ti < nt; ti++) th.emplace_back(fill, ti);
+        fill(0);
+        for (auto &t : th) t.join();
+    }
+    int NL = 0;
+    if (g.lut_fleet) {   // efficiency-vs-current tables: nearest given level over 0..100 A (utils.py:279-288)
+        NL = EV2G_GEN_FLEET_MAX;
+        r.lut.resize((size_t)NL * EV2G_LUT_LEN);
+        const int levels[6] = {6, 8, 10, 12, 14, 16};
+        for (int f = 0; f < NL; f++)
+            for (int i = 0; i < EV2G_LUT_LEN; i++) {
+                int best = 0;
+                for (int l = 1; l < 6; l++) if (std::abs(levels[l] - i) < std::abs(levels[best] - i)) best = l;
+                r.lut[(size_t)f * EV2G_LUT_LEN + i] = EV2G_FLEET_V2G_ETA[f][best];
+            }
+    }
+    ev2g_scenario_batch &b = r.b;
+    b.n_envs = M; b.n_steps = T; b.timescale = dt; b.n_chargers = C; b.ports_per_charger = npc_max; b.n_transformers = R; b.horizon = 20;
+    b.n_dr_max = ND; b.n_lut = NL; b.n_sessions = (int64_t)S;
+    b.cs_min_charge_current = r.cs_min_c.data(); b.cs_max_charge_current = r.cs_max_c.data(); b.cs_min_discharge_current = r.cs_min_d.data();
+    b.cs_max_discharge_current = r.cs_max_d.data(); b.cs_voltage = r.cs_volt.data(); b.cs_phases = r.cs_phases.data(); b.cs_transformer = r.cs_tr.data();
+    b.cs_n_ports = r.cs_np.data();
+    b.charge_price = r.charge_price.data(); b.discharge_price = r.discharge_price.data(); b.power_setpoints = r.setpoints.data();
+    b.tr_max_power = r.maxp.data(); b.tr_min_power = r.minp.data(); b.tr_inflexible_load = r.infl.data(); b.tr_solar_power = r.solar.data();
+    b.tr_load_forecast = r.lf.data(); b.tr_pv_forecast = r.pvf.data(); b.tr_dr = r.dr.data(); b.tr_n_dr = r.n_dr.data(); b.tr_steps_ahead = r.steps_ahead.data();
+    b.env_session_start = r.sess_start.data(); b.ev_cs = r.ev_cs.data(); b.ev_t_arr = r.ev_ta.data(); b.ev_t_dep = r.ev_td.data(); b.ev_phases = r.ev_ph.data();
+    b.ev_lut = r.ev_lut.data(); b.ev_cap0 = r.cap0.data(); b.ev_B = r.B.data(); b.ev_desired = r.desired.data(); b.ev_minB = r.minB.data();
+    b.ev_min_emerg = r.min_emerg.data(); b.ev_pac_max = r.pac_max.data(); b.ev_pac_min = r.pac_min.data(); b.ev_pdis_max = r.pdis_max.data();
+    b.ev_pdis_min = r.pdis_min.data(); b.ev_ts = r.ts.data(); b.ev_tsm = r.tsm.data(); b.ev_eta_ch = r.eta_ch.data(); b.ev_eta_dis = r.eta_dis.data();
+    b.lut = r.lut.data();
+    *out = res;
+    return EV2G_OK;
+}
+
+static int ev2g_gen_default_config_impl(int kind, ev2g_gen_config *c) {
+    if (!c || kind < 0 || kind > 1) return EV2G_ERR_ARG;
+    std::memset(c, 0, sizeof(*c));
+    c->simulation_length = 112; c->timescale = 15; c->number_of_charging_stations = 25; c->number_of_ports_per_cs = 1; c->number_of_transformers = 1;
+    c->scenario = 0; c->simulation_days = 0; c->hour = 5; c->minute = 0; c->random_hour = 0; c->v2g_enabled = 1; c->power_setpoint_enabled = 0;
+    c->inflexible_loads = 1; c->solar_power = 1; c->demand_response = 1; c->dr_events_per_day = 1; c->dr_event_length_minutes_min = 60;
+    c->dr_event_length_minutes_max = 60; c->dr_notification_of_event_minutes = 60; c->heterogeneous_ev_specs = 1; c->fleet_with_efficiency_tables = 1;
+    c->fleet = 0; c->cs_phases = 3; c->ev_phases = 3; c->ev_min_time_of_stay = 180; c->tr_seed = -1;
+    c->spawn_multiplier = 5; c->discharge_price_factor = 1; c->power_setpoint_flexiblity = 80;
+    c->inflexible_loads_capacity_multiplier_mean = 1; c->inflexible_loads_forecast_mean = 30; c->inflexible_loads_forecast_std = 5;
+    c->solar_power_capacity_multiplier_mean = 1; c->solar_power_forecast_mean = 20; c->solar_power_forecast_std = 5;
+    c->dr_event_capacity_percentage_mean = 35; c->dr_event_capacity_percentage_std = 5; c->dr_event_start_hour_mean = 12; c->dr_event_start_hour_std = 2;
+    c->transformer_max_power = 100; c->cs_min_charge_current = 0; c->cs_max_charge_current = 32; c->cs_min_discharge_current = 0; c->cs_max_discharge_current = -32;
+    c->cs_voltage = 400; c->ev_battery_capacity = 50; c->ev_max_ac_charge_power = 11; c->ev_min_ac_charge_power = 0; c->ev_max_discharge_power = -11;
+    c->ev_min_discharge_power = 0; c->ev_charge_efficiency = 1; c->ev_discharge_efficiency = 1; c->ev_transition_soc = 1; c->ev_transition_soc_multiplier = 5;
+    c->ev_min_battery_capacity = 5; c->ev_min_emergency_battery_capacity = 25; c->ev_desired_capacity = 1;
+    if (kind == 1) {   // PublicPST.yaml
+        c->number_of_charging_stations = 20; c->scenario = 1; c->v2g_enabled = 0; c->power_setpoint_enabled = 1; c->inflexible_loads = 0; c->solar_power = 0;
+        c->demand_response = 0; c->fleet_with_efficiency_tables = 0; c->fleet = 1; c->cs_max_charge_current = 16; c->cs_max_discharge_current = 0;
+        c->ev_min_time_of_stay = 60;
+    }
+    return EV2G_OK;
+}
+
+static int ev2g_gen_table_impl(int which, int kind, double *out, int n_max) {
+    if (!out) return EV2G_ERR_ARG;
+    if (which >= 0 && which <= 2) {
+        if (kind < 0 || kind >= EV2G_GEN_N_KINDS) return EV2G_ERR_ARG;
+        const int n = which == 2 ? 1 : 24;
+        if (n_max < n) return EV2G_ERR_ARG;
+        for (int i = 0; i < n; i++) out[i] = which == 0 ? EV2G_GEN_RATE[kind][i] : (which == 1 ? EV2G_GEN_STAY[kind][i] : EV2G_GEN_ENERGY[kind]);
+        return n;
+    }
+    if (which == 3 || which == 4) {
+        if (n_max < EV2G_GEN_FLEET_MAX * 3) return EV2G_ERR_ARG;
+        for (int i = 0; i < EV2G_GEN_FLEET_MAX; i++) for (int j = 0; j < 3; j++) out[i * 3 + j] = (which == 3 ? EV2G_FLEET_V2G : EV2G_FLEET_EV_PHEV)[i][j];
+        return EV2G_GEN_FLEET_MAX * 3;
+    }
+    return EV2G_ERR_ARG;
+}

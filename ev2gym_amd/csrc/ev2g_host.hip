@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 static thread_local std::string g_create_error;
+#include "ev2g_gen_host.h"
 
 struct ev2g_handle {
     int device = 0;
@@ -1302,5 +1303,14 @@ int ev2g_fill_uniform(ev2g_handle *h, double *dst, int64_t n, uint64_t seed, dou
 void ev2g_host_uniform(double *dst, int64_t n, uint64_t seed, double lo, double hi) {
     for (int64_t i = 0; i < n; i++) dst[i] = lo + (hi - lo) * ev2g_u01(seed, (uint64_t)i);
 }
+
+// ---- scenario generator (host only) ----
+int ev2g_gen_default_config(int kind, ev2g_gen_config *cfg) { return ev2g_gen_default_config_impl(kind, cfg); }
+int ev2g_generate(const ev2g_gen_config *cfg, int32_t n_scenarios, uint64_t seed, int32_t n_threads, ev2g_gen_result **out) {
+    return ev2g_generate_impl(cfg, n_scenarios, seed, n_threads, out);
+}
+const ev2g_scenario_batch *ev2g_gen_batch(const ev2g_gen_result *r) { return r ? &r->b : nullptr; }
+void ev2g_gen_free(ev2g_gen_result *r) { delete r; }
+int ev2g_gen_table(int which, int kind, double *out, int n_max) { return ev2g_gen_table_impl(which, kind, out, n_max); }
 
 }  // extern "C"

@@ -83,6 +83,11 @@ def load_library(path: Optional[str] = None):
         "ev2g_comm_world_size": (C.c_int, [vp]),
         "ev2g_comm_gathers": (C.c_longlong, [vp]),
         "ev2g_gather_stats": (C.c_int, [vp, vp]),
+        "ev2g_gen_default_config": (C.c_int, [C.c_int, C.POINTER(_abi.GenConfigC)]),
+        "ev2g_generate": (C.c_int, [C.POINTER(_abi.GenConfigC), i32, C.c_uint64, i32, C.POINTER(vp)]),
+        "ev2g_gen_batch": (C.POINTER(_abi.ScenarioBatchC), [vp]),
+        "ev2g_gen_free": (None, [vp]),
+        "ev2g_gen_table": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(L, name)  # AttributeError here = the .so does not export what include/ev2g.h declares
@@ -101,7 +106,8 @@ EXPORTED_SYMBOLS = [
     "ev2g_check_faults", "ev2g_get_stats", "ev2g_stat_name", "ev2g_peek", "ev2g_malloc", "ev2g_free",
     "ev2g_memcpy_h2d", "ev2g_memcpy_d2h", "ev2g_synchronize", "ev2g_fill_uniform", "ev2g_host_uniform",
     "ev2g_last_step_n_kernel_ms", "ev2g_mlp_create", "ev2g_mlp_destroy", "ev2g_mlp_forward", "ev2g_rollout",
-    "ev2g_rollout_graph_launches", "ev2g_comm_get_unique_id", "ev2g_comm_init", "ev2g_comm_destroy", "ev2g_comm_world_size", "ev2g_comm_gathers", "ev2g_gather_stats"]
+    "ev2g_rollout_graph_launches", "ev2g_comm_get_unique_id", "ev2g_comm_init", "ev2g_comm_destroy", "ev2g_comm_world_size", "ev2g_comm_gathers", "ev2g_gather_stats",
+    "ev2g_gen_default_config", "ev2g_generate", "ev2g_gen_batch", "ev2g_gen_free", "ev2g_gen_table"]
 
 
 def _ptr(x):

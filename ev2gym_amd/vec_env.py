@@ -68,7 +68,7 @@ class EV2GymVec:
                  reward_function="SquaredTrackingErrorReward", cost_function=None, seed: Optional[int] = None,
                  scenarios: Optional[ScenarioBatch] = None, auto_reset: bool = False, log_cs_history: bool = False, log_soc: bool = True,
                  use_torch: Optional[bool] = None, rank: int = 0, world_size: int = 1, verbose: bool = False,
-                 load_from_replay_path=None, pool_factor: int = 8, resample_every: Optional[int] = None, **unused):
+                 load_from_replay_path=None, pool_factor: int = 8, resample_every: Optional[int] = None, generator: str = "numpy", **unused):
         self.state_kind = _kind(state_function, _abi.STATE_KINDS, "state_function")
         self.reward_kind = _kind(reward_function, _abi.REWARD_KINDS, "reward_function")
         if self.state_kind is None or self.reward_kind is None:
@@ -86,6 +86,9 @@ class EV2GymVec:
         self._rng = np.random.default_rng(self.seed)     # the stream reset() draws scenario offsets from
         self.pool_factor = max(1, int(pool_factor))
         self.resample_every = resample_every
+        if generator not in ("numpy", "native"):
+            raise ValueError("generator: 'numpy' (scenario_gen.generate) or 'native' (the library's ev2g_generate)")
+        self.generator = generator   # which implementation of the scenario model draws the pool (same model, different random streams)
         self._episodes = 0
         self._pool_generation = 0
         if scenarios is None and load_from_replay_path is not None:
@@ -151,7 +154,10 @@ class EV2GymVec:
         reference's per-reset draw, scenario_gen.py); generation `g` of the pool uses the seed (seed, g)."""
         total = self._n_req * self.pool_factor * world_size
         gen_seed = self.seed if self._pool_generation == 0 else int(np.random.SeedSequence([self.seed, self._pool_generation]).generate_state(1)[0])
-        full = generate(gen_config_from_yaml(self.config, total, gen_seed))
+        draw = generate
+        if self.generator == "native":
+            from .scenario_gen import generate_native as draw
+        full = draw(gen_config_from_yaml(self.config, total, gen_seed))
         return full.shard(rank, world_size) if world_size > 1 else full
 
     # ---- buffers ---------------------------------------------------------------------------------

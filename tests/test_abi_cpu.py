@@ -44,6 +44,10 @@ def test_struct_mirrors_match_header_field_order():
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = [n for part in re.findall(r"(?:int32_t|int64_t|double|float|void|const float)\s+([^;]+);", body) for n in re.split(r"[,\s\*]+", part) if n]
         assert names == [f[0] for f in mirror._fields_], cname
+    body = txt[txt.index("typedef struct ev2g_gen_config {"):txt.index("} ev2g_gen_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n for part in re.findall(r"(?:const int32_t|const double|int32_t|int64_t|double)\s+([^;]+);", body) for n in re.split(r"[,\s\*]+", part) if n]
+    assert names == [f[0] for f in _abi.GenConfigC._fields_]
 
 
 @pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")

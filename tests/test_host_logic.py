@@ -125,14 +125,17 @@ def test_plugin_resolution():
 @pytest.mark.parametrize("name,yaml_file", [("V2GProfitPlusLoads", "V2GProfitPlusLoads.yaml"), ("PublicPST", "PublicPST.yaml"),
                                             ("PrivateV2GPPL", "V2GProfitPlusLoads.yaml"), ("PublicPSTWeekend", "PublicPST.yaml"),
                                             ("PrivateV2GPPLWeekend", "V2GProfitPlusLoads.yaml")])
-def test_generator_reproduces_the_reference_spawn_statistics(name, yaml_file):
+@pytest.mark.parametrize("backend", ["numpy", "native"])
+def test_generator_reproduces_the_reference_spawn_statistics(name, yaml_file, backend):
     """Statistical parity of the vectorised scenario generator with the reference's EV_spawner / spawn_single_EV
     (SURVEY.md §8f-1): tests/golden/spawn_stats.json holds summary statistics of 300 reference resets per config
     (oracle/capture_spawn_stats.py); 300 generated envs must land close to them.  Tolerances are a few standard errors
     of these sample sizes plus the modelling error of hourly tables / representative fleet classes."""
     import json
     from ev2gym_amd.config import gen_config_from_yaml, load_yaml
-    from ev2gym_amd.scenario_gen import generate, occupancy_fraction
+    from ev2gym_amd.scenario_gen import generate, generate_native, occupancy_fraction
+    if backend == "native":   # the library's own generator (ev2g_generate, csrc/ev2g_gen.h): same model, counter-based random numbers
+        generate = generate_native
     ref = json.load(open(os.path.join(GOLDEN_DIR, "spawn_stats.json")))[name]
     cfg_dir = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "ev2gym_amd", "example_config_files")
     over = {"scenario": "private"} if name.startswith("Private") else {}
@@ -164,12 +167,15 @@ def test_generator_reproduces_the_reference_spawn_statistics(name, yaml_file):
     assert np.abs(hist - np.array(ref["arrival_hist_7bins"])).max() <= 0.04, (hist, ref["arrival_hist_7bins"])
 
 
-def test_generated_power_setpoints_resemble_the_reference_ones():
+@pytest.mark.parametrize("backend", ["numpy", "native"])
+def test_generated_power_setpoints_resemble_the_reference_ones(backend):
     """generate_power_setpoints (utils.py:664-757) is re-implemented vectorised and simplified: its output must still
     carry about the same energy relative to what the EVs need, peak, duty and level as the reference's (PublicPST)."""
     import json
     from ev2gym_amd.config import gen_config_from_yaml, load_yaml
-    from ev2gym_amd.scenario_gen import generate
+    from ev2gym_amd.scenario_gen import generate, generate_native
+    if backend == "native":
+        generate = generate_native
     ref = json.load(open(os.path.join(GOLDEN_DIR, "spawn_stats.json")))["PublicPST"]
     cfg_dir = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "ev2gym_amd", "example_config_files")
     b = generate(gen_config_from_yaml(load_yaml(os.path.join(cfg_dir, "PublicPST.yaml")), 300, 5))
@@ -210,6 +216,99 @@ def test_every_shipped_config_generates_a_batch(yaml_file, T, P, R):
         assert len(np.unique(a["ev_B"])) == 1   # one EV model (ev2gym_env.py:  ev_specs are only read when heterogeneous)
     if not cfg["v2g_enabled"]:
         assert not b.v2g_enabled
+
+
+# ---- the library's own generator (ev2g_generate): the C-ABI's counterpart of scenario_gen.generate ---------------------------------
+def test_native_generator_shares_the_fitted_tables_with_the_numpy_one():
+    """Two copies of the fitted constants exist (scenario_gen._HOURLY / _FLEET_* and csrc/ev2g_gen.h): they must be the same numbers."""
+    import ctypes as C
+    from ev2gym_amd import scenario_gen as sg
+    from ev2gym_amd.engine import load_library
+    L = load_library()
+    out = (C.c_double * 24)()
+    for kind, name in enumerate(["workplace", "public", "private", "public_weekend", "private_weekend"]):
+        for which, key in enumerate(["rate", "stay"]):
+            assert L.ev2g_gen_table(which, kind, out, 24) == 24
+            assert np.array_equal(np.array(out[:24]), sg._HOURLY[name][key]), (name, key)
+        assert L.ev2g_gen_table(2, kind, out, 24) == 1 and out[0] == sg._HOURLY[name]["energy"][0]
+    fl = (C.c_double * 24)()
+    assert L.ev2g_gen_table(3, 0, fl, 24) == 24 and np.array_equal(np.array(fl[:24]).reshape(8, 3), np.array([f[:3] for f in sg._FLEET_V2G]))
+    assert L.ev2g_gen_table(4, 0, fl, 24) == 24 and np.array_equal(np.array(fl[:24]).reshape(8, 3), np.array(sg._FLEET_EV_PHEV))
+    assert L.ev2g_gen_table(0, 9, out, 24) < 0 and L.ev2g_gen_table(0, 0, out, 3) < 0
+
+
+def test_native_generator_is_a_pure_function_of_seed_and_scenario_index():
+    """Counter-based draws: the batch does not depend on the number of threads, scenario i is the same scenario whatever n_scenarios is,
+    another seed gives other scenarios; tr_seed pins the transformer side only (ev2gym_env.py:97-100)."""
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    cfg = GenConfig.v2g_profit_plus_loads(40, 12, 2, seed=9, number_of_ports_per_cs=2)
+    a, b = generate_native(cfg, 1), generate_native(cfg, 5)
+    assert all(np.array_equal(a.arrays[k], b.arrays[k], equal_nan=True) for k in a.arrays)
+    small = generate_native(GenConfig.v2g_profit_plus_loads(7, 12, 2, seed=9, number_of_ports_per_cs=2))
+    S = small.n_sessions
+    assert S == a.arrays["env_session_start"][7]
+    for k in ("ev_cap0", "ev_t_arr", "ev_t_dep", "ev_cs", "ev_ts"):
+        assert np.array_equal(small.arrays[k], a.arrays[k][:S]), k
+    for k in ("charge_price", "tr_inflexible_load", "tr_pv_forecast", "tr_dr"):
+        assert np.array_equal(small.arrays[k], a.arrays[k][:7]), k
+    other = generate_native(GenConfig.v2g_profit_plus_loads(40, 12, 2, seed=10, number_of_ports_per_cs=2))
+    assert not np.array_equal(other.arrays["charge_price"], a.arrays["charge_price"])
+    p1 = generate_native(GenConfig.v2g_profit_plus_loads(6, 12, 2, seed=1, tr_seed=77))
+    p2 = generate_native(GenConfig.v2g_profit_plus_loads(6, 12, 2, seed=2, tr_seed=77))
+    assert np.array_equal(p1.arrays["tr_inflexible_load"], p2.arrays["tr_inflexible_load"]) and np.array_equal(p1.arrays["tr_dr"], p2.arrays["tr_dr"])
+    assert not np.array_equal(p1.arrays["charge_price"], p2.arrays["charge_price"])
+
+
+@pytest.mark.parametrize("yaml_file", ["PublicPST.yaml", "simplePST.yaml", "V2GProfitMax.yaml", "V2GProfitPlusLoads.yaml", "V2GProfitPlusLoads_1000cs_50tr.yaml"])
+def test_native_generator_covers_the_shipped_configs_and_feeds_the_oracle(yaml_file):
+    """Every shipped config through ev2g_generate: same structure as the numpy generator's batch, the constraints of the reference's
+    spawner (a port is empty for at least two steps between two sessions, every EV leaves before the end), and the C oracle steps it."""
+    import warnings
+    from ev2gym_amd.config import gen_config_from_yaml, load_yaml
+    from ev2gym_amd.scenario import resolve_ports
+    from ev2gym_amd.scenario_gen import generate, generate_native
+    from oracle.oracle import Oracle
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cfg = gen_config_from_yaml(load_yaml(os.path.join(CFG, yaml_file)), 3, 4)
+        b, ref = generate_native(cfg), generate(cfg)
+    assert (b.n_envs, b.n_steps, b.n_ports, b.n_transformers, b.timescale) == (ref.n_envs, ref.n_steps, ref.n_ports, ref.n_transformers, ref.timescale)
+    a = b.arrays
+    for k, v in ref.arrays.items():
+        assert a[k].dtype == v.dtype and a[k].shape[1:] == v.shape[1:], k
+    assert b.n_sessions > 0 and (a["ev_t_dep"] < b.n_steps).all() and (a["ev_t_arr"] >= 3).all() and (a["ev_cap0"] <= a["ev_B"]).all()
+    port, st, last = resolve_ports(b), a["env_session_start"], {}
+    for e in range(b.n_envs):
+        for s in range(st[e], st[e + 1]):
+            if (e, port[s]) in last:
+                assert a["ev_t_arr"][s] >= a["ev_t_dep"][last[(e, port[s])]] + 3
+            last[(e, port[s])] = s
+    for k in ("tr_inflexible_load", "tr_solar_power", "power_setpoints"):
+        assert bool(np.abs(a[k]).sum() > 0) == bool(np.abs(ref.arrays[k]).sum() > 0), k
+    if b.n_ports <= 60:
+        ora = Oracle(b, 0 if b.v2g_enabled else 1, 0 if b.v2g_enabled else 1)
+        ora.reset()
+        for t in range(b.n_steps):
+            o, r, d, m, rc = ora.step(np.ones((b.n_envs, b.n_ports)))
+            assert rc == 0 and np.isfinite(o).all() and np.isfinite(r).all()
+        assert d.all()
+        ora.close()
+
+
+def test_native_generator_takes_a_topology_and_refuses_bad_input():
+    from ev2gym_amd.engine import EngineError
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    topo = dict(n_ports=np.array([3, 2, 2, 1]), transformer=np.array([0, 0, 1, 1]), phases=np.array([3, 3, 1, 3]),
+                min_charge_current=np.zeros(4), max_charge_current=np.array([32., 16., 16., 32.]), min_discharge_current=np.zeros(4),
+                max_discharge_current=np.array([-32., 0., -16., -32.]), voltage=np.array([400., 230., 230., 400.]), tr_max_power=np.array([80., 60.]))
+    b = generate_native(GenConfig(n_envs=5, seed=2, spawn_multiplier=10, scenario="public", topology=topo))
+    assert (b.n_chargers, b.n_ports, b.n_transformers, b.ports_per_charger) == (4, 8, 2, 3)
+    assert np.array_equal(b.arrays["cs_n_ports"], topo["n_ports"]) and np.array_equal(b.arrays["cs_max_discharge_current"], topo["max_discharge_current"])
+    assert (b.arrays["tr_max_power"][:, 1] <= 60.0 + 1e-9).all() and b.arrays["ev_cs"].max() <= 3
+    with pytest.raises(ValueError):
+        generate_native(GenConfig(n_envs=2, scenario="mall"))
+    with pytest.raises(EngineError):
+        generate_native(GenConfig(n_envs=2, simulation_length=3))
 
 
 # ---- topology files and the rest of the YAML schema (ADVICE: no key is dropped silently) -----------------------------------
