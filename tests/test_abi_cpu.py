@@ -66,3 +66,24 @@ def test_host_uniform_matches_splitmix_definition():
     assert u.min() >= -1.0 and u.max() < 1.0 and abs(u.mean()) < 0.1
     assert np.array_equal(u, host_uniform(1000, 42, -1.0, 1.0))
     assert not np.array_equal(u, host_uniform(1000, 43, -1.0, 1.0))
+
+
+def test_header_is_c99_and_a_c_host_links_and_generates(tmp_path):
+    """include/ev2g.h must be plain C (the boundary is a C-ABI): examples/c_host.c is compiled as C99 with warnings as errors, linked against
+    the library, and its host-only part -- the scenario generator -- is run (the GPU part of the example needs a device)."""
+    import shutil
+    import subprocess
+    from ev2gym_amd import build
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    lib_dir = os.path.dirname(build.build())
+    exe = str(tmp_path / "c_host")
+    subprocess.check_call([cc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_host.c"),
+                           "-L" + lib_dir, "-lev2g_hip", "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined", "-o", exe])
+    out = subprocess.run([exe, "--generate-only", "16"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.startswith("generated 64 scenarios: 112 steps, 50 chargers"), out.stdout
+    if not has_gpu():   # the engine part fails loudly without a device
+        out = subprocess.run([exe, "4", "1"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 1 and "no CPU fallback" in out.stderr, (out.stdout, out.stderr)
