@@ -156,6 +156,30 @@ class RolloutLoop:
                 self.episode_end()
 
 
+def full_episode_pass(loop, T, barrier, agree_max, min_s=0.1):
+    """Whole episodes (persistent launch + statistics + gather + reset) for at least `min_s`: returns (episodes, seconds per episode).
+    Every episode end issues a collective (the statistics gather), so all ranks must run the SAME number of episodes: the count is
+    fixed up front from one timed episode and agreed on (`agree_max`: MAX over the ranks) -- never decided by a rank's own clock
+    inside the loop, which would leave the faster rank waiting in a collective the slower one never issues."""
+    loop.reset()
+    loop.run(T, True)
+    barrier()
+    t0 = time.perf_counter()
+    if loop.eng.current_step:
+        loop.reset()
+    loop.run(T, True)
+    barrier()
+    n_ep = min(agree_max(max(3, int(np.ceil(min_s / max(time.perf_counter() - t0, 1e-6))))), 2000)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n_ep):
+        if loop.eng.current_step:
+            loop.reset()
+        loop.run(T, True)
+    barrier()
+    return n_ep, (time.perf_counter() - t0) / n_ep
+
+
 class PipelinedLoops:
     """Several RolloutLoops over disjoint env groups of one GPU, each with its own engine handle and HIP stream, fed by one host
     thread per group.  With a policy in the loop every step is a chain of two dependent kernels (actor forward -> env step); two
@@ -319,17 +343,13 @@ def main():
     # whole episodes, the RL-free upper bound of the path: one 112-step persistent launch + statistics + reset per episode
     full_ep = None
     if actor is None:
-        loop.reset()
-        loop.run(T, True)
-        barrier()
-        n_ep = 0
-        t0 = time.perf_counter()
-        while n_ep < 3 or time.perf_counter() - t0 < 0.1:
-            loop.reset() if loop.eng.current_step else None
-            loop.run(T, True)
-            n_ep += 1
-        barrier()
-        ep_s = (time.perf_counter() - t0) / n_ep
+        def agree_max(n):
+            if not multi:
+                return n
+            tt = torch.tensor([n], dtype=torch.int64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return int(tt.item())
+        n_ep, ep_s = full_episode_pass(loop, T, barrier, agree_max)
         full_ep = {"episodes": n_ep, "ms_per_episode": ep_s * 1e3, "env_steps_per_s": world * E * T / ep_s,
                    "contains": "112-step persistent launch + statistics kernel + reset onto fresh scenarios"}
 

@@ -187,3 +187,55 @@ def test_bench_rollout_loop_over_two_ranks(tmp_path):
         want.append(np.nan_to_num(ora.stats()))
         ora.close()
     assert np.array_equal(got, np.concatenate(want, 0))
+
+
+def _full_episode_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import time
+    import torch
+    import torch.distributed as dist
+    from bench import RolloutLoop, full_episode_pass
+    from ev2gym_amd.dist import AsyncStatsGather
+    from ev2gym_amd.engine import host_uniform
+    from ev2gym_amd.scenario_gen import GenConfig, generate
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    E, M = 3, 6
+    pool = generate(GenConfig.v2g_profit_plus_loads(M, 6, seed=400 + rank))
+    eng = _OracleEngine(pool, E, 0, 0)
+    if rank == 1:   # a slower rank: on its own clock it would run fewer episodes (and issue fewer gathers) than rank 0
+        fast = eng.step_n
+        eng.step_n = lambda *a, **k: (time.sleep(0.004), fast(*a, **k))[1]
+    T, P = eng.T, eng.P
+    eng.all_acts = torch.from_numpy(host_uniform(T * E * P, 60 + rank, -1.0, 1.0).reshape(T, E, P))
+    gath = AsyncStatsGather(E, world, "cpu")
+    loop = RolloutLoop(eng, E, P, T, M, eng.all_acts, None, None, None, None, None, gath=gath, actor=None)
+
+    def barrier():
+        gath.finish()
+        dist.barrier()
+
+    def agree_max(n):
+        tt = torch.tensor([n], dtype=torch.int64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        with open(os.path.join(out_dir, f"local_{rank}.txt"), "w") as f:
+            f.write(str(n))
+        return int(tt.item())
+    n_ep, ep_s = full_episode_pass(loop, T, barrier, agree_max, min_s=0.05)
+    with open(os.path.join(out_dir, f"agreed_{rank}.txt"), "w") as f:
+        f.write(f"{n_ep} {loop.episodes} {gath.collectives}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_bench_full_episode_pass_runs_the_same_number_of_episodes_on_every_rank(tmp_path):
+    """bench.py's whole-episode measurement issues one collective per episode: two ranks of different speed must agree on the
+    number of episodes up front (a count taken from each rank's own clock inside the loop leaves one rank waiting forever)."""
+    import torch.multiprocessing as mp
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_full_episode_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a0, a1 = [open(tmp_path / f"agreed_{r}.txt").read().split() for r in range(2)]
+    assert a0 == a1 and int(a0[0]) >= 3 and int(a0[1]) == int(a0[0]) + 2 == int(a0[2])   # + the warm-up and the timed single episode
+    l0, l1 = [int(open(tmp_path / f"local_{r}.txt").read()) for r in range(2)]
+    assert int(a0[0]) == max(l0, l1)
