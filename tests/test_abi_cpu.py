@@ -87,3 +87,32 @@ def test_header_is_c99_and_a_c_host_links_and_generates(tmp_path):
     if not has_gpu():   # the engine part fails loudly without a device
         out = subprocess.run([exe, "4", "1"], capture_output=True, text=True, timeout=120)
         assert out.returncode == 1 and "no CPU fallback" in out.stderr, (out.stdout, out.stderr)
+
+
+def test_generator_core_compiles_for_the_device(tmp_path):
+    """csrc/ev2g_gen.h claims its per-scenario code is host/device agnostic (the device-side generator of the next round runs it as is):
+    a probe kernel that calls every piece of it must cross-compile for gfx950, and the header must also be plain C++ for g++."""
+    import shutil
+    import subprocess
+    from ev2gym_amd import build
+    hdr = os.path.join(ROOT, "ev2gym_amd", "csrc", "ev2g_gen.h")
+    probe = tmp_path / "gen_probe.hip"
+    probe.write_text('''#include <hip/hip_runtime.h>
+#include "%s"
+__global__ void gen_probe(ev2g_gen_config c, Ev2gGenRun g, double *buf, int *ibuf, Ev2gGenSession *ss, int32_t *ndr) {
+    g.c = &c;
+    const Ev2gRng r = ev2g_rng(g.seed, blockIdx.x);
+    double *cp = buf, *dp = cp + g.T, *q = dp + g.T, *sp = q + 7 * g.T;
+    ev2g_gen_prices(g, r, cp, dp);
+    const int n = ev2g_gen_sessions(g, r, false, ibuf, ss, g.P * 8);
+    ev2g_gen_transformer(g, r, 0, 100.0, 0.5, q, q + g.T, q + 2 * g.T, q + 3 * g.T, q + 4 * g.T, q + 5 * g.T, q + 6 * g.T, ndr);
+    ev2g_gen_setpoints(g, r, cp, ss, n, sp + g.T, sp + g.T + g.P, 0.0, sp, sp + g.T + 2 * g.P, sp + 2 * g.T + 2 * g.P);
+}
+''' % hdr)
+    subprocess.check_call([build.hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-c", "-o", str(tmp_path / "gen_probe.o"), str(probe)])
+    cxx = shutil.which("g++")
+    if cxx:
+        host = tmp_path / "gen_host.cpp"
+        host.write_text('#include "%s"\nint main() { return ev2g_rng(1, 2).uni(3, 4, 5) < 1.0 ? 0 : 1; }\n' % hdr)
+        subprocess.check_call([cxx, "-std=c++17", "-Wall", "-Wextra", "-Werror", "-o", str(tmp_path / "gen_host"), str(host)])
+        assert subprocess.call([str(tmp_path / "gen_host")]) == 0
