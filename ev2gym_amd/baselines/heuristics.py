@@ -34,3 +34,16 @@ class RandomAgent:
             self._calls += 1
             return env.uniform_actions(self.seed * 1000003 + self._calls, low, 1.0)
         return self.rng.uniform(low, 1.0, env.number_of_ports)
+
+
+class DoNothing:
+    """heuristics.py:533-544: no port charges or discharges."""
+    algo_name = "DO NOTHING"
+
+    def __init__(self, verbose=False, **kwargs):
+        self.verbose = verbose
+
+    def get_action(self, env):
+        if hasattr(env, "num_envs"):
+            return env.full_like_actions(0.0)
+        return np.zeros(env.number_of_ports)

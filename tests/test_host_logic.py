@@ -399,3 +399,78 @@ def test_yaml_keys_are_passed_through_or_reported():
         gen_config_from_yaml(_yaml("PublicPST.yaml", random_day=False), 2)
     h = {generate(gen_config_from_yaml(_yaml("PublicPST.yaml", random_hour=True), 2, seed=s)).arrays["charge_price"][0, 0] for s in range(6)}
     assert len(h) > 1
+
+
+# ---- the batched evaluation loop (evaluator.py:102-109,248-287) -----------------------------------------------------------------
+class _OracleBackedEngine:
+    """Test stand-in for ev2gym_amd.engine.Engine on a box without a GPU (the calls ev2gym_amd.evaluator makes), served by the CPU oracle."""
+
+    class _Buf:
+        def __init__(self, shape):
+            self.a = np.zeros(shape)
+
+        def upload(self, arr):
+            self.a[...] = arr
+            return self
+
+    def __init__(self, batch, rk, sk):
+        from oracle.oracle import Oracle
+        self.ora, self.E, self.P, self.T = Oracle(batch, rk, sk), batch.n_envs, batch.n_ports, batch.n_steps
+
+    def empty(self, shape, dtype=np.float64):
+        return self._Buf(shape)
+
+    def fill_uniform(self, dst, n, seed, lo, hi):
+        from ev2gym_amd.engine import host_uniform
+        dst.a[...] = host_uniform(n, seed, lo, hi).reshape(dst.a.shape)
+
+    def reset(self):
+        self.ora.reset()
+
+    def step_n(self, k, acts, stride, auto_reset=0, persistent=True):
+        for t in range(k):
+            self.ora.step((acts.a[t] if stride else acts.a).copy())
+
+    def stats(self):
+        return self.ora.stats()
+
+    def check_faults(self):
+        pass
+
+    def last_step_n_kernel_ms(self):
+        return 0.0
+
+    def close(self):
+        self.ora.close()
+
+
+def test_batched_evaluator_builds_the_reference_results_table():
+    """ev2gym_amd.evaluator.evaluate: one row per (run, algorithm) with the reference's columns; the values are the terminal statistics of an
+    episode driven by that algorithm's action source (checked against a plain oracle loop).  The HIP engine is replaced by an oracle-backed
+    stand-in here; tests/test_python_surface_gpu.py runs the same call on the device."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import host_uniform
+    from ev2gym_amd.evaluator import ALGORITHMS, RESULT_STATS, evaluate
+    from ev2gym_amd.scenario_gen import GenConfig, generate
+    from oracle.oracle import Oracle
+    batch = generate(GenConfig.v2g_profit_plus_loads(4, 8, 1, seed=12))
+    df = evaluate(batch, engine_factory=_OracleBackedEngine, seed=5, discharge_price_factor=1.0)
+    assert list(df.columns) == ["run", "Algorithm", "control_horizon", "discharge_price_factor"] + RESULT_STATS + ["total_reward", "time"]
+    assert len(df) == 4 * len(ALGORITHMS) and sorted(df["Algorithm"].unique()) == sorted(ALGORITHMS)
+    T, E, P = batch.n_steps, batch.n_envs, batch.n_ports
+    sources = {"ChargeAsFastAsPossible": np.ones((T, E, P)), "DoNothing": np.zeros((T, E, P)),
+               "RandomAgent": host_uniform(T * E * P, 5, -1.0, 1.0).reshape(T, E, P)}
+    for name, acts in sources.items():
+        ora = Oracle(batch, 0, 0)
+        ora.reset()
+        for t in range(T):
+            ora.step(acts[t].copy())
+        st = ora.stats()
+        ora.close()
+        sub = df[df["Algorithm"] == name].sort_values("run")
+        for k in RESULT_STATS + ["total_reward"]:
+            assert np.allclose(sub[k].to_numpy(), st[:, _abi.STAT_NAMES.index(k)], rtol=0, atol=0, equal_nan=True), (name, k)
+    assert (df[df["Algorithm"] == "DoNothing"]["total_energy_charged"] == 0).all()
+    assert (df[df["Algorithm"] == "ChargeAsFastAsPossible"]["total_energy_charged"] > 0).all()
+    with pytest.raises(NotImplementedError):
+        evaluate(batch, algorithms=["RoundRobin"], engine_factory=_OracleBackedEngine)
