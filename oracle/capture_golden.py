@@ -26,6 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 OUT = os.path.join(REPO, "tests", "golden")
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))   # ev2gym_amd (scenario generator + replay writer of the back-to-back cases)
 warnings.filterwarnings("ignore")
 
 from ref_import import import_reference  # noqa: E402
@@ -298,6 +299,35 @@ def run_replay_case(name, config, state_fn, reward_fn, seed, policy):
     run_case(name, config, state_fn, reward_fn, seed, policy, env=env_b, extra=extra)
 
 
+def run_back_to_back_case(name, yml, over, state_fn, reward_fn, seed, policy):
+    """Back-to-back sessions (the next EV plugs in at the end of the very step its predecessor leaves in).  The reference's spawner keeps a
+    gap between two sessions of a port, so no scenario it generates holds this case; a replayed scenario may.  A scenario drawn by
+    ev2gym_amd's generator has its stays extended up to the step before the port's next arrival, is written as a replay file
+    (ev2gym_amd.replay.write_replay) and handed to the reference, which loads and steps it: the fixture holds the scenario as the
+    REFERENCE env carries it and the trajectory the reference produced."""
+    import tempfile
+    from ev2gym.models.ev2gym_env import EV2Gym
+    import ev2gym.rl_agent.state as S
+    import ev2gym.rl_agent.reward as RW
+    from ev2gym_amd.config import gen_config_from_yaml, load_yaml
+    from ev2gym_amd.replay import write_replay
+    from ev2gym_amd.scenario import resolve_ports
+    from ev2gym_amd.scenario_gen import generate
+    mine = os.path.join(os.path.dirname(HERE), "ev2gym_amd", "example_config_files", os.path.basename(yml))
+    batch = generate(gen_config_from_yaml({**load_yaml(mine), **over}, 1, seed))
+    a, port, last, n = batch.arrays, resolve_ports(batch), {}, 0
+    for s in range(batch.n_sessions):
+        if port[s] in last:
+            n += int(a["ev_t_dep"][last[port[s]]] != a["ev_t_arr"][s] - 1)
+            a["ev_t_dep"][last[port[s]]] = a["ev_t_arr"][s] - 1
+        last[port[s]] = s
+    assert n > 0, "no port with two sessions: pick another seed"
+    path = write_replay(os.path.join(tempfile.mkdtemp(), f"replay_sim_{name}.pkl"), batch)
+    cfg = _yaml_variant(yml, over, name)
+    env = EV2Gym(config_file=cfg, load_from_replay_path=path, state_function=getattr(S, state_fn), reward_function=getattr(RW, reward_fn))
+    run_case(name, cfg, state_fn, reward_fn, seed, policy, env=env, extra={"b2b_sessions_extended": np.array(n)})
+
+
 def main():
     import_reference()
     base = "ev2gym/example_config_files/"
@@ -393,6 +423,14 @@ def main():
         if only and c[0] not in only:
             continue
         run_replay_case(*c)
+    # back-to-back sessions on a port (replayed scenarios only: the reference's spawner keeps a gap)
+    for c in [("b2b_v2gppl_public_rand_s53", ppl, {"number_of_charging_stations": 6, "spawn_multiplier": 10, "scenario": "public"}, *PPL, 53, "rand"),
+              ("b2b_v2gmax_p2_mixed_s53", vmax, {"number_of_charging_stations": 4, "number_of_ports_per_cs": 2, "spawn_multiplier": 10, "scenario": "public"},
+               *VMX, 53, "mixed"),
+              ("b2b_pst_rand_s53", pst, {"number_of_charging_stations": 5, "spawn_multiplier": 10}, *PST, 53, "rand")]:
+        if only and c[0] not in only:
+            continue
+        run_back_to_back_case(*c)
 
 
 if __name__ == "__main__":
