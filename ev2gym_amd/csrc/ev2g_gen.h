@@ -164,7 +164,7 @@ EV2G_HD int ev2g_gen_sessions(const Ev2gGenRun &g, const Ev2gRng &r, bool weeken
             n++;
         }
     }
-    return n;   // > cap: the caller's buffer was too small (P * 8 always suffices: a stay takes at least 4 steps + the gap)
+    return n;   // > cap: the caller's buffer was too small (P * (T / 5 + 1) always suffices: a session keeps its port for at least 5 steps)
 }
 
 // ---- one scenario: one transformer -----------------------------------------------------------------------------------------------

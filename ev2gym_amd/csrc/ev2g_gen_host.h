@@ -86,7 +86,7 @@ static int ev2g_generate_impl(const ev2g_gen_config *cfg, int32_t M, uint64_t se
     bool overflow = false;
     auto work = [&](int ti) {
         const int m0 = (int)((long long)M * ti / nt), m1 = (int)((long long)M * (ti + 1) / nt);
-        const int cap = P * 8 + 8;
+        const int cap = P * (T / 5 + 2);   // a session keeps its port for at least 5 steps (arrival, >= 3 steps to the departure, the gap)
         std::vector<Ev2gGenSession> buf(cap);
         std::vector<int> free_from(P);
         std::vector<double> w(T), pad(T + 96);
