@@ -26,7 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 OUT = os.path.join(REPO, "tests", "golden")
 sys.path.insert(0, HERE)
-sys.path.insert(0, os.path.dirname(HERE))   # ev2gym_amd (scenario generator + replay writer of the back-to-back cases)
+sys.path.insert(1, os.path.dirname(HERE))   # ev2gym_amd (scenario generator + replay writer of the back-to-back cases); after HERE: `oracle` must stay oracle/oracle.py
 warnings.filterwarnings("ignore")
 
 from ref_import import import_reference  # noqa: E402
