@@ -12,7 +12,8 @@ if ROOT not in sys.path:
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 # plugin_*.npz: reference episodes with the reward built-ins beyond the three of the shipped configs (fused since round 2:
 # they run through the oracle and the engine like every other fixture; the facade tests also evaluate them on the host)
-GOLDEN_FILES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+# alphabetical, the back-to-back fixtures (added last, at the end of round 2) at the end
+GOLDEN_FILES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")), key=lambda f: (os.path.basename(f).startswith("b2b_"), f))
 GOLDEN_IDS = [os.path.basename(f)[:-4] for f in GOLDEN_FILES]
 
 
