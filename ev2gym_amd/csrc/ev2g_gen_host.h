@@ -1,6 +1,9 @@
 // ev2g_gen_host.h -- host driver of the scenario generator (ev2g_generate & co. of include/ev2g.h): slices the scenarios over
 // threads, runs ev2g_gen.h's per-scenario code, and assembles one ev2g_scenario_batch (sessions in CSR order).  Included by ev2g_host.hip.
 #pragma once
+#include <atomic>
+#include <exception>
+#include <memory>
 #include <thread>
 
 #include "ev2g_gen.h"
@@ -18,7 +21,7 @@ struct ev2g_gen_result {
 
 static int gen_fail(const char *msg) { g_create_error = msg; return EV2G_ERR_ARG; }
 
-static int ev2g_generate_impl(const ev2g_gen_config *cfg, int32_t M, uint64_t seed, int32_t n_threads, ev2g_gen_result **out) {
+static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t seed, int32_t n_threads, ev2g_gen_result **out) {
     if (out) *out = nullptr;
     if (!cfg || !out || M < 1) return gen_fail("ev2g_generate: bad arguments");
     const ev2g_gen_config &c = *cfg;
@@ -32,7 +35,8 @@ static int ev2g_generate_impl(const ev2g_gen_config *cfg, int32_t M, uint64_t se
         return gen_fail("ev2g_generate: a topology needs all nine topo_* arrays");
     if (!topo && c.number_of_ports_per_cs < 1) return gen_fail("ev2g_generate: number_of_ports_per_cs < 1");
     const int T = c.simulation_length, dt = c.timescale, C = c.number_of_charging_stations, R = c.number_of_transformers;
-    auto *res = new ev2g_gen_result();
+    std::unique_ptr<ev2g_gen_result> holder(new ev2g_gen_result());   // freed on every early return and on exceptions
+    ev2g_gen_result *res = holder.get();
     ev2g_gen_result &r = *res;
     // ---- chargers (load_ev_charger_profiles loaders.py:342-365; load_grid :494-498; topology :259-276,312-340) ----
     r.cs_min_c.resize(C); r.cs_max_c.resize(C); r.cs_min_d.resize(C); r.cs_max_d.resize(C); r.cs_volt.resize(C);
@@ -44,7 +48,7 @@ static int ev2g_generate_impl(const ev2g_gen_config *cfg, int32_t M, uint64_t se
             r.cs_min_c[i] = c.topo_min_charge_current[i]; r.cs_max_c[i] = c.topo_max_charge_current[i];
             r.cs_min_d[i] = c.topo_min_discharge_current[i]; r.cs_max_d[i] = c.topo_max_discharge_current[i];   // as written: v2g_enabled not consulted
             r.cs_volt[i] = c.topo_voltage[i]; r.cs_phases[i] = c.topo_phases[i]; r.cs_tr[i] = c.topo_transformer[i]; r.cs_np[i] = c.topo_n_ports[i];
-            if (r.cs_tr[i] < 0 || r.cs_tr[i] >= R || r.cs_np[i] < 1) { delete res; return gen_fail("ev2g_generate: topology entry out of range"); }
+            if (r.cs_tr[i] < 0 || r.cs_tr[i] >= R || r.cs_np[i] < 1) return gen_fail("ev2g_generate: topology entry out of range");
         } else {
             r.cs_min_c[i] = c.cs_min_charge_current; r.cs_max_c[i] = c.cs_max_charge_current;
             r.cs_min_d[i] = c.v2g_enabled ? c.cs_min_discharge_current : 0.0; r.cs_max_d[i] = c.v2g_enabled ? c.cs_max_discharge_current : 0.0;
@@ -83,7 +87,7 @@ static int ev2g_generate_impl(const ev2g_gen_config *cfg, int32_t M, uint64_t se
     nt = std::max(1, std::min(nt, (int)M));
     std::vector<std::vector<Ev2gGenSession>> part(nt);   // the sessions of each thread's slice, scenario after scenario
     std::vector<int> count(M, 0);
-    bool overflow = false;
+    std::atomic<bool> overflow{false};
     auto work = [&](int ti) {
         const int m0 = (int)((long long)M * ti / nt), m1 = (int)((long long)M * (ti + 1) / nt);
         const int cap = P * (T / 5 + 2);   // a session keeps its port for at least 5 steps (arrival, >= 3 steps to the departure, the gap)
@@ -117,7 +121,7 @@ static int ev2g_generate_impl(const ev2g_gen_config *cfg, int32_t M, uint64_t se
         work(0);
         for (auto &t : th) t.join();
     }
-    if (overflow) { delete res; return gen_fail("ev2g_generate: session buffer overflow (internal)"); }
+    if (overflow) return gen_fail("ev2g_generate: session buffer overflow (internal)");
     for (int m = 0; m < M; m++) r.sess_start[m + 1] = r.sess_start[m] + count[m];
     const size_t S = (size_t)r.sess_start[M];
     r.ev_cs.resize(S); r.ev_ta.resize(S); r.ev_td.resize(S); r.ev_ph.resize(S); r.ev_lut.resize(S);
@@ -185,8 +189,19 @@ static int ev2g_generate_impl(const ev2g_gen_config *cfg, int32_t M, uint64_t se
     b.ev_min_emerg = r.min_emerg.data(); b.ev_pac_max = r.pac_max.data(); b.ev_pac_min = r.pac_min.data(); b.ev_pdis_max = r.pdis_max.data();
     b.ev_pdis_min = r.pdis_min.data(); b.ev_ts = r.ts.data(); b.ev_tsm = r.tsm.data(); b.ev_eta_ch = r.eta_ch.data(); b.ev_eta_dis = r.eta_dis.data();
     b.lut = r.lut.data();
-    *out = res;
+    *out = holder.release();
     return EV2G_OK;
+}
+
+// no exception leaves the C-ABI: allocation failures (a batch too large for the host) and thread-creation failures become error codes
+static int ev2g_generate_impl(const ev2g_gen_config *cfg, int32_t M, uint64_t seed, int32_t n_threads, ev2g_gen_result **out) {
+    try {
+        return ev2g_generate_body(cfg, M, seed, n_threads, out);
+    } catch (const std::exception &e) {
+        if (out) *out = nullptr;
+        g_create_error = std::string("ev2g_generate: ") + e.what();
+        return EV2G_ERR_ARG;
+    }
 }
 
 static int ev2g_gen_default_config_impl(int kind, ev2g_gen_config *c) {
