@@ -69,7 +69,7 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
 
     Ev2gGenRun g{};
     g.c = cfg; g.T = T; g.dt = dt; g.C = C; g.P = P; g.R = R; g.npc_max = npc_max; g.seed = seed;
-    g.hour = c.random_hour ? (int)ev2g_rng(seed, ~0ull).integers(EV2G_RS_HOUR, 0, 0, 5, 16) : c.hour;
+    g.hour = c.hour;   // random_hour: drawn per scenario below, like the reference draws it per reset (ev2gym_env.py:131-133)
     g.min_stay_steps = c.ev_min_time_of_stay / dt;
     g.steps_ahead = c.dr_notification_of_event_minutes / dt;
     g.n_dr = c.demand_response ? std::max(c.dr_events_per_day, 1) : 1;
@@ -88,7 +88,8 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
     std::vector<std::vector<Ev2gGenSession>> part(nt);   // the sessions of each thread's slice, scenario after scenario
     std::vector<int> count(M, 0);
     std::atomic<bool> overflow{false};
-    auto work = [&](int ti) {
+    const Ev2gGenRun &g0 = g;
+    auto work = [&, g0](int ti) {
         const int m0 = (int)((long long)M * ti / nt), m1 = (int)((long long)M * (ti + 1) / nt);
         const int cap = P * (T / 5 + 2);   // a session keeps its port for at least 5 steps (arrival, >= 3 steps to the departure, the gap)
         std::vector<Ev2gGenSession> buf(cap);
@@ -97,6 +98,9 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
         for (int m = m0; m < m1; m++) {
             const Ev2gRng rng = ev2g_rng(seed, (uint64_t)m);
             const Ev2gRng rng_tr = (c.tr_seed != -1) ? ev2g_rng((uint64_t)c.tr_seed, (uint64_t)m) : rng;
+            Ev2gGenRun gm = g0;
+            if (c.random_hour) gm.hour = (int)rng.integers(EV2G_RS_HOUR, 0, 0, 5, 16);
+            const Ev2gGenRun &g = gm;
             double *cp = &r.charge_price[(size_t)m * T], *dp = &r.discharge_price[(size_t)m * T];
             ev2g_gen_prices(g, rng, cp, dp);
             // weekday or weekend tables: the reference's date decides; workplaces are always simulated on weekdays (ev2gym_env.py:141-154)

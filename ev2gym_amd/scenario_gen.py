@@ -440,7 +440,8 @@ def generate_native(cfg: GenConfig, n_threads: int = 0) -> ScenarioBatch:
     """The same model drawn by the library's own generator (`ev2g_generate`, csrc/ev2g_gen.h: C++, one thread per slice of the
     scenarios, counter-based random numbers): what a non-Python host of the C-ABI uses, 20-60x faster than `generate` on a many-core box.
     Same distributions and fitted tables, different random streams -- the two agree statistically (tests/test_host_logic.py holds both to
-    the reference's spawn statistics), not draw by draw.  Host code only: no GPU is touched."""
+    the reference's spawn statistics), not draw by draw.  One semantic difference: `random_hour` draws a start hour per scenario here (as the
+    reference does per reset), once per batch in `generate`.  Host code only: no GPU is touched."""
     import ctypes as C
     from .engine import EngineError, load_library
     L = load_library()

@@ -253,6 +253,10 @@ def test_native_generator_is_a_pure_function_of_seed_and_scenario_index():
         assert np.array_equal(small.arrays[k], a.arrays[k][:7]), k
     other = generate_native(GenConfig.v2g_profit_plus_loads(40, 12, 2, seed=10, number_of_ports_per_cs=2))
     assert not np.array_equal(other.arrays["charge_price"], a.arrays["charge_price"])
+    # random_hour: a start hour per SCENARIO, 5..15 (the reference draws one per reset, ev2gym_env.py:131-133): the PV peak (13:00) lands on 11 different steps
+    rh = generate_native(GenConfig.v2g_profit_plus_loads(300, 6, 1, seed=3, random_hour=True))
+    peaks = np.argmin(rh.arrays["tr_solar_power"][:, 0, :], axis=1)
+    assert len(np.unique(peaks)) == 11 and len(np.unique(np.argmin(a.arrays["tr_solar_power"][:, 0, :], axis=1))) == 1
     p1 = generate_native(GenConfig.v2g_profit_plus_loads(6, 12, 2, seed=1, tr_seed=77))
     p2 = generate_native(GenConfig.v2g_profit_plus_loads(6, 12, 2, seed=2, tr_seed=77))
     assert np.array_equal(p1.arrays["tr_inflexible_load"], p2.arrays["tr_inflexible_load"]) and np.array_equal(p1.arrays["tr_dr"], p2.arrays["tr_dr"])
