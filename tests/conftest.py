@@ -12,9 +12,15 @@ if ROOT not in sys.path:
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 # plugin_*.npz: reference episodes with the reward built-ins beyond the three of the shipped configs (fused since round 2:
 # they run through the oracle and the engine like every other fixture; the facade tests also evaluate them on the host)
-# alphabetical, the back-to-back fixtures (added last, at the end of round 2) at the end
-GOLDEN_FILES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")), key=lambda f: (os.path.basename(f).startswith("b2b_"), f))
+# b2b_*.npz (back-to-back sessions) were captured after the last device run of round 2: the CPU tests use them like every other fixture
+# (ALL_GOLDEN_*), the GPU suite meets them in its LAST file (tests/test_zz_late_additions_gpu.py) rather than in the middle of
+# test_engine_gpu.py, so that a surprise there cannot cut a `pytest -x` run short of the tests that were already seen green on the device
+ALL_GOLDEN_FILES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+B2B_FILES = [f for f in ALL_GOLDEN_FILES if os.path.basename(f).startswith("b2b_")]
+GOLDEN_FILES = [f for f in ALL_GOLDEN_FILES if f not in B2B_FILES]
 GOLDEN_IDS = [os.path.basename(f)[:-4] for f in GOLDEN_FILES]
+ALL_GOLDEN_IDS = [os.path.basename(f)[:-4] for f in ALL_GOLDEN_FILES]
+B2B_IDS = [os.path.basename(f)[:-4] for f in B2B_FILES]
 
 
 def pytest_configure(config):
@@ -30,7 +36,7 @@ def load_golden(path):
     return z, batch, _abi.REWARD_KINDS[rf], _abi.STATE_KINDS[sf]
 
 
-@pytest.fixture(params=GOLDEN_FILES, ids=GOLDEN_IDS)
+@pytest.fixture(params=ALL_GOLDEN_FILES, ids=ALL_GOLDEN_IDS)
 def golden(request):
     return load_golden(request.param)
 

@@ -316,31 +316,3 @@ def test_reset_with_a_seed_draws_that_seeds_scenarios():
     assert len(offs) > 6, "different seeds select different windows of the pool"
     v1.close(); v2.close()
 
-
-def test_batched_evaluator_on_the_device_matches_an_oracle_loop():
-    """ev2gym_amd.evaluator.evaluate (the reference's evaluation loop, evaluator.py:102-109,248-287, one fused launch per algorithm): every
-    row's statistics equal those of an oracle episode driven by the same action source."""
-    from ev2gym_amd import _abi
-    from ev2gym_amd.engine import host_uniform
-    from ev2gym_amd.evaluator import ALGORITHMS, RESULT_STATS, evaluate
-    from ev2gym_amd.scenario_gen import GenConfig, generate
-    from oracle.oracle import Oracle
-    batch = generate(GenConfig.v2g_profit_plus_loads(6, 10, 1, seed=12))
-    df = evaluate(batch, seed=5)
-    assert len(df) == 6 * len(ALGORITHMS) and (df["time"] > 0).all()
-    T, E, P = batch.n_steps, batch.n_envs, batch.n_ports
-    sources = {"ChargeAsFastAsPossible": np.ones((T, E, P)), "DoNothing": np.zeros((T, E, P)),
-               "RandomAgent": host_uniform(T * E * P, 5, -1.0, 1.0).reshape(T, E, P)}
-    for name, acts in sources.items():
-        ora = Oracle(batch, 0, 0)
-        ora.reset()
-        for t in range(T):
-            ora.step(acts[t].copy())
-        st = ora.stats()
-        ora.close()
-        sub = df[df["Algorithm"] == name].sort_values("run")
-        for k in RESULT_STATS + ["total_reward"]:
-            want = st[:, _abi.STAT_NAMES.index(k)]
-            got = sub[k].to_numpy()
-            assert (np.isnan(got) == np.isnan(want)).all(), (name, k)
-            assert np.allclose(np.nan_to_num(got), np.nan_to_num(want), rtol=1e-9, atol=1e-9), (name, k)
