@@ -51,7 +51,7 @@ def measured_traffic(workload, launch, steps_per_launch, envs):
     tools/prof_step.sh + tools/collect_evidence.py: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH doubled per
     the gfx950 note in MI355X_MICROARCH.md), or None when this workload / launch shape was not profiled."""
     t = None
-    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))[workload][launch]
             break
@@ -205,6 +205,100 @@ class PipelinedLoops:
             f.result()
 
 
+def rollout_record(Engine, batch, rk, sk, local_rank, devx, E, lo, rank, args, T, bytes_env_step, min_s=0.2):
+    """BASELINE configs[4] shape per GPU: the fused actor (obs -> 400 -> 300 -> P, tanh) produces the actions on the device
+    between single-step env launches (`ev2g_rollout`).  Returns env-steps/s of this rank and both kernel durations."""
+    import torch
+    from ev2gym_amd.actor import FusedMLPActor
+    st = devx.new_stream(make_current=False)
+    eng = Engine(batch, rk, sk, device=local_rank, stream=st, flags=0 if args.no_soc_log else _abi.FLAG_LOG_SOC, n_active_envs=E)
+    try:
+        dev, P, D = devx.device, eng.P, eng.D
+        obs = torch.empty((E, D), dtype=torch.float64, device=dev)
+        rew = torch.empty((E,), dtype=torch.float64, device=dev)
+        done = torch.empty((E,), dtype=torch.uint8, device=dev)
+        mask = torch.empty((E, P), dtype=torch.uint8, device=dev)
+        stats = torch.empty((E, _abi.N_STATS), dtype=torch.float64, device=dev)
+        actor = FusedMLPActor(eng, E, P, D, lo, dev, seed=1234 + rank)
+        loop = RolloutLoop(eng, E, P, T, eng.M, None, obs, rew, done, mask, stats, None, actor)
+        loop.reset()
+        loop.run(T, False)
+        eng.synchronize()
+        n, spent = 0, 0.0
+        while spent < min_s:
+            t0 = time.perf_counter()
+            loop.run(2 * T, False)
+            eng.synchronize()
+            spent += time.perf_counter() - t0
+            n += 2 * T
+        tim = []
+        for _ in range(64):
+            eng.step_n(1, None, 0, None, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=False)
+            tim.append(eng.last_step_n_kernel_ms())
+        step_us = float(np.median(tim)) * 1e3
+        actor_us = actor.forward_train_us(200)
+        eng.check_faults()
+        return {"env_steps_per_s_per_gpu": E * n / spent, "us_per_step_wall": spent / n * 1e6, "step_kernel_us": step_us,
+                "actor_kernel_us": actor_us, "step_kernel": eng.kernel_name,
+                "step_kernel_roofline_frac": bytes_env_step * E / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                "actor": actor.describe, "steps_timed": n,
+                "note": "single-step launches with the policy between steps (the RL-loop mode); kernel times: HIP events around "
+                        "single-step env launches / a back-to-back train of 200 actor forwards"}
+    finally:
+        eng.close()
+
+
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` with no rendezvous in the environment: re-run this file as N ranks (one per GPU) under
+    torch.distributed.run on this node -- the command the driver would type itself -- and pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+class Device:
+    """The few torch.cuda calls the benchmark makes, behind one switch: `cuda` (the product: HIP streams, RCCL) or `cpu`
+    (`--backend gloo`: tests/test_bench_launcher.py drives the launcher and the whole multi-rank control flow of this file
+    with a stand-in engine on a box without a GPU; its line is marked as such and is never a measurement)."""
+
+    def __init__(self, backend, local_rank):
+        import torch
+        self.torch, self.cuda, self.local_rank = torch, backend == "nccl", local_rank
+        self.device = torch.device("cuda", local_rank) if self.cuda else torch.device("cpu")
+        if self.cuda:
+            torch.cuda.set_device(local_rank)
+
+    def new_stream(self, make_current):
+        if not self.cuda:
+            return None
+        st = self.torch.cuda.Stream(device=self.local_rank)
+        if make_current:
+            self.torch.cuda.set_stream(st)
+        self._keep = getattr(self, "_keep", []) + [st]
+        return st.cuda_stream
+
+    def synchronize(self):
+        if self.cuda:
+            self.torch.cuda.synchronize()
+
+
+def load_engine_class(spec):
+    if not spec:
+        from ev2gym_amd.engine import Engine
+        return Engine
+    import importlib
+    mod, name = spec.split(":")
+    return getattr(importlib.import_module(mod), name)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,18 +321,23 @@ def main():
                          "produces the actions on the device between steps (forces per_step launches).  mlp: the fused one-kernel "
                          "forward of the library (bf16 MFMA); mlp_torch: the same network through torch.nn (fp32)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-rollout-record", action="store_true", help="skip the short policy-in-the-loop pass (`rollout` in the line)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)   # gloo: CPU launcher test only
+    ap.add_argument("--engine", default="", help=argparse.SUPPRESS)   # module:Class of a stand-in engine (tests only)
     args = ap.parse_args()
     if args.actor != "none":
         args.launch = "per_step"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but the rendezvous in the environment has WORLD_SIZE={world}")
+    stub = bool(args.engine) or args.backend != "nccl"
+    devx = Device(args.backend, local_rank)
     # EV2G_BENCH_FORCE_DIST=1: run the multi-process code path (process group, asynchronous gather, C-ABI gather) at any world
     # size -- under torch.distributed.run with ONE process it exercises, on a single GPU, exactly what the N-GPU launch runs
     multi = world > 1 or bool(os.environ.get("EV2G_BENCH_FORCE_DIST"))
@@ -246,9 +345,12 @@ def main():
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if devx.cuda:
+            dist.init_process_group("nccl", device_id=devx.device)
+        else:
+            dist.init_process_group("gloo")
 
-    from ev2gym_amd.engine import Engine
+    Engine = load_engine_class(args.engine)
     wl = WORKLOADS[args.workload]
     E = args.envs or wl["envs"]            # per GPU: weak scaling
     pool = args.pool or (2 if args.workload == "cfg4" else 8)
@@ -257,7 +359,7 @@ def main():
     batch = generate(wl["gen"](M, args.seed * 1000 + rank))   # every rank draws its own pool of scenarios
     phi = occupancy_fraction(batch)
     # engine kernels, torch allocations and the RCCL gather all run on ONE explicit (non-default) stream
-    dev = torch.device("cuda", local_rank)
+    dev = devx.device
     n_groups = args.actor_groups if (args.actor == "mlp" and args.actor_groups > 1 and E % args.actor_groups == 0) else 1
     Eg, Mg = E // n_groups, M // n_groups
     gath = None
@@ -267,11 +369,8 @@ def main():
     loops, engines, actor = [], [], None
     for gi in range(n_groups):
         # engine kernels, torch allocations and the RCCL gather of a group all run on ONE explicit (non-default) stream
-        tstream = torch.cuda.Stream(device=local_rank)
-        if gi == 0:
-            torch.cuda.set_stream(tstream)
         gb = batch if n_groups == 1 else batch.select(np.arange(gi * Mg, (gi + 1) * Mg))
-        eng = Engine(gb, rk, sk, device=local_rank, stream=tstream.cuda_stream,
+        eng = Engine(gb, rk, sk, device=local_rank, stream=devx.new_stream(make_current=(gi == 0)),
                      flags=0 if args.no_soc_log else _abi.FLAG_LOG_SOC, n_active_envs=Eg)
         P, D, T = eng.P, eng.D, eng.T
         acts = None
@@ -296,10 +395,10 @@ def main():
     def barrier():
         if gath is not None:
             gath.finish()
-        torch.cuda.synchronize()
+        devx.synchronize()
         if multi:
             dist.barrier()
-        torch.cuda.synchronize()
+        devx.synchronize()
 
     def timed(persistent):
         """Median over repetitions of the --steps-sized region.  One repetition = a chain of whole --steps regions long
@@ -361,7 +460,7 @@ def main():
         loop.reset()
         tim = []
         loop.run(max(min(args.steps, 2 * T), T), mode == "persistent", timing=tim)
-        torch.cuda.synchronize()
+        devx.synchronize()
         kern_ms = sum(x for x, _ in tim)
         kern_steps = sum(k for _, k in tim)
         n_launch = kern_steps if mode == "per_step" else len(tim)
@@ -373,38 +472,91 @@ def main():
                 "kernel": eng.kernel_name, "avg_launch_us": launch_s * 1e6, "steps_per_launch": kern_steps / n_launch,
                 "algorithmic_bytes_per_env_step": bytes_env_step}
 
-    roof = {m: roofline(m) for m in modes}
+    def actor_kernel_times():
+        """Policy-in-the-loop runs chain two kernels per step.  Their durations are measured apart: the single-step env kernel by
+        HIP events around single-step launches fed by the actor's action buffer, the actor forward as the average of a
+        back-to-back train of forwards (stream order: no host gap between them)."""
+        loop.reset()
+        tim = []
+        for _ in range(min(T, 64)):
+            eng.step_n(1, None, 0, None, 0, loop.rew, 0, loop.done, 0, loop.mask, 0, auto_reset=False, persistent=False)
+            tim.append(eng.last_step_n_kernel_ms())
+        step_us = float(np.median(tim)) * 1e3
+        actor_us = actor.forward_train_us(200) if hasattr(actor, "forward_train_us") else None
+        loop.reset()
+        return step_us, actor_us
+
+    if actor is None:
+        roof = {m: roofline(m) for m in modes}
+    else:   # no roofline fraction for a two-kernel chain: per-kernel times instead (never a frac computed from mixed durations)
+        step_us, actor_us = actor_kernel_times()
+        step_frac = bytes_env_step * Eg / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBPS
+        roof = {m: None for m in modes}
+        actor_times = {"step_kernel_us": step_us, "actor_kernel_us": actor_us, "step_kernel": eng.kernel_name,
+                       "step_kernel_roofline_frac": step_frac, "ms_per_step_wall": wall[best] / args.steps * 1e3}
     for e_ in engines:
         e_.check_faults()
+
+    # the configs[4]-shaped number for the driver's default run: a short policy-in-the-loop pass (fused actor obs->400->300->P
+    # between single-step launches) on a second handle over the same scenario pool, after the headline measurement
+    rollout = None
+    if actor is None and not stub and not args.no_rollout_record and args.workload != "cfg4":
+        rollout = rollout_record(Engine, batch, rk, sk, local_rank, devx, E, wl["lo"], rank, args, T, bytes_env_step)
 
     # outside the timed regions: the C-ABI's own RCCL gather (ev2g_comm_init / ev2g_gather_stats, the path of hosts without
     # torch.distributed) next to torch's, on the same statistics
     c_gather = None
-    if multi:
-        try:
-            from ev2gym_amd.dist import gather_stats_tensor
-            ids = [Engine.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            eng.comm_init(ids[0], rank, world)
-            st_all = torch.empty((world * eng.E, _abi.N_STATS), dtype=torch.float64, device=dev)
-            eng.gather_stats(st_all)
-            st_loc = torch.empty((eng.E, _abi.N_STATS), dtype=torch.float64, device=dev)
-            eng.stats(out=st_loc)
-            want = gather_stats_tensor(st_loc)
-            torch.cuda.synchronize()
+    if multi and hasattr(Engine, "comm_unique_id"):
+        # every rank takes part in every collective below whatever fails locally (an exception on one rank only would leave the
+        # others waiting): local failures are carried in `err` and agreed on before the next collective step
+        from ev2gym_amd.dist import gather_stats_tensor
+        err, ids = None, [None]
+        if rank == 0:
+            try:
+                ids = [Engine.comm_unique_id()]
+            except Exception as ex:
+                err = f"{type(ex).__name__}: {ex}"
+        dist.broadcast_object_list(ids, src=0)
+        st_all = torch.empty((world * eng.E, _abi.N_STATS), dtype=torch.float64, device=dev)
+        st_loc = torch.empty((eng.E, _abi.N_STATS), dtype=torch.float64, device=dev)
+        if ids[0] is not None:
+            try:
+                eng.comm_init(ids[0], rank, world)
+            except Exception as ex:
+                err = f"{type(ex).__name__}: {ex}"
+        ok = torch.tensor([0 if (err or ids[0] is None) else 1], dtype=torch.int64, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # the C-ABI collective is entered by all ranks or by none
+        if int(ok.item()):
+            try:
+                eng.gather_stats(st_all)
+                eng.stats(out=st_loc)
+            except Exception as ex:
+                err = f"{type(ex).__name__}: {ex}"
+        elif err is None:
+            err = "another rank could not initialise its communicator"
+        want = gather_stats_tensor(st_loc)
+        devx.synchronize()
+        if err is None and ids[0] is not None:
             c_gather = {"ranks": eng.comm_world_size, "rows": int(st_all.shape[0]),
                         "equals_torch_all_gather": bool(torch.equal(torch.nan_to_num(st_all, nan=-7.0), torch.nan_to_num(want, nan=-7.0)))}
-        except Exception as ex:   # reported, never fatal for the measurement
-            c_gather = {"error": f"{type(ex).__name__}: {ex}"}
+        else:   # reported, never fatal for the measurement
+            c_gather = {"error": err or "rank 0 could not create a communicator id"}
 
     env_steps_total = world * E * args.steps
     value = env_steps_total / wall[best]
-    per_rank = None
+    per_rank, ranks_seen = None, None
     if multi:   # what every rank measured itself (the driver computes scaling efficiency from `value`)
         mine = torch.tensor([E * args.steps / float(np.median(res[best][3]))], dtype=torch.float64, device=dev)
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         per_rank = [float(v.item()) for v in allv]
+        # what the communicator itself reports (not WORLD_SIZE echoed): its size, the blocks that came back from the all-gather
+        # above, the rows the last asynchronous statistics gather delivered, and the C-ABI communicator's own rank count
+        last = gath.finish()
+        ranks_seen = {"process_group_size": dist.get_world_size(), "backend": dist.get_backend(),
+                      "all_gather_blocks": len(per_rank), "stats_gather_rows": (int(last.shape[0]) if last is not None else 0),
+                      "stats_gather_ranks": (int(last.shape[0]) // E if last is not None else 0),
+                      "c_abi_comm_ranks": (c_gather or {}).get("ranks")}
     out = {
         "metric": "env-steps/sec (envs x chargers x steps); % HBM roofline",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -422,20 +574,29 @@ def main():
         "full_episode": full_ep,
         "roofline": roof[best],
         "roofline_by_launch_mode": roof,
-        "rccl_ranks_seen": (world if multi else None), "per_rank_env_steps_per_s": per_rank,
+        "rccl_ranks_seen": ranks_seen, "per_rank_env_steps_per_s": per_rank,
         "rccl_collectives_issued": (gath.collectives if gath is not None else 0),
         "c_abi_rccl_gather": c_gather,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(batch.select(np.arange(min(E, 512))), rk, sk, wl["lo"])
-    elif rank == 0:
-        out["cpu_baseline"] = None
+    if actor is not None:
+        out["actor_kernel_times"] = actor_times
+    if rollout is not None:
+        out["rollout"] = rollout
+    if stub:
+        out["data"] = "STUB ENGINE on CPU (launcher / control-flow test, not a measurement)"
     for e_ in engines:
         e_.close()
     if multi:
         gath.finish()
         dist.barrier()
         dist.destroy_process_group()
+    # after the process group is gone (no rank waits for this): the CPU baseline on rank 0's host cores.  At N > 1 the other
+    # ranks' processes are winding down meanwhile, so the sample is shorter there and the N = 1 line is the one to quote.
+    if rank == 0 and not args.no_cpu_baseline:
+        budget = float(os.environ.get("EV2G_BENCH_CPU_BUDGET", "12.0" if world == 1 else "4.0"))
+        out["cpu_baseline"] = cpu_baseline(batch.select(np.arange(min(E, 512))), rk, sk, wl["lo"], budget_s=budget)
+    elif rank == 0:
+        out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -60,6 +60,17 @@ class FusedMLPActor:
     def run(self, loop, k):
         loop.eng.rollout(self.mlp, k, loop.rew, 0, loop.done, 0, loop.mask, 0, auto_reset=0)
 
+    def forward_train_us(self, n=200):
+        """Average duration of one forward inside a back-to-back train of n on the engine's stream (microseconds)."""
+        import time
+        self.eng.mlp_forward(self.mlp, self.obs32, self.act32, self.E)
+        self.eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            self.eng.mlp_forward(self.mlp, self.obs32, self.act32, self.E)
+        self.eng.synchronize()
+        return (time.perf_counter() - t0) / n * 1e6
+
     def close(self):
         self.eng.mlp_destroy(self.mlp)
 
