@@ -231,11 +231,9 @@ def rollout_record(Engine, batch, rk, sk, local_rank, devx, E, lo, rank, args, T
             eng.synchronize()
             spent += time.perf_counter() - t0
             n += 2 * T
-        tim = []
-        for _ in range(64):
-            eng.step_n(1, None, 0, None, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=False)
-            tim.append(eng.last_step_n_kernel_ms())
-        step_us = float(np.median(tim)) * 1e3
+        loop.reset()   # HIP events around a train of 64 single-step launches fed by the actor's action buffer (one event pair per train)
+        eng.step_n(64, None, 0, None, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=False)
+        step_us = eng.last_step_n_kernel_ms() * 1e3 / 64
         actor_us = actor.forward_train_us(200)
         eng.check_faults()
         return {"env_steps_per_s_per_gpu": E * n / spent, "us_per_step_wall": spent / n * 1e6, "step_kernel_us": step_us,
@@ -322,6 +320,9 @@ def main():
                          "forward of the library (bf16 MFMA); mlp_torch: the same network through torch.nn (fp32)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-rollout-record", action="store_true", help="skip the short policy-in-the-loop pass (`rollout` in the line)")
+    ap.add_argument("--only-timed", action="store_true", help="profiling runs: nothing but the timed regions of the chosen launch mode "
+                    "(no whole-episode pass, no HIP-event roofline pass, no rollout record), so that a kernel trace of `--launch per_step` "
+                    "holds single-step dispatches only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)   # gloo: CPU launcher test only
     ap.add_argument("--engine", default="", help=argparse.SUPPRESS)   # module:Class of a stand-in engine (tests only)
     args = ap.parse_args()
@@ -441,7 +442,7 @@ def main():
 
     # whole episodes, the RL-free upper bound of the path: one 112-step persistent launch + statistics + reset per episode
     full_ep = None
-    if actor is None:
+    if actor is None and not args.only_timed:
         def agree_max(n):
             if not multi:
                 return n
@@ -474,19 +475,19 @@ def main():
 
     def actor_kernel_times():
         """Policy-in-the-loop runs chain two kernels per step.  Their durations are measured apart: the single-step env kernel by
-        HIP events around single-step launches fed by the actor's action buffer, the actor forward as the average of a
-        back-to-back train of forwards (stream order: no host gap between them)."""
+        HIP events around a train of single-step launches fed by the actor's action buffer, the actor forward as the average
+        of a back-to-back train of forwards (stream order: no host gap between them)."""
         loop.reset()
-        tim = []
-        for _ in range(min(T, 64)):
-            eng.step_n(1, None, 0, None, 0, loop.rew, 0, loop.done, 0, loop.mask, 0, auto_reset=False, persistent=False)
-            tim.append(eng.last_step_n_kernel_ms())
-        step_us = float(np.median(tim)) * 1e3
+        n = min(T, 64)
+        eng.step_n(n, None, 0, None, 0, loop.rew, 0, loop.done, 0, loop.mask, 0, auto_reset=False, persistent=False)
+        step_us = eng.last_step_n_kernel_ms() * 1e3 / n
         actor_us = actor.forward_train_us(200) if hasattr(actor, "forward_train_us") else None
         loop.reset()
         return step_us, actor_us
 
-    if actor is None:
+    if args.only_timed:
+        roof = {m: None for m in modes}
+    elif actor is None:
         roof = {m: roofline(m) for m in modes}
     else:   # no roofline fraction for a two-kernel chain: per-kernel times instead (never a frac computed from mixed durations)
         step_us, actor_us = actor_kernel_times()
@@ -500,7 +501,7 @@ def main():
     # the configs[4]-shaped number for the driver's default run: a short policy-in-the-loop pass (fused actor obs->400->300->P
     # between single-step launches) on a second handle over the same scenario pool, after the headline measurement
     rollout = None
-    if actor is None and not stub and not args.no_rollout_record and args.workload != "cfg4":
+    if actor is None and not stub and not args.no_rollout_record and not args.only_timed and args.workload != "cfg4":
         rollout = rollout_record(Engine, batch, rk, sk, local_rank, devx, E, wl["lo"], rank, args, T, bytes_env_step)
 
     # outside the timed regions: the C-ABI's own RCCL gather (ev2g_comm_init / ev2g_gather_stats, the path of hosts without
@@ -564,7 +565,8 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "reps": res[best][1], "regions_per_rep": res[best][2], "timing": "median over reps of (chain of `regions_per_rep` x `steps`-step regions) / regions_per_rep",
         "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": E, "scenario_pool_per_gpu": M, "chargers": C_,
-                   "transformers": R_, "steps_per_episode": T, "obs_dim": D, "occupancy_phi": round(phi, 4), "soc_log": not args.no_soc_log,
+                   "transformers": R_, "steps_per_episode": T, "obs_dim": D, "occupancy_phi": round(phi, 4),
+                   "algorithmic_bytes_per_env_step": bytes_env_step, "soc_log": not args.no_soc_log,
                    "launch": best, "actor": args.actor if actor is None else actor.describe,
                    "actor_env_groups": (n_groups if actor is not None else None),
                    "parallelism": f"env-sharded x{world}, RCCL all_gather of episode stats only (asynchronous, overlaps the next episode)"},
@@ -578,7 +580,7 @@ def main():
         "rccl_collectives_issued": (gath.collectives if gath is not None else 0),
         "c_abi_rccl_gather": c_gather,
     }
-    if actor is not None:
+    if actor is not None and not args.only_timed:
         out["actor_kernel_times"] = actor_times
     if rollout is not None:
         out["rollout"] = rollout

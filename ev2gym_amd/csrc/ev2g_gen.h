@@ -69,8 +69,10 @@ struct Ev2gRng {
         const long long n = hi - lo;
         return lo + (long long)floor(uni(stream, a, b) * (double)n);
     }
-    EV2G_HD double normal(uint64_t stream, uint64_t a, uint64_t b, double mean, double sd) const {   // Box-Muller on two counters
-        const double u1 = 1.0 - uni(stream, a, 2 * b), u2 = uni(stream, a, 2 * b + 1);
+    // Box-Muller on two counters of their own: bit 62 / 63 of `b` are never set by a uni() / integers() call site, so a normal draw
+    // shares no counter with any other draw of the same (stream, a) -- draws documented as independent are independent
+    EV2G_HD double normal(uint64_t stream, uint64_t a, uint64_t b, double mean, double sd) const {
+        const double u1 = 1.0 - uni(stream, a, b | (1ull << 62)), u2 = uni(stream, a, b | (1ull << 63));
         return mean + sd * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
     }
 };
@@ -83,6 +85,12 @@ EV2G_HD double ev2g_gen_interp24(const double *tab, double hour_of_day) {   // n
     const double f = h - (double)i;
     const double a = tab[i % 24], b = tab[(i + 1) % 24];
     return a + (b - a) * f;
+}
+// a[start:stop] of a length-n Python sequence: [*s0, *s1) (empty when *s0 >= *s1)
+EV2G_HD void ev2g_py_slice(int start, int stop, int n, int *s0, int *s1) {
+    if (start < 0) { start += n; if (start < 0) start = 0; } else if (start > n) start = n;
+    if (stop < 0) { stop += n; if (stop < 0) stop = 0; } else if (stop > n) stop = n;
+    *s0 = start; *s1 = stop;
 }
 EV2G_HD double ev2g_round_dec(double x, double scale) { return rint(x * scale) / scale; }   // np.round(x, k): round-half-even at 10^-k
 
@@ -217,13 +225,18 @@ EV2G_HD void ev2g_gen_transformer(const Ev2gGenRun &g, const Ev2gRng &r, int tr,
             capp = capp < 0 ? 0 : (capp > 100 ? 100 : capp);
             bool over = false;
             double load_max = -INFINITY;
-            for (int t = (es > 0 ? es : 0); t < ee && t < T; t++) {
+            // max_power[es:ee] is a Python slice (transformer.py:118-131): an event that starts before the simulation does has
+            // negative bounds, which count from the END of the array (es = -2, ee = 2 selects nothing; es = -8, ee = -4 hits the
+            // last steps of the episode); the recorded event keeps the raw bounds
+            int s0, s1;
+            ev2g_py_slice(es, ee, T, &s0, &s1);
+            for (int t = s0; t < s1; t++) {
                 maxp[t] = maxp[t] - maxp[t] * capp / 100;
                 if (infl[t] > maxp[t]) over = true;
                 if (infl[t] > load_max) load_max = infl[t];
             }
             if (over) {   // the load exceeds the reduced limit inside the event: the limit is lifted to the load's maximum
-                for (int t = (es > 0 ? es : 0); t < ee && t < T; t++) maxp[t] = load_max;
+                for (int t = s0; t < s1; t++) maxp[t] = load_max;
                 double mxp = -INFINITY;
                 for (int t = 0; t < T; t++) if (maxp[t] > mxp) mxp = maxp[t];
                 capp = 100 * (1 - load_max / mxp);

@@ -89,6 +89,28 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
     std::vector<int> count(M, 0);
     std::atomic<bool> overflow{false};
     const Ev2gGenRun &g0 = g;
+    // A worker thread that throws (std::bad_alloc for a batch too large for the host) must not reach std::terminate: the first
+    // exception is parked here and re-thrown on the calling thread after the joins; threads are joined on every path
+    std::exception_ptr failure;
+    std::atomic<bool> failed{false};
+    auto guarded = [&](auto &fn, int ti) {
+        try { fn(ti); }
+        catch (...) { if (!failed.exchange(true)) failure = std::current_exception(); }
+    };
+    auto run_slices = [&](auto &fn) {
+        struct Joiner { std::vector<std::thread> th; ~Joiner() { for (auto &t : th) if (t.joinable()) t.join(); } } j;
+        int ti = 1;
+        try {
+            j.th.reserve(nt);
+            for (; ti < nt; ti++) j.th.emplace_back([&, ti] { guarded(fn, ti); });
+        } catch (...) {   // thread creation failed (std::system_error): the calling thread takes the slices that have no thread
+        }
+        const int first_unthreaded = ti;
+        guarded(fn, 0);
+        for (int k = first_unthreaded; k < nt; k++) guarded(fn, k);
+        for (auto &t : j.th) t.join();
+        if (failed) std::rethrow_exception(failure);
+    };
     auto work = [&, g0](int ti) {
         const int m0 = (int)((long long)M * ti / nt), m1 = (int)((long long)M * (ti + 1) / nt);
         const int cap = P * (T / 5 + 2);   // a session keeps its port for at least 5 steps (arrival, >= 3 steps to the departure, the gap)
@@ -119,12 +141,7 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
                                &r.setpoints[(size_t)m * T], w.data(), pad.data());
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (int ti = 1; ti < nt; ti++) th.emplace_back(work, ti);
-        work(0);
-        for (auto &t : th) t.join();
-    }
+    run_slices(work);
     if (overflow) return gen_fail("ev2g_generate: session buffer overflow (internal)");
     for (int m = 0; m < M; m++) r.sess_start[m + 1] = r.sess_start[m] + count[m];
     const size_t S = (size_t)r.sess_start[M];
@@ -161,12 +178,7 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
             }
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (int ti = 1; ti < nt; ti++) th.emplace_back(fill, ti);
-        fill(0);
-        for (auto &t : th) t.join();
-    }
+    run_slices(fill);
     int NL = 0;
     if (g.lut_fleet) {   // efficiency-vs-current tables: nearest given level over 0..100 A (utils.py:279-288)
         NL = EV2G_GEN_FLEET_MAX;

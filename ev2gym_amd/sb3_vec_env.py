@@ -114,7 +114,7 @@ class EV2GymSB3VecEnv(_SB3VecEnv):
                 d.update({"action_mask": mask[i], "terminal_observation": term[i], "TimeLimit.truncated": False,
                           "episode": {"r": float(self._ep_return[i]), "l": T}})
                 infos.append(d)
-            vec.reset()
+            vec.reset(_keep_stats=True)
             obs = self._d_obs32.to_host(self._h_obs)
             self._ep_return[:] = 0.0
         return obs.copy(), rew.astype(np.float32), done, infos

@@ -387,7 +387,11 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
             es = (start_min // dt - (hour * 60 + cfg.minute) // dt).astype(int)
             ee = es + length // dt
             cap = np.clip(rng.normal(cfg.dr_event_capacity_percentage_mean, cfg.dr_event_capacity_percentage_std, (E, R)), 0, 100)
-            inside = (tt >= es[..., None]) & (tt < ee[..., None])
+            # max_power[es:ee] is a Python slice (transformer.py:118-131): negative bounds (an event that starts before the
+            # simulation does) count from the END of the array; the recorded event keeps the raw bounds
+            s0 = np.where(es < 0, np.maximum(es + T, 0), np.minimum(es, T))
+            s1 = np.where(ee < 0, np.maximum(ee + T, 0), np.minimum(ee, T))
+            inside = (tt >= s0[..., None]) & (tt < s1[..., None])
             maxp = np.where(inside, maxp - maxp * cap[..., None] / 100, maxp)
             # if the load exceeds the reduced limit inside the event, the limit is lifted to the load's maximum
             over = (inside & (infl > maxp)).any(axis=2)

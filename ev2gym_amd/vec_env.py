@@ -198,14 +198,28 @@ class EV2GymVec:
             self._pool_generation += 1
             self.scenarios = self._draw_pool(self.rank, self.world_size)
             self.engine.load(self.scenarios)
+            self._window_queue = None
         if seed is not None:
             offset = int(np.random.default_rng(int(seed)).integers(0, M)) if M > self.num_envs else 0
         else:
-            offset = int(self._rng.integers(0, M)) if M > self.num_envs else 0
+            offset = self._next_window(M)
         self.engine.reset(self._obs, offset=offset)
         self._episodes += 1
-        self.stats = None
+        if not kwargs.get("_keep_stats"):
+            self.stats = None
         return self._out(self._obs), {}
+
+    def _next_window(self, M):
+        """Scenario-pool windows WITHOUT replacement: a pass over the pool visits its M // E disjoint windows in a random order
+        (from a random base offset), so no scenario is stepped twice before every other one has been; the next pass draws a new base
+        and order.  (A uniformly random offset per episode made consecutive windows overlap.)"""
+        E = self.num_envs
+        if M <= E:
+            return 0
+        if not getattr(self, "_window_queue", None):
+            base = int(self._rng.integers(0, M))
+            self._window_queue = [(base + int(k) * E) % M for k in self._rng.permutation(M // E)]
+        return self._window_queue.pop()
 
     def _as_device_actions(self, actions):
         if self._torch is not None and self._torch.is_tensor(actions):
@@ -242,7 +256,7 @@ class EV2GymVec:
                     rew, done = rew.clone(), done.clone()
                 if self._cost is not None and self._torch is not None:
                     info["cost"] = info["cost"].clone()
-                self.reset()   # the next episode's scenarios: a fresh window of the pool
+                self.reset(_keep_stats=True)   # the next episode's scenarios: a fresh window of the pool; env.stats stays the finished episode's, like the reference's
                 return self._out(self._obs), rew, done, self._false(), info
         return self._out(self._obs), self._out(self._rew), self._out(self._done), self._false(), info
 

@@ -20,15 +20,23 @@ def test_bench_line_contract(extra):
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
-                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict)):
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
         assert isinstance(d[k], t), (k, d[k])
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["scaling"] == "weak" and d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
     assert d["value"] > 1e6 and abs(d["value"] - 512 * 20 / (d["ms_per_step"] * 20 / 1e3)) <= 1e-6 * d["value"]
+    if extra and extra[0] == "--actor":
+        # a step is a chain of two kernels: no roofline fraction from mixed durations -- per-kernel times instead, each plausible
+        assert d["roofline"] is None
+        k = d["actor_kernel_times"]
+        assert 1.0 < k["step_kernel_us"] < 200.0 and 1.0 < k["actor_kernel_us"] < 200.0 and 0.0 < k["step_kernel_roofline_frac"] < 1.0
+        return
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.0 < r["frac"] < 1.0
+    ro = d["rollout"]   # the configs[4]-shaped record rides on the default line
+    assert ro["env_steps_per_s_per_gpu"] > 1e6 and 1.0 < ro["step_kernel_us"] < 200.0 and 1.0 < ro["actor_kernel_us"] < 200.0
     if not extra or extra[0] == "--workload":
         cb = d["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
