@@ -1,7 +1,7 @@
 """ctypes mirrors of include/ev2g.h (the C-ABI structs).  Keep in sync with the header."""
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128   # EV2G_COMM_ID_BYTES = sizeof(ncclUniqueId)
 LUT_LEN = 101
 N_STATS = 17
@@ -107,7 +107,7 @@ GEN_INT_FIELDS = ["simulation_length", "timescale", "number_of_charging_stations
                   "scenario", "simulation_days", "hour", "minute", "random_hour", "v2g_enabled", "power_setpoint_enabled",
                   "inflexible_loads", "solar_power", "demand_response", "dr_events_per_day", "dr_event_length_minutes_min",
                   "dr_event_length_minutes_max", "dr_notification_of_event_minutes", "heterogeneous_ev_specs", "fleet_with_efficiency_tables",
-                  "fleet", "cs_phases", "ev_phases", "ev_min_time_of_stay", "reserved0"]
+                  "fleet", "cs_phases", "ev_phases", "ev_min_time_of_stay", "n_ev_specs"]
 GEN_DOUBLE_FIELDS = ["spawn_multiplier", "discharge_price_factor", "power_setpoint_flexiblity",
                      "inflexible_loads_capacity_multiplier_mean", "inflexible_loads_forecast_mean", "inflexible_loads_forecast_std",
                      "solar_power_capacity_multiplier_mean", "solar_power_forecast_mean", "solar_power_forecast_std",
@@ -124,6 +124,11 @@ GEN_DAYS = {"weekdays": 0, "weekends": 1, "both": 2}
 GEN_FLEETS = {"v2g2024": 0, "ev_plus_phev": 1}
 
 
+GEN_SPEC_DOUBLE = ["spec_registrations", "spec_battery_capacity", "spec_max_ac_charge_power", "spec_max_ac_discharge_power", "spec_efficiency"]
+GEN_TABLE_DOUBLE = ["tab_arrival_week", "tab_arrival_weekend", "tab_stay", "tab_energy", "tab_pv"]
+
+
 class GenConfigC(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in GEN_INT_FIELDS] + [("tr_seed", C.c_int64)] + [(n, C.c_double) for n in GEN_DOUBLE_FIELDS]
-                + [(n, _pi) for n in GEN_TOPO_INT] + [(n, _pd) for n in GEN_TOPO_DOUBLE])
+                + [(n, _pi) for n in GEN_TOPO_INT] + [(n, _pd) for n in GEN_TOPO_DOUBLE]
+                + [(n, _pd) for n in GEN_SPEC_DOUBLE] + [(n, _pd) for n in GEN_TABLE_DOUBLE] + [("n_pv", C.c_int64)])

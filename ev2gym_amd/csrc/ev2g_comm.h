@@ -44,4 +44,5 @@ struct CommState {
     double *d_send = nullptr;   // [E, 17] this rank's statistics
     int send_envs = 0;
     long long gathers = 0;      // all-gathers issued
+    int checked_envs = -1;      // the env count every rank was verified to share (-1: not verified yet)
 };

@@ -105,7 +105,29 @@ struct Ev2gGenRun {
     int n_fleet;
     bool lut_fleet;
     uint64_t seed;
+    const double *pv_series;   // tab_pv brought to the simulation timescale and smoothed (ev2g_gen_pv_series), two years long; or null
+    long long pv_per_day;      // its entries per day
 };
+
+// ---- the fleet a session's car model is drawn from: the spec file's models, or a built-in representative fleet -------------------
+struct Ev2gFleet {
+    int n;
+    const double (*builtin)[3];   // (share, battery kWh, max AC kW), when the config carries no spec file
+    const ev2g_gen_config *c;
+    EV2G_HD double share(int i) const { return c->n_ev_specs > 0 ? c->spec_registrations[i] : builtin[i][0]; }
+    EV2G_HD double battery(int i) const { return c->n_ev_specs > 0 ? c->spec_battery_capacity[i] : builtin[i][1]; }
+    EV2G_HD double pac(int i) const { return c->n_ev_specs > 0 ? c->spec_max_ac_charge_power[i] : builtin[i][2]; }
+};
+EV2G_HD Ev2gFleet ev2g_fleet(const Ev2gGenRun &g) {
+    const ev2g_gen_config &c = *g.c;
+    if (c.n_ev_specs > 0) return Ev2gFleet{c.n_ev_specs, nullptr, g.c};
+    return Ev2gFleet{g.n_fleet, (c.fleet_with_efficiency_tables || c.fleet != 1) ? EV2G_FLEET_V2G : EV2G_FLEET_EV_PHEV, g.c};
+}
+// minute of the day of step t (unwrapped hours -> 0..1439)
+EV2G_HD int ev2g_minute_of_day(const Ev2gGenRun &g, int t) {
+    const long long m = (long long)g.hour * 60 + g.c->minute + (long long)t * g.dt;
+    return (int)(((m % 1440) + 1440) % 1440);
+}
 
 // ---- one scenario: prices -----------------------------------------------------------------------------------------------------
 EV2G_HD void ev2g_gen_prices(const Ev2gGenRun &g, const Ev2gRng &r, double *charge_price, double *discharge_price) {
@@ -134,16 +156,25 @@ struct Ev2gGenSession { int port, t_arr, t_dep, model; double B, pac, cap0; };
 EV2G_HD int ev2g_gen_sessions(const Ev2gGenRun &g, const Ev2gRng &r, bool weekend, int *free_from /*[P] scratch*/, Ev2gGenSession *out, int cap) {
     const ev2g_gen_config &c = *g.c;
     const int kind = c.scenario + ((weekend && c.scenario != 0) ? 2 : 0);   // 0 workplace, 1 public, 2 private, 3 public weekend, 4 private weekend
-    const double (*fleet)[3] = (c.fleet_with_efficiency_tables || c.fleet != 1) ? EV2G_FLEET_V2G : EV2G_FLEET_EV_PHEV;
+    const Ev2gFleet fleet = ev2g_fleet(g);
     double share_sum = 0.0;
-    for (int i = 0; i < g.n_fleet; i++) share_sum += fleet[i][0];
+    for (int i = 0; i < fleet.n; i++) share_sum += fleet.share(i);
     for (int p = 0; p < g.P; p++) free_from[p] = 0;
     int n = 0;
     for (int t = 2; t < g.T - g.min_stay_steps - 1; t++) {
         const double hod = g.hour + c.minute / 60.0 + t * (double)g.dt / 60.0;
-        const double rate = ev2g_gen_interp24(EV2G_GEN_RATE[kind], hod) * (g.dt / 60.0) * c.spawn_multiplier;   // percent per step
+        double rate, stay_mean, e_mean;
+        if (c.tab_arrival_week) {   // the reference's own tables, looked up its way (utils.py:199-233, 505-528)
+            const int mod = ev2g_minute_of_day(g, t), hh = mod / 60;
+            rate = (weekend ? c.tab_arrival_weekend : c.tab_arrival_week)[mod / 15];
+            if (c.scenario == 0 && (hh < 6 || hh > 18)) rate = 0.0;
+            rate *= (g.dt / 60.0) * c.spawn_multiplier;
+            stay_mean = c.tab_stay[mod / 30]; e_mean = c.tab_energy[mod / 30];
+        } else {
+            rate = ev2g_gen_interp24(EV2G_GEN_RATE[kind], hod) * (g.dt / 60.0) * c.spawn_multiplier;   // percent per step
+            stay_mean = ev2g_gen_interp24(EV2G_GEN_STAY[kind], hod); e_mean = EV2G_GEN_ENERGY[kind];
+        }
         if (!(rate > 0.0)) continue;
-        const double stay_mean = ev2g_gen_interp24(EV2G_GEN_STAY[kind], hod), e_mean = EV2G_GEN_ENERGY[kind];
         for (int p = 0; p < g.P; p++) {
             if (free_from[p] > t) continue;   // occupied, or inside the 3-step-empty rule (utils.py:534-552)
             const uint64_t id = (uint64_t)t * (uint64_t)g.P + (uint64_t)p;
@@ -155,9 +186,9 @@ EV2G_HD int ev2g_gen_sessions(const Ev2gGenRun &g, const Ev2gRng &r, bool weeken
             if (c.heterogeneous_ev_specs) {
                 const double u = r.uni(EV2G_RS_SESSION, id, 11) * share_sum;
                 double acc = 0.0;
-                model = g.n_fleet - 1;
-                for (int i = 0; i < g.n_fleet; i++) { acc += fleet[i][0]; if (u < acc) { model = i; break; } }
-                B = fleet[model][1]; pac = fleet[model][2];
+                model = fleet.n - 1;
+                for (int i = 0; i < fleet.n; i++) { acc += fleet.share(i); if (u < acc) { model = i; break; } }
+                B = fleet.battery(model); pac = fleet.pac(model);
             }
             const long long Bi = (long long)B > 2 ? (long long)B : 2;
             double cap0 = (B < req) ? (double)r.integers(EV2G_RS_SESSION, id, 12, 1, Bi) : B - req;
@@ -204,6 +235,11 @@ EV2G_HD void ev2g_gen_transformer(const Ev2gGenRun &g, const Ev2gRng &r, int tr,
     if (c.solar_power) {
         const double a = r.uni(EV2G_RS_TR, k, 2, 0.9, 1.1), m = r.normal(EV2G_RS_TR, k, 3, c.solar_power_capacity_multiplier_mean, 0.1);
         for (int t = 0; t < T; t++) {
+            if (g.pv_series) {   // the reference's PV year (loaders.py:165-224): sun_scale carries the scenario's day of the year
+                const long long i0 = (long long)sun_scale * g.pv_per_day + (g.hour * 60 + c.minute) / g.dt;
+                solar[t] = -(g.pv_series[i0 + t] * a) * m * cap;
+                continue;
+            }
             const double tod = fmod(g.hour + c.minute / 60.0 + t * (double)g.dt / 60.0, 24.0);
             double s = sin((tod - 6.5) / 13.0 * 3.141592653589793);
             s = s > 0 ? s * sqrt(s) : 0.0;   // clip(., 0) ** 1.5

@@ -75,6 +75,34 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
     g.n_dr = c.demand_response ? std::max(c.dr_events_per_day, 1) : 1;
     g.lut_fleet = c.heterogeneous_ev_specs && c.fleet_with_efficiency_tables;
     g.n_fleet = EV2G_GEN_FLEET_MAX;
+    if (c.n_ev_specs < 0 || (c.n_ev_specs > 0 && !(c.spec_registrations && c.spec_battery_capacity && c.spec_max_ac_charge_power && c.spec_max_ac_discharge_power)))
+        return gen_fail("ev2g_generate: n_ev_specs > 0 needs the four spec_* model arrays");
+    if ((c.tab_arrival_week || c.tab_arrival_weekend || c.tab_stay || c.tab_energy) && !(c.tab_arrival_week && c.tab_arrival_weekend && c.tab_stay && c.tab_energy))
+        return gen_fail("ev2g_generate: the arrival / stay / energy tables of a data directory come together");
+    // which spec models carry an efficiency table, and the row of r.lut each one gets
+    std::vector<int> spec_row(std::max(c.n_ev_specs, 0), -1);
+    int n_spec_lut = 0;
+    if (c.n_ev_specs > 0 && c.spec_efficiency)
+        for (int i = 0; i < c.n_ev_specs; i++)
+            if (!std::isnan(c.spec_efficiency[(size_t)i * EV2G_LUT_LEN])) spec_row[i] = n_spec_lut++;
+    // pv_netherlands.csv's hourly year at the simulation timescale, smoothed like loaders.py:178-193, two years long
+    std::vector<double> pv_series;
+    if (c.solar_power && c.tab_pv && c.n_pv >= 8760) {
+        if (1440 % dt != 0 || (dt < 60 && 60 % dt != 0) || (dt > 60 && dt % 60 != 0)) return gen_fail("ev2g_generate: tab_pv needs a timescale that divides the hour or a multiple of it");
+        std::vector<double> x;
+        if (dt > 60) { const int k = dt / 60; for (long long i = 0; i + k <= c.n_pv; i += k) { double m = c.tab_pv[i]; for (int j = 1; j < k; j++) m = std::max(m, c.tab_pv[i + j]); x.push_back(m); } }
+        else { const int k = 60 / dt; x.reserve((size_t)c.n_pv * k); for (long long i = 0; i < c.n_pv; i++) for (int j = 0; j < k; j++) x.push_back(c.tab_pv[i]); }
+        const int w = std::max(60 / dt, 1);
+        std::vector<double> y(x.size());
+        double run = 0.0;
+        for (size_t i = 0; i < x.size(); i++) { run += x[i]; if (i >= (size_t)w) run -= x[i - w]; y[i] = run / (double)std::min<size_t>(i + 1, w); }   // rolling mean
+        const double alpha = 2.0 / (w + 1.0);
+        double num = 0.0, den = 0.0;
+        for (size_t i = 0; i < y.size(); i++) { num = y[i] + (1 - alpha) * num; den = 1 + (1 - alpha) * den; y[i] = num / den; }   // ewm(span=w, adjust=True)
+        pv_series = y;
+        pv_series.insert(pv_series.end(), y.begin(), y.end());
+        g.pv_series = pv_series.data(); g.pv_per_day = 1440 / dt;
+    }
     const int ND = g.n_dr;
 
     r.charge_price.resize((size_t)M * T); r.discharge_price.resize((size_t)M * T); r.setpoints.resize((size_t)M * T);
@@ -131,7 +159,8 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
             if (n > cap) { overflow = true; count[m] = 0; continue; }
             count[m] = n;
             part[ti].insert(part[ti].end(), buf.begin(), buf.begin() + n);
-            const double sun = c.solar_power ? rng_tr.uni(EV2G_RS_SOLAR_ENV, 0, 0, 0.3, 1.0) : 0.0;
+            // the env-wide sun factor: a cloudiness scale for the synthetic curve, the day of the year for the PV data
+            const double sun = !c.solar_power ? 0.0 : (g.pv_series ? (double)rng_tr.integers(EV2G_RS_SOLAR_ENV, 0, 0, 0, 365) : rng_tr.uni(EV2G_RS_SOLAR_ENV, 0, 0, 0.3, 1.0));
             for (int k = 0; k < R; k++) {
                 const size_t o = ((size_t)m * R + k) * T;
                 ev2g_gen_transformer(g, rng_tr, k, tr_cap[k], sun, &r.maxp[o], &r.minp[o], &r.infl[o], &r.solar[o], &r.lf[o], &r.pvf[o],
@@ -164,7 +193,9 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
                 if (c.heterogeneous_ev_specs) {
                     r.pac_min[s] = 0.0; r.pdis_max[s] = c.v2g_enabled ? -e.pac : 0.0; r.pdis_min[s] = 0.0; r.ev_ph[s] = 3;
                     r.ts[s] = ev2g_round_dec(0.9 - (rng.uni(EV2G_RS_SESSION, id, 20) + 0.00001) / 5, 1000.0);
-                    if (c.fleet_with_efficiency_tables) { r.ev_lut[s] = e.model; r.eta_ch[s] = NAN; r.eta_dis[s] = NAN; }
+                    if (c.n_ev_specs > 0) r.pdis_max[s] = -c.spec_max_ac_discharge_power[e.model];   // as written in the file (utils.py:303-304)
+                    if (c.n_ev_specs > 0 && spec_row[e.model] >= 0) { r.ev_lut[s] = spec_row[e.model]; r.eta_ch[s] = NAN; r.eta_dis[s] = NAN; }
+                    else if (c.n_ev_specs == 0 && c.fleet_with_efficiency_tables) { r.ev_lut[s] = e.model; r.eta_ch[s] = NAN; r.eta_dis[s] = NAN; }
                     else {
                         r.ev_lut[s] = -1;
                         r.eta_ch[s] = ev2g_round_dec(1 - (rng.uni(EV2G_RS_SESSION, id, 21) + 0.00001) / 20, 1000.0);
@@ -180,7 +211,12 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
     };
     run_slices(fill);
     int NL = 0;
-    if (g.lut_fleet) {   // efficiency-vs-current tables: nearest given level over 0..100 A (utils.py:279-288)
+    if (c.n_ev_specs > 0) {
+        NL = n_spec_lut;
+        r.lut.resize((size_t)NL * EV2G_LUT_LEN);
+        for (int i = 0; i < c.n_ev_specs; i++)
+            if (spec_row[i] >= 0) std::copy(c.spec_efficiency + (size_t)i * EV2G_LUT_LEN, c.spec_efficiency + (size_t)(i + 1) * EV2G_LUT_LEN, r.lut.begin() + (size_t)spec_row[i] * EV2G_LUT_LEN);
+    } else if (g.lut_fleet) {   // efficiency-vs-current tables: nearest given level over 0..100 A (utils.py:279-288)
         NL = EV2G_GEN_FLEET_MAX;
         r.lut.resize((size_t)NL * EV2G_LUT_LEN);
         const int levels[6] = {6, 8, 10, 12, 14, 16};

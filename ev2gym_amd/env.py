@@ -21,7 +21,8 @@ from .config import gen_config_from_yaml, load_yaml
 from .engine import Engine
 from .scenario import ScenarioBatch
 from .scenario_gen import generate
-from .vec_env import Box, _kind
+from .gym_compat import Box, EnvBase
+from .vec_env import _kind
 
 
 class EVView:
@@ -229,8 +230,10 @@ class TransformerView:
         return l, p
 
 
-class EV2Gym:
-    """Drop-in single-env `EV2Gym` running on the HIP engine (one env per handle)."""
+class EV2Gym(EnvBase):
+    """Drop-in single-env `EV2Gym` running on the HIP engine (one env per handle); a `gymnasium.Env` when gymnasium is installed
+    (ev2gym_env.py:36), registered as `EV2Gym-v1` (gym_compat.py)."""
+    metadata = {"render_modes": []}   # plots / rendering are outside the accelerated path
 
     def __init__(self, config_file=None, load_from_replay_path=None, replay_save_path='./replay/', generate_rnd_game=True,
                  seed=None, save_replay=False, save_plots=False, state_function="PublicPST",

@@ -128,6 +128,17 @@ class GenConfig:
     # "transformer", "min_charge_current", "max_charge_current", "min_discharge_current", "max_discharge_current", "voltage",
     # "phases" [C] and "tr_max_power" [R]; overrides the number_of_* / charging_station / transformer keys above
     topology: Optional[dict] = None
+    # the file `ev_specs_file` names (loaders.py:25-41; config.load_ev_specs): "registrations", "battery_capacity",
+    # "max_ac_charge_power", "max_ac_discharge_power" [n models] and "efficiency" [n, 101] (percent by charging current in A, the
+    # nearest-level fill of utils.py:268-288; a NaN row = no table in the file: a random scalar efficiency per EV).  When set it
+    # REPLACES the built-in representative fleets selected by `fleet` / `fleet_with_efficiency_tables`.
+    ev_specs: Optional[dict] = None
+    # tables of an EV2Gym data directory (config.load_data_tables): "arrival_week", "arrival_weekend" [96] arrivals per port per hour
+    # in percent by quarter hour (distribution-of-arrival*.csv), "stay" [48] mean stay in hours and "energy" [48] mean required energy
+    # in kWh by half hour of arrival (mean-session-length-per.csv, mean-demand-per-arrival.csv), "pv" [8760] hourly PV output of a
+    # year (pv_netherlands.csv).  When set they are looked up like the reference does (utils.py:199-233,505-528) INSTEAD of the fitted
+    # hour-of-day tables / the synthetic sun curve below.
+    data_tables: Optional[dict] = None
 
     @staticmethod
     def v2g_profit_plus_loads(n_envs, n_chargers=50, n_transformers=1, seed=0, **kw):
@@ -202,6 +213,33 @@ def _mean_energy_kwh(scenario, hours):
     return _hourly(scenario, "energy", hours)
 
 
+def _pv_series(pv_hourly, dt):
+    """pv_netherlands.csv's hourly year at the simulation timescale, smoothed like loaders.py:178-193 (two years long)."""
+    x = np.asarray(pv_hourly, float)
+    if dt > 60:
+        k = dt // 60
+        x = x[:len(x) // k * k].reshape(-1, k).max(axis=1)
+    elif dt < 60:
+        x = np.repeat(x, 60 // dt)
+    w = max(60 // dt, 1)
+    c = np.cumsum(np.insert(x, 0, 0.0))
+    n = np.minimum(np.arange(1, len(x) + 1), w)
+    x = (c[1:] - c[np.arange(1, len(x) + 1) - n]) / n                      # rolling(window=w, min_periods=1).mean()
+    alpha = 2.0 / (w + 1.0)                                                 # ewm(span=w, adjust=True).mean()
+    num, den, out = 0.0, 0.0, np.empty_like(x)
+    for i, v in enumerate(x):
+        num, den = v + (1 - alpha) * num, 1 + (1 - alpha) * den
+        out[i] = num / den
+    return np.concatenate([out, out])
+
+
+def _pv_windows(pv_hourly, dt, T, start_minute, day_of_year):
+    series = _pv_series(pv_hourly, dt)
+    per_day = 1440 // dt
+    i0 = np.asarray(day_of_year) * per_day + start_minute // dt
+    return series[i0[:, None] + np.arange(T)[None, :]]
+
+
 def generate(cfg: GenConfig) -> ScenarioBatch:
     rng = np.random.default_rng(cfg.seed)
     E, T, dt = cfg.n_envs, cfg.simulation_length, cfg.timescale
@@ -267,15 +305,34 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
         if not weekend.any():
             return np.broadcast_to(wd, (E, len(hod)))
         return np.where(weekend[:, None], fn(cfg.scenario + "_weekend", hod)[None, :], wd[None, :])
-    rate = table(_arrival_rate) * (dt / 60.0) * cfg.spawn_multiplier   # percent per step
-    stay_mean = table(_mean_stay_hours)
-    energy_mean = table(_mean_energy_kwh)
+    if cfg.data_tables is None:
+        rate = table(_arrival_rate) * (dt / 60.0) * cfg.spawn_multiplier   # percent per step
+        stay_mean = table(_mean_stay_hours)
+        energy_mean = table(_mean_energy_kwh)
+    else:
+        # the reference's own tables, looked up its way: arrivals by quarter hour (utils.py:505-528, workplaces only 06:00-18:59),
+        # stay / required energy by the half hour of arrival (utils.py:199-233)
+        dtab = cfg.data_tables
+        minute_of_day = np.floor(hod * 60.0 + 1e-9).astype(int) % 1440
+        q, hh = minute_of_day // 15, minute_of_day // 30
+        arr = np.where(weekend[:, None], np.asarray(dtab["arrival_weekend"], float)[q][None, :], np.asarray(dtab["arrival_week"], float)[q][None, :])
+        if cfg.scenario == "workplace":
+            arr = np.where((minute_of_day // 60 < 6) | (minute_of_day // 60 > 18), 0.0, arr)
+        rate = arr * (dt / 60.0) * cfg.spawn_multiplier
+        stay_mean = np.broadcast_to(np.asarray(dtab["stay"], float)[hh], (E, len(hod)))
+        energy_mean = np.broadcast_to(np.asarray(dtab["energy"], float)[hh], (E, len(hod)))
+    spec = cfg.ev_specs
     if cfg.heterogeneous_ev_specs:
-        fleet = _FLEET_V2G if (cfg.fleet_with_efficiency_tables or cfg.fleet != "ev_plus_phev") else _FLEET_EV_PHEV
-        share = np.array([f[0] for f in fleet])
+        if spec is not None:
+            share = np.asarray(spec["registrations"], float)
+            fleet_B = np.asarray(spec["battery_capacity"], float)
+            fleet_pac = np.asarray(spec["max_ac_charge_power"], float)
+        else:
+            fleet = _FLEET_V2G if (cfg.fleet_with_efficiency_tables or cfg.fleet != "ev_plus_phev") else _FLEET_EV_PHEV
+            share = np.array([f[0] for f in fleet])
+            fleet_B = np.array([f[1] for f in fleet])
+            fleet_pac = np.array([f[2] for f in fleet])
         share = share / share.sum()
-        fleet_B = np.array([f[1] for f in fleet])
-        fleet_pac = np.array([f[2] for f in fleet])
     se, sp, st_, sB, spac, scap0, stdep, smodel = [], [], [], [], [], [], [], []
     for t in range(2, T - min_stay_steps - 1):
         u = rng.random((E, P)) * 100.0
@@ -332,7 +389,18 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
         a["ev_pdis_min"] = np.zeros(S)
         a["ev_phases"] = np.full(S, 3, np.int32)
         a["ev_ts"] = np.round(0.9 - (rng.random(S) + 0.00001) / 5, 3)
-        if cfg.fleet_with_efficiency_tables:
+        if spec is not None:
+            # the file's own models: discharge power as written (utils.py:303-304: v2g_enabled is not consulted), an efficiency table
+            # where the model has one (utils.py:268-288), a random scalar in [0.95, 1] where it has not (:290-296)
+            a["ev_pdis_max"] = -np.asarray(spec["max_ac_discharge_power"], float)[smodel]
+            eff = np.asarray(spec["efficiency"], float).reshape(len(share), _abi.LUT_LEN)
+            has = ~np.isnan(eff[:, 0])
+            row = np.cumsum(has) - 1
+            a["lut"] = eff[has] if has.any() else np.zeros((0, _abi.LUT_LEN))
+            a["ev_lut"] = np.where(has[smodel], row[smodel], -1).astype(np.int32)
+            a["ev_eta_ch"] = np.where(has[smodel], np.nan, np.round(1 - (rng.random(S) + 0.00001) / 20, 3))
+            a["ev_eta_dis"] = np.where(has[smodel], np.nan, np.round(1 - (rng.random(S) + 0.00001) / 20, 3))
+        elif cfg.fleet_with_efficiency_tables:
             levels = [6, 8, 10, 12, 14, 16]
             a["lut"] = np.stack([_lut_from_levels(levels, f[3]) for f in _FLEET_V2G])
             a["ev_lut"] = smodel.astype(np.int32)
@@ -369,7 +437,13 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
         infl = np.clip(infl, minp, maxp)
     else:
         infl = np.zeros((E, R, T))
-    if cfg.solar_power:
+    if cfg.solar_power and cfg.data_tables is not None and cfg.data_tables.get("pv") is not None:
+        # the reference's PV data (load_pv_generation loaders.py:165-224): the hourly series of a year brought to the simulation's
+        # timescale (repeat / max-pool, rolling mean, exponentially weighted mean), the window of a random day starting at the
+        # simulation's start time
+        sun = _pv_windows(np.asarray(cfg.data_tables["pv"], float), dt, T, hour * 60 + cfg.minute, rng.integers(0, 365, E))[:, None, :]
+        solar = -(sun * rng.uniform(0.9, 1.1, (E, R, 1))) * rng.normal(cfg.solar_power_capacity_multiplier_mean, 0.1, (E, R, 1)) * tr_cap
+    elif cfg.solar_power:
         sun = np.clip(np.sin((tod - 6.5) / 13.0 * np.pi), 0, None) ** 1.5 * rng.uniform(0.3, 1.0, (E, 1, 1))
         solar = -(sun * rng.uniform(0.9, 1.1, (E, R, 1))) * rng.normal(cfg.solar_power_capacity_multiplier_mean, 0.1, (E, R, 1)) * tr_cap
         solar = np.where(tod < 24, solar, solar)
@@ -461,8 +535,8 @@ def generate_native(cfg: GenConfig, n_threads: int = 0) -> ScenarioBatch:
             v = _abi.GEN_DAYS[cfg.simulation_days]
         elif n == "fleet":
             v = _abi.GEN_FLEETS.get(cfg.fleet, 0)
-        elif n == "reserved0":
-            v = 0
+        elif n == "n_ev_specs":
+            v = 0 if cfg.ev_specs is None else len(cfg.ev_specs["registrations"])
         else:
             v = int(getattr(cfg, n))
         setattr(c, n, v)
@@ -477,6 +551,21 @@ def generate_native(cfg: GenConfig, n_threads: int = 0) -> ScenarioBatch:
             arr = np.ascontiguousarray(tp[n[5:]], np.int32 if n in _abi.GEN_TOPO_INT else np.float64)
             keep.append(arr)
             setattr(c, n, arr.ctypes.data_as(C.POINTER(C.c_int32 if n in _abi.GEN_TOPO_INT else C.c_double)))
+    if cfg.ev_specs is not None:
+        sp = cfg.ev_specs
+        for n, key in zip(_abi.GEN_SPEC_DOUBLE, ("registrations", "battery_capacity", "max_ac_charge_power", "max_ac_discharge_power", "efficiency")):
+            arr = np.ascontiguousarray(sp[key], np.float64)
+            keep.append(arr)
+            setattr(c, n, arr.ctypes.data_as(C.POINTER(C.c_double)))
+    if cfg.data_tables is not None:
+        for n, key in zip(_abi.GEN_TABLE_DOUBLE, ("arrival_week", "arrival_weekend", "stay", "energy", "pv")):
+            if cfg.data_tables.get(key) is None:
+                continue
+            arr = np.ascontiguousarray(cfg.data_tables[key], np.float64)
+            keep.append(arr)
+            setattr(c, n, arr.ctypes.data_as(C.POINTER(C.c_double)))
+            if key == "pv":
+                c.n_pv = len(arr)
     res = C.c_void_p()
     rc = L.ev2g_generate(C.byref(c), int(cfg.n_envs), int(cfg.seed) & (2 ** 64 - 1), int(n_threads), C.byref(res))
     if rc:

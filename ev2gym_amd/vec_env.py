@@ -33,17 +33,7 @@ from .scenario import ScenarioBatch
 from .scenario_gen import GenConfig, generate
 
 
-class Box:
-    """Minimal stand-in for gymnasium.spaces.Box (gymnasium is optional)."""
-
-    def __init__(self, low, high, shape, dtype=np.float64):
-        self.low = np.full(shape, low, dtype) if np.isscalar(low) else np.asarray(low, dtype)
-        self.high = np.full(shape, high, dtype) if np.isscalar(high) else np.asarray(high, dtype)
-        self.shape = tuple(shape)
-        self.dtype = np.dtype(dtype)
-
-    def sample(self):
-        return np.random.uniform(self.low, self.high).astype(self.dtype)
+from .gym_compat import Box  # noqa: E402,F401  (gymnasium.spaces.Box when gymnasium is present)
 
 
 def _kind(fn, table, what):

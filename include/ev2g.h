@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EV2G_ABI_VERSION 2
+#define EV2G_ABI_VERSION 3
 
 /* reward_function built-ins (rl_agent/reward.py) */
 #define EV2G_REWARD_PROFITMAX_TRPENALTY_USERINCENTIVES 0 /* reward.py:34-44  */
@@ -246,6 +246,10 @@ int ev2g_current_step(const ev2g_handle *h);
  * "ev2g_step_kernel"), and -- when the common-shape fast path was not taken -- why ("" otherwise). */
 const char *ev2g_kernel_name(const ev2g_handle *h);
 const char *ev2g_fallback_reason(const ev2g_handle *h);
+/* The kernel one ev2g_step_n launch of this shape runs.  Persistent launches (mode EV2G_STEPN_PERSISTENT) of the fast path with at
+ * least two fused steps, float64 actions and no in-launch reset run its software-pipelined form "ev2g_step_pipe<s,r>" (same
+ * arithmetic and results, battery maths overlapped with the previous step's outputs); everything else runs ev2g_kernel_name(). */
+const char *ev2g_launch_kernel_name(const ev2g_handle *h, int k_steps, int persistent, int auto_reset, int f32_actions);
 /* data-dependent faults recorded since the last reset (per-env flag word, device side):
  * returns 0 or EV2G_ERR_OVERCURRENT; synchronises the stream. */
 int ev2g_check_faults(ev2g_handle *h, int32_t *first_bad_env);
@@ -355,7 +359,8 @@ typedef struct ev2g_gen_config {
     int32_t dr_events_per_day, dr_event_length_minutes_min, dr_event_length_minutes_max, dr_notification_of_event_minutes;
     int32_t heterogeneous_ev_specs, fleet_with_efficiency_tables;
     int32_t fleet;           /* 0 "v2g2024", 1 "ev_plus_phev"                                      */
-    int32_t cs_phases, ev_phases, ev_min_time_of_stay, reserved0;
+    int32_t cs_phases, ev_phases, ev_min_time_of_stay;
+    int32_t n_ev_specs;      /* > 0: the car models of an EV-specification file replace the built-in fleets (spec_* below) */
     int64_t tr_seed;         /* != -1: loads / PV / events from their own seed (ev2gym_env.py:97-100) */
     double spawn_multiplier, discharge_price_factor, power_setpoint_flexiblity;
     double inflexible_loads_capacity_multiplier_mean, inflexible_loads_forecast_mean, inflexible_loads_forecast_std;
@@ -371,6 +376,16 @@ typedef struct ev2g_gen_config {
     const int32_t *topo_n_ports, *topo_transformer, *topo_phases;
     const double *topo_min_charge_current, *topo_max_charge_current, *topo_min_discharge_current, *topo_max_discharge_current;
     const double *topo_voltage, *topo_tr_max_power;
+    /* the file `ev_specs_file` names (loaders.py:25-41), or n_ev_specs = 0: per model [n_ev_specs] the registrations (sampling
+       weight), battery kWh, max AC charge / discharge kW; spec_efficiency [n_ev_specs][101] percent by charging current in A (the
+       nearest-level fill of utils.py:268-288), a row starting with NaN = the model has no table (random scalar efficiency per EV,
+       utils.py:290-296); NULL = no model has one */
+    const double *spec_registrations, *spec_battery_capacity, *spec_max_ac_charge_power, *spec_max_ac_discharge_power, *spec_efficiency;
+    /* tables of an EV2Gym data directory, or all NULL (the fitted hour-of-day tables / synthetic sun curve are used): arrivals per
+       port per hour in percent by quarter hour [96] on weekdays / weekend days, mean stay in hours and mean required energy in kWh
+       by half hour of arrival [48] (utils.py:199-233,505-528); tab_pv [n_pv] the hourly PV output of a year (loaders.py:165-224) */
+    const double *tab_arrival_week, *tab_arrival_weekend, *tab_stay, *tab_energy, *tab_pv;
+    int64_t n_pv;
 } ev2g_gen_config;
 /* fills *cfg with the values of V2GProfitPlusLoads.yaml (kind 0) or PublicPST.yaml (kind 1) */
 int ev2g_gen_default_config(int kind, ev2g_gen_config *cfg);

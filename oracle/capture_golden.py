@@ -187,6 +187,14 @@ def run_case(name, config, state_fn, reward_fn, seed, policy, steps=None, env=No
     elif policy == "mixed":     # many exact zeros and sign flips (cycle counter, a==0 branch)
         act = rng.uniform(lo, 1.0, (T, P)) * (rng.random((T, P)) < 0.7)
         act[rng.random((T, P)) < 0.1] = 1.0
+    elif policy.startswith("agent:"):
+        # actions chosen, step by step, by one of the reference's env-reading heuristics (baselines/heuristics.py:7-267); the
+        # fixture records what the agent chose.  The restated agent of ev2gym_amd (same name) is driven on the SAME reference env
+        # in lockstep and must choose the same actions bit for bit: that pins the restatement here, the GPU test pins the facade.
+        import ev2gym.baselines.heuristics as H
+        import ev2gym_amd.baselines.heuristics as MINE
+        agent, mine = getattr(H, policy[6:])(env=env), getattr(MINE, policy[6:])(env=env)
+        act = np.zeros((T, P))
     else:
         raise ValueError(policy)
     nT = T if steps is None else steps
@@ -207,6 +215,9 @@ def run_case(name, config, state_fn, reward_fn, seed, policy, steps=None, env=No
     trj["trj_obs"][0] = obs0
     info = None
     for t in range(nT):
+        if policy.startswith("agent:"):
+            act[t] = agent.get_action(env)
+            assert np.array_equal(act[t], mine.get_action(env)), (policy, t)
         a = act[t].copy()
         obs, rew, done, trunc, info = env.step(a)
         trj["trj_obs"][t + 1] = obs
@@ -415,6 +426,17 @@ def main():
               ("plugin_v2gppl_p2_pmaxv2_mixed_s34", p2, "V2G_profit_max_loads", "V2G_profitmaxV2", 34, "mixed", None),
               ("plugin_pst_pstpmaxv2_rand_s35", pst, "PublicPST", "pst_V2G_profitmaxV2", 35, "rand", None),
               ("plugin_v2gmax_c28p2r3_pstpmaxv2_s36", x3, "V2G_profit_max", "pst_V2G_profitmaxV2", 36, "rand", None)]:
+        if only and c[0] not in only:
+            continue
+        run_case(*c)
+    # env-reading heuristic agents of the reference (heuristics.py:7-267) choosing the actions: agent_*.npz
+    des80 = _yaml_variant(ppl, {"ev": {"desired_capacity": 0.8}}, "v2gppl_des80")
+    for c in [("agent_roundrobin_pst_s61", pst, *PST, 61, "agent:RoundRobin", None),
+              ("agent_roundrobin_pst_p3_s62", p3, *PST, 62, "agent:RoundRobin", None),
+              ("agent_calap_v2gppl_s63", ppl, *PPL, 63, "agent:ChargeAsLateAsPossible", None),
+              ("agent_calap_pst_s64", pst, *PST, 64, "agent:ChargeAsLateAsPossible", None),
+              ("agent_afapdes_v2gppl_des80_s65", des80, *PPL, 65, "agent:ChargeAsFastAsPossibleToDesiredCapacity", None),
+              ("agent_afapdes_v2gppl_p2_s66", p2, *PPL, 66, "agent:ChargeAsFastAsPossibleToDesiredCapacity", None)]:
         if only and c[0] not in only:
             continue
         run_case(*c)

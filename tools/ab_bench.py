@@ -21,7 +21,7 @@ def child(workload, pool, reps):
     from ev2gym_amd.engine import Engine
     from ev2gym_amd.scenario_gen import generate, occupancy_fraction
     wl = WORKLOADS[workload]
-    E = wl["envs"]
+    E = int(os.environ.get("AB_ENVS", wl["envs"]))
     M = E * pool
     gcfg = wl["gen"](M, 0)
     if os.environ.get("AB_SPAWN"):   # e.g. AB_SPAWN=0: no EV ever arrives, every step is a quiet step
@@ -35,7 +35,7 @@ def child(workload, pool, reps):
     obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
     stats = eng.empty((E, _abi.N_STATS))
     bes = P * (phi * wl["b_occ"] + (1 - phi) * wl["b_empty"]) + batch.n_transformers * wl["b_tr"] + wl["b_env"]
-    out = {"lib": os.environ.get("EV2G_LIB", "default"), "kernel": eng.kernel_name}
+    out = {"lib": os.environ.get("AB_LABEL") or os.environ.get("EV2G_LIB", "default"), "kernel": eng.launch_kernel_name(T, True)}
     off = 0
     for mode, persistent, n in (("persistent", True, reps), ("per_step", False, max(3, reps // 6))):
         ms = []
@@ -73,16 +73,26 @@ if __name__ == "__main__":
     rows = []
     for lib in libs or [""]:
         env = dict(os.environ)
+        label = lib
+        if "@" in lib:   # lib.so@VAR=value[,VAR=value]: the same library under other environment settings (e.g. EV2G_KERNEL=wave)
+            lib, sets = lib.split("@", 1)
+            for kv in sets.split(","):
+                k_, v_ = kv.split("=", 1)
+                env[k_] = v_
+        env["AB_LABEL"] = os.path.basename(label)
         if lib:
             env["EV2G_LIB"] = os.path.abspath(lib)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", wl, str(pool), str(reps)], env=env, capture_output=True, text=True)
+        for l in r.stderr.splitlines():
+            if l.startswith("[ev2g]"):
+                print(l)
         line = [l for l in r.stdout.splitlines() if l.startswith("AB ")]
         if not line:
             print(f"{lib}: FAILED\n{r.stdout[-800:]}\n{r.stderr[-1500:]}")
             continue
         d = json.loads(line[0][3:])
         rows.append(d)
-        print(f"{os.path.basename(lib) or 'default':40s} persistent {d['persistent']['us_per_step']:.3f} us/step ({d['persistent']['frac']:.4f})   "
+        print(f"{d['lib'] or 'default':34s} {d['kernel']:22s} persistent {d['persistent']['us_per_step']:.3f} us/step ({d['persistent']['frac']:.4f})   "
               f"per_step {d['per_step']['us_per_step']:.3f} us ({d['per_step']['frac']:.4f})   digest {['%.10g' % x for x in d['digest']]}", flush=True)
     if rows:
         ref = rows[0]["digest"]
