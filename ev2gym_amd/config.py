@@ -16,7 +16,9 @@ def load_yaml(path_or_dict) -> dict:
     if isinstance(path_or_dict, dict):
         return path_or_dict
     with open(path_or_dict, "r") as f:
-        return yaml.load(f, Loader=yaml.FullLoader)
+        c = yaml.load(f, Loader=yaml.FullLoader)
+    c["_config_dir"] = os.path.dirname(os.path.abspath(path_or_dict))   # where relative file names of the config are looked up as well
+    return c
 
 
 def load_topology(path, search_dirs=()) -> dict:
@@ -130,8 +132,8 @@ def _resolve_ev_specs(c, cfg, data_dir):
         name = "ev_specs.json"     # loaders.py:31-33: the packaged default
     name = str(name)
     cands = [name]
-    if isinstance(cfg, str):
-        cands.append(os.path.join(os.path.dirname(cfg), os.path.basename(name)))
+    if c.get("_config_dir"):
+        cands.append(os.path.join(c["_config_dir"], os.path.basename(name)))
     if data_dir:
         cands.append(os.path.join(data_dir, os.path.basename(name)))
     found = next((p for p in cands if os.path.isfile(p)), None)
@@ -172,7 +174,7 @@ def gen_config_from_yaml(cfg, n_envs: int, seed: int = 0, data_dir=None) -> GenC
     topology = None
     topo = c.get("charging_network_topology", "None")
     if topo not in (None, "None"):
-        dirs = [os.path.dirname(cfg)] if isinstance(cfg, str) else []
+        dirs = [c["_config_dir"]] if c.get("_config_dir") else []
         try:
             topology = load_topology(str(topo), dirs)
         except FileNotFoundError:      # ev2gym_env.py:182-186 prints this and carries on with the YAML's uniform chargers

@@ -17,7 +17,6 @@
 #include "ev2g_device.h"
 #include "ev2g_step_v2.h"
 #include "ev2g_step_wave.h"
-#include "ev2g_step_pipe.h"
 #include "ev2g_mlp.h"
 #include "ev2g_comm.h"
 #include <cstdlib>
@@ -50,12 +49,6 @@ struct ev2g_handle {
     V2P *d_v2p = nullptr;                       // device copy of the v2 kernel's parameter block
     int block = 0;                              // 256/512/1024: v2 kernel; 0: generic kernel (P > 1024)
     bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
-    bool pipe_ok = false;                       // persistent launches of the fast path may run ev2g_step_pipe (software-pipelined form)
-    int pipe_groups = 0;                        // its grid and dynamic LDS
-    size_t pipe_lds = 0;
-    const void *pipe_fn = nullptr;
-    int pipe_blocks_per_cu = 0;                 // what the runtime says fits on a CU (hipOccupancyMaxActiveBlocksPerMultiprocessor)
-    std::string pipe_name;
     std::string kernel_name;                    // the step kernel ev2g_load_scenarios selected (ev2g_kernel_name)
     std::string fallback_reason;                // why the common-shape fast path was NOT taken ("" when it was / does not apply)
     int current_step = 0;
@@ -112,23 +105,6 @@ static int dalloc(ev2g_handle *h, std::vector<void *> &pool, size_t n, T **dst) 
 static void free_pool(std::vector<void *> &pool) {
     for (void *p : pool) (void)hipFree(p);
     pool.clear();
-}
-
-static bool use_pipe(const ev2g_handle *h, bool f64_actions, int k, int auto_reset);
-// the instantiation of ev2g_step_pipe for a (state, reward) pair (rewards beyond the three compiled-in ones share instantiation 3)
-static const void *pipe_kernel_for(int sk, int rk) {
-#ifdef EV2G_ONLY_00
-    return (sk == 0 && rk == 0) ? (const void *)ev2g_step_pipe<0, 0> : nullptr;
-#else
-#define EV2G_PIPE_CASE(SK, RK) case SK * 4 + RK: return (const void *)ev2g_step_pipe<SK, RK>;
-    switch (sk * 4 + rk) {
-        EV2G_PIPE_CASE(0, 0) EV2G_PIPE_CASE(0, 1) EV2G_PIPE_CASE(0, 2) EV2G_PIPE_CASE(0, 3)
-        EV2G_PIPE_CASE(1, 0) EV2G_PIPE_CASE(1, 1) EV2G_PIPE_CASE(1, 2) EV2G_PIPE_CASE(1, 3)
-        EV2G_PIPE_CASE(2, 0) EV2G_PIPE_CASE(2, 1) EV2G_PIPE_CASE(2, 2) EV2G_PIPE_CASE(2, 3)
-    }
-#undef EV2G_PIPE_CASE
-    return nullptr;
-#endif
 }
 
 extern "C" {
@@ -202,10 +178,6 @@ int ev2g_n_steps(const ev2g_handle *h) { return h ? h->T : 0; }
 int ev2g_current_step(const ev2g_handle *h) { return h ? h->current_step : 0; }
 const char *ev2g_kernel_name(const ev2g_handle *h) { return (h && h->loaded) ? h->kernel_name.c_str() : ""; }
 const char *ev2g_fallback_reason(const ev2g_handle *h) { return (h && h->loaded) ? h->fallback_reason.c_str() : ""; }
-const char *ev2g_launch_kernel_name(const ev2g_handle *h, int k_steps, int persistent, int auto_reset, int f32_actions) {
-    if (!h || !h->loaded) return "";
-    return (persistent && use_pipe(h, !f32_actions, k_steps, auto_reset)) ? h->pipe_name.c_str() : h->kernel_name.c_str();
-}
 
 static const char *kStatNames[EV2G_N_STATS] = {
     "total_ev_served", "total_profits", "total_energy_charged", "total_energy_discharged",
@@ -509,29 +481,6 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         h->lds_bytes = ev2g_generic_lds_bytes(s.G, P, R, npc);
     if (h->lds_bytes > 160 * 1024)
         return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: ports per env exceed the LDS staging capacity (P <= ~2400)");
-    h->pipe_ok = false;
-    if (h->wave_path && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY)) {   // persistent launches: the software-pipelined form (ev2g_step_pipe.h)
-        const char *kn = std::getenv("EV2G_KERNEL");
-        const int Gp = EV2G_PIPE_ENVW * (64 / P);
-        h->pipe_fn = pipe_kernel_for(sk, std::min(h->cfg.reward_kind, 3));
-        if (!(kn && std::string(kn) == "wave") && h->pipe_fn) {
-            h->pipe_groups = (E + Gp - 1) / Gp;
-            h->pipe_lds = ev2g_pipe_lds_bytes(Gp);
-            HIPCHK(h, hipFuncSetAttribute(h->pipe_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->pipe_lds));
-            char nm[64];
-            std::snprintf(nm, sizeof nm, "ev2g_step_pipe<%d,%d>", sk, std::min(h->cfg.reward_kind, 3));
-            h->pipe_name = nm;
-            h->pipe_ok = true;
-            // the pipelined form only pays when the chip holds as many envs per CU as with ev2g_step_wave (two of its workgroups);
-            // ask the runtime instead of assuming (LDS granularity / reserved LDS decide whether the second workgroup fits)
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h->pipe_fn, EV2G_PIPE_BLOCK, h->pipe_lds) != hipSuccess) per_cu = 0;
-            h->pipe_blocks_per_cu = per_cu;
-            if (std::getenv("EV2G_DEBUG"))
-                std::fprintf(stderr, "[ev2g] %s: %d workgroups of %d threads, %zu B LDS each, %d resident per CU\n", nm, h->pipe_groups, EV2G_PIPE_BLOCK,
-                             h->pipe_lds, per_cu);
-        }
-    }
     {
         const void *fn = h->block == 256 ? (const void *)ev2g_step_v2<256>
                          : h->block == 512 ? (const void *)ev2g_step_v2<512>
@@ -790,29 +739,8 @@ static StepIO make_io(const ev2g_handle *h, const double *actions, long long a_s
     return io;
 }
 
-// which kernel a launch of this shape runs: the pipelined form needs >= 2 fused steps, float64 actions, no in-launch reset
-static bool use_pipe(const ev2g_handle *h, bool f64_actions, int k, int auto_reset) {
-    return h->pipe_ok && f64_actions && k >= 2 && !auto_reset;
-}
-
 static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int auto_reset) {
     const DevScn &s = h->scn;
-    if (h->wave_path && use_pipe(h, io.actions != nullptr, k, auto_reset)) {
-        const long long lim = 1ll << 32;
-        const ev2g_step_extras &x = h->extras;
-        if (io.a_stride * 8 >= lim || io.o_stride * 8 >= lim || io.r_stride * 8 >= lim || io.d_stride >= lim || io.m_stride >= lim ||
-            x.cost_step_stride * 8 >= lim || x.obs_f32_step_stride * 4 >= lim || io.a_stride < 0 || io.o_stride < 0 || io.r_stride < 0 ||
-            io.d_stride < 0 || io.m_stride < 0 || x.cost_step_stride < 0 || x.obs_f32_step_stride < 0)
-            return fail(h, EV2G_ERR_ARG, "ev2g_step_n: a step stride is negative or reaches 4 GiB (unsupported by the fast-path kernel)");
-        const V2P *pp = (const V2P *)h->d_v2p;
-        const DevState &st = h->st;
-        WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
-                    st.env_acc, s.cs_pack};
-        StepIO io2 = io;
-        void *args[] = {(void *)&pp, (void *)&io2, (void *)&t0, (void *)&k, (void *)&wa};
-        HIPCHK(h, hipLaunchKernel(h->pipe_fn, dim3(h->pipe_groups), dim3(EV2G_PIPE_BLOCK), args, h->pipe_lds, h->stream));
-        return EV2G_OK;
-    }
     if (h->wave_path) {
         // the fast path advances its output pointers by 32-bit byte strides
         const long long lim = 1ll << 32;

@@ -228,10 +228,13 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         double cap_before = 0.0;
         int ta_a = EV2G_INT_MAX, td_a = -1;   // this port's window as phase A saw it (idle lanes: no event)
         if (valid) {
-            const int ta = s_ta[tid_l], td = s_td[tid_l];
+            // every LDS operand of the phase in one batch (one wait) instead of one round trip per branch
+            int ta = s_ta[tid_l], td = s_td[tid_l];
+            double cap_b = s_cap[tid_l], c_thr = s_cst[0 * 64 + q_l], c_dmin = s_cst[1 * 64 + q_l];
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta), "+v"(td), "+v"(cap_b), "+v"(c_thr), "+v"(c_dmin));
             ta_a = ta; td_a = td;
             occ = (ta <= t) && (t <= td);
-            if (log_soc && occ) cap_before = s_cap[tid_l];
+            if (log_soc && occ) cap_before = cap_b;
             double a = occ ? a_next : 0.0;
             // one port per charger: a / sum(a) = a / a, which is exactly +-1 for every finite action (ev_charger.py:143-149)
             if (a > 1.0) a = 1.0;
@@ -239,8 +242,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             double amps = 0.0;
             if (occ) {
                 const double x = rnd5_x(a);
-                if (x > 0.0) { amps = x * c_imax; if (amps < s_cst[0 * 64 + q_l]) amps = 0.0; }
-                else if (x < 0.0) { const double c_dmin = s_cst[1 * 64 + q_l]; amps = x * c_dmaxabs; if (amps > c_dmin - 0.01) amps = c_dmin; }
+                if (x > 0.0) { amps = x * c_imax; if (amps < c_thr) amps = 0.0; }
+                else if (x < 0.0) { amps = x * c_dmaxabs; if (amps > c_dmin - 0.01) amps = c_dmin; }
             }
             s_amps[tid_l] = amps;
             stage[0 * RS + tid_l] = 0.0;
@@ -359,26 +362,33 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         bool occ_any = false;   // an EV on this port before or after the step
         if (valid) {
             double profit = 0.0, satpen = 0.0, pot = 0.0;
-            int ta = s_ta[tid_l], td = s_td[tid_l];
+            // every LDS operand of this phase in ONE batch (one wait), whichever branch consumes it: read one by one behind the
+            // branches below, each of them was its own LDS round trip on the workgroup-step chain
+            int ta = s_ta[tid_l], td = s_td[tid_l], ss_now = s_ss[tid_l];
             double cap = s_cap[tid_l];
+            double b_energy = s_amps[tid_l], b_cur = stage[7 * RS + tid_l], b_ech = stage[4 * RS + tid_l], b_edis = stage[5 * RS + tid_l];
+            double b_bcap = s_bcap[tid_l], b_potc = s_potc[tid_l], b_tot = (SK == 1) ? s_tot[tid_l] : 0.0;
+            double c_maxp = s_cst[2 * 64 + q_l], c_minp = s_cst[3 * 64 + q_l];
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta), "+v"(td), "+v"(ss_now), "+v"(cap), "+v"(b_energy), "+v"(b_cur), "+v"(b_ech), "+v"(b_edis),
+                         "+v"(b_bcap), "+v"(b_potc), "+v"(b_tot), "+v"(c_maxp), "+v"(c_minp));
             bool departed = false;
             if (occ) {
-                const double energy = s_amps[tid_l];
-                const double current = stage[7 * RS + tid_l];
+                const double energy = b_energy;
+                const double current = b_cur;
                 if (energy != 0.0) {  // profit by the sign of the ACTION (ev_charger.py:178,194), staged under 4 / 5
-                    const double ech = stage[4 * RS + tid_l];
-                    profit = (ech != 0.0) ? ech * pf_pch : stage[5 * RS + tid_l] * pf_pdis;
+                    const double ech = b_ech;
+                    profit = (ech != 0.0) ? ech * pf_pch : b_edis * pf_pdis;
                 }
                 if (log_cs && energy != 0.0) {   // charger accumulators (ev_charger.py:178-181,194-197): one lane per charger and step
                     __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_profits + g8), profit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_e_ch + g8), stage[4 * RS + tid_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_e_dis + g8), stage[5 * RS + tid_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_e_ch + g8), b_ech, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)((gptr)S->cs_e_dis + g8), b_edis, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (current - 0.0001 > c_imax) stg32<int>(S->env_fault, (unsigned)e_l * 4u, 1);  // ev_charger.py:203-205
                 if (last_step) { stg32<double>(PA(EV2G_PS_PENERGY), g8, energy); stg32<double>(PA(EV2G_PS_PCURRENT), g8, current); }
                 if (log_soc) stg32<double>(S->soc_log + (long long)t * P, g8 + (unsigned)e_l * (unsigned)((T - 1) * P * 8), (current != 0.0) ? cap_before : -cap_before);
                 if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
-                    const int ss = s_ss[tid_l];
+                    const int ss = ss_now;
                     const double des = pf_r6.y;
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
                     if (RK == 3) satpen = ev2g_departure_term(S->reward_kind, S->cost_kind, score, cap, des);
@@ -394,7 +404,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     ta = pf_r7.x; td = pf_r7.y;   // window of the port's next session
                     departed = true;
                     s_ta[tid_l] = ta; s_td[tid_l] = td;
-                    s_ss[tid_l] = (ta != EV2G_INT_MAX) ? ss + 1 : -1;
+                    ss_now = (ta != EV2G_INT_MAX) ? ss + 1 : -1;
+                    s_ss[tid_l] = ss_now;
                     s_cyc[tid_l] = 0;
                     s_dirty[tid_l] |= 2;
                 }
@@ -402,7 +413,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             if (ta == sstep) {  // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
                 if (departed) {   // the next session arrives right behind a departure of this very step (the reference's spawner leaves a
                                   // gap, replayed scenarios need not): its record was not the one prefetched
-                    const unsigned r8 = (unsigned)s_ss[tid_l] * (unsigned)sizeof(SessRec);
+                    const unsigned r8 = (unsigned)ss_now * (unsigned)sizeof(SessRec);
                     pf_r4 = ldg32<d2v>(S->rec, r8 + 64u); pf_r5 = ldg32<d2v>(S->rec, r8 + 80u);
                     pf_r6 = ldg32<d2v>(S->rec, r8 + 96u); pf_r7 = ldg32<i4v>(S->rec, r8 + 112u);
                 }
@@ -413,6 +424,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 const double potc = v * ((evc < c_imax) ? evc : c_imax) / 1000.0;
                 s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
                 s_abse[tid_l] = 0.0;
+                b_bcap = B; b_potc = potc; b_tot = 0.0;
                 const int lut_new = pf_r7.z;
                 stg32<int>(PA(EV2G_PS_LUT), g8 >> 1, lut_new);
                 stg32<double>(PA(EV2G_PS_BCAP), g8, B);
@@ -423,7 +435,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
             const bool occ_after = (ta <= sstep) && (sstep <= td);
             if (RK == 3 && occ_after && S->reward_kind >= 9) {   // (pst_)V2G_profitmaxV2: every connected EV (reward.py:173-195)
-                const unsigned r8 = (unsigned)s_ss[tid_l] * (unsigned)sizeof(SessRec);
+                const unsigned r8 = (unsigned)ss_now * (unsigned)sizeof(SessRec);
                 satpen += ev2g_connected_term(ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, des)), cap,
                                               ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, pacmax)), sixty_over_dt, td, sstep);
             }
@@ -431,15 +443,12 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             if (mask) stg32<uint8_t>(mask, (unsigned)g_l, occ_after ? 1 : 0);
             double o0 = 0.0, o1 = 0.0, o2 = 0.0;
             if (occ_after) {
-                const double soc = cap / s_bcap[tid_l];
-                if (SK == 1) { o0 = (soc == 1.0) ? 1.0 : 0.5; o1 = s_tot[tid_l]; o2 = (double)(sstep - ta); }
+                const double soc = cap / b_bcap;
+                if (SK == 1) { o0 = (soc == 1.0) ? 1.0 : 0.5; o1 = b_tot; o2 = (double)(sstep - ta); }
                 else { o0 = soc; o1 = (double)(td - sstep); }
-                if (soc < 1.0 && td > sstep) pot = s_potc[tid_l];  // utils.py:771
+                if (soc < 1.0 && td > sstep) pot = b_potc;  // utils.py:771
             }
-            {   // per-charger clamp (utils.py:779-789)
-                const double c_maxp = s_cst[2 * 64 + q_l], c_minp = s_cst[3 * 64 + q_l];
-                pot = (pot > c_maxp) ? c_maxp : ((pot < c_minp) ? 0.0 : pot);
-            }
+            pot = (pot > c_maxp) ? c_maxp : ((pot < c_minp) ? 0.0 : pot);   // per-charger clamp (utils.py:779-789)
             if (obs) {
                 const unsigned o8 = (unsigned)(e_l * D + ocol) * 8u;
                 stg32<d2v>(obs, o8, (d2v){o0, o1});   // one 16-byte store (D and the column offset are even for SK != 1)
@@ -451,7 +460,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 else stg32<f2v>(obs32, o4, (f2v){(float)o0, (float)o1});
             }
             if (log_cs) {   // cs_power / cs_current of the step (ev2gym_env.py:533-535) and the chargers' current_power_output / current_total_amps
-                const double pw = occ ? stage[0 * RS + tid_l] : 0.0, cur = occ ? stage[7 * RS + tid_l] : 0.0;
+                const double pw = occ ? stage[0 * RS + tid_l] : 0.0, cur = occ ? b_cur : 0.0;
                 const unsigned hc8 = ((unsigned)(t * E + e_l) * (unsigned)P + (unsigned)q_l) * 8u;
                 stg32<double>(S->cs_power_hist, hc8, pw); stg32<double>(S->cs_cur_hist, hc8, cur);
                 if (last_step) { stg32<double>(S->cs_power_now, g8, pw); stg32<double>(S->cs_cur_now, g8, cur); }

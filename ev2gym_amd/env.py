@@ -240,7 +240,7 @@ class EV2Gym(EnvBase):
                  reward_function="SquaredTrackingErrorReward", cost_function=None, eval_mode="Normal",
                  lightweight_plots=False, empty_ports_at_end_of_simulation=True, extra_sim_name=None, verbose=False,
                  render_mode=None, scenario: Optional[ScenarioBatch] = None, device: int = 0,
-                 log_cs_history: bool = True):
+                 log_cs_history: bool = True, data_dir=None):
         if save_plots or render_mode:
             raise NotImplementedError("plots and rendering are outside the accelerated path (SURVEY.md §2)")
         self.save_replay, self.replay_path, self.extra_sim_name = bool(save_replay), replay_save_path, extra_sim_name
@@ -252,6 +252,8 @@ class EV2Gym(EnvBase):
         if scenario is None:
             assert config_file is not None, "Please provide a config file!!!"   # ev2gym_env.py:64
             self.config = load_yaml(config_file)
+            if data_dir is not None:   # an EV2Gym install's ev2gym/data: its spawn tables / PV year / EV-spec files instead of the fitted stand-ins
+                self.config = {**self.config, "data_dir": str(data_dir)}
             self.seed = np.random.randint(0, 1000000) if seed is None else seed
             scenario = generate(gen_config_from_yaml(self.config, 1, self.seed))
         else:

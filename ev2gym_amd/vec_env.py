@@ -58,7 +58,7 @@ class EV2GymVec:
                  reward_function="SquaredTrackingErrorReward", cost_function=None, seed: Optional[int] = None,
                  scenarios: Optional[ScenarioBatch] = None, auto_reset: bool = False, log_cs_history: bool = False, log_soc: bool = True,
                  use_torch: Optional[bool] = None, rank: int = 0, world_size: int = 1, verbose: bool = False,
-                 load_from_replay_path=None, pool_factor: int = 8, resample_every: Optional[int] = None, generator: str = "numpy", **unused):
+                 load_from_replay_path=None, pool_factor: int = 8, resample_every: Optional[int] = None, generator: str = "numpy", data_dir=None, **unused):
         self.state_kind = _kind(state_function, _abi.STATE_KINDS, "state_function")
         self.reward_kind = _kind(reward_function, _abi.REWARD_KINDS, "reward_function")
         if self.state_kind is None or self.reward_kind is None:
@@ -90,6 +90,8 @@ class EV2GymVec:
             if config_file is None:
                 raise AssertionError("Please provide a config file!!!")   # ev2gym_env.py:64
             self.config = load_yaml(config_file)
+            if data_dir is not None:   # an EV2Gym install's ev2gym/data: its spawn tables / PV year / EV-spec files instead of the fitted stand-ins
+                self.config = {**self.config, "data_dir": str(data_dir)}
             self._n_req, self._world = int(num_envs), int(world_size)
             scenarios = self._draw_pool(rank, world_size)
             n_active = int(num_envs)

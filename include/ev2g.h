@@ -246,10 +246,6 @@ int ev2g_current_step(const ev2g_handle *h);
  * "ev2g_step_kernel"), and -- when the common-shape fast path was not taken -- why ("" otherwise). */
 const char *ev2g_kernel_name(const ev2g_handle *h);
 const char *ev2g_fallback_reason(const ev2g_handle *h);
-/* The kernel one ev2g_step_n launch of this shape runs.  Persistent launches (mode EV2G_STEPN_PERSISTENT) of the fast path with at
- * least two fused steps, float64 actions and no in-launch reset run its software-pipelined form "ev2g_step_pipe<s,r>" (same
- * arithmetic and results, battery maths overlapped with the previous step's outputs); everything else runs ev2g_kernel_name(). */
-const char *ev2g_launch_kernel_name(const ev2g_handle *h, int k_steps, int persistent, int auto_reset, int f32_actions);
 /* data-dependent faults recorded since the last reset (per-env flag word, device side):
  * returns 0 or EV2G_ERR_OVERCURRENT; synchronises the stream. */
 int ev2g_check_faults(ev2g_handle *h, int32_t *first_bad_env);

@@ -570,3 +570,88 @@ def test_native_generator_survives_a_request_it_cannot_allocate():
     assert rc != 0 and not out.value
     assert L.ev2g_generate(C.byref(cfg), 2, 1, 2, C.byref(out)) == 0 and out.value
     L.ev2g_gen_free(out)
+
+
+def _write_data_dir(d, scenario_cols=("private", "public", "workplace")):
+    """A small EV2Gym-style data directory (the file names and layouts of ev2gym/data, synthetic numbers)."""
+    import csv
+    q = [f"{m // 60:02d}:{m % 60:02d}" for m in range(0, 1440, 15)]
+    for name, vals in (("distribution-of-arrival.csv", lambda i: 3.0 if 32 <= i < 44 else 0.0),        # arrivals only 08:00-10:59
+                       ("distribution-of-arrival-weekend.csv", lambda i: 1.0)):
+        with open(os.path.join(d, name), "w", newline="", encoding="utf-8-sig") as f:
+            w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+            cols = scenario_cols if "weekend" not in name else scenario_cols[:2]
+            w.writerow(["Arrival time", *cols])
+            for i, t in enumerate(q):
+                w.writerow([t] + [vals(i)] * len(cols))
+    h = [f"{m // 60:02d}:{m % 60:02d}" for m in range(0, 1440, 30)]
+    for name, v in (("mean-session-length-per.csv", 4.0), ("mean-demand-per-arrival.csv", 20.0)):
+        with open(os.path.join(d, name), "w", newline="", encoding="utf-8-sig") as f:
+            w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+            w.writerow(["Arrival Time", "home", "public", "work"])
+            for t in h:
+                w.writerow([t, v, v, v])
+    with open(os.path.join(d, "pv_netherlands.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["time", "local_time", "electricity"])
+        for i in range(8760):
+            w.writerow([f"h{i}", f"h{i}", 0.5 if 10 <= i % 24 < 14 else 0.0])    # sun between 10:00 and 13:59 every day
+
+
+@pytest.mark.parametrize("backend", ["numpy", "native"])
+def test_ev_specs_file_named_by_the_yaml_is_read(tmp_path, backend):
+    """loaders.py:25-41: the fleet comes from the JSON `ev_specs_file` names.  A two-model file must give exactly those two
+    batteries / powers (in the registrations' proportions), the efficiency table where the model has one and a scalar where it has
+    not, the discharge power as written; a path that cannot be read is an error -- except for the three files EV2Gym ships, whose
+    built-in stand-in fleets still meet the reference's spawn statistics (the tests above)."""
+    import json
+    from ev2gym_amd.config import gen_config_from_yaml, load_yaml
+    from ev2gym_amd.scenario_gen import generate_native
+    gen = generate if backend == "numpy" else generate_native
+    spec = {"Tiny": {"number_of_registrations": 300, "battery_capacity": 21.5, "max_ac_charge_power": 3.7, "max_ac_discharge_power": 0,
+                     "max_dc_charge_power": 50},
+            "Big": {"number_of_registrations": 100, "battery_capacity": 88.0, "max_ac_charge_power": 22, "max_ac_discharge_power": 11,
+                    "max_dc_charge_power": 150, "ch_current": [6, 16, 32], "3ph_ch_efficiency": [80, 0, 95]}}
+    path = str(tmp_path / "my_fleet.json")
+    json.dump(spec, open(path, "w"))
+    y = {**load_yaml(os.path.join(CFG, "V2GProfitPlusLoads.yaml")), "ev_specs_file": path}
+    b = gen(gen_config_from_yaml(y, 200, 5))
+    a = b.arrays
+    assert set(np.unique(a["ev_B"])) == {21.5, 88.0} and set(np.unique(a["ev_pac_max"])) == {3.7, 22.0}
+    big = a["ev_B"] == 88.0
+    assert abs(big.mean() - 0.25) < 0.03
+    assert (a["ev_pdis_max"][big] == -11.0).all() and (a["ev_pdis_max"][~big] == 0).all()
+    assert b.n_lut == 1 and (a["ev_lut"][big] == 0).all() and (a["ev_lut"][~big] == -1).all()
+    assert np.isnan(a["ev_eta_ch"][big]).all() and ((a["ev_eta_ch"][~big] >= 0.95) & (a["ev_eta_ch"][~big] <= 1.0)).all()
+    lut = a["lut"][0]   # nearest level with a non-zero efficiency (utils.py:279-288): the 16 A entry is 0 in the file
+    assert lut[6] == 80 and lut[0] == 80 and lut[16] == 80 and lut[19] == 80 and lut[20] == 95 and lut[32] == 95 and lut[100] == 95
+    with pytest.raises(FileNotFoundError):
+        gen_config_from_yaml({**y, "ev_specs_file": str(tmp_path / "no_such_fleet.json")}, 2, 1)
+    g = gen_config_from_yaml({**y, "ev_specs_file": "./ev2gym/data/ev_specs_v2g_enabled2024.json"}, 2, 1)   # shipped name, file absent: stand-in
+    assert g.ev_specs is None and g.fleet == "v2g2024" and g.fleet_with_efficiency_tables
+
+
+@pytest.mark.parametrize("backend", ["numpy", "native"])
+def test_data_dir_tables_replace_the_fitted_ones(tmp_path, backend):
+    """`data_dir=` (an EV2Gym install's ev2gym/data): arrivals follow distribution-of-arrival*.csv by quarter hour, stays / required
+    energy the half-hourly means (utils.py:199-233,505-528), PV the smoothed pv_netherlands.csv window (loaders.py:165-224)."""
+    from ev2gym_amd.config import gen_config_from_yaml, load_yaml
+    from ev2gym_amd.scenario_gen import generate_native
+    gen = generate if backend == "numpy" else generate_native
+    _write_data_dir(str(tmp_path))
+    y = {**load_yaml(os.path.join(CFG, "V2GProfitPlusLoads.yaml")), "scenario": "public", "demand_response": {"include": False},
+         "ev": {**load_yaml(os.path.join(CFG, "V2GProfitPlusLoads.yaml"))["ev"], "min_time_of_stay": 60}}
+    g = gen_config_from_yaml(y, 300, 9, data_dir=str(tmp_path))
+    assert g.data_tables is not None and g.data_tables["arrival_week"][33] == 3.0 and len(g.data_tables["pv"]) == 8760
+    b = gen(g)
+    a, T, dt = b.arrays, b.n_steps, b.timescale
+    # the simulation starts at 05:00: arrivals are possible only at spawn steps in 08:00-10:59 -> t_arr (= spawn step + 1) in 13..24
+    assert a["ev_t_arr"].min() >= 13 and a["ev_t_arr"].max() <= 24
+    stay_h = (a["ev_t_dep"] - a["ev_t_arr"]) * dt / 60
+    assert abs(stay_h.mean() - 4.5) < 0.3          # N(4 h, 0.8 h) + 1 step + 2 steps to the departure (utils.py:236-262)
+    assert abs((a["ev_B"] - a["ev_cap0"]).mean() - 19.0) < 2.5   # N(20, 10) kWh, short of it where the battery is smaller
+    sol = -a["tr_solar_power"][:, 0, :]
+    sun_steps = np.arange(T)[(sol > 0.01 * sol.max()).any(axis=0)]
+    assert sun_steps.min() >= (10 - 5) * 4 and sun_steps.max() <= (14 - 5) * 4 + 14 and sol.max() > 20   # 10:00-14:00 plus the smoothing tail (rolling + exponentially weighted mean)
+    with pytest.raises(FileNotFoundError):
+        gen_config_from_yaml(y, 2, 1, data_dir=str(tmp_path / "missing"))

@@ -35,7 +35,7 @@ def child(workload, pool, reps):
     obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
     stats = eng.empty((E, _abi.N_STATS))
     bes = P * (phi * wl["b_occ"] + (1 - phi) * wl["b_empty"]) + batch.n_transformers * wl["b_tr"] + wl["b_env"]
-    out = {"lib": os.environ.get("AB_LABEL") or os.environ.get("EV2G_LIB", "default"), "kernel": eng.launch_kernel_name(T, True)}
+    out = {"lib": os.environ.get("AB_LABEL") or os.environ.get("EV2G_LIB", "default"), "kernel": eng.kernel_name}
     off = 0
     for mode, persistent, n in (("persistent", True, reps), ("per_step", False, max(3, reps // 6))):
         ms = []
