@@ -314,10 +314,11 @@ def main():
     ap.add_argument("--actor-groups", type=int, default=1, help="with --actor mlp: split the envs of a GPU into this many independently "
                     "pipelined groups (own engine handle + HIP stream each); 1 = one chain of dependent kernels.  Measured on MI355X: "
                     "1 -> 147 M, 2 -> 148-149 M, 4 -> 143-145 M env-steps/s (the gaps between dependent kernels are GPU-side)")
-    ap.add_argument("--actor", default="none", choices=["none", "mlp", "mlp_torch"],
+    ap.add_argument("--actor", default="none", choices=["none", "mlp", "mlp_fp32", "mlp_torch"],
                     help="BASELINE configs[4]-shaped rollout: an actor (obs->400->300->P, tanh; SB3-DDPG shape, random weights) "
                          "produces the actions on the device between steps (forces per_step launches).  mlp: the fused one-kernel "
-                         "forward of the library (bf16 MFMA); mlp_torch: the same network through torch.nn (fp32)")
+                         "forward of the library (bf16 MFMA); mlp_fp32: the same kernel structure with float32 MFMA operands (what an "
+                         "SB3-trained float32 policy computes); mlp_torch: the same network through torch.nn (fp32)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-rollout-record", action="store_true", help="skip the short policy-in-the-loop pass (`rollout` in the line)")
     ap.add_argument("--only-timed", action="store_true", help="profiling runs: nothing but the timed regions of the chosen launch mode "
@@ -361,7 +362,7 @@ def main():
     phi = occupancy_fraction(batch)
     # engine kernels, torch allocations and the RCCL gather all run on ONE explicit (non-default) stream
     dev = devx.device
-    n_groups = args.actor_groups if (args.actor == "mlp" and args.actor_groups > 1 and E % args.actor_groups == 0) else 1
+    n_groups = args.actor_groups if (args.actor in ("mlp", "mlp_fp32") and args.actor_groups > 1 and E % args.actor_groups == 0) else 1
     Eg, Mg = E // n_groups, M // n_groups
     gath = None
     if multi:   # double-buffered asynchronous all-gather: the statistics travel while the next episode steps
@@ -386,7 +387,7 @@ def main():
         g_actor = None
         if args.actor != "none":
             from ev2gym_amd.actor import make_actor
-            g_actor = make_actor(eng, Eg, P, D, wl["lo"], dev, seed=1234 + rank, kind="fused" if args.actor == "mlp" else "torch")
+            g_actor = make_actor(eng, Eg, P, D, wl["lo"], dev, seed=1234 + rank, kind={"mlp": "fused", "mlp_fp32": "fused_fp32"}.get(args.actor, "torch"))
             actor = actor or g_actor
         loops.append(RolloutLoop(eng, Eg, P, T, Mg, acts, obs, rew, done, mask, stats, gath if n_groups == 1 else None, g_actor))
         engines.append(eng)

@@ -43,10 +43,11 @@ def mlp_forward_numpy(x, weights, lo, bf16=False):
 class FusedMLPActor:
     """obs[E,D] float32 -> actions[E,P] float32 in [lo, 1], one kernel per forward; `run(loop, k)` enqueues k rollout steps."""
 
-    def __init__(self, eng, E, P, D, lo, dev=None, seed=0, weights=None):
+    def __init__(self, eng, E, P, D, lo, dev=None, seed=0, weights=None, precision="bf16"):
         self.eng, self.E, self.P, self.D, self.lo = eng, E, P, D, lo
         self.weights = weights if weights is not None else init_mlp_weights(D, P, seed)
-        self.mlp = eng.mlp_create(*self.weights, out_lo=lo)
+        self.precision = precision
+        self.mlp = eng.mlp_create(*self.weights, out_lo=lo, precision=precision)
         if dev is not None:
             import torch
             self.obs32 = torch.zeros((E, D), dtype=torch.float32, device=dev)
@@ -54,7 +55,7 @@ class FusedMLPActor:
         else:
             self.obs32, self.act32 = eng.empty((E, D), np.float32), eng.empty((E, P), np.float32)
         eng.set_extras(obs_f32=self.obs32, obs_f32_stride=0, actions_f32=self.act32)
-        self.describe = (f"fused MLP {D}->400->300->{P} tanh: one kernel per forward (bf16 MFMA, fp32 accumulate), float32 "
+        self.describe = (f"fused MLP {D}->400->300->{P} tanh: one kernel per forward ({'bf16' if precision == 'bf16' else 'float32'} MFMA operands, fp32 accumulate), float32 "
                          "obs/action hand-over, actor + step enqueued by one C call per segment (ev2g_rollout)")
 
     def run(self, loop, k):
@@ -111,5 +112,7 @@ class TorchMLPActor:
 
 
 def make_actor(eng, E, P, D, lo, dev, seed=0, kind="fused"):
+    if kind == "fused_fp32":
+        return FusedMLPActor(eng, E, P, D, lo, dev, seed=seed, precision="fp32")
     cls = FusedMLPActor if kind == "fused" else TorchMLPActor
     return cls(eng, E, P, D, lo, dev, seed=seed)

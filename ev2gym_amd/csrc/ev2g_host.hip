@@ -927,8 +927,22 @@ static std::vector<uint16_t> pack_linear(const float *W, int n_out, int n_in, in
     return p;
 }
 
-int ev2g_mlp_create(ev2g_handle *h, int d_in, int h1, int h2, int d_out, const float *W1, const float *b1, const float *W2,
-                    const float *b2, const float *W3, const float *b3, float out_lo, ev2g_mlp **out) {
+// float32 weights in the operand order of ev2g_mlp32_layer: [n_tile][k_group of 8][lane][4], lane l <-> (n = tile*32 + (l & 31), k = 8 g + 4 (l >> 5) + 0..3)
+static std::vector<float> pack_linear_f32(const float *W, int n_out, int n_in, int N, int K) {
+    std::vector<float> v((size_t)N * K, 0.f);
+    const int KG = K / 8;
+    for (int nt = 0; nt < N / 32; nt++)
+        for (int g = 0; g < KG; g++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 4; j++) {
+                    const int n = nt * 32 + (l & 31), k = g * 8 + 4 * (l >> 5) + j;
+                    v[(((size_t)nt * KG + g) * 64 + l) * 4 + j] = (n < n_out && k < n_in) ? W[(size_t)n * n_in + k] : 0.f;
+                }
+    return v;
+}
+
+int ev2g_mlp_create_ex(ev2g_handle *h, int d_in, int h1, int h2, int d_out, const float *W1, const float *b1, const float *W2,
+                    const float *b2, const float *W3, const float *b3, float out_lo, int precision, ev2g_mlp **out) {
     if (!h || !out || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || d_in <= 0 || h1 <= 0 || h2 <= 0 || d_out <= 0)
         return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create: bad arguments");
     if (out_lo != -1.0f && out_lo != 0.0f) return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create: out_lo must be -1 or 0");
@@ -943,20 +957,34 @@ int ev2g_mlp_create(ev2g_handle *h, int d_in, int h1, int h2, int d_out, const f
 #ifdef EV2G_MLP_TIMING
     { unsigned long long *p; if (dalloc(h, m->allocs, 8, &p)) { delete m; return EV2G_ERR_HIP; } d.dbg = p; }
 #endif
-    m->lds = ev2g_mlp_lds_bytes(d);
+    if (precision != EV2G_MLP_BF16 && precision != EV2G_MLP_F32) { delete m; return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create_ex: precision must be EV2G_MLP_BF16 or EV2G_MLP_F32"); }
+    const bool f32 = precision == EV2G_MLP_F32;
+    m->lds = f32 ? ev2g_mlp32_lds_bytes(d) : ev2g_mlp_lds_bytes(d);
     if (m->lds > 160 * 1024) { delete m; return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create: layers too wide for the LDS-resident activations"); }
     int rc = 0;
     auto upw = [&](const std::vector<uint16_t> &v, const uint16_t **dst) { uint16_t *p; rc = upload(h, m->allocs, v.data(), v.size(), &p); *dst = p; return rc; };
     auto upb = [&](const float *b, int n, int N, const float **dst) { std::vector<float> v((size_t)N, 0.f); std::copy(b, b + n, v.begin()); float *p; rc = upload(h, m->allocs, v.data(), v.size(), &p); *dst = p; return rc; };
+    auto upw32 = [&](const std::vector<float> &v, const uint16_t **dst) { float *p; rc = upload(h, m->allocs, v.data(), v.size(), &p); *dst = (const uint16_t *)p; return rc; };
+    if (f32) {
+        if (upw32(pack_linear_f32(W1, h1, d_in, d.n1, d.k1), &d.w1) || upw32(pack_linear_f32(W2, h2, h1, d.n2, d.n1), &d.w2) ||
+            upw32(pack_linear_f32(W3, d_out, h2, d.n3, d.n2), &d.w3) || upb(b1, h1, d.n1, &d.b1) || upb(b2, h2, d.n2, &d.b2) || upb(b3, d_out, d.n3, &d.b3)) {
+            free_pool(m->allocs); delete m; return rc;
+        }
+    } else
     if (upw(pack_linear(W1, h1, d_in, d.n1, d.k1), &d.w1) || upw(pack_linear(W2, h2, h1, d.n2, d.n1), &d.w2) ||
         upw(pack_linear(W3, d_out, h2, d.n3, d.n2), &d.w3) || upb(b1, h1, d.n1, &d.b1) || upb(b2, h2, d.n2, &d.b2) || upb(b3, d_out, d.n3, &d.b3)) {
         free_pool(m->allocs); delete m; return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));   // the staging vectors are temporaries
-    m->fn = mlp_kernel_for(d);
+    m->fn = f32 ? (const void *)ev2g_mlp3_f32 : mlp_kernel_for(d);
     if (m->lds > 48 * 1024) HIPCHK(h, hipFuncSetAttribute(m->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds));
     *out = m;
     return EV2G_OK;
+}
+
+int ev2g_mlp_create(ev2g_handle *h, int d_in, int h1, int h2, int d_out, const float *W1, const float *b1, const float *W2,
+                    const float *b2, const float *W3, const float *b3, float out_lo, ev2g_mlp **out) {
+    return ev2g_mlp_create_ex(h, d_in, h1, h2, d_out, W1, b1, W2, b2, W3, b3, out_lo, EV2G_MLP_BF16, out);
 }
 
 void ev2g_mlp_destroy(ev2g_handle *h, ev2g_mlp *m) {

@@ -311,3 +311,81 @@ __global__ void __launch_bounds__(EV2G_MLP_BLOCK) ev2g_mlp3_any(MlpDev m, const 
     __syncthreads();
     ev2g_mlp_layer_any<true>(bufA, sA, m.n2, m.n3, m.w3, m.b3, nullptr, 0, y, row0, n_rows, m.d_out, m.out_lo);
 }
+
+
+// ---- float32 variant: the SAME network with float32 operands (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation) ----
+// SB3 policies are float32 (train_stable_baselines.py:62-130): with this kernel a network trained there produces, on the device,
+// the actions its own framework would (agreement with a float32 numpy forward at the 1e-6 level: only the summation order
+// differs), at roughly twice the time of the bf16 kernel -- weights are twice the bytes and the f32 MFMA runs at 1/8 of the bf16 rate.
+// Operand layout of the 32x32x2 MFMA: lane l supplies A[row = l & 31][k(l)] and B[k(l)][col = l & 31], the instruction sums its two
+// k's.  Here MFMA j of a group of eight k's uses k = 8 g + 4 (l >> 5) + j, so a lane's four A values and four weights are contiguous:
+// one 16-byte LDS read and one 16-byte (pre-packed, coalesced) global load feed four MFMAs.  Activations stay in LDS as float32.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__host__ __device__ inline int ev2g_mlp32_lds_stride(int k) { return k + 4; }   // floats per LDS row (+16 bytes against bank conflicts)
+__host__ __device__ inline size_t ev2g_mlp32_lds_bytes(const MlpDev &m) {
+    const int a = ev2g_mlp32_lds_stride(m.k1 > m.n2 ? m.k1 : m.n2), b = ev2g_mlp32_lds_stride(m.n1);
+    return (size_t)EV2G_MLP_ROWS * (a + b) * sizeof(float);
+}
+#define EV2G_MLP32_DEPTH 8
+template <bool FINAL>
+__device__ __forceinline__ void ev2g_mlp32_layer(const float *__restrict__ A, int sa, int K, int N, const float *__restrict__ W,
+                                                 const float *__restrict__ bias, float *__restrict__ out, int so, float *__restrict__ gout,
+                                                 int row0, int n_rows, int d_out, float out_lo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int KG = K >> 3, NT = N >> 5;
+    const float *arow = A + (lane & 31) * sa + 4 * (lane >> 5);
+    for (int nt = wave; nt < NT; nt += EV2G_MLP_BLOCK / 64) {
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const f32x4 *w = (const f32x4 *)W + ((size_t)nt * KG) * 64 + lane;
+        f32x4 ring[EV2G_MLP32_DEPTH];
+#pragma unroll
+        for (int u = 0; u < EV2G_MLP32_DEPTH; u++) ring[u] = w[(size_t)min(u, KG - 1) * 64];
+        for (int g0 = 0; g0 < KG; g0 += EV2G_MLP32_DEPTH) {
+#pragma unroll
+            for (int u = 0; u < EV2G_MLP32_DEPTH; u++) {
+                const int g = g0 + u;
+                if (g < KG) {   // (uniform)
+                    const f32x4 a = *(const f32x4 *)(arow + g * 8), b = ring[u];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+                    ring[u] = w[(size_t)min(g + EV2G_MLP32_DEPTH, KG - 1) * 64];
+                }
+            }
+        }
+        const int col = nt * 32 + (lane & 31);
+        const float bv = bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float v = acc[r] + bv;
+            if (FINAL) {
+                v = tanhf(v);
+                if (out_lo == 0.0f) v = v * 0.5f + 0.5f;
+                if (col < d_out && row0 + row < n_rows) gout[(size_t)(row0 + row) * d_out + col] = v;
+            } else {
+                out[row * so + col] = v > 0.0f ? v : 0.0f;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(EV2G_MLP_BLOCK) ev2g_mlp3_f32(MlpDev m, const float *__restrict__ x, float *__restrict__ y, int n_rows) {
+    extern __shared__ __attribute__((aligned(16))) float mlds32[];
+    const int sA = ev2g_mlp32_lds_stride(m.k1 > m.n2 ? m.k1 : m.n2), sB = ev2g_mlp32_lds_stride(m.n1);
+    float *bufA = mlds32, *bufB = mlds32 + EV2G_MLP_ROWS * sA;
+    const int row0 = blockIdx.x * EV2G_MLP_ROWS;
+    // input rows -> LDS (zero-padded in K and past the last row): the 32 rows are one contiguous float32 range
+    const int nr = min(EV2G_MLP_ROWS, n_rows - row0);
+    for (int i = threadIdx.x; i < EV2G_MLP_ROWS * m.k1; i += EV2G_MLP_BLOCK) {
+        const int r = i / m.k1, c = i - r * m.k1;
+        bufA[r * sA + c] = (r < nr && c < m.d_in) ? x[(size_t)(row0 + r) * m.d_in + c] : 0.0f;
+    }
+    __syncthreads();
+    ev2g_mlp32_layer<false>(bufA, sA, m.k1, m.n1, (const float *)m.w1, m.b1, bufB, sB, nullptr, row0, n_rows, 0, 0.f);
+    __syncthreads();
+    ev2g_mlp32_layer<false>(bufB, sB, m.n1, m.n2, (const float *)m.w2, m.b2, bufA, sA, nullptr, row0, n_rows, 0, 0.f);
+    __syncthreads();
+    ev2g_mlp32_layer<true>(bufA, sA, m.n2, m.n3, (const float *)m.w3, m.b3, nullptr, 0, y, row0, n_rows, m.d_out, m.out_lo);
+}

@@ -73,6 +73,7 @@ def load_library(path: Optional[str] = None):
         "ev2g_host_uniform": (None, [vp, i64, C.c_uint64, dbl, dbl]),
         "ev2g_last_step_n_kernel_ms": (dbl, [vp]),
         "ev2g_mlp_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, C.POINTER(vp)]),
+        "ev2g_mlp_create_ex": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.POINTER(vp)]),
         "ev2g_mlp_destroy": (None, [vp, vp]),
         "ev2g_mlp_forward": (C.c_int, [vp, vp, vp, vp, C.c_int]),
         "ev2g_rollout": (C.c_int, [vp, vp, C.c_int, vp, i64, vp, i64, vp, i64, C.c_int]),
@@ -105,7 +106,7 @@ EXPORTED_SYMBOLS = [
     "ev2g_scenario_offset", "ev2g_set_step_extras", "ev2g_kernel_name", "ev2g_fallback_reason", "ev2g_step", "ev2g_step_n",
     "ev2g_check_faults", "ev2g_get_stats", "ev2g_stat_name", "ev2g_peek", "ev2g_malloc", "ev2g_free",
     "ev2g_memcpy_h2d", "ev2g_memcpy_d2h", "ev2g_synchronize", "ev2g_fill_uniform", "ev2g_host_uniform",
-    "ev2g_last_step_n_kernel_ms", "ev2g_mlp_create", "ev2g_mlp_destroy", "ev2g_mlp_forward", "ev2g_rollout",
+    "ev2g_last_step_n_kernel_ms", "ev2g_mlp_create", "ev2g_mlp_create_ex", "ev2g_mlp_destroy", "ev2g_mlp_forward", "ev2g_rollout",
     "ev2g_rollout_graph_launches", "ev2g_comm_get_unique_id", "ev2g_comm_init", "ev2g_comm_destroy", "ev2g_comm_world_size", "ev2g_comm_gathers", "ev2g_gather_stats",
     "ev2g_gen_default_config", "ev2g_generate", "ev2g_gen_batch", "ev2g_gen_free", "ev2g_gen_table"]
 
@@ -248,14 +249,17 @@ class Engine:
         self._check(rc)
 
     # ---- policy in the loop ----------------------------------------------------------------------
-    def mlp_create(self, W1, b1, W2, b2, W3, b3, out_lo=-1.0):
-        """Three-layer actor (torch.nn.Linear layout: W[out,in], b[out]; host float32 arrays) evaluated by one fused kernel."""
+    def mlp_create(self, W1, b1, W2, b2, W3, b3, out_lo=-1.0, precision="bf16"):
+        """Three-layer actor (torch.nn.Linear layout: W[out,in], b[out]; host float32 arrays) evaluated by one fused kernel.
+        precision: "bf16" (bf16 operands, fp32 accumulation: fastest) or "fp32" (float32 operands: what a float32-trained policy,
+        e.g. SB3's, computes -- agreement with a float32 forward at the 1e-6 level, about twice the time)."""
         arrs = [np.ascontiguousarray(a, np.float32) for a in (W1, b1, W2, b2, W3, b3)]
         h1, d_in = arrs[0].shape
         h2, d_out = arrs[2].shape[0], arrs[4].shape[0]
         assert arrs[2].shape == (h2, h1) and arrs[4].shape == (d_out, h2) and arrs[1].shape == (h1,) and arrs[3].shape == (h2,) and arrs[5].shape == (d_out,)
         m = C.c_void_p()
-        self._check(self._lib.ev2g_mlp_create(self._h, d_in, h1, h2, d_out, *[a.ctypes.data for a in arrs], float(out_lo), C.byref(m)))
+        prec = {"bf16": 0, "fp32": 1, "f32": 1}[precision]
+        self._check(self._lib.ev2g_mlp_create_ex(self._h, d_in, h1, h2, d_out, *[a.ctypes.data for a in arrs], float(out_lo), prec, C.byref(m)))
         return m
 
     def mlp_destroy(self, m):

@@ -308,6 +308,13 @@ int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *view);
 typedef struct ev2g_mlp ev2g_mlp;
 int ev2g_mlp_create(ev2g_handle *h, int d_in, int h1, int h2, int d_out, const float *W1, const float *b1, const float *W2,
                     const float *b2, const float *W3, const float *b3, float out_lo, ev2g_mlp **out);
+/* The same with the operand precision chosen: EV2G_MLP_BF16 (the call above: bf16 operands, fastest) or EV2G_MLP_F32 -- float32
+ * operands (v_mfma_f32_32x32x2_f32), for policies trained in float32 (SB3's are): the device forward then agrees with a float32
+ * forward of the same weights at the 1e-6 level, at about twice the time. */
+#define EV2G_MLP_BF16 0
+#define EV2G_MLP_F32 1
+int ev2g_mlp_create_ex(ev2g_handle *h, int d_in, int h1, int h2, int d_out, const float *W1, const float *b1, const float *W2,
+                    const float *b2, const float *W3, const float *b3, float out_lo, int precision, ev2g_mlp **out);
 void ev2g_mlp_destroy(ev2g_handle *h, ev2g_mlp *m);
 /* y[n_rows,d_out] = actor(x[n_rows,d_in]); float32 DEVICE pointers; asynchronous on the handle's stream. */
 int ev2g_mlp_forward(ev2g_handle *h, const ev2g_mlp *m, const float *x, float *y, int n_rows);

@@ -80,3 +80,64 @@ def test_gym_make_builds_the_facade_when_gymnasium_is_present():
     obs, _ = env.reset()
     obs, rew, done, trunc, info = env.step(env.action_space.sample())
     env.close()
+
+
+@pytest.mark.parametrize("n_rows,d_in,h1,h2,d_out,lo", [(100, 162, 400, 300, 50, -1.0), (4096, 162, 400, 300, 50, -1.0), (77, 63, 400, 300, 20, 0.0),
+                                                       (33, 17, 40, 70, 3, -1.0)])
+def test_float32_actor_matches_a_float32_forward(n_rows, d_in, h1, h2, d_out, lo):
+    """precision="fp32" (v_mfma_f32_32x32x2_f32, float32 operands): the fused actor agrees with the float32 numpy forward of the same
+    weights to 1e-5 -- what an SB3-trained float32 policy computes (train_stable_baselines.py:62-130) -- where the bf16 kernel is
+    allowed 6e-2 (tests/test_actor_gpu.py).  Same shapes as that test: ragged last row tile, ragged last column tiles."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.actor import init_mlp_weights, mlp_forward_numpy
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import GenConfig, generate
+    eng = Engine(generate(GenConfig.v2g_profit_plus_loads(8, 50, 1, seed=1)), _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"],
+                 _abi.STATE_KINDS["V2G_profit_max_loads"], device=0)
+    rng = np.random.default_rng(d_in + n_rows)
+    w = init_mlp_weights(d_in, d_out, seed=3, h1=h1, h2=h2)
+    x = (rng.normal(0, 1, (n_rows, d_in)) * rng.uniform(0.1, 3.0, d_in)).astype(np.float32)
+    m = eng.mlp_create(*w, out_lo=lo, precision="fp32")
+    dx, dy = eng.empty((n_rows, d_in), np.float32).upload(x), eng.empty((n_rows, d_out), np.float32)
+    eng.mlp_forward(m, dx, dy, n_rows)
+    y = dy.to_host()
+    ref = mlp_forward_numpy(x.astype(np.float64), [a.astype(np.float64) for a in w], lo).astype(np.float64)
+    W1, b1, W2, b2, W3, b3 = [a.astype(np.float64) for a in w]
+    h = np.maximum(x.astype(np.float64) @ W1.T + b1, 0)
+    h = np.maximum(h @ W2.T + b2, 0)
+    exact = np.tanh(h @ W3.T + b3)
+    exact = exact * 0.5 + 0.5 if lo == 0.0 else exact
+    assert np.abs(y - exact).max() <= 1e-5, np.abs(y - exact).max()
+    assert np.abs(y - mlp_forward_numpy(x, w, lo)).max() <= 1e-5
+    assert y.min() >= lo - 1e-6 and y.max() <= 1.0 + 1e-6
+    del ref
+    eng.mlp_destroy(m)
+    eng.close()
+
+
+def test_rollout_with_the_float32_actor_equals_forward_then_step():
+    """ev2g_rollout with a float32 actor == k x (ev2g_mlp_forward, ev2g_step) bit for bit (the same two kernels, enqueued by one call)."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.actor import FusedMLPActor
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import GenConfig, generate
+    pool = generate(GenConfig.v2g_profit_plus_loads(40, 50, 1, seed=4))
+    rk, sk = _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"]
+    out = []
+    for fused_call in (False, True):
+        eng = Engine(pool, rk, sk, device=0, flags=4)
+        E, P, D = eng.E, eng.P, eng.D
+        actor = FusedMLPActor(eng, E, P, D, -1.0, dev=None, seed=11, precision="fp32")
+        rew = eng.empty((30, E))
+        eng.reset()
+        if fused_call:
+            eng.rollout(actor.mlp, 30, rew, E, None, 0, None, 0)
+        else:
+            for t in range(30):
+                eng.mlp_forward(actor.mlp, actor.obs32, actor.act32, E)
+                eng.step_n(1, None, 0, None, 0, rew.at(t * E), 0, None, 0, None, 0, auto_reset=False, persistent=False)
+        out.append((rew.to_host().copy(), actor.obs32.to_host().copy(), actor.act32.to_host().copy()))
+        eng.close()
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    assert np.abs(out[0][2]).max() > 0.01
