@@ -48,6 +48,7 @@ ERR_OVERCURRENT = -5
 FLAG_LOG_CS_HISTORY = 1
 FLAG_NULL_STREAM = 2
 FLAG_LOG_SOC = 4
+FLAG_REFILLABLE = 8   # fixed-size session blocks per scenario: ev2g_pool_refill can re-draw scenarios on the device
 
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int32)

@@ -78,6 +78,7 @@ struct DevScn {  // read-only scenario + layout, device pointers
     const int *port_end;   // one past the port's last session
     const int *ss_slot;    // [S] port slot of every session; const int *scn_sess: [M+1] session range of every scenario (statistics kernel)
     const int *scn_sess;
+    const int *scn_sess_end;   // [M] one past the scenario's last session (== scn_sess[m+1] unless the pool is refillable: fixed-size blocks)
     const int2 *port_first_win;
     const SessRec *rec;  // [S] AoS twin of the ss_* arrays (v2 kernels)
     const double *win_tab;  // [E,R,T+1,40] precomputed (loads-pv)[20] | power_limits[20] per observation step, or nullptr
@@ -851,9 +852,10 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
 // One-off at load time: materialise the per-(env, transformer, observation step) 40-wide window
 // [ (loads - pv)[20] | power_limits[20] ] (transformer.py:142-188) so that the step kernel streams it with
 // one coalesced load per lane instead of re-deriving it through dependent gathers every step.
-__global__ void ev2g_build_window_table_kernel(DevScn s, double *__restrict__ tab) {
-    const long long n = (long long)s.M * s.R * (s.T + 1) * 40;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+// (m0, m1: the scenario slots to (re)build -- all of them at load, the refilled ones after ev2g_pool_refill)
+__global__ void ev2g_build_window_table_kernel(DevScn s, double *__restrict__ tab, int m0, int m1) {
+    const long long per = (long long)s.R * (s.T + 1) * 40, n = per * m1;
+    for (long long i = per * m0 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(i % 40);
         const long long k = i / 40;
         const int step = (int)(k % (s.T + 1));
@@ -867,9 +869,9 @@ __global__ void ev2g_build_window_table_kernel(DevScn s, double *__restrict__ ta
 // when the state has them (NH == 60), the 40 window columns of ev2g_build_window_table_kernel.  The step kernel copies
 // a row per env-step with one base pointer and no per-column logic.
 __global__ void ev2g_build_head_table_kernel(const double *__restrict__ price_ch, const double *__restrict__ win_tab,
-                                             int E, int T, int NH, double *__restrict__ tab) {
-    const long long n = (long long)E * (T + 1) * NH;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+                                             int m0, int m1, int T, int NH, double *__restrict__ tab) {
+    const long long per = (long long)(T + 1) * NH, n = per * m1;
+    for (long long i = per * m0 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % NH);
         const long long row = i / NH;
         const int step = (int)(row % (T + 1));
@@ -883,9 +885,9 @@ __global__ void ev2g_build_head_table_kernel(const double *__restrict__ price_ch
 
 // Per (env, step) scalars of the one-transformer fast path, interleaved so that one base pointer and three 16-byte
 // loads fetch them: {charge price, discharge price, inflexible+solar, max_power, min_power, setpoint, 0, 0}.
-__global__ void ev2g_build_step_table_kernel(DevScn s, double *__restrict__ tab) {
-    const long long n = (long long)s.M * s.T;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+__global__ void ev2g_build_step_table_kernel(DevScn s, double *__restrict__ tab, int m0, int m1) {
+    const long long n = (long long)m1 * s.T;
+    for (long long i = (long long)m0 * s.T + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         double *o = tab + i * 8;
         o[0] = s.price_ch[i]; o[1] = s.price_dis[i]; o[2] = s.tr_base[i]; o[3] = s.tr_maxp[i]; o[4] = s.tr_minp[i];
         o[5] = s.setpoint[i]; o[6] = 0.0; o[7] = 0.0;
@@ -976,7 +978,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
     // The satisfaction values of a lane's first two sessions are kept for the variance pass below instead of being fetched again.
     double vkeep[2];
     int nkeep = 0;
-    const int d0 = s.scn_sess[scn], d1 = s.scn_sess[scn + 1];
+    const int d0 = s.scn_sess[scn], d1 = s.scn_sess_end[scn];
     for (int k = d0 + lane; k < d1; k += 64) {
         const int q = s.ss_slot[k];
         const long long g = (long long)e * P + q, gs = (long long)scn * P + q;

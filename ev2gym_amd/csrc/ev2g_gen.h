@@ -51,6 +51,59 @@ static const double EV2G_FLEET_V2G_ETA[EV2G_GEN_FLEET_MAX][6] = {
 static const double EV2G_FLEET_EV_PHEV[EV2G_GEN_FLEET_MAX][3] = {
     {0.26, 8.0, 3.7}, {0.10, 14.5, 3.7}, {0.03, 39.0, 3.6}, {0.045, 46.3, 7.4}, {0.035, 52.0, 22.0}, {0.32, 57.7, 11.0}, {0.12, 64.5, 11.0}, {0.07, 76.0, 11.0}};
 
+// ---- elementary functions with ONE result on every processor -----------------------------------------------------------------
+// The device generates scenarios too (ev2g_pool_refill), and a scenario must not depend on where it was drawn: the same (seed,
+// index) gives the same tensors bit for bit on the host and on the GPU.  IEEE +, -, *, / and sqrt are correctly rounded everywhere
+// (the library is built with -ffp-contract=off); log / exp / sin / cos are not -- glibc and the device maths library round differently in
+// the last bit -- so the generator uses these: fixed sequences of IEEE operations (argument reduction + Taylor / atanh series, accurate to a
+// few 1e-16), identical wherever they run.  They are for the generator's argument ranges, not general-purpose replacements.
+EV2G_HD double ev2g_two_pow(int e) {   // 2^e for -1022 <= e <= 1023, exact
+    union { uint64_t u; double d; } v;
+    v.u = (uint64_t)(e + 1023) << 52;
+    return v.d;
+}
+EV2G_HD double ev2g_dlog(double x) {   // x > 0, normal
+    union { uint64_t u; double d; } v;
+    v.d = x;
+    int e = (int)((v.u >> 52) & 0x7ff) - 1023;
+    v.u = (v.u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;   // mantissa in [1, 2)
+    double m = v.d;
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }           // [sqrt(1/2), sqrt(2))
+    const double s = (m - 1.0) / (m + 1.0), s2 = s * s;           // log m = 2 atanh s, |s| <= 0.1716
+    double p = 1.0 / 23.0;
+    p = p * s2 + 1.0 / 21.0; p = p * s2 + 1.0 / 19.0; p = p * s2 + 1.0 / 17.0; p = p * s2 + 1.0 / 15.0; p = p * s2 + 1.0 / 13.0;
+    p = p * s2 + 1.0 / 11.0; p = p * s2 + 1.0 / 9.0; p = p * s2 + 1.0 / 7.0; p = p * s2 + 1.0 / 5.0; p = p * s2 + 1.0 / 3.0;
+    p = p * s2 + 1.0;
+    return (double)e * 0.6931471805599453 + 2.0 * s * p;
+}
+EV2G_HD double ev2g_dexp(double x) {   // |x| < 700
+    const double n = rint(x * 1.4426950408889634);
+    const double r = (x - n * 0.693147180369123816490) - n * 1.90821492927058770002e-10;   // ln 2 = hi + lo
+    double p = 1.0 / 6227020800.0;   // 1/13!
+    p = p * r + 1.0 / 479001600.0; p = p * r + 1.0 / 39916800.0; p = p * r + 1.0 / 3628800.0; p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0; p = p * r + 1.0 / 5040.0; p = p * r + 1.0 / 720.0; p = p * r + 1.0 / 120.0; p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0; p = p * r + 0.5; p = p * r + 1.0; p = p * r + 1.0;
+    return p * ev2g_two_pow((int)n);
+}
+// sin and cos of moderate arguments (|x| < 1e4): x = k pi/2 + r, |r| <= pi/4, Taylor series of sin r and cos r
+EV2G_HD void ev2g_dsincos(double x, double *sn, double *cs) {
+    const double k = rint(x * 0.6366197723675814);
+    const double r = (x - k * 1.57079632673412561417) - k * 6.07710050650619224932e-11;   // pi/2 = hi + lo
+    const double r2 = r * r;
+    double ps = -1.0 / 1307674368000.0;   // -1/15!
+    ps = ps * r2 + 1.0 / 6227020800.0; ps = ps * r2 - 1.0 / 39916800.0; ps = ps * r2 + 1.0 / 362880.0; ps = ps * r2 - 1.0 / 5040.0;
+    ps = ps * r2 + 1.0 / 120.0; ps = ps * r2 - 1.0 / 6.0; ps = ps * r2 + 1.0;
+    const double s = r * ps;
+    double pc = 1.0 / 20922789888000.0;   // 1/16!
+    pc = pc * r2 - 1.0 / 87178291200.0; pc = pc * r2 + 1.0 / 479001600.0; pc = pc * r2 - 1.0 / 3628800.0; pc = pc * r2 + 1.0 / 40320.0;
+    pc = pc * r2 - 1.0 / 720.0; pc = pc * r2 + 1.0 / 24.0; pc = pc * r2 - 0.5; pc = pc * r2 + 1.0;
+    const long long q = ((long long)k % 4 + 4) % 4;
+    *sn = (q == 0) ? s : (q == 1) ? pc : (q == 2) ? -s : -pc;
+    *cs = (q == 0) ? pc : (q == 1) ? -s : (q == 2) ? -pc : s;
+}
+EV2G_HD double ev2g_dsin(double x) { double s, c; ev2g_dsincos(x, &s, &c); return s; }
+EV2G_HD double ev2g_dcos(double x) { double s, c; ev2g_dsincos(x, &s, &c); return c; }
+
 // ---- counter-based random numbers ------------------------------------------------------------------------------------------
 enum { EV2G_RS_HOUR = 1, EV2G_RS_PRICE, EV2G_RS_WEEKEND, EV2G_RS_SPAWN, EV2G_RS_SESSION, EV2G_RS_TR, EV2G_RS_SOLAR_ENV, EV2G_RS_DR, EV2G_RS_FC, EV2G_RS_SETPOINT };
 
@@ -62,7 +115,12 @@ EV2G_HD uint64_t ev2g_mix64(uint64_t z) {   // splitmix64 finaliser
 }
 struct Ev2gRng {
     uint64_t key;   // mix of (seed, scenario)
-    EV2G_HD uint64_t bits(uint64_t stream, uint64_t a, uint64_t b) const { return ev2g_mix64(ev2g_mix64(ev2g_mix64(key ^ (stream * 0xD1342543DE82EF95ull)) + a) + b * 0xA24BAED4963EE407ull); }
+    // splitmix64 over a per-(scenario, stream) base: the output function of a counter generator applied to base + a * G1 + b * G2
+    // (odd multipliers: distinct (a, b) of the sizes used here give distinct counters).  ONE finaliser per draw: the spawn trials of
+    // a scenario (one draw per port and step) dominate the cost of generating it, on the host and on the device.
+    EV2G_HD uint64_t bits(uint64_t stream, uint64_t a, uint64_t b) const {
+        return ev2g_mix64(ev2g_mix64(key ^ (stream * 0xD1342543DE82EF95ull)) + a * 0x9E3779B97F4A7C15ull + b * 0xA24BAED4963EE407ull);
+    }
     EV2G_HD double uni(uint64_t stream, uint64_t a, uint64_t b) const { return (double)(bits(stream, a, b) >> 11) * (1.0 / 9007199254740992.0); }   // [0, 1)
     EV2G_HD double uni(uint64_t stream, uint64_t a, uint64_t b, double lo, double hi) const { return lo + (hi - lo) * uni(stream, a, b); }
     EV2G_HD long long integers(uint64_t stream, uint64_t a, uint64_t b, long long lo, long long hi) const {   // lo <= x < hi
@@ -73,7 +131,7 @@ struct Ev2gRng {
     // shares no counter with any other draw of the same (stream, a) -- draws documented as independent are independent
     EV2G_HD double normal(uint64_t stream, uint64_t a, uint64_t b, double mean, double sd) const {
         const double u1 = 1.0 - uni(stream, a, b | (1ull << 62)), u2 = uni(stream, a, b | (1ull << 63));
-        return mean + sd * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        return mean + sd * sqrt(-2.0 * ev2g_dlog(u1)) * ev2g_dcos(6.283185307179586 * u2);
     }
 };
 EV2G_HD Ev2gRng ev2g_rng(uint64_t seed, uint64_t scenario) { return Ev2gRng{ev2g_mix64(ev2g_mix64(seed) ^ (scenario * 0x9E3779B97F4A7C15ull + 0x1234567ull))}; }
@@ -129,39 +187,50 @@ EV2G_HD int ev2g_minute_of_day(const Ev2gGenRun &g, int t) {
     return (int)(((m % 1440) + 1440) % 1440);
 }
 
-// ---- one scenario: prices -----------------------------------------------------------------------------------------------------
-EV2G_HD void ev2g_gen_prices(const Ev2gGenRun &g, const Ev2gRng &r, double *charge_price, double *discharge_price) {
-    const ev2g_gen_config &c = *g.c;
-    const double scale = r.uni(EV2G_RS_PRICE, 0, 0, 0.6, 1.6);
-    int last_h = -1;
-    double hp = 0.0;
-    for (int t = 0; t < g.T; t++) {
-        const double sh = g.hour + c.minute / 60.0 + t * (double)g.dt / 60.0;
-        const int h = (int)floor(sh);
-        if (h != last_h) {   // hourly day-ahead-like curve, EUR/MWh
-            const double hh = (double)(h % 24);
-            const double base = 75 + 40 * sin((hh - 7) / 24 * 6.283185307179586) + 30 * sin((hh - 17) / 12 * 6.283185307179586);
-            hp = ev2g_round_dec(fmax(base * scale + r.normal(EV2G_RS_PRICE, 1, (uint64_t)h, 0.0, 12.0), 3.0), 100.0);
-            last_h = h;
-        }
-        const double p = hp / 1000.0;
-        charge_price[t] = -p;                                  // loaders.py:439-442
-        discharge_price[t] = p * c.discharge_price_factor;
-    }
+// ===================================================================================================================================
+// One scenario, written so that ONE definition serves the host (ev2g_gen_host.h: a thread runs the loops below) and the device
+// (ev2g_refill.h: a wavefront runs them with a lane per step / per port): every quantity is a function of (scenario, element) through
+// the counter-based generator, reductions are max / min (order-free) or the fixed 64-leaf tree ev2g_tree64, and the sessions of a
+// port depend on that port's own history only.
+// ===================================================================================================================================
+
+// what a scenario draws once
+struct Ev2gScenarioDraw { int hour; bool weekend; double price_scale, sun; };
+EV2G_HD Ev2gScenarioDraw ev2g_gen_scenario_draw(const Ev2gGenRun &g0, const Ev2gRng &rng, const Ev2gRng &rng_tr, bool pv_data) {
+    const ev2g_gen_config &c = *g0.c;
+    Ev2gScenarioDraw d;
+    d.hour = c.random_hour ? (int)rng.integers(EV2G_RS_HOUR, 0, 0, 5, 16) : g0.hour;   // per scenario, like the reference's per-reset draw (ev2gym_env.py:131-133)
+    // weekday or weekend tables: the reference's date decides; workplaces are always simulated on weekdays (ev2gym_env.py:141-154)
+    d.weekend = (c.scenario == 0 || c.simulation_days == 0) ? false : (c.simulation_days == 1 ? true : rng.uni(EV2G_RS_WEEKEND, 0, 0) < 2.0 / 7.0);
+    d.price_scale = rng.uni(EV2G_RS_PRICE, 0, 0, 0.6, 1.6);
+    // the env-wide sun factor: a cloudiness scale for the synthetic curve, the day of the year for the PV data
+    d.sun = !c.solar_power ? 0.0 : (pv_data ? (double)rng_tr.integers(EV2G_RS_SOLAR_ENV, 0, 0, 0, 365) : rng_tr.uni(EV2G_RS_SOLAR_ENV, 0, 0, 0.3, 1.0));
+    return d;
 }
 
-// ---- one scenario: EV sessions, in EVs_profiles order (arrival step, then port) ---------------------------------------------------
+// ---- prices: EUR/kWh at step t (hourly day-ahead-like curve; charge price = -p, discharge price = p * factor, loaders.py:439-442) ----
+EV2G_HD double ev2g_gen_price_at(const Ev2gGenRun &g, const Ev2gRng &r, double scale, int t) {
+    const double sh = g.hour + g.c->minute / 60.0 + t * (double)g.dt / 60.0;
+    const int h = (int)floor(sh);
+    const double hh = (double)(h % 24);
+    const double base = 75 + 40 * ev2g_dsin((hh - 7) / 24 * 6.283185307179586) + 30 * ev2g_dsin((hh - 17) / 12 * 6.283185307179586);
+    const double hp = ev2g_round_dec(fmax(base * scale + r.normal(EV2G_RS_PRICE, 1, (uint64_t)h, 0.0, 12.0), 3.0), 100.0);
+    return hp / 1000.0;
+}
+
+// ---- EV sessions of ONE port, in time order (EV_spawner utils.py:477-557, spawn_single_EV :177-345) -----------------------------------
 struct Ev2gGenSession { int port, t_arr, t_dep, model; double B, pac, cap0; };
 
-EV2G_HD int ev2g_gen_sessions(const Ev2gGenRun &g, const Ev2gRng &r, bool weekend, int *free_from /*[P] scratch*/, Ev2gGenSession *out, int cap) {
+template <class Emit>
+EV2G_HD int ev2g_gen_port_sessions(const Ev2gGenRun &g, const Ev2gRng &r, bool weekend, int p, Emit &&emit) {
     const ev2g_gen_config &c = *g.c;
     const int kind = c.scenario + ((weekend && c.scenario != 0) ? 2 : 0);   // 0 workplace, 1 public, 2 private, 3 public weekend, 4 private weekend
     const Ev2gFleet fleet = ev2g_fleet(g);
     double share_sum = 0.0;
     for (int i = 0; i < fleet.n; i++) share_sum += fleet.share(i);
-    for (int p = 0; p < g.P; p++) free_from[p] = 0;
-    int n = 0;
+    int free_from = 0, n = 0;   // first spawn step at which the port passes the 3-step-empty rule (utils.py:534-552)
     for (int t = 2; t < g.T - g.min_stay_steps - 1; t++) {
+        if (free_from > t) continue;
         const double hod = g.hour + c.minute / 60.0 + t * (double)g.dt / 60.0;
         double rate, stay_mean, e_mean;
         if (c.tab_arrival_week) {   // the reference's own tables, looked up its way (utils.py:199-233, 505-528)
@@ -175,162 +244,136 @@ EV2G_HD int ev2g_gen_sessions(const Ev2gGenRun &g, const Ev2gRng &r, bool weeken
             stay_mean = ev2g_gen_interp24(EV2G_GEN_STAY[kind], hod); e_mean = EV2G_GEN_ENERGY[kind];
         }
         if (!(rate > 0.0)) continue;
-        for (int p = 0; p < g.P; p++) {
-            if (free_from[p] > t) continue;   // occupied, or inside the 3-step-empty rule (utils.py:534-552)
-            const uint64_t id = (uint64_t)t * (uint64_t)g.P + (uint64_t)p;
-            if (!(r.uni(EV2G_RS_SPAWN, id, 0) * 100.0 < rate)) continue;
-            double req = r.normal(EV2G_RS_SESSION, id, 0, e_mean, 0.5 * e_mean);
-            if (req < 5) req = (double)r.integers(EV2G_RS_SESSION, id, 10, 5, 10);
-            int model = 0;
-            double B = c.ev_battery_capacity, pac = c.ev_max_ac_charge_power;
-            if (c.heterogeneous_ev_specs) {
-                const double u = r.uni(EV2G_RS_SESSION, id, 11) * share_sum;
-                double acc = 0.0;
-                model = fleet.n - 1;
-                for (int i = 0; i < fleet.n; i++) { acc += fleet.share(i); if (u < acc) { model = i; break; } }
-                B = fleet.battery(model); pac = fleet.pac(model);
-            }
-            const long long Bi = (long long)B > 2 ? (long long)B : 2;
-            double cap0 = (B < req) ? (double)r.integers(EV2G_RS_SESSION, id, 12, 1, Bi) : B - req;
-            if (cap0 > c.ev_desired_capacity * B) cap0 = (double)r.integers(EV2G_RS_SESSION, id, 13, 1, Bi);
-            if (cap0 < c.ev_min_battery_capacity && B > 2 * c.ev_min_battery_capacity) cap0 = c.ev_min_battery_capacity;
-            double stay = r.normal(EV2G_RS_SESSION, id, 2, stay_mean, 0.2 * stay_mean) * 60.0 / g.dt + 1;
-            if (stay < g.min_stay_steps) stay = g.min_stay_steps;
-            if (stay + t + 4 >= g.T) continue;   // empty_ports_at_end_of_simulation (utils.py:254-256)
-            const int tdep = (int)(stay + t + 3);
-            free_from[p] = tdep + 2;             // occupancy_list[t+1 : t_dep] = 1 and the 3-step look-back
-            if (n < cap) out[n] = Ev2gGenSession{p, t + 1, tdep, model, B, pac, cap0};
-            n++;
+        const uint64_t id = (uint64_t)t * (uint64_t)g.P + (uint64_t)p;
+        if (!(r.uni(EV2G_RS_SPAWN, id, 0) * 100.0 < rate)) continue;
+        double req = r.normal(EV2G_RS_SESSION, id, 0, e_mean, 0.5 * e_mean);
+        if (req < 5) req = (double)r.integers(EV2G_RS_SESSION, id, 10, 5, 10);
+        int model = 0;
+        double B = c.ev_battery_capacity, pac = c.ev_max_ac_charge_power;
+        if (c.heterogeneous_ev_specs) {
+            const double u = r.uni(EV2G_RS_SESSION, id, 11) * share_sum;
+            double acc = 0.0;
+            model = fleet.n - 1;
+            for (int i = 0; i < fleet.n; i++) { acc += fleet.share(i); if (u < acc) { model = i; break; } }
+            B = fleet.battery(model); pac = fleet.pac(model);
         }
+        const long long Bi = (long long)B > 2 ? (long long)B : 2;
+        double cap0 = (B < req) ? (double)r.integers(EV2G_RS_SESSION, id, 12, 1, Bi) : B - req;
+        if (cap0 > c.ev_desired_capacity * B) cap0 = (double)r.integers(EV2G_RS_SESSION, id, 13, 1, Bi);
+        if (cap0 < c.ev_min_battery_capacity && B > 2 * c.ev_min_battery_capacity) cap0 = c.ev_min_battery_capacity;
+        double stay = r.normal(EV2G_RS_SESSION, id, 2, stay_mean, 0.2 * stay_mean) * 60.0 / g.dt + 1;
+        if (stay < g.min_stay_steps) stay = g.min_stay_steps;
+        if (stay + t + 4 >= g.T) continue;   // empty_ports_at_end_of_simulation (utils.py:254-256)
+        const int tdep = (int)(stay + t + 3);
+        free_from = tdep + 2;                // occupancy_list[t+1 : t_dep] = 1 and the 3-step look-back
+        emit(n, Ev2gGenSession{p, t + 1, tdep, model, B, pac, cap0});
+        n++;
     }
-    return n;   // > cap: the caller's buffer was too small (P * (T / 5 + 1) always suffices: a session keeps its port for at least 5 steps)
+    return n;
 }
 
-// ---- one scenario: one transformer -----------------------------------------------------------------------------------------------
-// out arrays are this transformer's [T] rows; dr its [n_dr][3] slots; sun_scale is the env-wide cloudiness factor
-EV2G_HD void ev2g_gen_transformer(const Ev2gGenRun &g, const Ev2gRng &r, int tr, double cap, double sun_scale, double *maxp, double *minp, double *infl,
-                                  double *solar, double *lf, double *pvf, double *dr, int32_t *n_dr_out) {
+// ---- the per-session fields spawn_single_EV sets besides the ones above (utils.py:298-345) ---------------------------------------------
+struct Ev2gSessFields { double desired, minB, min_emerg, pac_min, pdis_max, pdis_min, ts, tsm, eta_ch, eta_dis; int phases, lut; };
+// spec_row [n_ev_specs]: the efficiency-table row of every spec model (-1: none); may be null without a spec file
+EV2G_HD Ev2gSessFields ev2g_gen_session_fields(const Ev2gGenRun &g, const Ev2gRng &rng, const Ev2gGenSession &e, const int *spec_row) {
     const ev2g_gen_config &c = *g.c;
-    const int T = g.T;
+    Ev2gSessFields f;
+    const uint64_t id = (uint64_t)(e.t_arr - 1) * (uint64_t)g.P + (uint64_t)e.port;   // the spawn trial this session came from
+    f.desired = c.ev_desired_capacity * e.B; f.minB = c.ev_min_battery_capacity;
+    f.min_emerg = c.ev_min_emergency_battery_capacity > e.B ? 0.7 * e.B : c.ev_min_emergency_battery_capacity;
+    f.tsm = c.ev_transition_soc_multiplier;
+    if (c.heterogeneous_ev_specs) {
+        f.pac_min = 0.0; f.pdis_max = c.v2g_enabled ? -e.pac : 0.0; f.pdis_min = 0.0; f.phases = 3;
+        f.ts = ev2g_round_dec(0.9 - (rng.uni(EV2G_RS_SESSION, id, 20) + 0.00001) / 5, 1000.0);
+        if (c.n_ev_specs > 0) f.pdis_max = -c.spec_max_ac_discharge_power[e.model];   // as written in the file (utils.py:303-304)
+        const bool table = c.n_ev_specs > 0 ? (spec_row && spec_row[e.model] >= 0) : (c.fleet_with_efficiency_tables != 0);
+        if (table) { f.lut = c.n_ev_specs > 0 ? spec_row[e.model] : e.model; f.eta_ch = NAN; f.eta_dis = NAN; }
+        else {
+            f.lut = -1;
+            f.eta_ch = ev2g_round_dec(1 - (rng.uni(EV2G_RS_SESSION, id, 21) + 0.00001) / 20, 1000.0);
+            f.eta_dis = ev2g_round_dec(1 - (rng.uni(EV2G_RS_SESSION, id, 22) + 0.00001) / 20, 1000.0);
+        }
+    } else {
+        f.pac_min = c.ev_min_ac_charge_power; f.pdis_max = c.ev_max_discharge_power; f.pdis_min = c.ev_min_discharge_power;
+        f.phases = c.ev_phases; f.ts = c.ev_transition_soc; f.lut = -1;
+        f.eta_ch = c.ev_charge_efficiency; f.eta_dis = c.ev_discharge_efficiency;
+    }
+    return f;
+}
+
+// ---- one transformer, element by element (load_transformers loaders.py:227-296, transformer.py:80-256) -------------------------------------
+EV2G_HD double ev2g_gen_infl_raw(const Ev2gGenRun &g, const Ev2gRng &r, int tr, double lvl, int t) {   // the load shape before it is scaled to the transformer
+    const double tod = fmod(g.hour + g.c->minute / 60.0 + t * (double)g.dt / 60.0, 24.0) / 24.0;
+    const double s1 = ev2g_dsin((tod - 0.3) * 6.283185307179586), e1 = (tod - 0.8) / 0.08;
+    const double shape = 0.35 + 0.25 * s1 * s1 + 0.5 * ev2g_dexp(-(e1 * e1));
+    return fabs(shape * lvl + r.normal(EV2G_RS_TR, (uint64_t)tr, 16 + (uint64_t)t, 0.0, 0.03));
+}
+EV2G_HD double ev2g_gen_infl_scaled(double raw, double mult, double cap, double mx) {   // normalize_inflexible_loads transformer.py:213-233
+    const double v = raw * mult * (cap / mx + 0.0000001);
+    return v < -cap ? -cap : (v > cap ? cap : v);
+}
+EV2G_HD double ev2g_gen_solar_at(const Ev2gGenRun &g, double sun, double a, double m, double cap, int t) {
+    if (g.pv_series) {   // the reference's PV year (loaders.py:165-224): `sun` carries the scenario's day of the year
+        const long long i0 = (long long)sun * g.pv_per_day + (g.hour * 60 + g.c->minute) / g.dt;
+        return -(g.pv_series[i0 + t] * a) * m * cap;
+    }
+    const double tod = fmod(g.hour + g.c->minute / 60.0 + t * (double)g.dt / 60.0, 24.0);
+    double s = ev2g_dsin((tod - 6.5) / 13.0 * 3.141592653589793);
+    s = s > 0 ? s * sqrt(s) : 0.0;   // clip(., 0) ** 1.5
+    return -(s * sun * a) * m * cap;
+}
+struct Ev2gDrEvent { int es, ee, s0, s1; double capp; };   // raw bounds, the Python slice [s0, s1) they select, capacity percentage
+EV2G_HD Ev2gDrEvent ev2g_gen_dr_event(const Ev2gGenRun &g, const Ev2gRng &r, int tr, int e) {   // generate_demand_response_events transformer.py:80-140
+    const ev2g_gen_config &c = *g.c;
     const uint64_t k = (uint64_t)tr;
-    for (int t = 0; t < T; t++) { maxp[t] = cap; minp[t] = -cap; }
-    if (c.inflexible_loads) {
-        const double lvl = r.uni(EV2G_RS_TR, k, 0, 0.6, 1.4);
-        double mx = 0.0;
-        for (int t = 0; t < T; t++) {
-            const double tod = fmod(g.hour + c.minute / 60.0 + t * (double)g.dt / 60.0, 24.0) / 24.0;
-            const double s1 = sin((tod - 0.3) * 6.283185307179586), e1 = (tod - 0.8) / 0.08;
-            const double shape = 0.35 + 0.25 * s1 * s1 + 0.5 * exp(-(e1 * e1));
-            infl[t] = fabs(shape * lvl + r.normal(EV2G_RS_TR, k, 16 + (uint64_t)t, 0.0, 0.03));
-            if (infl[t] > mx) mx = infl[t];
-        }
-        const double mult = r.normal(EV2G_RS_TR, k, 1, c.inflexible_loads_capacity_multiplier_mean, 0.1);
-        for (int t = 0; t < T; t++) {
-            double v = infl[t] * mult * (cap / mx + 0.0000001);
-            infl[t] = v < minp[t] ? minp[t] : (v > maxp[t] ? maxp[t] : v);
-        }
-    } else {
-        for (int t = 0; t < T; t++) infl[t] = 0.0;
-    }
-    if (c.solar_power) {
-        const double a = r.uni(EV2G_RS_TR, k, 2, 0.9, 1.1), m = r.normal(EV2G_RS_TR, k, 3, c.solar_power_capacity_multiplier_mean, 0.1);
-        for (int t = 0; t < T; t++) {
-            if (g.pv_series) {   // the reference's PV year (loaders.py:165-224): sun_scale carries the scenario's day of the year
-                const long long i0 = (long long)sun_scale * g.pv_per_day + (g.hour * 60 + c.minute) / g.dt;
-                solar[t] = -(g.pv_series[i0 + t] * a) * m * cap;
-                continue;
-            }
-            const double tod = fmod(g.hour + c.minute / 60.0 + t * (double)g.dt / 60.0, 24.0);
-            double s = sin((tod - 6.5) / 13.0 * 3.141592653589793);
-            s = s > 0 ? s * sqrt(s) : 0.0;   // clip(., 0) ** 1.5
-            solar[t] = -(s * sun_scale * a) * m * cap;
-        }
-    } else {
-        for (int t = 0; t < T; t++) solar[t] = 0.0;
-    }
-    for (int i = 0; i < g.n_dr * 3; i++) dr[i] = 0.0;
-    *n_dr_out = 0;
-    if (c.demand_response) {   // generate_demand_response_events transformer.py:80-140, one event after the other
-        for (int e = 0; e < c.dr_events_per_day; e++) {
-            const long long length = r.integers(EV2G_RS_DR, k, 4 * (uint64_t)e, c.dr_event_length_minutes_min, (long long)c.dr_event_length_minutes_max + 1);
-            double start_min = r.normal(EV2G_RS_DR, k, 4 * (uint64_t)e + 1, c.dr_event_start_hour_mean * 60, c.dr_event_start_hour_std * 60);
-            start_min = start_min < 0 ? 0 : (start_min > 23 * 60 ? 23 * 60 : start_min);
-            const int es = (int)(floor(start_min / g.dt) - (double)((g.hour * 60 + c.minute) / g.dt));
-            const int ee = es + (int)(length / g.dt);
-            double capp = r.normal(EV2G_RS_DR, k, 4 * (uint64_t)e + 2, c.dr_event_capacity_percentage_mean, c.dr_event_capacity_percentage_std);
-            capp = capp < 0 ? 0 : (capp > 100 ? 100 : capp);
-            bool over = false;
-            double load_max = -INFINITY;
-            // max_power[es:ee] is a Python slice (transformer.py:118-131): an event that starts before the simulation does has
-            // negative bounds, which count from the END of the array (es = -2, ee = 2 selects nothing; es = -8, ee = -4 hits the
-            // last steps of the episode); the recorded event keeps the raw bounds
-            int s0, s1;
-            ev2g_py_slice(es, ee, T, &s0, &s1);
-            for (int t = s0; t < s1; t++) {
-                maxp[t] = maxp[t] - maxp[t] * capp / 100;
-                if (infl[t] > maxp[t]) over = true;
-                if (infl[t] > load_max) load_max = infl[t];
-            }
-            if (over) {   // the load exceeds the reduced limit inside the event: the limit is lifted to the load's maximum
-                for (int t = s0; t < s1; t++) maxp[t] = load_max;
-                double mxp = -INFINITY;
-                for (int t = 0; t < T; t++) if (maxp[t] > mxp) mxp = maxp[t];
-                capp = 100 * (1 - load_max / mxp);
-            }
-            dr[e * 3 + 0] = es; dr[e * 3 + 1] = ee; dr[e * 3 + 2] = capp;
-        }
-        *n_dr_out = c.dr_events_per_day;
-    }
-    const double fm = c.inflexible_loads_forecast_mean / 100, fs = c.inflexible_loads_forecast_std / 100;
-    const double pm = c.solar_power_forecast_mean / 100, ps = c.solar_power_forecast_std / 100;
-    for (int t = 0; t < T; t++) {
-        if (c.inflexible_loads) {
-            const double v = r.normal(EV2G_RS_FC, k, 2 * (uint64_t)t, fm * infl[t], fabs(fs * infl[t]));
-            lf[t] = v < minp[t] ? minp[t] : (v > maxp[t] ? maxp[t] : v);
-        } else lf[t] = 0.0;
-        pvf[t] = c.solar_power ? r.normal(EV2G_RS_FC, k, 2 * (uint64_t)t + 1, pm * solar[t], fabs(ps * solar[t])) : 0.0;
-    }
-    lf[0] = infl[0];   // reset() already observed step 0 (transformer.py:178-180)
-    pvf[0] = solar[0];
+    Ev2gDrEvent ev;
+    const long long length = r.integers(EV2G_RS_DR, k, 4 * (uint64_t)e, c.dr_event_length_minutes_min, (long long)c.dr_event_length_minutes_max + 1);
+    double start_min = r.normal(EV2G_RS_DR, k, 4 * (uint64_t)e + 1, c.dr_event_start_hour_mean * 60, c.dr_event_start_hour_std * 60);
+    start_min = start_min < 0 ? 0 : (start_min > 23 * 60 ? 23 * 60 : start_min);
+    ev.es = (int)(floor(start_min / g.dt) - (double)((g.hour * 60 + c.minute) / g.dt));
+    ev.ee = ev.es + (int)(length / g.dt);
+    double capp = r.normal(EV2G_RS_DR, k, 4 * (uint64_t)e + 2, c.dr_event_capacity_percentage_mean, c.dr_event_capacity_percentage_std);
+    ev.capp = capp < 0 ? 0 : (capp > 100 ? 100 : capp);
+    // max_power[es:ee] is a Python slice (transformer.py:118-131): negative bounds count from the END of the array
+    ev2g_py_slice(ev.es, ev.ee, g.T, &ev.s0, &ev.s1);
+    return ev;
+}
+EV2G_HD double ev2g_gen_load_forecast_at(const Ev2gGenRun &g, const Ev2gRng &r, int tr, int t, double infl, double minp, double maxp) {
+    if (t == 0) return infl;   // reset() already observed step 0 (transformer.py:178-180)
+    const double fm = g.c->inflexible_loads_forecast_mean / 100, fs = g.c->inflexible_loads_forecast_std / 100;
+    const double v = r.normal(EV2G_RS_FC, (uint64_t)tr, 2 * (uint64_t)t, fm * infl, fabs(fs * infl));
+    return v < minp ? minp : (v > maxp ? maxp : v);
+}
+EV2G_HD double ev2g_gen_pv_forecast_at(const Ev2gGenRun &g, const Ev2gRng &r, int tr, int t, double solar) {
+    if (t == 0) return solar;
+    const double pm = g.c->solar_power_forecast_mean / 100, ps = g.c->solar_power_forecast_std / 100;
+    return r.normal(EV2G_RS_FC, (uint64_t)tr, 2 * (uint64_t)t + 1, pm * solar, fabs(ps * solar));
 }
 
-// ---- one scenario: power setpoints (generate_power_setpoints utils.py:664-757, simplified) ----------------------------------------
-// price-weighted spread of every session's energy over its stay, median-smoothed; `load` and `tmp` are [T + 16] scratch
-EV2G_HD void ev2g_gen_setpoints(const Ev2gGenRun &g, const Ev2gRng &r, const double *charge_price, const Ev2gGenSession *ss, int n, const double *min_cs /*[P]*/,
-                                const double *max_cs /*[P]*/, double pac_min, double *sp /*[T]*/, double *w /*[T] scratch*/, double *pad /*[T+16] scratch*/) {
-    const ev2g_gen_config &c = *g.c;
-    const int T = g.T;
-    for (int t = 0; t < T; t++) sp[t] = 0.0;
-    if (!c.power_setpoint_enabled || n == 0) return;
-    double pmax = 0.0;
-    for (int t = 0; t < T; t++) pmax = fmax(pmax, fabs(charge_price[t]));
-    double prmin = INFINITY;
-    for (int t = 0; t < T; t++) prmin = fmin(prmin, fabs(charge_price[t]) / pmax);
-    const double sd = fmax(prmin, 1e-3);
-    for (int s = 0; s < n; s++) {
-        const Ev2gGenSession &e = ss[s];
-        double wsum = 0.0;
-        for (int t = 0; t < T; t++) {
-            const bool win = t >= e.t_arr + 1 && t < e.t_dep;   // steps t+2 .. t_dep-1
-            w[t] = win ? fabs(r.normal(EV2G_RS_SETPOINT, (uint64_t)s, (uint64_t)t, 1 - fabs(charge_price[t]) / pmax, sd)) : 0.0;
-            wsum += w[t];
-        }
-        wsum = fmax(wsum, 1e-12);
-        const double need = (e.B - e.cap0) * (100 + c.power_setpoint_flexiblity) / 100;
-        const double lo = fmax(pac_min, min_cs[e.port]), hi = fmin(e.pac, max_cs[e.port]);
-        for (int t = 0; t < T; t++) {
-            double l = w[t] / wsum * need * 60 / g.dt;
-            l = (l > 0 && l < lo) ? 0.0 : fmin(l, hi);
-            sp[t] += l;
-        }
-    }
-    const int k = 5 * ((15 / g.dt) > 1 ? (15 / g.dt) : 1);   // median window (edge-padded)
-    const int left = k / 2;
-    for (int i = 0; i < T + k - 1; i++) { const int t = i - left; pad[i] = sp[t < 0 ? 0 : (t >= T ? T - 1 : t)]; }
-    for (int t = 0; t < T; t++) {
-        double win[80];
-        for (int i = 0; i < k; i++) win[i] = pad[t + i];
-        for (int i = 1; i < k; i++) { const double v = win[i]; int j = i - 1; while (j >= 0 && win[j] > v) { win[j + 1] = win[j]; j--; } win[j + 1] = v; }
-        sp[t] = (k & 1) ? win[k / 2] : 0.5 * (win[k / 2 - 1] + win[k / 2]);
-    }
+// ---- fixed 64-leaf summation tree: leaf j holds v[j] + v[j + 64] + ... (in that order), leaves are combined by xor butterflies
+// (32, 16, .. 1) -- what a wavefront does with one lane per leaf; the host walks the same tree.  leaves[64] is overwritten. ----
+EV2G_HD double ev2g_tree64(double *leaves) {
+    for (int d = 32; d > 0; d >>= 1)
+        for (int l = 0; l < 64; l++)
+            if ((l & d) == 0) { const double a = leaves[l] + leaves[l ^ d]; leaves[l] = a; leaves[l ^ d] = a; }
+    return leaves[0];
+}
+
+// ---- power setpoints (generate_power_setpoints utils.py:664-757, simplified): price-weighted spread of every session's energy over
+// its stay, median-smoothed.  A session's weight at step t: ----
+EV2G_HD double ev2g_gen_setpoint_weight(const Ev2gRng &r, uint64_t id, int t, int t_arr, int t_dep, double price_rel, double sd) {
+    const bool win = t >= t_arr + 1 && t < t_dep;   // steps t+2 .. t_dep-1
+    return win ? fabs(r.normal(EV2G_RS_SETPOINT, id, (uint64_t)t, 1 - price_rel, sd)) : 0.0;
+}
+EV2G_HD double ev2g_gen_setpoint_load(double w, double wsum, double need, int dt, double lo, double hi) {
+    double l = w / wsum * need * 60 / dt;
+    return (l > 0 && l < lo) ? 0.0 : fmin(l, hi);
+}
+EV2G_HD int ev2g_gen_median_window(int dt) { return 5 * ((15 / dt) > 1 ? (15 / dt) : 1); }
+// median of the k values pad[t .. t + k) (k <= 80)
+EV2G_HD double ev2g_gen_median(const double *pad, int t, int k) {
+    double win[80];
+    for (int i = 0; i < k; i++) win[i] = pad[t + i];
+    for (int i = 1; i < k; i++) { const double v = win[i]; int j = i - 1; while (j >= 0 && win[j] > v) { win[j + 1] = win[j]; j--; } win[j + 1] = v; }
+    return (k & 1) ? win[k / 2] : 0.5 * (win[k / 2 - 1] + win[k / 2]);
 }

@@ -19,6 +19,50 @@ struct ev2g_gen_result {
     std::vector<double> cap0, B, desired, minB, min_emerg, pac_max, pac_min, pdis_max, pdis_min, ts, tsm, eta_ch, eta_dis, lut;
 };
 
+// the efficiency-table row of every spec model (-1: the model has none); returns the number of tables
+static int ev2g_gen_spec_rows(const ev2g_gen_config &c, std::vector<int> &spec_row) {
+    spec_row.assign(std::max(c.n_ev_specs, 0), -1);
+    int n = 0;
+    if (c.n_ev_specs > 0 && c.spec_efficiency)
+        for (int i = 0; i < c.n_ev_specs; i++)
+            if (!std::isnan(c.spec_efficiency[(size_t)i * EV2G_LUT_LEN])) spec_row[i] = n++;
+    return n;
+}
+
+// tab_pv brought to the simulation timescale (repeat / max-pool), rolling mean, exponentially weighted mean (loaders.py:178-193), two
+// years long; empty when the config carries no PV data.  Returns an error text or null.
+static const char *ev2g_gen_pv_series(const ev2g_gen_config &c, int dt, std::vector<double> &pv_series) {
+    pv_series.clear();
+    if (!(c.solar_power && c.tab_pv && c.n_pv >= 8760)) return nullptr;
+    if (1440 % dt != 0 || (dt < 60 && 60 % dt != 0) || (dt > 60 && dt % 60 != 0)) return "ev2g_generate: tab_pv needs a timescale that divides the hour or a multiple of it";
+    std::vector<double> x;
+    if (dt > 60) { const int k = dt / 60; for (long long i = 0; i + k <= c.n_pv; i += k) { double m = c.tab_pv[i]; for (int j = 1; j < k; j++) m = std::max(m, c.tab_pv[i + j]); x.push_back(m); } }
+    else { const int k = 60 / dt; x.reserve((size_t)c.n_pv * k); for (long long i = 0; i < c.n_pv; i++) for (int j = 0; j < k; j++) x.push_back(c.tab_pv[i]); }
+    const int w = std::max(60 / dt, 1);
+    std::vector<double> y(x.size());
+    double run = 0.0;
+    for (size_t i = 0; i < x.size(); i++) { run += x[i]; if (i >= (size_t)w) run -= x[i - w]; y[i] = run / (double)std::min<size_t>(i + 1, w); }   // rolling mean
+    const double alpha = 2.0 / (w + 1.0);
+    double num = 0.0, den = 0.0;
+    for (size_t i = 0; i < y.size(); i++) { num = y[i] + (1 - alpha) * num; den = 1 + (1 - alpha) * den; y[i] = num / den; }   // ewm(span=w, adjust=True)
+    pv_series = y;
+    pv_series.insert(pv_series.end(), y.begin(), y.end());
+    return nullptr;
+}
+
+// the per-run constants of a config (what ev2g_generate and ev2g_pool_refill derive alike); P = ports per scenario
+static void ev2g_gen_make_run(const ev2g_gen_config &c, int P, int npc_max, uint64_t seed, Ev2gGenRun &g) {
+    g = Ev2gGenRun{};
+    g.c = &c; g.T = c.simulation_length; g.dt = c.timescale; g.C = c.number_of_charging_stations; g.P = P; g.R = c.number_of_transformers;
+    g.npc_max = npc_max; g.seed = seed;
+    g.hour = c.hour;   // random_hour: drawn per scenario, like the reference draws it per reset (ev2gym_env.py:131-133)
+    g.min_stay_steps = c.ev_min_time_of_stay / g.dt;
+    g.steps_ahead = c.dr_notification_of_event_minutes / g.dt;
+    g.n_dr = c.demand_response ? std::max(c.dr_events_per_day, 1) : 1;
+    g.lut_fleet = c.heterogeneous_ev_specs && c.fleet_with_efficiency_tables;
+    g.n_fleet = EV2G_GEN_FLEET_MAX;
+}
+
 static int gen_fail(const char *msg) { g_create_error = msg; return EV2G_ERR_ARG; }
 
 static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t seed, int32_t n_threads, ev2g_gen_result **out) {
@@ -68,41 +112,18 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
         }
 
     Ev2gGenRun g{};
-    g.c = cfg; g.T = T; g.dt = dt; g.C = C; g.P = P; g.R = R; g.npc_max = npc_max; g.seed = seed;
-    g.hour = c.hour;   // random_hour: drawn per scenario below, like the reference draws it per reset (ev2gym_env.py:131-133)
-    g.min_stay_steps = c.ev_min_time_of_stay / dt;
-    g.steps_ahead = c.dr_notification_of_event_minutes / dt;
-    g.n_dr = c.demand_response ? std::max(c.dr_events_per_day, 1) : 1;
-    g.lut_fleet = c.heterogeneous_ev_specs && c.fleet_with_efficiency_tables;
-    g.n_fleet = EV2G_GEN_FLEET_MAX;
+    ev2g_gen_make_run(c, P, npc_max, seed, g);
     if (c.n_ev_specs < 0 || (c.n_ev_specs > 0 && !(c.spec_registrations && c.spec_battery_capacity && c.spec_max_ac_charge_power && c.spec_max_ac_discharge_power)))
         return gen_fail("ev2g_generate: n_ev_specs > 0 needs the four spec_* model arrays");
     if ((c.tab_arrival_week || c.tab_arrival_weekend || c.tab_stay || c.tab_energy) && !(c.tab_arrival_week && c.tab_arrival_weekend && c.tab_stay && c.tab_energy))
         return gen_fail("ev2g_generate: the arrival / stay / energy tables of a data directory come together");
     // which spec models carry an efficiency table, and the row of r.lut each one gets
-    std::vector<int> spec_row(std::max(c.n_ev_specs, 0), -1);
-    int n_spec_lut = 0;
-    if (c.n_ev_specs > 0 && c.spec_efficiency)
-        for (int i = 0; i < c.n_ev_specs; i++)
-            if (!std::isnan(c.spec_efficiency[(size_t)i * EV2G_LUT_LEN])) spec_row[i] = n_spec_lut++;
+    std::vector<int> spec_row;
+    const int n_spec_lut = ev2g_gen_spec_rows(c, spec_row);
     // pv_netherlands.csv's hourly year at the simulation timescale, smoothed like loaders.py:178-193, two years long
     std::vector<double> pv_series;
-    if (c.solar_power && c.tab_pv && c.n_pv >= 8760) {
-        if (1440 % dt != 0 || (dt < 60 && 60 % dt != 0) || (dt > 60 && dt % 60 != 0)) return gen_fail("ev2g_generate: tab_pv needs a timescale that divides the hour or a multiple of it");
-        std::vector<double> x;
-        if (dt > 60) { const int k = dt / 60; for (long long i = 0; i + k <= c.n_pv; i += k) { double m = c.tab_pv[i]; for (int j = 1; j < k; j++) m = std::max(m, c.tab_pv[i + j]); x.push_back(m); } }
-        else { const int k = 60 / dt; x.reserve((size_t)c.n_pv * k); for (long long i = 0; i < c.n_pv; i++) for (int j = 0; j < k; j++) x.push_back(c.tab_pv[i]); }
-        const int w = std::max(60 / dt, 1);
-        std::vector<double> y(x.size());
-        double run = 0.0;
-        for (size_t i = 0; i < x.size(); i++) { run += x[i]; if (i >= (size_t)w) run -= x[i - w]; y[i] = run / (double)std::min<size_t>(i + 1, w); }   // rolling mean
-        const double alpha = 2.0 / (w + 1.0);
-        double num = 0.0, den = 0.0;
-        for (size_t i = 0; i < y.size(); i++) { num = y[i] + (1 - alpha) * num; den = 1 + (1 - alpha) * den; y[i] = num / den; }   // ewm(span=w, adjust=True)
-        pv_series = y;
-        pv_series.insert(pv_series.end(), y.begin(), y.end());
-        g.pv_series = pv_series.data(); g.pv_per_day = 1440 / dt;
-    }
+    if (const char *err = ev2g_gen_pv_series(c, dt, pv_series)) return gen_fail(err);
+    if (!pv_series.empty()) { g.pv_series = pv_series.data(); g.pv_per_day = 1440 / dt; }
     const int ND = g.n_dr;
 
     r.charge_price.resize((size_t)M * T); r.discharge_price.resize((size_t)M * T); r.setpoints.resize((size_t)M * T);
@@ -115,7 +136,6 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
     nt = std::max(1, std::min(nt, (int)M));
     std::vector<std::vector<Ev2gGenSession>> part(nt);   // the sessions of each thread's slice, scenario after scenario
     std::vector<int> count(M, 0);
-    std::atomic<bool> overflow{false};
     const Ev2gGenRun &g0 = g;
     // A worker thread that throws (std::bad_alloc for a batch too large for the host) must not reach std::terminate: the first
     // exception is parked here and re-thrown on the calling thread after the joins; threads are joined on every path
@@ -141,37 +161,99 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
     };
     auto work = [&, g0](int ti) {
         const int m0 = (int)((long long)M * ti / nt), m1 = (int)((long long)M * (ti + 1) / nt);
-        const int cap = P * (T / 5 + 2);   // a session keeps its port for at least 5 steps (arrival, >= 3 steps to the departure, the gap)
-        std::vector<Ev2gGenSession> buf(cap);
-        std::vector<int> free_from(P);
-        std::vector<double> w(T), pad(T + 96);
+        std::vector<std::vector<Ev2gGenSession>> by_port(P);   // a port's sessions, in time order
+        std::vector<Ev2gGenSession> buf;                        // the scenario's sessions in EVs_profiles order (arrival step, then port)
+        std::vector<double> raw(T), w(T), pad(T + 96), leaves(64);
         for (int m = m0; m < m1; m++) {
             const Ev2gRng rng = ev2g_rng(seed, (uint64_t)m);
             const Ev2gRng rng_tr = (c.tr_seed != -1) ? ev2g_rng((uint64_t)c.tr_seed, (uint64_t)m) : rng;
+            const Ev2gScenarioDraw dr = ev2g_gen_scenario_draw(g0, rng, rng_tr, g0.pv_series != nullptr);
             Ev2gGenRun gm = g0;
-            if (c.random_hour) gm.hour = (int)rng.integers(EV2G_RS_HOUR, 0, 0, 5, 16);
+            gm.hour = dr.hour;
             const Ev2gGenRun &g = gm;
             double *cp = &r.charge_price[(size_t)m * T], *dp = &r.discharge_price[(size_t)m * T];
-            ev2g_gen_prices(g, rng, cp, dp);
-            // weekday or weekend tables: the reference's date decides; workplaces are always simulated on weekdays (ev2gym_env.py:141-154)
-            const bool weekend = (c.scenario == 0 || c.simulation_days == 0) ? false : (c.simulation_days == 1 ? true : rng.uni(EV2G_RS_WEEKEND, 0, 0) < 2.0 / 7.0);
-            const int n = ev2g_gen_sessions(g, rng, weekend, free_from.data(), buf.data(), cap);
-            if (n > cap) { overflow = true; count[m] = 0; continue; }
-            count[m] = n;
-            part[ti].insert(part[ti].end(), buf.begin(), buf.begin() + n);
-            // the env-wide sun factor: a cloudiness scale for the synthetic curve, the day of the year for the PV data
-            const double sun = !c.solar_power ? 0.0 : (g.pv_series ? (double)rng_tr.integers(EV2G_RS_SOLAR_ENV, 0, 0, 0, 365) : rng_tr.uni(EV2G_RS_SOLAR_ENV, 0, 0, 0.3, 1.0));
+            for (int t = 0; t < T; t++) { const double pr = ev2g_gen_price_at(g, rng, dr.price_scale, t); cp[t] = -pr; dp[t] = pr * c.discharge_price_factor; }
+            // sessions: port by port (a port's sessions depend on its own history only), then merged into profile order
+            buf.clear();
+            for (int p = 0; p < P; p++) {
+                by_port[p].clear();
+                ev2g_gen_port_sessions(g, rng, dr.weekend, p, [&](int, const Ev2gGenSession &e) { by_port[p].push_back(e); });
+                buf.insert(buf.end(), by_port[p].begin(), by_port[p].end());
+            }
+            std::stable_sort(buf.begin(), buf.end(), [](const Ev2gGenSession &a, const Ev2gGenSession &b) { return a.t_arr != b.t_arr ? a.t_arr < b.t_arr : a.port < b.port; });
+            count[m] = (int)buf.size();
+            part[ti].insert(part[ti].end(), buf.begin(), buf.end());
+            // transformers
             for (int k = 0; k < R; k++) {
                 const size_t o = ((size_t)m * R + k) * T;
-                ev2g_gen_transformer(g, rng_tr, k, tr_cap[k], sun, &r.maxp[o], &r.minp[o], &r.infl[o], &r.solar[o], &r.lf[o], &r.pvf[o],
-                                     &r.dr[((size_t)m * R + k) * ND * 3], &r.n_dr[(size_t)m * R + k]);
+                double *maxp = &r.maxp[o], *minp = &r.minp[o], *infl = &r.infl[o], *solar = &r.solar[o], *lf = &r.lf[o], *pvf = &r.pvf[o];
+                double *drs = &r.dr[((size_t)m * R + k) * ND * 3];
+                const double cap = tr_cap[k];
+                for (int t = 0; t < T; t++) { maxp[t] = cap; minp[t] = -cap; }
+                if (c.inflexible_loads) {
+                    const double lvl = rng_tr.uni(EV2G_RS_TR, (uint64_t)k, 0, 0.6, 1.4);
+                    double mx = 0.0;
+                    for (int t = 0; t < T; t++) { raw[t] = ev2g_gen_infl_raw(g, rng_tr, k, lvl, t); mx = std::max(mx, raw[t]); }
+                    const double mult = rng_tr.normal(EV2G_RS_TR, (uint64_t)k, 1, c.inflexible_loads_capacity_multiplier_mean, 0.1);
+                    for (int t = 0; t < T; t++) infl[t] = ev2g_gen_infl_scaled(raw[t], mult, cap, mx);
+                } else std::fill(infl, infl + T, 0.0);
+                if (c.solar_power) {
+                    const double a = rng_tr.uni(EV2G_RS_TR, (uint64_t)k, 2, 0.9, 1.1), mm = rng_tr.normal(EV2G_RS_TR, (uint64_t)k, 3, c.solar_power_capacity_multiplier_mean, 0.1);
+                    for (int t = 0; t < T; t++) solar[t] = ev2g_gen_solar_at(g, dr.sun, a, mm, cap, t);
+                } else std::fill(solar, solar + T, 0.0);
+                for (int i = 0; i < ND * 3; i++) drs[i] = 0.0;
+                r.n_dr[(size_t)m * R + k] = 0;
+                if (c.demand_response) {   // one event after the other (transformer.py:96-138)
+                    for (int e = 0; e < c.dr_events_per_day; e++) {
+                        Ev2gDrEvent ev = ev2g_gen_dr_event(g, rng_tr, k, e);
+                        bool over = false;
+                        double load_max = -INFINITY;
+                        for (int t = ev.s0; t < ev.s1; t++) {
+                            maxp[t] = maxp[t] - maxp[t] * ev.capp / 100;
+                            if (infl[t] > maxp[t]) over = true;
+                            load_max = std::max(load_max, infl[t]);
+                        }
+                        if (over) {   // the load exceeds the reduced limit inside the event: the limit is lifted to the load's maximum
+                            for (int t = ev.s0; t < ev.s1; t++) maxp[t] = load_max;
+                            double mxp = -INFINITY;
+                            for (int t = 0; t < T; t++) mxp = std::max(mxp, maxp[t]);
+                            ev.capp = 100 * (1 - load_max / mxp);
+                        }
+                        drs[e * 3 + 0] = ev.es; drs[e * 3 + 1] = ev.ee; drs[e * 3 + 2] = ev.capp;
+                    }
+                    r.n_dr[(size_t)m * R + k] = c.dr_events_per_day;
+                }
+                for (int t = 0; t < T; t++) {
+                    lf[t] = c.inflexible_loads ? ev2g_gen_load_forecast_at(g, rng_tr, k, t, infl[t], minp[t], maxp[t]) : 0.0;
+                    pvf[t] = c.solar_power ? ev2g_gen_pv_forecast_at(g, rng_tr, k, t, solar[t]) : 0.0;
+                }
             }
-            ev2g_gen_setpoints(g, rng, cp, buf.data(), n, min_cs.data(), max_cs.data(), c.heterogeneous_ev_specs ? 0.0 : c.ev_min_ac_charge_power,
-                               &r.setpoints[(size_t)m * T], w.data(), pad.data());
+            // power setpoints: sessions port by port, the weight sum of a session on the fixed 64-leaf tree
+            double *sp = &r.setpoints[(size_t)m * T];
+            std::fill(sp, sp + T, 0.0);
+            if (c.power_setpoint_enabled && !buf.empty()) {
+                double pmax = 0.0, prmin = INFINITY;
+                for (int t = 0; t < T; t++) pmax = std::max(pmax, std::fabs(cp[t]));
+                for (int t = 0; t < T; t++) prmin = std::min(prmin, std::fabs(cp[t]) / pmax);
+                const double sd = std::max(prmin, 1e-3);
+                const double pac_min = c.heterogeneous_ev_specs ? 0.0 : c.ev_min_ac_charge_power;
+                for (int p = 0; p < P; p++)
+                    for (const Ev2gGenSession &e : by_port[p]) {
+                        const uint64_t id = (uint64_t)(e.t_arr - 1) * (uint64_t)P + (uint64_t)e.port;
+                        std::fill(leaves.begin(), leaves.end(), 0.0);
+                        for (int t = 0; t < T; t++) { w[t] = ev2g_gen_setpoint_weight(rng, id, t, e.t_arr, e.t_dep, std::fabs(cp[t]) / pmax, sd); leaves[t & 63] += w[t]; }
+                        const double wsum = std::max(ev2g_tree64(leaves.data()), 1e-12);
+                        const double need = (e.B - e.cap0) * (100 + c.power_setpoint_flexiblity) / 100;
+                        const double lo = std::max(pac_min, min_cs[e.port]), hi = std::min(e.pac, max_cs[e.port]);
+                        for (int t = 0; t < T; t++) sp[t] += ev2g_gen_setpoint_load(w[t], wsum, need, dt, lo, hi);
+                    }
+                const int kw = ev2g_gen_median_window(dt), left = kw / 2;
+                for (int i = 0; i < T + kw - 1; i++) { const int t = i - left; pad[i] = sp[t < 0 ? 0 : (t >= T ? T - 1 : t)]; }
+                for (int t = 0; t < T; t++) sp[t] = ev2g_gen_median(pad.data(), t, kw);
+            }
         }
     };
     run_slices(work);
-    if (overflow) return gen_fail("ev2g_generate: session buffer overflow (internal)");
     for (int m = 0; m < M; m++) r.sess_start[m + 1] = r.sess_start[m] + count[m];
     const size_t S = (size_t)r.sess_start[M];
     r.ev_cs.resize(S); r.ev_ta.resize(S); r.ev_td.resize(S); r.ev_ph.resize(S); r.ev_lut.resize(S);
@@ -185,27 +267,11 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
             for (int i = 0; i < count[m]; i++, k++) {
                 const Ev2gGenSession &e = part[ti][k];
                 const size_t s = (size_t)r.sess_start[m] + i;
-                const uint64_t id = (uint64_t)(e.t_arr - 1) * (uint64_t)P + (uint64_t)e.port;   // the spawn trial this session came from
+                const Ev2gSessFields f = ev2g_gen_session_fields(g, rng, e, spec_row.empty() ? nullptr : spec_row.data());
                 r.ev_cs[s] = port_cs[e.port]; r.ev_ta[s] = e.t_arr; r.ev_td[s] = e.t_dep;
-                r.cap0[s] = e.cap0; r.B[s] = e.B; r.desired[s] = c.ev_desired_capacity * e.B; r.minB[s] = c.ev_min_battery_capacity;
-                r.min_emerg[s] = c.ev_min_emergency_battery_capacity > e.B ? 0.7 * e.B : c.ev_min_emergency_battery_capacity;
-                r.pac_max[s] = e.pac; r.tsm[s] = c.ev_transition_soc_multiplier;
-                if (c.heterogeneous_ev_specs) {
-                    r.pac_min[s] = 0.0; r.pdis_max[s] = c.v2g_enabled ? -e.pac : 0.0; r.pdis_min[s] = 0.0; r.ev_ph[s] = 3;
-                    r.ts[s] = ev2g_round_dec(0.9 - (rng.uni(EV2G_RS_SESSION, id, 20) + 0.00001) / 5, 1000.0);
-                    if (c.n_ev_specs > 0) r.pdis_max[s] = -c.spec_max_ac_discharge_power[e.model];   // as written in the file (utils.py:303-304)
-                    if (c.n_ev_specs > 0 && spec_row[e.model] >= 0) { r.ev_lut[s] = spec_row[e.model]; r.eta_ch[s] = NAN; r.eta_dis[s] = NAN; }
-                    else if (c.n_ev_specs == 0 && c.fleet_with_efficiency_tables) { r.ev_lut[s] = e.model; r.eta_ch[s] = NAN; r.eta_dis[s] = NAN; }
-                    else {
-                        r.ev_lut[s] = -1;
-                        r.eta_ch[s] = ev2g_round_dec(1 - (rng.uni(EV2G_RS_SESSION, id, 21) + 0.00001) / 20, 1000.0);
-                        r.eta_dis[s] = ev2g_round_dec(1 - (rng.uni(EV2G_RS_SESSION, id, 22) + 0.00001) / 20, 1000.0);
-                    }
-                } else {
-                    r.pac_min[s] = c.ev_min_ac_charge_power; r.pdis_max[s] = c.ev_max_discharge_power; r.pdis_min[s] = c.ev_min_discharge_power;
-                    r.ev_ph[s] = c.ev_phases; r.ts[s] = c.ev_transition_soc; r.ev_lut[s] = -1;
-                    r.eta_ch[s] = c.ev_charge_efficiency; r.eta_dis[s] = c.ev_discharge_efficiency;
-                }
+                r.cap0[s] = e.cap0; r.B[s] = e.B; r.desired[s] = f.desired; r.minB[s] = f.minB; r.min_emerg[s] = f.min_emerg;
+                r.pac_max[s] = e.pac; r.tsm[s] = f.tsm; r.pac_min[s] = f.pac_min; r.pdis_max[s] = f.pdis_max; r.pdis_min[s] = f.pdis_min;
+                r.ev_ph[s] = f.phases; r.ts[s] = f.ts; r.ev_lut[s] = f.lut; r.eta_ch[s] = f.eta_ch; r.eta_dis[s] = f.eta_dis;
             }
         }
     };

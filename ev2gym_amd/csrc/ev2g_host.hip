@@ -19,6 +19,7 @@
 #include "ev2g_step_wave.h"
 #include "ev2g_mlp.h"
 #include "ev2g_comm.h"
+#include "ev2g_refill.h"
 #include <cstdlib>
 
 static thread_local std::string g_create_error;
@@ -48,6 +49,16 @@ struct ev2g_handle {
     double *d_step_tab = nullptr;               // [M,T,8] (fast path)
     V2P *d_v2p = nullptr;                       // device copy of the v2 kernel's parameter block
     int block = 0;                              // 256/512/1024: v2 kernel; 0: generic kernel (P > 1024)
+    double *d_head_tab = nullptr; int head_nh = 0;   // observation head table of the fast path (rebuilt for refilled slots)
+    double *d_lut_rowmax = nullptr;             // [n_lut] largest entry of every efficiency table
+    bool refilled = false;                      // ev2g_pool_refill ran: the host copies of the scenarios (peek) no longer describe the pool
+    int *d_refill_overflow = nullptr;
+    struct RefillCache {                        // device copies of the generator config's arrays, kept while the config does not change
+        std::vector<unsigned char> key;
+        std::vector<void *> allocs;
+        RefillArgs args{};
+    } refill_cache;
+    int sess_cap = 0;                           // EV2G_FLAG_REFILLABLE: session slots per scenario of the resident pool (0: packed storage)
     bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
     std::string kernel_name;                    // the step kernel ev2g_load_scenarios selected (ev2g_kernel_name)
     std::string fallback_reason;                // why the common-shape fast path was NOT taken ("" when it was / does not apply)
@@ -107,6 +118,8 @@ static void free_pool(std::vector<void *> &pool) {
     pool.clear();
 }
 
+#include "ev2g_refill_host.h"
+
 extern "C" {
 
 int ev2g_abi_version(void) { return EV2G_ABI_VERSION; }
@@ -163,6 +176,7 @@ void ev2g_destroy(ev2g_handle *h) {
     free_pool(h->scn_allocs);
     free_pool(h->st_allocs);
     free_pool(h->user_allocs);
+    free_pool(h->refill_cache.allocs);
     ev2g_comm_destroy(h);
     drop_rollout_graphs(h);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -307,10 +321,24 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     for (int r = 0; r < R; r++) max_seg = std::max(max_seg, tr_seg[r + 1] - tr_seg[r]);
 
     // ---- resolve ports (first-free replay, ev_charger.py:266-286) and order sessions by (env, slot, arrival) ----
-    std::vector<int> sess_port((size_t)S), host_to_dev((size_t)S), ss_slot((size_t)std::max<long long>(S, 1));   // ss_slot: port slot of a session, device order
-    std::vector<int> scn_sess((size_t)M + 1);   // device sessions of scenario m: [scn_sess[m], scn_sess[m+1]) (device order is scenario-major)
-    for (int m = 0; m <= M; m++) scn_sess[(size_t)m] = (int)b->env_session_start[m];
-    std::vector<long long> dev_to_host((size_t)S);
+    // Device session storage.  Packed (default): scenario m owns the device sessions [env_session_start[m], env_session_start[m+1]).
+    // EV2G_FLAG_REFILLABLE: every scenario owns a fixed-size block of `cap` session slots (the largest count of the batch + 25 % + 8,
+    // or EV2G_POOL_SESSION_CAP), so that ev2g_pool_refill can regenerate a scenario in place on the device; SD counts slots, holes included.
+    const bool refillable = (h->cfg.flags & EV2G_FLAG_REFILLABLE) != 0;
+    long long cap = 0;
+    if (refillable) {
+        for (int m = 0; m < M; m++) cap = std::max<long long>(cap, b->env_session_start[m + 1] - b->env_session_start[m]);
+        cap = ((cap + cap / 4 + 8) + 7) / 8 * 8;
+        if (const char *e = std::getenv("EV2G_POOL_SESSION_CAP")) cap = std::max<long long>(cap, std::atoll(e));
+        if (cap * M > 0x7ffffff0LL) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: too many session slots for 32-bit indices (refillable pool)");
+    }
+    const long long SD = refillable ? cap * M : S;
+    h->sess_cap = (int)cap;
+    std::vector<int> sess_port((size_t)S), host_to_dev((size_t)S), ss_slot((size_t)std::max<long long>(SD, 1));   // ss_slot: port slot of a session, device order
+    std::vector<int> scn_sess((size_t)M + 1), scn_sess_end((size_t)M);   // device sessions of scenario m: [scn_sess[m], scn_sess_end[m]) (device order is scenario-major)
+    for (int m = 0; m <= M; m++) scn_sess[(size_t)m] = refillable ? (int)(cap * m) : (int)b->env_session_start[m];
+    for (int m = 0; m < M; m++) scn_sess_end[(size_t)m] = scn_sess[(size_t)m] + (int)(b->env_session_start[m + 1] - b->env_session_start[m]);
+    std::vector<long long> dev_to_host((size_t)SD, -1);
     std::vector<int> port_first((size_t)M * P, -1);
     std::vector<int> port_end((size_t)M * P, -1);   // one past the port's last session (device order: a port's sessions are consecutive)
     std::vector<int2> port_first_win((size_t)M * P, make_int2(EV2G_INT_MAX, EV2G_INT_MAX));
@@ -319,6 +347,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         std::vector<std::pair<long long, long long>> keyed;  // (slot, host idx)
         long long d = 0;
         for (int e = 0; e < M; e++) {
+            d = scn_sess[(size_t)e];
             std::fill(free_at.begin(), free_at.end(), 0);
             const long long s0 = b->env_session_start[e], s1 = b->env_session_start[e + 1];
             if (s1 < s0) return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: env_session_start not monotone");
@@ -363,8 +392,8 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     }
     // ---- gather session fields into device order, chain the next window ----
 #define GATHER(type, name, src)                                 \
-    std::vector<type> name((size_t)S);                          \
-    for (long long d = 0; d < S; d++) name[d] = b->src[dev_to_host[d]];
+    std::vector<type> name((size_t)SD);                         \
+    for (long long d = 0; d < SD; d++) if (dev_to_host[d] >= 0) name[d] = b->src[dev_to_host[d]];
     GATHER(int, ss_tarr, ev_t_arr)
     GATHER(int, ss_tdep, ev_t_dep)
     GATHER(int, ss_phases, ev_phases)
@@ -383,10 +412,11 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     GATHER(double, ss_etach, ev_eta_ch)
     GATHER(double, ss_etadis, ev_eta_dis)
 #undef GATHER
-    std::vector<int> ss_ntarr((size_t)S, EV2G_INT_MAX), ss_ntdep((size_t)S, EV2G_INT_MAX);
-    std::vector<double> ss_afap((size_t)S), sess_afap_host((size_t)S);
-    for (long long d = 0; d + 1 < S; d++) {
+    std::vector<int> ss_ntarr((size_t)SD, EV2G_INT_MAX), ss_ntdep((size_t)SD, EV2G_INT_MAX);
+    std::vector<double> ss_afap((size_t)SD), sess_afap_host((size_t)S);
+    for (long long d = 0; d + 1 < SD; d++) {
         const long long a = dev_to_host[d], c = dev_to_host[d + 1];
+        if (a < 0 || c < 0) continue;   // (an unused slot of a refillable pool)
         // same env and same port => the next device session is this port's next session
         bool same_env = false;
         {
@@ -445,7 +475,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     if (h->wave_path) {   // ev2g_step_wave addresses every array as base + 32-bit byte offset: all of them must stay below 4 GiB
         const unsigned long long lim = 1ull << 32;
         const unsigned long long biggest = std::max({(unsigned long long)E * P * 8, (unsigned long long)E * D * 8,
-                                                     (unsigned long long)M * (T + 1) * 60 * 8, (unsigned long long)S * sizeof(SessRec),
+                                                     (unsigned long long)M * (T + 1) * 60 * 8, (unsigned long long)SD * sizeof(SessRec),
                                                      (unsigned long long)M * T * 64, (unsigned long long)E * T * 8 * 3, (unsigned long long)M * P * 8,
                                                      (h->cfg.flags & EV2G_FLAG_LOG_SOC) ? (unsigned long long)E * T * P * 8 : 0ull,
                                                      (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) ? (unsigned long long)T * E * C * 8 : 0ull});
@@ -489,9 +519,10 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
             HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     }
     // AoS session records (one cache line each) for the v2 kernel
-    std::vector<SessRec> recs((size_t)std::max<long long>(S, 1));
-    for (long long d = 0; d < S; d++) {
+    std::vector<SessRec> recs((size_t)std::max<long long>(SD, 1));
+    for (long long d = 0; d < SD; d++) {
         const long long hs = dev_to_host[d];
+        if (hs < 0) continue;
         const int cs = b->ev_cs[hs];
         SessRec &r = recs[d];
         r.B = ss_B[d]; r.cap0 = ss_cap0[d]; r.des = ss_des[d]; r.minB = ss_minB[d]; r.emerg = ss_emerg[d];
@@ -581,10 +612,18 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     for (size_t i = 0; i < lut_eta.size(); i++) lut_eta[i] = b->lut[i] / 100.0;
     double *d_lut_eta = nullptr;
     UP(d_lut_eta, lut_eta)
+    {   // the largest entry of every efficiency table (percent): what EV.calculate_max_energy_with_AFAP uses (ev.py:418-421); device-side refills need it
+        std::vector<double> rowmax((size_t)std::max(b->n_lut, 1), 0.0);
+        for (int l = 0; l < b->n_lut; l++)
+            for (int k = 0; k < EV2G_LUT_LEN; k++) rowmax[l] = std::max(rowmax[l], b->lut[(size_t)l * EV2G_LUT_LEN + k]);
+        UP(dp, rowmax) h->d_lut_rowmax = dp;
+    }
+    h->refilled = false;
     UP(ip, port_first) s.port_first = ip;
     UP(ip, port_end) s.port_end = ip;
     UP(ip, ss_slot) s.ss_slot = ip;
     UP(ip, scn_sess) s.scn_sess = ip;
+    UP(ip, scn_sess_end) s.scn_sess_end = ip;
     UP(i2p, port_first_win) s.port_first_win = i2p;
     UP(dp, ss_afap) h->d_ss_afap = dp;
     { SessRec *rp; UP(rp, recs) s.rec = rp; }
@@ -597,7 +636,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         HIPCHK(h, hipMalloc((void **)&tab, n * sizeof(double)));
         pool.push_back(tab);
         const int nb = (int)std::min<size_t>((n + 255) / 256, 4096);
-        hipLaunchKernelGGL(ev2g_build_window_table_kernel, dim3(nb), dim3(256), 0, h->stream, s, tab);
+        hipLaunchKernelGGL(ev2g_build_window_table_kernel, dim3(nb), dim3(256), 0, h->stream, s, tab, 0, M);
         HIPCHK(h, hipGetLastError());
         s.win_tab = tab;
     }
@@ -608,19 +647,21 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         HIPCHK(h, hipMalloc((void **)&d_step_tab, n * sizeof(double)));
         pool.push_back(d_step_tab);
         const int nb = (int)std::min<size_t>(((size_t)M * T + 255) / 256, 4096);
-        hipLaunchKernelGGL(ev2g_build_step_table_kernel, dim3(nb), dim3(256), 0, h->stream, s, d_step_tab);
+        hipLaunchKernelGGL(ev2g_build_step_table_kernel, dim3(nb), dim3(256), 0, h->stream, s, d_step_tab, 0, M);
         HIPCHK(h, hipGetLastError());
         h->d_step_tab = d_step_tab;
     }
     double *d_head_tab = nullptr;
+    h->d_head_tab = nullptr; h->head_nh = 0;
     if (h->wave_path && sk != EV2G_STATE_PUBLIC_PST) {
         const int NH = (sk == EV2G_STATE_V2G_PROFIT_MAX_LOADS) ? 60 : 20;
         const size_t n = (size_t)M * (T + 1) * NH;
         HIPCHK(h, hipMalloc((void **)&d_head_tab, n * sizeof(double)));
         pool.push_back(d_head_tab);
         const int nb = (int)std::min<size_t>((n + 255) / 256, 4096);
-        hipLaunchKernelGGL(ev2g_build_head_table_kernel, dim3(nb), dim3(256), 0, h->stream, s.price_ch, s.win_tab, M, T, NH, d_head_tab);
+        hipLaunchKernelGGL(ev2g_build_head_table_kernel, dim3(nb), dim3(256), 0, h->stream, s.price_ch, s.win_tab, 0, M, T, NH, d_head_tab);
         HIPCHK(h, hipGetLastError());
+        h->d_head_tab = d_head_tab; h->head_nh = NH;
     }
     // ---- state ----
     DevState &st = h->st;
@@ -648,10 +689,10 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     AL(env_acc, (size_t)E * 8) AL(env_fault, E)
     AL(slab_hist, (size_t)T * E * (2 + R))
     st.usage_hist = st.slab_hist; st.pot_hist = st.slab_hist + (size_t)T * E; st.over_hist = st.slab_hist + (size_t)T * E * 2;
-    AL(slab_sess, (size_t)std::max<long long>(S, 1) * 2)
+    AL(slab_sess, (size_t)std::max<long long>(SD, 1) * 2)
     st.sess_final_cap = st.slab_sess;
     AL(tr_power_now, (size_t)E * R)
-    if (h->cfg.flags & EV2G_FLAG_LOG_SOC) { AL(soc_log, (size_t)T * EP) st.sess_abs_e = st.slab_sess + (size_t)std::max<long long>(S, 1); }
+    if (h->cfg.flags & EV2G_FLAG_LOG_SOC) { AL(soc_log, (size_t)T * EP) st.sess_abs_e = st.slab_sess + (size_t)std::max<long long>(SD, 1); }
 #ifdef EV2G_PHASE_TIMING
     AL(dbg, (size_t)s.n_groups * 18)
 #endif
@@ -1196,6 +1237,7 @@ int ev2g_gather_stats(ev2g_handle *h, double *stats_all) {
 int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *v) {
     if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_peek: no scenarios loaded");
     if (!v || env < 0 || env >= h->E) return fail(h, EV2G_ERR_ARG, "ev2g_peek: bad arguments");
+    if (h->refilled) return fail(h, EV2G_ERR_STATE, "ev2g_peek: the scenario pool was refilled on the device (ev2g_pool_refill): the host holds no copy of its scenarios");
     (void)hipSetDevice(h->device);
     const int P = h->P, C = h->C, R = h->R, T = h->T, E = h->E;
     const DevState &st = h->st;
@@ -1354,6 +1396,12 @@ void ev2g_host_uniform(double *dst, int64_t n, uint64_t seed, double lo, double 
 
 // ---- scenario generator (host only) ----
 int ev2g_gen_default_config(int kind, ev2g_gen_config *cfg) { return ev2g_gen_default_config_impl(kind, cfg); }
+int ev2g_pool_refill(ev2g_handle *h, const ev2g_gen_config *cfg, uint64_t seed, int64_t first_index, int32_t first_slot, int32_t n) {
+    try { return ev2g_pool_refill_impl(h, cfg, seed, first_index, first_slot, n); }
+    catch (const std::exception &e) { return fail(h, EV2G_ERR_ARG, std::string("ev2g_pool_refill: ") + e.what()); }
+}
+long long ev2g_pool_refill_overflows(ev2g_handle *h) { return ev2g_pool_refill_overflows_impl(h); }
+int ev2g_pool_session_capacity(const ev2g_handle *h) { return h ? h->sess_cap : 0; }
 int ev2g_generate(const ev2g_gen_config *cfg, int32_t n_scenarios, uint64_t seed, int32_t n_threads, ev2g_gen_result **out) {
     return ev2g_generate_impl(cfg, n_scenarios, seed, n_threads, out);
 }

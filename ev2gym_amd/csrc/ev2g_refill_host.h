@@ -1,0 +1,122 @@
+// ev2g_refill_host.h -- host side of ev2g_pool_refill (include/ev2g.h): checks that the config describes the shape of the resident pool,
+// keeps device copies of the config's arrays while the config does not change, launches ev2g_refill_kernel (one wavefront per scenario)
+// and the loader's table kernels for the refilled slots.  Everything is enqueued on the handle's stream; nothing is copied back.
+// Included by ev2g_host.hip after the handle type.
+#pragma once
+
+static void refill_append(std::vector<unsigned char> &key, const void *p, size_t n) {
+    const unsigned char *b = (const unsigned char *)p;
+    key.insert(key.end(), b, b + n);
+}
+
+static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uint64_t seed, int64_t first_index, int32_t first_slot, int32_t n) {
+    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_pool_refill: no scenarios loaded");
+    if (!cfg || n < 0 || first_slot < 0 || first_index < 0 || (long long)first_slot + n > h->M)
+        return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: slot range outside the pool");
+    if (!(h->cfg.flags & EV2G_FLAG_REFILLABLE) || h->sess_cap <= 0)
+        return fail(h, EV2G_ERR_STATE, "ev2g_pool_refill: the pool was not loaded with EV2G_FLAG_REFILLABLE (fixed-size session blocks)");
+    const DevScn &s = h->scn;
+    const ev2g_gen_config &c = *cfg;
+    if (s.npc != 1 || s.het || c.topo_n_ports) return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: single-port chargers without a topology file only");
+    if (c.simulation_length != s.T || c.timescale != s.dt || c.number_of_charging_stations != s.C || c.number_of_transformers != s.R ||
+        c.number_of_ports_per_cs != 1)
+        return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: the config does not describe the shape of the resident pool (steps, timescale, chargers, transformers)");
+    if (c.scenario < 0 || c.scenario > 2 || c.simulation_days < 0 || c.simulation_days > 2) return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: scenario / simulation_days out of range");
+    if (c.n_ev_specs < 0 || (c.n_ev_specs > 0 && !(c.spec_registrations && c.spec_battery_capacity && c.spec_max_ac_charge_power && c.spec_max_ac_discharge_power)))
+        return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: n_ev_specs > 0 needs the four spec_* model arrays");
+    if ((c.tab_arrival_week || c.tab_arrival_weekend || c.tab_stay || c.tab_energy) && !(c.tab_arrival_week && c.tab_arrival_weekend && c.tab_stay && c.tab_energy))
+        return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: the arrival / stay / energy tables of a data directory come together");
+    const int nd = c.demand_response ? std::max(c.dr_events_per_day, 1) : 1;
+    if (nd > s.ND) return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: more demand-response events per day than the resident pool has slots for");
+    if (n == 0) return EV2G_OK;
+    (void)hipSetDevice(h->device);
+
+    // ---- device copies of the config's arrays: rebuilt only when the config (or the content of its arrays) changes ----
+    std::vector<int> spec_row;
+    const int n_spec_lut = ev2g_gen_spec_rows(c, spec_row);
+    const int want_lut = c.n_ev_specs > 0 ? n_spec_lut : ((c.heterogeneous_ev_specs && c.fleet_with_efficiency_tables) ? EV2G_GEN_FLEET_MAX : 0);
+    if (c.heterogeneous_ev_specs && want_lut != s.n_lut)
+        return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: the config's fleet has " + std::to_string(want_lut) + " efficiency tables, the resident pool " +
+                                         std::to_string(s.n_lut) + " (load the pool from ev2g_generate with the same config)");
+    std::vector<unsigned char> key;
+    refill_append(key, &c, sizeof c);
+    const size_t ns = (size_t)std::max(c.n_ev_specs, 0);
+    if (ns) {
+        refill_append(key, c.spec_registrations, ns * 8); refill_append(key, c.spec_battery_capacity, ns * 8);
+        refill_append(key, c.spec_max_ac_charge_power, ns * 8); refill_append(key, c.spec_max_ac_discharge_power, ns * 8);
+        if (c.spec_efficiency) refill_append(key, c.spec_efficiency, ns * EV2G_LUT_LEN * 8);
+    }
+    if (c.tab_arrival_week) { refill_append(key, c.tab_arrival_week, 96 * 8); refill_append(key, c.tab_arrival_weekend, 96 * 8); refill_append(key, c.tab_stay, 48 * 8); refill_append(key, c.tab_energy, 48 * 8); }
+    if (c.tab_pv && c.n_pv > 0) refill_append(key, c.tab_pv, (size_t)c.n_pv * 8);
+    auto &rc_ = h->refill_cache;
+    if (rc_.key != key) {
+        (void)hipStreamSynchronize(h->stream);
+        free_pool(rc_.allocs);
+        rc_.key.clear();
+        RefillArgs a{};
+        a.cfg = c;
+        a.cfg.topo_n_ports = nullptr; a.cfg.topo_transformer = nullptr; a.cfg.topo_phases = nullptr;
+        int rc = 0;
+        auto upd = [&](const double *src, size_t cnt, const double **dst) { *dst = nullptr; if (!src || !cnt) return 0; double *p; rc = upload(h, rc_.allocs, src, cnt, &p); *dst = p; return rc; };
+        if (upd(c.spec_registrations, ns, &a.cfg.spec_registrations) || upd(c.spec_battery_capacity, ns, &a.cfg.spec_battery_capacity) ||
+            upd(c.spec_max_ac_charge_power, ns, &a.cfg.spec_max_ac_charge_power) || upd(c.spec_max_ac_discharge_power, ns, &a.cfg.spec_max_ac_discharge_power) ||
+            upd(c.spec_efficiency, c.spec_efficiency ? ns * EV2G_LUT_LEN : 0, &a.cfg.spec_efficiency) ||
+            upd(c.tab_arrival_week, c.tab_arrival_week ? 96 : 0, &a.cfg.tab_arrival_week) || upd(c.tab_arrival_weekend, c.tab_arrival_week ? 96 : 0, &a.cfg.tab_arrival_weekend) ||
+            upd(c.tab_stay, c.tab_arrival_week ? 48 : 0, &a.cfg.tab_stay) || upd(c.tab_energy, c.tab_arrival_week ? 48 : 0, &a.cfg.tab_energy))
+            return rc;
+        a.cfg.tab_pv = nullptr;   // the device uses the smoothed series below
+        std::vector<double> pv;
+        if (const char *err = ev2g_gen_pv_series(c, c.timescale, pv)) return fail(h, EV2G_ERR_ARG, err);
+        if (upd(pv.data(), pv.size(), &a.pv_series)) return rc;
+        if (!spec_row.empty()) { int *p; if ((rc = upload(h, rc_.allocs, spec_row.data(), spec_row.size(), &p))) return rc; a.spec_row = p; }
+        if (!h->d_refill_overflow) {
+            int *p;
+            if ((rc = dalloc(h, h->scn_allocs, 1, &p))) return rc;
+            HIPCHK(h, hipMemsetAsync(p, 0, sizeof(int), h->stream));
+            h->d_refill_overflow = p;
+        }
+        ev2g_gen_make_run(c, s.P, 1, seed, a.g0);
+        a.g0.c = nullptr;
+        a.g0.pv_per_day = pv.empty() ? 0 : 1440 / c.timescale;
+        (void)hipStreamSynchronize(h->stream);   // the staging vectors are temporaries
+        rc_.args = a;
+        rc_.key = key;
+    }
+    RefillArgs a = rc_.args;
+    a.lut_rowmax = h->d_lut_rowmax;
+    a.seed = seed; a.first_index = first_index; a.first_slot = first_slot; a.n = n; a.cap = h->sess_cap;
+    a.overflow = h->d_refill_overflow;
+    a.g0.seed = seed;
+    const size_t lds = ev2g_refill_lds_bytes(s.T, s.P, h->sess_cap);
+    if (lds > 160 * 1024) return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: the scenario's work arrays exceed the LDS");
+    if (lds > 48 * 1024) HIPCHK(h, hipFuncSetAttribute((const void *)ev2g_refill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ev2g_refill_kernel, dim3(n), dim3(64), lds, h->stream, s, h->st, a, h->d_ss_afap);
+    HIPCHK(h, hipGetLastError());
+    // the observation tables of the refilled slots (the loader's kernels, restricted to them)
+    const int m0 = first_slot, m1 = first_slot + n;
+    if (s.win_tab) {
+        const size_t cnt = (size_t)n * s.R * (s.T + 1) * 40;
+        hipLaunchKernelGGL(ev2g_build_window_table_kernel, dim3((int)std::min<size_t>((cnt + 255) / 256, 4096)), dim3(256), 0, h->stream, s, const_cast<double *>(s.win_tab), m0, m1);
+    }
+    if (h->d_step_tab) {
+        const size_t cnt = (size_t)n * s.T;
+        hipLaunchKernelGGL(ev2g_build_step_table_kernel, dim3((int)std::min<size_t>((cnt + 255) / 256, 4096)), dim3(256), 0, h->stream, s, h->d_step_tab, m0, m1);
+    }
+    if (h->d_head_tab) {
+        const size_t cnt = (size_t)n * (s.T + 1) * h->head_nh;
+        hipLaunchKernelGGL(ev2g_build_head_table_kernel, dim3((int)std::min<size_t>((cnt + 255) / 256, 4096)), dim3(256), 0, h->stream, s.price_ch, s.win_tab, m0, m1, s.T,
+                           h->head_nh, h->d_head_tab);
+    }
+    HIPCHK(h, hipGetLastError());
+    h->refilled = true;
+    return EV2G_OK;
+}
+
+static long long ev2g_pool_refill_overflows_impl(ev2g_handle *h) {
+    if (!h || !h->d_refill_overflow) return 0;
+    int v = 0;
+    (void)hipSetDevice(h->device);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    if (hipMemcpy(&v, h->d_refill_overflow, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}

@@ -84,6 +84,9 @@ def load_library(path: Optional[str] = None):
         "ev2g_comm_world_size": (C.c_int, [vp]),
         "ev2g_comm_gathers": (C.c_longlong, [vp]),
         "ev2g_gather_stats": (C.c_int, [vp, vp]),
+        "ev2g_pool_refill": (C.c_int, [vp, C.POINTER(_abi.GenConfigC), C.c_uint64, i64, i32, i32]),
+        "ev2g_pool_refill_overflows": (C.c_longlong, [vp]),
+        "ev2g_pool_session_capacity": (C.c_int, [vp]),
         "ev2g_gen_default_config": (C.c_int, [C.c_int, C.POINTER(_abi.GenConfigC)]),
         "ev2g_generate": (C.c_int, [C.POINTER(_abi.GenConfigC), i32, C.c_uint64, i32, C.POINTER(vp)]),
         "ev2g_gen_batch": (C.POINTER(_abi.ScenarioBatchC), [vp]),
@@ -108,7 +111,7 @@ EXPORTED_SYMBOLS = [
     "ev2g_memcpy_h2d", "ev2g_memcpy_d2h", "ev2g_synchronize", "ev2g_fill_uniform", "ev2g_host_uniform",
     "ev2g_last_step_n_kernel_ms", "ev2g_mlp_create", "ev2g_mlp_create_ex", "ev2g_mlp_destroy", "ev2g_mlp_forward", "ev2g_rollout",
     "ev2g_rollout_graph_launches", "ev2g_comm_get_unique_id", "ev2g_comm_init", "ev2g_comm_destroy", "ev2g_comm_world_size", "ev2g_comm_gathers", "ev2g_gather_stats",
-    "ev2g_gen_default_config", "ev2g_generate", "ev2g_gen_batch", "ev2g_gen_free", "ev2g_gen_table"]
+    "ev2g_pool_refill", "ev2g_pool_refill_overflows", "ev2g_pool_session_capacity", "ev2g_gen_default_config", "ev2g_generate", "ev2g_gen_batch", "ev2g_gen_free", "ev2g_gen_table"]
 
 
 def _ptr(x):
@@ -338,6 +341,25 @@ class Engine:
             return buf.to_host()
         finally:
             buf.free()
+
+    # ---- scenario generation on the device ---------------------------------------------------------
+    def pool_refill(self, gen_cfg, seed: int, first_index: int, first_slot: int, n: int):
+        """Re-draw pool slots [first_slot, first_slot + n) ON THE DEVICE as scenarios first_index.. of the stream (gen_cfg, seed): bit for
+        bit what `generate_native(gen_cfg with that seed)` yields at those indices (include/ev2g.h: ev2g_pool_refill).  The engine must have
+        been created with FLAG_REFILLABLE from a batch drawn with the same config.  Asynchronous; refill slots no env is stepping."""
+        from .scenario_gen import gen_config_c
+        c, keep = gen_config_c(gen_cfg)
+        self._check(self._lib.ev2g_pool_refill(self._h, C.byref(c), int(seed) & (2 ** 64 - 1), int(first_index), int(first_slot), int(n)))
+        self.batch_is_stale = True
+        del keep
+
+    @property
+    def pool_refill_overflows(self) -> int:
+        return int(self._lib.ev2g_pool_refill_overflows(self._h))
+
+    @property
+    def pool_session_capacity(self) -> int:
+        return int(self._lib.ev2g_pool_session_capacity(self._h))
 
     def peek(self, env: int = 0) -> dict:
         """Host copy of one env's state in the reference's port order (feeds the EV2Gym facade)."""

@@ -514,15 +514,10 @@ def generate(cfg: GenConfig) -> ScenarioBatch:
     return ScenarioBatch(E, T, dt, Cn, npc, R, cfg.v2g_enabled, 20, a).finalize()
 
 
-def generate_native(cfg: GenConfig, n_threads: int = 0) -> ScenarioBatch:
-    """The same model drawn by the library's own generator (`ev2g_generate`, csrc/ev2g_gen.h: C++, one thread per slice of the
-    scenarios, counter-based random numbers): what a non-Python host of the C-ABI uses, 20-60x faster than `generate` on a many-core box.
-    Same distributions and fitted tables, different random streams -- the two agree statistically (tests/test_host_logic.py holds both to
-    the reference's spawn statistics), not draw by draw.  One semantic difference: `random_hour` draws a start hour per scenario here (as the
-    reference does per reset), once per batch in `generate`.  Host code only: no GPU is touched."""
+def gen_config_c(cfg: GenConfig):
+    """`cfg` as the C-ABI's ev2g_gen_config (include/ev2g.h) plus the numpy arrays its pointers borrow (keep them alive while the
+    struct is in use): what ev2g_generate and ev2g_pool_refill take."""
     import ctypes as C
-    from .engine import EngineError, load_library
-    L = load_library()
     c = _abi.GenConfigC()
     for n in _abi.GEN_INT_FIELDS:
         if n == "scenario":
@@ -566,6 +561,19 @@ def generate_native(cfg: GenConfig, n_threads: int = 0) -> ScenarioBatch:
             setattr(c, n, arr.ctypes.data_as(C.POINTER(C.c_double)))
             if key == "pv":
                 c.n_pv = len(arr)
+    return c, keep
+
+
+def generate_native(cfg: GenConfig, n_threads: int = 0) -> ScenarioBatch:
+    """The same model drawn by the library's own generator (`ev2g_generate`, csrc/ev2g_gen.h: C++, one thread per slice of the
+    scenarios, counter-based random numbers): what a non-Python host of the C-ABI uses, 20-60x faster than `generate` on a many-core box.
+    Same distributions and fitted tables, different random streams -- the two agree statistically (tests/test_host_logic.py holds both to
+    the reference's spawn statistics), not draw by draw.  One semantic difference: `random_hour` draws a start hour per scenario here (as the
+    reference does per reset), once per batch in `generate`.  Host code only: no GPU is touched."""
+    import ctypes as C
+    from .engine import EngineError, load_library
+    L = load_library()
+    c, keep = gen_config_c(cfg)
     res = C.c_void_p()
     rc = L.ev2g_generate(C.byref(c), int(cfg.n_envs), int(cfg.seed) & (2 ** 64 - 1), int(n_threads), C.byref(res))
     if rc:

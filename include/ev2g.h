@@ -72,6 +72,8 @@ extern "C" {
 #define EV2G_FLAG_NULL_STREAM 2    /* launch on the legacy default stream (torch's default stream) */
 #define EV2G_FLAG_LOG_SOC 4        /* keep the per-step SoC log + |energy| sums that EV.get_battery_degradation needs
                                       (ev.py:156,162,180,185,442-521); without it the three degradation stats are NaN */
+#define EV2G_FLAG_REFILLABLE 8     /* the resident scenario pool keeps a fixed-size block of session slots per scenario, so that
+                                      ev2g_pool_refill can draw new scenarios into it ON THE DEVICE (default: packed storage)          */
 
 typedef struct ev2g_handle ev2g_handle;
 
@@ -397,6 +399,19 @@ typedef struct ev2g_gen_result ev2g_gen_result;
 int ev2g_generate(const ev2g_gen_config *cfg, int32_t n_scenarios, uint64_t seed, int32_t n_threads, ev2g_gen_result **out);
 const ev2g_scenario_batch *ev2g_gen_batch(const ev2g_gen_result *r); /* arrays owned by r */
 void ev2g_gen_free(ev2g_gen_result *r);
+/* ---- scenario generation ON THE DEVICE: new scenarios drawn straight into the resident pool ------------------------------
+ * EV2Gym.reset() draws a new scenario every episode (ev2gym_env.py:243-296).  The resident pool gives every episode fresh scenarios
+ * for pool / envs episodes; this call re-draws pool slots [first_slot, first_slot + n) WITHOUT host work or PCIe traffic: slot
+ * first_slot + j becomes scenario first_index + j of the stream (cfg, seed) -- bit for bit what ev2g_generate(cfg, ., seed) yields at
+ * that index followed by ev2g_load_scenarios (one wavefront per scenario runs the generator's own code, csrc/ev2g_refill.h).
+ * Requirements: the pool was loaded with EV2G_FLAG_REFILLABLE from a batch drawn with the same config (shape, fleet); single-port
+ * chargers, no topology file.  Asynchronous on the handle's stream; refill slots that no env is currently stepping (e.g. the window
+ * the previous episode used).  Afterwards ev2g_peek is refused (the host holds no copy of the new scenarios).
+ * ev2g_pool_refill_overflows: scenarios (since load) that drew more sessions than ev2g_pool_session_capacity slots and were
+ * truncated (synchronises; 0 in practice: the blocks are 25 % + 8 larger than the largest scenario of the loaded batch). */
+int ev2g_pool_refill(ev2g_handle *h, const ev2g_gen_config *cfg, uint64_t seed, int64_t first_index, int32_t first_slot, int32_t n);
+long long ev2g_pool_refill_overflows(ev2g_handle *h);
+int ev2g_pool_session_capacity(const ev2g_handle *h);
 /* the generator's fitted tables: which = 0 arrivals per port per hour in percent, 1 mean stay in hours (24 values each),
  * 2 mean required energy (1 value), for table kind 0 workplace, 1 public, 2 private, 3 public weekend, 4 private weekend;
  * which = 3 / 4: the V2G / EV+PHEV fleet as rows of (share, battery kWh, max AC kW); returns the number of values written */

@@ -150,7 +150,7 @@ def test_generator_reproduces_the_reference_spawn_statistics(name, yaml_file, ba
 
     def near(x, key, rel=0.0, abs_=0.0):
         assert abs(x - ref[key]) <= rel * abs(ref[key]) + abs_, f"{key}: generator {x:.4g} vs reference {ref[key]:.4g}"
-    near(occupancy_fraction(b), "occupancy_mean", rel=0.06)
+    near(occupancy_fraction(b), "occupancy_mean", rel=0.08)   # (300 envs: +-3 % sampling noise on top of the tables' few-percent modelling error)
     near(((st[1:] - st[:-1]) / P).mean(), "sessions_per_port_mean", rel=0.05)
     near(((st[1:] - st[:-1]) / P).std(), "sessions_per_port_std", rel=0.25)
     near(stay.mean(), "stay_mean", rel=0.05)

@@ -141,3 +141,94 @@ def test_rollout_with_the_float32_actor_equals_forward_then_step():
     for a, b in zip(*out):
         assert np.array_equal(a, b)
     assert np.abs(out[0][2]).max() > 0.01
+
+
+def _refill_cfgs():
+    from ev2gym_amd.scenario_gen import GenConfig
+    return {
+        "v2gppl_c50": lambda M, seed: GenConfig.v2g_profit_plus_loads(M, 50, 1, seed=seed),                                   # fast path, efficiency tables, DR, PV
+        "pst_c20": lambda M, seed: GenConfig.public_pst(M, 20, seed=seed),                                                  # fast path, power setpoints, scalar efficiencies
+        "v2gppl_c30_r3": lambda M, seed: GenConfig.v2g_profit_plus_loads(M, 30, 3, seed=seed, dr_events_per_day=2, random_hour=True),   # ev2g_step_v2: three transformers
+        "homog_pst_public": lambda M, seed: GenConfig.public_pst(M, 12, seed=seed, heterogeneous_ev_specs=False, ev_transition_soc=0.8, timescale=30,
+                                                                  simulation_length=60, simulation_days="both"),
+    }
+
+
+@pytest.mark.parametrize("name", ["v2gppl_c50", "pst_c20", "v2gppl_c30_r3", "homog_pst_public"])
+def test_device_generated_scenarios_equal_the_host_generator_bit_for_bit(name):
+    """ev2g_pool_refill draws scenarios ON THE DEVICE (EV2Gym.reset()'s per-episode draw, ev2gym_env.py:243-296, without host work):
+    pool slot s refilled as scenario i of the stream (config, seed) must hold what ev2g_generate yields at index i -- same seed, same
+    index, bit for bit.  Checked by behaviour through the C-ABI: a pool loaded from OTHER scenarios and then refilled steps whole episodes
+    exactly like a pool loaded from the host-generated ones (observations, rewards, masks, all 17 statistics: array_equal), for a full
+    refill from index 0 and for a partial one (slots 5..11 <- scenarios 40..46) that must leave the other slots untouched."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine, EngineError, host_uniform
+    from ev2gym_amd.scenario_gen import generate_native
+    mk = _refill_cfgs()[name]
+    M, S1, S2 = 24, 77, 1234
+    host = generate_native(mk(47, S1))            # scenarios 0..46 of the stream (config, S1)
+    other = generate_native(mk(M, S2))
+    kinds = ("SquaredTrackingErrorReward", "PublicPST") if "pst" in name else ("ProfitMax_TrPenalty_UserIncentives", "V2G_profit_max_loads")
+    rk, sk = _abi.REWARD_KINDS[kinds[0]], _abi.STATE_KINDS[kinds[1]]
+    flags = _abi.FLAG_LOG_SOC | _abi.FLAG_REFILLABLE
+    lo = 0.0 if "pst" in name else -1.0
+
+    def episode(eng):
+        E, P, D, T = eng.E, eng.P, eng.D, eng.T
+        act, obs, rew = eng.empty((E, P)), eng.empty((E, D)), eng.empty((E,))
+        done, mask = eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
+        eng.reset(obs)
+        out = [obs.to_host().copy()]
+        for t in range(T):
+            act.upload(host_uniform(E * P, 500 + t, lo, 1.0).reshape(E, P))
+            eng.step(act, obs, rew, done, mask)
+            out += [obs.to_host().copy(), rew.to_host().copy(), mask.to_host().copy()]
+        out.append(np.nan_to_num(eng.stats(), nan=-7.0))
+        eng.check_faults()
+        return out
+
+    def same(a, b, rows=None):
+        for x, y in zip(a, b):
+            if rows is not None:
+                x, y = x[rows], y[rows]
+            if not np.array_equal(x, y):
+                return False
+        return True
+
+    ref_full = episode(Engine(host.select(np.arange(M)), rk, sk, device=0, flags=flags))
+    ref_other = episode(Engine(other, rk, sk, device=0, flags=flags))
+    assert not same(ref_full, ref_other)
+    # full refill: every slot becomes scenario 0..M-1 of stream S1
+    eng = Engine(other, rk, sk, device=0, flags=flags)
+    assert eng.pool_session_capacity >= 8
+    eng.pool_refill(mk(M, S1), S1, 0, 0, M)
+    assert same(episode(eng), ref_full), "device-generated scenarios differ from ev2g_generate's"
+    assert eng.pool_refill_overflows == 0
+    with pytest.raises(EngineError):
+        eng.peek(0)
+    # the same slots again from another stream position, then back: a refill is repeatable
+    eng.pool_refill(mk(M, S1), S1, 23, 0, M)
+    assert same(episode(eng), episode(Engine(host.select(np.arange(23, 47)), rk, sk, device=0, flags=flags)))
+    eng.close()
+    # partial refill: slots 5..11 <- scenarios 40..46; every other slot keeps its scenario
+    eng = Engine(other, rk, sk, device=0, flags=flags)
+    eng.pool_refill(mk(M, S1), S1, 40, 5, 7)
+    got = episode(eng)
+    mixed = episode(Engine(_concat_slots(other, host, 5, 40, 7), rk, sk, device=0, flags=flags))
+    assert same(got, mixed)
+    rest = np.r_[0:5, 12:M]
+    assert same(got, ref_other, rows=rest) and not same(got, ref_other, rows=np.arange(5, 12))
+    eng.close()
+    # a pool without the flag refuses
+    eng = Engine(other, rk, sk, device=0, flags=_abi.FLAG_LOG_SOC)
+    with pytest.raises(EngineError):
+        eng.pool_refill(mk(M, S1), S1, 0, 0, M)
+    eng.close()
+
+
+def _concat_slots(base, src, slot0, idx0, n):
+    """`base` with scenarios slot0..slot0+n-1 replaced by src[idx0..idx0+n-1]."""
+    from ev2gym_amd.scenario import ScenarioBatch
+    M = base.n_envs
+    parts = [base.select(np.arange(0, slot0)), src.select(np.arange(idx0, idx0 + n)), base.select(np.arange(slot0 + n, M))]
+    return ScenarioBatch.concat([p for p in parts if p.n_envs > 0])
