@@ -113,24 +113,34 @@ EV2G_HD uint64_t ev2g_mix64(uint64_t z) {   // splitmix64 finaliser
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+// A draw is a 32-bit hash of (scenario key, stream, a, b): two rounds of a multiply-xorshift finaliser ("lowbias32": avalanche bias
+// < 0.2 %) keyed by two words of the scenario's splitmix64 key.  32-bit multiplies because the GPU draws scenarios too: a spawn trial
+// -- one draw per port and step -- is what generating a scenario mostly costs, and a 64 x 64-bit product is four quarter-rate
+// instructions there where this is one.  Integer arithmetic only: the same bits on every processor.
+EV2G_HD uint32_t ev2g_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
 struct Ev2gRng {
     uint64_t key;   // mix of (seed, scenario)
-    // splitmix64 over a per-(scenario, stream) base: the output function of a counter generator applied to base + a * G1 + b * G2
-    // (odd multipliers: distinct (a, b) of the sizes used here give distinct counters).  ONE finaliser per draw: the spawn trials of
-    // a scenario (one draw per port and step) dominate the cost of generating it, on the host and on the device.
-    EV2G_HD uint64_t bits(uint64_t stream, uint64_t a, uint64_t b) const {
-        return ev2g_mix64(ev2g_mix64(key ^ (stream * 0xD1342543DE82EF95ull)) + a * 0x9E3779B97F4A7C15ull + b * 0xA24BAED4963EE407ull);
+    EV2G_HD uint32_t bits(uint64_t stream, uint64_t a, uint64_t b) const {
+        const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+        uint32_t x = ev2g_hash32((k0 + (uint32_t)stream * 0x9E3779B1u) ^ ((uint32_t)a * 0x85EBCA6Bu) ^ (uint32_t)(a >> 32));
+        x = ev2g_hash32((x + k1) ^ ((uint32_t)b * 0xC2B2AE35u) ^ (uint32_t)(b >> 32));
+        return x;
     }
-    EV2G_HD double uni(uint64_t stream, uint64_t a, uint64_t b) const { return (double)(bits(stream, a, b) >> 11) * (1.0 / 9007199254740992.0); }   // [0, 1)
+    EV2G_HD double uni(uint64_t stream, uint64_t a, uint64_t b) const { return ((double)bits(stream, a, b) + 0.5) * (1.0 / 4294967296.0); }   // (0, 1)
     EV2G_HD double uni(uint64_t stream, uint64_t a, uint64_t b, double lo, double hi) const { return lo + (hi - lo) * uni(stream, a, b); }
     EV2G_HD long long integers(uint64_t stream, uint64_t a, uint64_t b, long long lo, long long hi) const {   // lo <= x < hi
         const long long n = hi - lo;
         return lo + (long long)floor(uni(stream, a, b) * (double)n);
     }
-    // Box-Muller on two counters of their own: bit 62 / 63 of `b` are never set by a uni() / integers() call site, so a normal draw
+    // Box-Muller on two draws of their own: bit 62 / 63 of `b` are never set by a uni() / integers() call site, so a normal draw
     // shares no counter with any other draw of the same (stream, a) -- draws documented as independent are independent
     EV2G_HD double normal(uint64_t stream, uint64_t a, uint64_t b, double mean, double sd) const {
-        const double u1 = 1.0 - uni(stream, a, b | (1ull << 62)), u2 = uni(stream, a, b | (1ull << 63));
+        const double u1 = uni(stream, a, b | (1ull << 62)), u2 = uni(stream, a, b | (1ull << 63));
         return mean + sd * sqrt(-2.0 * ev2g_dlog(u1)) * ev2g_dcos(6.283185307179586 * u2);
     }
 };
@@ -221,52 +231,81 @@ EV2G_HD double ev2g_gen_price_at(const Ev2gGenRun &g, const Ev2gRng &r, double s
 // ---- EV sessions of ONE port, in time order (EV_spawner utils.py:477-557, spawn_single_EV :177-345) -----------------------------------
 struct Ev2gGenSession { int port, t_arr, t_dep, model; double B, pac, cap0; };
 
-template <class Emit>
-EV2G_HD int ev2g_gen_port_sessions(const Ev2gGenRun &g, const Ev2gRng &r, bool weekend, int p, Emit &&emit) {
+// `rate` in percent; the comparison is done on the integer draw: hit <=> bits < rate / 100 * 2^32 (a threshold per step, computed once)
+EV2G_HD uint32_t ev2g_gen_spawn_threshold(double rate) {
+    const double x = rate * (4294967296.0 / 100.0);
+    return !(x > 0.0) ? 0u : (x >= 4294967295.0 ? 4294967295u : (uint32_t)x);
+}
+// the spawner's tables at spawn step t: arrivals per port in percent per step, mean stay in hours, mean required energy in kWh
+struct Ev2gStepTables { double rate, stay, emean; uint32_t threshold, key; };   // threshold / key: the integer form of the spawn trial
+EV2G_HD Ev2gStepTables ev2g_gen_step_tables(const Ev2gGenRun &g, const Ev2gRng &r, bool weekend, int t) {
     const ev2g_gen_config &c = *g.c;
-    const int kind = c.scenario + ((weekend && c.scenario != 0) ? 2 : 0);   // 0 workplace, 1 public, 2 private, 3 public weekend, 4 private weekend
-    const Ev2gFleet fleet = ev2g_fleet(g);
-    double share_sum = 0.0;
-    for (int i = 0; i < fleet.n; i++) share_sum += fleet.share(i);
+    Ev2gStepTables s;
+    if (c.tab_arrival_week) {   // the reference's own tables, looked up its way (utils.py:199-233, 505-528)
+        const int mod = ev2g_minute_of_day(g, t), hh = mod / 60;
+        s.rate = (weekend ? c.tab_arrival_weekend : c.tab_arrival_week)[mod / 15];
+        if (c.scenario == 0 && (hh < 6 || hh > 18)) s.rate = 0.0;
+        s.rate *= (g.dt / 60.0) * c.spawn_multiplier;
+        s.stay = c.tab_stay[mod / 30]; s.emean = c.tab_energy[mod / 30];
+    } else {
+        const int kind = c.scenario + ((weekend && c.scenario != 0) ? 2 : 0);   // 0 workplace, 1 public, 2 private, 3 public weekend, 4 private weekend
+        const double hod = g.hour + c.minute / 60.0 + t * (double)g.dt / 60.0;
+        s.rate = ev2g_gen_interp24(EV2G_GEN_RATE[kind], hod) * (g.dt / 60.0) * c.spawn_multiplier;
+        s.stay = ev2g_gen_interp24(EV2G_GEN_STAY[kind], hod); s.emean = EV2G_GEN_ENERGY[kind];
+    }
+    s.threshold = ev2g_gen_spawn_threshold(s.rate);
+    s.key = r.bits(EV2G_RS_SPAWN, (uint64_t)t, 0);   // the step's own key: a port's trial is one more hash round on top of it
+    return s;
+}
+EV2G_HD double ev2g_gen_share_sum(const Ev2gFleet &fleet) {
+    double a = 0.0;
+    for (int i = 0; i < fleet.n; i++) a += fleet.share(i);
+    return a;
+}
+// does an EV arrive at port p at the end of spawn step t?  (one draw per port and step: what generating a scenario mostly costs)
+// does an EV arrive at port p at the end of spawn step t?  One draw per port and step -- what generating a scenario mostly costs --, so
+// it is one hash round on the step's key, compared as an integer: hit <=> hash32(key_t ^ p * C) < rate_t / 100 * 2^32
+EV2G_HD bool ev2g_gen_spawn_trial(uint32_t step_key, uint32_t threshold, int p) {
+    return ev2g_hash32(step_key ^ ((uint32_t)p * 0x85EBCA6Bu + 0x9E3779B1u)) < threshold;
+}
+// the session spawned at step t on port p (spawn_single_EV utils.py:177-345); false: dropped by empty_ports_at_end_of_simulation (:254-256)
+EV2G_HD bool ev2g_gen_make_session(const Ev2gGenRun &g, const Ev2gRng &r, const Ev2gFleet &fleet, double share_sum, int t, int p, double stay_mean,
+                                   double e_mean, Ev2gGenSession *out) {
+    const ev2g_gen_config &c = *g.c;
+    const uint64_t id = (uint64_t)t * (uint64_t)g.P + (uint64_t)p;
+    double stay = r.normal(EV2G_RS_SESSION, id, 2, stay_mean, 0.2 * stay_mean) * 60.0 / g.dt + 1;
+    if (stay < g.min_stay_steps) stay = g.min_stay_steps;
+    if (stay + t + 4 >= g.T) return false;
+    double req = r.normal(EV2G_RS_SESSION, id, 0, e_mean, 0.5 * e_mean);
+    if (req < 5) req = (double)r.integers(EV2G_RS_SESSION, id, 10, 5, 10);
+    int model = 0;
+    double B = c.ev_battery_capacity, pac = c.ev_max_ac_charge_power;
+    if (c.heterogeneous_ev_specs) {
+        const double u = r.uni(EV2G_RS_SESSION, id, 11) * share_sum;
+        double acc = 0.0;
+        model = fleet.n - 1;
+        for (int i = 0; i < fleet.n; i++) { acc += fleet.share(i); if (u < acc) { model = i; break; } }
+        B = fleet.battery(model); pac = fleet.pac(model);
+    }
+    const long long Bi = (long long)B > 2 ? (long long)B : 2;
+    double cap0 = (B < req) ? (double)r.integers(EV2G_RS_SESSION, id, 12, 1, Bi) : B - req;
+    if (cap0 > c.ev_desired_capacity * B) cap0 = (double)r.integers(EV2G_RS_SESSION, id, 13, 1, Bi);
+    if (cap0 < c.ev_min_battery_capacity && B > 2 * c.ev_min_battery_capacity) cap0 = c.ev_min_battery_capacity;
+    *out = Ev2gGenSession{p, t + 1, (int)(stay + t + 3), model, B, pac, cap0};
+    return true;
+}
+// a port's sessions in time order; tab(t) -> Ev2gStepTables of spawn step t (computed once per scenario by the caller)
+template <class Tab, class Emit>
+EV2G_HD int ev2g_gen_port_sessions(const Ev2gGenRun &g, const Ev2gRng &r, const Ev2gFleet &fleet, double share_sum, int p, Tab &&tab, Emit &&emit) {
     int free_from = 0, n = 0;   // first spawn step at which the port passes the 3-step-empty rule (utils.py:534-552)
     for (int t = 2; t < g.T - g.min_stay_steps - 1; t++) {
         if (free_from > t) continue;
-        const double hod = g.hour + c.minute / 60.0 + t * (double)g.dt / 60.0;
-        double rate, stay_mean, e_mean;
-        if (c.tab_arrival_week) {   // the reference's own tables, looked up its way (utils.py:199-233, 505-528)
-            const int mod = ev2g_minute_of_day(g, t), hh = mod / 60;
-            rate = (weekend ? c.tab_arrival_weekend : c.tab_arrival_week)[mod / 15];
-            if (c.scenario == 0 && (hh < 6 || hh > 18)) rate = 0.0;
-            rate *= (g.dt / 60.0) * c.spawn_multiplier;
-            stay_mean = c.tab_stay[mod / 30]; e_mean = c.tab_energy[mod / 30];
-        } else {
-            rate = ev2g_gen_interp24(EV2G_GEN_RATE[kind], hod) * (g.dt / 60.0) * c.spawn_multiplier;   // percent per step
-            stay_mean = ev2g_gen_interp24(EV2G_GEN_STAY[kind], hod); e_mean = EV2G_GEN_ENERGY[kind];
-        }
-        if (!(rate > 0.0)) continue;
-        const uint64_t id = (uint64_t)t * (uint64_t)g.P + (uint64_t)p;
-        if (!(r.uni(EV2G_RS_SPAWN, id, 0) * 100.0 < rate)) continue;
-        double req = r.normal(EV2G_RS_SESSION, id, 0, e_mean, 0.5 * e_mean);
-        if (req < 5) req = (double)r.integers(EV2G_RS_SESSION, id, 10, 5, 10);
-        int model = 0;
-        double B = c.ev_battery_capacity, pac = c.ev_max_ac_charge_power;
-        if (c.heterogeneous_ev_specs) {
-            const double u = r.uni(EV2G_RS_SESSION, id, 11) * share_sum;
-            double acc = 0.0;
-            model = fleet.n - 1;
-            for (int i = 0; i < fleet.n; i++) { acc += fleet.share(i); if (u < acc) { model = i; break; } }
-            B = fleet.battery(model); pac = fleet.pac(model);
-        }
-        const long long Bi = (long long)B > 2 ? (long long)B : 2;
-        double cap0 = (B < req) ? (double)r.integers(EV2G_RS_SESSION, id, 12, 1, Bi) : B - req;
-        if (cap0 > c.ev_desired_capacity * B) cap0 = (double)r.integers(EV2G_RS_SESSION, id, 13, 1, Bi);
-        if (cap0 < c.ev_min_battery_capacity && B > 2 * c.ev_min_battery_capacity) cap0 = c.ev_min_battery_capacity;
-        double stay = r.normal(EV2G_RS_SESSION, id, 2, stay_mean, 0.2 * stay_mean) * 60.0 / g.dt + 1;
-        if (stay < g.min_stay_steps) stay = g.min_stay_steps;
-        if (stay + t + 4 >= g.T) continue;   // empty_ports_at_end_of_simulation (utils.py:254-256)
-        const int tdep = (int)(stay + t + 3);
-        free_from = tdep + 2;                // occupancy_list[t+1 : t_dep] = 1 and the 3-step look-back
-        emit(n, Ev2gGenSession{p, t + 1, tdep, model, B, pac, cap0});
+        const Ev2gStepTables st = tab(t);
+        if (st.threshold == 0u || !ev2g_gen_spawn_trial(st.key, st.threshold, p)) continue;
+        Ev2gGenSession e;
+        if (!ev2g_gen_make_session(g, r, fleet, share_sum, t, p, st.stay, st.emean, &e)) continue;
+        free_from = e.t_dep + 2;                // occupancy_list[t+1 : t_dep] = 1 and the 3-step look-back
+        emit(n, e);
         n++;
     }
     return n;

@@ -164,6 +164,7 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
         std::vector<std::vector<Ev2gGenSession>> by_port(P);   // a port's sessions, in time order
         std::vector<Ev2gGenSession> buf;                        // the scenario's sessions in EVs_profiles order (arrival step, then port)
         std::vector<double> raw(T), w(T), pad(T + 96), leaves(64);
+        std::vector<Ev2gStepTables> steptab(T);
         for (int m = m0; m < m1; m++) {
             const Ev2gRng rng = ev2g_rng(seed, (uint64_t)m);
             const Ev2gRng rng_tr = (c.tr_seed != -1) ? ev2g_rng((uint64_t)c.tr_seed, (uint64_t)m) : rng;
@@ -175,9 +176,12 @@ static int ev2g_generate_body(const ev2g_gen_config *cfg, int32_t M, uint64_t se
             for (int t = 0; t < T; t++) { const double pr = ev2g_gen_price_at(g, rng, dr.price_scale, t); cp[t] = -pr; dp[t] = pr * c.discharge_price_factor; }
             // sessions: port by port (a port's sessions depend on its own history only), then merged into profile order
             buf.clear();
+            const Ev2gFleet fleet = ev2g_fleet(g);
+            const double share_sum = ev2g_gen_share_sum(fleet);
+            for (int t = 0; t < T; t++) steptab[t] = ev2g_gen_step_tables(g, rng, dr.weekend, t);
             for (int p = 0; p < P; p++) {
                 by_port[p].clear();
-                ev2g_gen_port_sessions(g, rng, dr.weekend, p, [&](int, const Ev2gGenSession &e) { by_port[p].push_back(e); });
+                ev2g_gen_port_sessions(g, rng, fleet, share_sum, p, [&](int t) { return steptab[t]; }, [&](int, const Ev2gGenSession &e) { by_port[p].push_back(e); });
                 buf.insert(buf.end(), by_port[p].begin(), by_port[p].end());
             }
             std::stable_sort(buf.begin(), buf.end(), [](const Ev2gGenSession &a, const Ev2gGenSession &b) { return a.t_arr != b.t_arr ? a.t_arr < b.t_arr : a.port < b.port; });

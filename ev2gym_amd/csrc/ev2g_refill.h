@@ -33,7 +33,11 @@ struct RefillArgs {
     long long first_index;
     int first_slot, n, cap;
     int *overflow;
+    double *head_tab; int head_nh;   // fast path: observation head table [M, T+1, NH] (or null)
+    double *step_tab;                // fast path: [M, T, 8] per-step scalars (or null)
+    unsigned long long *dbg;    // [16] cycle stamps of workgroup 0 (tools/refill_time.py --stamps), or null
 };
+#define RF_STAMP(i) if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = __builtin_readcyclecounter();
 
 __device__ __forceinline__ double rf_wave_max(double v) {
     for (int d = 32; d > 0; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
@@ -60,19 +64,30 @@ __device__ inline double rf_afap(double cap0, double B, double pac, double max_c
     return x;
 }
 
-// LDS (dynamic): doubles l_cp[T] | l_a[T] | l_b[T] | l_pad[T + 96] | per staged session need, lo, hi [cap] ; ints t_arr, t_dep [cap],
-// base / count per PORT [P]; u64 id [cap]
+// LDS (dynamic), kept under 10 KB at the shipped shapes so that 16 one-wavefront workgroups share a CU (4096 scenarios = one round):
+//   doubles l_cp[T] | l_a[T] | l_b[T] | X[3T + 96] | demand-response events [16][3] | per staged session need, lo, hi [cap]
+//   X is, phase after phase: the spawner's per-step {stay, energy} + uint2 {key, threshold} [T]  ->  solar, load forecast, PV forecast of
+//   the transformer in work [T each]  ->  the median filter's padded row [T + 96]
+//   u64 id [cap]; ints t_arr, t_dep [cap], base / count per PORT [P]; uint8 spawn steps [P][EV2G_RF_K]
+#define EV2G_RF_K 8   // spawn steps remembered per port between the two passes (a port with more re-runs its trials in pass 2)
 __host__ __device__ inline size_t ev2g_refill_lds_bytes(int T, int P, int cap) {
-    return sizeof(double) * ((size_t)4 * T + 96 + 3 * (size_t)cap) + sizeof(unsigned long long) * (size_t)cap + sizeof(int) * (2 * (size_t)cap + 2 * (size_t)P);
+    return sizeof(double) * ((size_t)6 * T + 96 + 3 * 16 + 3 * (size_t)cap) + sizeof(unsigned long long) * (size_t)cap + sizeof(int) * (2 * (size_t)cap + 2 * (size_t)P) +
+           (((size_t)P * EV2G_RF_K + 7) & ~(size_t)7);
 }
 
 __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, RefillArgs a, double *ss_afap) {
     extern __shared__ double rlds[];
     const int lane = threadIdx.x;
     const int T = s.T, P = s.P, R = s.R, cap = a.cap;
-    double *l_cp = rlds, *l_a = l_cp + T, *l_b = l_a + T, *l_pad = l_b + T, *l_need = l_pad + T + 96, *l_lo = l_need + cap, *l_hi = l_lo + cap;
+    double *l_cp = rlds, *l_a = l_cp + T, *l_b = l_a + T, *l_x = l_b + T;
+    double *l_stay = l_x, *l_emean = l_x + T; uint2 *l_kt = (uint2 *)(l_x + 2 * T);          // phase 1 (sessions)
+    double *l_sol = l_x, *l_lf = l_x + T, *l_pvf = l_x + 2 * T;                                 // phase 2 (transformers)
+    double *l_pad = l_x;                                                                        // phase 3 (setpoints)
+    double *l_dr = l_x + 3 * T + 96;
+    double *l_need = l_dr + 3 * 16, *l_lo = l_need + cap, *l_hi = l_lo + cap;
     unsigned long long *l_id = (unsigned long long *)(l_hi + cap);
     int *l_ta = (int *)(l_id + cap), *l_td = l_ta + cap, *l_pbase = l_td + cap, *l_pcnt = l_pbase + P;
+    unsigned char *l_spawn = (unsigned char *)(l_pcnt + P);
     const int ms = a.first_slot + blockIdx.x;                  // pool slot
     const unsigned long long m = (unsigned long long)(a.first_index + blockIdx.x);   // scenario index of the stream
     const ev2g_gen_config &c = a.cfg;
@@ -85,6 +100,7 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
     g.hour = dr.hour;
     const int dt = g.dt;
 #define RW(type, field) (const_cast<type *>(s.field))
+    RF_STAMP(0)
 
     // ---- prices ----
     for (int t = lane; t < T; t += 64) {
@@ -94,14 +110,26 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
         RW(double, price_dis)[(size_t)ms * T + t] = pr * c.discharge_price_factor;
     }
 
-    // ---- sessions, pass 1: how many each port slot draws; prefix over the slots (device order = scenario, slot, arrival) ----
+    RF_STAMP(1)
+    // ---- the spawner's tables of every step, once per scenario (a lane per step) ----
+    for (int t = lane; t < T; t += 64) {
+        const Ev2gStepTables stt = ev2g_gen_step_tables(g, rng, dr.weekend, t);
+        l_stay[t] = stt.stay; l_emean[t] = stt.emean; l_kt[t] = make_uint2(stt.key, stt.threshold);
+    }
+    const Ev2gFleet fleet = ev2g_fleet(g);
+    const double share_sum = ev2g_gen_share_sum(fleet);
+    __syncthreads();
+    auto tab = [&](int t) { const uint2 kt = l_kt[t]; return Ev2gStepTables{0.0, l_stay[t], l_emean[t], kt.y, kt.x}; };
+
+    RF_STAMP(2)
+    // ---- sessions, pass 1: how many each port slot draws (and at which steps); prefix over the slots (device order = scenario, slot, arrival) ----
     int carry = 0;
     for (int q0 = 0; q0 < P; q0 += 64) {
         const int q = q0 + lane;
         int n = 0, p = 0;
         if (q < P) {
             p = s.slot_port[q];
-            n = ev2g_gen_port_sessions(g, rng, dr.weekend, p, [](int, const Ev2gGenSession &) {});
+            n = ev2g_gen_port_sessions(g, rng, fleet, share_sum, p, tab, [&](int i, const Ev2gGenSession &e) { if (i < EV2G_RF_K) l_spawn[p * EV2G_RF_K + i] = (unsigned char)(e.t_arr - 1); });
         }
         const int incl = rf_wave_incl_scan(n, lane);
         const int base = carry + incl - n;
@@ -115,6 +143,7 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
     }
     __syncthreads();
 
+    RF_STAMP(3)
     // ---- sessions, pass 2: draw again and write where they belong ----
     const size_t d0 = (size_t)ms * cap;
     for (int q0 = 0; q0 < P; q0 += 64) {
@@ -134,7 +163,7 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
         const double min_cs = s.cs_imin[cs] * V * sq / 1000, max_cs = s.cs_imax[cs] * V * sq / 1000;   // (generate_power_setpoints)
         const double v_gate = s.cs_vk[(size_t)cs * 4 + ph];
         const double pac_min_sp = c.heterogeneous_ev_specs ? 0.0 : c.ev_min_ac_charge_power;
-        ev2g_gen_port_sessions(g, rng, dr.weekend, p, [&](int i, const Ev2gGenSession &e) {
+        auto write_session = [&](int i, const Ev2gGenSession &e) {
             if (i >= n_eff) return;
             const size_t d = d0 + base + i;
             const Ev2gSessFields f = ev2g_gen_session_fields(g, rng, e, a.spec_row);
@@ -166,9 +195,20 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
             l_ta[k] = e.t_arr; l_td[k] = e.t_dep;
             l_need[k] = (e.B - e.cap0) * (100 + c.power_setpoint_flexiblity) / 100;
             l_lo[k] = fmax(pac_min_sp, min_cs); l_hi[k] = fmin(e.pac, max_cs);
-        });
+        };
+        if (l_pcnt[p] <= EV2G_RF_K && T <= 256) {   // the steps at which this port spawned are known from pass 1: only the sessions are drawn again
+            for (int i = 0; i < n_eff; i++) {
+                const int t = l_spawn[p * EV2G_RF_K + i];
+                Ev2gGenSession e;
+                ev2g_gen_make_session(g, rng, fleet, share_sum, t, p, l_stay[t], l_emean[t], &e);
+                write_session(i, e);
+            }
+        } else {
+            ev2g_gen_port_sessions(g, rng, fleet, share_sum, p, tab, write_session);
+        }
     }
 
+    RF_STAMP(4)
     // ---- transformers ----
     for (int k = 0; k < R; k++) {
         const size_t o = ((size_t)ms * R + k) * T;
@@ -214,7 +254,10 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
                     mxp = rf_wave_max(mxp);
                     ev.capp = 100 * (1 - load_max / mxp);
                 }
-                if (lane == 0) { drs[e * 3 + 0] = ev.es; drs[e * 3 + 1] = ev.ee; drs[e * 3 + 2] = ev.capp; }
+                if (lane == 0) {
+                    drs[e * 3 + 0] = ev.es; drs[e * 3 + 1] = ev.ee; drs[e * 3 + 2] = ev.capp;
+                    if (e < 16) { l_dr[e * 3 + 0] = ev.es; l_dr[e * 3 + 1] = ev.ee; l_dr[e * 3 + 2] = ev.capp; }
+                }
             }
         }
         __syncthreads();
@@ -224,16 +267,63 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
             const double sol = c.solar_power ? ev2g_gen_solar_at(g, dr.sun, sa, sm, capk, t) : 0.0;
             RW(double, tr_maxp)[o + t] = mxv; RW(double, tr_minp)[o + t] = mnv; RW(double, tr_infl)[o + t] = il; RW(double, tr_solar)[o + t] = sol;
             RW(double, tr_base)[o + t] = il + sol;
-            RW(double, tr_lf)[o + t] = c.inflexible_loads ? ev2g_gen_load_forecast_at(g, rng_tr, k, t, il, mnv, mxv) : 0.0;
-            RW(double, tr_pvf)[o + t] = c.solar_power ? ev2g_gen_pv_forecast_at(g, rng_tr, k, t, sol) : 0.0;
+            const double lfv = c.inflexible_loads ? ev2g_gen_load_forecast_at(g, rng_tr, k, t, il, mnv, mxv) : 0.0;
+            const double pvv = c.solar_power ? ev2g_gen_pv_forecast_at(g, rng_tr, k, t, sol) : 0.0;
+            RW(double, tr_lf)[o + t] = lfv; RW(double, tr_pvf)[o + t] = pvv;
+            l_sol[t] = sol; l_lf[t] = lfv; l_pvf[t] = pvv;
             peak = fmax(peak, mxv);
         }
         peak = rf_wave_max(peak);
         if (lane == 0) RW(double, tr_peak)[(size_t)ms * R + k] = peak;
+        // ---- this transformer's observation windows (ev2g_build_window_table_kernel's values: load_minus_pv_at / power_limit_at), from LDS;
+        //      on the fast path (one transformer) they are also columns 20..59 of the observation head table ----
+        if (s.win_tab || a.head_tab) {
+            __syncthreads();
+            const int nd = (c.demand_response && c.dr_events_per_day <= 16) ? c.dr_events_per_day : 0, ahead = g.steps_ahead;
+            double *ht = (a.head_tab && a.head_nh == 60) ? a.head_tab + (size_t)ms * (size_t)(T + 1) * 60 : nullptr;
+            // (the window table itself is read by ev2g_step_v2 only: where the fast path's head table exists nothing reads it after the load)
+            double *wt = (s.win_tab && !ht) ? RW(double, win_tab) + ((size_t)ms * R + k) * (size_t)(T + 1) * 40 : nullptr;
+            for (int i = lane; i < (T + 1) * 40; i += 64) {
+                const int step = i / 40, j40 = i - step * 40;
+                double v;
+                if (j40 < 20) {   // (loads - pv) window, Transformer.get_load_pv_forecast transformer.py:173-188
+                    const int j = j40, kk = step + j;
+                    double l, pv;
+                    if (kk < T) { if (j == 0) { l = infl[kk]; pv = l_sol[kk]; } else { l = l_lf[kk]; pv = l_pvf[kk]; } }
+                    else if (step >= T - 1) { l = 1.0 * infl[T - 1]; pv = 1.0 * l_sol[T - 1]; }
+                    else { l = 1.0 * l_lf[T - 1]; pv = 1.0 * l_pvf[T - 1]; }
+                    v = l - pv;
+                } else {          // power limits, Transformer.get_power_limits transformer.py:142-171
+                    const int j = j40 - 20;
+                    v = peak * 1.0;
+                    for (int e = 0; e < nd; e++) {
+                        const int es = (int)l_dr[e * 3], ee = (int)l_dr[e * 3 + 1];
+                        if (step + ahead >= es && ee >= step) {
+                            int aa, bb;
+                            if (step > es) { aa = 0; bb = ee - step; } else { aa = es - step; bb = ee - step; }
+                            if (aa < 0) aa = -aa;
+                            if (bb < 0) bb = -bb;
+                            if (j >= aa && j < bb) v = peak - peak * l_dr[e * 3 + 2] / 100.0;
+                        }
+                    }
+                }
+                if (wt) wt[i] = v;
+                if (ht) ht[(size_t)step * 60 + 20 + j40] = v;
+            }
+        }
+    }
+    // the price columns of the head table (|charge price| for the next 20 steps, zero past the horizon; state.py:75-83, :121-129)
+    if (a.head_tab) {
+        double *ht = a.head_tab + (size_t)ms * (size_t)(T + 1) * a.head_nh;
+        for (int i = lane; i < (T + 1) * 20; i += 64) {
+            const int step = i / 20, cc = i - step * 20, kk = step + cc;
+            ht[(size_t)step * a.head_nh + cc] = (kk < T) ? l_cp[kk] : 0.0;
+        }
     }
 
     // ---- power setpoints ----
     __syncthreads();
+    RF_STAMP(5)
     double *sp_out = RW(double, setpoint) + (size_t)ms * T;
     const int n_sess = min(total, cap);
     if (!c.power_setpoint_enabled || n_sess == 0) {
@@ -271,5 +361,16 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
         __syncthreads();
         for (int t = lane; t < T; t += 64) sp_out[t] = ev2g_gen_median(l_pad, t, kw);
     }
+    // the fast path's per-step scalars (ev2g_build_step_table_kernel's rows: one transformer)
+    if (a.step_tab) {
+        __syncthreads();
+        for (int t = lane; t < T; t += 64) {
+            double *o8 = a.step_tab + ((size_t)ms * T + t) * 8;
+            const size_t i = (size_t)ms * T + t;
+            o8[0] = s.price_ch[i]; o8[1] = s.price_dis[i]; o8[2] = s.tr_base[i]; o8[3] = s.tr_maxp[i]; o8[4] = s.tr_minp[i];
+            o8[5] = s.setpoint[i]; o8[6] = 0.0; o8[7] = 0.0;
+        }
+    }
+    RF_STAMP(6)
 #undef RW
 }

@@ -87,26 +87,28 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
     a.seed = seed; a.first_index = first_index; a.first_slot = first_slot; a.n = n; a.cap = h->sess_cap;
     a.overflow = h->d_refill_overflow;
     a.g0.seed = seed;
+    a.head_tab = h->d_head_tab; a.head_nh = h->head_nh; a.step_tab = h->d_step_tab;
+    if (c.demand_response && c.dr_events_per_day > 16 && (s.win_tab || h->d_head_tab))
+        return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: at most 16 demand-response events per day");
+    a.dbg = nullptr;
+    if (std::getenv("EV2G_REFILL_STAMPS")) {   // development: cycle stamps of workgroup 0, printed at the next call
+        static unsigned long long *d_dbg = nullptr;
+        if (!d_dbg) { (void)hipMalloc((void **)&d_dbg, 16 * 8); (void)hipMemset(d_dbg, 0, 16 * 8); }
+        else {
+            unsigned long long v[8];
+            (void)hipStreamSynchronize(h->stream);
+            (void)hipMemcpy(v, d_dbg, 64, hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "[ev2g] refill stamps (cycles): prices %llu | step tables %llu | pass 1 %llu | pass 2 %llu | transformers %llu | setpoints %llu\n",
+                         v[1] - v[0], v[2] - v[1], v[3] - v[2], v[4] - v[3], v[5] - v[4], v[6] - v[5]);
+        }
+        a.dbg = d_dbg;
+    }
     const size_t lds = ev2g_refill_lds_bytes(s.T, s.P, h->sess_cap);
     if (lds > 160 * 1024) return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: the scenario's work arrays exceed the LDS");
     if (lds > 48 * 1024) HIPCHK(h, hipFuncSetAttribute((const void *)ev2g_refill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(ev2g_refill_kernel, dim3(n), dim3(64), lds, h->stream, s, h->st, a, h->d_ss_afap);
     HIPCHK(h, hipGetLastError());
-    // the observation tables of the refilled slots (the loader's kernels, restricted to them)
-    const int m0 = first_slot, m1 = first_slot + n;
-    if (s.win_tab) {
-        const size_t cnt = (size_t)n * s.R * (s.T + 1) * 40;
-        hipLaunchKernelGGL(ev2g_build_window_table_kernel, dim3((int)std::min<size_t>((cnt + 255) / 256, 4096)), dim3(256), 0, h->stream, s, const_cast<double *>(s.win_tab), m0, m1);
-    }
-    if (h->d_step_tab) {
-        const size_t cnt = (size_t)n * s.T;
-        hipLaunchKernelGGL(ev2g_build_step_table_kernel, dim3((int)std::min<size_t>((cnt + 255) / 256, 4096)), dim3(256), 0, h->stream, s, h->d_step_tab, m0, m1);
-    }
-    if (h->d_head_tab) {
-        const size_t cnt = (size_t)n * (s.T + 1) * h->head_nh;
-        hipLaunchKernelGGL(ev2g_build_head_table_kernel, dim3((int)std::min<size_t>((cnt + 255) / 256, 4096)), dim3(256), 0, h->stream, s.price_ch, s.win_tab, m0, m1, s.T,
-                           h->head_nh, h->d_head_tab);
-    }
+    // (the observation tables of the refilled slots -- window, head and step table -- are rebuilt by the kernel itself, from LDS)
     HIPCHK(h, hipGetLastError());
     h->refilled = true;
     return EV2G_OK;

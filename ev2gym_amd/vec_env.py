@@ -58,7 +58,7 @@ class EV2GymVec:
                  reward_function="SquaredTrackingErrorReward", cost_function=None, seed: Optional[int] = None,
                  scenarios: Optional[ScenarioBatch] = None, auto_reset: bool = False, log_cs_history: bool = False, log_soc: bool = True,
                  use_torch: Optional[bool] = None, rank: int = 0, world_size: int = 1, verbose: bool = False,
-                 load_from_replay_path=None, pool_factor: int = 8, resample_every: Optional[int] = None, generator: str = "numpy", data_dir=None, **unused):
+                 load_from_replay_path=None, pool_factor: int = 8, resample_every: Optional[int] = None, generator: str = "numpy", data_dir=None, device_refill: bool = False, **unused):
         self.state_kind = _kind(state_function, _abi.STATE_KINDS, "state_function")
         self.reward_kind = _kind(reward_function, _abi.REWARD_KINDS, "reward_function")
         if self.state_kind is None or self.reward_kind is None:
@@ -81,6 +81,14 @@ class EV2GymVec:
         self.generator = generator   # which implementation of the scenario model draws the pool (same model, different random streams)
         self._episodes = 0
         self._pool_generation = 0
+        # device_refill: every window of the pool is re-drawn ON THE DEVICE (ev2g_pool_refill) right after the episode that used it, so
+        # no scenario is ever stepped twice and no reset does host work -- the reference's fresh draw per reset (ev2gym_env.py:243-296)
+        # at the GPU's pace.  The pool must come from the library's own generator (the device continues ITS stream of scenarios).
+        self.device_refill = bool(device_refill)
+        if self.device_refill:
+            if config_file is None or scenarios is not None or load_from_replay_path is not None:
+                raise ValueError("device_refill draws scenarios from a config: pass config_file (not scenarios / a replay file)")
+            self.generator = generator = "native"
         if scenarios is None and load_from_replay_path is not None:
             # one replay file, or a list of them recorded with the same config: one env per file (ev2gym_env.py:102-116)
             from .replay import load_replay
@@ -118,6 +126,8 @@ class EV2GymVec:
             flags |= _abi.FLAG_LOG_SOC   # battery-degradation statistics need the SoC log (ev.py:442-521)
         if use_torch and stream is None:
             flags |= _abi.FLAG_NULL_STREAM   # torch's current stream is the default stream: share it
+        if self.device_refill:
+            flags |= _abi.FLAG_REFILLABLE
         self.engine = Engine(scenarios, self.reward_kind, self.state_kind, device=device, flags=flags, stream=stream,
                              cost_kind=self.cost_kind, n_active_envs=n_active)
         e = self.engine
@@ -139,7 +149,26 @@ class EV2GymVec:
             self._cost = self._alloc((e.E,))
             e.set_extras(cost=self._cost)
         self.stats = None
+        self._refill_next = e.M * max(1, world_size)   # next unused scenario index of this env's stream (every rank continues after the whole first pool)
+        self._refill_stride = max(1, world_size)
+        self._last_offset = None
         self.reset(seed=self.seed)
+
+    def _refill_used_window(self):
+        """device_refill: the window the finished episode ran on gets new scenarios (indices never used before: rank r of w takes
+        the blocks r, r + w, ... of the stream), drawn on the device while the host goes on."""
+        e = self.engine
+        E, M = e.E, e.M
+        off = self._last_offset
+        if off is None or M < 2 * E:
+            return
+        cfg = gen_config_from_yaml(self.config, E, self._gen_seed)
+        idx0 = self._refill_next + self.rank * E
+        n1 = min(E, M - off)                       # the window may wrap around the end of the pool
+        e.pool_refill(cfg, self._gen_seed, idx0, off, n1)
+        if n1 < E:
+            e.pool_refill(cfg, self._gen_seed, idx0 + n1, 0, E - n1)
+        self._refill_next += E * self._refill_stride
 
     def _draw_pool(self, rank, world_size):
         """pool_factor x num_envs scenarios per rank from the vectorised generator (statistically matched to the
@@ -149,6 +178,7 @@ class EV2GymVec:
         draw = generate
         if self.generator == "native":
             from .scenario_gen import generate_native as draw
+        self._gen_seed = gen_seed
         full = draw(gen_config_from_yaml(self.config, total, gen_seed))
         return full.shard(rank, world_size) if world_size > 1 else full
 
@@ -195,6 +225,9 @@ class EV2GymVec:
             offset = int(np.random.default_rng(int(seed)).integers(0, M)) if M > self.num_envs else 0
         else:
             offset = self._next_window(M)
+        if self.device_refill and self._episodes > 0:
+            self._refill_used_window()
+        self._last_offset = offset
         self.engine.reset(self._obs, offset=offset)
         self._episodes += 1
         if not kwargs.get("_keep_stats"):
