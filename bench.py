@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from ev2gym_amd import _abi  # noqa: E402
-from ev2gym_amd.scenario_gen import GenConfig, generate, occupancy_fraction  # noqa: E402
+from ev2gym_amd.scenario_gen import GenConfig, generate_native, occupancy_fraction  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
@@ -246,6 +246,66 @@ def rollout_record(Engine, batch, rk, sk, local_rank, devx, E, lo, rank, args, T
         eng.close()
 
 
+def refill_record(Engine, wl, rk, sk, local_rank, devx, E, rank, args, T, min_s=0.1):
+    """Scenario generation ON THE DEVICE (ev2g_pool_refill: EV2Gym.reset()'s per-episode draw, ev2gym_env.py:243-296, without host
+    work): a pool of 3 windows drawn by the library's generator; every episode steps one window while the window of the episode
+    before is re-drawn in place.  Returns the cost of re-drawing one window and the episode rate with perpetual fresh scenarios."""
+    import torch
+    from ev2gym_amd.scenario_gen import generate_native
+    cfg = wl["gen"](3 * E, 7000 + rank)
+    st = devx.new_stream(make_current=False)
+    eng = Engine(generate_native(cfg), rk, sk, device=local_rank, stream=st, n_active_envs=E,
+                 flags=(0 if args.no_soc_log else _abi.FLAG_LOG_SOC) | _abi.FLAG_REFILLABLE)
+    try:
+        dev, P, D = devx.device, eng.P, eng.D
+        acts = torch.empty((T, E, P), dtype=torch.float64, device=dev)
+        eng.fill_uniform(acts, T * E * P, 77 + rank, wl["lo"], 1.0)
+        obs = torch.empty((E, D), dtype=torch.float64, device=dev)
+        rew = torch.empty((E,), dtype=torch.float64, device=dev)
+        done = torch.empty((E,), dtype=torch.uint8, device=dev)
+        mask = torch.empty((E, P), dtype=torch.uint8, device=dev)
+        stats = torch.empty((E, _abi.N_STATS), dtype=torch.float64, device=dev)
+        nxt = 3 * E
+        eng.pool_refill(cfg, cfg.seed, nxt, 0, E); nxt += E   # (first call: uploads the config's tables)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for i in range(10):
+            eng.pool_refill(cfg, cfg.seed, nxt, (i % 3) * E, E); nxt += E
+        eng.synchronize()
+        refill_us = (time.perf_counter() - t0) / 10 * 1e6
+
+        def episode(k, refill):
+            off = (k % 3) * E
+            eng.reset(obs, offset=off)
+            eng.step_n(T, acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=True)
+            eng.stats(out=stats)
+            if refill:   # the window of the episode before gets new scenarios, in stream order behind this episode's kernels
+                nonlocal_nxt[0] += E
+                eng.pool_refill(cfg, cfg.seed, nonlocal_nxt[0], ((k + 2) % 3) * E, E)
+        nonlocal_nxt = [nxt]
+        rates = {}
+        for refill in (False, True):
+            episode(0, refill); eng.synchronize()
+            n, spent = 0, 0.0
+            while spent < min_s:
+                t0 = time.perf_counter()
+                for k in range(6):
+                    episode(n + k, refill)
+                eng.synchronize()
+                spent += time.perf_counter() - t0
+                n += 6
+            rates[refill] = spent / n
+        eng.check_faults()
+        return {"us_per_window": refill_us, "scenarios_per_window": E, "scenarios_per_s": E / (refill_us * 1e-6),
+                "ms_per_episode_without_refill": rates[False] * 1e3, "ms_per_episode_with_refill": rates[True] * 1e3,
+                "env_steps_per_s_with_refill_per_gpu": E * T / rates[True], "truncated_scenarios": eng.pool_refill_overflows,
+                "session_slots_per_scenario": eng.pool_session_capacity,
+                "note": "every episode runs scenarios never stepped before, drawn on the device (bit-identical to ev2g_generate); "
+                        "whole episodes = 112-step persistent launch + statistics kernel + reset (+ ev2g_pool_refill of one window)"}
+    finally:
+        eng.close()
+
+
 def self_launch(n_gpus, argv):
     """`python bench.py --gpus N` with no rendezvous in the environment: re-run this file as N ranks (one per GPU) under
     torch.distributed.run on this node -- the command the driver would type itself -- and pass rank 0's JSON line through."""
@@ -358,7 +418,8 @@ def main():
     pool = args.pool or (2 if args.workload == "cfg4" else 8)
     M = E * pool
     rk, sk = _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]]
-    batch = generate(wl["gen"](M, args.seed * 1000 + rank))   # every rank draws its own pool of scenarios
+    # every rank draws its own pool of scenarios, with the library's own generator (ev2g_generate: the stream ev2g_pool_refill continues on the device)
+    batch = generate_native(wl["gen"](M, args.seed * 1000 + rank))
     phi = occupancy_fraction(batch)
     # engine kernels, torch allocations and the RCCL gather all run on ONE explicit (non-default) stream
     dev = devx.device
@@ -544,6 +605,10 @@ def main():
         else:   # reported, never fatal for the measurement
             c_gather = {"error": err or "rank 0 could not create a communicator id"}
 
+    refill = None
+    if actor is None and not stub and not args.no_rollout_record and not args.only_timed and args.workload != "cfg4":
+        refill = refill_record(Engine, wl, rk, sk, local_rank, devx, E, rank, args, T)
+
     env_steps_total = world * E * args.steps
     value = env_steps_total / wall[best]
     per_rank, ranks_seen = None, None
@@ -585,6 +650,8 @@ def main():
         out["actor_kernel_times"] = actor_times
     if rollout is not None:
         out["rollout"] = rollout
+    if refill is not None:
+        out["device_refill"] = refill
     if stub:
         out["data"] = "STUB ENGINE on CPU (launcher / control-flow test, not a measurement)"
     for e_ in engines:

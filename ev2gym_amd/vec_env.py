@@ -58,7 +58,7 @@ class EV2GymVec:
                  reward_function="SquaredTrackingErrorReward", cost_function=None, seed: Optional[int] = None,
                  scenarios: Optional[ScenarioBatch] = None, auto_reset: bool = False, log_cs_history: bool = False, log_soc: bool = True,
                  use_torch: Optional[bool] = None, rank: int = 0, world_size: int = 1, verbose: bool = False,
-                 load_from_replay_path=None, pool_factor: int = 8, resample_every: Optional[int] = None, generator: str = "numpy", data_dir=None, device_refill: bool = False, **unused):
+                 load_from_replay_path=None, pool_factor: int = 8, resample_every: Optional[int] = None, generator: str = "native", data_dir=None, device_refill: bool = False, **unused):
         self.state_kind = _kind(state_function, _abi.STATE_KINDS, "state_function")
         self.reward_kind = _kind(reward_function, _abi.REWARD_KINDS, "reward_function")
         if self.state_kind is None or self.reward_kind is None:

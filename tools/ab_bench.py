@@ -19,7 +19,7 @@ def child(workload, pool, reps):
     from bench import WORKLOADS
     from ev2gym_amd import _abi
     from ev2gym_amd.engine import Engine
-    from ev2gym_amd.scenario_gen import generate, occupancy_fraction
+    from ev2gym_amd.scenario_gen import generate_native as generate, occupancy_fraction
     wl = WORKLOADS[workload]
     E = int(os.environ.get("AB_ENVS", wl["envs"]))
     M = E * pool

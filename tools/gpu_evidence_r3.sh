@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 3 evidence (run on the GPU box via gpurun): parity suite, bench lines, rocprofv3 kernel traces + PMC passes; results under gpurun_out/r3ev
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r3ev; mkdir -p $O
+timeout 900 python -m pytest tests -m gpu -q > $O/r03_gpu_tests.txt 2>&1; echo "pytest rc=$?" | tee -a $O/r03_gpu_tests.txt; tail -3 $O/r03_gpu_tests.txt
+python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+timeout 300 python bench.py > $O/r03_bench_cfg2_default.json 2> $O/bench_default.err; echo "default rc=$?"
+timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r03_bench_cfg2_driver_shaped.json 2> $O/bench_driver.err; echo "driver rc=$?"
+timeout 300 python bench.py --workload cfg3 > $O/r03_bench_cfg3.json 2> $O/bench_cfg3.err; echo "cfg3 rc=$?"
+timeout 400 python bench.py --workload cfg4 > $O/r03_bench_cfg4.json 2> $O/bench_cfg4.err; echo "cfg4 rc=$?"
+timeout 300 python bench.py --actor mlp --no-cpu-baseline > $O/r03_bench_cfg2_actor_mlp.json 2> $O/bench_actor.err; echo "actor rc=$?"
+timeout 300 python bench.py --actor mlp_fp32 --no-cpu-baseline > $O/r03_bench_cfg2_actor_mlp_fp32.json 2> $O/bench_actor32.err; echo "actor32 rc=$?"
+EV2G_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --no-cpu-baseline > $O/r03_bench_cfg2_torchrun_world1_forced_dist.json 2> $O/bench_dist.err; echo "dist rc=$?"
+for spec in "cfg2_persistent --workload cfg2 --launch persistent" "cfg2_per_step --workload cfg2 --launch per_step" "cfg3_persistent --workload cfg3 --launch persistent" "cfg4_persistent --workload cfg4 --launch persistent"; do
+  set -- $spec; tag=$1; shift
+  bash tools/prof_step.sh $tag "$@" > $O/r03_${tag}_rocprofv3.txt 2>&1; tail -8 $O/r03_${tag}_rocprofv3.txt
+done
+python tools/collect_evidence.py $O/r03_hbm_traffic.json cfg2_persistent=cfg2:persistent cfg2_per_step=cfg2:per_step cfg3_persistent=cfg3:persistent cfg4_persistent=cfg4:persistent > /dev/null
+timeout 200 python tools/refill_time.py cfg2 2>&1 | tail -1 > $O/r03_refill_time.txt; timeout 200 python tools/refill_time.py cfg3 2>&1 | tail -1 >> $O/r03_refill_time.txt; cat $O/r03_refill_time.txt
