@@ -392,6 +392,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
+    # stdout carries ONE line, the JSON: libraries that print banners on it (RCCL does at communicator creation) are sent to stderr
+    # for the duration of the run -- file descriptor 1 itself, so that C-level printf is covered too
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -667,8 +673,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline(batch.select(np.arange(min(E, 512))), rk, sk, wl["lo"], budget_s=budget)
     elif rank == 0:
         out["cpu_baseline"] = None
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

@@ -794,9 +794,22 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         const DevState &st = h->st;
         const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
                           st.env_acc, s.cs_pack};
+        // every float64 output present, no extras, no charger histories: the specialisation without their checks (not for the run-time rewards)
+        const bool full = io.actions && io.obs && io.reward && io.done && io.mask && !x.cost && !x.obs_f32 && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) &&
+                          io.o_stride == 0 && io.r_stride == 0 && io.d_stride == 0 && io.m_stride == 0 && !auto_reset && t0 + k <= s.T &&
+                          std::min(s.reward_kind, 3) != 3 && !std::getenv("EV2G_NO_FULL");
+        // ... and: SoC log on, one observation-head column pair per lane at most (PublicPST has no head table), three lanes for the history store
+        const bool wide = full && (h->cfg.flags & EV2G_FLAG_LOG_SOC) && s.P >= 3 && !std::getenv("EV2G_NO_WIDE") &&
+                          s.P >= (s.state_kind == EV2G_STATE_PUBLIC_PST ? 3 : (s.state_kind == EV2G_STATE_V2G_PROFIT_MAX_LOADS ? 30 : 10));
 #define EV2G_WAVE_CASE(SK, RK)                                                                                              \
     case SK * 4 + RK:                                                                                                       \
-        if (!io.actions)                                                                                                    \
+        if (full && RK != 3 && wide)                                                                                        \
+            hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), false, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
+                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
+        else if (full && RK != 3)                                                                                           \
+            hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), false, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
+                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
+        else if (!io.actions)                                                                                               \
             hipLaunchKernelGGL((ev2g_step_wave<SK, RK, true>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes,       \
                                h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
         else                                                                                                                \
@@ -806,7 +819,9 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         switch (s.state_kind * 4 + std::min(s.reward_kind, 3)) {   // rewards beyond the three compiled-in ones share instantiation 3
 #ifdef EV2G_ONLY_00   /* tuning builds (tools/): one specialisation, seconds to compile */
             case 0:
-                hipLaunchKernelGGL((ev2g_step_wave<0, 0, false>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
+                if (wide) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
+                else if (full) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
+                else hipLaunchKernelGGL((ev2g_step_wave<0, 0, false>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
                 break;
             default: return fail(h, EV2G_ERR_ARG, "EV2G_ONLY_00 build: only the cfg2 specialisation exists");
 #else

@@ -72,10 +72,19 @@ struct WaveArgs {
 // written whenever that pointer is set, in either instantiation.
 // RK: 0..2 = the reward of the three shipped configs, compiled in; 3 = any other fused reward, selected at run time by
 // V2P::reward_kind (ev2g_reward / ev2g_departure_term in ev2g_device.h).
-template <int SK, int RK, bool IO32>
+// FULL: the launch writes all four float64 outputs (observation, reward, done, mask) with step stride 0 (each step overwrites the last:
+// what a loop that consumes them step by step, or a benchmark, passes), takes float64 actions, uses no extras (fused cost, float32
+// observations, charger histories) and contains no in-launch reset.  The null checks, the extras' parameter fetches, the outputs'
+// per-step pointer arithmetic and the reset branch -- dozens of scalar instructions a step, issued by every wavefront -- are compiled
+// out: measured 4.53 -> 4.28 us/step at cfg2, 5.40 -> 5.08 at cfg3 (the kernel's time is its instruction count, SURVEY par.8d / DESIGN par.3).
+// FULLK = 2 additionally knows at compile time that the SoC log is on (EV2G_FLAG_LOG_SOC: the Python surface's and the benchmark's default)
+// and that the env is wide enough for one observation-head column pair per lane (P >= 30 for the 60-column head, P >= 10 for the
+// 20-column one): the second pair's prefetch and stores and the tail loop of narrow envs go too.
+template <int SK, int RK, bool IO32, int FULLK = 0>
 __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
                                                                      int k_steps, int auto_reset, WaveArgs wa) {
     extern __shared__ double lds[];
+    constexpr bool FULL = FULLK >= 1, WIDE = FULLK >= 2;
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
     const unsigned long long pt_k0 = __builtin_readcyclecounter();   // slot 7 := prologue, slot 6 := epilogue (tools/phase_timing.py --outer)
 #endif
@@ -111,8 +120,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     int *s_td = s_ta + NS, *s_ss = s_td + NS, *s_cyc = s_ss + NS, *s_dirty = s_cyc + NS, *items = s_dirty + NS;
     int *cnt = items + NS;  // cnt[2*(kk&1) + {0 charge, 1 discharge}]
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const bool log_soc = S->soc_log != nullptr;
-    const bool log_cs = S->cs_profits != nullptr;   // EV2G_FLAG_LOG_CS_HISTORY: charger-level accumulators and histories (ev2gym_env.py:533-535)
+    const bool log_soc = WIDE ? true : (S->soc_log != nullptr);
+    const bool log_cs = FULL ? false : (S->cs_profits != nullptr);   // EV2G_FLAG_LOG_CS_HISTORY: charger-level accumulators and histories (ev2gym_env.py:533-535)
     const double dtd = (double)S->dt, sixty_over_dt = S->sixty_over_dt, dt_over_60 = S->dt_over_60;
     const bool pow2_dt = S->pow2_dt != 0;
 
@@ -194,7 +203,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         int tid_l = tid, g_l = g, e_l = e, q_l = q, lane_l = lane;
         asm volatile("" : "+v"(tid_l), "+v"(g_l), "+v"(e_l), "+v"(q_l), "+v"(lane_l));
         const unsigned g8 = (unsigned)g_l * 8u;   // byte offset of this port in every [E*P] float64 / int2 array
-        if (t >= T) {  // episode finished inside a fused run: in-kernel ev2g_reset for this workgroup
+        if (!FULL && t >= T) {  // episode finished inside a fused run: in-kernel ev2g_reset for this workgroup
             if (!auto_reset) break;
             off = ev2g_scn(off, io.scn_stride, M);
             if (valid) {
@@ -216,11 +225,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
             t = 0;
         }
-        double *obs = io.obs ? io.obs + (long long)kk * io.o_stride : nullptr;       // uniform bases (scalar arithmetic)
-        float *obs32 = S->x_obs32 ? (float *)S->x_obs32 + (long long)(io.step0 + kk) * S->x_o32_stride : nullptr;
-        uint8_t *mask = io.mask ? io.mask + (long long)kk * io.m_stride : nullptr;
+        double *obs = FULL ? io.obs : (io.obs ? io.obs + (long long)kk * io.o_stride : nullptr);       // uniform bases (scalar arithmetic)
+        float *obs32 = (!FULL && S->x_obs32) ? (float *)S->x_obs32 + (long long)(io.step0 + kk) * S->x_o32_stride : nullptr;
+        uint8_t *mask = FULL ? io.mask : (io.mask ? io.mask + (long long)kk * io.m_stride : nullptr);
         const int sstep = t + 1;
-        const bool last_step = (kk == k_steps - 1) || (sstep >= T && !auto_reset);
+        const bool last_step = (kk == k_steps - 1) || (!FULL && sstep >= T && !auto_reset);
         int *cntk = cnt + 2 * (kk & 1);
 
         // ---------------- A: home lanes, charger level (ev_charger.py:137-186) ----------------
@@ -258,7 +267,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // Every prefetch is ONE unconditional load from a clamped (always valid) address; the conditions are applied
         // where the value is consumed.  A load inside a divergent branch whose result merges with a default makes the
         // compiler serialise on the destination register (write-after-write) with a full vmcnt(0) drain.
-        const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
+        const bool more = (kk + 1 < k_steps) && (FULL || sstep < T || auto_reset);
         const int ec = valid ? e_l : e0;   // clamped env for idle lanes
         const int gc = valid ? g_l : e0 * P;
         a_next = IO32 ? (double)ldg32_nt<float>(S->x_act32 + (long long)(io.step0 + (more ? kk + 1 : kk)) * io.a_stride, (unsigned)gc * 4u)
@@ -284,7 +293,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             // the values of columns 2..2+NHEAD of the observation emitted at the end of step sstep-1 (state.py:65-83, :108-135)
             const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
             pf_h0 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l, NPAIR - 1) * 16u);
-            if (P < NPAIR) pf_h1 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l + P, NPAIR - 1) * 16u);   // (uniform)
+            if (!WIDE && P < NPAIR) pf_h1 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l + P, NPAIR - 1) * 16u);   // (uniform)
         }
         // Departures and arrivals are known before the step (occupancy does not depend on the actions): the fields phase C needs
         // from the session record -- its last four 16-byte chunks -- travel with the other prefetches instead of being fetched,
@@ -440,7 +449,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                                               ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, pacmax)), sixty_over_dt, td, sstep);
             }
             occ_any = occ || occ_after;
-            if (mask) stg32<uint8_t>(mask, (unsigned)g_l, occ_after ? 1 : 0);
+            if (FULL || mask) stg32<uint8_t>(mask, (unsigned)g_l, occ_after ? 1 : 0);
             double o0 = 0.0, o1 = 0.0, o2 = 0.0;
             if (occ_after) {
                 const double soc = cap / b_bcap;
@@ -449,12 +458,12 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 if (soc < 1.0 && td > sstep) pot = b_potc;  // utils.py:771
             }
             pot = (pot > c_maxp) ? c_maxp : ((pot < c_minp) ? 0.0 : pot);   // per-charger clamp (utils.py:779-789)
-            if (obs) {
+            if (FULL || obs) {
                 const unsigned o8 = (unsigned)(e_l * D + ocol) * 8u;
                 stg32<d2v>(obs, o8, (d2v){o0, o1});   // one 16-byte store (D and the column offset are even for SK != 1)
                 if (SK == 1) stg32<double>(obs, o8 + 16u, o2);
             }
-            if (obs32) {
+            if (!FULL && obs32) {
                 const unsigned o4 = (unsigned)(e_l * D + ocol) * 4u;
                 if (SK == 1) { stg32<float>(obs32, o4, (float)o0); stg32<float>(obs32, o4 + 4u, (float)o1); stg32<float>(obs32, o4 + 8u, (float)o2); }
                 else stg32<f2v>(obs32, o4, (f2v){(float)o0, (float)o1});
@@ -524,7 +533,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // Transformer.reset + step + get_how_overloaded (transformer.py:258-302), evaluated wave-wide (meaningful in head lanes)
         const double tr_power = pf_base + usage;   // inflexible_load[t] + solar_power[t] + sum of the charger powers
         const double over = (tr_power > pf_maxp + 0.0001 || tr_power < pf_minp - 0.0001) ? fabs(tr_power - pf_maxp) : 0.0;
-        if (P >= 3) {
+        if (WIDE || P >= 3) {
             // the three history entries of the step in ONE store: lane 0 of the env writes usage[t], lane 1 the overload
             // (handed over by a DPP wave shift), lane 2 potential[t+1] -- not three stores with one active lane each
             const double over_n = dpp_mov_f64<0x138>(over);   // wave_shr:1: lane L takes lane L-1's value
@@ -546,7 +555,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             if (RK == 0 || RK == 3) over100 = 100.0 * over;
             if (last_step) stg32<double>(S->tr_power_now, e8, tr_power);
             const double potn = esum[3];
-            if (P < 3) {   // two-port envs: no third lane to share the history stores with
+            if (!WIDE && P < 3) {   // two-port envs: no third lane to share the history stores with
                 stg32<double>((slabH + 2 * HS8) + (long long)t * E * 8, e8, over);
                 stg32<double>(slabH + (long long)t * E * 8, e8, usage);
                 if (sstep < T) stg32<double>((slabH + HS8) + (long long)sstep * E * 8, e8, potn);
@@ -571,9 +580,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             const double n0 = ea0 + reward, n1 = ea1 + costs, n2 = ea2 + esum[4], n3 = ea3 + esum[5], n4 = ea4 + esum[6];
             ea[0] = n0; ea[1] = n1; ea[2] = n2; ea[3] = n3; ea[4] = n4; ea[5] = potn;
             if (RK == 3) ea[6] = ea5;
-            if (io.reward) stg32<double>(io.reward + (long long)kk * io.r_stride, e8, reward);
-            if (io.done) stg32<uint8_t>(io.done + (long long)kk * io.d_stride, (unsigned)e_l, (sstep >= T) ? 1 : 0);
-            if (S->x_cost)   // cost_function (rl_agent/cost.py:8-27); the overload weight is applied here when the reward does not carry it
+            if (FULL) { stg32<double>(io.reward, e8, reward); stg32<uint8_t>(io.done, (unsigned)e_l, (sstep >= T) ? 1 : 0); }
+            if (!FULL && io.reward) stg32<double>(io.reward + (long long)kk * io.r_stride, e8, reward);
+            if (!FULL && io.done) stg32<uint8_t>(io.done + (long long)kk * io.d_stride, (unsigned)e_l, (sstep >= T) ? 1 : 0);
+            if (!FULL && S->x_cost)   // cost_function (rl_agent/cost.py:8-27); the overload weight is applied here when the reward does not carry it
                 stg32<double>(S->x_cost + (long long)(io.step0 + kk) * S->x_c_stride, e8, (S->cost_kind == 2) ? costs : 100.0 * over + esum[2]);
             if (sstep >= T || last_step) {  // publish the running episode totals (get_statistics reads them)
                 const unsigned a8 = (unsigned)e_l * 64u;
@@ -582,7 +592,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 stg32<double>(env_acc, a8 + 32u, n4);
             }
         }
-        if (valid && obs32) {
+        if (!FULL && valid && obs32) {
             const unsigned o4 = (unsigned)(e_l * D) * 4u;
             if (SK == 1) {
                 if (q_l == 0) {
@@ -601,7 +611,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 }
             }
         }
-        if (valid && obs) {
+        if (valid && (FULL || obs)) {
             const unsigned o8 = (unsigned)(e_l * D) * 8u;
             if (SK == 1) {  // PublicPST state.py:6-35
                 if (q_l == 0) {
@@ -612,10 +622,12 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135: columns 2.. are a copy of the head table row
                 if (q_l == 0) stg32<d2v>(obs, o8, (d2v){(double)sstep, usage});
                 if (q_l < NPAIR) stg32<d2v>(obs, o8 + 16u + (unsigned)q_l * 16u, pf_h0);
-                if (q_l + P < NPAIR) stg32<d2v>(obs, o8 + 16u + (unsigned)(q_l + P) * 16u, pf_h1);
-                const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
-                for (int pi = q_l + 2 * P; pi < NPAIR; pi += P)    // tiny envs (P < 15): the remaining pairs, unprefetched
-                    stg32<d2v>(obs, o8 + 16u + (unsigned)pi * 16u, ldg32<d2v>(S->head_tab, h8 + (unsigned)pi * 16u));
+                if (!WIDE) {
+                    if (q_l + P < NPAIR) stg32<d2v>(obs, o8 + 16u + (unsigned)(q_l + P) * 16u, pf_h1);
+                    const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
+                    for (int pi = q_l + 2 * P; pi < NPAIR; pi += P)    // tiny envs (P < 15): the remaining pairs, unprefetched
+                        stg32<d2v>(obs, o8 + 16u + (unsigned)pi * 16u, ldg32<d2v>(S->head_tab, h8 + (unsigned)pi * 16u));
+                }
             }
         }
         PT_MARK(5)

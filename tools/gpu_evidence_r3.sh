@@ -13,6 +13,8 @@ EV2G_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 -
 for spec in "cfg2_persistent --workload cfg2 --launch persistent" "cfg2_per_step --workload cfg2 --launch per_step" "cfg3_persistent --workload cfg3 --launch persistent" "cfg4_persistent --workload cfg4 --launch persistent"; do
   set -- $spec; tag=$1; shift
   bash tools/prof_step.sh $tag "$@" > $O/r03_${tag}_rocprofv3.txt 2>&1; tail -8 $O/r03_${tag}_rocprofv3.txt
+  mkdir -p $O/summaries; cp gpurun_out/prof_$tag/summary.json $O/summaries/$tag.json
 done
 python tools/collect_evidence.py $O/r03_hbm_traffic.json cfg2_persistent=cfg2:persistent cfg2_per_step=cfg2:per_step cfg3_persistent=cfg3:persistent cfg4_persistent=cfg4:persistent > /dev/null
 timeout 200 python tools/refill_time.py cfg2 2>&1 | tail -1 > $O/r03_refill_time.txt; timeout 200 python tools/refill_time.py cfg3 2>&1 | tail -1 >> $O/r03_refill_time.txt; cat $O/r03_refill_time.txt
+rm -rf gpurun_out/prof_*   # raw rocprofv3 output: too large to travel back (the summaries above carry what is committed)
