@@ -140,6 +140,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     // cold caches: occupancy windows, charger constants, the first action and the env accumulators are fetched in one
     // round trip (unconditional, clamped loads), the per-EV state in a second one, only where an EV is attached.
     double c_imax, c_dmaxabs, a_next;
+    // FULL kernels keep what only the port's own lane touches -- its occupancy window, the attached EV's battery size and potential
+    // term -- in registers instead of LDS (no in-launch reset rewrites them from outside): six LDS instructions a step less
+    int r_ta = EV2G_INT_MAX, r_td = -1;
+    double r_bcap = 1.0, r_potc = 0.0;
     {
         const unsigned g8 = (unsigned)g * 8u, c8 = (unsigned)cs * 8u, cp8 = (unsigned)min(tid, P - 1) * 8u;
         const unsigned ec = (unsigned)(valid ? e : e0);
@@ -164,7 +168,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             s_cst[2 * 64 + tid] = k_pow.x; s_cst[3 * 64 + tid] = k_pow.y;
         }
         if (valid) {
-            s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = sc.x; s_cyc[tid] = sc.y;
+            r_ta = w.x; r_td = w.y;
+            if (!FULL) { s_ta[tid] = w.x; s_td[tid] = w.y; }
+            s_ss[tid] = sc.x; s_cyc[tid] = sc.y;
             // s_dirty: bits 0,1 = what the epilogue must write back; bits 8.. = 1 + efficiency-table id of the attached EV,
             // so that the battery maths can issue the table look-up together with (not behind) the session-record load
             s_dirty[tid] = (lut0 + 1) << 8;
@@ -172,7 +178,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             if (w.x <= t && t <= w.y) {
                 s_cap[tid] = ldg32<double>(PA(EV2G_PS_CAP), g8); s_tot[tid] = ldg32<double>(PA(EV2G_PS_TOT), g8);
                 s_prev[tid] = ldg32<double>(PA(EV2G_PS_PREV), g8);
-                s_bcap[tid] = ldg32<double>(PA(EV2G_PS_BCAP), g8); s_potc[tid] = ldg32<double>(PA(EV2G_PS_POTC), g8);
+                r_bcap = ldg32<double>(PA(EV2G_PS_BCAP), g8); r_potc = ldg32<double>(PA(EV2G_PS_POTC), g8);
+                if (!FULL) { s_bcap[tid] = r_bcap; s_potc[tid] = r_potc; }
                 s_abse[tid] = log_soc ? ldg32<double>(PA(EV2G_PS_ABSE), g8) : 0.0;
             } else {
                 s_cap[tid] = 0.0; s_tot[tid] = 0.0; s_prev[tid] = 0.0; s_bcap[tid] = 1.0; s_potc[tid] = 0.0; s_abse[tid] = 0.0;
@@ -189,6 +196,18 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     for (int k = 0; k < EV2G_NQ; k++) stage[k * RS + tid] = 0.0;
     __syncthreads();
 
+    // FULL kernels have registers to spare (no extras, no second head pair): what the step loop otherwise re-derives every step with
+    // quarter-rate integer multiplies -- this lane's rows in the step / head tables (the scenario does not change: no in-launch reset)
+    // and its places in the observation -- is computed once and kept
+    unsigned hb_step = 0, hb_head = 0, hb_obs_port = 0, hb_obs_env = 0;
+    const double *act_run = io.actions;   // the actions of the step in work
+    if (FULL) {
+        const int scn0 = ev2g_scn(valid ? e : e0, off, M);
+        hb_step = (unsigned)(scn0 * T) * 64u;
+        hb_head = (unsigned)(scn0 * (T + 1)) * (unsigned)(((SK == 1) ? 0 : (SK == 0 ? 60 : 20)) * 8);
+        hb_obs_env = (unsigned)(e * D) * 8u;
+        hb_obs_port = hb_obs_env + (unsigned)ocol * 8u;
+    }
     PT_DECL
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
     pt_cur[7] += pt_last - pt_k0;
@@ -231,6 +250,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const int sstep = t + 1;
         const bool last_step = (kk == k_steps - 1) || (!FULL && sstep >= T && !auto_reset);
         int *cntk = cnt + 2 * (kk & 1);
+        // next step's counters, cleared BEFORE this step's first barrier: they were last read in the battery-maths phase of the step
+        // before, which a busy step closes with a barrier and a quiet step leaves at zero
+        if (tid_l < 2) cnt[2 * ((kk + 1) & 1) + tid_l] = 0;
 
         // ---------------- A: home lanes, charger level (ev_charger.py:137-186) ----------------
         bool occ = false;
@@ -238,7 +260,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         int ta_a = EV2G_INT_MAX, td_a = -1;   // this port's window as phase A saw it (idle lanes: no event)
         if (valid) {
             // every LDS operand of the phase in one batch (one wait) instead of one round trip per branch
-            int ta = s_ta[tid_l], td = s_td[tid_l];
+            int ta = FULL ? r_ta : s_ta[tid_l], td = FULL ? r_td : s_td[tid_l];
             double cap_b = s_cap[tid_l], c_thr = s_cst[0 * 64 + q_l], c_dmin = s_cst[1 * 64 + q_l];
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta), "+v"(td), "+v"(cap_b), "+v"(c_thr), "+v"(c_dmin));
             ta_a = ta; td_a = td;
@@ -270,10 +292,14 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const bool more = (kk + 1 < k_steps) && (FULL || sstep < T || auto_reset);
         const int ec = valid ? e_l : e0;   // clamped env for idle lanes
         const int gc = valid ? g_l : e0 * P;
+        if (FULL) {   // a running pointer instead of a 64-bit scalar product per step
+            a_next = ldg32_nt<double>(act_run + (more ? io.a_stride : 0), (unsigned)gc * 8u);
+            act_run += io.a_stride;
+        } else
         a_next = IO32 ? (double)ldg32_nt<float>(S->x_act32 + (long long)(io.step0 + (more ? kk + 1 : kk)) * io.a_stride, (unsigned)gc * 4u)
                       : ldg32_nt<double>(io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride, (unsigned)gc * 8u);
         const int scn = ev2g_scn(ec, off, M);             // this env's scenario in the resident pool
-        const unsigned eT64 = (unsigned)(scn * T) * 64u;  // its rows in the [M,T,8] step table
+        const unsigned eT64 = FULL ? hb_step : (unsigned)(scn * T) * 64u;  // its rows in the [M,T,8] step table
         const unsigned et64 = eT64 + (unsigned)t * 64u;
         const d2v st0 = ldg32_nt<d2v>(S->step_tab, et64);                                  // charge price, discharge price
         double pf_pch = st0.x, pf_pdis = st0.y;
@@ -291,7 +317,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         } else {
             // observation head table [E, T+1, NHEAD]: |charge price| window (zero-padded) + load/PV/limit window, exactly
             // the values of columns 2..2+NHEAD of the observation emitted at the end of step sstep-1 (state.py:65-83, :108-135)
-            const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
+            const unsigned h8 = FULL ? hb_head + (unsigned)sstep * (unsigned)(NHEAD * 8) : (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
             pf_h0 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l, NPAIR - 1) * 16u);
             if (!WIDE && P < NPAIR) pf_h1 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l + P, NPAIR - 1) * 16u);   // (uniform)
         }
@@ -316,14 +342,16 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
 #endif
         lds_barrier();
         PT_MARK(1)
-        if (tid_l < 2) cnt[2 * ((kk + 1) & 1) + tid_l] = 0;   // next step's counters (last used two barriers ago)
 
         // ---------------- B: worker lanes, battery maths on the compact list ----------------
         // The wavefronts that hold list items are the critical path of the whole workgroup (the others wait at the next
         // barrier): they issue at raised priority until their items are done.
+        const int nch = cntk[0], ndis = cntk[1];
+        // A step in which no port of the workgroup has an EV to integrate (the night half of a workplace episode, the early morning: 40 % of the
+        // workgroup-steps at cfg2) has no battery-maths phase to fence: the second barrier is skipped.  Every wavefront reads the same counts.
+        if (nch + ndis != 0) {
         __builtin_amdgcn_s_setprio(3);
         {
-            const int nch = cntk[0], ndis = cntk[1];
             const int nchp = (nch + 63) & ~63;
             for (int i = tid_l; i < nchp + ndis; i += EV2G_WAVE_BLOCK) {
                 int h = -1;
@@ -359,6 +387,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         __builtin_amdgcn_s_setprio(0);
         PT_MARK(2)
         lds_barrier();
+        }
         PT_MARK(1)
 
         // ---------------- C: home lanes (from here on everything of one env lives in one wavefront) ----------------
@@ -373,10 +402,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             double profit = 0.0, satpen = 0.0, pot = 0.0;
             // every LDS operand of this phase in ONE batch (one wait), whichever branch consumes it: read one by one behind the
             // branches below, each of them was its own LDS round trip on the workgroup-step chain
-            int ta = s_ta[tid_l], td = s_td[tid_l], ss_now = s_ss[tid_l];
+            int ta = FULL ? r_ta : s_ta[tid_l], td = FULL ? r_td : s_td[tid_l], ss_now = s_ss[tid_l];
             double cap = s_cap[tid_l];
             double b_energy = s_amps[tid_l], b_cur = stage[7 * RS + tid_l], b_ech = stage[4 * RS + tid_l], b_edis = stage[5 * RS + tid_l];
-            double b_bcap = s_bcap[tid_l], b_potc = s_potc[tid_l], b_tot = (SK == 1) ? s_tot[tid_l] : 0.0;
+            double b_bcap = FULL ? r_bcap : s_bcap[tid_l], b_potc = FULL ? r_potc : s_potc[tid_l], b_tot = (SK == 1) ? s_tot[tid_l] : 0.0;
             double c_maxp = s_cst[2 * 64 + q_l], c_minp = s_cst[3 * 64 + q_l];
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta), "+v"(td), "+v"(ss_now), "+v"(cap), "+v"(b_energy), "+v"(b_cur), "+v"(b_ech), "+v"(b_edis),
                          "+v"(b_bcap), "+v"(b_potc), "+v"(b_tot), "+v"(c_maxp), "+v"(c_minp));
@@ -412,7 +441,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     if (log_soc) stg32<double>((slabS + SS8), (unsigned)ss * 8u, s_abse[tid_l]);
                     ta = pf_r7.x; td = pf_r7.y;   // window of the port's next session
                     departed = true;
-                    s_ta[tid_l] = ta; s_td[tid_l] = td;
+                    if (FULL) { r_ta = ta; r_td = td; } else { s_ta[tid_l] = ta; s_td[tid_l] = td; }
                     ss_now = (ta != EV2G_INT_MAX) ? ss + 1 : -1;
                     s_ss[tid_l] = ss_now;
                     s_cyc[tid_l] = 0;
@@ -431,7 +460,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 const double v = pf_r5.y;
                 const double evc = pf_r5.x * 1000.0 / v;            // utils.py:773-777
                 const double potc = v * ((evc < c_imax) ? evc : c_imax) / 1000.0;
-                s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
+                s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0;
+                if (FULL) { r_bcap = B; r_potc = potc; } else { s_bcap[tid_l] = B; s_potc[tid_l] = potc; }
                 s_abse[tid_l] = 0.0;
                 b_bcap = B; b_potc = potc; b_tot = 0.0;
                 const int lut_new = pf_r7.z;
@@ -459,7 +489,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
             pot = (pot > c_maxp) ? c_maxp : ((pot < c_minp) ? 0.0 : pot);   // per-charger clamp (utils.py:779-789)
             if (FULL || obs) {
-                const unsigned o8 = (unsigned)(e_l * D + ocol) * 8u;
+                const unsigned o8 = FULL ? hb_obs_port : (unsigned)(e_l * D + ocol) * 8u;
                 stg32<d2v>(obs, o8, (d2v){o0, o1});   // one 16-byte store (D and the column offset are even for SK != 1)
                 if (SK == 1) stg32<double>(obs, o8 + 16u, o2);
             }
@@ -612,7 +642,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
         }
         if (valid && (FULL || obs)) {
-            const unsigned o8 = (unsigned)(e_l * D) * 8u;
+            const unsigned o8 = FULL ? hb_obs_env : (unsigned)(e_l * D) * 8u;
             if (SK == 1) {  // PublicPST state.py:6-35
                 if (q_l == 0) {
                     stg32<double>(obs, o8, (double)sstep / (double)T);
@@ -641,7 +671,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     if (valid) {
         const int d = s_dirty[tid];
         const unsigned g8 = (unsigned)g * 8u;
-        if (d & 2) stg32<i2v>(PA(EV2G_PS_WIN), g8, (i2v){s_ta[tid], s_td[tid]});
+        if (d & 2) stg32<i2v>(PA(EV2G_PS_WIN), g8, FULL ? (i2v){r_ta, r_td} : (i2v){s_ta[tid], s_td[tid]});
         if (d & 3) stg32<i2v>(PA(EV2G_PS_SC), g8, (i2v){s_ss[tid], s_cyc[tid]});
         if (d & 1) {
             stg32<double>(PA(EV2G_PS_CAP), g8, s_cap[tid]); stg32<double>(PA(EV2G_PS_TOT), g8, s_tot[tid]); stg32<double>(PA(EV2G_PS_PREV), g8, s_prev[tid]);
