@@ -60,6 +60,8 @@ struct ev2g_handle {
     } refill_cache;
     int sess_cap = 0;                           // EV2G_FLAG_REFILLABLE: session slots per scenario of the resident pool (0: packed storage)
     bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
+    bool no_full = false, no_wide = false;      // EV2G_NO_FULL / EV2G_NO_WIDE at load time: A/B and routing tests only
+    int last_spec = -1;                         // ev2g_last_launch_specialisation
     std::string kernel_name;                    // the step kernel ev2g_load_scenarios selected (ev2g_kernel_name)
     std::string fallback_reason;                // why the common-shape fast path was NOT taken ("" when it was / does not apply)
     int current_step = 0;
@@ -192,6 +194,7 @@ int ev2g_n_steps(const ev2g_handle *h) { return h ? h->T : 0; }
 int ev2g_current_step(const ev2g_handle *h) { return h ? h->current_step : 0; }
 const char *ev2g_kernel_name(const ev2g_handle *h) { return (h && h->loaded) ? h->kernel_name.c_str() : ""; }
 const char *ev2g_fallback_reason(const ev2g_handle *h) { return (h && h->loaded) ? h->fallback_reason.c_str() : ""; }
+int ev2g_last_launch_specialisation(const ev2g_handle *h) { return (h && h->loaded && h->wave_path) ? h->last_spec : -1; }
 
 static const char *kStatNames[EV2G_N_STATS] = {
     "total_ev_served", "total_profits", "total_energy_charged", "total_energy_discharged",
@@ -472,6 +475,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     else if (npc != 1) h->fallback_reason = "multi-port chargers";
     if (het) h->fallback_reason = "chargers with different port counts (topology file)";
     h->wave_path = h->fallback_reason.empty();
+    h->no_full = std::getenv("EV2G_NO_FULL") != nullptr; h->no_wide = std::getenv("EV2G_NO_WIDE") != nullptr; h->last_spec = -1;
     if (h->wave_path) {   // ev2g_step_wave addresses every array as base + 32-bit byte offset: all of them must stay below 4 GiB
         const unsigned long long lim = 1ull << 32;
         const unsigned long long biggest = std::max({(unsigned long long)E * P * 8, (unsigned long long)E * D * 8,
@@ -797,10 +801,11 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         // every float64 output present, no extras, no charger histories: the specialisation without their checks (not for the run-time rewards)
         const bool full = io.actions && io.obs && io.reward && io.done && io.mask && !x.cost && !x.obs_f32 && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) &&
                           io.o_stride == 0 && io.r_stride == 0 && io.d_stride == 0 && io.m_stride == 0 && !auto_reset && t0 + k <= s.T &&
-                          std::min(s.reward_kind, 3) != 3 && !std::getenv("EV2G_NO_FULL");
+                          std::min(s.reward_kind, 3) != 3 && !h->no_full;
         // ... and: SoC log on, one observation-head column pair per lane at most (PublicPST has no head table), three lanes for the history store
-        const bool wide = full && (h->cfg.flags & EV2G_FLAG_LOG_SOC) && s.P >= 3 && !std::getenv("EV2G_NO_WIDE") &&
+        const bool wide = full && (h->cfg.flags & EV2G_FLAG_LOG_SOC) && s.P >= 3 && !h->no_wide &&
                           s.P >= (s.state_kind == EV2G_STATE_PUBLIC_PST ? 3 : (s.state_kind == EV2G_STATE_V2G_PROFIT_MAX_LOADS ? 30 : 10));
+        h->last_spec = (full && std::min(s.reward_kind, 3) != 3) ? (wide ? 2 : 1) : 0;
 #define EV2G_WAVE_CASE(SK, RK)                                                                                              \
     case SK * 4 + RK:                                                                                                       \
         if (full && RK != 3 && wide)                                                                                        \

@@ -248,6 +248,12 @@ int ev2g_current_step(const ev2g_handle *h);
  * "ev2g_step_kernel"), and -- when the common-shape fast path was not taken -- why ("" otherwise). */
 const char *ev2g_kernel_name(const ev2g_handle *h);
 const char *ev2g_fallback_reason(const ev2g_handle *h);
+/* Which instantiation of the fast-path kernel the last ev2g_step / ev2g_step_n launch used: 0 = the general one (any subset of outputs,
+ * strides, extras, in-launch resets); 1 = "full" (all four float64 outputs with step stride 0, float64 actions, no extras, no charger
+ * histories, the launch ends within the episode, one of the three compiled-in rewards): their checks are compiled out; 2 = full, plus
+ * EV2G_FLAG_LOG_SOC on and an env wide enough for one observation-head column pair per lane.  -1: no launch yet or not the fast path.
+ * Results are identical in all three (tests/test_round3_gpu.py); EV2G_NO_FULL / EV2G_NO_WIDE in the environment at load time force 0 / 1. */
+int ev2g_last_launch_specialisation(const ev2g_handle *h);
 /* data-dependent faults recorded since the last reset (per-env flag word, device side):
  * returns 0 or EV2G_ERR_OVERCURRENT; synchronises the stream. */
 int ev2g_check_faults(ev2g_handle *h, int32_t *first_bad_env);

@@ -37,6 +37,9 @@ def test_bench_line_contract(extra):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.0 < r["frac"] < 1.0
     ro = d["rollout"]   # the configs[4]-shaped record rides on the default line
     assert ro["env_steps_per_s_per_gpu"] > 1e6 and 1.0 < ro["step_kernel_us"] < 200.0 and 1.0 < ro["actor_kernel_us"] < 200.0
+    rf = d["device_refill"]   # scenario generation on the device: never truncated, cheaper than the episode it feeds
+    assert rf["truncated_scenarios"] == 0 and rf["scenarios_per_window"] == 512 and 0.0 < rf["us_per_window"] < 1e4
+    assert rf["ms_per_episode_with_refill"] >= 0.5 * rf["ms_per_episode_without_refill"] > 0.0
     if not extra or extra[0] == "--workload":
         cb = d["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb

@@ -256,3 +256,86 @@ def test_vec_env_device_refill_never_repeats_a_scenario():
             assert env.engine.pool_refill_overflows == 0
         env.close()
     assert seen[False] <= 48 and seen[True] == 7 * 16, seen
+
+
+SPEC_CASES = [   # (name, generator config, reward, state, lowest action, specialisation the plain launch must get)
+    ("v2gppl_c50", lambda E: ("v2g", 50), "ProfitMax_TrPenalty_UserIncentives", "V2G_profit_max_loads", -1.0, 2),
+    ("v2gppl_c12", lambda E: ("v2g", 12), "ProfitMax_TrPenalty_UserIncentives", "V2G_profit_max_loads", -1.0, 1),   # too narrow for "wide"
+    ("pst_c20", lambda E: ("pst", 20), "SquaredTrackingErrorReward", "PublicPST", 0.0, 2),
+    ("v2gpm_c25", lambda E: ("v2g", 25), "profit_maximization", "V2G_profit_max", -1.0, 2),
+    ("v2gpm_c7_runtime_reward", lambda E: ("v2g", 7), "SimpleReward", "V2G_profit_max", -1.0, 0),   # run-time rewards have no full kernel
+]
+
+
+@pytest.mark.parametrize("case", SPEC_CASES, ids=[c[0] for c in SPEC_CASES])
+def test_fast_path_specialisations_agree_bit_for_bit(case, monkeypatch):
+    """The fast-path kernel has three instantiations per (state, reward) pair (include/ev2g.h, ev2g_last_launch_specialisation): general,
+    "full" and "full + wide".  Which one a launch gets depends only on what the caller passes; what it computes must not: the same
+    episode -- whole-episode launch and step-by-step -- through each of them gives the same observations, rewards, dones, masks,
+    episode statistics and port state, bit for bit."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    name, mk, reward, state, lo, want = case
+    E = 37   # ragged: the last workgroup is partly empty
+    kind, C = mk(E)
+    g = GenConfig.v2g_profit_plus_loads(E, C, 1, seed=11) if kind == "v2g" else GenConfig.public_pst(E, C, seed=11)
+    batch = generate_native(g)
+    rk, sk = _abi.REWARD_KINDS[reward], _abi.STATE_KINDS[state]
+
+    def run(env, strided, per_step):
+        for k in ("EV2G_NO_FULL", "EV2G_NO_WIDE"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
+        eng = Engine(batch, rk, sk, flags=_abi.FLAG_LOG_SOC)
+        assert eng.kernel_name.startswith("ev2g_step_wave"), eng.kernel_name
+        P, D, T = eng.P, eng.D, eng.T
+        acts = eng.empty((T, E, P)); eng.fill_uniform(acts, T * E * P, 3, lo, 1.0)
+        n = T if strided else 1
+        obs, rew, done, mask = eng.empty((n, E, D)), eng.empty((n, E)), eng.empty((n, E), np.uint8), eng.empty((n, E, P), np.uint8)
+        eng.reset(eng.empty((E, D)))
+        out = []
+        if per_step:
+            for t in range(T):
+                eng.step_n(1, acts.at(t * E * P), E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False)
+                out.append((obs.to_host()[0].copy(), rew.to_host()[0].copy(), done.to_host()[0].copy(), mask.to_host()[0].copy()))
+        elif strided:
+            eng.step_n(T, acts, E * P, obs, E * D, rew, E, done, E, mask, E * P, auto_reset=False, persistent=True)
+            o, r, d, m = obs.to_host(), rew.to_host(), done.to_host(), mask.to_host()
+            out = [(o[t], r[t], d[t], m[t]) for t in range(T)]
+        else:
+            eng.step_n(T, acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=True)
+            out = [(obs.to_host()[0].copy(), rew.to_host()[0].copy(), done.to_host()[0].copy(), mask.to_host()[0].copy())]
+        spec = eng.last_launch_specialisation
+        res = dict(out=out, stats=eng.stats().copy(), peek=[eng.peek(e) for e in (0, E - 1)])
+        eng.close()
+        return spec, res
+
+    def same(a, b, last_only=False):
+        xa, xb = (a["out"][-1:], b["out"][-1:]) if last_only else (a["out"], b["out"])
+        assert len(xa) == len(xb)
+        for ta, tb in zip(xa, xb):
+            for u, v in zip(ta, tb):
+                assert np.array_equal(u, v, equal_nan=True)
+        assert np.array_equal(a["stats"], b["stats"], equal_nan=True)
+        for pa, pb in zip(a["peek"], b["peek"]):
+            assert pa.keys() == pb.keys()
+            for k in pa:
+                assert np.array_equal(np.asarray(pa[k]), np.asarray(pb[k]), equal_nan=True), k
+
+    s_ref, ref = run(("EV2G_NO_FULL",), strided=False, per_step=True)    # general kernel, step by step: every step's outputs
+    assert s_ref == 0
+    s_str, strided = run((), strided=True, per_step=False)               # strided outputs select the general kernel too
+    assert s_str == 0
+    same(ref, strided)
+    s_plain, plain = run((), strided=False, per_step=True)
+    assert s_plain == want
+    same(ref, plain)
+    s_ep, episode = run((), strided=False, per_step=False)                # one launch for the episode: last step's outputs
+    assert s_ep == want
+    same(ref, episode, last_only=True)
+    if want == 2:
+        s_nw, narrow = run(("EV2G_NO_WIDE",), strided=False, per_step=True)
+        assert s_nw == 1
+        same(ref, narrow)
