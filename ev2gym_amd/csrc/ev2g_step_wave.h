@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         hb_step = (unsigned)(scn0 * T) * 64u;
         hb_head = (unsigned)(scn0 * (T + 1)) * (unsigned)(((SK == 1) ? 0 : (SK == 0 ? 60 : 20)) * 8);
         hb_obs_env = (unsigned)(e * D) * 8u;
-        hb_obs_port = hb_obs_env + (unsigned)ocol * 8u;
+        if (WIDE) hb_obs_port = hb_obs_env + (unsigned)ocol * 8u;
     }
     PT_DECL
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
@@ -489,7 +489,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
             pot = (pot > c_maxp) ? c_maxp : ((pot < c_minp) ? 0.0 : pot);   // per-charger clamp (utils.py:779-789)
             if (FULL || obs) {
-                const unsigned o8 = FULL ? hb_obs_port : (unsigned)(e_l * D + ocol) * 8u;
+                // (the narrow full kernels sit at the register limit: they re-derive the port's column from the env's base)
+                const unsigned ocol8_l = (unsigned)((SK == 1) ? 3 + 3 * q_l : (SK == 0 ? 62 + 2 * q_l : 22 + 2 * q_l)) * 8u;
+                const unsigned o8 = WIDE ? hb_obs_port : (FULL ? hb_obs_env + ocol8_l : (unsigned)(e_l * D + ocol) * 8u);
                 stg32<d2v>(obs, o8, (d2v){o0, o1});   // one 16-byte store (D and the column offset are even for SK != 1)
                 if (SK == 1) stg32<double>(obs, o8 + 16u, o2);
             }
@@ -528,17 +530,14 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             const int k = lane_l >> 3, j = lane_l & 7;
             const int wbase = (tid_l & ~63);
             const double *row = stage + k * RS;
-#pragma unroll 1
-            for (int w = 0; w < EPW; w++) {
-                const int a = wbase + w * P, b = a + P;
+            // The order of the additions is the same in every branch (chains j, j+16, j+32, j+48 and j+8, j+24, j+40, j+56, then the
+            // butterfly); the branches differ in which of the operands they know to be zero without looking.
+            if (EPW == 1) {   // (uniform) one env per wavefront: the slots behind its last port belong to idle lanes and still hold the
+                              // zeros they were initialised with -- eight reads at constant offsets, no masks, no index clamps
+                const double *r0 = row + wbase + j;
                 double xa[4], xb[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int i = a + j + 16 * u;
-                    const double ra = row[min(i, NS - 1)], rb = row[min(i + 8, NS - 1)];
-                    xa[u] = (i < b) ? ra : 0.0;
-                    xb[u] = (i + 8 < b) ? rb : 0.0;
-                }
+                for (int u = 0; u < 4; u++) { xa[u] = r0[16 * u]; xb[u] = r0[16 * u + 8]; }
                 double acc = 0.0, accb = 0.0;
 #pragma unroll
                 for (int u = 0; u < 4; u++) { acc += xa[u]; accb += xb[u]; }
@@ -546,7 +545,29 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 acc += xor1_f64(acc);
                 acc += xor2_f64(acc);
                 acc += xor4_f64(acc);
-                if (j == 0) stage[k * RS + a] = acc;
+                if (j == 0) stage[k * RS + wbase] = acc;
+            } else {          // several envs per wavefront: P <= 32, so ports j+32 .. j+56 do not exist (their terms were exact zeros);
+                              // an unclamped index past the env reads a neighbour's slot (or, behind the last row, the array that
+                              // follows `stage` in LDS) and is masked
+                const bool upper = P > 16;   // (uniform)
+#pragma unroll 1
+                for (int w = 0; w < EPW; w++) {
+                    const int a = wbase + w * P, b = a + P;
+                    const double *r0 = row + a + j;
+                    const double ra0 = r0[0], rb0 = r0[8];
+                    double ra1 = 0.0, rb1 = 0.0;
+                    if (upper) { ra1 = r0[16]; rb1 = r0[24]; }
+                    const int i = a + j;
+                    double acc = 0.0, accb = 0.0;
+                    acc += (i < b) ? ra0 : 0.0;
+                    accb += (i + 8 < b) ? rb0 : 0.0;
+                    if (upper) { acc += (i + 16 < b) ? ra1 : 0.0; accb += (i + 24 < b) ? rb1 : 0.0; }
+                    acc += accb;
+                    acc += xor1_f64(acc);
+                    acc += xor2_f64(acc);
+                    acc += xor4_f64(acc);
+                    if (j == 0) stage[k * RS + a] = acc;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
