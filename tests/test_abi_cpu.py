@@ -121,3 +121,31 @@ int main() {
 ''' % hdr)
     subprocess.check_call([cxx, "-std=c++17", "-O2", "-ffp-contract=off", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", str(tmp_path / "gen_host"), str(host)])
     assert subprocess.call([str(tmp_path / "gen_host")]) == 0
+
+
+def test_fast_path_kernels_keep_four_wavefronts_per_simd_and_do_not_spill():
+    """Every instantiation of the fast-path kernel must fit 128 VGPRs (4 wavefronts per SIMD: 4096 envs x 50 chargers are then resident at
+    once) without spilling to scratch -- the specialisations sit right at that limit, and a spill is silent at run time (only slower).
+    hipcc cross-compiles gfx950 here; the figures are the compiler's own (-Rpass-analysis=kernel-resource-usage)."""
+    import subprocess
+    from ev2gym_amd import build
+    cmd = [build.hipcc()] + [f for f in build.FLAGS if f not in ("-shared", "-fPIC")] + ["--cuda-device-only", "-c", "-Rpass-analysis=kernel-resource-usage",
+                                                                                      "-o", os.devnull, build.SRC]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    cur, res = None, {}
+    for line in p.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+        m = re.search(r" (VGPRs|VGPRs Spill|SGPRs Spill|ScratchSize \[bytes/lane\]): (\d+)", line)
+        if m and cur:
+            res.setdefault(cur, {})[m.group(1)] = int(m.group(2))
+    wave = {k: v for k, v in res.items() if "ev2g_step_wave" in k}
+    assert len(wave) == 42, sorted(wave)   # 3 states x (4 rewards x {float64, float32 actions} + 3 rewards x {full, full + wide})
+    for k, v in wave.items():
+        # (SGPRs parked in VGPR lanes are no memory traffic, and the VGPR count includes the lanes they use; the headline instantiations --
+        # full + wide -- must stay nearly free of them, each is a v_readlane / v_writelane pair in the step loop)
+        assert v["VGPRs"] <= 128 and v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
+        if "Lb0ELi2EEv" in k:
+            assert v["SGPRs Spill"] <= 8, (k, v)
