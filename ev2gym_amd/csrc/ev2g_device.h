@@ -132,6 +132,7 @@ struct StepIO {
     int step0;   // index of this launch's first step inside the caller's ev2g_step_n run (offsets the extras' step strides)
     int log_soc; // EV2G_FLAG_LOG_SOC (the fast path's prologue reads it from here: no parameter-block fetch on its first round trip)
     const float *act32;   // StepExtras::act32 when `actions` is null (same reason)
+    float *obs32;         // StepExtras::obs32 when its step stride is 0 (the full float32 kernels of the fast path write it instead of `obs`)
 };
 
 // optional extra step outputs / inputs (ev2g_set_step_extras), device-resident next to the kernel parameter block: they are

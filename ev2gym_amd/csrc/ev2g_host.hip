@@ -781,6 +781,7 @@ static StepIO make_io(const ev2g_handle *h, const double *actions, long long a_s
     io.step0 = (int)step0;
     io.log_soc = (h->cfg.flags & EV2G_FLAG_LOG_SOC) ? 1 : 0;
     io.act32 = actions ? nullptr : h->extras.actions_f32;
+    io.obs32 = (h->extras.obs_f32 && h->extras.obs_f32_step_stride == 0) ? h->extras.obs_f32 : nullptr;
     return io;
 }
 
@@ -799,7 +800,10 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
                           st.env_acc, s.cs_pack};
         // every float64 output present, no extras, no charger histories: the specialisation without their checks (not for the run-time rewards)
-        const bool full = io.actions && io.obs && io.reward && io.done && io.mask && !x.cost && !x.obs_f32 && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) &&
+        // ... in two flavours: float64 actions in / float64 observations out (a loop that consumes them, the benchmark), or the policy
+        // network's hand-over, float32 actions in / float32 observations out and no float64 observation (ev2g_rollout)
+        const bool f64io = io.actions && io.obs && !x.obs_f32, f32io = !io.actions && io.act32 && !io.obs && io.obs32;
+        const bool full = (f64io || f32io) && io.reward && io.done && io.mask && !x.cost && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) &&
                           io.o_stride == 0 && io.r_stride == 0 && io.d_stride == 0 && io.m_stride == 0 && !auto_reset && t0 + k <= s.T &&
                           std::min(s.reward_kind, 3) != 3 && !h->no_full;
         // ... and: SoC log on, one observation-head column pair per lane at most (PublicPST has no head table), three lanes for the history store
@@ -808,7 +812,13 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         h->last_spec = (full && std::min(s.reward_kind, 3) != 3) ? (wide ? 2 : 1) : 0;
 #define EV2G_WAVE_CASE(SK, RK)                                                                                              \
     case SK * 4 + RK:                                                                                                       \
-        if (full && RK != 3 && wide)                                                                                        \
+        if (full && RK != 3 && wide && f32io)                                                                               \
+            hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), true, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
+                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
+        else if (full && RK != 3 && f32io)                                                                                  \
+            hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), true, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
+                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
+        else if (full && RK != 3 && wide)                                                                                   \
             hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), false, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
                                h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
         else if (full && RK != 3)                                                                                           \
@@ -824,8 +834,11 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         switch (s.state_kind * 4 + std::min(s.reward_kind, 3)) {   // rewards beyond the three compiled-in ones share instantiation 3
 #ifdef EV2G_ONLY_00   /* tuning builds (tools/): one specialisation, seconds to compile */
             case 0:
-                if (wide) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
+                if (wide && f32io) hipLaunchKernelGGL((ev2g_step_wave<0, 0, true, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
+                else if (full && f32io) hipLaunchKernelGGL((ev2g_step_wave<0, 0, true, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
+                else if (wide) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
                 else if (full) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
+                else if (!io.actions) hipLaunchKernelGGL((ev2g_step_wave<0, 0, true>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
                 else hipLaunchKernelGGL((ev2g_step_wave<0, 0, false>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
                 break;
             default: return fail(h, EV2G_ERR_ARG, "EV2G_ONLY_00 build: only the cfg2 specialisation exists");

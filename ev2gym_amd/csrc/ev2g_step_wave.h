@@ -72,7 +72,9 @@ struct WaveArgs {
 // written whenever that pointer is set, in either instantiation.
 // RK: 0..2 = the reward of the three shipped configs, compiled in; 3 = any other fused reward, selected at run time by
 // V2P::reward_kind (ev2g_reward / ev2g_departure_term in ev2g_device.h).
-// FULL: the launch writes all four float64 outputs (observation, reward, done, mask) with step stride 0 (each step overwrites the last:
+// FULL (with IO32: the same for the policy network's hand-over -- float32 actions in, the float32 observation out INSTEAD of the float64
+// one; what ev2g_rollout launches between two actor forwards):
+// the launch writes all four float64 outputs (observation, reward, done, mask) with step stride 0 (each step overwrites the last:
 // what a loop that consumes them step by step, or a benchmark, passes), takes float64 actions, uses no extras (fused cost, float32
 // observations, charger histories) and contains no in-launch reset.  The null checks, the extras' parameter fetches, the outputs'
 // per-step pointer arithmetic and the reset branch -- dozens of scalar instructions a step, issued by every wavefront -- are compiled
@@ -85,6 +87,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                                                                      int k_steps, int auto_reset, WaveArgs wa) {
     extern __shared__ double lds[];
     constexpr bool FULL = FULLK >= 1, WIDE = FULLK >= 2;
+    constexpr bool F64 = FULL && !IO32, F32 = FULL && IO32;   // full with float64 actions in / observations out, or with the float32 hand-over
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
     const unsigned long long pt_k0 = __builtin_readcyclecounter();   // slot 7 := prologue, slot 6 := epilogue (tools/phase_timing.py --outer)
 #endif
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const d2v k_max = ldg32<d2v>(wa.cs_pack, c8 * 6u);   // (imax, |dmax|) of this lane's charger
         d2v k_min = {0.0, 0.0}, k_pow = {0.0, 0.0};            // gates and clamps, staged in LDS by the first P lanes of the workgroup
         if (tid < 64) { k_min = ldg32<d2v>(wa.cs_pack, cp8 * 6u + 16u); k_pow = ldg32<d2v>(wa.cs_pack, cp8 * 6u + 32u); }   // (wavefront 0 only)
-        a_next = IO32 ? (double)ldg32<float>(S->x_act32 + (long long)io.step0 * io.a_stride, (unsigned)(valid ? g : e0 * P) * 4u)
+        a_next = IO32 ? (double)ldg32<float>(io.act32 + (long long)io.step0 * io.a_stride, (unsigned)(valid ? g : e0 * P) * 4u)
                       : ldg32<double>(io.actions, (unsigned)(valid ? g : e0 * P) * 8u);
         double l_pot = ldg32<double>(slabH + HS8, ((unsigned)min(t, T - 1) * (unsigned)E + ec) * 8u);
         double l_pot2 = 0.0;   // charge_power_potential[t-1]: only SquaredTrackingErrorRewardWithPenalty (a run-time reward) reads it
@@ -201,12 +204,14 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     // and its places in the observation -- is computed once and kept
     unsigned hb_step = 0, hb_head = 0, hb_obs_port = 0, hb_obs_env = 0;
     const double *act_run = io.actions;   // the actions of the step in work
+    const float *act32_run = F32 ? io.act32 + (long long)io.step0 * io.a_stride : nullptr;
+    constexpr unsigned OB = F32 ? 4u : 8u;    // bytes per observation element the full kernel writes
     if (FULL) {
         const int scn0 = ev2g_scn(valid ? e : e0, off, M);
         hb_step = (unsigned)(scn0 * T) * 64u;
         hb_head = (unsigned)(scn0 * (T + 1)) * (unsigned)(((SK == 1) ? 0 : (SK == 0 ? 60 : 20)) * 8);
-        hb_obs_env = (unsigned)(e * D) * 8u;
-        if (WIDE) hb_obs_port = hb_obs_env + (unsigned)ocol * 8u;
+        hb_obs_env = (unsigned)(e * D) * OB;
+        if (WIDE) hb_obs_port = hb_obs_env + (unsigned)ocol * OB;
     }
     PT_DECL
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
@@ -244,8 +249,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
             t = 0;
         }
-        double *obs = FULL ? io.obs : (io.obs ? io.obs + (long long)kk * io.o_stride : nullptr);       // uniform bases (scalar arithmetic)
-        float *obs32 = (!FULL && S->x_obs32) ? (float *)S->x_obs32 + (long long)(io.step0 + kk) * S->x_o32_stride : nullptr;
+        double *obs = F64 ? io.obs : ((!FULL && io.obs) ? io.obs + (long long)kk * io.o_stride : nullptr);       // uniform bases (scalar arithmetic)
+        float *obs32 = F32 ? io.obs32 : ((!FULL && S->x_obs32) ? (float *)S->x_obs32 + (long long)(io.step0 + kk) * S->x_o32_stride : nullptr);
         uint8_t *mask = FULL ? io.mask : (io.mask ? io.mask + (long long)kk * io.m_stride : nullptr);
         const int sstep = t + 1;
         const bool last_step = (kk == k_steps - 1) || (!FULL && sstep >= T && !auto_reset);
@@ -292,11 +297,14 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const bool more = (kk + 1 < k_steps) && (FULL || sstep < T || auto_reset);
         const int ec = valid ? e_l : e0;   // clamped env for idle lanes
         const int gc = valid ? g_l : e0 * P;
-        if (FULL) {   // a running pointer instead of a 64-bit scalar product per step
+        if (F64) {   // a running pointer instead of a 64-bit scalar product per step
             a_next = ldg32_nt<double>(act_run + (more ? io.a_stride : 0), (unsigned)gc * 8u);
             act_run += io.a_stride;
+        } else if (F32) {
+            a_next = (double)ldg32_nt<float>(act32_run + (more ? io.a_stride : 0), (unsigned)gc * 4u);
+            act32_run += io.a_stride;
         } else
-        a_next = IO32 ? (double)ldg32_nt<float>(S->x_act32 + (long long)(io.step0 + (more ? kk + 1 : kk)) * io.a_stride, (unsigned)gc * 4u)
+        a_next = IO32 ? (double)ldg32_nt<float>(io.act32 + (long long)(io.step0 + (more ? kk + 1 : kk)) * io.a_stride, (unsigned)gc * 4u)
                       : ldg32_nt<double>(io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride, (unsigned)gc * 8u);
         const int scn = ev2g_scn(ec, off, M);             // this env's scenario in the resident pool
         const unsigned eT64 = FULL ? hb_step : (unsigned)(scn * T) * 64u;  // its rows in the [M,T,8] step table
@@ -488,15 +496,15 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 if (soc < 1.0 && td > sstep) pot = b_potc;  // utils.py:771
             }
             pot = (pot > c_maxp) ? c_maxp : ((pot < c_minp) ? 0.0 : pot);   // per-charger clamp (utils.py:779-789)
-            if (FULL || obs) {
-                // (the narrow full kernels sit at the register limit: they re-derive the port's column from the env's base)
-                const unsigned ocol8_l = (unsigned)((SK == 1) ? 3 + 3 * q_l : (SK == 0 ? 62 + 2 * q_l : 22 + 2 * q_l)) * 8u;
-                const unsigned o8 = WIDE ? hb_obs_port : (FULL ? hb_obs_env + ocol8_l : (unsigned)(e_l * D + ocol) * 8u);
+            // (the narrow full kernels sit at the register limit: they re-derive the port's column from the env's base)
+            const unsigned ocol_l = (unsigned)((SK == 1) ? 3 + 3 * q_l : (SK == 0 ? 62 + 2 * q_l : 22 + 2 * q_l));
+            if (F64 || (!FULL && obs)) {
+                const unsigned o8 = WIDE ? hb_obs_port : (FULL ? hb_obs_env + ocol_l * 8u : (unsigned)(e_l * D + ocol) * 8u);
                 stg32<d2v>(obs, o8, (d2v){o0, o1});   // one 16-byte store (D and the column offset are even for SK != 1)
                 if (SK == 1) stg32<double>(obs, o8 + 16u, o2);
             }
-            if (!FULL && obs32) {
-                const unsigned o4 = (unsigned)(e_l * D + ocol) * 4u;
+            if (F32 || (!FULL && obs32)) {
+                const unsigned o4 = WIDE ? hb_obs_port : (FULL ? hb_obs_env + ocol_l * 4u : (unsigned)(e_l * D + ocol) * 4u);
                 if (SK == 1) { stg32<float>(obs32, o4, (float)o0); stg32<float>(obs32, o4 + 4u, (float)o1); stg32<float>(obs32, o4 + 8u, (float)o2); }
                 else stg32<f2v>(obs32, o4, (f2v){(float)o0, (float)o1});
             }
@@ -643,8 +651,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 stg32<double>(env_acc, a8 + 32u, n4);
             }
         }
-        if (!FULL && valid && obs32) {
-            const unsigned o4 = (unsigned)(e_l * D) * 4u;
+        if (valid && (F32 || (!FULL && obs32))) {
+            const unsigned o4 = FULL ? hb_obs_env : (unsigned)(e_l * D) * 4u;
             if (SK == 1) {
                 if (q_l == 0) {
                     stg32<float>(obs32, o4, (float)((double)sstep / (double)T));
@@ -654,15 +662,17 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             } else {
                 if (q_l == 0) stg32<f2v>(obs32, o4, (f2v){(float)sstep, (float)usage});
                 if (q_l < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)q_l * 8u, (f2v){(float)pf_h0.x, (float)pf_h0.y});
-                if (q_l + P < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)(q_l + P) * 8u, (f2v){(float)pf_h1.x, (float)pf_h1.y});
-                const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
-                for (int pi = q_l + 2 * P; pi < NPAIR; pi += P) {
-                    const d2v hv = ldg32<d2v>(S->head_tab, h8 + (unsigned)pi * 16u);
-                    stg32<f2v>(obs32, o4 + 8u + (unsigned)pi * 8u, (f2v){(float)hv.x, (float)hv.y});
+                if (!WIDE) {
+                    if (q_l + P < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)(q_l + P) * 8u, (f2v){(float)pf_h1.x, (float)pf_h1.y});
+                    const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
+                    for (int pi = q_l + 2 * P; pi < NPAIR; pi += P) {
+                        const d2v hv = ldg32<d2v>(S->head_tab, h8 + (unsigned)pi * 16u);
+                        stg32<f2v>(obs32, o4 + 8u + (unsigned)pi * 8u, (f2v){(float)hv.x, (float)hv.y});
+                    }
                 }
             }
         }
-        if (valid && (FULL || obs)) {
+        if (valid && (F64 || (!FULL && obs))) {
             const unsigned o8 = FULL ? hb_obs_env : (unsigned)(e_l * D) * 8u;
             if (SK == 1) {  // PublicPST state.py:6-35
                 if (q_l == 0) {

@@ -249,7 +249,8 @@ int ev2g_current_step(const ev2g_handle *h);
 const char *ev2g_kernel_name(const ev2g_handle *h);
 const char *ev2g_fallback_reason(const ev2g_handle *h);
 /* Which instantiation of the fast-path kernel the last ev2g_step / ev2g_step_n launch used: 0 = the general one (any subset of outputs,
- * strides, extras, in-launch resets); 1 = "full" (all four float64 outputs with step stride 0, float64 actions, no extras, no charger
+ * strides, extras, in-launch resets); 1 = "full" (all four outputs with step stride 0 -- float64 actions in and float64 observations out, or, with the float32 action and
+ * observation buffers of ev2g_set_step_extras registered and no float64 ones passed, float32 in and out: ev2g_rollout --, no cost output, no charger
  * histories, the launch ends within the episode, one of the three compiled-in rewards): their checks are compiled out; 2 = full, plus
  * EV2G_FLAG_LOG_SOC on and an env wide enough for one observation-head column pair per lane.  -1: no launch yet or not the fast path.
  * Results are identical in all three (tests/test_round3_gpu.py); EV2G_NO_FULL / EV2G_NO_WIDE in the environment at load time force 0 / 1. */

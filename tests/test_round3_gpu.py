@@ -339,3 +339,50 @@ def test_fast_path_specialisations_agree_bit_for_bit(case, monkeypatch):
         s_nw, narrow = run(("EV2G_NO_WIDE",), strided=False, per_step=True)
         assert s_nw == 1
         same(ref, narrow)
+
+
+@pytest.mark.parametrize("case", SPEC_CASES[:4], ids=[c[0] for c in SPEC_CASES[:4]])
+def test_float32_hand_over_specialisations_agree_bit_for_bit(case, monkeypatch):
+    """The rollout's launches -- float32 actions in, float32 observations out, no float64 observation (ev2g_rollout between two actor
+    forwards) -- have their own full / full + wide instantiations; same requirement as above against the general kernel, step by step."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine, host_uniform
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    name, mk, reward, state, lo, want = case
+    E = 37
+    kind, C = mk(E)
+    g = GenConfig.v2g_profit_plus_loads(E, C, 1, seed=12) if kind == "v2g" else GenConfig.public_pst(E, C, seed=12)
+    batch = generate_native(g)
+    rk, sk = _abi.REWARD_KINDS[reward], _abi.STATE_KINDS[state]
+
+    def run(env):
+        for k in ("EV2G_NO_FULL", "EV2G_NO_WIDE"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
+        eng = Engine(batch, rk, sk, flags=_abi.FLAG_LOG_SOC)
+        P, D, T = eng.P, eng.D, eng.T
+        acts32 = eng.empty((T, E, P), np.float32).upload(host_uniform(T * E * P, 5, lo, 1.0).astype(np.float32))
+        obs32 = eng.empty((E, D), np.float32)
+        rew, done, mask = eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
+        eng.reset(eng.empty((E, D)))
+        out = []
+        for t in range(T):
+            eng.set_extras(obs_f32=obs32, actions_f32=acts32.at(t * E * P))
+            eng.step_n(1, None, E * P, None, 0, rew, 0, done, 0, mask, 0, auto_reset=False)
+            out.append((obs32.to_host().copy(), rew.to_host().copy(), done.to_host().copy(), mask.to_host().copy()))
+        spec = eng.last_launch_specialisation
+        res = dict(out=out, stats=eng.stats().copy())
+        eng.close()
+        return spec, res
+
+    s0, ref = run(("EV2G_NO_FULL",))
+    assert s0 == 0
+    variants = [((), want)] + ([(("EV2G_NO_WIDE",), 1)] if want == 2 else [])
+    for env, expect in variants:
+        s1, got = run(env)
+        assert s1 == expect
+        for ta, tb in zip(ref["out"], got["out"]):
+            for u, v in zip(ta, tb):
+                assert np.array_equal(u, v, equal_nan=True)
+        assert np.array_equal(ref["stats"], got["stats"], equal_nan=True)

@@ -34,6 +34,12 @@ def child(workload, pool, reps):
     acts = eng.empty((T, E, P)); eng.fill_uniform(acts, T * E * P, 1, wl["lo"], 1.0)
     obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
     stats = eng.empty((E, _abi.N_STATS))
+    io32 = bool(os.environ.get("AB_IO32"))   # the rollout's hand-over: float32 actions in, float32 observations out (no float64 ones)
+    if io32:
+        from ev2gym_amd.engine import host_uniform
+        acts32 = eng.empty((T, E, P), np.float32).upload(host_uniform(T * E * P, 1, wl["lo"], 1.0).astype(np.float32))
+        obs32 = eng.empty((E, D), np.float32)
+        eng.set_extras(obs_f32=obs32, actions_f32=acts32)
     bes = P * (phi * wl["b_occ"] + (1 - phi) * wl["b_empty"]) + batch.n_transformers * wl["b_tr"] + wl["b_env"]
     out = {"lib": os.environ.get("AB_LABEL") or os.environ.get("EV2G_LIB", "default"), "kernel": eng.kernel_name}
     off = 0
@@ -42,7 +48,7 @@ def child(workload, pool, reps):
         for r in range(n + 2):
             off = (off + E) % M
             eng.reset(obs, offset=off)
-            eng.step_n(T, acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=persistent)
+            eng.step_n(T, None if io32 else acts, E * P, None if io32 else obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=persistent)
             k = eng.last_step_n_kernel_ms()
             eng.stats(out=stats)
             if r >= 2:
@@ -52,7 +58,7 @@ def child(workload, pool, reps):
     eng.check_faults()
     # a parity spot check against the checksum of the default library's run is done by the caller: here only a digest
     eng.reset(obs, offset=0)
-    eng.step_n(T, acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=True)
+    eng.step_n(T, None if io32 else acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=True)
     st = eng.stats()
     out["digest"] = [float(np.nansum(st[:, i])) for i in (1, 2, 3, 12, 16)] + [float(obs.to_host().sum()), float(rew.to_host().sum())]
     print("AB " + json.dumps(out), flush=True)
