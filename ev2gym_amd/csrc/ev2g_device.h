@@ -53,6 +53,7 @@ struct DevScn {  // read-only scenario + layout, device pointers
     // chargers whose port counts differ (topology file; generic kernel only): ports [C] and first port [C+1] of every charger, and per
     // slot the action-mask entry the reference sets for it, i*cs.n_ports + j (ev2gym_env.py:452-457) -- the port itself when counts are equal
     const int *cs_np, *cs_pbase, *slot_mask;
+    const int *cs_slot0;   // [C] slot of each charger's port 0 (a charger's ports are adjacent slots, in port order)
     int het;
     // chargers [C]
     const double *cs_imin, *cs_imax, *cs_dmin, *cs_dmax_abs, *cs_volt, *cs_maxp, *cs_minp;
@@ -357,7 +358,34 @@ __device__ __forceinline__ double ev2g_connected_term(double des, double cap, do
 // The reward of a step from its env-level quantities.  costs: total profit of the step; usage: current_power_usage[t]; sp:
 // power_setpoints[t]; pot_t / pot_tm1: charge_power_potential[t] / [t-1] (0 before the episode's first entry); over100: sum over
 // the transformers of 100 * get_how_overloaded(); user: sum of ev2g_departure_term; tr0_maxp: transformers[0].max_power[t].
-struct RewardIn { double costs, usage, sp, pot_t, pot_tm1, over100, user, tr0_maxp; };
+// usage_seq: current_power_usage as the reference accumulates it -- charger by charger (ev2gym_env.py:375), each charger's output EV by EV
+// (ev_charger.py:180,196).  Every consumer of the usage tolerates the last-bit difference to the kernels' fixed summation tree except ONE:
+// SquaredTrackingErrorRewardWithPenalty tests it against an exact zero (reward.py:50), and with V2G cancelling charge and discharge powers leave
+// a rounding residue or an exact zero depending on the order.  The kernels therefore add the powers up a second time, sequentially, when (and
+// only when) that reward is selected (ev2g_usage_seq); for every other reward usage_seq is simply `usage`.
+struct RewardIn { double costs, usage, usage_seq, sp, pot_t, pot_tm1, over100, user, tr0_maxp; };
+// the sequential sum over one env's `stage` row of port powers (LDS, slot order); npc > 0: equal port counts, else per charger (cs_np)
+template <class IP>
+__device__ __forceinline__ double ev2g_usage_seq(const double *pw_row, int C, int npc, IP cs_slot0, IP cs_np) {
+    double u = 0.0;
+    if (npc == 1) {   // single-port chargers: a charger's output is its EV's power; loads batched eight at a time, additions in order
+        for (int c0 = 0; c0 < C; c0 += 8) {
+            double x[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = pw_row[cs_slot0[min(c0 + i, C - 1)]];
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (c0 + i < C) u += x[i];
+        }
+    } else {
+        for (int c = 0; c < C; c++) {
+            const int q0 = cs_slot0[c], np = (npc > 0) ? npc : cs_np[c];
+            double pw = 0.0;
+            for (int j = 0; j < np; j++) pw += pw_row[q0 + j];
+            u += pw;
+        }
+    }
+    return u;
+}
 __device__ __forceinline__ double ev2g_reward(int kind, const RewardIn &x) {
     switch (kind) {
     case 1: { const double m = (x.pot_t < x.sp) ? x.pot_t : x.sp; const double d = m - x.usage; return -(d * d); }   // reward.py:7-14
@@ -371,7 +399,7 @@ __device__ __forceinline__ double ev2g_reward(int kind, const RewardIn &x) {
     }
     case 4: {                                                                                                        // :46-58
         const double m = (x.pot_t < x.sp) ? x.pot_t : x.sp; const double d = m - x.usage;
-        return (x.usage == 0.0 && x.pot_tm1 != 0.0) ? -(d * d) - 100.0 : -(d * d);
+        return (x.usage_seq == 0.0 && x.pot_tm1 != 0.0) ? -(d * d) - 100.0 : -(d * d);
     }
     case 5: { const double d = x.sp - x.usage; return -(d * d); }                                                    // :60-65
     case 6: { double r = 0.0; if (x.sp < x.usage) r -= (x.usage - x.sp) * (x.usage - x.sp); return r + x.usage; }   // :67-76
@@ -825,6 +853,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                     const double costs = esum[2 * s.G + el];
                     RewardIn ri;
                     ri.costs = costs; ri.usage = usage; ri.over100 = over_sum; ri.user = esum[3 * s.G + el];
+                    ri.usage_seq = (s.reward_kind == 4) ? ev2g_usage_seq(stage + (size_t)el * P, C, s.het ? 0 : s.npc, s.cs_slot0, s.cs_np) : usage;
                     ri.sp = s.setpoint[(long long)scn * T + t];
                     ri.pot_t = st.pot_hist[(long long)t * s.E + e];
                     ri.pot_tm1 = (t > 0) ? st.pot_hist[(long long)(t - 1) * s.E + e] : 0.0;

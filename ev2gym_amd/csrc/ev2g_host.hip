@@ -552,6 +552,11 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     UP(ip, slot_mask) s.slot_mask = ip;
     UP(ip, np_of) s.cs_np = ip;
     UP(ip, pbase) s.cs_pbase = ip;
+    {
+        std::vector<int> cs_slot0(C);
+        for (int c = 0; c < C; c++) cs_slot0[c] = port_slot[pbase[c]];
+        UP(ip, cs_slot0) s.cs_slot0 = ip;
+    }
     s.het = het ? 1 : 0;
     UPP(dp, b->cs_min_charge_current, C) s.cs_imin = dp;
     UPP(dp, b->cs_max_charge_current, C) s.cs_imax = dp;

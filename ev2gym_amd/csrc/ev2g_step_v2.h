@@ -146,7 +146,7 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, double lutv, double a
 struct V2P {
     int E, M, T, C, npc, P, R, D, G, dt, reward_kind, state_kind, cost_kind, n_lut, pow2_dt;
     double sixty_over_dt, dt_over_60;
-    EV2G_GP(const int) slot_cs; EV2G_GP(const int) slot_port; EV2G_GP(const int) slot_obs;
+    EV2G_GP(const int) slot_cs; EV2G_GP(const int) slot_port; EV2G_GP(const int) slot_obs; EV2G_GP(const int) cs_slot0;
     EV2G_GP(const int) tr_seg; EV2G_GP(const int) tr_obs; EV2G_GP(const int) port_first;
     EV2G_GP(const int2) port_first_win;
     EV2G_GP(const double) cs_imax; EV2G_GP(const double) cs_imin; EV2G_GP(const double) cs_dmin;
@@ -189,7 +189,7 @@ inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
     p.sess_slice = (unsigned long long)(st.sess_abs_e ? (st.sess_abs_e - st.slab_sess) : 0) * 8ull;
 #define CPS(f) EV2G_SETP(p.f, s.f);
 #define CPT(f) EV2G_SETP(p.f, st.f);
-    CPS(slot_cs) CPS(slot_port) CPS(slot_obs) CPS(tr_seg) CPS(tr_obs) CPS(port_first) CPS(port_first_win)
+    CPS(slot_cs) CPS(slot_port) CPS(slot_obs) CPS(cs_slot0) CPS(tr_seg) CPS(tr_obs) CPS(port_first) CPS(port_first_win)
     CPS(cs_imax) CPS(cs_imin) CPS(cs_dmin) CPS(cs_dmax_abs) CPS(cs_maxp) CPS(cs_minp)
     CPS(price_ch) CPS(price_dis) CPS(setpoint) CPS(tr_infl) CPS(tr_solar) CPS(tr_base) CPS(tr_maxp) CPS(tr_minp)
     CPS(win_tab) CPS(lut) CPS(rec)
@@ -615,6 +615,13 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             lds_barrier();
         }
 
+        // SquaredTrackingErrorRewardWithPenalty only: the env's owner lane also adds the port powers up charger by charger, the order in
+        // which the reference tests the sum against an exact zero (RewardIn::usage_seq).  Here, in front of phase D's closing barrier: in
+        // the one-env scheme the other wavefronts enter the next step (and clear their slots of this row) without waiting for the owner.
+        double q_useq = 0.0;
+        const bool seq_usage = S->reward_kind == 4;   // (uniform)
+        if (seq_usage && env_lane && pl_l == 0) q_useq = ev2g_usage_seq(stage + (size_t)pel_l * P, C, npc, S->cs_slot0, S->cs_slot0);
+
         // ---------------- D: LDS-staged segmented reduction, one wavefront per (env, transformer) ----------------
         const bool one_env = (BLOCK >= 512) && (G == 1) && (R > 1) && (R <= 64);   // a big env owns the whole workgroup (P > 256), several transformers
         if (one_env) {
@@ -744,7 +751,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 if (sstep < T) p_pot[sstep * E + pe_l] = potn;
                 const double costs = q_costs;
                 RewardIn ri;
-                ri.costs = costs; ri.usage = usage; ri.sp = pf_sp; ri.over100 = over_sum; ri.user = q_sat;
+                ri.costs = costs; ri.usage = usage; ri.usage_seq = seq_usage ? q_useq : usage; ri.sp = pf_sp; ri.over100 = over_sum; ri.user = q_sat;
                 ri.pot_t = pot_prev[pel_l]; ri.pot_tm1 = pot_prev2[pel_l]; ri.tr0_maxp = tr0max[pel_l];
                 const double reward = ev2g_reward(rkind, ri);
                 pot_prev2[pel_l] = ri.pot_t;

@@ -533,6 +533,19 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         double esum[EV2G_NQ];
 #pragma unroll
         for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = 0.0;
+        // SquaredTrackingErrorRewardWithPenalty only (a run-time reward): the port powers once more, charger by charger like the reference
+        // (RewardIn::usage_seq, ev2g_device.h) -- by the env's head lane, before the reduction parks the env's sum in its first slot
+        double useq = 0.0;
+        if (RK == 3 && S->reward_kind == 4 && head) {
+            const double *prow = stage + tid_l;   // slot == reference port on this path (one transformer, single-port chargers)
+            for (int c0 = 0; c0 < P; c0 += 8) {
+                double x[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = prow[min(c0 + i, P - 1)];
+#pragma unroll
+                for (int i = 0; i < 8; i++) if (c0 + i < P) useq += x[i];
+            }
+        }
         if (__ballot(occ_any) != 0ull) {   // (uniform)
         {
             const int k = lane_l >> 3, j = lane_l & 7;
@@ -630,7 +643,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 reward = costs - esum[2];
             } else if (RK == 3) {  // the other fused rewards, by V2P::reward_kind
                 RewardIn ri;
-                ri.costs = costs; ri.usage = usage; ri.sp = pf_sp; ri.pot_t = ea5; ri.pot_tm1 = ea6; ri.over100 = over100;
+                ri.costs = costs; ri.usage = usage; ri.usage_seq = (S->reward_kind == 4) ? useq : usage; ri.sp = pf_sp; ri.pot_t = ea5; ri.pot_tm1 = ea6; ri.over100 = over100;
                 ri.user = esum[2]; ri.tr0_maxp = pf_maxp;
                 reward = ev2g_reward(S->reward_kind, ri);
             } else {  // ProfitMax_TrPenalty_UserIncentives reward.py:34-44
