@@ -62,6 +62,7 @@ struct ev2g_handle {
     bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
     bool no_full = false, no_wide = false;      // EV2G_NO_FULL / EV2G_NO_WIDE at load time: A/B and routing tests only
     int last_spec = -1;                         // ev2g_last_launch_specialisation
+    bool pow2_dt = false;                       // 60 / timescale is a power of two (15, 30, 60 minutes): compiled into ev2g_step_v2<.., 1>
     std::string kernel_name;                    // the step kernel ev2g_load_scenarios selected (ev2g_kernel_name)
     std::string fallback_reason;                // why the common-shape fast path was NOT taken ("" when it was / does not apply)
     int current_step = 0;
@@ -194,7 +195,7 @@ int ev2g_n_steps(const ev2g_handle *h) { return h ? h->T : 0; }
 int ev2g_current_step(const ev2g_handle *h) { return h ? h->current_step : 0; }
 const char *ev2g_kernel_name(const ev2g_handle *h) { return (h && h->loaded) ? h->kernel_name.c_str() : ""; }
 const char *ev2g_fallback_reason(const ev2g_handle *h) { return (h && h->loaded) ? h->fallback_reason.c_str() : ""; }
-int ev2g_last_launch_specialisation(const ev2g_handle *h) { return (h && h->loaded && h->wave_path) ? h->last_spec : -1; }
+int ev2g_last_launch_specialisation(const ev2g_handle *h) { return (h && h->loaded) ? h->last_spec : -1; }
 
 static const char *kStatNames[EV2G_N_STATS] = {
     "total_ev_served", "total_profits", "total_energy_charged", "total_energy_discharged",
@@ -521,6 +522,11 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
                          : h->block == 1024 ? (const void *)ev2g_step_v2<1024> : (const void *)ev2g_step_kernel;
         if (h->lds_bytes > 48 * 1024)
             HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        const void *fs = h->block == 256 ? (const void *)ev2g_step_v2<256, 1>
+                         : h->block == 512 ? (const void *)ev2g_step_v2<512, 1>
+                         : h->block == 1024 ? (const void *)ev2g_step_v2<1024, 1> : nullptr;
+        if (fs && h->lds_bytes > 48 * 1024)
+            HIPCHK(h, hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     }
     // AoS session records (one cache line each) for the v2 kernel
     std::vector<SessRec> recs((size_t)std::max<long long>(SD, 1));
@@ -714,6 +720,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         EV2G_SETP(v2p.step_tab, d_step_tab);
         int ex = 0;   // 60/dt a power of two and dt/60 its exact reciprocal -> divisions by them are multiplications
         v2p.pow2_dt = (std::frexp(h->scn.sixty_over_dt, &ex) == 0.5 && h->scn.sixty_over_dt * h->scn.dt_over_60 == 1.0) ? 1 : 0;
+        h->pow2_dt = v2p.pow2_dt != 0;
         if ((rc = upload(h, sp, &v2p, 1, &h->d_v2p))) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
@@ -854,6 +861,21 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
 #endif
         }
 #undef EV2G_WAVE_CASE
+        HIPCHK(h, hipGetLastError());
+        return EV2G_OK;
+    }
+    // the general kernel's instantiation for the default plugin pair launched with everything present (ev2g_step_v2.h, SPEC)
+    const bool spec = h->block && s.state_kind == EV2G_STATE_V2G_PROFIT_MAX_LOADS && s.reward_kind == 0 && s.npc == 1 && io.actions && io.obs &&
+                      io.reward && io.done && io.mask && !h->extras.cost && !h->extras.obs_f32 && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) &&
+                      (h->cfg.flags & EV2G_FLAG_LOG_SOC) && io.o_stride == 0 && io.r_stride == 0 && io.d_stride == 0 && io.m_stride == 0 &&
+                      !auto_reset && t0 + k <= s.T && h->pow2_dt && !h->no_full;
+    h->last_spec = h->block ? (spec ? 1 : 0) : -1;
+    if (spec) {
+        switch (h->block) {
+        case 256: hipLaunchKernelGGL((ev2g_step_v2<256, 1>), dim3(s.n_groups), dim3(256), h->lds_bytes, h->stream, (const V2P *)h->d_v2p, io, t0, k, auto_reset); break;
+        case 512: hipLaunchKernelGGL((ev2g_step_v2<512, 1>), dim3(s.n_groups), dim3(512), h->lds_bytes, h->stream, (const V2P *)h->d_v2p, io, t0, k, auto_reset); break;
+        default: hipLaunchKernelGGL((ev2g_step_v2<1024, 1>), dim3(s.n_groups), dim3(1024), h->lds_bytes, h->stream, (const V2P *)h->d_v2p, io, t0, k, auto_reset); break;
+        }
         HIPCHK(h, hipGetLastError());
         return EV2G_OK;
     }

@@ -252,7 +252,10 @@ const char *ev2g_fallback_reason(const ev2g_handle *h);
  * strides, extras, in-launch resets); 1 = "full" (all four outputs with step stride 0 -- float64 actions in and float64 observations out, or, with the float32 action and
  * observation buffers of ev2g_set_step_extras registered and no float64 ones passed, float32 in and out: ev2g_rollout --, no cost output, no charger
  * histories, the launch ends within the episode, one of the three compiled-in rewards): their checks are compiled out; 2 = full, plus
- * EV2G_FLAG_LOG_SOC on and an env wide enough for one observation-head column pair per lane.  -1: no launch yet or not the fast path.
+ * EV2G_FLAG_LOG_SOC on and an env wide enough for one observation-head column pair per lane.  The general kernel ("ev2g_step_v2<..>") has
+ * one such instantiation (1) for the reference's default plugin pair -- V2G_profit_max_loads + ProfitMax_TrPenalty_UserIncentives, single-port
+ * chargers, everything of the float64 list above, EV2G_FLAG_LOG_SOC, 15 / 30 / 60-minute steps -- and 0 otherwise.  -1: no launch yet, or the
+ * generic kernel.
  * Results are identical in all three (tests/test_round3_gpu.py); EV2G_NO_FULL / EV2G_NO_WIDE in the environment at load time force 0 / 1. */
 int ev2g_last_launch_specialisation(const ev2g_handle *h);
 /* data-dependent faults recorded since the last reset (per-env flag word, device side):

@@ -470,3 +470,52 @@ def test_penalty_reward_on_the_general_kernels_with_cancelling_powers(shape):
         if residue_steps >= 3:
             break
     assert residue_steps >= 1, "no episode with a cancellation residue found"
+
+
+@pytest.mark.parametrize("C,R", [(30, 3), (200, 4), (600, 12)], ids=["v2_256", "v2_256_wide", "v2_1024_one_env"])
+def test_general_kernel_specialisation_agrees_bit_for_bit(C, R, monkeypatch):
+    """`ev2g_step_v2<BLOCK, 1>` -- the general kernel compiled for the default plugin pair with every output present (what cfg4 runs) --
+    against the general instantiation: same episodes, whole-episode and step-by-step launches, everything `array_equal`."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    E = 5
+    batch = generate_native(GenConfig.v2g_profit_plus_loads(E, C, R, seed=21))
+    rk, sk = _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"]
+
+    def run(no_full, per_step):
+        monkeypatch.delenv("EV2G_NO_FULL", raising=False)
+        if no_full:
+            monkeypatch.setenv("EV2G_NO_FULL", "1")
+        eng = Engine(batch, rk, sk, flags=_abi.FLAG_LOG_SOC)
+        assert eng.kernel_name.startswith("ev2g_step_v2"), eng.kernel_name
+        P, D, T = eng.P, eng.D, eng.T
+        acts = eng.empty((T, E, P)); eng.fill_uniform(acts, T * E * P, 9, -1.0, 1.0)
+        obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
+        eng.reset(eng.empty((E, D)))
+        out = []
+        if per_step:
+            for t in range(T):
+                eng.step_n(1, acts.at(t * E * P), E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False)
+                out.append((obs.to_host().copy(), rew.to_host().copy(), done.to_host().copy(), mask.to_host().copy()))
+        else:
+            eng.step_n(T, acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=True)
+            out.append((obs.to_host().copy(), rew.to_host().copy(), done.to_host().copy(), mask.to_host().copy()))
+        spec, name = eng.last_launch_specialisation, eng.kernel_name
+        res = dict(out=out, stats=eng.stats().copy(), peek=[eng.peek(e) for e in (0, E - 1)])
+        eng.close()
+        return spec, name, res
+
+    s0, name, ref = run(True, True)
+    assert s0 == 0
+    for per_step in (True, False):
+        s1, _, got = run(False, per_step)
+        assert s1 == 1, name
+        xa, xb = (ref["out"], got["out"]) if per_step else (ref["out"][-1:], got["out"])
+        for ta, tb in zip(xa, xb):
+            for u, v in zip(ta, tb):
+                assert np.array_equal(u, v, equal_nan=True)
+        assert np.array_equal(ref["stats"], got["stats"], equal_nan=True)
+        for pa, pb in zip(ref["peek"], got["peek"]):
+            for k in pa:
+                assert np.array_equal(np.asarray(pa[k]), np.asarray(pb[k]), equal_nan=True), k
