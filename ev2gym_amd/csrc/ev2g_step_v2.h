@@ -310,8 +310,17 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     }
     const float *act32 = (const float *)S->x_act32;   // float32 actions (StepExtras), used when io.actions is null
     const long long a_base = io.actions ? 0 : (long long)io.step0 * io.a_stride;
-    double a_next = ev2g_action(io, act32, a_base, valid ? e * P + pref : e0 * P);
+    double a_next = SPEC ? io.actions[valid ? e * P + pref : e0 * P] : ev2g_action(io, act32, a_base, valid ? e * P + pref : e0 * P);
     __syncthreads();
+    // SPEC: the rows this lane reads every step (its transformer's series, its envs' prices / setpoints) do not move during the launch
+    int h_erT0 = 0, h_pec = 0, h_pecT = 0, h_evcT = 0;
+    if (SPEC) {
+        const int trl = min(tid, ne * R - 1), trl_e = trl / R;
+        h_erT0 = (ev2g_scn(e0 + trl_e, off, M) * R + (trl - trl_e * R)) * T;
+        h_pec = ev2g_scn(e0 + min(pel, ne - 1), off, M);
+        h_pecT = h_pec * T;
+        h_evcT = ev2g_scn(valid ? e : e0, off, M) * T;
+    }
 
     PT_DECL
     for (int kk = 0; kk < k_steps; kk++) {
@@ -362,9 +371,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             occ = (ta <= t) && (t <= td);
             if (log_soc && occ) cap_before = s_cap[tid_l];
             double a = occ ? a_next : 0.0;
-            if (npc == 1) {
-                if (a > 1.0) a = a / a;
-                else if (a < -1.0) a = -a / a;
+            if (npc == 1) {   // one port per charger: a / sum(a) = a / a and -a / a, exactly +-1 for every finite action (ev_charger.py:143-149)
+                if (a > 1.0) a = 1.0;
+                else if (a < -1.0) a = -1.0;
             } else {
                 const long long a_off = a_base + (long long)kk * io.a_stride;
                 const int j0 = tid_l - (pref_l - cs_l * npc);
@@ -407,25 +416,31 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
         //      phase A never waits on them; the loads stay in flight across the LDS-only barriers) ----
         {
             const bool more = (kk + 1 < k_steps) && (sstep < T || auto_reset);
-            a_next = ev2g_action(io, act32, a_base + (long long)(more ? kk + 1 : kk) * io.a_stride, valid ? e_l * P + pref_l : e0 * P);
+            a_next = SPEC ? io.actions[(long long)(more ? kk + 1 : kk) * io.a_stride + (valid ? e_l * P + pref_l : e0 * P)]
+                          : ev2g_action(io, act32, a_base + (long long)(more ? kk + 1 : kk) * io.a_stride, valid ? e_l * P + pref_l : e0 * P);
         }
         // Every prefetch is ONE unconditional load from a clamped (always valid) address; the conditions are applied where
         // the value is consumed.  A load in a divergent branch whose result merges with a default makes the compiler
         // serialise on the destination register (write-after-write) with a full vmcnt(0) drain.
-        const int trl = min(tid_l, ne * R - 1), trl_e = trl / R;   // this lane's (env, transformer) role
-        const int erT = (ev2g_scn(e0 + trl_e, off, M) * R + (trl - trl_e * R)) * T + t;
+        int erT;
+        if (SPEC) erT = h_erT0 + t;   // (no in-launch reset: this lane's rows do not move)
+        else {
+            const int trl = min(tid_l, ne * R - 1), trl_e = trl / R;   // this lane's (env, transformer) role
+            erT = (ev2g_scn(e0 + trl_e, off, M) * R + (trl - trl_e * R)) * T + t;
+        }
         const double pf_infl = S->tr_infl[erT], pf_solar = S->tr_solar[erT], pf_maxp = S->tr_maxp[erT], pf_minp = S->tr_minp[erT];
-        const int pec = ev2g_scn(e0 + min(pel_l, ne - 1), off, M);   // scenario of the (clamped) env of this lane's env-level role
-        const double pf_sp = S->setpoint[pec * T + t];
-        const int evc = ev2g_scn(valid ? e_l : e0, off, M);   // scenario of the (clamped) env of this lane's home role
-        const double pf_pch = S->price_ch[evc * T + t], pf_pdis = S->price_dis[evc * T + t];
+        const int pec = SPEC ? h_pec : ev2g_scn(e0 + min(pel_l, ne - 1), off, M);   // scenario of the (clamped) env of this lane's env-level role
+        const int pecT = SPEC ? h_pecT : pec * T;
+        const double pf_sp = S->setpoint[pecT + t];
+        const int evcT = SPEC ? h_evcT : ev2g_scn(valid ? e_l : e0, off, M) * T;   // scenario of the (clamped) env of this lane's home role
+        const double pf_pch = S->price_ch[evcT + t], pf_pdis = S->price_dis[evcT + t];
         // head / window columns of the observation this step emits (step counter sstep): one coalesced load per lane
         double pf_ob0 = 0.0, pf_ob1 = 0.0;
         const int nhead = (V2C(S->state_kind, 0) == 1) ? 0 : 20 + ((V2C(S->state_kind, 0) == 0) ? 40 * R : 0);
         if (V2C(S->state_kind, 0) == 1) {
-            pf_ob0 = S->setpoint[pec * T + min(sstep, T - 1)];   // consumed by pl == 0, masked by sstep < T
+            pf_ob0 = S->setpoint[pecT + min(sstep, T - 1)];   // consumed by pl == 0, masked by sstep < T
         } else {
-            const double *pprice = (const double *)S->price_ch + pec * T;
+            const double *pprice = (const double *)S->price_ch + pecT;
             const double *pwin = (const double *)S->win_tab + ((long long)pec * R * (T + 1) + sstep) * 40 - 20;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -450,7 +465,20 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 if (i < nch) h = items[i];
                 else if (i >= nchp) h = items[NS - 1 - (i - nchp)];
                 if (h >= 0) {
-                    const SessRec r = *(const SessRec *)(S->rec + s_ss[h]);
+                    // the 96 bytes the battery maths reads + the efficiency-table id, not the whole 128-byte record (its arrival / departure
+                    // fields are phase C's): 7 loads instead of 8, issued together
+                    SessRec r;
+                    {
+                        typedef double d2_t __attribute__((ext_vector_type(2)));
+                        const char __attribute__((address_space(1))) *rp = (const char __attribute__((address_space(1))) *)(S->rec + s_ss[h]);
+                        union { SessRec r; d2_t v[8]; } u;
+                        static_assert(offsetof(SessRec, cap0) == 96 && offsetof(SessRec, lut) == 120, "record layout");
+#pragma unroll
+                        for (int i = 0; i < 6; i++) u.v[i] = *(const d2_t __attribute__((address_space(1))) *)(rp + 16 * i);
+                        u.v[6] = (d2_t){0.0, 0.0}; u.v[7] = (d2_t){0.0, 0.0};
+                        u.r.lut = *(const int __attribute__((address_space(1))) *)(rp + 120);
+                        r = u.r;
+                    }
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
                     const double amps_h = s_amps[h];
