@@ -13,7 +13,8 @@ w = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 wl = WORKLOADS[w]
 E = wl["envs"]
 cfg = wl["gen"](2 * E, 3)
-t0 = time.perf_counter(); pool = generate_native(cfg); t_host = time.perf_counter() - t0
+pool = generate_native(cfg)   # (first call: loads the library)
+t0 = time.perf_counter(); pool = generate_native(cfg); t_host = time.perf_counter() - t0   # ev2g_generate + the numpy copies / port resolution of the Python wrapper
 eng = Engine(pool, _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]], device=0, flags=_abi.FLAG_LOG_SOC | _abi.FLAG_REFILLABLE, n_active_envs=E)
 eng.pool_refill(cfg, 3, 2 * E, 0, E); eng.synchronize()
 n = 20
@@ -23,4 +24,4 @@ for i in range(n):
 eng.synchronize()
 dt = (time.perf_counter() - t0) / n
 print(f"{w}: device refill of {E} scenarios: {dt * 1e6:.1f} us = {E / dt / 1e6:.1f} M scenarios/s (session capacity {eng.pool_session_capacity}, overflows {eng.pool_refill_overflows}); "
-      f"host ev2g_generate ({os.cpu_count()} threads): {t_host / (2 * E) * 1e6:.2f} us per scenario = {2 * E / t_host / 1e6:.2f} M scenarios/s")
+      f"host generate_native (warm, default threads of {os.cpu_count()} cpus): {t_host / (2 * E) * 1e6:.2f} us per scenario = {2 * E / t_host / 1e6:.3f} M scenarios/s; tools/gen_host_scaling.py times ev2g_generate alone")
