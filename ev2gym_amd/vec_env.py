@@ -286,8 +286,14 @@ class EV2GymVec:
         return self._out(self._obs), self._out(self._rew), self._out(self._done), self._false(), info
 
     def _false(self):
+        """`truncated`: always False (the reference never truncates, ev2gym_env.py:476-500).  With torch ONE device tensor is created and
+        returned every step -- a fresh `torch.zeros` per step was a kernel launch and 7 us of host time, half of the loop (treat it as
+        read-only, like the observation / reward / done tensors, which are the engine's own output buffers)."""
         if self._torch is not None:
-            return self._torch.zeros(self.num_envs, dtype=self._torch.bool, device=f"cuda:{self.device}")
+            t = getattr(self, "_trunc", None)
+            if t is None:
+                t = self._trunc = self._torch.zeros(self.num_envs, dtype=self._torch.bool, device=f"cuda:{self.device}")
+            return t
         return np.zeros(self.num_envs, bool)
 
     def get_statistics(self) -> dict:
