@@ -519,3 +519,46 @@ def test_general_kernel_specialisation_agrees_bit_for_bit(C, R, monkeypatch):
         for pa, pb in zip(ref["peek"], got["peek"]):
             for k in pa:
                 assert np.array_equal(np.asarray(pa[k]), np.asarray(pb[k]), equal_nan=True), k
+
+
+@pytest.mark.parametrize("workload,K", [("cfg2", 112), ("cfg3", 112), ("cfg4", 5)])
+def test_full_size_specialised_kernels_equal_the_general_ones(workload, K):
+    """BASELINE.json's full sizes: the instantiations the benchmark runs (fast path "full + wide", `ev2g_step_v2<1024, 1>`) against the general
+    ones -- every env, every step, every output, bit for bit (a full grid, the XCD-aware group mapping, the hoisted 32-bit offsets near their
+    largest values).  The general instantiations are held to the oracle at these sizes by tests/test_engine_gpu.py."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import WORKLOADS
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import generate_native
+    wl = WORKLOADS[workload]
+    E = wl["envs"]
+    batch = generate_native(wl["gen"](E, 7))
+    rk, sk = _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]]
+    eng = Engine(batch, rk, sk, flags=_abi.FLAG_LOG_SOC)
+    P, D, T = eng.P, eng.D, eng.T
+    K = min(K, T)
+    d_act = eng.empty((K, E, P))
+    eng.fill_uniform(d_act, K * E * P, 123, wl["lo"], 1.0)
+    # general instantiation: one launch, strided outputs
+    g_obs, g_rew, g_done, g_mask = eng.empty((K, E, D)), eng.empty((K, E)), eng.empty((K, E), np.uint8), eng.empty((K, E, P), np.uint8)
+    eng.reset()
+    eng.step_n(K, d_act, E * P, g_obs, E * D, g_rew, E, g_done, E, g_mask, E * P, auto_reset=False, persistent=True)
+    assert eng.last_launch_specialisation == 0
+    stats_general = eng.stats().copy() if K == T else None
+    G, R_, DN, MK = g_obs.to_host(), g_rew.to_host(), g_done.to_host(), g_mask.to_host()
+    g_obs.free()
+    # specialised instantiation: single-step launches with everything present, stride 0
+    obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
+    eng.reset()
+    for t in range(K):
+        eng.step(d_act.at(t * E * P), obs, rew, done, mask)
+        assert eng.last_launch_specialisation == (2 if workload != "cfg4" else 1)
+        assert np.array_equal(obs.to_host(), G[t], equal_nan=True), f"obs[{t}]"
+        assert np.array_equal(rew.to_host(), R_[t]), f"reward[{t}]"
+        assert np.array_equal(done.to_host(), DN[t]) and np.array_equal(mask.to_host(), MK[t]), f"done / mask [{t}]"
+    if K == T:
+        assert np.array_equal(np.nan_to_num(eng.stats()), np.nan_to_num(stats_general))
+    eng.check_faults()
+    eng.close()
