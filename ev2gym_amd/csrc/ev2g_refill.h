@@ -277,6 +277,7 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
         if (lane == 0) RW(double, tr_peak)[(size_t)ms * R + k] = peak;
         // ---- this transformer's observation windows (ev2g_build_window_table_kernel's values: load_minus_pv_at / power_limit_at), from LDS;
         //      on the fast path (one transformer) they are also columns 20..59 of the observation head table ----
+        RF_STAMP(7)
         if (s.win_tab || a.head_tab) {
             __syncthreads();
             const int nd = (c.demand_response && c.dr_events_per_day <= 16) ? c.dr_events_per_day : 0, ahead = g.steps_ahead;

@@ -98,8 +98,8 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
             unsigned long long v[8];
             (void)hipStreamSynchronize(h->stream);
             (void)hipMemcpy(v, d_dbg, 64, hipMemcpyDeviceToHost);
-            std::fprintf(stderr, "[ev2g] refill stamps (cycles): prices %llu | step tables %llu | pass 1 %llu | pass 2 %llu | transformers %llu | setpoints %llu\n",
-                         v[1] - v[0], v[2] - v[1], v[3] - v[2], v[4] - v[3], v[5] - v[4], v[6] - v[5]);
+            std::fprintf(stderr, "[ev2g] refill stamps (cycles): prices %llu | step tables %llu | pass 1 %llu | pass 2 %llu | transformer series %llu | observation tables %llu | setpoints %llu\n",
+                         v[1] - v[0], v[2] - v[1], v[3] - v[2], v[4] - v[3], v[7] - v[4], v[5] - v[7], v[6] - v[5]);   // (series / tables: of the LAST transformer)
         }
         a.dbg = d_dbg;
     }
