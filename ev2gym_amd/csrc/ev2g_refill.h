@@ -284,8 +284,18 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
             double *ht = (a.head_tab && a.head_nh == 60) ? a.head_tab + (size_t)ms * (size_t)(T + 1) * 60 : nullptr;
             // (the window table itself is read by ev2g_step_v2 only: where the fast path's head table exists nothing reads it after the load)
             double *wt = (s.win_tab && !ht) ? RW(double, win_tab) + ((size_t)ms * R + k) * (size_t)(T + 1) * 40 : nullptr;
+            // events in registers (their limit is one value per event); beyond four, the rest from LDS
+            int d_es[4], d_ee[4];
+            double d_lim[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const bool on = e < nd;
+                d_es[e] = on ? (int)l_dr[e * 3] : 0x7fffffff; d_ee[e] = on ? (int)l_dr[e * 3 + 1] : -1;
+                d_lim[e] = on ? peak - peak * l_dr[e * 3 + 2] / 100.0 : 0.0;
+            }
+            // element i = step * 40 + j40, i = lane, lane + 64, ...: (step, j40) advance by (1, +24) with a carry -- no division per element
+            int step = lane / 40, j40 = lane - step * 40;
             for (int i = lane; i < (T + 1) * 40; i += 64) {
-                const int step = i / 40, j40 = i - step * 40;
                 double v;
                 if (j40 < 20) {   // (loads - pv) window, Transformer.get_load_pv_forecast transformer.py:173-188
                     const int j = j40, kk = step + j;
@@ -297,7 +307,18 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
                 } else {          // power limits, Transformer.get_power_limits transformer.py:142-171
                     const int j = j40 - 20;
                     v = peak * 1.0;
-                    for (int e = 0; e < nd; e++) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int es = d_es[e], ee = d_ee[e];
+                        if (step + ahead >= es && ee >= step) {   // (an unused slot never matches: es = INT_MAX)
+                            int aa, bb;
+                            if (step > es) { aa = 0; bb = ee - step; } else { aa = es - step; bb = ee - step; }
+                            if (aa < 0) aa = -aa;
+                            if (bb < 0) bb = -bb;
+                            if (j >= aa && j < bb) v = d_lim[e];
+                        }
+                    }
+                    for (int e = 4; e < nd; e++) {
                         const int es = (int)l_dr[e * 3], ee = (int)l_dr[e * 3 + 1];
                         if (step + ahead >= es && ee >= step) {
                             int aa, bb;
@@ -310,15 +331,20 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
                 }
                 if (wt) wt[i] = v;
                 if (ht) ht[(size_t)step * 60 + 20 + j40] = v;
+                step += 1; j40 += 24;
+                if (j40 >= 40) { j40 -= 40; step += 1; }
             }
         }
     }
     // the price columns of the head table (|charge price| for the next 20 steps, zero past the horizon; state.py:75-83, :121-129)
     if (a.head_tab) {
         double *ht = a.head_tab + (size_t)ms * (size_t)(T + 1) * a.head_nh;
+        int step = lane / 20, cc = lane - step * 20;   // element i = step * 20 + cc advances by 64 = 3 * 20 + 4
         for (int i = lane; i < (T + 1) * 20; i += 64) {
-            const int step = i / 20, cc = i - step * 20, kk = step + cc;
+            const int kk = step + cc;
             ht[(size_t)step * a.head_nh + cc] = (kk < T) ? l_cp[kk] : 0.0;
+            step += 3; cc += 4;
+            if (cc >= 20) { cc -= 20; step += 1; }
         }
     }
 
