@@ -273,14 +273,16 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             if (log_soc && occ) cap_before = cap_b;
             double a = occ ? a_next : 0.0;
             // one port per charger: a / sum(a) = a / a, which is exactly +-1 for every finite action (ev_charger.py:143-149)
-            if (a > 1.0) a = 1.0;
-            else if (a < -1.0) a = -1.0;
-            double amps = 0.0;
-            if (occ) {
-                const double x = rnd5_x(a);
-                if (x > 0.0) { amps = x * c_imax; if (amps < c_thr) amps = 0.0; }
-                else if (x < 0.0) { amps = x * c_dmaxabs; if (amps > c_dmin - 0.01) amps = c_dmin; }
-            }
+            a = (a > 1.0) ? 1.0 : ((a < -1.0) ? -1.0 : a);
+            // Straight-line selects instead of nested branches (each divergent `if` is three scalar instructions around a handful of vector
+            // ones): an empty port has a == 0, hence x == 0 and amps == 0, like the branch it replaces.  |a| <= 1, so rint(a * 1e5) is
+            // within the range in which the two-FMA form of the division by 1e5 is exact (div_int_by_const, tests/test_fma_division.py):
+            // no fallback division.
+            const double n5 = rint(a * 100000.0), q5 = n5 * (1.0 / 100000.0);
+            const double x = fma(fma(-q5, 100000.0, n5), 1.0 / 100000.0, q5);   // rnd5 (ev_charger.py:157)
+            const double ac = x * c_imax, ad = x * c_dmaxabs;
+            const double amps_c = (ac < c_thr) ? 0.0 : ac, amps_d = (ad > c_dmin - 0.01) ? c_dmin : ad;
+            const double amps = (x > 0.0) ? amps_c : ((x < 0.0) ? amps_d : 0.0);
             s_amps[tid_l] = amps;
             stage[0 * RS + tid_l] = 0.0;
             stage[4 * RS + tid_l] = 0.0;
