@@ -202,6 +202,19 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+__device__ __forceinline__ double wave_min_dpp(double v) {   // the same walk with fmin
+    v = fmin(v, xor1_f64(v));
+    v = fmin(v, xor2_f64(v));
+    v = fmin(v, xor4_f64(v));
+    v = fmin(v, dpp_mov_f64<0x128>(v));
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return fmin(fmin(r0, r1), fmin(r2, r3));
+}
+
 // dict.get(np.round(amps), 1): integer keys 0..100 exist, anything else -> 1   (ev.py:287-290, :375-379)
 __device__ __forceinline__ double lut_get(const double *__restrict__ lut, int id, double key) {
     if (key >= 0.0 && key <= 100.0) return lut[id * 101 + (int)key];
@@ -966,22 +979,61 @@ __device__ __forceinline__ void port_sessions(const DevScn &s, const DevState &s
     }
 }
 
+// reductions over the W = 64 / EPWS lanes of one env's segment of a wavefront (EPWS == 1: the whole wavefront, wave_sum_dpp's order)
+template <int EPWS> __device__ __forceinline__ double seg_sum(double v) {
+    v += xor1_f64(v);
+    v += xor2_f64(v);
+    v += xor4_f64(v);
+    v += dpp_mov_f64<0x128>(v);   // row_ror:8 -- every lane now holds the sum of its 16-lane row
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    if (EPWS == 1) return (r0 + r1) + (r2 + r3);
+    return (threadIdx.x < 32) ? r0 + r1 : r2 + r3;
+}
+template <int EPWS> __device__ __forceinline__ double seg_min(double v) {
+    v = fmin(v, xor1_f64(v));
+    v = fmin(v, xor2_f64(v));
+    v = fmin(v, xor4_f64(v));
+    v = fmin(v, dpp_mov_f64<0x128>(v));
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    if (EPWS == 1) return fmin(fmin(r0, r1), fmin(r2, r3));
+    return (threadIdx.x < 32) ? fmin(r0, r1) : fmin(r2, r3);
+}
+template <int EPWS> __device__ __forceinline__ bool seg_all(bool p) {
+    const unsigned long long m = __ballot(p);
+    if (EPWS == 1) return m == ~0ull;
+    return (threadIdx.x < 32) ? ((unsigned)m == 0xffffffffu) : ((unsigned)(m >> 32) == 0xffffffffu);
+}
+
+template <int EPWS>
 __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, int scn_off,
                                                         const double *__restrict__ ss_afap, int cur_step,
                                                         double *__restrict__ out) {
-    const int e = blockIdx.x, lane = threadIdx.x;
-    if (e >= s.E) return;
+    // EPWS envs share a wavefront (W = 64 / EPWS lanes each): a wavefront's time is its chain of dependent memory round trips, not its lane
+    // count, so small envs (their sessions fit 32 lanes) are paired -- half the wavefronts for the same chain (ev2g_get_stats decides).
+    constexpr int W = 64 / EPWS;
+    const int sub = threadIdx.x / W, lane = threadIdx.x - sub * W;   // `lane`: inside the env's segment
+    const int e_raw = blockIdx.x * EPWS + sub;
+    const bool e_valid = e_raw < s.E;
+    const int e = e_valid ? e_raw : s.E - 1;   // (an odd env count: the idle segment recomputes the last env and stores nothing)
     const int scn = ev2g_scn(e, scn_off, s.M);
     const int T = s.T, C = s.C, R = s.R, P = s.P;
     double served = 0.0, sat = 0.0, nsat = 0.0;
-    for (int c = lane; c < C; c += 64) {
+    for (int c = lane; c < C; c += W) {
         const int n = st.cs_served[(long long)e * C + c];
         served += n;
         if (n > 0) { sat += st.cs_sat_sum[(long long)e * C + c] / n; nsat += 1.0; }
     }
-    served = wave_sum(served); sat = wave_sum(sat); nsat = wave_sum(nsat);
+    served = seg_sum<EPWS>(served); sat = seg_sum<EPWS>(sat); nsat = seg_sum<EPWS>(nsat);
     double over = 0.0, te = 0.0, ete = 0.0, ptv = 0.0;
-    for (int t = lane; t < T; t += 64) {
+    for (int t = lane; t < T; t += W) {
         // steps the running episode has not reached count as zeros (the reference's arrays are zero-initialised at reset); the
         // history slab may still hold the previous episode's values there after an in-kernel reset of a fused run
         const bool past = t < cur_step;
@@ -992,7 +1044,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
         ete += fabs(d);
         if (u > sp) ptv += u - sp;
     }
-    over = wave_sum(over); te = wave_sum(te); ete = wave_sum(ete); ptv = wave_sum(ptv);
+    over = seg_sum<EPWS>(over); te = seg_sum<EPWS>(te); ete = seg_sum<EPWS>(ete); ptv = seg_sum<EPWS>(ptv);
     ete *= (double)s.dt / 60.0;
     // energy user satisfaction (utils.py:57-63) and battery degradation (ev.py:442-521) over every spawned session
     const double e0 = 7.543e6, e1 = 23.75e6, e2 = 6976, z0 = 7.348e-3, z1 = 3.667, z2 = 7.6e-4, z3 = 4.081e-3;
@@ -1001,7 +1053,11 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
     // per-session constants of get_battery_degradation, evaluated once (same operations, same values)
     const double k_arrh = exp(-e2 / theta), k_age = pow(b_age, 0.25);
     const double Q_acc = 2 * (b_age * (d_dist / 365) * G_ * b_cap_ah) / b_cap_kwh, k_qacc = pow(Q_acc, 0.5);
+#ifdef EV2G_STATS_NO_LOG   /* timing experiment */
+    const bool log_soc = false;
+#else
     const bool log_soc = st.soc_log != nullptr;
+#endif
     double sum = 0.0, mn = INFINITY, cnt = 0.0, deg_cal = 0.0, deg_cyc = 0.0;
     // One SESSION per lane (an env has ~0.7 sessions per port: 35 at cfg2): every lane's chain is the two or three memory round
     // trips of ONE session's SoC log.  With a lane per port the wavefront waited for its busiest port (up to six sessions in a row).
@@ -1009,7 +1065,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
     double vkeep[2];
     int nkeep = 0;
     const int d0 = s.scn_sess[scn], d1 = s.scn_sess_end[scn];
-    for (int k = d0 + lane; k < d1; k += 64) {
+    for (int k = d0 + lane; k < d1; k += W) {
         const int q = s.ss_slot[k];
         const long long g = (long long)e * P + q, gs = (long long)scn * P + q;
         int first, last;
@@ -1030,6 +1086,11 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                 const int ta = s.ss_tarr[k], td = s.ss_tdep[k];
                 const int tend = min(td, cur_step - 1);
                 const double soc_f = capk / B;
+                // historic_soc entries are capacity / battery_capacity (ev.py:156): one reciprocal per session and a multiplication per
+                // entry instead of a float64 division per entry and pass -- the kernel's time was those ~60 divisions per session, not the
+                // log's bytes (a log confined to a quarter of its footprint: 52.7 -> 46.9 us).  Each entry differs from the quotient by at
+                // most one ulp; the statistics are sums of ~30 of them, compared at 1e-9 (relative) like every float64 output.
+                const double invB = 1.0 / B;
                 double hs = 0.0, fs = 0.0;
                 int n = 0, nf = 0;
                 // historic_soc / active_steps (sign bit set = inactive step).  The log is [E, T, P]: an env's block is contiguous
@@ -1047,7 +1108,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
 #pragma unroll
                 for (int u = 0; u < NK; u++) {
                     if (ta + u <= tend) {
-                        const double soc = fabs(xk[u]) / B;
+                        const double soc = fabs(xk[u]) * invB;
                         hs += soc; n++;
                         if (__double_as_longlong(xk[u]) >= 0) { fs += soc; nf++; }
                     }
@@ -1060,7 +1121,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         if (t + u <= tend) {
-                            const double soc = fabs(x[u]) / B;
+                            const double soc = fabs(x[u]) * invB;
                             hs += soc; n++;
                             if (__double_as_longlong(x[u]) >= 0) { fs += soc; nf++; }
                         }
@@ -1072,7 +1133,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                 double mad = 0.0;
 #pragma unroll
                 for (int u = 0; u < NK; u++) {
-                    if (ta + u <= tend && __double_as_longlong(xk[u]) >= 0) mad += fabs(avg_f - fabs(xk[u]) / B);
+                    if (ta + u <= tend && __double_as_longlong(xk[u]) >= 0) mad += fabs(avg_f - fabs(xk[u]) * invB);
                     if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
                 for (int t = ta + NK; t <= tend; t += 8) {
@@ -1081,7 +1142,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                     for (int u = 0; u < 8; u++) x[u] = slog[(long long)min(t + u, tend) * P];
 #pragma unroll
                     for (int u = 0; u < 8; u++)
-                        if (t + u <= tend && __double_as_longlong(x[u]) >= 0) mad += fabs(avg_f - fabs(x[u]) / B);
+                        if (t + u <= tend && __double_as_longlong(x[u]) >= 0) mad += fabs(avg_f - fabs(x[u]) * invB);
                 }
                 mad += fabs(avg_f - soc_f);
                 const double delta_DoD = 2 * (mad / nf);
@@ -1097,17 +1158,17 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
             }
         }
     }
-    sum = wave_sum(sum); cnt = wave_sum(cnt); mn = wave_min(mn);
-    deg_cal = wave_sum(deg_cal); deg_cyc = wave_sum(deg_cyc);
+    sum = seg_sum<EPWS>(sum); cnt = seg_sum<EPWS>(cnt); mn = seg_min<EPWS>(mn);
+    deg_cal = seg_sum<EPWS>(deg_cal); deg_cyc = seg_sum<EPWS>(deg_cyc);
     double mean = NAN, sd = NAN, mnv = NAN;
     if (cnt > 0.0) {
         mean = sum / cnt;
         double var = 0.0;
-        if (__all(nkeep <= 2)) {   // every lane kept all of its values (an env with at most 128 spawned sessions)
+        if (seg_all<EPWS>(nkeep <= 2)) {   // every lane kept all of its values (an env with at most 128 spawned sessions)
             if (nkeep > 0) { const double v = vkeep[0] - mean; var += v * v; }
             if (nkeep > 1) { const double v = vkeep[1] - mean; var += v * v; }
         } else {
-            for (int k = d0 + lane; k < d1; k += 64) {
+            for (int k = d0 + lane; k < d1; k += W) {
                 const int q = s.ss_slot[k];
                 const long long g = (long long)e * P + q, gs = (long long)scn * P + q;
                 int first, last;
@@ -1120,11 +1181,11 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                 }
             }
         }
-        var = wave_sum(var);
+        var = seg_sum<EPWS>(var);
         sd = sqrt(var / cnt);
         mnv = mn;
     }
-    if (lane != 0) return;
+    if (lane != 0 || !e_valid) return;
     const double *acc = st.env_acc + (long long)e * 8;
     double *o = out + (long long)e * 17;
     o[0] = served;

@@ -1209,8 +1209,15 @@ int ev2g_get_stats(ev2g_handle *h, double *stats) {
     if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_get_stats: no scenarios loaded");
     if (!stats) return fail(h, EV2G_ERR_ARG, "ev2g_get_stats: null output");
     (void)hipSetDevice(h->device);
-    hipLaunchKernelGGL(ev2g_stats_kernel, dim3(h->E), dim3(64), 0, h->stream, h->scn, h->st, (int)h->scn_off,
-                       (const double *)h->d_ss_afap, h->current_step, stats);
+    // two envs per wavefront where an env's sessions fit 32 lanes with room to spare (PublicPST: ~14 per env -- 74.6 -> 58.0 us at cfg3; at
+    // cfg2's ~35 per env half of the lanes would need a second pass: 47 -> 52 us, so it keeps a wavefront per env)
+    const bool pair = h->S <= (long long)h->M * 24 && h->C <= 32 && !std::getenv("EV2G_STATS_ONE_ENV");
+    if (pair)
+        hipLaunchKernelGGL(ev2g_stats_kernel<2>, dim3((h->E + 1) / 2), dim3(64), 0, h->stream, h->scn, h->st, (int)h->scn_off,
+                           (const double *)h->d_ss_afap, h->current_step, stats);
+    else
+        hipLaunchKernelGGL(ev2g_stats_kernel<1>, dim3(h->E), dim3(64), 0, h->stream, h->scn, h->st, (int)h->scn_off,
+                           (const double *)h->d_ss_afap, h->current_step, stats);
     HIPCHK(h, hipGetLastError());
     return EV2G_OK;
 }
