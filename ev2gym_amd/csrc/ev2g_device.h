@@ -1053,11 +1053,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
     // per-session constants of get_battery_degradation, evaluated once (same operations, same values)
     const double k_arrh = exp(-e2 / theta), k_age = pow(b_age, 0.25);
     const double Q_acc = 2 * (b_age * (d_dist / 365) * G_ * b_cap_ah) / b_cap_kwh, k_qacc = pow(Q_acc, 0.5);
-#ifdef EV2G_STATS_NO_LOG   /* timing experiment */
-    const bool log_soc = false;
-#else
     const bool log_soc = st.soc_log != nullptr;
-#endif
     double sum = 0.0, mn = INFINITY, cnt = 0.0, deg_cal = 0.0, deg_cyc = 0.0;
     // One SESSION per lane (an env has ~0.7 sessions per port: 35 at cfg2): every lane's chain is the two or three memory round
     // trips of ONE session's SoC log.  With a lane per port the wavefront waited for its busiest port (up to six sessions in a row).
