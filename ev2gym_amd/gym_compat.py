@@ -12,6 +12,8 @@ import numpy as np
 
 try:
     import gymnasium as _gym
+    if not (hasattr(_gym, "Env") and hasattr(_gym, "spaces") and hasattr(_gym.spaces, "Box")):
+        _gym = None   # not a real gymnasium (e.g. a stub somebody parked in sys.modules)
 except ImportError:   # optional
     _gym = None
 
@@ -43,7 +45,10 @@ def register_gym_id():
     """Register `EV2Gym-v1` (once).  Returns True when gymnasium is present."""
     if _gym is None:
         return False
-    from gymnasium.envs.registration import register, registry
+    try:   # a partial `gymnasium` in sys.modules (a test stand-in, the oracle's import stub) must never break `import ev2gym_amd`
+        from gymnasium.envs.registration import register, registry
+    except (ImportError, AttributeError):
+        return False
     if GYM_ID not in registry:
         default_cfg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "example_config_files", "V2GProfitMax.yaml")
         register(id=GYM_ID, entry_point="ev2gym_amd.env:EV2Gym", kwargs={"config_file": default_cfg})

@@ -24,7 +24,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-OUT = os.path.join(REPO, "tests", "golden")
+OUT = os.environ.get("EV2G_GOLDEN_OUT") or os.path.join(REPO, "tests", "golden")   # the recipe test regenerates into a temp dir
 sys.path.insert(0, HERE)
 sys.path.insert(1, os.path.dirname(HERE))   # ev2gym_amd (scenario generator + replay writer of the back-to-back cases); after HERE: `oracle` must stay oracle/oracle.py
 warnings.filterwarnings("ignore")

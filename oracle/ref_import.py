@@ -121,6 +121,10 @@ def import_reference():
     """Returns the reference `ev2gym` package (imported from /root/reference)."""
     if not os.path.isdir(REF_ROOT):
         raise RuntimeError("reference tree not present: this only works in the build container")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if repo not in sys.path:
+        sys.path.insert(1, repo)
+    import ev2gym_amd  # noqa: F401  -- BEFORE the gymnasium stub exists: the package must see the image's gymnasium (none), not ours
     _install_stubs()
     standins = _make_standins()
     import pkg_resources
