@@ -73,11 +73,15 @@ def load_ev_specs(path) -> dict:
             levels, eff = list(m["ch_current"]), list(m["3ph_ch_efficiency"])
             if len(levels) != len(eff) or not all(0 <= x <= 100 for x in eff):
                 raise ValueError(f"{path}: model '{name}': ch_current / 3ph_ch_efficiency must pair up, efficiencies in 0..100")
-            tab = {int(k): float(v) for k, v in zip(levels, eff)}
-            good = [k for k, v in tab.items() if v != 0]
+            # utils.py:279-286 verbatim in behaviour: the dict is filled IN PLACE while the levels are walked, so a level filled earlier is a
+            # candidate for the next one (the value propagates from the left neighbour; ties go to the earlier key in insertion order), and
+            # the keys stay what the file holds (a level 12.5 never answers an integer current)
+            tab = dict(zip(levels, (float(v) for v in eff)))
             for a in range(101):
-                if (a not in tab or tab[a] == 0) and good:
-                    tab[a] = tab[min(good, key=lambda k: abs(k - a))]
+                if a not in tab or tab[a] == 0:
+                    good = [k for k, v in tab.items() if v != 0]
+                    if good:
+                        tab[a] = tab[min(good, key=lambda k: abs(k - a))]
             out["efficiency"][i] = [tab.get(a, 1.0) for a in range(101)]   # (EV.get reads missing levels as 1, ev.py:288)
     if out["registrations"].sum() <= 0:
         raise ValueError(f"{path}: number_of_registrations sum to zero")

@@ -23,18 +23,30 @@
 #define EV2G_BLOCK 256
 #define EV2G_NQ 8  // staged quantities per port
 
-// One EV session, 128 bytes = one cache line: everything the per-step battery maths needs (ev.py:68-113).
+// One EV session, 128 bytes = one cache line: what the per-step battery maths and an arrival need (ev.py:68-113), laid out by CONSUMER so that
+// each of them fetches a contiguous run of 16-byte chunks: a charging step reads chunks 0..4 (80 bytes), a discharging step chunks 3..6
+// (64 bytes), an arrival chunks 2 and 7.  `rB` / `rv` are the correctly rounded reciprocals of `B` / `v` (computed once per session, by the
+// loader or the device generator, with an IEEE division): the battery maths divides by B and v through them (ev2g_fdiv2, below) instead of
+// through ~11-instruction hardware division sequences.
 struct __attribute__((aligned(128))) SessRec {
-    // the first 96 bytes are what the battery maths reads every step (the fast path fetches only those six 16-byte chunks) ...
-    double minB, emerg, pdismax, ts, tsm, eta_ch, eta_dis;
-    double gate_ch;   // min_ac_charge_power*1000/(voltage*sqrt(charger phases))   (ev.py:151)
-    double gate_dis;  // min_discharge_power*1000/(voltage*sqrt(charger phases))   (ev.py:153)
-    // ... an arrival reads the LAST four chunks (B .. lut), a departure the last two: the fast path prefetches them as such
-    double B, pacmax;
-    double v;         // voltage*sqrt(min(charger phases, ev_phases))              (ev.py:169,279,365)
-    double cap0, des;    // battery_capacity_at_arrival, desired_capacity
+    double pacmax, ts;        // chunk 0  (charge)
+    double tsm, eta_ch;       // chunk 1  (charge)
+    double gate_ch;           // chunk 2  (charge)  min_ac_charge_power*1000/(voltage*sqrt(charger phases))   (ev.py:151)
+    double B;                 //          (charge, arrival)
+    double rB;                // chunk 3  (charge)  RN(1 / B)
+    double v;                 //          (charge, discharge)  voltage*sqrt(min(charger phases, ev_phases))   (ev.py:169,279,365)
+    double rv;                // chunk 4  (charge, discharge)  RN(1 / v)
+    double gate_dis;          //          (discharge)  min_discharge_power*1000/(voltage*sqrt(charger phases))   (ev.py:153)
+    double minB, emerg;       // chunk 5  (discharge)
+    double pdismax, eta_dis;  // chunk 6  (discharge)
+    double cap0;              // chunk 7  (arrival)  battery_capacity_at_arrival
+    double potc;              //          (arrival)  this EV's term of calculate_charge_power_potential before the charger clamp:
+                              //          v * min(pacmax*1000/v, charger max current) / 1000   (utils.py:773-777), evaluated once per session
+};
+// What a departure reads (and the rewards that look at every connected EV's desired capacity), 16 bytes per session next to the records
+struct SessTail {
+    double des;          // desired_capacity
     int nt_arr, nt_dep;  // window of the next session on the same port (EV2G_INT_MAX = none)
-    int lut, pad;        // efficiency table id or -1
 };
 
 struct DevScn {  // read-only scenario + layout, device pointers
@@ -82,6 +94,7 @@ struct DevScn {  // read-only scenario + layout, device pointers
     const int *scn_sess_end;   // [M] one past the scenario's last session (== scn_sess[m+1] unless the pool is refillable: fixed-size blocks)
     const int2 *port_first_win;
     const SessRec *rec;  // [S] AoS twin of the ss_* arrays (v2 kernels)
+    const SessTail *tail;  // [S] departure-side fields of the same sessions
     const double *win_tab;  // [E,R,T+1,40] precomputed (loads-pv)[20] | power_limits[20] per observation step, or nullptr
 };
 
@@ -170,6 +183,27 @@ __device__ __forceinline__ double div_int_by_const(double n, double b, double rb
 }
 __device__ __forceinline__ double ceil2_x(double a) { return div_int_by_const(ceil(a * 100.0), 100.0, 1.0 / 100.0, 2.0e7); }
 __device__ __forceinline__ double rnd5_x(double x) { return div_int_by_const(rint(x * 100000.0), 100000.0, 1.0 / 100000.0, 2.0e5); }
+
+// a / b through the correctly rounded reciprocal rb = RN(1/b) (Markstein): q0 = RN(a*rb); r = a - b*q0 (exact, one fma); q = RN(q0 + r*rb).
+// THEOREM (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic, "division with an FMA"): if rb is 1/b rounded to nearest and
+// q0 is a FAITHFUL rounding of a/b (one of its two floating-point neighbours), then q is a/b correctly rounded -- bit for bit what the IEEE
+// division returns (no overflow / underflow / subnormals: every operand here is a physical quantity of magnitude 1e-6 .. 1e6, or zero).
+//   * ev2g_fdiv1 -- ONE correction step -- is used where b is a compile-time (or launch-time) CONSTANT whose reciprocal error
+//     delta_b = |b*RN(1/b) - 1| is <= 2^-54: then |a*rb - a/b| <= ulp/2 for EVERY a, so RN(a*rb) is faithful and the theorem applies.
+//     1000, 100, 60, 15, 30 qualify (0.375, 0.375, 0.25, 0.25, 0.25 x 2^-54; tests/test_fma_division.py recomputes them with exact rational
+//     arithmetic); the step length dt is checked on the host at load (V2P::dt_fdiv) and falls back to the division otherwise.
+//   * ev2g_fdiv2 -- TWO correction steps -- is used for the per-session divisors B and v, whose delta can reach 2^-53: the first step's result
+//     is within ulp/2 + 2^-52 ulp of a/b, hence faithful, and the second step makes it exact by the theorem.  5 full-rate instructions instead of the
+//     ~11 of the hardware sequence (v_div_scale x2, quarter-rate v_rcp_f64, 5 fma, v_div_fmas, v_div_fixup).
+// tests/test_fma_division.py runs both forms against the IEEE division on 4e8 random and near-midpoint operand pairs (0 differences).
+__host__ __device__ __forceinline__ double ev2g_fdiv1(double a, double b, double rb) {
+    const double q0 = a * rb;
+    return fma(fma(-q0, b, a), rb, q0);
+}
+__host__ __device__ __forceinline__ double ev2g_fdiv2(double a, double b, double rb) {
+    const double q1 = ev2g_fdiv1(a, b, rb);
+    return fma(fma(-q1, b, a), rb, q1);
+}
 
 // xor-butterfly partners inside 8-lane groups through DPP (VALU cross-lane moves, a few cycles) instead of
 // ds_bpermute (an LDS crossbar round trip per step): quad_perm [1,0,3,2], quad_perm [2,3,0,1], and

@@ -180,6 +180,7 @@ void ev2g_destroy(ev2g_handle *h) {
     free_pool(h->st_allocs);
     free_pool(h->user_allocs);
     free_pool(h->refill_cache.allocs);
+    if (h->d_refill_overflow) (void)hipFree(h->d_refill_overflow);
     ev2g_comm_destroy(h);
     drop_rollout_graphs(h);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -530,19 +531,27 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     }
     // AoS session records (one cache line each) for the v2 kernel
     std::vector<SessRec> recs((size_t)std::max<long long>(SD, 1));
+    std::vector<SessTail> tails((size_t)std::max<long long>(SD, 1));
+    std::memset(recs.data(), 0, recs.size() * sizeof(SessRec));
+    std::memset(tails.data(), 0, tails.size() * sizeof(SessTail));
     for (long long d = 0; d < SD; d++) {
         const long long hs = dev_to_host[d];
         if (hs < 0) continue;
         const int cs = b->ev_cs[hs];
         SessRec &r = recs[d];
-        r.B = ss_B[d]; r.cap0 = ss_cap0[d]; r.des = ss_des[d]; r.minB = ss_minB[d]; r.emerg = ss_emerg[d];
+        r.B = ss_B[d]; r.cap0 = ss_cap0[d]; r.minB = ss_minB[d]; r.emerg = ss_emerg[d];
         r.pacmax = ss_pacmax[d]; r.pdismax = ss_pdismax[d]; r.ts = ss_ts[d]; r.tsm = ss_tsm[d];
         r.eta_ch = ss_etach[d]; r.eta_dis = ss_etadis[d];
         const double v_gate = cs_vk[(size_t)cs * 4 + b->cs_phases[cs]];
         r.gate_ch = ss_pacmin[d] * 1000.0 / v_gate;
         r.gate_dis = ss_pdismin[d] * 1000.0 / v_gate;
         r.v = cs_vk[(size_t)cs * 4 + std::min(b->cs_phases[cs], ss_phases[d])];
-        r.nt_arr = ss_ntarr[d]; r.nt_dep = ss_ntdep[d]; r.lut = ss_lut[d]; r.pad = 0;
+        r.rB = 1.0 / r.B; r.rv = 1.0 / r.v;   // correctly rounded reciprocals (IEEE division): what ev2g_fdiv2 divides through
+        {   // this EV's charge-power-potential term before the charger clamp (utils.py:773-777), the reference's operations in its order
+            const double evc = r.pacmax * 1000.0 / r.v, imax = b->cs_max_charge_current[cs];
+            r.potc = r.v * ((evc < imax) ? evc : imax) / 1000.0;
+        }
+        tails[d].des = ss_des[d]; tails[d].nt_arr = ss_ntarr[d]; tails[d].nt_dep = ss_ntdep[d];
     }
 
     // ---- upload ----
@@ -642,6 +651,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     UP(i2p, port_first_win) s.port_first_win = i2p;
     UP(dp, ss_afap) h->d_ss_afap = dp;
     { SessRec *rp; UP(rp, recs) s.rec = rp; }
+    { SessTail *tp; UP(tp, tails) s.tail = tp; }
 #undef UP
 #undef UPP
     s.win_tab = nullptr;

@@ -174,16 +174,23 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
             RW(double, ss_pdismax)[d] = f.pdis_max; RW(double, ss_pdismin)[d] = f.pdis_min; RW(double, ss_ts)[d] = f.ts; RW(double, ss_tsm)[d] = f.tsm;
             RW(double, ss_etach)[d] = f.eta_ch; RW(double, ss_etadis)[d] = f.eta_dis;
             SessRec r;
-            r.B = e.B; r.cap0 = e.cap0; r.des = f.desired; r.minB = f.minB; r.emerg = f.min_emerg;
+            r.B = e.B; r.cap0 = e.cap0; r.minB = f.minB; r.emerg = f.min_emerg;
             r.pacmax = e.pac; r.pdismax = f.pdis_max; r.ts = f.ts; r.tsm = f.tsm; r.eta_ch = f.eta_ch; r.eta_dis = f.eta_dis;
             r.gate_ch = f.pac_min * 1000.0 / v_gate;
             r.gate_dis = f.pdis_min * 1000.0 / v_gate;
             r.v = s.cs_vk[(size_t)cs * 4 + min(ph, f.phases)];
-            r.nt_arr = EV2G_INT_MAX; r.nt_dep = EV2G_INT_MAX; r.lut = f.lut; r.pad = 0;
+            r.rB = 1.0 / r.B; r.rv = 1.0 / r.v;
+            {
+                const double evc = r.pacmax * 1000.0 / r.v, imax = s.cs_imax[cs];
+                r.potc = r.v * ((evc < imax) ? evc : imax) / 1000.0;
+            }
             RW(SessRec, rec)[d] = r;
+            SessTail tl;
+            tl.des = f.desired; tl.nt_arr = EV2G_INT_MAX; tl.nt_dep = EV2G_INT_MAX;
+            RW(SessTail, tail)[d] = tl;
             if (i > 0) {   // this port's previous session learns its successor's window
                 RW(int, ss_ntarr)[d - 1] = e.t_arr; RW(int, ss_ntdep)[d - 1] = e.t_dep;
-                RW(SessRec, rec)[d - 1].nt_arr = e.t_arr; RW(SessRec, rec)[d - 1].nt_dep = e.t_dep;
+                RW(SessTail, tail)[d - 1].nt_arr = e.t_arr; RW(SessTail, tail)[d - 1].nt_dep = e.t_dep;
             } else {
                 RW(int2, port_first_win)[gs] = make_int2(e.t_arr, e.t_dep);
             }

@@ -48,6 +48,10 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
     }
     if (c.tab_arrival_week) { refill_append(key, c.tab_arrival_week, 96 * 8); refill_append(key, c.tab_arrival_weekend, 96 * 8); refill_append(key, c.tab_stay, 48 * 8); refill_append(key, c.tab_energy, 48 * 8); }
     if (c.tab_pv && c.n_pv > 0) refill_append(key, c.tab_pv, (size_t)c.n_pv * 8);
+    if (!h->d_refill_overflow) {   // its own allocation, freed by ev2g_destroy: it must survive ev2g_load_scenarios (which frees scn_allocs) and config changes
+        HIPCHK(h, hipMalloc((void **)&h->d_refill_overflow, sizeof(int)));
+        HIPCHK(h, hipMemsetAsync(h->d_refill_overflow, 0, sizeof(int), h->stream));
+    }
     auto &rc_ = h->refill_cache;
     if (rc_.key != key) {
         (void)hipStreamSynchronize(h->stream);
@@ -69,12 +73,6 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
         if (const char *err = ev2g_gen_pv_series(c, c.timescale, pv)) return fail(h, EV2G_ERR_ARG, err);
         if (upd(pv.data(), pv.size(), &a.pv_series)) return rc;
         if (!spec_row.empty()) { int *p; if ((rc = upload(h, rc_.allocs, spec_row.data(), spec_row.size(), &p))) return rc; a.spec_row = p; }
-        if (!h->d_refill_overflow) {
-            int *p;
-            if ((rc = dalloc(h, h->scn_allocs, 1, &p))) return rc;
-            HIPCHK(h, hipMemsetAsync(p, 0, sizeof(int), h->stream));
-            h->d_refill_overflow = p;
-        }
         ev2g_gen_make_run(c, s.P, 1, seed, a.g0);
         a.g0.c = nullptr;
         a.g0.pv_per_day = pv.empty() ? 0 : 1440 / c.timescale;

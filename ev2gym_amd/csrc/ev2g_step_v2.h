@@ -70,62 +70,75 @@ __device__ __forceinline__ int ev_lut_index(int lut, double amps) {
 //   * when 60/dt is a power of two (dt = 15, 30, 60 -- every shipped config) `x / (60/dt)` is `x * (dt/60)` and
 //     `x / (dt/60)` is `x * (60/dt)`, bit for bit (`pow2_dt`, uniform);
 //   * the final `ceil(cap*100)/100` goes through div_int_by_const (exhaustively verified range).
-__device__ __forceinline__ EvRes ev_math(const SessRec &r, double lutv, double amps, double cap,
-                                         double prev_power, double tot_e, int cycles, double sixty_over_dt,
-                                         double dt_over_60, double dt, bool pow2_dt, bool has_lut) {
-    EvRes o;
-    o.cap = cap; o.prev_power = prev_power; o.tot_e = tot_e; o.energy = 0.0; o.current = 0.0; o.cycles = cycles; o.emerg = 0;
-    if (amps > 0.0 && amps < r.gate_ch) amps = 0.0;
-    else if (amps < 0.0 && amps > r.gate_dis) amps = 0.0;
-    if (amps == 0.0) return o;  // ev.py:158-163: no ceil, previous_power untouched
-    if (prev_power == 0.0 || ((prev_power < 0.0) != (amps < 0.0))) o.cycles = cycles + 1;
-    const double B = r.B, v = r.v;
-    if (amps > 0.0) {
-        const double eta = has_lut ? lutv : r.eta_ch;
-        const double pd0 = eta * amps * v / 1000.0 / B, md0 = eta * r.pacmax / B;
-        double pilot_dsoc = pow2_dt ? pd0 * dt_over_60 : pd0 / sixty_over_dt;
-        const double max_dsoc = pow2_dt ? md0 * dt_over_60 : md0 / sixty_over_dt;
-        if (pilot_dsoc > max_dsoc) pilot_dsoc = max_dsoc;
-        const double soc = cap / B;
-        double curr_soc;
-        if (r.ts == 1.0) {
-            curr_soc = pilot_dsoc + soc;
-            if (curr_soc > 1.0) curr_soc = 1.0;
-        } else {
-            const double pts = r.ts + (pilot_dsoc - max_dsoc) / max_dsoc * (r.ts - 1.0);
-            // the two exponential branches of ev.py:318-334 share one exp(): per lane exactly one of them applies, the
-            // operands of the selected one are evaluated in the reference's order, the other one costs nothing
-            const bool below = soc < pts;
-            const double num = below ? r.tsm * (pilot_dsoc + soc - pts) : r.tsm * pilot_dsoc;
-            const double fac = below ? (pts - 1.0) : (soc - 1.0);
-            double new_soc = 1.0 + exp(num / (pts - 1.0)) * fac;
-            if (below && (pilot_dsoc > 0.0 ? (pts - soc >= pilot_dsoc) : (1.0 <= (pts - soc) / pilot_dsoc))) new_soc = pilot_dsoc + soc;
-            const double lim = (max_dsoc > pilot_dsoc) ? pilot_dsoc : max_dsoc;
-            curr_soc = (new_soc - soc > lim) ? (lim + soc) : new_soc;
-        }
-        const double dsoc = curr_soc - soc;
-        o.cap = curr_soc * B;
-        o.energy = dsoc * B;
-        o.current = (pow2_dt ? o.energy * sixty_over_dt : o.energy / dt_over_60) * 1000.0 / v;
-    } else {
-        double given_power = amps * v / 1000.0;
-        if (fabs(given_power) > fabs(r.pdismax)) given_power = r.pdismax;
-        const double eta = has_lut ? lutv : r.eta_dis;
-        double given_energy = given_power * eta * dt / 60.0;
-        if (cap + given_energy < r.minB) {
-            if (cap > r.minB) { o.energy = -(cap - r.minB); given_energy = o.energy; }
-            else { o.energy = 0.0; given_energy = 0.0; }
-            o.cap = r.minB;
-        } else {
-            o.energy = given_energy;
-            o.cap = cap + given_energy;
-        }
-        if (cap > r.emerg && o.cap < r.emerg) o.emerg = 1;
-        o.current = given_energy * 60.0 / dt * 1000.0 / v;
-    }
+// The compacted lists separate charging from discharging items (each on its own wavefronts), so each kind has its own function and reads only
+// its own chunks of the record (SessRec, ev2g_device.h).  `amps` is > 0 for ev_math_charge and < 0 for ev_math_discharge on entry.
+// Divisions by the constants 1000 and 60 and by the per-session B and v go through their correctly rounded reciprocals (ev2g_fdiv1 / ev2g_fdiv2,
+// ev2g_device.h: bit-identical to the IEEE division, 3 / 5 instructions instead of ~11); the two divisions by values of this very step
+// (max_dsoc, pts - 1) are the hardware sequence.
+__device__ __forceinline__ void ev_math_finish(EvRes &o, double tot_e) {
     o.prev_power = o.energy;
     o.tot_e = tot_e + o.energy;
     o.cap = ceil2_x(o.cap);
+}
+__device__ __forceinline__ EvRes ev_math_charge(const SessRec &r, double lutv, double amps, double cap, double prev_power, double tot_e, int cycles,
+                                                double sixty_over_dt, double dt_over_60, bool pow2_dt, bool has_lut) {
+    EvRes o;
+    o.cap = cap; o.prev_power = prev_power; o.tot_e = tot_e; o.energy = 0.0; o.current = 0.0; o.cycles = cycles; o.emerg = 0;
+    if (amps < r.gate_ch) return o;  // ev.py:151-163: below the EV's minimum power the step is a no-op (no ceil, previous_power untouched)
+    if (prev_power == 0.0 || prev_power < 0.0) o.cycles = cycles + 1;   // previous_power / amps < 0 as a sign test (amps > 0)
+    const double B = r.B, rB = r.rB, v = r.v, rv = r.rv;
+    const double eta = has_lut ? lutv : r.eta_ch;
+    const double pd0 = ev2g_fdiv2(ev2g_fdiv1(eta * amps * v, 1000.0, 1.0 / 1000.0), B, rB), md0 = ev2g_fdiv2(eta * r.pacmax, B, rB);
+    double pilot_dsoc = pow2_dt ? pd0 * dt_over_60 : pd0 / sixty_over_dt;
+    const double max_dsoc = pow2_dt ? md0 * dt_over_60 : md0 / sixty_over_dt;
+    if (pilot_dsoc > max_dsoc) pilot_dsoc = max_dsoc;
+    const double soc = ev2g_fdiv2(cap, B, rB);
+    double curr_soc;
+    if (r.ts == 1.0) {
+        curr_soc = pilot_dsoc + soc;
+        if (curr_soc > 1.0) curr_soc = 1.0;
+    } else {
+        const double pts = r.ts + (pilot_dsoc - max_dsoc) / max_dsoc * (r.ts - 1.0);
+        // the two exponential branches of ev.py:318-334 share one exp(): per lane exactly one of them applies, the
+        // operands of the selected one are evaluated in the reference's order, the other one costs nothing
+        const bool below = soc < pts;
+        const double num = below ? r.tsm * (pilot_dsoc + soc - pts) : r.tsm * pilot_dsoc;
+        const double fac = below ? (pts - 1.0) : (soc - 1.0);
+        double new_soc = 1.0 + exp(num / (pts - 1.0)) * fac;
+        if (below && (pilot_dsoc > 0.0 ? (pts - soc >= pilot_dsoc) : (1.0 <= (pts - soc) / pilot_dsoc))) new_soc = pilot_dsoc + soc;
+        const double lim = (max_dsoc > pilot_dsoc) ? pilot_dsoc : max_dsoc;
+        curr_soc = (new_soc - soc > lim) ? (lim + soc) : new_soc;
+    }
+    const double dsoc = curr_soc - soc;
+    o.cap = curr_soc * B;
+    o.energy = dsoc * B;
+    o.current = ev2g_fdiv2((pow2_dt ? o.energy * sixty_over_dt : o.energy / dt_over_60) * 1000.0, v, rv);
+    ev_math_finish(o, tot_e);
+    return o;
+}
+__device__ __forceinline__ EvRes ev_math_discharge(const SessRec &r, double lutv, double amps, double cap, double prev_power, double tot_e, int cycles,
+                                                   double dt, bool has_lut, double rdt, bool dt_fdiv) {
+    EvRes o;
+    o.cap = cap; o.prev_power = prev_power; o.tot_e = tot_e; o.energy = 0.0; o.current = 0.0; o.cycles = cycles; o.emerg = 0;
+    if (amps > r.gate_dis) return o;  // ev.py:153-163
+    if (prev_power == 0.0 || prev_power > 0.0) o.cycles = cycles + 1;   // previous_power / amps < 0 as a sign test (amps < 0)
+    const double v = r.v, rv = r.rv;
+    double given_power = ev2g_fdiv1(amps * v, 1000.0, 1.0 / 1000.0);
+    if (fabs(given_power) > fabs(r.pdismax)) given_power = r.pdismax;
+    const double eta = has_lut ? lutv : r.eta_dis;
+    double given_energy = ev2g_fdiv1(given_power * eta * dt, 60.0, 1.0 / 60.0);
+    if (cap + given_energy < r.minB) {
+        if (cap > r.minB) { o.energy = -(cap - r.minB); given_energy = o.energy; }
+        else { o.energy = 0.0; given_energy = 0.0; }
+        o.cap = r.minB;
+    } else {
+        o.energy = given_energy;
+        o.cap = cap + given_energy;
+    }
+    if (cap > r.emerg && o.cap < r.emerg) o.emerg = 1;
+    const double e60 = given_energy * 60.0;
+    o.current = ev2g_fdiv2((dt_fdiv ? ev2g_fdiv1(e60, dt, rdt) : e60 / dt) * 1000.0, v, rv);
+    ev_math_finish(o, tot_e);
     return o;
 }
 
@@ -145,7 +158,8 @@ __device__ __forceinline__ EvRes ev_math(const SessRec &r, double lutv, double a
 // which was 40 % of the VALU instruction stream.
 struct V2P {
     int E, M, T, C, npc, P, R, D, G, dt, reward_kind, state_kind, cost_kind, n_lut, pow2_dt;
-    double sixty_over_dt, dt_over_60;
+    int dt_fdiv;   // |dt*RN(1/dt) - 1| <= 2^-54: x / dt may go through ev2g_fdiv1 (ev2g_device.h)
+    double sixty_over_dt, dt_over_60, rdt;
     EV2G_GP(const int) slot_cs; EV2G_GP(const int) slot_port; EV2G_GP(const int) slot_obs; EV2G_GP(const int) cs_slot0;
     EV2G_GP(const int) tr_seg; EV2G_GP(const int) tr_obs; EV2G_GP(const int) port_first;
     EV2G_GP(const int2) port_first_win;
@@ -158,7 +172,7 @@ struct V2P {
     EV2G_GP(char) slab_port; unsigned long long slab_port_slice;   // DevState slabs (ev2g_device.h)
     EV2G_GP(double) slab_hist; EV2G_GP(double) slab_sess; unsigned long long hist_slice, sess_slice;   // bytes
     EV2G_GP(const double) head_tab;   // [E, T+1, NH] observation head rows (fast path only, ev2g_build_head_table_kernel)
-    EV2G_GP(const SessRec) rec;
+    EV2G_GP(const SessRec) rec; EV2G_GP(const SessTail) tail; EV2G_GP(const int) ss_lut;
     EV2G_GP(double) cap; EV2G_GP(double) tot_e; EV2G_GP(double) prev_power; EV2G_GP(double) bcap; EV2G_GP(double) potc;
     EV2G_GP(int2) win; EV2G_GP(int2) sc;
     EV2G_GP(double) cs_sat_sum; EV2G_GP(int) cs_served;
@@ -179,6 +193,7 @@ inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
     p.E = s.E; p.M = s.M; p.cost_kind = s.cost_kind; p.T = s.T; p.C = s.C; p.npc = s.npc; p.P = s.P; p.R = s.R; p.D = s.D; p.G = s.G; p.dt = s.dt;
     p.reward_kind = s.reward_kind; p.state_kind = s.state_kind; p.n_lut = s.n_lut;
     p.sixty_over_dt = s.sixty_over_dt; p.dt_over_60 = s.dt_over_60;
+    p.rdt = 1.0 / (double)s.dt; p.dt_fdiv = fabs(fma((double)s.dt, p.rdt, -1.0)) <= 0x1p-54 ? 1 : 0;   // (the fma's result is exact: |dt*rdt - 1| < 2^-52 has at most 53 significant bits)
     EV2G_SETP(p.x_cost, (double *)nullptr); EV2G_SETP(p.x_obs32, (float *)nullptr); EV2G_SETP(p.x_act32, (const float *)nullptr);
     p.x_c_stride = 0; p.x_o32_stride = 0;
     p.pow2_dt = 0; EV2G_SETP(p.head_tab, (const double *)nullptr);
@@ -192,7 +207,7 @@ inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
     CPS(slot_cs) CPS(slot_port) CPS(slot_obs) CPS(cs_slot0) CPS(tr_seg) CPS(tr_obs) CPS(port_first) CPS(port_first_win)
     CPS(cs_imax) CPS(cs_imin) CPS(cs_dmin) CPS(cs_dmax_abs) CPS(cs_maxp) CPS(cs_minp)
     CPS(price_ch) CPS(price_dis) CPS(setpoint) CPS(tr_infl) CPS(tr_solar) CPS(tr_base) CPS(tr_maxp) CPS(tr_minp)
-    CPS(win_tab) CPS(lut) CPS(rec)
+    CPS(win_tab) CPS(lut) CPS(rec) CPS(tail) CPS(ss_lut)
     CPT(cap) CPT(tot_e) CPT(prev_power) CPT(bcap) CPT(potc) CPT(win) CPT(sc) CPT(cs_sat_sum) CPT(cs_served)
     CPT(cs_profits) CPT(cs_e_ch) CPT(cs_e_dis) CPT(cs_power_hist) CPT(cs_cur_hist) CPT(cs_power_now) CPT(cs_cur_now)
     CPT(env_acc) CPT(env_fault) CPT(usage_hist) CPT(pot_hist) CPT(over_hist) CPT(tr_power_now)
@@ -465,26 +480,30 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 if (i < nch) h = items[i];
                 else if (i >= nchp) h = items[NS - 1 - (i - nchp)];
                 if (h >= 0) {
-                    // the 96 bytes the battery maths reads + the efficiency-table id, not the whole 128-byte record (its arrival / departure
-                    // fields are phase C's): 7 loads instead of 8, issued together
-                    SessRec r;
-                    {
-                        typedef double d2_t __attribute__((ext_vector_type(2)));
-                        const char __attribute__((address_space(1))) *rp = (const char __attribute__((address_space(1))) *)(S->rec + s_ss[h]);
-                        union { SessRec r; d2_t v[8]; } u;
-                        static_assert(offsetof(SessRec, cap0) == 96 && offsetof(SessRec, lut) == 120, "record layout");
-#pragma unroll
-                        for (int i = 0; i < 6; i++) u.v[i] = *(const d2_t __attribute__((address_space(1))) *)(rp + 16 * i);
-                        u.v[6] = (d2_t){0.0, 0.0}; u.v[7] = (d2_t){0.0, 0.0};
-                        u.r.lut = *(const int __attribute__((address_space(1))) *)(rp + 120);
-                        r = u.r;
-                    }
+                    // the chunks of the record this wavefront's kind of step reads (charging: 0..4, discharging: 3..6 -- `i < nchp` is uniform: the
+                    // discharge items start on a wavefront boundary) + the efficiency-table id, issued together
+                    typedef double d2_t __attribute__((ext_vector_type(2)));
+                    const int ssh = s_ss[h];
+                    const char __attribute__((address_space(1))) *rp = (const char __attribute__((address_space(1))) *)(S->rec + ssh);
+                    union { SessRec r; d2_t v[8]; } u;
+                    static_assert(sizeof(SessRec) == 128 && offsetof(SessRec, rB) == 48 && offsetof(SessRec, minB) == 80 && offsetof(SessRec, cap0) == 112, "record layout");
+                    const int r_lut = S->ss_lut[ssh];
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
                     const double amps_h = s_amps[h];
                     double lutv = 1.0 / 100.0;
-                    if (r.lut >= 0) { const int li = ev_lut_index(r.lut, amps_h); if (li >= 0) lutv = S->lut[li]; }
-                    const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt, r.lut >= 0);
+                    EvRes o;
+                    if (i < nchp) {   // (uniform)
+#pragma unroll
+                        for (int c = 0; c < 5; c++) u.v[c] = *(const d2_t __attribute__((address_space(1))) *)(rp + 16 * c);
+                        if (r_lut >= 0) { const int li = ev_lut_index(r_lut, amps_h); if (li >= 0) lutv = S->lut[li]; }
+                        o = ev_math_charge(u.r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, pow2_dt, r_lut >= 0);
+                    } else {
+#pragma unroll
+                        for (int c = 3; c < 7; c++) u.v[c] = *(const d2_t __attribute__((address_space(1))) *)(rp + 16 * c);
+                        if (r_lut >= 0) { const int li = ev_lut_index(r_lut, amps_h); if (li >= 0) lutv = S->lut[li]; }
+                        o = ev_math_discharge(u.r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, dtd, r_lut >= 0, S->rdt, S->dt_fdiv != 0);
+                    }
                     if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
                     s_cap[h] = o.cap;
                     s_prev[h] = o.prev_power;
@@ -503,16 +522,17 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
         // Departures and arrivals are known before the step (occupancy does not depend on the actions): the session-record fields
         // phase C needs are requested here, behind this wavefront's battery maths (the register file has no room to hold them across it) and before the
         // barrier -- wavefronts without items overlap them with the others' maths -- instead of dependently inside that phase's branches.
-        // A lane has at most one of the two events: {B | des}, {cap0 | next window}, pacmax, v -- four 8-byte loads, issued only by
-        // wavefront-steps that have such an event; the other lanes of such a wavefront read record 0.
-        double pf_ra = 0.0, pf_rb = 0.0, pf_rc = 0.0, pf_rd = 0.0;
+        // A lane has at most one of the two events: an arrival takes {B, cap0, potc} from the record, a departure {des, next window} from the
+        // session's tail entry -- three 8-byte loads, issued only by wavefront-steps that have such an event; the other lanes of such a
+        // wavefront read session 0.
+        double pf_ra = 0.0, pf_rb = 0.0, pf_rc = 0.0;
         const bool ev_dep = occ && t >= s_td[valid ? tid_l : 0], ev_arr = valid && (s_ta[tid_l] == sstep);   // (the battery maths does not touch the windows)
         if (__ballot(ev_dep || ev_arr) != 0ull) {   // (uniform)
-            const char *rp = (const char *)((const SessRec *)S->rec + ((ev_dep || ev_arr) ? s_ss[tid_l] : 0));
-            pf_ra = *(const double *)(rp + (ev_arr ? offsetof(SessRec, B) : offsetof(SessRec, des)));
-            pf_rb = *(const double *)(rp + (ev_arr ? offsetof(SessRec, cap0) : offsetof(SessRec, nt_arr)));   // (the window: two ints)
-            pf_rc = *(const double *)(rp + offsetof(SessRec, pacmax));
-            pf_rd = *(const double *)(rp + offsetof(SessRec, v));
+            const int sse = (ev_dep || ev_arr) ? s_ss[tid_l] : 0;
+            const char *rp = (const char *)((const SessRec *)S->rec + sse), *tp = (const char *)((const SessTail *)S->tail + sse);
+            pf_ra = *(const double *)(ev_arr ? rp + offsetof(SessRec, B) : tp + offsetof(SessTail, des));
+            pf_rb = *(const double *)(ev_arr ? rp + offsetof(SessRec, cap0) : tp + offsetof(SessTail, nt_arr));   // (the window: two ints)
+            pf_rc = *(const double *)(rp + offsetof(SessRec, potc));
         }
         PT_MARK(2)
         lds_barrier();
@@ -566,12 +586,11 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 if (departed) {   // the next session arrives right behind a departure of this very step (the reference's spawner leaves a
                                   // gap, replayed scenarios need not): its record was not the one prefetched
                     const SessRec &r = *(const SessRec *)(S->rec + s_ss[tid_l]);
-                    pf_ra = r.B; pf_rb = r.cap0; pf_rc = r.pacmax; pf_rd = r.v;
+                    pf_ra = r.B; pf_rb = r.cap0; pf_rc = r.potc;
                 }
                 cap = pf_rb;
-                const double B = pf_ra, v = pf_rd;
-                const double evc = pf_rc * 1000.0 / v;            // utils.py:773-777
-                const double potc = v * ((evc < c_imax) ? evc : c_imax) / 1000.0;
+                const double B = pf_ra;
+                const double potc = pf_rc;   // v * min(pacmax*1000/v, charger max current) / 1000 (utils.py:773-777), evaluated when the session was loaded
                 s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
                 s_abse[tid_l] = 0.0;
                 S->bcap[g_l] = B;
@@ -582,8 +601,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             }
             const bool occ_after = (ta <= sstep) && (sstep <= td);
             if (occ_after && V2C(S->reward_kind, 0) >= 9) {   // (pst_)V2G_profitmaxV2: every connected EV (reward.py:173-195)
-                const SessRec &r = *(const SessRec *)(S->rec + s_ss[tid_l]);
-                satpen += ev2g_connected_term(r.des, cap, r.pacmax, sixty_over_dt, td, sstep);
+                const int ssc = s_ss[tid_l];
+                satpen += ev2g_connected_term(S->tail[ssc].des, cap, S->rec[ssc].pacmax, sixty_over_dt, td, sstep);
             }
             if (SPEC || mask) mask[e_l * P + pref_l] = occ_after ? 1 : 0;
             double o0 = 0.0, o1 = 0.0, o2 = 0.0;

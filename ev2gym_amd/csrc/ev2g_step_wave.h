@@ -41,19 +41,28 @@ template <class T, class B> __device__ __forceinline__ void stg32(B base, unsign
     *(T __attribute__((address_space(1))) *)((gptr)base + boff) = v;
 }
 typedef double d2v __attribute__((ext_vector_type(2)));   // builtin vectors: loadable from any address space
+typedef double d2v_a8 __attribute__((ext_vector_type(2), aligned(8)));   // the same at an 8-byte aligned address (global_load_dwordx4 needs dword alignment only)
 typedef int i2v __attribute__((ext_vector_type(2)));
 typedef int i4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
-// The battery-maths part of the record (its first 96 bytes) in one memory round trip: 6 x 16-byte loads issued back to back, then pinned by an empty asm so
-// that the compiler cannot sink the ones a later branch does not need behind that branch (it otherwise loads the
-// two gate fields first and the rest only after testing them: two dependent round trips).
-template <class B> __device__ __forceinline__ SessRec ldg32_rec(B base, unsigned boff) {
+// The battery-maths part of the record in one memory round trip: the chunks this wavefront's kind of step reads (charging 0..4, discharging
+// 3..6; uniform -- the two lists start on wavefront boundaries), issued back to back, then pinned by an empty asm so that the compiler cannot
+// sink the ones a later branch does not need behind that branch (it otherwise loads the gate field first and the rest only after testing
+// it: two dependent round trips).
+template <class B> __device__ __forceinline__ SessRec ldg32_rec_charge(B base, unsigned boff) {
     union { SessRec r; d2v v[sizeof(SessRec) / 16]; } u;
-    static_assert(offsetof(SessRec, cap0) == 96, "the battery maths reads the first six 16-byte chunks");
+    static_assert(sizeof(SessRec) == 128 && offsetof(SessRec, rB) == 48 && offsetof(SessRec, rv) == 64 && offsetof(SessRec, minB) == 80 && offsetof(SessRec, cap0) == 112,
+                  "charging reads chunks 0..4, discharging chunks 3..6");
 #pragma unroll
-    for (int i = 0; i < 6; i++) u.v[i] = ldg32<d2v>(base, boff + 16u * i);
-    asm volatile("" : "+v"(u.v[0]), "+v"(u.v[1]), "+v"(u.v[2]), "+v"(u.v[3]), "+v"(u.v[4]), "+v"(u.v[5]));
-    u.v[6] = (d2v){0.0, 0.0}; u.v[7] = (d2v){0.0, 0.0};   // arrival / departure fields: not read by ev_math
+    for (int i = 0; i < 5; i++) u.v[i] = ldg32<d2v>(base, boff + 16u * i);
+    asm volatile("" : "+v"(u.v[0]), "+v"(u.v[1]), "+v"(u.v[2]), "+v"(u.v[3]), "+v"(u.v[4]));
+    return u.r;
+}
+template <class B> __device__ __forceinline__ SessRec ldg32_rec_discharge(B base, unsigned boff) {
+    union { SessRec r; d2v v[sizeof(SessRec) / 16]; } u;
+#pragma unroll
+    for (int i = 3; i < 7; i++) u.v[i] = ldg32<d2v>(base, boff + 16u * i);
+    asm volatile("" : "+v"(u.v[3]), "+v"(u.v[4]), "+v"(u.v[5]), "+v"(u.v[6]));
     return u.r;
 }
 
@@ -147,6 +156,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     // term -- in registers instead of LDS (no in-launch reset rewrites them from outside): six LDS instructions a step less
     int r_ta = EV2G_INT_MAX, r_td = -1;
     double r_bcap = 1.0, r_potc = 0.0;
+    double r_rb = 1.0;   // RN(1 / battery size) of the attached EV: the observation's cap / B goes through it (ev2g_fdiv2) in the full kernels
     {
         const unsigned g8 = (unsigned)g * 8u, c8 = (unsigned)cs * 8u, cp8 = (unsigned)min(tid, P - 1) * 8u;
         const unsigned ec = (unsigned)(valid ? e : e0);
@@ -182,6 +192,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 s_cap[tid] = ldg32<double>(PA(EV2G_PS_CAP), g8); s_tot[tid] = ldg32<double>(PA(EV2G_PS_TOT), g8);
                 s_prev[tid] = ldg32<double>(PA(EV2G_PS_PREV), g8);
                 r_bcap = ldg32<double>(PA(EV2G_PS_BCAP), g8); r_potc = ldg32<double>(PA(EV2G_PS_POTC), g8);
+                if (FULL) r_rb = 1.0 / r_bcap;
                 if (!FULL) { s_bcap[tid] = r_bcap; s_potc[tid] = r_potc; }
                 s_abse[tid] = log_soc ? ldg32<double>(PA(EV2G_PS_ABSE), g8) : 0.0;
             } else {
@@ -336,14 +347,15 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // dependently, inside that phase's branches.  Only wavefront-steps that have such an event issue them (about half at cfg2);
         // the other lanes of such a wavefront read record 0.
         const bool ev_dep = occ && t >= td_a, ev_arr = (ta_a == sstep);
-        d2v pf_r4 = {0.0, 0.0}, pf_r5 = {0.0, 0.0}, pf_r6 = {0.0, 0.0};
-        i4v pf_r7 = {0, 0, 0, 0};
+        d2v pf_c2 = {0.0, 0.0}, pf_c7 = {0.0, 0.0};   // an arrival: {B, RN(1/B)}, {cap0, potc} of the arriving session's record ...
+        int pf_lut = -1;                              // ... and its efficiency-table id
+        i4v pf_tl = {0, 0, 0, 0};                     // a departure: {des (two words), next window} of the leaving session's tail entry
         if (__ballot(ev_dep || ev_arr) != 0ull) {   // (uniform)
-            const unsigned r8 = (ev_dep || ev_arr) ? (unsigned)s_ss[tid_l] * (unsigned)sizeof(SessRec) : 0u;
-            static_assert(offsetof(SessRec, B) == 72 && offsetof(SessRec, pacmax) == 80 && offsetof(SessRec, v) == 88 && offsetof(SessRec, cap0) == 96 &&
-                          offsetof(SessRec, des) == 104 && offsetof(SessRec, nt_arr) == 112 && offsetof(SessRec, lut) == 120, "SessRec tail layout");
-            pf_r4 = ldg32<d2v>(S->rec, r8 + 64u); pf_r5 = ldg32<d2v>(S->rec, r8 + 80u);
-            pf_r6 = ldg32<d2v>(S->rec, r8 + 96u); pf_r7 = ldg32<i4v>(S->rec, r8 + 112u);
+            const unsigned sse = (ev_dep || ev_arr) ? (unsigned)s_ss[tid_l] : 0u;
+            static_assert(offsetof(SessRec, B) == 40 && offsetof(SessRec, rB) == 48 && offsetof(SessRec, cap0) == 112 && offsetof(SessRec, potc) == 120 && sizeof(SessTail) == 16 &&
+                          offsetof(SessTail, nt_arr) == 8, "SessRec / SessTail layout");
+            pf_c2 = ldg32<d2v_a8>(S->rec, sse * (unsigned)sizeof(SessRec) + 40u); pf_c7 = ldg32<d2v>(S->rec, sse * (unsigned)sizeof(SessRec) + 112u);
+            pf_tl = ldg32<i4v>(S->tail, sse * 16u); pf_lut = ldg32<int>(S->ss_lut, sse * 4u);
         }
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
         PT_MARK(0)
@@ -374,12 +386,21 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     // is unconditional (clamped index); whether it applies is decided where it is used.
                     const int li = (lut_id >= 0) ? ev_lut_index(lut_id, amps_h) : -1;
                     double lut_raw = ldg32<double>(S->lut, (unsigned)max(li, 0) * 8u);
-                    const SessRec r = ldg32_rec(S->rec, (unsigned)s_ss[h] * (unsigned)sizeof(SessRec));
-                    asm volatile("" : "+v"(lut_raw));
+                    const unsigned r8 = (unsigned)s_ss[h] * (unsigned)sizeof(SessRec);
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
-                    const double lutv = (li >= 0) ? lut_raw : 1.0 / 100.0;
-                    const EvRes o = ev_math(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, dtd, pow2_dt, lut_id >= 0);
+                    EvRes o;
+                    if (i < nchp) {   // (uniform: the discharge items start on a wavefront boundary)
+                        const SessRec r = ldg32_rec_charge(S->rec, r8);
+                        asm volatile("" : "+v"(lut_raw));
+                        const double lutv = (li >= 0) ? lut_raw : 1.0 / 100.0;
+                        o = ev_math_charge(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, pow2_dt, lut_id >= 0);
+                    } else {
+                        const SessRec r = ldg32_rec_discharge(S->rec, r8);
+                        asm volatile("" : "+v"(lut_raw));
+                        const double lutv = (li >= 0) ? lut_raw : 1.0 / 100.0;
+                        o = ev_math_discharge(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, dtd, lut_id >= 0, S->rdt, S->dt_fdiv != 0);   // (fetched here, by the discharging wavefronts only: not kept across the step loop)
+                    }
                     if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] |= 1;
                     s_cap[h] = o.cap;
                     s_prev[h] = o.prev_power;
@@ -406,7 +427,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // prefetched registers are plain values from here on, so their later uses -- after this phase's stores, and
         // across the loop back-edge for the next action -- no longer cost a conservative vmcnt(0) drain
         asm volatile("" : "+v"(a_next), "+v"(pf_pch), "+v"(pf_pdis), "+v"(pf_tr), "+v"(pf_ob0), "+v"(pf_h0), "+v"(pf_h1));
-        asm volatile("" : "+v"(pf_r4), "+v"(pf_r5), "+v"(pf_r6), "+v"(pf_r7));
+        asm volatile("" : "+v"(pf_c2), "+v"(pf_c7), "+v"(pf_tl), "+v"(pf_lut));
         bool occ_any = false;   // an EV on this port before or after the step
         if (valid) {
             double profit = 0.0, satpen = 0.0, pot = 0.0;
@@ -437,7 +458,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 if (log_soc) stg32<double>(S->soc_log + (long long)t * P, g8 + (unsigned)e_l * (unsigned)((T - 1) * P * 8), (current != 0.0) ? cap_before : -cap_before);
                 if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
                     const int ss = ss_now;
-                    const double des = pf_r6.y;
+                    const double des = __hiloint2double(pf_tl.y, pf_tl.x);
                     const double score = (cap < des - 0.001) ? cap / des : 1.0;
                     if (RK == 3) satpen = ev2g_departure_term(S->reward_kind, S->cost_kind, score, cap, des);
                     else if (RK != 1 || S->cost_kind == 1) satpen = 100.0 * exp(-10.0 * score);
@@ -449,7 +470,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     stg32<double>(slabS, (unsigned)ss * 8u, cap);
                     if (log_soc) stg32<double>((slabS + SS8), (unsigned)ss * 8u, s_abse[tid_l]);
-                    ta = pf_r7.x; td = pf_r7.y;   // window of the port's next session
+                    ta = pf_tl.z; td = pf_tl.w;   // window of the port's next session
                     departed = true;
                     if (FULL) { r_ta = ta; r_td = td; } else { s_ta[tid_l] = ta; s_td[tid_l] = td; }
                     ss_now = (ta != EV2G_INT_MAX) ? ss + 1 : -1;
@@ -462,19 +483,16 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 if (departed) {   // the next session arrives right behind a departure of this very step (the reference's spawner leaves a
                                   // gap, replayed scenarios need not): its record was not the one prefetched
                     const unsigned r8 = (unsigned)ss_now * (unsigned)sizeof(SessRec);
-                    pf_r4 = ldg32<d2v>(S->rec, r8 + 64u); pf_r5 = ldg32<d2v>(S->rec, r8 + 80u);
-                    pf_r6 = ldg32<d2v>(S->rec, r8 + 96u); pf_r7 = ldg32<i4v>(S->rec, r8 + 112u);
+                    pf_c2 = ldg32<d2v_a8>(S->rec, r8 + 40u); pf_c7 = ldg32<d2v>(S->rec, r8 + 112u); pf_lut = ldg32<int>(S->ss_lut, (unsigned)ss_now * 4u);
                 }
-                cap = pf_r6.x;
-                const double B = pf_r4.y;
-                const double v = pf_r5.y;
-                const double evc = pf_r5.x * 1000.0 / v;            // utils.py:773-777
-                const double potc = v * ((evc < c_imax) ? evc : c_imax) / 1000.0;
+                cap = pf_c7.x;
+                const double B = pf_c2.x;
+                const double potc = pf_c7.y;   // v * min(pacmax*1000/v, charger max current) / 1000 (utils.py:773-777), evaluated when the session was loaded
                 s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0;
-                if (FULL) { r_bcap = B; r_potc = potc; } else { s_bcap[tid_l] = B; s_potc[tid_l] = potc; }
+                if (FULL) { r_bcap = B; r_potc = potc; r_rb = pf_c2.y; } else { s_bcap[tid_l] = B; s_potc[tid_l] = potc; }
                 s_abse[tid_l] = 0.0;
                 b_bcap = B; b_potc = potc; b_tot = 0.0;
-                const int lut_new = pf_r7.z;
+                const int lut_new = pf_lut;
                 stg32<int>(PA(EV2G_PS_LUT), g8 >> 1, lut_new);
                 stg32<double>(PA(EV2G_PS_BCAP), g8, B);
                 stg32<double>(PA(EV2G_PS_POTC), g8, potc);
@@ -485,14 +503,14 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             const bool occ_after = (ta <= sstep) && (sstep <= td);
             if (RK == 3 && occ_after && S->reward_kind >= 9) {   // (pst_)V2G_profitmaxV2: every connected EV (reward.py:173-195)
                 const unsigned r8 = (unsigned)ss_now * (unsigned)sizeof(SessRec);
-                satpen += ev2g_connected_term(ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, des)), cap,
+                satpen += ev2g_connected_term(ldg32<double>(S->tail, (unsigned)ss_now * 16u), cap,
                                               ldg32<double>(S->rec, r8 + (unsigned)offsetof(SessRec, pacmax)), sixty_over_dt, td, sstep);
             }
             occ_any = occ || occ_after;
             if (FULL || mask) stg32<uint8_t>(mask, (unsigned)g_l, occ_after ? 1 : 0);
             double o0 = 0.0, o1 = 0.0, o2 = 0.0;
             if (occ_after) {
-                const double soc = cap / b_bcap;
+                const double soc = FULL ? ev2g_fdiv2(cap, b_bcap, r_rb) : cap / b_bcap;   // bit-identical (ev2g_device.h)
                 if (SK == 1) { o0 = (soc == 1.0) ? 1.0 : 0.5; o1 = b_tot; o2 = (double)(sstep - ta); }
                 else { o0 = soc; o1 = (double)(td - sstep); }
                 if (soc < 1.0 && td > sstep) pot = b_potc;  // utils.py:771

@@ -89,6 +89,8 @@ class EV2GymVec:
             if config_file is None or scenarios is not None or load_from_replay_path is not None:
                 raise ValueError("device_refill draws scenarios from a config: pass config_file (not scenarios / a replay file)")
             self.generator = generator = "native"
+            if self.pool_factor < 2:
+                raise ValueError("device_refill re-draws the window an episode used while the next episode runs on another one: it needs pool_factor >= 2")
         if scenarios is None and load_from_replay_path is not None:
             # one replay file, or a list of them recorded with the same config: one env per file (ev2gym_env.py:102-116)
             from .replay import load_replay
@@ -221,6 +223,8 @@ class EV2GymVec:
             self.scenarios = self._draw_pool(self.rank, self.world_size)
             self.engine.load(self.scenarios)
             self._window_queue = None
+            self._last_offset = None   # names a window of the OLD pool: nothing of the new one has been used yet
+            self._refill_next = self.engine.M * max(1, self.world_size)   # the new pool is a new stream of scenarios (its own seed)
         if seed is not None:
             offset = int(np.random.default_rng(int(seed)).integers(0, M)) if M > self.num_envs else 0
         else:

@@ -623,12 +623,29 @@ def test_ev_specs_file_named_by_the_yaml_is_read(tmp_path, backend):
     assert (a["ev_pdis_max"][big] == -11.0).all() and (a["ev_pdis_max"][~big] == 0).all()
     assert b.n_lut == 1 and (a["ev_lut"][big] == 0).all() and (a["ev_lut"][~big] == -1).all()
     assert np.isnan(a["ev_eta_ch"][big]).all() and ((a["ev_eta_ch"][~big] >= 0.95) & (a["ev_eta_ch"][~big] <= 1.0)).all()
-    lut = a["lut"][0]   # nearest level with a non-zero efficiency (utils.py:279-288): the 16 A entry is 0 in the file
-    assert lut[6] == 80 and lut[0] == 80 and lut[16] == 80 and lut[19] == 80 and lut[20] == 95 and lut[32] == 95 and lut[100] == 95
+    lut = a["lut"][0]   # nearest level with a non-zero efficiency (utils.py:279-288): the 16 A entry is 0 in the file.  The reference fills
+    # its dict IN PLACE, level by level, so a level filled a moment ago is the nearest candidate of the next: 80 walks right up to 30 A (31 A ties 30 with 32, and 32 is the earlier key)
+    assert lut[6] == 80 and lut[0] == 80 and lut[16] == 80 and lut[19] == 80 and lut[20] == 80 and lut[30] == 80 and lut[31] == 95 and lut[32] == 95 and lut[100] == 95
     with pytest.raises(FileNotFoundError):
         gen_config_from_yaml({**y, "ev_specs_file": str(tmp_path / "no_such_fleet.json")}, 2, 1)
     g = gen_config_from_yaml({**y, "ev_specs_file": "./ev2gym/data/ev_specs_v2g_enabled2024.json"}, 2, 1)   # shipped name, file absent: stand-in
     assert g.ev_specs is None and g.fleet == "v2g2024" and g.fleet_with_efficiency_tables
+
+
+def test_ev_specs_efficiency_curve_is_filled_like_the_reference_fills_it(tmp_path):
+    """utils.py:279-286 mutates the level dict while walking 0..100: interior zeros and wide gaps take the LEFT neighbour's value
+    (a tie between an original level and one filled earlier goes to the earlier key in insertion order), non-integer levels stay
+    keys that no integer current reads.  Expected values worked out by hand from that loop."""
+    import json
+    from ev2gym_amd.config import load_ev_specs
+    spec = {"M": {"number_of_registrations": 1, "battery_capacity": 50, "max_ac_charge_power": 11, "max_ac_discharge_power": 0,
+                  "ch_current": [12, 14, 16, 18, 20, 40.5], "3ph_ch_efficiency": [90, 0, 0, 0, 95, 70]}}
+    path = str(tmp_path / "gaps.json")
+    json.dump(spec, open(path, "w"))
+    eff = load_ev_specs(path)["efficiency"][0]
+    assert (eff[:20] == 90).all()          # 0..11 from 12; 13..18 hand the 90 on; 19 ties 18 (filled, earlier key) with 20 -> 18's 90
+    assert eff[20] == 95 and (eff[21:40] == 95).all()
+    assert eff[40] == 70 and (eff[40:] == 70).all()   # 40: |40.5 - 40| < |39 - 40| -> the 40.5 A level's 70; from there 70 walks on
 
 
 @pytest.mark.parametrize("backend", ["numpy", "native"])
