@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     for (int kk = 0; kk < k_steps; kk++) {
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
         PT_MARK(5)
-#else
+#elif !defined(EV2G_PT_BSPLIT)   // (tools/phase_timing.py -DEV2G_PT_BSPLIT: slot 7 := the battery maths' operand wait, the loop top counts as phase A)
         PT_MARK(7)
 #endif
         asm volatile("" : "+s"(S));
@@ -270,39 +270,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // before, which a busy step closes with a barrier and a quiet step leaves at zero
         if (tid_l < 2) cnt[2 * ((kk + 1) & 1) + tid_l] = 0;
 
-        // ---------------- A: home lanes, charger level (ev_charger.py:137-186) ----------------
-        bool occ = false;
-        double cap_before = 0.0;
-        int ta_a = EV2G_INT_MAX, td_a = -1;   // this port's window as phase A saw it (idle lanes: no event)
-        if (valid) {
-            // every LDS operand of the phase in one batch (one wait) instead of one round trip per branch
-            int ta = FULL ? r_ta : s_ta[tid_l], td = FULL ? r_td : s_td[tid_l];
-            double cap_b = s_cap[tid_l], c_thr = s_cst[0 * 64 + q_l], c_dmin = s_cst[1 * 64 + q_l];
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta), "+v"(td), "+v"(cap_b), "+v"(c_thr), "+v"(c_dmin));
-            ta_a = ta; td_a = td;
-            occ = (ta <= t) && (t <= td);
-            if (log_soc && occ) cap_before = cap_b;
-            double a = occ ? a_next : 0.0;
-            // one port per charger: a / sum(a) = a / a, which is exactly +-1 for every finite action (ev_charger.py:143-149)
-            a = (a > 1.0) ? 1.0 : ((a < -1.0) ? -1.0 : a);
-            // Straight-line selects instead of nested branches (each divergent `if` is three scalar instructions around a handful of vector
-            // ones): an empty port has a == 0, hence x == 0 and amps == 0, like the branch it replaces.  |a| <= 1, so rint(a * 1e5) is
-            // within the range in which the two-FMA form of the division by 1e5 is exact (div_int_by_const, tests/test_fma_division.py):
-            // no fallback division.
-            const double n5 = rint(a * 100000.0), q5 = n5 * (1.0 / 100000.0);
-            const double x = fma(fma(-q5, 100000.0, n5), 1.0 / 100000.0, q5);   // rnd5 (ev_charger.py:157)
-            const double ac = x * c_imax, ad = x * c_dmaxabs;
-            const double amps_c = (ac < c_thr) ? 0.0 : ac, amps_d = (ad > c_dmin - 0.01) ? c_dmin : ad;
-            const double amps = (x > 0.0) ? amps_c : ((x < 0.0) ? amps_d : 0.0);
-            s_amps[tid_l] = amps;
-            stage[0 * RS + tid_l] = 0.0;
-            stage[4 * RS + tid_l] = 0.0;
-            stage[5 * RS + tid_l] = 0.0;
-            stage[6 * RS + tid_l] = 0.0;
-            stage[7 * RS + tid_l] = 0.0;
-            if (amps != 0.0) items[(amps > 0.0) ? atomicAdd(&cntk[0], 1) : NS - 1 - atomicAdd(&cntk[1], 1)] = tid_l;
-        }
-        PT_MARK(0)
+        const double a_cur = a_next;   // this step's action; the prefetch below replaces a_next by the next step's
         // ---- prefetch what the rest of this step needs (collected before the stores of phase C) ----
         // Every prefetch is ONE unconditional load from a clamped (always valid) address; the conditions are applied
         // where the value is consumed.  A load inside a divergent branch whose result merges with a default makes the
@@ -342,6 +310,39 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             pf_h0 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l, NPAIR - 1) * 16u);
             if (!WIDE && P < NPAIR) pf_h1 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l + P, NPAIR - 1) * 16u);   // (uniform)
         }
+        // ---------------- A: home lanes, charger level (ev_charger.py:137-186) ----------------
+        bool occ = false;
+        double cap_before = 0.0;
+        int ta_a = EV2G_INT_MAX, td_a = -1;   // this port's window as phase A saw it (idle lanes: no event)
+        if (valid) {
+            // every LDS operand of the phase in one batch (one wait) instead of one round trip per branch
+            int ta = FULL ? r_ta : s_ta[tid_l], td = FULL ? r_td : s_td[tid_l];
+            double cap_b = s_cap[tid_l], c_thr = s_cst[0 * 64 + q_l], c_dmin = s_cst[1 * 64 + q_l];
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta), "+v"(td), "+v"(cap_b), "+v"(c_thr), "+v"(c_dmin));
+            ta_a = ta; td_a = td;
+            occ = (ta <= t) && (t <= td);
+            if (log_soc && occ) cap_before = cap_b;
+            double a = occ ? a_cur : 0.0;
+            // one port per charger: a / sum(a) = a / a, which is exactly +-1 for every finite action (ev_charger.py:143-149)
+            a = (a > 1.0) ? 1.0 : ((a < -1.0) ? -1.0 : a);
+            // Straight-line selects instead of nested branches (each divergent `if` is three scalar instructions around a handful of vector
+            // ones): an empty port has a == 0, hence x == 0 and amps == 0, like the branch it replaces.  |a| <= 1, so rint(a * 1e5) is
+            // within the range in which the two-FMA form of the division by 1e5 is exact (div_int_by_const, tests/test_fma_division.py):
+            // no fallback division.
+            const double n5 = rint(a * 100000.0), q5 = n5 * (1.0 / 100000.0);
+            const double x = fma(fma(-q5, 100000.0, n5), 1.0 / 100000.0, q5);   // rnd5 (ev_charger.py:157)
+            const double ac = x * c_imax, ad = x * c_dmaxabs;
+            const double amps_c = (ac < c_thr) ? 0.0 : ac, amps_d = (ad > c_dmin - 0.01) ? c_dmin : ad;
+            const double amps = (x > 0.0) ? amps_c : ((x < 0.0) ? amps_d : 0.0);
+            s_amps[tid_l] = amps;
+            stage[0 * RS + tid_l] = 0.0;
+            stage[4 * RS + tid_l] = 0.0;
+            stage[5 * RS + tid_l] = 0.0;
+            stage[6 * RS + tid_l] = 0.0;
+            stage[7 * RS + tid_l] = 0.0;
+            if (amps != 0.0) items[(amps > 0.0) ? atomicAdd(&cntk[0], 1) : NS - 1 - atomicAdd(&cntk[1], 1)] = tid_l;
+        }
+        PT_MARK(0)
         // Departures and arrivals are known before the step (occupancy does not depend on the actions): the fields phase C needs
         // from the session record -- its last four 16-byte chunks -- travel with the other prefetches instead of being fetched,
         // dependently, inside that phase's branches.  Only wavefront-steps that have such an event issue them (about half at cfg2);
@@ -393,6 +394,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     if (i < nchp) {   // (uniform: the discharge items start on a wavefront boundary)
                         const SessRec r = ldg32_rec_charge(S->rec, r8);
                         asm volatile("" : "+v"(lut_raw));
+#if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_BSPLIT)
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        PT_MARK(7)
+#endif
                         const double lutv = (li >= 0) ? lut_raw : 1.0 / 100.0;
                         o = ev_math_charge(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, pow2_dt, lut_id >= 0);
                     } else {
@@ -586,7 +591,13 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 acc += xor1_f64(acc);
                 acc += xor2_f64(acc);
                 acc += xor4_f64(acc);
-                if (j == 0) stage[k * RS + wbase] = acc;
+                // lane 8k now holds the env's sum of quantity k: with ONE env per wavefront the sums are wave-uniform, so they are
+                // read out with v_readlane (scalar registers) instead of being parked in LDS and read back by every lane --
+                // two LDS round trips less on the step's chain.  (Quantity 7, the summed current, has no consumer on this path.)
+                const int acc_lo = __double2loint(acc), acc_hi = __double2hiint(acc);
+#pragma unroll
+                for (int kq = 0; kq < EV2G_NQ - 1; kq++)
+                    esum[kq] = __hiloint2double(__builtin_amdgcn_readlane(acc_hi, kq * 8), __builtin_amdgcn_readlane(acc_lo, kq * 8));
             } else {          // several envs per wavefront: P <= 32, so ports j+32 .. j+56 do not exist (their terms were exact zeros);
                               // an unclamped index past the env reads a neighbour's slot (or, behind the last row, the array that
                               // follows `stage` in LDS) and is masked
@@ -611,9 +622,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (EPW != 1) {   // (uniform)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = stage[kq * RS + (tid_l - q_l)];   // the env's sums (its head slot), every lane
+            for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = stage[kq * RS + (tid_l - q_l)];   // the env's sums (its head slot), every lane
+        }
         }
 
         PT_MARK(4)

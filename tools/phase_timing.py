@@ -29,6 +29,7 @@ acts = eng.empty((T, E, P)); eng.fill_uniform(acts, T * E * P, 1, wl["lo"], 1.0)
 obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
 names = ["A home/charger", "barrier waits", "B battery maths", "C home", "D reduce", "E env-level", "prefetch issue", "loop top"]
 if OUTER: names[6], names[7] = "EPILOGUE (state write-back)", "PROLOGUE (state load)"
+if "-DEV2G_PT_BSPLIT" in defs: names[7], names[2], names[0] = "B operands (LDS + record wait)", "B battery maths proper", "A home/charger + loop top"
 print(f"## {wname} {eng.kernel_name} defs={defs}")
 for persistent in (True, False):
     eng.reset(obs)
