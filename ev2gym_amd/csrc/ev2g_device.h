@@ -98,21 +98,32 @@ struct DevScn {  // read-only scenario + layout, device pointers
     const double *win_tab;  // [E,R,T+1,40] precomputed (loads-pv)[20] | power_limits[20] per observation step, or nullptr
 };
 
-// The [E*P]-shaped state arrays live in ONE allocation of equal slices (slice = max(E*P, E*C) * 8 bytes), in this
-// order; likewise {usage, potential, overload} histories and the two per-session result arrays.  Every kernel keeps
-// using the individual pointers below; the fast-path kernel derives them from the slab base with scalar adds, which
-// replaces ~25 pointer fetches per step by a handful (ev2g_step_wave.h).
-enum { EV2G_PS_CAP = 0, EV2G_PS_TOT, EV2G_PS_PREV, EV2G_PS_BCAP, EV2G_PS_POTC, EV2G_PS_PENERGY, EV2G_PS_PCURRENT, EV2G_PS_ABSE,
-       EV2G_PS_SATSUM, EV2G_PS_WIN, EV2G_PS_SC, EV2G_PS_SERVED, EV2G_PS_LUT, EV2G_PS_N };
+// Per-port dynamic state: ONE 64-byte line per (env, port slot) -- one memory sector.  A launch that runs a single step (the RL loop with a
+// policy between steps) starts with cold caches and fetches state only for the ports that hold an EV or receive one in this step (a fifth of
+// them; which ones is known before the step from the scenario's occupancy masks, ev2g_build_occ_mask_kernel): one line each, instead of
+// eight-byte pieces of nine arrays whose sectors were nearly all touched (round 3: 30.7 MB of traffic per launch against 16 MB algorithmic).
+struct __attribute__((aligned(64))) PortLine {
+    int ta, td;          // {t_arr, t_dep} of the attached-or-next session (EV2G_INT_MAX = none)
+    int ss;              // its index in the session arrays (-1: the port's list is exhausted)
+    int cyc_lut;         // EV.charging_cycles (low 16 bits) | (efficiency-table id + 1) << 16 of the attached EV; T and the table count are < 65536 (checked at load)
+    double cap, tot;     // EV.current_capacity, EV.total_energy_exchanged
+    double prev, abse;   // EV.previous_power, EV.abs_total_energy_exchanged
+    double bcap, potc;   // battery_capacity and charge-power-potential term of the attached EV
+};
+__host__ __device__ __forceinline__ int ev2g_line_cycles(int cyc_lut) { return cyc_lut & 0xffff; }
+__host__ __device__ __forceinline__ int ev2g_line_lut(int cyc_lut) { return (int)((unsigned)cyc_lut >> 16) - 1; }
+__host__ __device__ __forceinline__ int ev2g_line_pack(int cycles, int lut) { return (cycles & 0xffff) | (int)((unsigned)(lut + 1) << 16); }
+
+// The other [E*P]- / [E*C]-shaped state arrays live in ONE allocation of equal slices (slice = max(E*P, E*C) * 8 bytes), in this order;
+// likewise {usage, potential, overload} histories and the two per-session result arrays.  Every kernel keeps using the individual pointers
+// below; the fast-path kernel derives them from the slab base with scalar adds (ev2g_step_wave.h).
+enum { EV2G_PS_PENERGY = 0, EV2G_PS_PCURRENT, EV2G_PS_SATSUM, EV2G_PS_SERVED, EV2G_PS_N };
 
 struct DevState {  // mutable engine state, device pointers
     char *slab_port; unsigned long long slab_port_slice;   // EV2G_PS_* slices, bytes per slice
     double *slab_hist;   // usage_hist | pot_hist | over_hist   ([T,E] each when R == 1)
     double *slab_sess;   // sess_final_cap | sess_abs_e         ([S] each)
-    double *cap, *tot_e, *prev_power;  // [E*P] EV.current_capacity / total_energy_exchanged / previous_power
-    double *bcap, *potc;               // [E*P] battery_capacity and charge-power-potential term of the attached EV (v2)
-    int2 *win;                         // [E*P] {t_arr, t_dep} of the attached-or-next session (INT_MAX = none)
-    int2 *sc;                          // [E*P] {session index, charging_cycles}
+    PortLine *line;                    // [E*P] per-port dynamic state (above)
     double *cs_sat_sum;                // [E*C] EV_Charger.total_user_satisfaction
     int *cs_served;                    // [E*C] EV_Charger.total_evs_served
     double *cs_profits, *cs_e_ch, *cs_e_dis;  // [E*C] (EV2G_FLAG_LOG_CS_HISTORY) else nullptr
@@ -127,10 +138,8 @@ struct DevState {  // mutable engine state, device pointers
     double *soc_log;                   // [E,T,P] (EV2G_FLAG_LOG_SOC; env-major blocks, time-major inside: the step kernel's writes of one env-step are
                                        // contiguous and the statistics kernel reads an env's block with neighbouring sectors; a PORT-major log made
                                        // the statistics kernel 20 % faster and the step kernel 13 % slower) capacity before each EV.step, negated when the step was inactive
-    double *abs_e;                     // [E*P]  (flag) EV.abs_total_energy_exchanged of the attached session
     double *sess_abs_e;                // [S]    (flag) the same, frozen at departure
     double *port_energy, *port_current;  // [E*P] EV.current_energy / actual_current of the last step
-    int *port_lut;                       // [E*P] efficiency-table id of the attached EV (-1: scalar efficiencies); fast path only
     unsigned long long *dbg;             // [n_groups*8] phase timing (EV2G_PHASE_TIMING builds only), else nullptr
 };
 
@@ -515,11 +524,11 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_reset_kernel(DevScn s, DevSta
         const long long gs = (long long)ev2g_scn(e, scn_off, s.M) * P + q;   // this env's scenario for the coming episode
         const int2 w = s.port_first_win[gs];
         const int first = s.port_first[gs];
-        st.win[g] = w;
-        st.sc[g] = make_int2(first, 0);
-        st.cap[g] = 0.0;
-        st.tot_e[g] = 0.0;
-        st.prev_power[g] = 0.0;
+        st.line[g].ta = w.x; st.line[g].td = w.y;
+        st.line[g].ss = first; st.line[g].cyc_lut = 0;
+        st.line[g].cap = 0.0;
+        st.line[g].tot = 0.0;
+        st.line[g].prev = 0.0;
         st.port_energy[g] = 0.0;
         st.port_current[g] = 0.0;
         if (obs) {
@@ -601,8 +610,8 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 const int el = idx / P, q = idx - el * P;
                 const long long g = (long long)e0 * P + idx;
                 const long long gs = (long long)ev2g_scn(e0 + el, off, s.M) * P + q;
-                st.win[g] = s.port_first_win[gs];
-                st.sc[g] = make_int2(s.port_first[gs], 0);
+                { const int2 w0 = s.port_first_win[gs]; st.line[g].ta = w0.x; st.line[g].td = w0.y; }
+                st.line[g].ss = s.port_first[gs]; st.line[g].cyc_lut = 0;
                 st.port_energy[g] = 0.0;
                 st.port_current[g] = 0.0;
             }
@@ -630,7 +639,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
             for (int idx = tid; idx < N; idx += EV2G_BLOCK) {
                 const int el = idx / P, q = idx - el * P;
                 const int e = e0 + el;
-                const int2 w = st.win[(long long)e * P + q];
+                const int2 w = make_int2(st.line[(long long)e * P + q].ta, st.line[(long long)e * P + q].td);
                 const bool occ = (w.x <= t) && (t <= w.y);
                 amask[idx] = occ ? ev2g_action(io, xt.act32, a_off, (long long)e * P + s.slot_port[q]) : 0.0;
                 if (s.het && mask) mask[(long long)e * P + q] = 0;   // entries are OR-ed below: two ports can share one (ev2gym_env.py:452-457)
@@ -646,7 +655,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
             const long long g = (long long)e * P + q;
             const int cs = s.slot_cs[q];
             const int pref = s.slot_port[q];
-            int2 w = st.win[g];
+            int2 w = make_int2(st.line[g].ta, st.line[g].td);
             const bool occ = (w.x <= t) && (t <= w.y);
             double a;
             if (npc == 1) {     // ev_charger.py:143-149 with one port: a/a
@@ -667,10 +676,10 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
             int ss = -1;
             if (occ) {
                 const double x = rnd5(a);
-                int2 sc = st.sc[g];
+                int2 sc = make_int2(st.line[g].ss, ev2g_line_cycles(st.line[g].cyc_lut));
                 ss = sc.x;
-                cap = st.cap[g];
-                tot_e = st.tot_e[g];
+                cap = st.line[g].cap;
+                tot_e = st.line[g].tot;
                 const double cap_before = cap;
                 if (x != 0.0) {
                     double amps;
@@ -682,7 +691,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                         amps = x * s.cs_dmax_abs[cs];
                         if (amps > s.cs_dmin[cs] - 0.01) amps = s.cs_dmin[cs];
                     }
-                    double prev_power = st.prev_power[g];
+                    double prev_power = st.line[g].prev;
                     int cycles = sc.y;
                     EvOut o = ev_step(s, ss, cs, amps, ph, cap, tot_e, prev_power, cycles);
                     energy = o.energy;
@@ -692,17 +701,17 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                     if (x > 0.0) { profit = ae * s.price_ch[(long long)scn * T + t]; e_ch = ae; }
                     else         { profit = ae * s.price_dis[(long long)scn * T + t]; e_dis = ae; }
                     if (o.active) {
-                        st.cap[g] = cap;
-                        st.tot_e[g] = tot_e;
-                        st.prev_power[g] = prev_power;
-                        if (cycles != sc.y) st.sc[g] = make_int2(ss, cycles);
+                        st.line[g].cap = cap;
+                        st.line[g].tot = tot_e;
+                        st.line[g].prev = prev_power;
+                        if (cycles != sc.y) st.line[g].cyc_lut = ev2g_line_pack(cycles, s.ss_lut[ss]);
                     }
                 }
                 st.port_energy[g] = energy;
                 st.port_current[g] = current;
                 if (st.soc_log) {  // historic_soc / active_steps (ev.py:156,162,185) and abs_total_energy_exchanged (:180)
                     st.soc_log[((long long)e * T + t) * P + q] = (current != 0.0) ? cap_before : -cap_before;
-                    if (energy != 0.0) st.abs_e[g] += fabs(energy);
+                    if (energy != 0.0) st.line[g].abse += fabs(energy);
                 }
                 // departure (ev_charger.py:209-229, ev.py:191-214)
                 if (t >= w.y) {
@@ -718,23 +727,25 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                         atomicAdd(&st.cs_sat_sum[gc], score);
                     }
                     st.sess_final_cap[ss] = cap;
-                    if (st.soc_log) st.sess_abs_e[ss] = st.abs_e[g];
+                    if (st.soc_log) st.sess_abs_e[ss] = st.line[g].abse;
                     w = make_int2(s.ss_ntarr[ss], s.ss_ntdep[ss]);
                     ss = (w.x != EV2G_INT_MAX) ? ss + 1 : -1;
-                    st.win[g] = w;
-                    st.sc[g] = make_int2(ss, 0);
+                    st.line[g].ta = w.x; st.line[g].td = w.y;
+                    st.line[g].ss = ss; st.line[g].cyc_lut = 0;
                 }
             }
             // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
             bool occ_after = (w.x <= sstep) && (sstep <= w.y);
             if (w.x == sstep) {
-                if (ss < 0) ss = st.sc[g].x;
+                if (ss < 0) ss = st.line[g].ss;
                 cap = s.ss_cap0[ss];
                 tot_e = 0.0;
-                st.cap[g] = cap;
-                st.tot_e[g] = 0.0;
-                st.prev_power[g] = 0.0;
-                if (st.soc_log) st.abs_e[g] = 0.0;
+                st.line[g].cap = cap;
+                st.line[g].tot = 0.0;
+                st.line[g].prev = 0.0;
+                if (st.soc_log) st.line[g].abse = 0.0;
+                st.line[g].cyc_lut = ev2g_line_pack(0, s.ss_lut[ss]);   // (the line stays complete whichever kernel wrote it)
+                st.line[g].bcap = s.ss_B[ss]; st.line[g].potc = s.rec[ss].potc;
                 st.port_energy[g] = 0.0;
                 st.port_current[g] = 0.0;
             }
@@ -971,6 +982,35 @@ __global__ void ev2g_build_step_table_kernel(DevScn s, double *__restrict__ tab,
     }
 }
 
+// Occupancy does not depend on the actions (ev.py:191-202; arrivals are fixed when the scenario is drawn): which ports hold an EV during step t,
+// and which receive one at its end, is a property of (scenario, step).  One wavefront per scenario (P <= 64: the fast path), a lane per port
+// slot, walks the port's session chain exactly like the step kernels do and leaves the two 64-bit masks in slots 6 and 7 of the step table --
+// what a single-step launch reads first, so that it fetches state lines only for those ports (ev2g_step_wave.h, prologue).
+__global__ void __launch_bounds__(64) ev2g_build_occ_mask_kernel(DevScn s, double *__restrict__ step_tab, int m0, int m1) {
+    const int lane = threadIdx.x, P = s.P, T = s.T;
+    for (int m = m0 + blockIdx.x; m < m1; m += gridDim.x) {
+        int ta = EV2G_INT_MAX, td = -1, ss = -1;
+        if (lane < P) {
+            const long long gs = (long long)m * P + lane;
+            const int2 w = s.port_first_win[gs];
+            ta = w.x; td = w.y; ss = s.port_first[gs];
+        }
+        for (int t = 0; t < T; t++) {
+            const bool occ = (ta <= t) && (t <= td);
+            if (occ && t >= td) {   // departure during step t: the window of the port's next session (ev_charger.py:209-229)
+                const SessTail tl = s.tail[ss];
+                ta = tl.nt_arr; td = tl.nt_dep;
+                ss = (ta != EV2G_INT_MAX) ? ss + 1 : -1;
+            }
+            const unsigned long long m_occ = __ballot(occ), m_arr = __ballot(ta == t + 1);
+            if (lane == 0) {
+                double *o = step_tab + ((long long)m * T + t) * 8;
+                o[6] = __longlong_as_double((long long)m_occ); o[7] = __longlong_as_double((long long)m_arr);
+            }
+        }
+    }
+}
+
 // counter-based uniform generator (splitmix64 of (seed, index)); identical on host (ev2g_host_uniform)
 __host__ __device__ inline double ev2g_u01(uint64_t seed, uint64_t i) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
@@ -1003,8 +1043,8 @@ __device__ __forceinline__ void port_sessions(const DevScn &s, const DevState &s
     last = first;
     attached = false;
     if (first < 0) return;
-    const int2 w = st.win[g];
-    const int cur = st.sc[g].x;  // attached-or-next session, -1 when the port's list is exhausted
+    const int2 w = make_int2(st.line[g].ta, st.line[g].td);
+    const int cur = st.line[g].ss;  // attached-or-next session, -1 when the port's list is exhausted
     if (cur < 0) {
         last = s.port_end[gs];
     } else {
@@ -1103,7 +1143,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
         port_sessions(s, st, g, gs, cur_step, first, last, attached);
         if (k >= first && k < last) {   // spawned so far
             const bool live = attached && k == last - 1;
-            const double capk = live ? st.cap[g] : st.sess_final_cap[k];
+            const double capk = live ? st.line[g].cap : st.sess_final_cap[k];
             const double v = capk / ss_afap[k] * 100.0;
             sum += v;
             mn = fmin(mn, v);
@@ -1182,7 +1222,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                 deg_cal += alpha * 0.75 * T_sim / k_age;
                 const double v_half = v_min + kk * 0.5;
                 const double beta = z0 * (v_half - z1) * (v_half - z1) + z2 + z3 * delta_DoD;
-                const double abs_e = live ? st.abs_e[g] : st.sess_abs_e[k];
+                const double abs_e = live ? st.line[g].abse : st.sess_abs_e[k];
                 const double Q_sim = (abs_e / b_cap_kwh) * b_cap_ah;
                 deg_cyc += beta * 0.5 * Q_sim / k_qacc;
             }
@@ -1205,7 +1245,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                 bool attached;
                 port_sessions(s, st, g, gs, cur_step, first, last, attached);
                 if (k >= first && k < last) {
-                    const double capk = (attached && k == last - 1) ? st.cap[g] : st.sess_final_cap[k];
+                    const double capk = (attached && k == last - 1) ? st.line[g].cap : st.sess_final_cap[k];
                     const double v = capk / ss_afap[k] * 100.0 - mean;
                     var += v * v;
                 }

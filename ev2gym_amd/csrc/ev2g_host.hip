@@ -276,6 +276,9 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
             return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: batch too large for 32-bit element offsets "
                                          "(need M*P, M*D, M*R*(T+1)*40, T*M*C < 2^31): split it over more handles / GPUs");
     }
+    if (T > 65535 || b->n_lut > 65534)
+        return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: simulation_length and the number of efficiency tables must stay below 65536 (a port's state line "
+                                     "packs charging_cycles and the table id into 16 bits each)");
     for (int c = 0; c < C; c++) {
         if (b->cs_transformer[c] < 0 || b->cs_transformer[c] >= R)
             return fail(h, EV2G_ERR_ARG, "ev2g_load_scenarios: cs_transformer out of range");
@@ -674,6 +677,8 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         const int nb = (int)std::min<size_t>(((size_t)M * T + 255) / 256, 4096);
         hipLaunchKernelGGL(ev2g_build_step_table_kernel, dim3(nb), dim3(256), 0, h->stream, s, d_step_tab, 0, M);
         HIPCHK(h, hipGetLastError());
+        hipLaunchKernelGGL(ev2g_build_occ_mask_kernel, dim3(std::min(M, 8192)), dim3(64), 0, h->stream, s, d_step_tab, 0, M);   // slots 6, 7
+        HIPCHK(h, hipGetLastError());
         h->d_step_tab = d_step_tab;
     }
     double *d_head_tab = nullptr;
@@ -694,17 +699,15 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     auto &sp = h->st_allocs;
     const size_t EP = (size_t)E * P, EC = (size_t)E * C;
 #define AL(field, n) if ((rc = dalloc(h, sp, (size_t)(n), &st.field))) return rc;
-    {   // per-port state: one slab, EV2G_PS_* slices
+    {   // per-port state: one 64-byte line per port + one slab of EV2G_PS_* slices for what is not on the step's path
+        AL(line, EP)
+        HIPCHK(h, hipMemsetAsync(st.line, 0, EP * sizeof(PortLine), h->stream));
         const size_t slice = std::max(EP, EC) * 8;
         if ((rc = dalloc(h, sp, slice * EV2G_PS_N, &st.slab_port))) return rc;
         st.slab_port_slice = slice;
 #define SLICE(T, k) ((T *)(st.slab_port + slice * (size_t)(k)))
-        st.cap = SLICE(double, EV2G_PS_CAP); st.tot_e = SLICE(double, EV2G_PS_TOT); st.prev_power = SLICE(double, EV2G_PS_PREV);
-        st.bcap = SLICE(double, EV2G_PS_BCAP); st.potc = SLICE(double, EV2G_PS_POTC);
         st.port_energy = SLICE(double, EV2G_PS_PENERGY); st.port_current = SLICE(double, EV2G_PS_PCURRENT);
-        st.cs_sat_sum = SLICE(double, EV2G_PS_SATSUM); st.win = SLICE(int2, EV2G_PS_WIN); st.sc = SLICE(int2, EV2G_PS_SC);
-        st.cs_served = SLICE(int, EV2G_PS_SERVED); st.port_lut = SLICE(int, EV2G_PS_LUT);
-        if (h->cfg.flags & EV2G_FLAG_LOG_SOC) st.abs_e = SLICE(double, EV2G_PS_ABSE);
+        st.cs_sat_sum = SLICE(double, EV2G_PS_SATSUM); st.cs_served = SLICE(int, EV2G_PS_SERVED);
 #undef SLICE
     }
     if (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) {
@@ -820,7 +823,7 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         const V2P *pp = (const V2P *)h->d_v2p;
         const DevState &st = h->st;
         const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
-                          st.env_acc, s.cs_pack};
+                          st.env_acc, s.cs_pack, (char *)st.line, h->d_step_tab};
         // every float64 output present, no extras, no charger histories: the specialisation without their checks (not for the run-time rewards)
         // ... in two flavours: float64 actions in / float64 observations out (a loop that consumes them, the benchmark), or the policy
         // network's hand-over, float32 actions in / float32 observations out and no float64 observation (ev2g_rollout)
@@ -1322,13 +1325,10 @@ int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *v) {
     std::vector<int2> win(P), sc(P);
     const size_t off = (size_t)env * P;
 #define D2H(dst, src, n, type) HIPCHK(h, hipMemcpyAsync((dst), (src), sizeof(type) * (size_t)(n), hipMemcpyDeviceToHost, h->stream))
-    D2H(cap.data(), st.cap + off, P, double);
-    D2H(tot.data(), st.tot_e + off, P, double);
-    D2H(prev.data(), st.prev_power + off, P, double);
+    std::vector<PortLine> lines(P);
+    D2H(lines.data(), st.line + off, P, PortLine);
     D2H(pe.data(), st.port_energy + off, P, double);
     D2H(pc.data(), st.port_current + off, P, double);
-    D2H(win.data(), st.win + off, P, int2);
-    D2H(sc.data(), st.sc + off, P, int2);
     std::vector<double> trp(R), csv;
     D2H(trp.data(), st.tr_power_now + (size_t)env * R, R, double);
     const bool log_cs = st.cs_profits != nullptr;
@@ -1350,6 +1350,10 @@ int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *v) {
                                sizeof(double) * R, T, hipMemcpyDeviceToHost, h->stream));
 #undef D2H
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int q = 0; q < P; q++) {
+        const PortLine &l = lines[q];
+        cap[q] = l.cap; tot[q] = l.tot; prev[q] = l.prev; win[q] = make_int2(l.ta, l.td); sc[q] = make_int2(l.ss, ev2g_line_cycles(l.cyc_lut));
+    }
     const int t = h->current_step;
     v->current_step = t;
     v->n_ports = P; v->n_chargers = C; v->n_transformers = R; v->n_steps = T;

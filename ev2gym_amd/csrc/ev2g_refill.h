@@ -402,7 +402,21 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
             double *o8 = a.step_tab + ((size_t)ms * T + t) * 8;
             const size_t i = (size_t)ms * T + t;
             o8[0] = s.price_ch[i]; o8[1] = s.price_dis[i]; o8[2] = s.tr_base[i]; o8[3] = s.tr_maxp[i]; o8[4] = s.tr_minp[i];
-            o8[5] = s.setpoint[i]; o8[6] = 0.0; o8[7] = 0.0;
+            o8[5] = s.setpoint[i];
+        }
+        // slots 6, 7: the scenario's occupancy / arrival masks of every step -- ev2g_build_occ_mask_kernel's walk (ev2g_device.h), a lane per port slot,
+        // over the session windows this wavefront holds in LDS
+        int cur = 0, end = 0;
+        if (lane < P) { const int p = s.slot_port[lane]; cur = l_pbase[p]; end = cur + max(0, min(l_pcnt[p], cap - cur)); }
+        int ta = (cur < end) ? l_ta[cur] : EV2G_INT_MAX, td = (cur < end) ? l_td[cur] : EV2G_INT_MAX;
+        for (int t = 0; t < T; t++) {
+            const bool occ = (ta <= t) && (t <= td);
+            if (occ && t >= td) { cur++; ta = (cur < end) ? l_ta[cur] : EV2G_INT_MAX; td = (cur < end) ? l_td[cur] : EV2G_INT_MAX; }
+            const unsigned long long m_occ = __ballot(occ), m_arr = __ballot(ta == t + 1);
+            if (lane == 0) {
+                double *o8 = a.step_tab + ((size_t)ms * T + t) * 8;
+                o8[6] = __longlong_as_double((long long)m_occ); o8[7] = __longlong_as_double((long long)m_arr);
+            }
         }
     }
     RF_STAMP(6)

@@ -173,15 +173,14 @@ struct V2P {
     EV2G_GP(double) slab_hist; EV2G_GP(double) slab_sess; unsigned long long hist_slice, sess_slice;   // bytes
     EV2G_GP(const double) head_tab;   // [E, T+1, NH] observation head rows (fast path only, ev2g_build_head_table_kernel)
     EV2G_GP(const SessRec) rec; EV2G_GP(const SessTail) tail; EV2G_GP(const int) ss_lut;
-    EV2G_GP(double) cap; EV2G_GP(double) tot_e; EV2G_GP(double) prev_power; EV2G_GP(double) bcap; EV2G_GP(double) potc;
-    EV2G_GP(int2) win; EV2G_GP(int2) sc;
+    EV2G_GP(PortLine) line;
     EV2G_GP(double) cs_sat_sum; EV2G_GP(int) cs_served;
     EV2G_GP(double) cs_profits; EV2G_GP(double) cs_e_ch; EV2G_GP(double) cs_e_dis;
     EV2G_GP(double) cs_power_hist; EV2G_GP(double) cs_cur_hist; EV2G_GP(double) cs_power_now; EV2G_GP(double) cs_cur_now;
     EV2G_GP(double) env_acc; EV2G_GP(int) env_fault;
     EV2G_GP(double) usage_hist; EV2G_GP(double) pot_hist; EV2G_GP(double) over_hist; EV2G_GP(double) tr_power_now;
-    EV2G_GP(double) sess_final_cap; EV2G_GP(double) port_energy; EV2G_GP(double) port_current; EV2G_GP(int) port_lut;
-    EV2G_GP(double) soc_log; EV2G_GP(double) abs_e; EV2G_GP(double) sess_abs_e;
+    EV2G_GP(double) sess_final_cap; EV2G_GP(double) port_energy; EV2G_GP(double) port_current;
+    EV2G_GP(double) soc_log; EV2G_GP(double) sess_abs_e;
     EV2G_GP(unsigned long long) dbg;
     // StepExtras (ev2g_set_step_extras), refreshed in place when they change
     EV2G_GP(double) x_cost; long long x_c_stride;
@@ -208,10 +207,10 @@ inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
     CPS(cs_imax) CPS(cs_imin) CPS(cs_dmin) CPS(cs_dmax_abs) CPS(cs_maxp) CPS(cs_minp)
     CPS(price_ch) CPS(price_dis) CPS(setpoint) CPS(tr_infl) CPS(tr_solar) CPS(tr_base) CPS(tr_maxp) CPS(tr_minp)
     CPS(win_tab) CPS(lut) CPS(rec) CPS(tail) CPS(ss_lut)
-    CPT(cap) CPT(tot_e) CPT(prev_power) CPT(bcap) CPT(potc) CPT(win) CPT(sc) CPT(cs_sat_sum) CPT(cs_served)
+    CPT(line) CPT(cs_sat_sum) CPT(cs_served)
     CPT(cs_profits) CPT(cs_e_ch) CPT(cs_e_dis) CPT(cs_power_hist) CPT(cs_cur_hist) CPT(cs_power_now) CPT(cs_cur_now)
     CPT(env_acc) CPT(env_fault) CPT(usage_hist) CPT(pot_hist) CPT(over_hist) CPT(tr_power_now)
-    CPT(sess_final_cap) CPT(port_energy) CPT(port_current) CPT(port_lut) CPT(soc_log) CPT(abs_e) CPT(sess_abs_e) CPT(dbg)
+    CPT(sess_final_cap) CPT(port_energy) CPT(port_current) CPT(soc_log) CPT(sess_abs_e) CPT(dbg)
 #undef CPS
 #undef CPT
 }
@@ -283,13 +282,13 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     const double c_maxp = S->cs_maxp[cs], c_minp = S->cs_minp[cs];
     int t = t0;
     if (valid) {
-        const int2 w = S->win[g];
-        const int2 sc = S->sc[g];
-        s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = sc.x; s_cyc[tid] = sc.y; s_dirty[tid] = 0;
+        const EV2G_GP(PortLine) ln = S->line + g;   // this port's 64-byte state line (ev2g_device.h)
+        const int2 w = make_int2(ln->ta, ln->td);
+        s_ta[tid] = w.x; s_td[tid] = w.y; s_ss[tid] = ln->ss; s_cyc[tid] = ev2g_line_cycles(ln->cyc_lut); s_dirty[tid] = 0;
         if (w.x <= t && t <= w.y) {
-            s_cap[tid] = S->cap[g]; s_tot[tid] = S->tot_e[g]; s_prev[tid] = S->prev_power[g];
-            s_bcap[tid] = S->bcap[g]; s_potc[tid] = S->potc[g];
-            s_abse[tid] = log_soc ? S->abs_e[g] : 0.0;
+            s_cap[tid] = ln->cap; s_tot[tid] = ln->tot; s_prev[tid] = ln->prev;
+            s_bcap[tid] = ln->bcap; s_potc[tid] = ln->potc;
+            s_abse[tid] = log_soc ? ln->abse : 0.0;
         } else {
             s_abse[tid] = 0.0;
             s_cap[tid] = 0.0; s_tot[tid] = 0.0; s_prev[tid] = 0.0; s_bcap[tid] = 1.0; s_potc[tid] = 0.0;
@@ -593,8 +592,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
                 const double potc = pf_rc;   // v * min(pacmax*1000/v, charger max current) / 1000 (utils.py:773-777), evaluated when the session was loaded
                 s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0; s_bcap[tid_l] = B; s_potc[tid_l] = potc;
                 s_abse[tid_l] = 0.0;
-                S->bcap[g_l] = B;
-                S->potc[g_l] = potc;
+                S->line[g_l].bcap = B;
+                S->line[g_l].potc = potc;
                 S->port_energy[g_l] = 0.0;
                 S->port_current[g_l] = 0.0;
                 s_dirty[tid_l] |= 1;
@@ -861,9 +860,13 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     __syncthreads();
     if (valid) {
         const int d = s_dirty[tid];
-        if (d & 2) S->win[g] = make_int2(s_ta[tid], s_td[tid]);
-        if (d) S->sc[g] = make_int2(s_ss[tid], s_cyc[tid]);
-        if (d & 1) { S->cap[g] = s_cap[tid]; S->tot_e[g] = s_tot[tid]; S->prev_power[g] = s_prev[tid]; if (log_soc) S->abs_e[g] = s_abse[tid]; }
+        EV2G_GP(PortLine) ln = S->line + g;
+        if (d & 2) { ln->ta = s_ta[tid]; ln->td = s_td[tid]; }
+        if (d) {   // the line carries the efficiency-table id of the attached EV next to its cycle count (the fast path reads it from there)
+            const int ssd = s_ss[tid];
+            ln->ss = ssd; ln->cyc_lut = ev2g_line_pack(s_cyc[tid], ssd >= 0 ? S->ss_lut[ssd] : -1);
+        }
+        if (d & 1) { ln->cap = s_cap[tid]; ln->tot = s_tot[tid]; ln->prev = s_prev[tid]; if (log_soc) ln->abse = s_abse[tid]; }
     }
 }
 #undef V2C

@@ -75,6 +75,8 @@ struct WaveArgs {
     double *slab_hist; unsigned long long hist_slice;
     double *env_acc;
     const double *cs_pack;   // [C][6] imax, |dmax|, imin, dmin, max power, min power
+    char *lines;             // [E*P] PortLine
+    const double *step_tab;  // [M, T, 8]; slots 6, 7: the scenario's occupancy / arrival masks of the step
 };
 
 // IO32: the actions are float32 (StepIO::act32) -- the policy-network interface; float32 observations (StepIO::obs32) are
@@ -148,20 +150,27 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     int t = t0;
     const bool head = valid && q == 0;   // one lane per env: env-level scalars
     const int elg = wv * EPW + elw;      // env inside the workgroup
-    // ---- launch prologue.  A single-step launch (the RL loop with a policy between steps) pays it every step, with
-    // cold caches: occupancy windows, charger constants, the first action and the env accumulators are fetched in one
-    // round trip (unconditional, clamped loads), the per-EV state in a second one, only where an EV is attached.
+    // ---- launch prologue.  A single-step launch (the RL loop with a policy between steps) pays it every step, with cold caches.
+    // Round trip 1: what does not depend on data -- charger constants, the first action, the env accumulators and, for a single-step launch,
+    // the scenario's occupancy / arrival masks of this step (step table slots 6, 7: occupancy does not depend on the actions); for a longer
+    // launch the head chunk of every port's state line instead.  Round trip 2: the state lines (PortLine, 64 bytes = one sector) of the
+    // ports that hold an EV -- in a single-step launch also the head chunk, and only for ports that hold an EV or receive one this step.
     double c_imax, c_dmaxabs, a_next;
     // FULL kernels keep what only the port's own lane touches -- its occupancy window, the attached EV's battery size and potential
     // term -- in registers instead of LDS (no in-launch reset rewrites them from outside): six LDS instructions a step less
     int r_ta = EV2G_INT_MAX, r_td = -1;
     double r_bcap = 1.0, r_potc = 0.0;
     double r_rb = 1.0;   // RN(1 / battery size) of the attached EV: the observation's cap / B goes through it (ev2g_fdiv2) in the full kernels
+    const unsigned l64 = (unsigned)g * (unsigned)sizeof(PortLine);   // this port's state line
+    static_assert(sizeof(PortLine) == 64 && offsetof(PortLine, cap) == 16 && offsetof(PortLine, prev) == 32 && offsetof(PortLine, bcap) == 48, "PortLine layout");
     {
-        const unsigned g8 = (unsigned)g * 8u, c8 = (unsigned)cs * 8u, cp8 = (unsigned)min(tid, P - 1) * 8u;
+        const unsigned c8 = (unsigned)cs * 8u, cp8 = (unsigned)min(tid, P - 1) * 8u;
         const unsigned ec = (unsigned)(valid ? e : e0);
-        i2v w = ldg32<i2v>(PA(EV2G_PS_WIN), g8), sc = ldg32<i2v>(PA(EV2G_PS_SC), g8);
-        int lut0 = ldg32<int>(PA(EV2G_PS_LUT), g8 >> 1);
+        const bool by_mask = (k_steps == 1) && (t < T);   // (uniform)
+        i4v hd = {EV2G_INT_MAX, -1, -1, 0};                // {t_arr, t_dep, session, cycles | table id + 1}
+        d2v mk = {0.0, 0.0};
+        if (by_mask) mk = ldg32<d2v>(wa.step_tab, (unsigned)(ev2g_scn((int)ec, off, M) * T + t) * 64u + 48u);
+        else hd = ldg32<i4v>(wa.lines, l64);
         const d2v k_max = ldg32<d2v>(wa.cs_pack, c8 * 6u);   // (imax, |dmax|) of this lane's charger
         d2v k_min = {0.0, 0.0}, k_pow = {0.0, 0.0};            // gates and clamps, staged in LDS by the first P lanes of the workgroup
         if (tid < 64) { k_min = ldg32<d2v>(wa.cs_pack, cp8 * 6u + 16u); k_pow = ldg32<d2v>(wa.cs_pack, cp8 * 6u + 32u); }   // (wavefront 0 only)
@@ -173,7 +182,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         d2v acc01 = ldg32<d2v>(env_acc, ec * 64u), acc23 = ldg32<d2v>(env_acc, ec * 64u + 16u);
         double acc4 = ldg32<double>(env_acc, ec * 64u + 32u);
         d2v k_max_w = k_max;
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w), "+v"(sc), "+v"(lut0), "+v"(k_max_w), "+v"(k_min), "+v"(k_pow),
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(hd), "+v"(mk), "+v"(k_max_w), "+v"(k_min), "+v"(k_pow),
                      "+v"(a_next), "+v"(l_pot), "+v"(l_pot2), "+v"(acc01), "+v"(acc23), "+v"(acc4));
         c_imax = k_max_w.x; c_dmaxabs = k_max_w.y;
         if (tid < P) {
@@ -181,23 +190,24 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             s_cst[2 * 64 + tid] = k_pow.x; s_cst[3 * 64 + tid] = k_pow.y;
         }
         if (valid) {
-            r_ta = w.x; r_td = w.y;
-            if (!FULL) { s_ta[tid] = w.x; s_td[tid] = w.y; }
-            s_ss[tid] = sc.x; s_cyc[tid] = sc.y;
-            // s_dirty: bits 0,1 = what the epilogue must write back; bits 8.. = 1 + efficiency-table id of the attached EV,
+            bool body;   // an EV is attached in the launch's first step: the rest of the line is needed
+            if (by_mask) {
+                const unsigned long long m_occ = (unsigned long long)__double_as_longlong(mk.x), m_arr = (unsigned long long)__double_as_longlong(mk.y);
+                body = (m_occ >> q) & 1ull;
+                if (body || ((m_arr >> q) & 1ull)) hd = ldg32<i4v>(wa.lines, l64);   // (a port without either keeps the defaults: no event can touch it this step)
+            } else body = (hd.x <= t) && (t <= hd.y);
+            d2v b1 = {0.0, 0.0}, b2 = {0.0, 0.0}, b3 = {1.0, 0.0};
+            if (body) { b1 = ldg32<d2v>(wa.lines, l64 + 16u); b2 = ldg32<d2v>(wa.lines, l64 + 32u); b3 = ldg32<d2v>(wa.lines, l64 + 48u); }
+            r_ta = hd.x; r_td = hd.y;
+            if (!FULL) { s_ta[tid] = hd.x; s_td[tid] = hd.y; }
+            s_ss[tid] = hd.z; s_cyc[tid] = ev2g_line_cycles(hd.w);
+            // s_dirty: bits 0,1 = what the epilogue must write back; bits 8..23 = 1 + efficiency-table id of the attached EV,
             // so that the battery maths can issue the table look-up together with (not behind) the session-record load
-            s_dirty[tid] = (lut0 + 1) << 8;
-            // the per-EV state is fetched only where an EV is attached (a launch starts with cold caches: bytes count)
-            if (w.x <= t && t <= w.y) {
-                s_cap[tid] = ldg32<double>(PA(EV2G_PS_CAP), g8); s_tot[tid] = ldg32<double>(PA(EV2G_PS_TOT), g8);
-                s_prev[tid] = ldg32<double>(PA(EV2G_PS_PREV), g8);
-                r_bcap = ldg32<double>(PA(EV2G_PS_BCAP), g8); r_potc = ldg32<double>(PA(EV2G_PS_POTC), g8);
-                if (FULL) r_rb = 1.0 / r_bcap;
-                if (!FULL) { s_bcap[tid] = r_bcap; s_potc[tid] = r_potc; }
-                s_abse[tid] = log_soc ? ldg32<double>(PA(EV2G_PS_ABSE), g8) : 0.0;
-            } else {
-                s_cap[tid] = 0.0; s_tot[tid] = 0.0; s_prev[tid] = 0.0; s_bcap[tid] = 1.0; s_potc[tid] = 0.0; s_abse[tid] = 0.0;
-            }
+            s_dirty[tid] = (int)((unsigned)hd.w >> 16) << 8;
+            s_cap[tid] = b1.x; s_tot[tid] = b1.y; s_prev[tid] = b2.x; s_abse[tid] = log_soc ? b2.y : 0.0;
+            r_bcap = b3.x; r_potc = b3.y;
+            if (FULL) { if (body) r_rb = 1.0 / r_bcap; }
+            else { s_bcap[tid] = r_bcap; s_potc[tid] = r_potc; }
         }
         if (head) {   // episode accumulators (continued from global memory) and charge_power_potential[t], in LDS
             double *ea = eacc + elg * 7;
@@ -382,7 +392,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 else if (i >= nchp) h = items[NS - 1 - (i - nchp)];
                 if (h >= 0) {
                     const double amps_h = s_amps[h];
-                    const int lut_id = (s_dirty[h] >> 8) - 1;
+                    const int lut_id = ((s_dirty[h] >> 8) & 0xffff) - 1;
                     // table entry and session record are independent loads: one memory round trip, not two.  The look-up
                     // is unconditional (clamped index); whether it applies is decided where it is used.
                     const int li = (lut_id >= 0) ? ev_lut_index(lut_id, amps_h) : -1;
@@ -498,9 +508,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 s_abse[tid_l] = 0.0;
                 b_bcap = B; b_potc = potc; b_tot = 0.0;
                 const int lut_new = pf_lut;
-                stg32<int>(PA(EV2G_PS_LUT), g8 >> 1, lut_new);
-                stg32<double>(PA(EV2G_PS_BCAP), g8, B);
-                stg32<double>(PA(EV2G_PS_POTC), g8, potc);
+                stg32<d2v>(wa.lines, l64 + 48u, (d2v){B, potc});   // (the table id travels in s_dirty and reaches the line's head chunk in the epilogue)
                 stg32<double>(PA(EV2G_PS_PENERGY), g8, 0.0);
                 stg32<double>(PA(EV2G_PS_PCURRENT), g8, 0.0);
                 s_dirty[tid_l] = (s_dirty[tid_l] & 3) | 1 | ((lut_new + 1) << 8);
@@ -748,11 +756,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     if (valid) {
         const int d = s_dirty[tid];
         const unsigned g8 = (unsigned)g * 8u;
-        if (d & 2) stg32<i2v>(PA(EV2G_PS_WIN), g8, FULL ? (i2v){r_ta, r_td} : (i2v){s_ta[tid], s_td[tid]});
-        if (d & 3) stg32<i2v>(PA(EV2G_PS_SC), g8, (i2v){s_ss[tid], s_cyc[tid]});
+        if (d & 3) stg32<i4v>(wa.lines, l64, (i4v){FULL ? r_ta : s_ta[tid], FULL ? r_td : s_td[tid], s_ss[tid], ev2g_line_pack(s_cyc[tid], ((d >> 8) & 0xffff) - 1)});
         if (d & 1) {
-            stg32<double>(PA(EV2G_PS_CAP), g8, s_cap[tid]); stg32<double>(PA(EV2G_PS_TOT), g8, s_tot[tid]); stg32<double>(PA(EV2G_PS_PREV), g8, s_prev[tid]);
-            if (log_soc) stg32<double>(PA(EV2G_PS_ABSE), g8, s_abse[tid]);
+            stg32<d2v>(wa.lines, l64 + 16u, (d2v){s_cap[tid], s_tot[tid]});
+            stg32<d2v>(wa.lines, l64 + 32u, (d2v){s_prev[tid], s_abse[tid]});
         }
     }
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)

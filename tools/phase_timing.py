@@ -14,7 +14,12 @@ argv = sys.argv[1:]
 OUTER = "--outer" in argv
 defs = [a for a in argv if a.startswith("-D")]
 argv = [a for a in argv if a != "--outer" and not a.startswith("-D")]
-subprocess.check_call([build.hipcc()] + build.FLAGS + ["-DEV2G_PHASE_TIMING"] + (["-DEV2G_PT_OUTER"] if OUTER else []) + defs + ["-o", so, build.SRC])
+if os.environ.get("EV2G_PT_LIB"):   # a library built beforehand with the same flags (the build container cross-compiles; GPU minutes are for running)
+    so = os.path.abspath(os.environ["EV2G_PT_LIB"])
+else:
+    subprocess.check_call([build.hipcc()] + build.FLAGS + ["-DEV2G_PHASE_TIMING"] + (["-DEV2G_PT_OUTER"] if OUTER else []) + defs + ["-o", so, build.SRC])
+if os.environ.get("EV2G_PT_BUILD_ONLY"):
+    sys.exit(0)
 engine._LIB_PATH = so
 L = engine.load_library(so)
 from bench import WORKLOADS
