@@ -47,19 +47,20 @@ WORKLOADS = {
 
 
 def measured_traffic(workload, launch, steps_per_launch, envs):
-    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes (profiles/r02_hbm_traffic.json, written by
-    tools/prof_step.sh + tools/collect_evidence.py: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH doubled per
-    the gfx950 note in MI355X_MICROARCH.md), or None when this workload / launch shape was not profiled."""
-    t = None
-    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    """(bytes, source): HBM bytes per launch of the step kernel from the COMMITTED rocprofv3 PMC passes of the newest round that profiled this
+    workload / launch shape (profiles/rNN_hbm_traffic.json, written by tools/prof_step.sh + tools/collect_evidence.py: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs, FETCH doubled per the gfx950 note in MI355X_MICROARCH.md) -- a stored figure of the same
+    kernel on the same workload, NOT a measurement of this run (counters need rocprofv3 around the process): `roofline.traffic_source` names
+    the file.  (None, None) when the shape was not profiled."""
+    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))[workload][launch]
-            break
         except Exception:
             continue
-    if t is None or abs(t["steps_per_launch"] - steps_per_launch) > 1e-9 or envs != WORKLOADS[workload]["envs"]:
-        return None
-    return (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
+        if abs(t["steps_per_launch"] - steps_per_launch) > 1e-9 or envs != WORKLOADS[workload]["envs"]:
+            return None, None
+        return (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0, "profiles/" + name + " (rocprofv3 PMC passes of an earlier run of this workload; not re-measured here)"
+    return None, None
 
 
 def cpu_baseline(batch, rk, sk, lo, budget_s=float(os.environ.get("EV2G_BENCH_CPU_BUDGET", "12.0"))):
@@ -130,13 +131,20 @@ class RolloutLoop:
         self.eng.reset(self.obs, offset=self.offset)
 
     def episode_end(self):
-        if self.gath is None:
-            self.eng.stats(out=self.stats)
+        """Terminal statistics of the finished episode, then the reset onto the next pool window -- one kernel launch where the engine
+        offers it (ev2g_get_stats_reset), two otherwise; the asynchronous gather over the ranks is ordered behind the statistics."""
+        out = self.stats if self.gath is None else self.gath.buffer()
+        fused = getattr(self.eng, "stats_reset", None)
+        if fused is not None:
+            self.offset = (self.offset + self.E) % self.M
+            fused(out, self.obs, self.offset)
         else:
-            self.eng.stats(out=self.gath.buffer())
+            self.eng.stats(out=out)
+        if self.gath is not None:
             self.gath.launch()
         self.episodes += 1
-        self.reset()
+        if fused is None:
+            self.reset()
 
     def run(self, n_steps, persistent, timing=None):
         eng, T = self.eng, self.T
@@ -536,8 +544,9 @@ def main():
         launch_s = kern_ms / 1e3 / n_launch
         bytes_per_launch = bytes_env_step * Eg * (kern_steps / n_launch)   # (the timed launches are those of env group 0)
         achieved = bytes_per_launch / launch_s / 1e9
+        traffic, traffic_source = measured_traffic(args.workload, mode, kern_steps / n_launch, Eg)
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": measured_traffic(args.workload, mode, kern_steps / n_launch, Eg),
+                "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": eng.kernel_name, "avg_launch_us": launch_s * 1e6, "steps_per_launch": kern_steps / n_launch,
                 "algorithmic_bytes_per_env_step": bytes_env_step}
 

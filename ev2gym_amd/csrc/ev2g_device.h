@@ -117,11 +117,13 @@ __host__ __device__ __forceinline__ int ev2g_line_pack(int cycles, int lut) { re
 // The other [E*P]- / [E*C]-shaped state arrays live in ONE allocation of equal slices (slice = max(E*P, E*C) * 8 bytes), in this order;
 // likewise {usage, potential, overload} histories and the two per-session result arrays.  Every kernel keeps using the individual pointers
 // below; the fast-path kernel derives them from the slab base with scalar adds (ev2g_step_wave.h).
+// word index of row (env e, step t) of the history array [E, T, 2 + R]: + 0 usage, + 1 charge-power potential, + 2 + r overload of transformer r
+#define EV2G_HIST(e, t, T, R) (((long long)(e) * (T) + (t)) * (2 + (R)))
 enum { EV2G_PS_PENERGY = 0, EV2G_PS_PCURRENT, EV2G_PS_SATSUM, EV2G_PS_SERVED, EV2G_PS_N };
 
 struct DevState {  // mutable engine state, device pointers
     char *slab_port; unsigned long long slab_port_slice;   // EV2G_PS_* slices, bytes per slice
-    double *slab_hist;   // usage_hist | pot_hist | over_hist   ([T,E] each when R == 1)
+    double *slab_hist;   // == hist
     double *slab_sess;   // sess_final_cap | sess_abs_e         ([S] each)
     PortLine *line;                    // [E*P] per-port dynamic state (above)
     double *cs_sat_sum;                // [E*C] EV_Charger.total_user_satisfaction
@@ -131,13 +133,15 @@ struct DevState {  // mutable engine state, device pointers
     double *cs_power_now, *cs_cur_now;        // [E*C] last step (flag)
     double *env_acc;                   // [E,8] total_reward, profits, e_charged, e_discharged, emerg_violations
     int *env_fault;                    // [E]
-    double *usage_hist, *pot_hist;     // [T,E]  env.current_power_usage / charge_power_potential (time-major)
-    double *over_hist;                 // [T,E,R] env.tr_overload
+    double *hist;                      // [E, T, 2 + R] per (env, step): env.current_power_usage[t], charge_power_potential[t], tr_overload[0..R)[t] -- env-major and
+                                       // interleaved since round 4: the three values a step writes share a sector, and the statistics kernel reads an env's
+                                       // rows contiguously (time-major [T,E] arrays cost it one sector per value: 88 MB of traffic for 11 MB of data at cfg2)
     double *tr_power_now;              // [E,R]  Transformer.current_power of the last step
     double *sess_final_cap;            // [S] capacity at departure
-    double *soc_log;                   // [E,T,P] (EV2G_FLAG_LOG_SOC; env-major blocks, time-major inside: the step kernel's writes of one env-step are
-                                       // contiguous and the statistics kernel reads an env's block with neighbouring sectors; a PORT-major log made
-                                       // the statistics kernel 20 % faster and the step kernel 13 % slower) capacity before each EV.step, negated when the step was inactive
+    double *soc_log;                   // [E,T,P] (EV2G_FLAG_LOG_SOC; env-major blocks, time-major inside: the step kernel's writes of one env-step fall into a few
+                                       // neighbouring sectors.  A PORT-major log [E*P,T] -- a session's entries contiguous for the statistics kernel -- was measured
+                                       // twice: round 1 (statistics -20 %, step kernel +13 %) and round 4 (statistics 48 -> 44 us, cfg2 step kernel 3.49 -> 4.15
+                                       // us/step: every occupied lane then writes its own sector)) capacity before each EV.step, negated when the step was inactive
     double *sess_abs_e;                // [S]    (flag) the same, frozen at departure
     double *port_energy, *port_current;  // [E*P] EV.current_energy / actual_current of the last step
     unsigned long long *dbg;             // [n_groups*8] phase timing (EV2G_PHASE_TIMING builds only), else nullptr
@@ -622,7 +626,7 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                 if (log_cs) { st.cs_profits[g] = 0.0; st.cs_e_ch[g] = 0.0; st.cs_e_dis[g] = 0.0; }
             }
             for (int idx = tid; idx < ne * 8; idx += EV2G_BLOCK) st.env_acc[(long long)e0 * 8 + idx] = 0.0;
-            for (int idx = tid; idx < ne; idx += EV2G_BLOCK) st.pot_hist[e0 + idx] = 0.0;
+            for (int idx = tid; idx < ne; idx += EV2G_BLOCK) st.hist[EV2G_HIST(e0 + idx, 0, T, s.R) + 1] = 0.0;
             t = 0;
             __syncthreads();
         }
@@ -901,20 +905,20 @@ __global__ void __launch_bounds__(EV2G_BLOCK) ev2g_step_kernel(DevScn s, DevStat
                         ptr += tsum[0 * (s.G * R) + el * R + r];
                         const double mx = s.tr_maxp[erT], mn = s.tr_minp[erT];
                         const double over = (ptr > mx + 0.0001 || ptr < mn - 0.0001) ? fabs(ptr - mx) : 0.0;
-                        st.over_hist[((long long)t * s.E + e) * R + r] = over;
+                        st.hist[EV2G_HIST(e, t, T, R) + 2 + r] = over;
                         st.tr_power_now[(long long)e * R + r] = ptr;
                         over_sum += 100.0 * over;
                     }
-                    st.usage_hist[(long long)t * s.E + e] = usage;
+                    st.hist[EV2G_HIST(e, t, T, R)] = usage;
                     const double pot = esum[4 * s.G + el];
-                    if (sstep < T) st.pot_hist[(long long)sstep * s.E + e] = pot;
+                    if (sstep < T) st.hist[EV2G_HIST(e, sstep, T, R) + 1] = pot;
                     const double costs = esum[2 * s.G + el];
                     RewardIn ri;
                     ri.costs = costs; ri.usage = usage; ri.over100 = over_sum; ri.user = esum[3 * s.G + el];
                     ri.usage_seq = (s.reward_kind == 4) ? ev2g_usage_seq(stage + (size_t)el * P, C, s.het ? 0 : s.npc, s.cs_slot0, s.cs_np) : usage;
                     ri.sp = s.setpoint[(long long)scn * T + t];
-                    ri.pot_t = st.pot_hist[(long long)t * s.E + e];
-                    ri.pot_tm1 = (t > 0) ? st.pot_hist[(long long)(t - 1) * s.E + e] : 0.0;
+                    ri.pot_t = st.hist[EV2G_HIST(e, t, T, R) + 1];
+                    ri.pot_tm1 = (t > 0) ? st.hist[EV2G_HIST(e, t - 1, T, R) + 1] : 0.0;
                     ri.tr0_maxp = s.tr_maxp[(long long)scn * R * T + t];
                     const double reward = ev2g_reward(s.reward_kind, ri);
                     double *acc = st.env_acc + (long long)e * 8;
@@ -1086,10 +1090,15 @@ template <int EPWS> __device__ __forceinline__ bool seg_all(bool p) {
     return (threadIdx.x < 32) ? ((unsigned)m == 0xffffffffu) : ((unsigned)(m >> 32) == 0xffffffffu);
 }
 
-template <int EPWS>
+// RESET: the episode-end sequence "statistics, then reset onto the next scenario window" (what an auto-resetting vectorised env does) in ONE
+// launch: the wavefront that computed an env's statistics re-arms that env's state right behind them (ev2g_reset_kernel's work for one env:
+// state lines from the new window's first-session tables, charger and env accumulators, history rows, reset observation) -- one kernel
+// launch and one cold start per episode less (ev2g_get_stats_reset, include/ev2g.h).
+template <int EPWS, bool RESET = false>
 __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, int scn_off,
                                                         const double *__restrict__ ss_afap, int cur_step,
-                                                        double *__restrict__ out) {
+                                                        double *__restrict__ out, int reset_off = 0, double *__restrict__ r_obs = nullptr,
+                                                        float *__restrict__ r_obs32 = nullptr) {
     // EPWS envs share a wavefront (W = 64 / EPWS lanes each): a wavefront's time is its chain of dependent memory round trips, not its lane
     // count, so small envs (their sessions fit 32 lanes) are paired -- half the wavefronts for the same chain (ev2g_get_stats decides).
     constexpr int W = 64 / EPWS;
@@ -1111,8 +1120,8 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
         // steps the running episode has not reached count as zeros (the reference's arrays are zero-initialised at reset); the
         // history slab may still hold the previous episode's values there after an in-kernel reset of a fused run
         const bool past = t < cur_step;
-        if (past) for (int r = 0; r < R; r++) over += st.over_hist[((long long)t * s.E + e) * R + r];
-        const double sp = s.setpoint[(long long)scn * T + t], u = past ? st.usage_hist[(long long)t * s.E + e] : 0.0;
+        if (past) for (int r = 0; r < R; r++) over += st.hist[EV2G_HIST(e, t, T, R) + 2 + r];
+        const double sp = s.setpoint[(long long)scn * T + t], u = past ? st.hist[EV2G_HIST(e, t, T, R)] : 0.0;
         const double d = sp - u;
         te += d * d;
         ete += fabs(d);
@@ -1134,42 +1143,47 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
     // The satisfaction values of a lane's first two sessions are kept for the variance pass below instead of being fetched again.
     double vkeep[2];
     int nkeep = 0;
+    // Which sessions have been spawned so far, and which of them is still attached, follows from the session's own window (arrivals and
+    // departures do not depend on the actions: a session is attached from step t_arr until the step t_dep has run; the loader refuses
+    // sessions that would depart before they arrive): everything a lane needs of its session depends on the session index alone and is
+    // requested in ONE round trip -- the port's state line (the attached EV's capacity) and the SoC log follow in a second one.  (Round 3
+    // walked the port's chain first: first session, the line's current session, last session -- three dependent round trips more.)
     const int d0 = s.scn_sess[scn], d1 = s.scn_sess_end[scn];
-    for (int k = d0 + lane; k < d1; k += W) {
-        const int q = s.ss_slot[k];
-        const long long g = (long long)e * P + q, gs = (long long)scn * P + q;
-        int first, last;
-        bool attached;
-        port_sessions(s, st, g, gs, cur_step, first, last, attached);
-        if (k >= first && k < last) {   // spawned so far
-            const bool live = attached && k == last - 1;
-            const double capk = live ? st.line[g].cap : st.sess_final_cap[k];
-            const double v = capk / ss_afap[k] * 100.0;
+    for (int k0 = d0; k0 < d1; k0 += W) {
+        const int k = min(k0 + lane, d1 - 1);
+        const bool has = k0 + lane < d1;
+        const int q = s.ss_slot[k], ta = s.ss_tarr[k], td = s.ss_tdep[k];
+        const double B = s.ss_B[k], afap = ss_afap[k], fin_cap = st.sess_final_cap[k];
+        const double fin_abs = log_soc ? st.sess_abs_e[k] : 0.0;
+        const long long g = (long long)e * P + q;
+        const bool spawned = has && ta <= cur_step;   // spawned so far
+        const bool live = td >= cur_step;             // still attached
+        const double l_cap = st.line[g].cap, l_abs = st.line[g].abse;
+        const double capk = live ? l_cap : fin_cap;
+        if (spawned) {
+            const double v = capk / afap * 100.0;
             sum += v;
             mn = fmin(mn, v);
             cnt += 1.0;
             if (nkeep < 2) vkeep[nkeep] = v;
             nkeep++;
+        }
+        if (spawned) {
             if (log_soc) {
                 const double *__restrict__ slog = st.soc_log + (long long)e * T * P + q;   // this port's column of the env's [T, P] block
-                const double B = s.ss_B[k];
-                const int ta = s.ss_tarr[k], td = s.ss_tdep[k];
                 const int tend = min(td, cur_step - 1);
                 const double soc_f = capk / B;
                 // historic_soc entries are capacity / battery_capacity (ev.py:156): one reciprocal per session and a multiplication per
-                // entry instead of a float64 division per entry and pass -- the kernel's time was those ~60 divisions per session, not the
-                // log's bytes (a log confined to a quarter of its footprint: 52.7 -> 46.9 us).  Each entry differs from the quotient by at
+                // entry instead of a float64 division per entry and pass.  Each entry differs from the quotient by at
                 // most one ulp; the statistics are sums of ~30 of them, compared at 1e-9 (relative) like every float64 output.
                 const double invB = 1.0 / B;
                 double hs = 0.0, fs = 0.0;
                 int n = 0, nf = 0;
-                // historic_soc / active_steps (sign bit set = inactive step).  The log is [E, T, P]: an env's block is contiguous
-                // (T*P*8 bytes, 45 KB at cfg2), consecutive steps of a port are P*8 bytes apart, so the sectors the lanes of this
-                // wavefront touch lie next to each other and are shared between neighbouring ports.  The first NK steps of a session are fetched by unconditional (clamped) loads issued together
-                // and KEPT in registers for the second pass; only the tail of longer sessions is read twice, in batches
-                // of eight.  Accumulation order is the sequential one.
+                // historic_soc / active_steps (sign bit set = inactive step).  The first NK entries of a session are fetched by unconditional
+                // (clamped) loads issued together and KEPT in registers for the second pass; only the tail of longer sessions is read twice,
+                // in batches of eight.  Accumulation order is the sequential one.
 #ifndef EV2G_STATS_NK
-#define EV2G_STATS_NK 24
+#define EV2G_STATS_NK 12
 #endif
                 constexpr int NK = EV2G_STATS_NK;
                 double xk[NK];
@@ -1182,7 +1196,6 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                         hs += soc; n++;
                         if (__double_as_longlong(xk[u]) >= 0) { fs += soc; nf++; }
                     }
-                    if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four divisions in flight, not NK (registers)
                 }
                 for (int t = ta + NK; t <= tend; t += 8) {
                     double x[8];
@@ -1202,10 +1215,8 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                 const double avg_soc = hs / n, avg_f = fs / nf;
                 double mad = 0.0;
 #pragma unroll
-                for (int u = 0; u < NK; u++) {
+                for (int u = 0; u < NK; u++)
                     if (ta + u <= tend && __double_as_longlong(xk[u]) >= 0) mad += fabs(avg_f - fabs(xk[u]) * invB);
-                    if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
                 for (int t = ta + NK; t <= tend; t += 8) {
                     double x[8];
 #pragma unroll
@@ -1222,7 +1233,7 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                 deg_cal += alpha * 0.75 * T_sim / k_age;
                 const double v_half = v_min + kk * 0.5;
                 const double beta = z0 * (v_half - z1) * (v_half - z1) + z2 + z3 * delta_DoD;
-                const double abs_e = live ? st.line[g].abse : st.sess_abs_e[k];
+                const double abs_e = live ? l_abs : fin_abs;
                 const double Q_sim = (abs_e / b_cap_kwh) * b_cap_ah;
                 deg_cyc += beta * 0.5 * Q_sim / k_qacc;
             }
@@ -1239,13 +1250,9 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
             if (nkeep > 1) { const double v = vkeep[1] - mean; var += v * v; }
         } else {
             for (int k = d0 + lane; k < d1; k += W) {
-                const int q = s.ss_slot[k];
-                const long long g = (long long)e * P + q, gs = (long long)scn * P + q;
-                int first, last;
-                bool attached;
-                port_sessions(s, st, g, gs, cur_step, first, last, attached);
-                if (k >= first && k < last) {
-                    const double capk = (attached && k == last - 1) ? st.line[g].cap : st.sess_final_cap[k];
+                const int ta = s.ss_tarr[k];
+                if (ta <= cur_step) {
+                    const double capk = (s.ss_tdep[k] >= cur_step) ? st.line[(long long)e * P + s.ss_slot[k]].cap : st.sess_final_cap[k];
                     const double v = capk / ss_afap[k] * 100.0 - mean;
                     var += v * v;
                 }
@@ -1255,24 +1262,48 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
         sd = sqrt(var / cnt);
         mnv = mn;
     }
-    if (lane != 0 || !e_valid) return;
-    const double *acc = st.env_acc + (long long)e * 8;
-    double *o = out + (long long)e * 17;
-    o[0] = served;
-    o[1] = acc[1];
-    o[2] = acc[2];
-    o[3] = acc[3];
-    o[4] = (nsat > 0.0) ? sat / nsat : NAN;
-    o[5] = ptv;
-    o[6] = te;
-    o[7] = ete;
-    o[8] = mean;
-    o[9] = sd;
-    o[10] = mnv;
-    o[11] = acc[4];
-    o[12] = over;
-    o[13] = log_soc ? deg_cal + deg_cyc : NAN;
-    o[14] = log_soc ? deg_cal : NAN;
-    o[15] = log_soc ? deg_cyc : NAN;
-    o[16] = acc[0];
+    if (lane == 0 && e_valid) {
+        const double *acc = st.env_acc + (long long)e * 8;
+        double *o = out + (long long)e * 17;
+        o[0] = served;
+        o[1] = acc[1];
+        o[2] = acc[2];
+        o[3] = acc[3];
+        o[4] = (nsat > 0.0) ? sat / nsat : NAN;
+        o[5] = ptv;
+        o[6] = te;
+        o[7] = ete;
+        o[8] = mean;
+        o[9] = sd;
+        o[10] = mnv;
+        o[11] = acc[4];
+        o[12] = over;
+        o[13] = log_soc ? deg_cal + deg_cyc : NAN;
+        o[14] = log_soc ? deg_cal : NAN;
+        o[15] = log_soc ? deg_cyc : NAN;
+        o[16] = acc[0];
+    }
+    if (RESET && e_valid) {   // EV2Gym.reset()'s state-init part for this env, on scenario (e + reset_off) mod M (ev2g_reset_kernel, one env per segment)
+        const int scn_n = ev2g_scn(e, reset_off, s.M);
+        for (int q = lane; q < P; q += W) {
+            const long long g = (long long)e * P + q, gs = (long long)scn_n * P + q;
+            const int2 w = s.port_first_win[gs];
+            st.line[g].ta = w.x; st.line[g].td = w.y; st.line[g].ss = s.port_first[gs]; st.line[g].cyc_lut = 0;
+            st.line[g].cap = 0.0; st.line[g].tot = 0.0; st.line[g].prev = 0.0;
+            st.port_energy[g] = 0.0; st.port_current[g] = 0.0;
+            if (r_obs) { double *o = r_obs + (long long)e * s.D + s.slot_obs[q]; o[0] = 0.0; o[1] = 0.0; if (s.state_kind == 1) o[2] = 0.0; }
+            if (r_obs32) { float *o = r_obs32 + (long long)e * s.D + s.slot_obs[q]; o[0] = 0.f; o[1] = 0.f; if (s.state_kind == 1) o[2] = 0.f; }
+        }
+        for (int c = lane; c < C; c += W) {
+            const long long gc = (long long)e * C + c;
+            st.cs_sat_sum[gc] = 0.0; st.cs_served[gc] = 0;
+            if (st.cs_profits) { st.cs_profits[gc] = 0.0; st.cs_e_ch[gc] = 0.0; st.cs_e_dis[gc] = 0.0; st.cs_power_now[gc] = 0.0; st.cs_cur_now[gc] = 0.0; }
+        }
+        for (int i = lane; i < 8; i += W) st.env_acc[(long long)e * 8 + i] = 0.0;
+        for (int i = lane; i < T * (2 + R); i += W) st.hist[EV2G_HIST(e, 0, T, R) + i] = 0.0;   // this env's history rows: contiguous
+        for (int r = lane; r < R; r += W) st.tr_power_now[(long long)e * R + r] = 0.0;
+        if (lane == 0) st.env_fault[e] = 0;
+        if (r_obs) write_obs_env(s, r_obs + (long long)e * s.D, scn_n, 0, 0.0, lane, W);
+        if (r_obs32) write_obs_env(s, r_obs32 + (long long)e * s.D, scn_n, 0, 0.0, lane, W);
+    }
 }

@@ -62,6 +62,7 @@ struct ev2g_handle {
     bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
     bool no_full = false, no_wide = false;      // EV2G_NO_FULL / EV2G_NO_WIDE at load time: A/B and routing tests only
     int last_spec = -1;                         // ev2g_last_launch_specialisation
+    const char *general_reason = "";            // ev2g_last_launch_general_reason
     bool pow2_dt = false;                       // 60 / timescale is a power of two (15, 30, 60 minutes): compiled into ev2g_step_v2<.., 1>
     std::string kernel_name;                    // the step kernel ev2g_load_scenarios selected (ev2g_kernel_name)
     std::string fallback_reason;                // why the common-shape fast path was NOT taken ("" when it was / does not apply)
@@ -197,6 +198,7 @@ int ev2g_current_step(const ev2g_handle *h) { return h ? h->current_step : 0; }
 const char *ev2g_kernel_name(const ev2g_handle *h) { return (h && h->loaded) ? h->kernel_name.c_str() : ""; }
 const char *ev2g_fallback_reason(const ev2g_handle *h) { return (h && h->loaded) ? h->fallback_reason.c_str() : ""; }
 int ev2g_last_launch_specialisation(const ev2g_handle *h) { return (h && h->loaded) ? h->last_spec : -1; }
+const char *ev2g_last_launch_general_reason(const ev2g_handle *h) { return (h && h->loaded && h->last_spec == 0) ? h->general_reason : ""; }
 
 static const char *kStatNames[EV2G_N_STATS] = {
     "total_ev_served", "total_profits", "total_energy_charged", "total_energy_discharged",
@@ -485,7 +487,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         const unsigned long long lim = 1ull << 32;
         const unsigned long long biggest = std::max({(unsigned long long)E * P * 8, (unsigned long long)E * D * 8,
                                                      (unsigned long long)M * (T + 1) * 60 * 8, (unsigned long long)SD * sizeof(SessRec),
-                                                     (unsigned long long)M * T * 64, (unsigned long long)E * T * 8 * 3, (unsigned long long)M * P * 8,
+                                                     (unsigned long long)M * T * 64, (unsigned long long)E * T * 8 * 3, (unsigned long long)M * P * 8, (unsigned long long)E * P * sizeof(PortLine),
                                                      (h->cfg.flags & EV2G_FLAG_LOG_SOC) ? (unsigned long long)E * T * P * 8 : 0ull,
                                                      (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) ? (unsigned long long)T * E * C * 8 : 0ull});
         if (biggest >= lim) { h->wave_path = false; h->fallback_reason = "an array of the batch reaches 4 GiB (32-bit byte offsets)"; }
@@ -716,7 +718,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     }
     AL(env_acc, (size_t)E * 8) AL(env_fault, E)
     AL(slab_hist, (size_t)T * E * (2 + R))
-    st.usage_hist = st.slab_hist; st.pot_hist = st.slab_hist + (size_t)T * E; st.over_hist = st.slab_hist + (size_t)T * E * 2;
+    st.hist = st.slab_hist;
     AL(slab_sess, (size_t)std::max<long long>(SD, 1) * 2)
     st.sess_final_cap = st.slab_sess;
     AL(tr_power_now, (size_t)E * R)
@@ -772,6 +774,14 @@ int ev2g_reset_ex(ev2g_handle *h, double *obs, int64_t scenario_offset) {
 }
 
 int ev2g_reset(ev2g_handle *h, double *obs) { return ev2g_reset_ex(h, obs, h ? h->scn_off : 0); }
+int ev2g_reset_f32(ev2g_handle *h, float *obs32, int64_t scenario_offset) {
+    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_reset: no scenarios loaded");
+    const ev2g_step_extras keep = h->extras;
+    if (obs32) h->extras.obs_f32 = obs32;   // (the reset kernel writes the float32 observation where the extras point; only the host-side copy changes here)
+    const int rc = ev2g_reset_ex(h, nullptr, scenario_offset);
+    h->extras = keep;
+    return rc;
+}
 int64_t ev2g_scenario_offset(const ev2g_handle *h) { return h ? h->scn_off : 0; }
 int ev2g_n_scenarios(const ev2g_handle *h) { return h ? h->M : 0; }
 
@@ -822,7 +832,7 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
             return fail(h, EV2G_ERR_ARG, "ev2g_step_n: a step stride is negative or reaches 4 GiB (unsupported by the fast-path kernel)");
         const V2P *pp = (const V2P *)h->d_v2p;
         const DevState &st = h->st;
-        const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.slab_hist, (unsigned long long)s.T * s.E * 8ull,
+        const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.hist,
                           st.env_acc, s.cs_pack, (char *)st.line, h->d_step_tab};
         // every float64 output present, no extras, no charger histories: the specialisation without their checks (not for the run-time rewards)
         // ... in two flavours: float64 actions in / float64 observations out (a loop that consumes them, the benchmark), or the policy
@@ -835,6 +845,21 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         const bool wide = full && (h->cfg.flags & EV2G_FLAG_LOG_SOC) && s.P >= 3 && !h->no_wide &&
                           s.P >= (s.state_kind == EV2G_STATE_PUBLIC_PST ? 3 : (s.state_kind == EV2G_STATE_V2G_PROFIT_MAX_LOADS ? 30 : 10));
         h->last_spec = (full && std::min(s.reward_kind, 3) != 3) ? (wide ? 2 : 1) : 0;
+        {   // why not the full instantiation: the FIRST thing the caller passed (or configured) that rules it out -- ev2g_last_launch_general_reason
+            const char *why = "";
+            if (!full) {
+                if (h->no_full) why = "EV2G_NO_FULL is set";
+                else if (std::min(s.reward_kind, 3) == 3) why = "the reward function is one of the eight selected at run time (only the shipped configs' three are compiled in)";
+                else if (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) why = "EV2G_FLAG_LOG_CS_HISTORY (charger histories)";
+                else if (x.cost) why = "a cost buffer is registered (ev2g_set_step_extras)";
+                else if (auto_reset) why = "auto_reset";
+                else if (!(io.reward && io.done && io.mask)) why = "a reward / done / mask output is NULL";
+                else if (!(f64io || f32io)) why = "the observation / action buffers are neither the float64 pair nor the float32 hand-over pair (e.g. obs NULL, or a float32 observation copy next to the float64 one)";
+                else if (io.o_stride || io.r_stride || io.d_stride || io.m_stride) why = "an output step stride is not 0";
+                else why = "the launch would run past the episode end";
+            }
+            h->general_reason = why;
+        }
 #define EV2G_WAVE_CASE(SK, RK)                                                                                              \
     case SK * 4 + RK:                                                                                                       \
         if (full && RK != 3 && wide && f32io)                                                                               \
@@ -1196,6 +1221,48 @@ int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward,
 
 long long ev2g_rollout_graph_launches(const ev2g_handle *h) { return h ? h->graph_launches : 0; }
 
+int ev2g_collect(ev2g_handle *h, const ev2g_mlp *m, int k_steps, const ev2g_transitions *tr) {
+    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_collect: no scenarios loaded");
+    if (!m || !tr || k_steps < 0 || !tr->obs || !tr->actions || !tr->reward || !tr->done || !tr->mask)
+        return fail(h, EV2G_ERR_ARG, "ev2g_collect: null argument (every transition array is required)");
+    if (m->dev.d_in != h->D || m->dev.d_out != h->P) return fail(h, EV2G_ERR_ARG, "ev2g_collect: actor shape != (obs dim, ports)");
+    if (h->current_step + k_steps > h->T) return fail(h, EV2G_ERR_DONE, "ev2g_collect: the segment would run past the episode end");
+    (void)hipSetDevice(h->device);
+    const size_t ED = (size_t)h->E * h->D, EP = (size_t)h->E * h->P;
+    // On the fast path the policy hand-over instantiations take their float32 buffers per launch (StepIO::act32 / obs32): every step
+    // reads and writes the caller's rows directly.  Elsewhere (general kernels; run-time rewards; a registered cost buffer) the step
+    // works on the registered hand-over buffers of ev2g_set_step_extras and the rows are copied device-to-device around it.
+    const ev2g_step_extras &x = h->extras;
+    const bool direct = h->wave_path && !x.cost && !x.obs_f32 && !x.actions_f32 && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) &&
+                        std::min(h->scn.reward_kind, 3) != 3 && !h->no_full;
+    if (!direct && !(x.obs_f32 && x.actions_f32 && x.obs_f32_step_stride == 0))
+        return fail(h, EV2G_ERR_ARG, "ev2g_collect: this configuration steps through the registered float32 hand-over buffers: register them with "
+                                     "ev2g_set_step_extras (observation step stride 0) first");
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < k_steps; i++) {
+        float *obs_i = tr->obs + (size_t)i * ED, *obs_n = obs_i + ED, *act_i = tr->actions + (size_t)i * EP;
+        int rc;
+        if (direct) {
+            if ((rc = ev2g_mlp_forward(h, m, obs_i, act_i, h->E))) return rc;
+            StepIO io = make_io(h, nullptr, 0, nullptr, 0, tr->reward + (size_t)i * h->E, 0, tr->done + (size_t)i * h->E, 0, tr->mask + (size_t)i * EP, 0, 0, 0);
+            io.act32 = act_i; io.obs32 = obs_n;
+            if ((rc = launch_steps(h, io, h->current_step, 1, 0))) return rc;
+            if (h->last_spec <= 0) return fail(h, EV2G_ERR_STATE, "ev2g_collect: internal: the direct path needs the full instantiation");
+        } else {
+            if (i == 0) HIPCHK(h, hipMemcpyAsync(x.obs_f32, obs_i, ED * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+            if ((rc = ev2g_mlp_forward(h, m, x.obs_f32, (float *)x.actions_f32, h->E))) return rc;
+            StepIO io = make_io(h, nullptr, 0, nullptr, 0, tr->reward + (size_t)i * h->E, 0, tr->done + (size_t)i * h->E, 0, tr->mask + (size_t)i * EP, 0, 0, 0);
+            if ((rc = launch_steps(h, io, h->current_step, 1, 0))) return rc;
+            HIPCHK(h, hipMemcpyAsync(act_i, x.actions_f32, EP * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(obs_n, x.obs_f32, ED * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        }
+        h->current_step += 1;
+    }
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return EV2G_OK;
+}
+
 double ev2g_last_step_n_kernel_ms(ev2g_handle *h) {
     if (!h || !h->timed) return -1.0;
     if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0;
@@ -1218,22 +1285,47 @@ int ev2g_check_faults(ev2g_handle *h, int32_t *first_bad_env) {
     return EV2G_OK;
 }
 
-int ev2g_get_stats(ev2g_handle *h, double *stats) {
-    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_get_stats: no scenarios loaded");
-    if (!stats) return fail(h, EV2G_ERR_ARG, "ev2g_get_stats: null output");
+static int launch_stats(ev2g_handle *h, double *stats, bool reset, double *obs, long long off, float *obs32 = nullptr) {
     (void)hipSetDevice(h->device);
     // two envs per wavefront where an env's sessions fit 32 lanes with room to spare (PublicPST: ~14 per env -- 74.6 -> 58.0 us at cfg3; at
-    // cfg2's ~35 per env half of the lanes would need a second pass: 47 -> 52 us, so it keeps a wavefront per env)
-    const bool pair = h->S <= (long long)h->M * 24 && h->C <= 32 && !std::getenv("EV2G_STATS_ONE_ENV");
-    if (pair)
-        hipLaunchKernelGGL(ev2g_stats_kernel<2>, dim3((h->E + 1) / 2), dim3(64), 0, h->stream, h->scn, h->st, (int)h->scn_off,
-                           (const double *)h->d_ss_afap, h->current_step, stats);
-    else
-        hipLaunchKernelGGL(ev2g_stats_kernel<1>, dim3(h->E), dim3(64), 0, h->stream, h->scn, h->st, (int)h->scn_off,
-                           (const double *)h->d_ss_afap, h->current_step, stats);
+    // cfg2's ~35 per env half of the lanes would need a second pass: 47 -> 52 us, so it keeps a wavefront per env).  Refillable pools: by the
+    // session slots per scenario, not by what the loaded batch happened to hold -- the choice (and the summation order) stays put across refills.
+    const long long per_scn = h->sess_cap > 0 ? (long long)h->sess_cap : (h->S + h->M - 1) / std::max(h->M, 1);
+    const bool pair = (h->sess_cap > 0 ? per_scn <= 48 : h->S <= (long long)h->M * 24) && h->C <= 32 && !std::getenv("EV2G_STATS_ONE_ENV");
+    const dim3 grid(pair ? (h->E + 1) / 2 : h->E);
+#define EV2G_STATS_LAUNCH(EPWS, RESET)                                                                                                    \
+    hipLaunchKernelGGL((ev2g_stats_kernel<EPWS, RESET>), grid, dim3(64), 0, h->stream, h->scn, h->st, (int)h->scn_off, (const double *)h->d_ss_afap, \
+                       h->current_step, stats, (int)off, obs, RESET ? (obs32 ? obs32 : (float *)h->extras.obs_f32) : (float *)nullptr)
+    if (pair) { if (reset) EV2G_STATS_LAUNCH(2, true); else EV2G_STATS_LAUNCH(2, false); }
+    else { if (reset) EV2G_STATS_LAUNCH(1, true); else EV2G_STATS_LAUNCH(1, false); }
+#undef EV2G_STATS_LAUNCH
     HIPCHK(h, hipGetLastError());
     return EV2G_OK;
 }
+
+int ev2g_get_stats(ev2g_handle *h, double *stats) {
+    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_get_stats: no scenarios loaded");
+    if (!stats) return fail(h, EV2G_ERR_ARG, "ev2g_get_stats: null output");
+    return launch_stats(h, stats, false, nullptr, 0);
+}
+
+static int stats_reset_impl(ev2g_handle *h, double *stats, double *obs, float *obs32, int64_t scenario_offset) {
+    if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_get_stats_reset: no scenarios loaded");
+    if (!stats) return fail(h, EV2G_ERR_ARG, "ev2g_get_stats_reset: null output");
+    long long off = scenario_offset % (long long)h->scn.M;
+    if (off < 0) off += h->scn.M;
+    const int rc = launch_stats(h, stats, true, obs, off, obs32);
+    if (rc) return rc;
+    if (h->st.cs_power_hist) {
+        HIPCHK(h, hipMemsetAsync(h->st.cs_power_hist, 0, sizeof(double) * (size_t)h->scn.T * h->scn.E * h->scn.C, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->st.cs_cur_hist, 0, sizeof(double) * (size_t)h->scn.T * h->scn.E * h->scn.C, h->stream));
+    }
+    h->scn_off = off;
+    h->current_step = 0;
+    return EV2G_OK;
+}
+int ev2g_get_stats_reset(ev2g_handle *h, double *stats, double *obs, int64_t scenario_offset) { return stats_reset_impl(h, stats, obs, nullptr, scenario_offset); }
+int ev2g_get_stats_reset_f32(ev2g_handle *h, double *stats, float *obs32, int64_t scenario_offset) { return stats_reset_impl(h, stats, nullptr, obs32, scenario_offset); }
 
 // ---- multi-GPU statistics exchange (RCCL) --------------------------------------------------------------------------------
 int ev2g_comm_get_unique_id(void *id) {
@@ -1342,14 +1434,14 @@ int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *v) {
     }
     // time-major histories: strided 2D copies
     std::vector<double> usage(T), pot(T), over((size_t)T * R);
-    HIPCHK(h, hipMemcpy2DAsync(usage.data(), sizeof(double), st.usage_hist + env, sizeof(double) * E, sizeof(double), T,
-                               hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpy2DAsync(pot.data(), sizeof(double), st.pot_hist + env, sizeof(double) * E, sizeof(double), T,
-                               hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpy2DAsync(over.data(), sizeof(double) * R, st.over_hist + (size_t)env * R, sizeof(double) * E * R,
-                               sizeof(double) * R, T, hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> hist_rows((size_t)T * (2 + R));   // this env's rows of the history array [E, T, 2 + R]: contiguous
+    HIPCHK(h, hipMemcpyAsync(hist_rows.data(), st.hist + (size_t)env * T * (2 + R), sizeof(double) * hist_rows.size(), hipMemcpyDeviceToHost, h->stream));
 #undef D2H
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int t = 0; t < T; t++) {
+        usage[t] = hist_rows[(size_t)t * (2 + R)]; pot[t] = hist_rows[(size_t)t * (2 + R) + 1];
+        for (int r = 0; r < R; r++) over[(size_t)t * R + r] = hist_rows[(size_t)t * (2 + R) + 2 + r];
+    }
     for (int q = 0; q < P; q++) {
         const PortLine &l = lines[q];
         cap[q] = l.cap; tot[q] = l.tot; prev[q] = l.prev; win[q] = make_int2(l.ta, l.td); sc[q] = make_int2(l.ss, ev2g_line_cycles(l.cyc_lut));

@@ -170,7 +170,7 @@ struct V2P {
     EV2G_GP(const double) tr_minp; EV2G_GP(const double) win_tab; EV2G_GP(const double) lut;
     EV2G_GP(const double) step_tab;   // [E, T, 8] per (env, step) scalars (fast path only, ev2g_build_step_table_kernel)
     EV2G_GP(char) slab_port; unsigned long long slab_port_slice;   // DevState slabs (ev2g_device.h)
-    EV2G_GP(double) slab_hist; EV2G_GP(double) slab_sess; unsigned long long hist_slice, sess_slice;   // bytes
+    EV2G_GP(double) slab_hist; EV2G_GP(double) slab_sess; unsigned long long sess_slice;   // bytes
     EV2G_GP(const double) head_tab;   // [E, T+1, NH] observation head rows (fast path only, ev2g_build_head_table_kernel)
     EV2G_GP(const SessRec) rec; EV2G_GP(const SessTail) tail; EV2G_GP(const int) ss_lut;
     EV2G_GP(PortLine) line;
@@ -178,7 +178,7 @@ struct V2P {
     EV2G_GP(double) cs_profits; EV2G_GP(double) cs_e_ch; EV2G_GP(double) cs_e_dis;
     EV2G_GP(double) cs_power_hist; EV2G_GP(double) cs_cur_hist; EV2G_GP(double) cs_power_now; EV2G_GP(double) cs_cur_now;
     EV2G_GP(double) env_acc; EV2G_GP(int) env_fault;
-    EV2G_GP(double) usage_hist; EV2G_GP(double) pot_hist; EV2G_GP(double) over_hist; EV2G_GP(double) tr_power_now;
+    EV2G_GP(double) hist; EV2G_GP(double) tr_power_now;
     EV2G_GP(double) sess_final_cap; EV2G_GP(double) port_energy; EV2G_GP(double) port_current;
     EV2G_GP(double) soc_log; EV2G_GP(double) sess_abs_e;
     EV2G_GP(unsigned long long) dbg;
@@ -199,7 +199,6 @@ inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
     EV2G_SETP(p.step_tab, (const double *)nullptr);
     EV2G_SETP(p.slab_port, st.slab_port); p.slab_port_slice = st.slab_port_slice;
     EV2G_SETP(p.slab_hist, st.slab_hist); EV2G_SETP(p.slab_sess, st.slab_sess);
-    p.hist_slice = (unsigned long long)s.T * s.E * 8ull;
     p.sess_slice = (unsigned long long)(st.sess_abs_e ? (st.sess_abs_e - st.slab_sess) : 0) * 8ull;
 #define CPS(f) EV2G_SETP(p.f, s.f);
 #define CPT(f) EV2G_SETP(p.f, st.f);
@@ -209,7 +208,7 @@ inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
     CPS(win_tab) CPS(lut) CPS(rec) CPS(tail) CPS(ss_lut)
     CPT(line) CPT(cs_sat_sum) CPT(cs_served)
     CPT(cs_profits) CPT(cs_e_ch) CPT(cs_e_dis) CPT(cs_power_hist) CPT(cs_cur_hist) CPT(cs_power_now) CPT(cs_cur_now)
-    CPT(env_acc) CPT(env_fault) CPT(usage_hist) CPT(pot_hist) CPT(over_hist) CPT(tr_power_now)
+    CPT(env_acc) CPT(env_fault) CPT(hist) CPT(tr_power_now)
     CPT(sess_final_cap) CPT(port_energy) CPT(port_current) CPT(soc_log) CPT(sess_abs_e) CPT(dbg)
 #undef CPS
 #undef CPT
@@ -304,8 +303,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
     for (int i = tid; i < R; i += BLOCK) trobs[i] = S->tr_obs[i];
     for (int i = tid; i < ne * 5; i += BLOCK) eacc[i] = 0.0;
     for (int i = tid; i < ne; i += BLOCK) {
-        pot_prev[i] = (t < T) ? S->pot_hist[t * E + e0 + i] : 0.0;
-        pot_prev2[i] = (t > 0 && t <= T) ? S->pot_hist[(t - 1) * E + e0 + i] : 0.0;
+        pot_prev[i] = (t < T) ? S->hist[EV2G_HIST(e0 + i, t, T, R) + 1] : 0.0;
+        pot_prev2[i] = (t > 0 && t <= T) ? S->hist[EV2G_HIST(e0 + i, t - 1, T, R) + 1] : 0.0;
     }
     // observation-head role of this lane (columns pl and pl + lpe of the env it serves at env level), fixed for the launch:
     // destination column, and where the value comes from -- charge price `hsrc` steps ahead (hsrc < 20), or entry hsrc - 20 of the
@@ -731,7 +730,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             ptr += tsum[0 * NT + tid_l];
             const double over = (ptr > pf_maxp + 0.0001 || ptr < pf_minp - 0.0001) ? fabs(ptr - pf_maxp) : 0.0;
             const int tel = tid_l / R, r = tid_l - tel * R;
-            S->over_hist[(t * E + e0 + tel) * R + r] = over;
+            S->hist[EV2G_HIST(e0 + tel, t, T, R) + 2 + r] = over;
             if (last_step) S->tr_power_now[(e0 + tel) * R + r] = ptr;
             over100 = 100.0 * over;
             over_l[tid_l] = over100;
@@ -791,7 +790,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
 
         // ---------------- E2: per env: reward, histories, observation head ----------------
         // the parameters the owner lane's chain needs, fetched in ONE scalar-load batch (one wait) instead of a round trip per use
-        double *const p_usage = (double *)S->usage_hist, *const p_pot = (double *)S->pot_hist, *const p_cost = (double *)S->x_cost;
+        double *const p_hist = (double *)S->hist, *const p_cost = (double *)S->x_cost;
         double *const p_acc = (double *)S->env_acc;
         const long long c_stride = S->x_c_stride;
         const int rkind = V2C(S->reward_kind, 0), ckind = V2C(S->cost_kind, 0);
@@ -799,9 +798,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_v2(const V2P *__restrict__
             const double usage = q_usage;
             if (pl_l == 0) {
                 const double over_sum = q_over;
-                p_usage[t * E + pe_l] = usage;
+                p_hist[EV2G_HIST(pe_l, t, T, R)] = usage;
                 const double potn = q_pot;
-                if (sstep < T) p_pot[sstep * E + pe_l] = potn;
+                if (sstep < T) p_hist[EV2G_HIST(pe_l, sstep, T, R) + 1] = potn;
                 const double costs = q_costs;
                 RewardIn ri;
                 ri.costs = costs; ri.usage = usage; ri.usage_seq = seq_usage ? q_useq : usage; ri.sp = pf_sp; ri.over100 = over_sum; ri.user = q_sat;

@@ -72,7 +72,7 @@ template <class B> __device__ __forceinline__ SessRec ldg32_rec_discharge(B base
 struct WaveArgs {
     int P, T, E, D, M;
     char *slab_port; unsigned long long slab_port_slice;
-    double *slab_hist; unsigned long long hist_slice;
+    double *hist;            // [E, T, 3] usage | potential | overload per (env, step) (one transformer)
     double *env_acc;
     const double *cs_pack;   // [C][6] imax, |dmax|, imin, dmin, max power, min power
     char *lines;             // [E*P] PortLine
@@ -111,8 +111,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     // state slabs (ev2g_device.h): every [E*P] array is slabP + k * PS8, the three [T,E] histories slabH + k * HS8, the
     // two per-session result arrays slabS + k * SS8 -- scalar adds on three base pointers instead of one pointer fetch
     // from the parameter block per array and use
-    const gptr slabP = (gptr)wa.slab_port, slabH = (gptr)wa.slab_hist, slabS = (gptr)S->slab_sess;
-    const unsigned long long PS8 = wa.slab_port_slice, HS8 = wa.hist_slice, SS8 = S->sess_slice;
+    const gptr slabP = (gptr)wa.slab_port, hist = (gptr)wa.hist, slabS = (gptr)S->slab_sess;
+    const unsigned long long PS8 = wa.slab_port_slice, SS8 = S->sess_slice;
     const gptr env_acc = (gptr)wa.env_acc;
 #define PA(k) (slabP + PS8 * (unsigned long long)(k))
     const int EPW = 64 / P;   // envs per wavefront
@@ -176,9 +176,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         if (tid < 64) { k_min = ldg32<d2v>(wa.cs_pack, cp8 * 6u + 16u); k_pow = ldg32<d2v>(wa.cs_pack, cp8 * 6u + 32u); }   // (wavefront 0 only)
         a_next = IO32 ? (double)ldg32<float>(io.act32 + (long long)io.step0 * io.a_stride, (unsigned)(valid ? g : e0 * P) * 4u)
                       : ldg32<double>(io.actions, (unsigned)(valid ? g : e0 * P) * 8u);
-        double l_pot = ldg32<double>(slabH + HS8, ((unsigned)min(t, T - 1) * (unsigned)E + ec) * 8u);
+        double l_pot = ldg32<double>(hist, ((ec * (unsigned)T + (unsigned)min(t, T - 1)) * 3u + 1u) * 8u);
         double l_pot2 = 0.0;   // charge_power_potential[t-1]: only SquaredTrackingErrorRewardWithPenalty (a run-time reward) reads it
-        if (RK == 3) l_pot2 = ldg32<double>(slabH + HS8, ((unsigned)min(max(t - 1, 0), T - 1) * (unsigned)E + ec) * 8u);
+        if (RK == 3) l_pot2 = ldg32<double>(hist, ((ec * (unsigned)T + (unsigned)min(max(t - 1, 0), T - 1)) * 3u + 1u) * 8u);
         d2v acc01 = ldg32<d2v>(env_acc, ec * 64u), acc23 = ldg32<d2v>(env_acc, ec * 64u + 16u);
         double acc4 = ldg32<double>(env_acc, ec * 64u + 32u);
         d2v k_max_w = k_max;
@@ -652,9 +652,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             const double over_n = dpp_mov_f64<0x138>(over);   // wave_shr:1: lane L takes lane L-1's value
             if (valid && q_l < 3 && (q_l != 2 || sstep < T)) {
                 const double hv = (q_l == 0) ? usage : ((q_l == 1) ? over_n : esum[3]);
-                const unsigned hoff = (q_l == 0) ? 0u : ((q_l == 1) ? 2u * (unsigned)HS8 : (unsigned)HS8);
-                const unsigned hstep = (q_l == 2) ? (unsigned)sstep : (unsigned)t;
-                stg32<double>(slabH, hoff + (hstep * (unsigned)E + (unsigned)e_l) * 8u, hv);
+                // row (e, t) of the history array [E, T, 3]: words {usage, potential, overload}; lane 2 writes into row t + 1 -- 40 bytes in all
+                const unsigned hword = (q_l == 0) ? 0u : ((q_l == 1) ? 16u : 32u);
+                stg32<double>(hist + (long long)t * 24, (unsigned)(e_l * T) * 24u + hword, hv);
             }
         }
         if (head) {
@@ -669,9 +669,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             if (last_step) stg32<double>(S->tr_power_now, e8, tr_power);
             const double potn = esum[3];
             if (!WIDE && P < 3) {   // two-port envs: no third lane to share the history stores with
-                stg32<double>((slabH + 2 * HS8) + (long long)t * E * 8, e8, over);
-                stg32<double>(slabH + (long long)t * E * 8, e8, usage);
-                if (sstep < T) stg32<double>((slabH + HS8) + (long long)sstep * E * 8, e8, potn);
+                const unsigned h8 = (unsigned)(e_l * T + t) * 24u;
+                stg32<double>(hist, h8 + 16u, over);
+                stg32<double>(hist, h8, usage);
+                if (sstep < T) stg32<double>(hist, h8 + 32u, potn);
             }
             const double costs = esum[1];
             double reward;

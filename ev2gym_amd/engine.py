@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import warnings
 from typing import Optional
 
 import numpy as np
@@ -58,11 +59,16 @@ def load_library(path: Optional[str] = None):
         "ev2g_set_step_extras": (C.c_int, [vp, C.POINTER(_abi.StepExtrasC)]),
         "ev2g_kernel_name": (C.c_char_p, [vp]),
         "ev2g_last_launch_specialisation": (C.c_int, [vp]),
+        "ev2g_last_launch_general_reason": (C.c_char_p, [vp]),
         "ev2g_fallback_reason": (C.c_char_p, [vp]),
         "ev2g_step": (C.c_int, [vp, vp, vp, vp, vp, vp]),
         "ev2g_step_n": (C.c_int, [vp, C.c_int, C.c_int, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, C.c_int]),
         "ev2g_check_faults": (C.c_int, [vp, C.POINTER(i32)]),
         "ev2g_get_stats": (C.c_int, [vp, vp]),
+        "ev2g_get_stats_reset": (C.c_int, [vp, vp, vp, C.c_int64]),
+        "ev2g_get_stats_reset_f32": (C.c_int, [vp, vp, vp, C.c_int64]),
+        "ev2g_reset_f32": (C.c_int, [vp, vp, C.c_int64]),
+        "ev2g_collect": (C.c_int, [vp, vp, C.c_int, vp]),
         "ev2g_stat_name": (C.c_char_p, [C.c_int]),
         "ev2g_peek": (C.c_int, [vp, C.c_int, C.POINTER(_abi.EnvViewC)]),
         "ev2g_malloc": (vp, [vp, C.c_size_t]),
@@ -107,8 +113,8 @@ def load_library(path: Optional[str] = None):
 EXPORTED_SYMBOLS = [
     "ev2g_abi_version", "ev2g_create", "ev2g_destroy", "ev2g_last_error", "ev2g_load_scenarios", "ev2g_n_envs",
     "ev2g_n_scenarios", "ev2g_n_ports", "ev2g_obs_dim", "ev2g_n_steps", "ev2g_current_step", "ev2g_reset", "ev2g_reset_ex",
-    "ev2g_scenario_offset", "ev2g_set_step_extras", "ev2g_kernel_name", "ev2g_last_launch_specialisation", "ev2g_fallback_reason", "ev2g_step", "ev2g_step_n",
-    "ev2g_check_faults", "ev2g_get_stats", "ev2g_stat_name", "ev2g_peek", "ev2g_malloc", "ev2g_free",
+    "ev2g_scenario_offset", "ev2g_set_step_extras", "ev2g_kernel_name", "ev2g_last_launch_specialisation", "ev2g_last_launch_general_reason", "ev2g_fallback_reason", "ev2g_step", "ev2g_step_n",
+    "ev2g_check_faults", "ev2g_get_stats", "ev2g_get_stats_reset", "ev2g_get_stats_reset_f32", "ev2g_reset_f32", "ev2g_collect", "ev2g_stat_name", "ev2g_peek", "ev2g_malloc", "ev2g_free",
     "ev2g_memcpy_h2d", "ev2g_memcpy_d2h", "ev2g_synchronize", "ev2g_fill_uniform", "ev2g_host_uniform",
     "ev2g_last_step_n_kernel_ms", "ev2g_mlp_create", "ev2g_mlp_create_ex", "ev2g_mlp_destroy", "ev2g_mlp_forward", "ev2g_rollout",
     "ev2g_rollout_graph_launches", "ev2g_comm_get_unique_id", "ev2g_comm_init", "ev2g_comm_destroy", "ev2g_comm_world_size", "ev2g_comm_gathers", "ev2g_gather_stats",
@@ -171,6 +177,7 @@ class Engine:
         per call, each reset choosing which window of the pool they run (`reset(offset=...)`)."""
         self._lib = load_library()
         self._h = None
+        self._spec_checks_left = 4   # launches still examined by _warn_if_general
         cfg = _abi.ConfigC(int(device), int(reward_kind), int(state_kind), int(flags), stream, int(cost_kind), int(n_active_envs))
         h = C.c_void_p()
         rc = self._lib.ev2g_create(C.byref(cfg), C.byref(h))
@@ -247,8 +254,23 @@ class Engine:
         else:
             self._check(self._lib.ev2g_reset_ex(self._h, _ptr(obs), int(offset)))
 
+    def _warn_if_general(self):
+        """The fast path has a specialised instantiation (~20 % faster) that a launch gets only when it passes every output with step
+        stride 0 and no extras (include/ev2g.h).  Falling off it is legal but silent: the first launches of an engine are checked and the
+        caller is told, once, which argument did it (like the kernel-routing warning at load)."""
+        if self._spec_checks_left <= 0:
+            return
+        self._spec_checks_left -= 1
+        if self._lib.ev2g_last_launch_specialisation(self._h) == 0:
+            why = (self._lib.ev2g_last_launch_general_reason(self._h) or b"").decode()
+            if why and not why.startswith("EV2G_NO_FULL"):
+                self._spec_checks_left = 0
+                warnings.warn(f"ev2gym_amd: this launch ran the GENERAL instantiation of {self.kernel_name} (slower than the full one): {why}", stacklevel=3)
+
     def step(self, actions, obs=None, reward=None, done=None, mask=None):
         self._check(self._lib.ev2g_step(self._h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(mask)))
+        if self._spec_checks_left > 0:
+            self._warn_if_general()
 
     def step_n(self, k, actions, a_stride, obs=None, o_stride=0, reward=None, r_stride=0, done=None, d_stride=0,
                mask=None, m_stride=0, auto_reset=True, persistent=False):
@@ -256,6 +278,8 @@ class Engine:
                                    int(o_stride), _ptr(reward), int(r_stride), _ptr(done), int(d_stride), _ptr(mask),
                                    int(m_stride), int(auto_reset))   # 0 / AUTO_RESET_SAME (True) / AUTO_RESET_NEXT
         self._check(rc)
+        if self._spec_checks_left > 0:
+            self._warn_if_general()
 
     # ---- policy in the loop ----------------------------------------------------------------------
     def mlp_create(self, W1, b1, W2, b2, W3, b3, out_lo=-1.0, precision="bf16"):
@@ -311,6 +335,27 @@ class Engine:
             return buf.to_host()
         finally:
             buf.free()
+
+    def collect(self, m, k, obs, actions, reward, done, mask):
+        """k x (actor forward -> env step) with the transitions written straight into the caller's DEVICE arrays (ev2g_collect):
+        obs float32 [k + 1, E, D] (row 0 is the input observation), actions float32 [k, E, P], reward float64 [k, E], done / mask uint8."""
+        class _Tr(C.Structure):
+            _fields_ = [("obs", C.c_void_p), ("actions", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("mask", C.c_void_p)]
+        tr = _Tr(_ptr(obs), _ptr(actions), _ptr(reward), _ptr(done), _ptr(mask))
+        self._check(self._lib.ev2g_collect(self._h, m, int(k), C.byref(tr)))
+
+    def reset_f32(self, obs32=None, offset: int = 0):
+        self._check(self._lib.ev2g_reset_f32(self._h, _ptr(obs32), int(offset)))
+
+    def stats_reset_f32(self, out, obs32=None, offset: int = 0):
+        self._check(self._lib.ev2g_get_stats_reset_f32(self._h, _ptr(out), _ptr(obs32), int(offset)))
+        return out
+
+    def stats_reset(self, out, obs=None, offset: int = 0):
+        """Episode end in one launch: get_statistics() of the finished episode into the device buffer `out`, then reset() onto the pool
+        window `offset` (reset observation into `obs`) -- ev2g_get_stats_reset."""
+        self._check(self._lib.ev2g_get_stats_reset(self._h, _ptr(out), _ptr(obs), int(offset)))
+        return out
 
     # ---- multi-GPU statistics exchange over RCCL (include/ev2g.h: ev2g_comm_*, ev2g_gather_stats) ----
     @staticmethod

@@ -179,3 +179,106 @@ class EV2GymSB3VecEnv(_SB3VecEnv):
 
     def render(self, mode: Optional[str] = None):
         return None
+
+
+class DeviceReplayCollector:
+    """Off-policy rollout collection that never leaves the device: the `collect_rollouts()` half of an SB3 DDPG / TD3 / SAC loop
+    (`/root/reference/train_stable_baselines.py:62-130`) for thousands of envs.
+
+    SB3's `VecEnv` protocol (the adapter above) moves numpy arrays every step -- 3.6 MB per step at 4096 x 50 -- and its replay buffer lives on
+    the host.  Here the replay buffer is a ring of EPISODE BLOCKS in device memory and `ev2g_collect` fills a block in place: the fused actor
+    reads observation row t and writes action row t, the step kernel reads that action row and writes observation row t + 1, reward, done and
+    action-mask row t.  `next_obs[t] = obs[t + 1]`, so a block IS the (obs, action, reward, next_obs, done) sequence of its episode (SB3's
+    `ReplayBuffer(optimize_memory_usage=True)` layout); its row T is every env's `terminal_observation`, and the reset observation of the
+    next episode lands in row 0 of the next block (`ev2g_get_stats_reset_f32`, which also yields the terminal `info` statistics).
+
+        col = DeviceReplayCollector(engine, actor_weights, lo=-1.0, capacity_episodes=4)
+        col.collect_episode()                       # one episode of all E envs: T x (actor forward -> env step), no host copies
+        obs, act, rew, nxt, done = col.sample(256)  # host-side draw of indices, device gathers (torch) -- what a learner consumes
+        col.set_weights(new_weights)                # the learner's updated actor
+
+    `engine` must not have float32 hand-over buffers registered (`ev2g_set_step_extras`): the collector's rows are the hand-over.
+    Arrays are torch tensors when torch is importable (PyTorch-ROCm is the SB3 side's tensor type), DeviceBuffers otherwise."""
+
+    def __init__(self, engine, weights, lo: float, capacity_episodes: int = 2, precision: str = "bf16", offset_stride: Optional[int] = None, use_torch: Optional[bool] = None):
+        from . import _abi
+        self.eng = eng = engine
+        self.E, self.P, self.D, self.T, self.M = eng.E, eng.P, eng.D, eng.T, eng.M
+        self.lo, self.precision = float(lo), precision
+        self.mlp = eng.mlp_create(*weights, out_lo=self.lo, precision=precision)
+        self.cap = max(2, int(capacity_episodes))   # (the reset observation of the next episode is written into the NEXT block)
+        if use_torch is None:
+            try:
+                import torch
+                use_torch = torch.cuda.is_available()
+            except Exception:
+                use_torch = False
+        self._torch = None
+        if use_torch:
+            import torch
+            self._torch = torch
+
+        def alloc(shape, dtype):
+            if self._torch is not None:
+                td = {np.float32: self._torch.float32, np.float64: self._torch.float64, np.uint8: self._torch.uint8}[dtype]
+                return self._torch.zeros(shape, dtype=td, device=f"cuda:{eng.device if hasattr(eng, 'device') else 0}")
+            return eng.empty(shape, dtype)
+        E, P, D, T = self.E, self.P, self.D, self.T
+        self.obs = [alloc((T + 1, E, D), np.float32) for _ in range(self.cap)]
+        self.actions = [alloc((T, E, P), np.float32) for _ in range(self.cap)]
+        self.reward = [alloc((T, E), np.float64) for _ in range(self.cap)]
+        self.done = [alloc((T, E), np.uint8) for _ in range(self.cap)]
+        self.mask = [alloc((T, E, P), np.uint8) for _ in range(self.cap)]
+        self.stats = alloc((E, _abi.N_STATS), np.float64)   # get_statistics() of the episode collected last (terminal info)
+        self.head = 0            # block the next episode goes into
+        self.filled = 0          # complete episodes in the ring
+        self.offset = 0
+        self.offset_stride = self.E if offset_stride is None else int(offset_stride)
+        self.episodes = 0
+        eng.reset_f32(self.obs[0], self.offset)
+
+    def set_weights(self, weights):
+        """The learner's new actor (host float32 arrays, torch.nn.Linear layout)."""
+        old = self.mlp
+        self.mlp = self.eng.mlp_create(*weights, out_lo=self.lo, precision=self.precision)
+        self.eng.mlp_destroy(old)
+
+    def collect_episode(self):
+        """One whole episode of every env into the head block; statistics of the finished episode; reset onto the next pool window with the
+        reset observation in row 0 of the next block.  Returns the index of the block that was filled."""
+        b, eng = self.head, self.eng
+        eng.collect(self.mlp, self.T - eng.current_step, self.obs[b], self.actions[b], self.reward[b], self.done[b], self.mask[b])
+        nb = (b + 1) % self.cap
+        self.offset = (self.offset + self.offset_stride) % self.M
+        eng.stats_reset_f32(self.stats, self.obs[nb], self.offset)
+        self.head = nb
+        self.filled = min(self.filled + 1, self.cap - 1)
+        self.episodes += 1
+        return b
+
+    def terminal_observation(self, block):
+        """[E, D] float32: the observation after the block's last step (SB3's infos[i]["terminal_observation"])."""
+        return self.obs[block][self.T]
+
+    def sample(self, batch_size: int, rng: Optional[np.random.Generator] = None):
+        """Uniform transitions from the complete blocks as device tensors (torch only): (obs, action, reward, next_obs, done)."""
+        if self._torch is None:
+            raise RuntimeError("sample() gathers with torch; without it read the blocks directly (col.obs[b], col.actions[b], ...)")
+        torch = self._torch
+        rng = rng or np.random.default_rng()
+        blocks = [(self.head - 1 - i) % self.cap for i in range(self.filled)]
+        bi = rng.integers(0, len(blocks), batch_size)
+        t = torch.as_tensor(rng.integers(0, self.T, batch_size), device=self.stats.device)
+        e = torch.as_tensor(rng.integers(0, self.E, batch_size), device=self.stats.device)
+        out = [[], [], [], [], []]
+        for j, b in enumerate(blocks):
+            sel = torch.as_tensor(np.nonzero(bi == j)[0], device=self.stats.device)
+            if sel.numel() == 0:
+                continue
+            tt, ee = t[sel], e[sel]
+            out[0].append(self.obs[b][tt, ee]); out[1].append(self.actions[b][tt, ee]); out[2].append(self.reward[b][tt, ee])
+            out[3].append(self.obs[b][tt + 1, ee]); out[4].append(self.done[b][tt, ee])
+        return tuple(torch.cat(x) for x in out)
+
+    def close(self):
+        self.eng.mlp_destroy(self.mlp)

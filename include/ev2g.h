@@ -258,6 +258,9 @@ const char *ev2g_fallback_reason(const ev2g_handle *h);
  * generic kernel.
  * Results are identical in all three (tests/test_round3_gpu.py); EV2G_NO_FULL / EV2G_NO_WIDE in the environment at load time force 0 / 1. */
 int ev2g_last_launch_specialisation(const ev2g_handle *h);
+/* When the last fast-path launch got the general instantiation (0): what the caller passed or configured that ruled the full one out (the
+ * first such thing), "" otherwise.  The Python Engine warns once with it: the general instantiation is ~20 % slower, silently. */
+const char *ev2g_last_launch_general_reason(const ev2g_handle *h);
 /* data-dependent faults recorded since the last reset (per-env flag word, device side):
  * returns 0 or EV2G_ERR_OVERCURRENT; synchronises the stream. */
 int ev2g_check_faults(ev2g_handle *h, int32_t *first_bad_env);
@@ -265,6 +268,14 @@ int ev2g_check_faults(ev2g_handle *h, int32_t *first_bad_env);
 /* ---- episode statistics (get_statistics utils.py:12-123) ------------------------------------ */
 /* stats [E,EV2G_N_STATS] float64 DEVICE pointer, key order = ev2g_stat_name(i). */
 int ev2g_get_stats(ev2g_handle *h, double *stats);
+/* ev2g_get_stats followed by ev2g_reset_ex(h, obs, scenario_offset) in ONE kernel launch: what an auto-resetting vectorised env does at an
+ * episode end (terminal info = get_statistics(), then reset(); ev2gym_env.py:243-331 + utils.py:12-123).  The wavefront that computed an env's
+ * statistics re-arms that env on the new pool window; `obs` (DEVICE, may be NULL) receives the reset observation like ev2g_reset_ex. */
+int ev2g_get_stats_reset(ev2g_handle *h, double *stats, double *obs, int64_t scenario_offset);
+/* The same with the reset observation as float32 (the policy-network side of ev2g_collect / ev2g_rollout), and the plain reset with a float32
+ * observation: `obs32` DEVICE [E, D] or NULL. */
+int ev2g_get_stats_reset_f32(ev2g_handle *h, double *stats, float *obs32, int64_t scenario_offset);
+int ev2g_reset_f32(ev2g_handle *h, float *obs32, int64_t scenario_offset);
 const char *ev2g_stat_name(int i);
 
 /* ---- multi-GPU: one process per GPU, envs sharded, statistics gathered over RCCL ---------------
@@ -338,6 +349,22 @@ int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward,
 /* Segments that contain no episode end are captured once as a HIP graph (keyed by their full launch signature) and replayed;
  * EV2G_ROLLOUT_GRAPHS=0 in the environment falls back to plain launches.  Number of graph replays so far: */
 long long ev2g_rollout_graph_launches(const ev2g_handle *h);
+
+/* Off-policy ROLLOUT COLLECTION into device memory (the collect_rollouts() half of an SB3 DDPG / TD3 / SAC loop,
+ * train_stable_baselines.py:62-130): k_steps x (actor forward -> env step) whose transitions land directly in the caller's device arrays --
+ * no host copy, no staging copy: the actor reads observation row i and writes action row i, the step kernel reads that action row and writes
+ * observation row i + 1, reward / done / mask row i.  With next_obs[i] = obs[i + 1] these arrays ARE a replay-buffer segment (SB3's
+ * ReplayBuffer(optimize_memory_usage=True) layout).  obs[0] is input: the observation the first action is computed from (the reset
+ * observation, or the last row of the previous segment).  The segment must end at or before the episode end; statistics, the reset and
+ * the terminal observation (= the segment's last observation row) are the caller's (ev2g_get_stats_reset).  All pointers DEVICE. */
+typedef struct {
+    float *obs;         /* [k_steps + 1, E, D]; row 0 read, rows 1.. written */
+    float *actions;     /* [k_steps, E, P] written */
+    double *reward;     /* [k_steps, E] written */
+    uint8_t *done;      /* [k_steps, E] written */
+    uint8_t *mask;      /* [k_steps, E, P] written */
+} ev2g_transitions;
+int ev2g_collect(ev2g_handle *h, const ev2g_mlp *m, int k_steps, const ev2g_transitions *tr);
 
 /* ---- plain device-memory helpers so a ctypes host needs no other HIP binding --------------- */
 void *ev2g_malloc(ev2g_handle *h, size_t bytes);
