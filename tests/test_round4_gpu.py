@@ -209,7 +209,7 @@ def test_device_replay_collector_against_the_oracle(kind, with_torch):
         assert np.array_equal(obs[0], o.astype(np.float32)), "reset observation (row 0)"
         for t in range(T):
             ref_a = mlp_forward_numpy(obs[t], w, lo, bf16=True)
-            assert np.abs(act[t] - ref_a).max() <= 3e-3, f"action row {t}"
+            assert np.abs(act[t] - ref_a).max() <= 2e-2, f"action row {t}"   # (bf16 operands; the numpy mimic and the MFMA chain add in different orders)
             o, r, d, mk, rc = ora.step(act[t].astype(np.float64))
             assert rc == 0
             assert np.array_equal(obs[t + 1], o.astype(np.float32)), f"observation row {t + 1}"
