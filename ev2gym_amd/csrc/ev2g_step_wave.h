@@ -396,8 +396,16 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     // table entry and session record are independent loads: one memory round trip, not two.  The look-up
                     // is unconditional (clamped index); whether it applies is decided where it is used.
                     const int li = (lut_id >= 0) ? ev_lut_index(lut_id, amps_h) : -1;
+#ifdef EV2G_X_REC0
+                    double lut_raw = ldg32<double>(S->lut, (li >= 0) ? 8u : 0u);
+#else
                     double lut_raw = ldg32<double>(S->lut, (unsigned)max(li, 0) * 8u);
+#endif
+#ifdef EV2G_X_REC0   /* ablation only (wrong results): every worker reads session 0's record -- what the phase costs without its L2 round trip */
+                    const unsigned r8 = 0u;
+#else
                     const unsigned r8 = (unsigned)s_ss[h] * (unsigned)sizeof(SessRec);
+#endif
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
                     EvRes o;

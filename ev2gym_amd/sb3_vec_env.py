@@ -257,8 +257,11 @@ class DeviceReplayCollector:
         return b
 
     def terminal_observation(self, block):
-        """[E, D] float32: the observation after the block's last step (SB3's infos[i]["terminal_observation"])."""
-        return self.obs[block][self.T]
+        """[E, D] float32: the observation after the block's last step (SB3's infos[i]["terminal_observation"]) -- a device view of the block's
+        last row with torch, a host copy of it otherwise."""
+        if self._torch is not None:
+            return self.obs[block][self.T]
+        return self.obs[block].to_host()[self.T]
 
     def sample(self, batch_size: int, rng: Optional[np.random.Generator] = None):
         """Uniform transitions from the complete blocks as device tensors (torch only): (obs, action, reward, next_obs, done)."""
