@@ -62,7 +62,6 @@ struct ev2g_handle {
     bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
     bool no_full = false, no_wide = false;      // EV2G_NO_FULL / EV2G_NO_WIDE at load time: A/B and routing tests only
     int last_spec = -1;                         // ev2g_last_launch_specialisation
-    bool last_staged = false;                   // ... and whether that launch staged session records in LDS
     const char *general_reason = "";            // ev2g_last_launch_general_reason
     bool pow2_dt = false;                       // 60 / timescale is a power of two (15, 30, 60 minutes): compiled into ev2g_step_v2<.., 1>
     std::string kernel_name;                    // the step kernel ev2g_load_scenarios selected (ev2g_kernel_name)
@@ -199,7 +198,6 @@ int ev2g_current_step(const ev2g_handle *h) { return h ? h->current_step : 0; }
 const char *ev2g_kernel_name(const ev2g_handle *h) { return (h && h->loaded) ? h->kernel_name.c_str() : ""; }
 const char *ev2g_fallback_reason(const ev2g_handle *h) { return (h && h->loaded) ? h->fallback_reason.c_str() : ""; }
 int ev2g_last_launch_specialisation(const ev2g_handle *h) { return (h && h->loaded) ? h->last_spec : -1; }
-int ev2g_last_launch_staged(const ev2g_handle *h) { return (h && h->loaded && h->last_staged) ? 1 : 0; }
 const char *ev2g_last_launch_general_reason(const ev2g_handle *h) { return (h && h->loaded && h->last_spec == 0) ? h->general_reason : ""; }
 
 static const char *kStatNames[EV2G_N_STATS] = {
@@ -846,10 +844,7 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         // ... and: SoC log on, one observation-head column pair per lane at most (PublicPST has no head table), three lanes for the history store
         const bool wide = full && (h->cfg.flags & EV2G_FLAG_LOG_SOC) && s.P >= 3 && !h->no_wide &&
                           s.P >= (s.state_kind == EV2G_STATE_PUBLIC_PST ? 3 : (s.state_kind == EV2G_STATE_V2G_PROFIT_MAX_LOADS ? 30 : 10));
-        // ... and, for launches of several steps: session records staged in LDS (FULLK = 3; a single step would stage and never reuse)
-        const bool staged = wide && f64io && k > 1 && !std::getenv("EV2G_NO_STAGED");
         h->last_spec = (full && std::min(s.reward_kind, 3) != 3) ? (wide ? 2 : 1) : 0;
-        h->last_staged = staged;
         {   // why not the full instantiation: the FIRST thing the caller passed (or configured) that rules it out -- ev2g_last_launch_general_reason
             const char *why = "";
             if (!full) {
@@ -872,9 +867,6 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
                                h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
         else if (full && RK != 3 && f32io)                                                                                  \
             hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), true, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
-                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
-        else if (full && RK != 3 && wide && staged)                                                                         \
-            hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), false, 3>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
                                h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
         else if (full && RK != 3 && wide)                                                                                   \
             hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), false, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \

@@ -261,9 +261,6 @@ int ev2g_last_launch_specialisation(const ev2g_handle *h);
 /* When the last fast-path launch got the general instantiation (0): what the caller passed or configured that ruled the full one out (the
  * first such thing), "" otherwise.  The Python Engine warns once with it: the general instantiation is ~20 % slower, silently. */
 const char *ev2g_last_launch_general_reason(const ev2g_handle *h);
-/* 1 when the last fast-path launch was a full + wide launch of SEVERAL steps: those additionally keep the attached EVs' session records in
- * LDS for the whole launch (the battery maths then reads no global memory); results are identical.  EV2G_NO_STAGED in the environment turns it off. */
-int ev2g_last_launch_staged(const ev2g_handle *h);
 /* data-dependent faults recorded since the last reset (per-env flag word, device side):
  * returns 0 or EV2G_ERR_OVERCURRENT; synchronises the stream. */
 int ev2g_check_faults(ev2g_handle *h, int32_t *first_bad_env);

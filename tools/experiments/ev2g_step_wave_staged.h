@@ -1,3 +1,13 @@
+// tools/experiments/ev2g_step_wave_staged.h -- NOT part of the build.  Round-4 experiment (measured negative): the fast-path kernel with a fourth
+// specialisation level (FULLK = 3) that keeps the attached EVs session records in LDS slots for the whole launch (20 slots per wavefront, 9 chunks of
+// 16 bytes each: record + tail entry; co-operative copy by nine lanes per session; total energy and |energy| in the port lane registers; phase C
+// reads arrival / departure fields, battery size and potential term from the slot).  Parity: the whole GPU suite green (513 tests).  Time, cfg2
+// persistent: 3.57 -> 3.93 us/step (+10 %); cfg3 4.12 -> 4.59.  Phase timing (profiles/r04_phase_cfg2_staged.txt): the battery-maths phase
+// 4 080 -> 3 767 ticks (its efficiency-table load still pays an L2 round trip), but phase A 1 409 -> 2 090 (slot allocation: ballots, readlanes,
+// four unrolled uniform branches every step) and phase C 1 779 -> 2 615 (four more 16-byte LDS reads per lane and the slot hand-back).  The first form
+// (table entry and record copy consumed inside phase A) was worse still: a load consumed in phase A waits for the store drain of the step before
+// (loads and stores share vmcnt).  An ablation in which every worker reads record 0 (L1 hits, no extra work) ran 9 % faster -- the bound this
+// design could not realise.
 // ev2g_step_wave.h -- fast path of the step kernel for the common shape: P <= 64 ports per env, one transformer,
 // single-port chargers (BASELINE cfg2 / cfg3 / cfg5 and the reference's shipped YAML files).
 //
@@ -18,9 +28,16 @@
 #define EV2G_WAVE_BLOCK 256
 #endif
 
+#define EV2G_WAVE_SLOTS 20   // session slots per WAVEFRONT in the kernels that stage session records in LDS (FULLK = 3)
+#define EV2G_WAVE_SLOT_CHUNKS 9   // 16-byte chunks per slot: the 128-byte record + its 16-byte tail entry
 __host__ __device__ inline size_t ev2g_wave_lds_bytes(int envs_per_group) {
     const size_t NS = EV2G_WAVE_BLOCK;
-    return sizeof(double) * (EV2G_NQ * (NS + 8) + 7 * NS + 7 * (size_t)envs_per_group + 4 * 64) + sizeof(int) * (6 * NS + 8);
+    const size_t general = sizeof(double) * (EV2G_NQ * (NS + 8) + 7 * NS + 7 * (size_t)envs_per_group + 4 * 64) + sizeof(int) * (6 * NS + 8);
+    // staged-record layout: four per-port arrays less (total energy and |energy| live in the port's own lane's registers there, battery size and
+    // potential term in the slot), two int arrays less (the window), plus EV2G_WAVE_SLOT_CHUNKS x 16 bytes for EV2G_WAVE_SLOTS sessions per wavefront
+    const size_t staged = sizeof(double) * (EV2G_NQ * (NS + 8) + 3 * NS + 7 * (size_t)envs_per_group + 4 * 64 + 2 * EV2G_WAVE_SLOT_CHUNKS * (size_t)EV2G_WAVE_SLOTS * (NS / 64)) +
+                          sizeof(int) * (4 * NS + 8);
+    return general > staged ? general : staged;
 }
 
 // Global accesses as  uniform base (an SGPR pair) + 32-bit unsigned BYTE offset (one VGPR):  the
@@ -98,6 +115,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                                                                      int k_steps, int auto_reset, WaveArgs wa) {
     extern __shared__ double lds[];
     constexpr bool FULL = FULLK >= 1, WIDE = FULLK >= 2;
+    // STG (FULLK = 3, whole-episode launches): the battery maths reads its session records from LDS -- see "staged records" below
+    constexpr bool STG = FULLK >= 3;
     constexpr bool F64 = FULL && !IO32, F32 = FULL && IO32;   // full with float64 actions in / observations out, or with the float32 hand-over
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
     const unsigned long long pt_k0 = __builtin_readcyclecounter();   // slot 7 := prologue, slot 6 := epilogue (tools/phase_timing.py --outer)
@@ -125,14 +144,35 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     const int e0 = grp * G;
     double *stage = lds;                                   // [NQ][RS] per-port step results, by home index (= tid)
     double *s_cap = stage + (size_t)EV2G_NQ * RS;
-    double *s_tot = s_cap + NS, *s_prev = s_tot + NS, *s_bcap = s_prev + NS, *s_potc = s_bcap + NS;
-    double *s_amps = s_potc + NS, *s_abse = s_amps + NS;
-    double *eacc = s_abse + NS;                            // [G][7] episode accumulators + charge_power_potential[t], [t-1], per env
-    double *s_cst = eacc + 7 * G;                          // [4][64] per-charger gates and clamps (rarely changing operands
+    // "staged records" (STG, whole-episode launches): nothing of a session is fetched from global memory more than once per launch.  A port
+    // that holds an EV or receives one at the end of the step takes one of the EV2G_WAVE_SLOTS slots of its wavefront (phase A) and copies
+    // the session's record and tail entry into it; the slot is given back when the EV has left.  From then on the battery maths reads its
+    // operands from the slot, phase C the arrival / departure fields, the battery size and the potential term; the efficiency-table entry of
+    // the step is fetched by the port's own lane in phase A and handed over in a stage row.  Measured before the change: ~2 000 cycles of
+    // operand wait in the battery-maths phase (an L2 round trip behind two LDS ones) next to ~2 000 of arithmetic; with the records' L2 round
+    // trip short-circuited (ablation: every worker reads record 0) the cfg2 episode ran 9 % faster.  The slots fit the 40 KB a workgroup may
+    // use because these kernels keep total energy and |energy| in the port's own lane's registers and the other per-EV constants in the slot;
+    // an EV that finds the pool empty (more than EV2G_WAVE_SLOTS EVs on the wavefront's ports) works from global memory like in the other
+    // kernels and asks again every step.
+    constexpr int NSLOT = EV2G_WAVE_SLOTS * (EV2G_WAVE_BLOCK / 64);
+    double *s_tot = nullptr, *s_prev, *s_bcap = nullptr, *s_potc = nullptr, *s_amps, *s_abse = nullptr, *eacc, *s_cst;
+    d2v *s_rec = nullptr;   // [EV2G_WAVE_SLOT_CHUNKS][NSLOT]: chunks 0..7 the session record, chunk 8 its tail entry
+    int *s_ta = nullptr, *s_td = nullptr, *s_ss, *s_cyc, *s_dirty, *items, *cnt;
+    if (STG) {
+        s_prev = s_cap + NS; s_amps = s_prev + NS;
+        eacc = s_amps + NS; s_cst = eacc + 7 * G;
+        s_rec = (d2v *)(s_cst + 4 * 64);
+        s_ss = (int *)(s_rec + EV2G_WAVE_SLOT_CHUNKS * NSLOT); s_cyc = s_ss + NS; s_dirty = s_cyc + NS; items = s_dirty + NS; cnt = items + NS;
+    } else {
+        s_tot = s_cap + NS; s_prev = s_tot + NS; s_bcap = s_prev + NS; s_potc = s_bcap + NS;
+        s_amps = s_potc + NS; s_abse = s_amps + NS;
+        eacc = s_abse + NS;                                // [G][7] episode accumulators + charge_power_potential[t], [t-1], per env
+        s_cst = eacc + 7 * G;                              // [4][64] per-charger gates and clamps (rarely changing operands
                                                            // kept out of the register file): imin-0.01, dmin, max power, min power
-    int *s_ta = (int *)(s_cst + 4 * 64);
-    int *s_td = s_ta + NS, *s_ss = s_td + NS, *s_cyc = s_ss + NS, *s_dirty = s_cyc + NS, *items = s_dirty + NS;
-    int *cnt = items + NS;  // cnt[2*(kk&1) + {0 charge, 1 discharge}]
+        s_ta = (int *)(s_cst + 4 * 64);
+        s_td = s_ta + NS; s_ss = s_td + NS; s_cyc = s_ss + NS; s_dirty = s_cyc + NS; items = s_dirty + NS;
+        cnt = items + NS;  // cnt[2*(kk&1) + {0 charge, 1 discharge}]
+    }
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const bool log_soc = WIDE ? true : (S->soc_log != nullptr);
     const bool log_cs = FULL ? false : (S->cs_profits != nullptr);   // EV2G_FLAG_LOG_CS_HISTORY: charger-level accumulators and histories (ev2gym_env.py:533-535)
@@ -161,6 +201,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     int r_ta = EV2G_INT_MAX, r_td = -1;
     double r_bcap = 1.0, r_potc = 0.0;
     double r_rb = 1.0;   // RN(1 / battery size) of the attached EV: the observation's cap / B goes through it (ev2g_fdiv2) in the full kernels
+    double r_tot = 0.0, r_abse = 0.0;   // STG: EV.total_energy_exchanged / abs_total_energy_exchanged of the attached EV (LDS arrays otherwise)
+    int r_slot = -1;                    // STG: this port's record slot in its wavefront's pool (-1: none)
+    unsigned free_slots = (1u << EV2G_WAVE_SLOTS) - 1u;   // STG: the wavefront's free slots (uniform)
     const unsigned l64 = (unsigned)g * (unsigned)sizeof(PortLine);   // this port's state line
     static_assert(sizeof(PortLine) == 64 && offsetof(PortLine, cap) == 16 && offsetof(PortLine, prev) == 32 && offsetof(PortLine, bcap) == 48, "PortLine layout");
     {
@@ -204,9 +247,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             // s_dirty: bits 0,1 = what the epilogue must write back; bits 8..23 = 1 + efficiency-table id of the attached EV,
             // so that the battery maths can issue the table look-up together with (not behind) the session-record load
             s_dirty[tid] = (int)((unsigned)hd.w >> 16) << 8;
-            s_cap[tid] = b1.x; s_tot[tid] = b1.y; s_prev[tid] = b2.x; s_abse[tid] = log_soc ? b2.y : 0.0;
+            s_cap[tid] = b1.x; s_prev[tid] = b2.x;
+            if (STG) { r_tot = b1.y; r_abse = log_soc ? b2.y : 0.0; } else { s_tot[tid] = b1.y; s_abse[tid] = log_soc ? b2.y : 0.0; }
             r_bcap = b3.x; r_potc = b3.y;
-            if (FULL) { if (body) r_rb = 1.0 / r_bcap; }
+            if (FULL && !STG) { if (body) r_rb = 1.0 / r_bcap; }
             else { s_bcap[tid] = r_bcap; s_potc[tid] = r_potc; }
         }
         if (head) {   // episode accumulators (continued from global memory) and charge_power_potential[t], in LDS
@@ -285,50 +329,59 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // Every prefetch is ONE unconditional load from a clamped (always valid) address; the conditions are applied
         // where the value is consumed.  A load inside a divergent branch whose result merges with a default makes the
         // compiler serialise on the destination register (write-after-write) with a full vmcnt(0) drain.
+        // (The loads themselves are EV2G_WAVE_PREFETCH_1 below: issued above phase A, or -- in the kernels that stage session records in
+        // LDS -- behind that phase's own loads, which must not queue up behind these streaming ones: vector loads return in order.)
         const bool more = (kk + 1 < k_steps) && (FULL || sstep < T || auto_reset);
         const int ec = valid ? e_l : e0;   // clamped env for idle lanes
         const int gc = valid ? g_l : e0 * P;
-        if (F64) {   // a running pointer instead of a 64-bit scalar product per step
-            a_next = ldg32_nt<double>(act_run + (more ? io.a_stride : 0), (unsigned)gc * 8u);
-            act_run += io.a_stride;
-        } else if (F32) {
-            a_next = (double)ldg32_nt<float>(act32_run + (more ? io.a_stride : 0), (unsigned)gc * 4u);
-            act32_run += io.a_stride;
-        } else
-        a_next = IO32 ? (double)ldg32_nt<float>(io.act32 + (long long)(io.step0 + (more ? kk + 1 : kk)) * io.a_stride, (unsigned)gc * 4u)
-                      : ldg32_nt<double>(io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride, (unsigned)gc * 8u);
         const int scn = ev2g_scn(ec, off, M);             // this env's scenario in the resident pool
         const unsigned eT64 = FULL ? hb_step : (unsigned)(scn * T) * 64u;  // its rows in the [M,T,8] step table
         const unsigned et64 = eT64 + (unsigned)t * 64u;
-        const d2v st0 = ldg32_nt<d2v>(S->step_tab, et64);                                  // charge price, discharge price
-        double pf_pch = st0.x, pf_pdis = st0.y;
-        // the transformer scalars only the head lane needs: ONE more load in which the head lane (q == 0) takes
-        // {inflexible + solar, max_power} and its neighbour takes {min_power, setpoint}; the head lane picks the
-        // neighbour's pair up with a DPP wave shift in phase E
-        d2v pf_tr = ldg32_nt<d2v>(S->step_tab, et64 + ((q_l == 0) ? 16u : 32u));
-        // observation head columns of this env, distributed over its P lanes as 16-byte column PAIRS: pair q, q+P
-        double pf_ob0 = 0.0;
-        d2v pf_h0 = {0.0, 0.0}, pf_h1 = {0.0, 0.0};
+        double pf_pch = 0.0, pf_pdis = 0.0, pf_ob0 = 0.0;
+        d2v pf_tr = {0.0, 0.0}, pf_h0 = {0.0, 0.0}, pf_h1 = {0.0, 0.0};
         constexpr int NHEAD = (SK == 1) ? 0 : (SK == 0 ? 60 : 20);   // 20 prices (+ 40 window columns)
         constexpr int NPAIR = NHEAD / 2;
-        if (SK == 1) {
-            pf_ob0 = ldg32_nt<double>(S->step_tab, eT64 + (unsigned)min(sstep, T - 1) * 64u + 40u);   // next setpoint; head lane only, masked by sstep < T
-        } else {
-            // observation head table [E, T+1, NHEAD]: |charge price| window (zero-padded) + load/PV/limit window, exactly
-            // the values of columns 2..2+NHEAD of the observation emitted at the end of step sstep-1 (state.py:65-83, :108-135)
-            const unsigned h8 = FULL ? hb_head + (unsigned)sstep * (unsigned)(NHEAD * 8) : (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
-            pf_h0 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l, NPAIR - 1) * 16u);
-            if (!WIDE && P < NPAIR) pf_h1 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l + P, NPAIR - 1) * 16u);   // (uniform)
+#define EV2G_WAVE_PREFETCH_1                                                                                                                  \
+        {                                                                                                                                     \
+            if (F64) {   /* a running pointer instead of a 64-bit scalar product per step */                                                  \
+                a_next = ldg32_nt<double>(act_run + (more ? io.a_stride : 0), (unsigned)gc * 8u);                                             \
+                act_run += io.a_stride;                                                                                                       \
+            } else if (F32) {                                                                                                                 \
+                a_next = (double)ldg32_nt<float>(act32_run + (more ? io.a_stride : 0), (unsigned)gc * 4u);                                    \
+                act32_run += io.a_stride;                                                                                                     \
+            } else                                                                                                                            \
+                a_next = IO32 ? (double)ldg32_nt<float>(io.act32 + (long long)(io.step0 + (more ? kk + 1 : kk)) * io.a_stride, (unsigned)gc * 4u) \
+                              : ldg32_nt<double>(io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride, (unsigned)gc * 8u);              \
+            const d2v st0 = ldg32_nt<d2v>(S->step_tab, et64);                                  /* charge price, discharge price */            \
+            pf_pch = st0.x; pf_pdis = st0.y;                                                                                                  \
+            /* the transformer scalars only the head lane needs: ONE more load in which the head lane (q == 0) takes {inflexible + solar,     \
+               max_power} and its neighbour takes {min_power, setpoint}; the head lane picks the neighbour's pair up with a DPP wave shift in  \
+               phase E */                                                                                                                     \
+            pf_tr = ldg32_nt<d2v>(S->step_tab, et64 + ((q_l == 0) ? 16u : 32u));                                                              \
+            /* observation head columns of this env, distributed over its P lanes as 16-byte column PAIRS: pair q, q+P */                     \
+            if (SK == 1) {                                                                                                                    \
+                pf_ob0 = ldg32_nt<double>(S->step_tab, eT64 + (unsigned)min(sstep, T - 1) * 64u + 40u);   /* next setpoint; head lane only */   \
+            } else {                                                                                                                          \
+                /* observation head table [E, T+1, NHEAD]: |charge price| window (zero-padded) + load/PV/limit window, exactly the values of  \
+                   columns 2..2+NHEAD of the observation emitted at the end of step sstep-1 (state.py:65-83, :108-135) */                      \
+                const unsigned h8 = FULL ? hb_head + (unsigned)sstep * (unsigned)(NHEAD * 8) : (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u; \
+                pf_h0 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l, NPAIR - 1) * 16u);                                                 \
+                if (!WIDE && P < NPAIR) pf_h1 = ldg32_nt<d2v>(S->head_tab, h8 + (unsigned)min(q_l + P, NPAIR - 1) * 16u);   /* (uniform) */   \
+            }                                                                                                                                 \
         }
+        EV2G_WAVE_PREFETCH_1
         // ---------------- A: home lanes, charger level (ev_charger.py:137-186) ----------------
         bool occ = false;
         double cap_before = 0.0;
         int ta_a = EV2G_INT_MAX, td_a = -1;   // this port's window as phase A saw it (idle lanes: no event)
+        double amps = 0.0;
+        int dirty_a = 0, ss_a = 0;
         if (valid) {
             // every LDS operand of the phase in one batch (one wait) instead of one round trip per branch
             int ta = FULL ? r_ta : s_ta[tid_l], td = FULL ? r_td : s_td[tid_l];
             double cap_b = s_cap[tid_l], c_thr = s_cst[0 * 64 + q_l], c_dmin = s_cst[1 * 64 + q_l];
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta), "+v"(td), "+v"(cap_b), "+v"(c_thr), "+v"(c_dmin));
+            if (STG) { dirty_a = s_dirty[tid_l]; ss_a = s_ss[tid_l]; }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta), "+v"(td), "+v"(cap_b), "+v"(c_thr), "+v"(c_dmin), "+v"(dirty_a), "+v"(ss_a));
             ta_a = ta; td_a = td;
             occ = (ta <= t) && (t <= td);
             if (log_soc && occ) cap_before = cap_b;
@@ -343,7 +396,50 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             const double x = fma(fma(-q5, 100000.0, n5), 1.0 / 100000.0, q5);   // rnd5 (ev_charger.py:157)
             const double ac = x * c_imax, ad = x * c_dmaxabs;
             const double amps_c = (ac < c_thr) ? 0.0 : ac, amps_d = (ad > c_dmin - 0.01) ? c_dmin : ad;
-            const double amps = (x > 0.0) ? amps_c : ((x < 0.0) ? amps_d : 0.0);
+            amps = (x > 0.0) ? amps_c : ((x < 0.0) ? amps_d : 0.0);
+        }
+        // STG, between the two halves of the phase: the loads the battery maths used to issue itself.  (1) A port whose EV starts its first
+        // step (or the launch's first step) takes a record slot of its wavefront and requests the record's seven chunks; (2) a port with
+        // work for the battery maths requests this step's efficiency-table entry.  Both are collected at the end of the phase and handed
+        // over through LDS; the streaming prefetches are issued BEHIND them (vector loads return in order).
+        // The copy itself is CO-OPERATIVE: a slot's nine 16-byte chunks are fetched by nine lanes (one chunk each), up to four sessions per
+        // wavefront and step side by side in 16-lane groups -- four registers per lane instead of thirty-six in the port's own lane (the phase
+        // has no room for those: they spilled).  A fifth new EV of the same step asks again next step.
+        d2v stg_chunk = {0.0, 0.0};
+        int stg_lut = -1, stg_n = 0, stg_dst = 0;
+        bool stg_act = false;
+        bool stage_now = false;
+        if (STG) {
+            stage_now = valid && r_slot < 0 && (occ || ta_a == sstep);   // an EV here, or one arriving at the end of this step, and no slot yet
+            unsigned long long need = __ballot(stage_now);
+            int st_ss[4] = {0, 0, 0, 0}, st_sl[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (need != 0ull && free_slots != 0u) {   // (uniform; about one arrival per wavefront every fourth step)
+                    const int l = (int)__builtin_ctzll(need);
+                    need &= need - 1ull;
+                    const int sl = (int)__builtin_ctz(free_slots);
+                    free_slots &= ~(1u << sl);
+                    if (lane_l == l) r_slot = sl;
+                    st_ss[j] = __builtin_amdgcn_readlane(ss_a, l);
+                    st_sl[j] = wv * EV2G_WAVE_SLOTS + sl;
+                    stg_n = j + 1;
+                }
+            }
+            stage_now = stage_now && r_slot >= 0;   // (no slot: this EV works from global memory this step and asks again)
+            if (stg_n > 0) {   // (uniform)
+                const int k = lane_l >> 4, c = lane_l & 15;
+                const int my_ss = (k == 0) ? st_ss[0] : ((k == 1) ? st_ss[1] : ((k == 2) ? st_ss[2] : st_ss[3]));
+                const int my_sl = (k == 0) ? st_sl[0] : ((k == 1) ? st_sl[1] : ((k == 2) ? st_sl[2] : st_sl[3]));
+                stg_act = k < stg_n && c < EV2G_WAVE_SLOT_CHUNKS;
+                stg_dst = c * NSLOT + my_sl;
+                // chunks 0..7: the record; chunk 8: the tail entry
+                const gcptr src = (c < 8) ? (gcptr)S->rec + ((size_t)my_ss * sizeof(SessRec) + 16 * c) : (gcptr)S->tail + (size_t)my_ss * sizeof(SessTail);
+                if (stg_act) stg_chunk = *(const d2v __attribute__((address_space(1))) *)src;
+                if (stage_now) stg_lut = ldg32<int>(S->ss_lut, (unsigned)ss_a * 4u);
+            }
+        }
+        if (valid) {
             s_amps[tid_l] = amps;
             stage[0 * RS + tid_l] = 0.0;
             stage[4 * RS + tid_l] = 0.0;
@@ -361,7 +457,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         d2v pf_c2 = {0.0, 0.0}, pf_c7 = {0.0, 0.0};   // an arrival: {B, RN(1/B)}, {cap0, potc} of the arriving session's record ...
         int pf_lut = -1;                              // ... and its efficiency-table id
         i4v pf_tl = {0, 0, 0, 0};                     // a departure: {des (two words), next window} of the leaving session's tail entry
-        if (__ballot(ev_dep || ev_arr) != 0ull) {   // (uniform)
+        if (!STG && __ballot(ev_dep || ev_arr) != 0ull) {   // (uniform; STG: phase C takes these fields from the slot)
             const unsigned sse = (ev_dep || ev_arr) ? (unsigned)s_ss[tid_l] : 0u;
             static_assert(offsetof(SessRec, B) == 40 && offsetof(SessRec, rB) == 48 && offsetof(SessRec, cap0) == 112 && offsetof(SessRec, potc) == 120 && sizeof(SessTail) == 16 &&
                           offsetof(SessTail, nt_arr) == 8, "SessRec / SessTail layout");
@@ -390,14 +486,70 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 int h = -1;
                 if (i < nch) h = items[i];
                 else if (i >= nchp) h = items[NS - 1 - (i - nchp)];
-                if (h >= 0) {
+                if (STG && h >= 0) {   // every operand from LDS: the record from its slot, the table entry from the port's own lane (phase A)
+                    const double amps_h = s_amps[h];
+                    const int dirty_h = s_dirty[h];
+                    const double cap0 = s_cap[h], prev0 = s_prev[h];
+                    const int cyc0 = s_cyc[h];
+                    const int lut_id = ((dirty_h >> 8) & 0xffff) - 1, slot = ((dirty_h >> 24) & 0xff) - 1;   // slot -1: the wavefront's pool was exhausted
+                    // the step's efficiency-table entry: the one global load left in this phase (the tables are a few KB and, with the records
+                    // out of the way, stay in the vector L1)
+                    const int li = (lut_id >= 0) ? ev_lut_index(lut_id, amps_h) : -1;
+                    const double lut_raw = ldg32<double>(S->lut, (unsigned)max(li, 0) * 8u);
+                    const double lutv = (li >= 0) ? lut_raw : 1.0 / 100.0;
+                    const int sc = max(slot, 0);
+                    const bool no_slot = __ballot(slot < 0) != 0ull;   // (rare) an EV without a slot: its record from global memory, like the other kernels
+                    const unsigned r8 = (unsigned)s_ss[h] * (unsigned)sizeof(SessRec);
+                    EvRes o;
+                    if (i < nchp) {   // (uniform: the discharge items start on a wavefront boundary)
+                        union { SessRec r; d2v v[8]; } u;
+#pragma unroll
+                        for (int c = 0; c < 5; c++) u.v[c] = s_rec[c * NSLOT + sc];
+                        if (no_slot) {
+                            if (slot < 0) {
+#pragma unroll
+                                for (int c = 0; c < 5; c++) u.v[c] = ldg32<d2v>(S->rec, r8 + 16u * c);
+                            }
+                        }
+                        o = ev_math_charge(u.r, lutv, amps_h, cap0, prev0, 0.0, cyc0, sixty_over_dt, dt_over_60, pow2_dt, lut_id >= 0);
+                    } else {
+                        union { SessRec r; d2v v[8]; } u;
+#pragma unroll
+                        for (int c = 3; c < 7; c++) u.v[c] = s_rec[c * NSLOT + sc];
+                        if (no_slot) {
+                            if (slot < 0) {
+#pragma unroll
+                                for (int c = 3; c < 7; c++) u.v[c] = ldg32<d2v>(S->rec, r8 + 16u * c);
+                            }
+                        }
+                        o = ev_math_discharge(u.r, lutv, amps_h, cap0, prev0, 0.0, cyc0, dtd, lut_id >= 0, S->rdt, S->dt_fdiv != 0);
+                    }
+                    if (o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0) s_dirty[h] = dirty_h | 1;
+                    s_cap[h] = o.cap;
+                    s_prev[h] = o.prev_power;
+                    s_cyc[h] = o.cycles;
+                    s_amps[h] = o.energy;   // (total energy and |energy| are accumulated by the port's own lane in phase C)
+                    stage[0 * RS + h] = o.energy * 60.0 / dtd;
+                    stage[(i < nch ? 4 : 5) * RS + h] = fabs(o.energy);
+                    stage[6 * RS + h] = (double)o.emerg;
+                    stage[7 * RS + h] = o.current;
+                }
+                if (!STG && h >= 0) {
                     const double amps_h = s_amps[h];
                     const int lut_id = ((s_dirty[h] >> 8) & 0xffff) - 1;
                     // table entry and session record are independent loads: one memory round trip, not two.  The look-up
                     // is unconditional (clamped index); whether it applies is decided where it is used.
                     const int li = (lut_id >= 0) ? ev_lut_index(lut_id, amps_h) : -1;
+#ifdef EV2G_X_REC0
+                    double lut_raw = ldg32<double>(S->lut, (li >= 0) ? 8u : 0u);
+#else
                     double lut_raw = ldg32<double>(S->lut, (unsigned)max(li, 0) * 8u);
+#endif
+#ifdef EV2G_X_REC0   /* ablation only (wrong results): every worker reads session 0's record -- what the phase costs without its L2 round trip */
+                    const unsigned r8 = 0u;
+#else
                     const unsigned r8 = (unsigned)s_ss[h] * (unsigned)sizeof(SessRec);
+#endif
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
                     EvRes o;
@@ -443,7 +595,15 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // across the loop back-edge for the next action -- no longer cost a conservative vmcnt(0) drain
         asm volatile("" : "+v"(a_next), "+v"(pf_pch), "+v"(pf_pdis), "+v"(pf_tr), "+v"(pf_ob0), "+v"(pf_h0), "+v"(pf_h1));
         asm volatile("" : "+v"(pf_c2), "+v"(pf_c7), "+v"(pf_tl), "+v"(pf_lut));
+        if (STG && stg_n > 0) {   // (uniform) the session slots taken in phase A: their chunks have arrived with the other prefetches
+            asm volatile("" : "+v"(stg_chunk), "+v"(stg_lut));
+            if (stg_act) s_rec[stg_dst] = stg_chunk;
+            // slot + 1 in bits 24..31; the session's efficiency-table id in bits 8..23 (an EV that is already here has it there; one that
+            // arrives at the end of the step finds it there)
+            if (stage_now) s_dirty[tid_l] = (s_dirty[tid_l] & 0xff) | ((stg_lut + 1) << 8) | ((wv * EV2G_WAVE_SLOTS + r_slot + 1) << 24);
+        }
         bool occ_any = false;   // an EV on this port before or after the step
+        bool departed = false;
         if (valid) {
             double profit = 0.0, satpen = 0.0, pot = 0.0;
             // every LDS operand of this phase in ONE batch (one wait), whichever branch consumes it: read one by one behind the
@@ -451,11 +611,36 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             int ta = FULL ? r_ta : s_ta[tid_l], td = FULL ? r_td : s_td[tid_l], ss_now = s_ss[tid_l];
             double cap = s_cap[tid_l];
             double b_energy = s_amps[tid_l], b_cur = stage[7 * RS + tid_l], b_ech = stage[4 * RS + tid_l], b_edis = stage[5 * RS + tid_l];
-            double b_bcap = FULL ? r_bcap : s_bcap[tid_l], b_potc = FULL ? r_potc : s_potc[tid_l], b_tot = (SK == 1) ? s_tot[tid_l] : 0.0;
+            double b_bcap = FULL ? r_bcap : s_bcap[tid_l], b_potc = FULL ? r_potc : s_potc[tid_l], b_tot = (SK == 1 && !STG) ? s_tot[tid_l] : 0.0;
             double c_maxp = s_cst[2 * 64 + q_l], c_minp = s_cst[3 * 64 + q_l];
+            double b_rb = r_rb;
+            if (STG) {   // the slot's {B, 1/B}, {cap0, potc} and tail entry: of the EV that is here, or of the one that arrives at the end of this step
+                const int sl = max(wv * EV2G_WAVE_SLOTS + r_slot, 0);
+                const d2v x2 = s_rec[2 * NSLOT + sl], x3 = s_rec[3 * NSLOT + sl];
+                pf_c7 = s_rec[7 * NSLOT + sl];
+                const d2v x8 = s_rec[8 * NSLOT + sl];
+                pf_c2 = (d2v){x2.y, x3.x};
+                pf_tl = (i4v){__double2loint(x8.x), __double2hiint(x8.x), __double2loint(x8.y), __double2hiint(x8.y)};
+                pf_lut = ((s_dirty[tid_l] >> 8) & 0xffff) - 1;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta), "+v"(td), "+v"(ss_now), "+v"(cap), "+v"(b_energy), "+v"(b_cur), "+v"(b_ech), "+v"(b_edis),
-                         "+v"(b_bcap), "+v"(b_potc), "+v"(b_tot), "+v"(c_maxp), "+v"(c_minp));
-            bool departed = false;
+                         "+v"(b_bcap), "+v"(b_potc), "+v"(b_tot), "+v"(c_maxp), "+v"(c_minp), "+v"(pf_c2), "+v"(pf_c7), "+v"(pf_tl), "+v"(pf_lut));
+            if (STG) {
+                const bool fb = (occ || ta == sstep) && r_slot < 0;   // (rare) no slot: the same fields from global memory
+                if (__ballot(fb) != 0ull) {
+                    if (fb) {
+                        const unsigned sse = (unsigned)ss_now;
+                        pf_c2 = ldg32<d2v_a8>(S->rec, sse * (unsigned)sizeof(SessRec) + 40u); pf_c7 = ldg32<d2v>(S->rec, sse * (unsigned)sizeof(SessRec) + 112u);
+                        pf_tl = ldg32<i4v>(S->tail, sse * 16u); pf_lut = ldg32<int>(S->ss_lut, sse * 4u);
+                    }
+                }
+                b_bcap = pf_c2.x; b_rb = pf_c2.y; b_potc = pf_c7.y;
+            }
+            if (STG) {   // EV.total_energy_exchanged / abs_total_energy_exchanged (ev.py:177-180) by the port's own lane: an idle or empty port adds an exact 0
+                r_tot += b_energy;
+                if (log_soc) r_abse += fabs(b_energy);
+                b_tot = r_tot;
+            }
             if (occ) {
                 const double energy = b_energy;
                 const double current = b_cur;
@@ -484,14 +669,15 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                     __hip_atomic_fetch_add((double __attribute__((address_space(1))) *)(PA(EV2G_PS_SATSUM) + g8), score,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     stg32<double>(slabS, (unsigned)ss * 8u, cap);
-                    if (log_soc) stg32<double>((slabS + SS8), (unsigned)ss * 8u, s_abse[tid_l]);
+                    if (log_soc) stg32<double>((slabS + SS8), (unsigned)ss * 8u, STG ? r_abse : s_abse[tid_l]);
                     ta = pf_tl.z; td = pf_tl.w;   // window of the port's next session
                     departed = true;
                     if (FULL) { r_ta = ta; r_td = td; } else { s_ta[tid_l] = ta; s_td[tid_l] = td; }
                     ss_now = (ta != EV2G_INT_MAX) ? ss + 1 : -1;
                     s_ss[tid_l] = ss_now;
                     s_cyc[tid_l] = 0;
-                    s_dirty[tid_l] |= 2;
+                    if (STG) s_dirty[tid_l] = (s_dirty[tid_l] & 0x00ffffff) | 2;   // (the record slot is given back below)
+                    else s_dirty[tid_l] |= 2;
                 }
             }
             if (ta == sstep) {  // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
@@ -503,15 +689,17 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 cap = pf_c7.x;
                 const double B = pf_c2.x;
                 const double potc = pf_c7.y;   // v * min(pacmax*1000/v, charger max current) / 1000 (utils.py:773-777), evaluated when the session was loaded
-                s_cap[tid_l] = cap; s_tot[tid_l] = 0.0; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0;
-                if (FULL) { r_bcap = B; r_potc = potc; r_rb = pf_c2.y; } else { s_bcap[tid_l] = B; s_potc[tid_l] = potc; }
-                s_abse[tid_l] = 0.0;
+                s_cap[tid_l] = cap; s_prev[tid_l] = 0.0; s_cyc[tid_l] = 0;
+                if (STG) r_tot = 0.0; else s_tot[tid_l] = 0.0;
+                b_rb = pf_c2.y;
+                if (STG) { /* the slot holds them */ } else if (FULL) { r_bcap = B; r_potc = potc; r_rb = pf_c2.y; } else { s_bcap[tid_l] = B; s_potc[tid_l] = potc; }
+                if (STG) r_abse = 0.0; else s_abse[tid_l] = 0.0;
                 b_bcap = B; b_potc = potc; b_tot = 0.0;
                 const int lut_new = pf_lut;
                 stg32<d2v>(wa.lines, l64 + 48u, (d2v){B, potc});   // (the table id travels in s_dirty and reaches the line's head chunk in the epilogue)
                 stg32<double>(PA(EV2G_PS_PENERGY), g8, 0.0);
                 stg32<double>(PA(EV2G_PS_PCURRENT), g8, 0.0);
-                s_dirty[tid_l] = (s_dirty[tid_l] & 3) | 1 | ((lut_new + 1) << 8);
+                s_dirty[tid_l] = (s_dirty[tid_l] & (STG ? 0xff000003 : 3)) | 1 | ((lut_new + 1) << 8);   // (STG: the slot taken in phase A stays)
             }
             const bool occ_after = (ta <= sstep) && (sstep <= td);
             if (RK == 3 && occ_after && S->reward_kind >= 9) {   // (pst_)V2G_profitmaxV2: every connected EV (reward.py:173-195)
@@ -523,7 +711,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             if (FULL || mask) stg32<uint8_t>(mask, (unsigned)g_l, occ_after ? 1 : 0);
             double o0 = 0.0, o1 = 0.0, o2 = 0.0;
             if (occ_after) {
-                const double soc = FULL ? ev2g_fdiv2(cap, b_bcap, r_rb) : cap / b_bcap;   // bit-identical (ev2g_device.h)
+                const double soc = FULL ? ev2g_fdiv2(cap, b_bcap, b_rb) : cap / b_bcap;   // bit-identical (ev2g_device.h)
                 if (SK == 1) { o0 = (soc == 1.0) ? 1.0 : 0.5; o1 = b_tot; o2 = (double)(sstep - ta); }
                 else { o0 = soc; o1 = (double)(td - sstep); }
                 if (soc < 1.0 && td > sstep) pot = b_potc;  // utils.py:771
@@ -550,6 +738,15 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             stage[1 * RS + tid_l] = profit;
             stage[2 * RS + tid_l] = satpen;
             stage[3 * RS + tid_l] = pot;
+        }
+        if (STG) {   // departed EVs give their record slots back to the wavefront's pool
+            unsigned long long dm = __ballot(departed && r_slot >= 0);
+            while (dm) {   // (uniform)
+                const int l = (int)__builtin_ctzll(dm);
+                dm &= dm - 1ull;
+                free_slots |= 1u << __builtin_amdgcn_readlane(r_slot, l);
+            }
+            if (departed) r_slot = -1;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wavefront's LDS writes are visible to itself
         PT_MARK(3)
@@ -759,8 +956,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const unsigned g8 = (unsigned)g * 8u;
         if (d & 3) stg32<i4v>(wa.lines, l64, (i4v){FULL ? r_ta : s_ta[tid], FULL ? r_td : s_td[tid], s_ss[tid], ev2g_line_pack(s_cyc[tid], ((d >> 8) & 0xffff) - 1)});
         if (d & 1) {
-            stg32<d2v>(wa.lines, l64 + 16u, (d2v){s_cap[tid], s_tot[tid]});
-            stg32<d2v>(wa.lines, l64 + 32u, (d2v){s_prev[tid], s_abse[tid]});
+            stg32<d2v>(wa.lines, l64 + 16u, (d2v){s_cap[tid], STG ? r_tot : s_tot[tid]});
+            stg32<d2v>(wa.lines, l64 + 32u, (d2v){s_prev[tid], STG ? r_abse : s_abse[tid]});
         }
     }
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
