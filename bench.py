@@ -372,6 +372,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=112)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
+    ap.add_argument("--keep-pool-order", action="store_true", help="do not co-schedule scenarios with similar busy windows (ScenarioBatch.sorted_by_busy_window)")
     ap.add_argument("--pool", type=int, default=0, help="scenario pool size as a multiple of --envs (default 8; cfg4: 2): every "
                     "episode steps a fresh window of the resident pool (the per-reset scenario draw of the reference)")
     ap.add_argument("--launch", default="auto", choices=["auto", "per_step", "persistent"])
@@ -434,6 +435,11 @@ def main():
     rk, sk = _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]]
     # every rank draws its own pool of scenarios, with the library's own generator (ev2g_generate: the stream ev2g_pool_refill continues on the device)
     batch = generate_native(wl["gen"](M, args.seed * 1000 + rank))
+    if not args.keep_pool_order:
+        # The order of an i.i.d. pool is arbitrary; inside every window of E scenarios (one episode's env set) scenarios with similar busy
+        # windows sit next to each other, so that the few envs a workgroup advances in lockstep wake up and fall idle together (a workgroup
+        # without work skips its battery-maths phase): cfg2 -1.5 %, cfg3 -4 % kernel time (profiles/r04_ab_sorted_pool.txt)
+        batch = batch.sorted_by_busy_window(E)
     phi = occupancy_fraction(batch)
     # engine kernels, torch allocations and the RCCL gather all run on ONE explicit (non-default) stream
     dev = devx.device
@@ -645,7 +651,7 @@ def main():
         "ms_per_step": wall[best] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "reps": res[best][1], "regions_per_rep": res[best][2], "timing": "median over reps of (chain of `regions_per_rep` x `steps`-step regions) / regions_per_rep",
-        "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": E, "scenario_pool_per_gpu": M, "chargers": C_,
+        "config": {"workload": f"{args.workload}: {wl['desc']}", "envs_per_gpu": E, "scenario_pool_per_gpu": M, "scenario_pool_order": "generated" if args.keep_pool_order else "sorted by busy window inside every window of envs_per_gpu scenarios", "chargers": C_,
                    "transformers": R_, "steps_per_episode": T, "obs_dim": D, "occupancy_phi": round(phi, 4),
                    "algorithmic_bytes_per_env_step": bytes_env_step, "soc_log": not args.no_soc_log,
                    "launch": best, "actor": args.actor if actor is None else actor.describe,

@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass, field
-from typing import Dict, List, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
@@ -239,6 +239,31 @@ class ScenarioBatch:
         a["lut"] = self.arrays["lut"]
         return ScenarioBatch(len(env_ids), self.n_steps, self.timescale, self.n_chargers, self.ports_per_charger,
                              self.n_transformers, self.v2g_enabled, self.horizon, a).finalize()
+
+    def busy_window(self):
+        """(first, last) step of every scenario in which a port holds an EV: first arrival .. last departure (T, -1 for a scenario without
+        EVs).  Occupancy does not depend on the actions (ev.py:191-202), so this is a property of the scenario."""
+        st = self.arrays["env_session_start"]
+        ta, td = self.arrays["ev_t_arr"], self.arrays["ev_t_dep"]
+        first = np.full(self.n_envs, self.n_steps, np.int64)
+        last = np.full(self.n_envs, -1, np.int64)
+        env_of = np.repeat(np.arange(self.n_envs), np.diff(st))
+        if len(env_of):
+            np.minimum.at(first, env_of, ta)
+            np.maximum.at(last, env_of, np.minimum(td, self.n_steps - 1))
+        return first, last
+
+    def sorted_by_busy_window(self, window: Optional[int] = None) -> "ScenarioBatch":
+        """The same scenarios, re-ordered so that neighbours have similar busy windows (within consecutive blocks of `window` scenarios, or
+        over the whole batch).  The step kernel advances a few envs per workgroup in lockstep; a workgroup whose envs are all idle skips the
+        battery-maths phase of that step, so co-scheduling envs that wake up and fall idle together saves whole phases (an independent,
+        identically distributed pool of generated scenarios has no meaningful order; a batch whose order matters -- replay files -- should not
+        be sorted)."""
+        first, last = self.busy_window()
+        n = self.n_envs
+        w = n if not window else int(window)
+        order = np.concatenate([b0 + np.lexsort((last[b0:b0 + w], first[b0:b0 + w])) for b0 in range(0, n, w)])
+        return self.select(order)
 
     def tile(self, n_envs: int) -> "ScenarioBatch":
         """Repeat this batch's envs cyclically up to n_envs (scenario pool reuse)."""

@@ -182,7 +182,11 @@ class EV2GymVec:
             from .scenario_gen import generate_native as draw
         self._gen_seed = gen_seed
         full = draw(gen_config_from_yaml(self.config, total, gen_seed))
-        return full.shard(rank, world_size) if world_size > 1 else full
+        full = full.shard(rank, world_size) if world_size > 1 else full
+        # (an i.i.d. pool has no meaningful order: scenarios with similar busy windows next to each other, so that the envs a workgroup
+        # advances in lockstep are busy and idle together -- ScenarioBatch.sorted_by_busy_window; not with device_refill, whose re-drawn
+        # windows must stay where the generator's stream puts them)
+        return full if self.device_refill else full.sorted_by_busy_window(self._n_req)
 
     # ---- buffers ---------------------------------------------------------------------------------
     def _alloc(self, shape, dtype=np.float64):

@@ -672,3 +672,21 @@ def test_data_dir_tables_replace_the_fitted_ones(tmp_path, backend):
     assert sun_steps.min() >= (10 - 5) * 4 and sun_steps.max() <= (14 - 5) * 4 + 14 and sol.max() > 20   # 10:00-14:00 plus the smoothing tail (rolling + exponentially weighted mean)
     with pytest.raises(FileNotFoundError):
         gen_config_from_yaml(y, 2, 1, data_dir=str(tmp_path / "missing"))
+
+
+def test_sorting_a_pool_by_busy_window_keeps_the_scenarios_and_groups_similar_ones():
+    """ScenarioBatch.sorted_by_busy_window (co-scheduling for the step kernel's workgroups): a permutation of the scenarios inside every
+    window, first arrivals non-decreasing inside a window, and the span a group of four neighbours is busy for shrinks."""
+    b = generate(GenConfig.v2g_profit_plus_loads(96, 50, 1, seed=4))
+    s = b.sorted_by_busy_window(48)
+    f0, l0 = b.busy_window()
+    f1, l1 = s.busy_window()
+    for w in (slice(0, 48), slice(48, 96)):
+        assert sorted(zip(f0[w].tolist(), l0[w].tolist())) == sorted(zip(f1[w].tolist(), l1[w].tolist()))
+        assert (np.diff(f1[w]) >= 0).all()
+    assert np.array_equal(np.sort(b.arrays["ev_B"]), np.sort(s.arrays["ev_B"])) and b.n_sessions == s.n_sessions
+    span = lambda f, l: (l.reshape(-1, 4).max(1) - f.reshape(-1, 4).min(1) + 1).sum()
+    assert span(f1, l1) < span(f0, l0)
+    e = generate(GenConfig.v2g_profit_plus_loads(4, 3, 1, seed=1, spawn_multiplier=0))   # no EV at all: first = T, last = -1
+    fe, le = e.busy_window()
+    assert (fe == e.n_steps).all() and (le == -1).all() and e.sorted_by_busy_window().n_envs == 4

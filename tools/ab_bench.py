@@ -27,6 +27,8 @@ def child(workload, pool, reps):
     if os.environ.get("AB_SPAWN"):   # e.g. AB_SPAWN=0: no EV ever arrives, every step is a quiet step
         gcfg.spawn_multiplier = float(os.environ["AB_SPAWN"])
     batch = generate(gcfg)
+    if os.environ.get("AB_SORT"):   # scenarios with similar busy windows next to each other (per window of E scenarios: every episode's env set)
+        batch = batch.sorted_by_busy_window(E)
     phi = occupancy_fraction(batch)
     rk, sk = _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]]
     eng = Engine(batch, rk, sk, device=0, flags=_abi.FLAG_LOG_SOC, n_active_envs=E)
