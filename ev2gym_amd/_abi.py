@@ -1,7 +1,7 @@
 """ctypes mirrors of include/ev2g.h (the C-ABI structs).  Keep in sync with the header."""
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 COMM_ID_BYTES = 128   # EV2G_COMM_ID_BYTES = sizeof(ncclUniqueId)
 LUT_LEN = 101
 N_STATS = 17

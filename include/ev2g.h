@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EV2G_ABI_VERSION 3
+#define EV2G_ABI_VERSION 4
 
 /* reward_function built-ins (rl_agent/reward.py) */
 #define EV2G_REWARD_PROFITMAX_TRPENALTY_USERINCENTIVES 0 /* reward.py:34-44  */

@@ -25,7 +25,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/ev2g.h but not exported"
     assert set(engine.EXPORTED_SYMBOLS) == set(decl)
     from ev2gym_amd import _abi
-    assert L.ev2g_abi_version() == _abi.ABI_VERSION == 3
+    assert L.ev2g_abi_version() == _abi.ABI_VERSION == 4
 
 
 def test_struct_mirrors_match_header_field_order():

@@ -5,7 +5,7 @@ import json, sys
 out, specs = sys.argv[1], sys.argv[2:]
 res = {"_comment": "HBM bytes per step-kernel launch from rocprofv3 PMC passes (tools/prof_step.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc "
                    "runs, KB, average over the dispatches of the step kernel); bench.py reports 2*FETCH + WRITE (gfx950 FETCH_SIZE note in "
-                   "MI355X_MICROARCH.md).  Every entry is the summary.json of one profiles/r03_<tag>_rocprofv3.txt"}
+                   "MI355X_MICROARCH.md).  Every entry is the summary.json of one profiles/rNN_<tag>_rocprofv3.txt"}
 for spec in specs:
     tag, wl = spec.split("=")
     workload, launch = wl.split(":")
