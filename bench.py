@@ -254,6 +254,35 @@ def rollout_record(Engine, batch, rk, sk, local_rank, devx, E, lo, rank, args, T
         eng.close()
 
 
+def collector_record(Engine, batch, rk, sk, local_rank, devx, E, lo, rank, args, T, min_s=0.2):
+    """The off-policy collection loop of an SB3 DDPG run with the replay buffer on the device (sb3_vec_env.DeviceReplayCollector over ev2g_collect):
+    actor forward -> env step with every transition written in place, statistics + reset at the episode ends; no host copy of observations."""
+    from ev2gym_amd.actor import init_mlp_weights
+    from ev2gym_amd.sb3_vec_env import DeviceReplayCollector
+    st = devx.new_stream(make_current=False)
+    eng = Engine(batch, rk, sk, device=local_rank, stream=st, flags=0 if args.no_soc_log else _abi.FLAG_LOG_SOC, n_active_envs=E)
+    try:
+        col = DeviceReplayCollector(eng, init_mlp_weights(eng.D, eng.P, seed=1234 + rank), lo, capacity_episodes=2, use_torch=False)
+        col.collect_episode()
+        eng.synchronize()
+        n, spent = 0, 0.0
+        while spent < min_s:
+            t0 = time.perf_counter()
+            col.collect_episode()
+            eng.synchronize()
+            spent += time.perf_counter() - t0
+            n += 1
+        eng.check_faults()
+        spec = eng.last_launch_specialisation
+        col.close()
+        return {"env_steps_per_s_per_gpu": E * T * n / spent, "us_per_step_wall": spent / (n * T) * 1e6, "episodes_timed": n, "step_kernel_specialisation": spec,
+                "replay_block_mb": round(((T + 1) * E * eng.D * 4 + T * E * (eng.P * 5 + 9)) / 1e6, 1),
+                "note": "DeviceReplayCollector: k x (fused actor forward -> single-step env launch) with observation / action / reward / done / mask rows "
+                        "written in place into a device-resident episode block (next_obs[t] = obs[t + 1]); get_statistics + reset in one launch at every episode end"}
+    finally:
+        eng.close()
+
+
 def refill_record(Engine, wl, rk, sk, local_rank, devx, E, rank, args, T, min_s=0.1):
     """Scenario generation ON THE DEVICE (ev2g_pool_refill: EV2Gym.reset()'s per-episode draw, ev2gym_env.py:243-296, without host
     work): a pool of 3 windows drawn by the library's generator; every episode steps one window while the window of the episode
@@ -586,6 +615,10 @@ def main():
     rollout = None
     if actor is None and not stub and not args.no_rollout_record and not args.only_timed and args.workload != "cfg4":
         rollout = rollout_record(Engine, batch, rk, sk, local_rank, devx, E, wl["lo"], rank, args, T, bytes_env_step)
+        try:
+            rollout["collector"] = collector_record(Engine, batch, rk, sk, local_rank, devx, E, wl["lo"], rank, args, T)
+        except Exception as ex:   # (a record next to the headline: never lets the line fail)
+            rollout["collector"] = {"error": str(ex)}
 
     # outside the timed regions: the C-ABI's own RCCL gather (ev2g_comm_init / ev2g_gather_stats, the path of hosts without
     # torch.distributed) next to torch's, on the same statistics
