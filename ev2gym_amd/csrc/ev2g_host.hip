@@ -1029,6 +1029,7 @@ struct ev2g_mlp {
     std::vector<void *> allocs;
     size_t lds = 0;
     const void *fn = nullptr;   // the kernel for this shape
+    int rows = EV2G_MLP_ROWS;   // env rows per workgroup of that kernel
 };
 
 // the fixed-shape kernels exist for the layer widths of the shipped configs (obs 162 / 63 -> 400 -> 300 -> ports); anything else
@@ -1040,6 +1041,17 @@ static const void *mlp_kernel_for(const MlpDev &d) {
     if (k1 == 11 && k2 == 26 && k3 == 20) return (const void *)ev2g_mlp3_fixed<11, 26, 20>;
     if (k1 == 4 && k2 == 26 && k3 == 20) return (const void *)ev2g_mlp3_fixed<4, 26, 20>;
     return (const void *)ev2g_mlp3_any;
+}
+
+// the 16-row streaming kernel (ev2g_mlp3_s16) exists for the shipped shapes; EV2G_MLP_OLD=1 keeps round 3's 32-row kernel (A/B runs)
+struct MlpS16Pick { const void *fn; size_t lds; int ks1, nt1, nt2, nt3; };
+static MlpS16Pick mlp_s16_for(int d_in, int h1, int h2, int d_out) {
+    const int ks1 = (d_in + 31) / 32, nt1 = (h1 + 15) / 16, nt2 = (h2 + 15) / 16, nt3 = (d_out + 15) / 16;
+    const char *old = std::getenv("EV2G_MLP_OLD");
+    if (old && old[0] == '1') return {nullptr, 0, 0, 0, 0, 0};
+    if (ks1 == 6 && nt1 == 25 && nt2 == 19 && nt3 == 4) return {(const void *)ev2g_mlp3_s16<6, 25, 19, 4>, MlpS16<6, 25, 19, 4>::lds_bytes, ks1, nt1, nt2, nt3};
+    if (ks1 == 2 && nt1 == 25 && nt2 == 19 && nt3 == 2) return {(const void *)ev2g_mlp3_s16<2, 25, 19, 2>, MlpS16<2, 25, 19, 2>::lds_bytes, ks1, nt1, nt2, nt3};
+    return {nullptr, 0, 0, 0, 0, 0};
 }
 
 static uint16_t host_bf16(float f) {   // round to nearest even (same as the kernel's)
@@ -1061,6 +1073,22 @@ static std::vector<uint16_t> pack_linear(const float *W, int n_out, int n_in, in
                 for (int i = 0; i < 8; i++) {
                     const int k = ks * 16 + (l >> 5) * 8 + i;
                     if (j < n_out && k < n_in) p[(((size_t)nt * KS + ks) * 64 + l) * 8 + i] = host_bf16(W[(size_t)j * n_in + k]);
+                }
+            }
+    return p;
+}
+
+// ... and for ev2g_mlp3_s16 (weights are the MFMA's A operand there): [tile of 16 outputs][k-step of 32][lane][8],
+// lane l holds W[tile*16 + (l & 15)][ks*32 + 8*(l >> 4) + 0..7]
+static std::vector<uint16_t> pack_linear_s16(const float *W, int n_out, int n_in, int NT, int KS) {
+    std::vector<uint16_t> p((size_t)NT * KS * 64 * 8, 0);
+    for (int t = 0; t < NT; t++)
+        for (int ks = 0; ks < KS; ks++)
+            for (int l = 0; l < 64; l++) {
+                const int j = t * 16 + (l & 15);
+                for (int i = 0; i < 8; i++) {
+                    const int k = ks * 32 + (l >> 4) * 8 + i;
+                    if (j < n_out && k < n_in) p[(((size_t)t * KS + ks) * 64 + l) * 8 + i] = host_bf16(W[(size_t)j * n_in + k]);
                 }
             }
     return p;
@@ -1094,11 +1122,13 @@ int ev2g_mlp_create_ex(ev2g_handle *h, int d_in, int h1, int h2, int d_out, cons
     d.out_lo = out_lo;
     d.dbg = nullptr;
 #ifdef EV2G_MLP_TIMING
-    { unsigned long long *p; if (dalloc(h, m->allocs, 8, &p)) { delete m; return EV2G_ERR_HIP; } d.dbg = p; }
+    { unsigned long long *p; if (dalloc(h, m->allocs, 16, &p)) { delete m; return EV2G_ERR_HIP; } d.dbg = p; }
 #endif
     if (precision != EV2G_MLP_BF16 && precision != EV2G_MLP_F32) { delete m; return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create_ex: precision must be EV2G_MLP_BF16 or EV2G_MLP_F32"); }
     const bool f32 = precision == EV2G_MLP_F32;
-    m->lds = f32 ? ev2g_mlp32_lds_bytes(d) : ev2g_mlp_lds_bytes(d);
+    const MlpS16Pick s16 = f32 ? MlpS16Pick{nullptr, 0, 0, 0, 0, 0} : mlp_s16_for(d_in, h1, h2, d_out);
+    m->lds = f32 ? ev2g_mlp32_lds_bytes(d) : (s16.fn ? s16.lds : ev2g_mlp_lds_bytes(d));
+    if (s16.fn) m->rows = EV2G_MLPS_ROWS;
     if (m->lds > 160 * 1024) { delete m; return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create: layers too wide for the LDS-resident activations"); }
     int rc = 0;
     auto upw = [&](const std::vector<uint16_t> &v, const uint16_t **dst) { uint16_t *p; rc = upload(h, m->allocs, v.data(), v.size(), &p); *dst = p; return rc; };
@@ -1109,13 +1139,25 @@ int ev2g_mlp_create_ex(ev2g_handle *h, int d_in, int h1, int h2, int d_out, cons
             upw32(pack_linear_f32(W3, d_out, h2, d.n3, d.n2), &d.w3) || upb(b1, h1, d.n1, &d.b1) || upb(b2, h2, d.n2, &d.b2) || upb(b3, d_out, d.n3, &d.b3)) {
             free_pool(m->allocs); delete m; return rc;
         }
+    } else if (s16.fn) {
+        if (upw(pack_linear_s16(W1, h1, d_in, s16.nt1, s16.ks1), &d.w1) || upw(pack_linear_s16(W2, h2, h1, s16.nt2, (s16.nt1 * 16 + 31) / 32), &d.w2) ||
+            upw(pack_linear_s16(W3, d_out, h2, s16.nt3, (s16.nt2 * 16 + 31) / 32), &d.w3)) {
+            free_pool(m->allocs); delete m; return rc;
+        }
+        {   // the three bias vectors as ONE array (b1 | b2 | b3, each padded with zeros to its 16-column tiles): one coalesced load in the kernel
+            std::vector<float> ball((size_t)(s16.nt1 + s16.nt2 + s16.nt3) * 16, 0.f);
+            std::copy(b1, b1 + h1, ball.begin()); std::copy(b2, b2 + h2, ball.begin() + s16.nt1 * 16); std::copy(b3, b3 + d_out, ball.begin() + (s16.nt1 + s16.nt2) * 16);
+            float *p;
+            if ((rc = upload(h, m->allocs, ball.data(), ball.size(), &p))) { free_pool(m->allocs); delete m; return rc; }
+            d.b1 = p; d.b2 = p + s16.nt1 * 16; d.b3 = p + (s16.nt1 + s16.nt2) * 16;
+        }
     } else
     if (upw(pack_linear(W1, h1, d_in, d.n1, d.k1), &d.w1) || upw(pack_linear(W2, h2, h1, d.n2, d.n1), &d.w2) ||
         upw(pack_linear(W3, d_out, h2, d.n3, d.n2), &d.w3) || upb(b1, h1, d.n1, &d.b1) || upb(b2, h2, d.n2, &d.b2) || upb(b3, d_out, d.n3, &d.b3)) {
         free_pool(m->allocs); delete m; return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));   // the staging vectors are temporaries
-    m->fn = f32 ? (const void *)ev2g_mlp3_f32 : mlp_kernel_for(d);
+    m->fn = f32 ? (const void *)ev2g_mlp3_f32 : (s16.fn ? s16.fn : mlp_kernel_for(d));
     if (m->lds > 48 * 1024) HIPCHK(h, hipFuncSetAttribute(m->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds));
     *out = m;
     return EV2G_OK;
@@ -1138,14 +1180,14 @@ int ev2g_mlp_forward(ev2g_handle *h, const ev2g_mlp *m, const float *x, float *y
     (void)hipSetDevice(h->device);
     MlpDev dev = m->dev;
     void *args[] = {&dev, &x, &y, &n_rows};
-    HIPCHK(h, hipLaunchKernel(m->fn, dim3((n_rows + EV2G_MLP_ROWS - 1) / EV2G_MLP_ROWS), dim3(EV2G_MLP_BLOCK), args, m->lds, h->stream));
+    HIPCHK(h, hipLaunchKernel(m->fn, dim3((n_rows + m->rows - 1) / m->rows), dim3(EV2G_MLP_BLOCK), args, m->lds, h->stream));
     return EV2G_OK;
 }
 
 #ifdef EV2G_MLP_TIMING
 int ev2g_mlp_debug_stamps(ev2g_handle *h, const ev2g_mlp *m, unsigned long long *out8) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out8, m->dev.dbg, 64, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out8, m->dev.dbg, 128, hipMemcpyDeviceToHost));   // (16 stamps: 0..7 the phases, 8.. finer ones of the prologue)
     return 0;
 }
 #endif

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define EV2G_MLP_ROWS 32
 #define EV2G_MLP_BLOCK 256
@@ -46,6 +47,17 @@ __device__ __forceinline__ uint16_t ev2g_f32_to_bf16(float f) {   // round to ne
     uint32_t u = __float_as_uint(f);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
+}
+
+// two float32 -> two bf16 in one word (v_cvt_pk_bf16_f32: round to nearest even, like ev2g_f32_to_bf16 and the host's packing)
+typedef __bf16 ev2g_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ev2g_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t ev2g_pack_bf16(float a, float b) {
+    const ev2g_f32x2 f = {a, b};
+    const ev2g_bf16x2 h = __builtin_convertvector(f, ev2g_bf16x2);
+    uint32_t u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
 }
 
 // tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp (relative error ~1e-6, saturates cleanly at +-1)
@@ -295,6 +307,193 @@ __global__ void __launch_bounds__(EV2G_MLP_BLOCK) ev2g_mlp3_fixed(MlpDev m, cons
     __syncthreads();
     MLP_STAMP(6)
     ev2g_mlp_layer_fixed<true, KS3, 1, 1>(F3, bufA, sA, lb3, nullptr, 0, y, row0, n_rows, m.d_out, m.out_lo);
+    MLP_STAMP(7)
+}
+
+// ---- fixed shapes, round 4: 16-row workgroups on every CU, transposed product, one continuous weight stream ------------------------
+// What a forward costs is streaming the 0.44 MB of weights into each CU (64 B/clk per CU: ~3 us, `tools/micro/weight_stream.hip` -- the same
+// whether 64, 128 or 256 workgroups do it) plus whatever of the rest is NOT hidden under that stream.  Round 2-3's kernel (ev2g_mlp3_fixed) hid
+// little: 28 k cycles against the stream's 7 k.  This one is built around the stream:
+//   * a workgroup owns 16 env rows (256 workgroups at 4096 envs: every CU; half the input rows to fetch cold, half the MFMA and epilogue
+//     work on the chain behind the stream);
+//   * v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand and the activations as B: D[m][n] = sum_k W[n0 + m][k] X[n][k], so a lane
+//     ends up with four CONSECUTIVE output columns of one env row -- the next layer's operand is written with one 8-byte LDS store per
+//     tile (the 32x32 form left 16 two-byte stores), the actions with two 8-byte global stores;
+//   * column tiles of 16 go round-robin over the four wavefronts (25 / 19 / 4 tiles: 7 + 5 + 1 per wavefront at most); the bias is the
+//     accumulator's initial value; two accumulators per tile (even / odd k-steps) so that no MFMA waits for the one before it;
+//   * every wavefront walks ONE static sequence of weight fragments -- layer 1's tiles, layer 2's, layer 3's, in the order it consumes
+//     them -- through a ring of EV2G_MLPS_RING register slots: the first RING fragments are requested at kernel start (before the input
+//     rows have arrived), and fragment s + RING is requested the moment fragment s has been consumed, across layer boundaries and barriers:
+//     the stream never waits for the compute, only the other way round.
+// Weights are packed per layer as [tile][k-step][lane] 16-byte fragments: lane l holds W[tile*16 + (l & 15)][ks*32 + 8*(l >> 4) + 0..7].
+#define EV2G_MLPS_ROWS 16
+#define EV2G_MLPS_RING 52
+#ifndef EV2G_MLPS_HEAD
+#define EV2G_MLPS_HEAD 28   // fragments requested before the input rows are converted
+#endif
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+template <int KS1, int NT1, int NT2, int NT3> struct MlpS16 {
+    static constexpr int KS2 = (NT1 * 16 + 31) / 32, KS3 = (NT2 * 16 + 31) / 32;
+    static constexpr int MT1 = (NT1 + 3) / 4, MT2 = (NT2 + 3) / 4, MT3 = (NT3 + 3) / 4;   // tile slots per wavefront
+    static constexpr int S1 = MT1 * KS1, S2 = MT2 * KS2, S3 = MT3 * KS3, STOT = S1 + S2 + S3;   // fragments of the sequence, per layer
+    static constexpr int SX = KS1 * 32 + 8, SH1 = KS2 * 32 + 8, SH2 = KS3 * 32 + 8;             // LDS row strides (bf16 elements; +16 bytes against bank conflicts)
+    static constexpr int NB = (NT1 + NT2 + NT3) * 16;                                          // staged biases (floats)
+    static constexpr size_t lds_bytes = (size_t)EV2G_MLPS_ROWS * (SX + SH1 + SH2) * 2 + (size_t)NB * 4;
+};
+
+template <int KS1, int NT1, int NT2, int NT3>
+__global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__restrict__ x, float *__restrict__ y, int n_rows) {
+    typedef MlpS16<KS1, NT1, NT2, NT3> C;
+    constexpr int RING = EV2G_MLPS_RING;
+    extern __shared__ __attribute__((aligned(16))) uint16_t mlds[];
+    uint16_t *bufX = mlds, *bufH1 = bufX + EV2G_MLPS_ROWS * C::SX, *bufH2 = bufH1 + EV2G_MLPS_ROWS * C::SH1;
+    float *lb = (float *)(bufH2 + EV2G_MLPS_ROWS * C::SH2);   // biases: layer 1 | layer 2 | layer 3
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+    const int row0 = blockIdx.x * EV2G_MLPS_ROWS;
+    const int nr = min(EV2G_MLPS_ROWS, n_rows - row0);
+    MLP_STAMP(0)
+    // ---- requests, oldest first (vmcnt retires in order): input rows, biases, then the head of the weight sequence ----
+    const int d_in = m.d_in, total = nr * d_in;
+    const float *xs = x + (size_t)row0 * d_in;
+    constexpr int NL2 = (EV2G_MLPS_ROWS * KS1 * 32 / 2 + 255) / 256;   // 8-byte pieces per lane (16 rows of at most KS1*32 columns)
+    const bool pairs = (d_in & 1) == 0 && (((size_t)xs) & 7) == 0;    // (uniform) an even row length: two neighbours never straddle a row
+    // (unconditional loads from clamped addresses: a load inside a per-lane branch whose result merges with a default makes the compiler
+    // drain vmcnt before the next one -- six round trips in a row instead of one)
+    float2 xin[NL2];
+    if (pairs) {
+#pragma unroll
+        for (int it = 0; it < NL2; it++) xin[it] = *(const float2 *)(xs + min((it * 256 + tid) * 2, total - 2));
+    } else {
+#pragma unroll
+        for (int it = 0; it < NL2; it++) { const int f = (it * 256 + tid) * 2; xin[it].x = xs[min(f, total - 1)]; xin[it].y = xs[min(f + 1, total - 1)]; }
+    }
+    float bv[(C::NB + 255) / 256];   // the three bias vectors are ONE array on this path (ev2g_mlp_create_ex): b1 | b2 | b3, each padded to its tiles
+#pragma unroll
+    for (int j = 0; j < (C::NB + 255) / 256; j++) bv[j] = m.b1[min(tid + j * 256, C::NB - 1)];
+    const uint4 *w1 = (const uint4 *)m.w1 + lane, *w2 = (const uint4 *)m.w2 + lane, *w3 = (const uint4 *)m.w3 + lane;
+    uint4 ring[RING];
+    // fragment `seq` of this wavefront's sequence -> ring slot seq % RING (seq is a constant wherever this is called, after unrolling; the
+    // tile guard is a compile-time `true` except in a layer's last tile slot)
+    auto request = [&](int seq) __attribute__((always_inline)) {
+        if (seq >= C::STOT) return;
+        const int L = seq < C::S1 ? 0 : (seq < C::S1 + C::S2 ? 1 : 2);
+        const int r = seq - (L == 0 ? 0 : (L == 1 ? C::S1 : C::S1 + C::S2));
+        const int KS = L == 0 ? KS1 : (L == 1 ? C::KS2 : C::KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3);
+        const int i = r / KS, ks = r - i * KS;
+        const uint4 *w = L == 0 ? w1 : (L == 1 ? w2 : w3);
+        if (4 * i + 3 < NT || wave + 4 * i < NT) ring[seq % RING] = w[(unsigned)(((wave + 4 * i) * KS + ks) * 64)];
+    };
+    MLP_STAMP(8)
+    // The CU's vector-memory port takes ~64 cycles per wavefront and fragment with four wavefronts asking (3.3 k cycles for the whole ring):
+    // the input rows arrive while the first fragments are being requested.  HEAD of them go out first, then the rows are converted (the
+    // port works the queue off meanwhile), then the rest of the ring; padding and biases come last, behind the requests.
+    constexpr int HEAD = EV2G_MLPS_HEAD < RING ? EV2G_MLPS_HEAD : RING;
+#pragma unroll
+    for (int sq = 0; sq < HEAD; sq++) request(sq);
+    MLP_STAMP(9)
+    // ---- input rows -> bf16 operand rows in LDS ----
+    if (pairs) {   // element pair p = it * 256 + tid sits at (row, column) = divmod(2 p, d_in): one division, then steps of 512 elements
+        const int q512 = 512 / d_in, r512 = 512 - q512 * d_in;   // (uniform)
+        int f = tid * 2;
+        int r = (int)((float)f * (1.0f / (float)d_in)), c = f - r * d_in;   // exact after the one-step correction (f < 2^23)
+        if (c < 0) { r--; c += d_in; } else if (c >= d_in) { r++; c -= d_in; }
+#pragma unroll
+        for (int it = 0; it < NL2; it++) {
+            if (f < total) *(uint32_t *)(bufX + r * C::SX + c) = ev2g_pack_bf16(xin[it].x, xin[it].y);
+            f += 512; r += q512; c += r512;
+            if (c >= d_in) { c -= d_in; r++; }
+        }
+    } else {
+        const float rdin = 1.0f / (float)d_in;
+#pragma unroll
+        for (int it = 0; it < NL2; it++) {
+            const int f = (it * 256 + tid) * 2;
+            int r = (int)((float)f * rdin), c = f - r * d_in;
+            if (c < 0) { r--; c += d_in; } else if (c >= d_in) { r++; c -= d_in; }
+            if (f < total) bufX[r * C::SX + c] = ev2g_f32_to_bf16(xin[it].x);
+            if (++c == d_in) { c = 0; r++; }
+            if (f + 1 < total) bufX[r * C::SX + c] = ev2g_f32_to_bf16(xin[it].y);
+        }
+    }
+    MLP_STAMP(10)
+#pragma unroll
+    for (int sq = HEAD; sq < RING; sq++) request(sq);
+    {   // zero padding: thread (row = tid / 16, j = tid % 16) clears columns j, j + 16, ... of its row's tail in every operand buffer
+        const int pr = tid >> 4, pj = tid & 15;
+        for (int cc = d_in + pj; cc < KS1 * 32; cc += 16) bufX[pr * C::SX + cc] = 0;                 // columns d_in .. KS1*32
+        if (pr >= nr) for (int cc = pj; cc < d_in; cc += 16) bufX[pr * C::SX + cc] = 0;             // rows past the batch
+        constexpr int P1 = C::KS2 * 32 - NT1 * 16, P2 = C::KS3 * 32 - NT2 * 16;                       // columns no tile writes
+        if (pj < P1) bufH1[pr * C::SH1 + NT1 * 16 + pj] = 0;
+        if (pj < P2) bufH2[pr * C::SH2 + NT2 * 16 + pj] = 0;
+        static_assert(P1 <= 16 && P2 <= 16, "tail columns");
+#pragma unroll
+        for (int j = 0; j < (C::NB + 255) / 256; j++) { const int i = tid + j * 256; if (i < C::NB) lb[i] = bv[j]; }
+    }
+    MLP_STAMP(1)
+    __syncthreads();
+    MLP_STAMP(2)
+    const int brow = (lane & 15), kq = (lane >> 4);
+    // one layer for this wavefront: operand fragments of the 16 rows from LDS (once), then its tile slots
+    auto layer = [&](auto Lc, const uint16_t *A, int sa, const float *bias, uint16_t *out, int so) __attribute__((always_inline)) {
+        constexpr int L = decltype(Lc)::value;
+        constexpr int KS = L == 0 ? KS1 : (L == 1 ? C::KS2 : C::KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3), MT = (NT + 3) / 4;
+        constexpr int base = L == 0 ? 0 : (L == 1 ? C::S1 : C::S1 + C::S2);
+        uint4 bfr[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) bfr[ks] = *(const uint4 *)(A + brow * sa + ks * 32 + kq * 8);
+        f32x4m bini[MT];
+#pragma unroll
+        for (int i = 0; i < MT; i++) bini[i] = *(const f32x4m *)(bias + min(wave + 4 * i, NT - 1) * 16 + kq * 4);
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const int tile = wave + 4 * i;
+            if (4 * i + 3 < NT || tile < NT) {   // (uniform; a constant but for the last slot)
+                f32x4m acc0 = bini[i], acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    bf16x8 a, b;
+                    __builtin_memcpy(&a, &ring[(base + i * KS + ks) % RING], 16); __builtin_memcpy(&b, &bfr[ks], 16);
+                    if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0, 0, 0, 0);
+                    request(base + i * KS + ks + RING);   // this slot is free again
+                }
+                const f32x4m acc = acc0 + acc1;
+                const int col = tile * 16 + kq * 4;   // this lane: columns col .. col + 3 of env row `brow`
+                if (L < 2) {
+                    const uint32_t lo = ev2g_pack_bf16(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f)), hi = ev2g_pack_bf16(fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+                    *(uint2 *)(out + brow * so + col) = make_uint2(lo, hi);
+                } else {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { v[r] = ev2g_fast_tanh(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
+                    const int d_out = m.d_out;
+                    if (brow < nr) {
+                        float *yr = y + (size_t)(row0 + brow) * d_out + col;
+                        if ((d_out & 1) == 0) {   // (uniform) even row length: the pairs are 8-byte aligned
+                            if (col + 1 < d_out) *(float2 *)yr = make_float2(v[0], v[1]);
+                            if (col + 3 < d_out) *(float2 *)(yr + 2) = make_float2(v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) if (col + r < d_out) yr[r] = v[r];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) request(base + i * KS + ks + RING);   // no tile in this slot: the sequence moves on all the same
+            }
+        }
+    };
+    layer(std::integral_constant<int, 0>{}, bufX, C::SX, lb, bufH1, C::SH1);
+    MLP_STAMP(3)
+    __syncthreads();
+    MLP_STAMP(4)
+    layer(std::integral_constant<int, 1>{}, bufH1, C::SH1, lb + NT1 * 16, bufH2, C::SH2);
+    MLP_STAMP(5)
+    __syncthreads();
+    MLP_STAMP(6)
+    layer(std::integral_constant<int, 2>{}, bufH2, C::SH2, lb + (NT1 + NT2) * 16, nullptr, 0);
     MLP_STAMP(7)
 }
 

@@ -23,8 +23,10 @@ y = eng.empty((E, P), np.float32)
 names = ["input load+convert", "(sync)", "layer 1", "(sync)", "layer 2", "(sync)", "layer 3"]
 for rep in range(3):
     eng.mlp_forward(m, x, y, E)
-    out = (C.c_ulonglong * 8)()
+    out = (C.c_ulonglong * 16)()
     eng._lib.ev2g_mlp_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     eng._lib.ev2g_mlp_debug_stamps(eng._h, m, out)
     v = list(out)
     print("run", rep, "total", v[7] - v[0], "cycles:", ", ".join(f"{n} {v[i+1]-v[i]}" for i, n in enumerate(names)))
+    if v[8]:   # the 16-row kernel's finer prologue stamps: requests issued | weight head issued | input rows converted
+        print("      prologue: to first weight request", v[8] - v[0], "| ring head issued", v[9] - v[8], "| input arrived + converted", v[10] - v[9], "| padding + biases", v[1] - v[10])
