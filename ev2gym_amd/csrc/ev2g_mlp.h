@@ -389,6 +389,7 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
     // the input rows arrive while the first fragments are being requested.  HEAD of them go out first, then the rows are converted (the
     // port works the queue off meanwhile), then the rest of the ring; padding and biases come last, behind the requests.
     constexpr int HEAD = EV2G_MLPS_HEAD < RING ? EV2G_MLPS_HEAD : RING;
+    constexpr int PER = (RING - HEAD + NL2 - 1) / NL2;   // requests per conversion step
 #pragma unroll
     for (int sq = 0; sq < HEAD; sq++) request(sq);
     MLP_STAMP(9)
@@ -403,6 +404,10 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
             if (f < total) *(uint32_t *)(bufX + r * C::SX + c) = ev2g_pack_bf16(xin[it].x, xin[it].y);
             f += 512; r += q512; c += r512;
             if (c >= d_in) { c -= d_in; r++; }
+            // the rest of the ring goes out BETWEEN the conversion steps: a request blocks its wavefront while the port is busy, the conversion
+            // of the other wavefronts fills that time (and their requests, this one's conversion)
+#pragma unroll
+            for (int u = 0; u < PER; u++) request(HEAD + it * PER + u < RING ? HEAD + it * PER + u : C::STOT);
         }
     } else {
         const float rdin = 1.0f / (float)d_in;
@@ -417,8 +422,10 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
         }
     }
     MLP_STAMP(10)
+    if (!pairs) {
 #pragma unroll
-    for (int sq = HEAD; sq < RING; sq++) request(sq);
+        for (int sq = HEAD; sq < RING; sq++) request(sq);
+    }
     {   // zero padding: thread (row = tid / 16, j = tid % 16) clears columns j, j + 16, ... of its row's tail in every operand buffer
         const int pr = tid >> 4, pj = tid & 15;
         for (int cc = d_in + pj; cc < KS1 * 32; cc += 16) bufX[pr * C::SX + cc] = 0;                 // columns d_in .. KS1*32
