@@ -415,8 +415,8 @@ def main():
     ap.add_argument("--actor", default="none", choices=["none", "mlp", "mlp_fp32", "mlp_torch"],
                     help="BASELINE configs[4]-shaped rollout: an actor (obs->400->300->P, tanh; SB3-DDPG shape, random weights) "
                          "produces the actions on the device between steps (forces per_step launches).  mlp: the fused one-kernel "
-                         "forward of the library (bf16 MFMA); mlp_fp32: the same kernel structure with float32 MFMA operands (what an "
-                         "SB3-trained float32 policy computes); mlp_torch: the same network through torch.nn (fp32)")
+                         "forward of the library (bf16 MFMA); mlp_fp32: the same kernel with float32 weights held as two bf16 terms (what an "
+                         "SB3-trained float32 policy computes, to 1e-5); mlp_torch: the same network through torch.nn (fp32)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-rollout-record", action="store_true", help="skip the short policy-in-the-loop pass (`rollout` in the line)")
     ap.add_argument("--only-timed", action="store_true", help="profiling runs: nothing but the timed regions of the chosen launch mode "

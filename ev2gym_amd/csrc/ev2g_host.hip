@@ -1044,14 +1044,19 @@ static const void *mlp_kernel_for(const MlpDev &d) {
 }
 
 // the 16-row streaming kernel (ev2g_mlp3_s16) exists for the shipped shapes; EV2G_MLP_OLD=1 keeps round 3's 32-row kernel (A/B runs)
-struct MlpS16Pick { const void *fn; size_t lds; int ks1, nt1, nt2, nt3; };
-static MlpS16Pick mlp_s16_for(int d_in, int h1, int h2, int d_out) {
+struct MlpS16Pick { const void *fn; size_t lds; int ks1, nt1, nt2, nt3, nw; };
+// nw: bf16 terms per weight -- 1: the bf16 network; 2 / 3: the float32 network as split bf16 operands (EV2G_MLP_F32 / EV2G_MLP_F32X3, ev2g_mlp.h)
+static MlpS16Pick mlp_s16_for(int d_in, int h1, int h2, int d_out, int nw) {
     const int ks1 = (d_in + 31) / 32, nt1 = (h1 + 15) / 16, nt2 = (h2 + 15) / 16, nt3 = (d_out + 15) / 16;
     const char *old = std::getenv("EV2G_MLP_OLD");
-    if (old && old[0] == '1') return {nullptr, 0, 0, 0, 0, 0};
-    if (ks1 == 6 && nt1 == 25 && nt2 == 19 && nt3 == 4) return {(const void *)ev2g_mlp3_s16<6, 25, 19, 4>, MlpS16<6, 25, 19, 4>::lds_bytes, ks1, nt1, nt2, nt3};
-    if (ks1 == 2 && nt1 == 25 && nt2 == 19 && nt3 == 2) return {(const void *)ev2g_mlp3_s16<2, 25, 19, 2>, MlpS16<2, 25, 19, 2>::lds_bytes, ks1, nt1, nt2, nt3};
-    return {nullptr, 0, 0, 0, 0, 0};
+    if (old && old[0] == '1') return {nullptr, 0, 0, 0, 0, 0, 0};
+#define EV2G_S16_CASE(K, A, B, Cc, N) \
+    if (ks1 == K && nt1 == A && nt2 == B && nt3 == Cc && nw == N) return {(const void *)ev2g_mlp3_s16<K, A, B, Cc, N>, MlpS16<K, A, B, Cc, N>::lds_bytes, ks1, nt1, nt2, nt3, nw};
+    EV2G_S16_CASE(6, 25, 19, 4, 1) EV2G_S16_CASE(2, 25, 19, 2, 1)
+    EV2G_S16_CASE(6, 25, 19, 4, 2) EV2G_S16_CASE(2, 25, 19, 2, 2)
+    EV2G_S16_CASE(6, 25, 19, 4, 3) EV2G_S16_CASE(2, 25, 19, 2, 3)
+#undef EV2G_S16_CASE
+    return {nullptr, 0, 0, 0, 0, 0, 0};
 }
 
 static uint16_t host_bf16(float f) {   // round to nearest even (same as the kernel's)
@@ -1078,17 +1083,24 @@ static std::vector<uint16_t> pack_linear(const float *W, int n_out, int n_in, in
     return p;
 }
 
-// ... and for ev2g_mlp3_s16 (weights are the MFMA's A operand there): [tile of 16 outputs][k-step of 32][lane][8],
-// lane l holds W[tile*16 + (l & 15)][ks*32 + 8*(l >> 4) + 0..7]
-static std::vector<uint16_t> pack_linear_s16(const float *W, int n_out, int n_in, int NT, int KS) {
-    std::vector<uint16_t> p((size_t)NT * KS * 64 * 8, 0);
+// ... and for ev2g_mlp3_s16 (weights are the MFMA's A operand there): [tile of 16 outputs][k-step of 32][term][lane][8],
+// lane l holds W[tile*16 + (l & 15)][ks*32 + 8*(l >> 4) + 0..7]; term t of NW is the bf16 rounding of what terms 0..t-1 left of the float32 weight
+static std::vector<uint16_t> pack_linear_s16(const float *W, int n_out, int n_in, int NT, int KS, int NW) {
+    std::vector<uint16_t> p((size_t)NT * KS * NW * 64 * 8, 0);
     for (int t = 0; t < NT; t++)
         for (int ks = 0; ks < KS; ks++)
             for (int l = 0; l < 64; l++) {
                 const int j = t * 16 + (l & 15);
                 for (int i = 0; i < 8; i++) {
                     const int k = ks * 32 + (l >> 4) * 8 + i;
-                    if (j < n_out && k < n_in) p[(((size_t)t * KS + ks) * 64 + l) * 8 + i] = host_bf16(W[(size_t)j * n_in + k]);
+                    if (j >= n_out || k >= n_in) continue;
+                    float r = W[(size_t)j * n_in + k];
+                    for (int q = 0; q < NW; q++) {
+                        const uint16_t hb = host_bf16(r);
+                        p[((((size_t)t * KS + ks) * NW + q) * 64 + l) * 8 + i] = hb;
+                        uint32_t u = (uint32_t)hb << 16; float hf; std::memcpy(&hf, &u, 4);
+                        r -= hf;   // (exact)
+                    }
                 }
             }
     return p;
@@ -1124,24 +1136,24 @@ int ev2g_mlp_create_ex(ev2g_handle *h, int d_in, int h1, int h2, int d_out, cons
 #ifdef EV2G_MLP_TIMING
     { unsigned long long *p; if (dalloc(h, m->allocs, 16, &p)) { delete m; return EV2G_ERR_HIP; } d.dbg = p; }
 #endif
-    if (precision != EV2G_MLP_BF16 && precision != EV2G_MLP_F32) { delete m; return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create_ex: precision must be EV2G_MLP_BF16 or EV2G_MLP_F32"); }
-    const bool f32 = precision == EV2G_MLP_F32;
-    const MlpS16Pick s16 = f32 ? MlpS16Pick{nullptr, 0, 0, 0, 0, 0} : mlp_s16_for(d_in, h1, h2, d_out);
-    m->lds = f32 ? ev2g_mlp32_lds_bytes(d) : (s16.fn ? s16.lds : ev2g_mlp_lds_bytes(d));
+    if (precision != EV2G_MLP_BF16 && precision != EV2G_MLP_F32 && precision != EV2G_MLP_F32X3) { delete m; return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create_ex: precision must be EV2G_MLP_BF16, EV2G_MLP_F32 or EV2G_MLP_F32X3"); }
+    const bool f32 = precision != EV2G_MLP_BF16;
+    const MlpS16Pick s16 = mlp_s16_for(d_in, h1, h2, d_out, precision == EV2G_MLP_BF16 ? 1 : (precision == EV2G_MLP_F32 ? 2 : 3));
+    m->lds = s16.fn ? s16.lds : (f32 ? ev2g_mlp32_lds_bytes(d) : ev2g_mlp_lds_bytes(d));
     if (s16.fn) m->rows = EV2G_MLPS_ROWS;
     if (m->lds > 160 * 1024) { delete m; return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create: layers too wide for the LDS-resident activations"); }
     int rc = 0;
     auto upw = [&](const std::vector<uint16_t> &v, const uint16_t **dst) { uint16_t *p; rc = upload(h, m->allocs, v.data(), v.size(), &p); *dst = p; return rc; };
     auto upb = [&](const float *b, int n, int N, const float **dst) { std::vector<float> v((size_t)N, 0.f); std::copy(b, b + n, v.begin()); float *p; rc = upload(h, m->allocs, v.data(), v.size(), &p); *dst = p; return rc; };
     auto upw32 = [&](const std::vector<float> &v, const uint16_t **dst) { float *p; rc = upload(h, m->allocs, v.data(), v.size(), &p); *dst = (const uint16_t *)p; return rc; };
-    if (f32) {
+    if (f32 && !s16.fn) {
         if (upw32(pack_linear_f32(W1, h1, d_in, d.n1, d.k1), &d.w1) || upw32(pack_linear_f32(W2, h2, h1, d.n2, d.n1), &d.w2) ||
             upw32(pack_linear_f32(W3, d_out, h2, d.n3, d.n2), &d.w3) || upb(b1, h1, d.n1, &d.b1) || upb(b2, h2, d.n2, &d.b2) || upb(b3, d_out, d.n3, &d.b3)) {
             free_pool(m->allocs); delete m; return rc;
         }
     } else if (s16.fn) {
-        if (upw(pack_linear_s16(W1, h1, d_in, s16.nt1, s16.ks1), &d.w1) || upw(pack_linear_s16(W2, h2, h1, s16.nt2, (s16.nt1 * 16 + 31) / 32), &d.w2) ||
-            upw(pack_linear_s16(W3, d_out, h2, s16.nt3, (s16.nt2 * 16 + 31) / 32), &d.w3)) {
+        if (upw(pack_linear_s16(W1, h1, d_in, s16.nt1, s16.ks1, s16.nw), &d.w1) || upw(pack_linear_s16(W2, h2, h1, s16.nt2, (s16.nt1 * 16 + 31) / 32, s16.nw), &d.w2) ||
+            upw(pack_linear_s16(W3, d_out, h2, s16.nt3, (s16.nt2 * 16 + 31) / 32, s16.nw), &d.w3)) {
             free_pool(m->allocs); delete m; return rc;
         }
         {   // the three bias vectors as ONE array (b1 | b2 | b3, each padded with zeros to its 16-column tiles): one coalesced load in the kernel
@@ -1157,7 +1169,7 @@ int ev2g_mlp_create_ex(ev2g_handle *h, int d_in, int h1, int h2, int d_out, cons
         free_pool(m->allocs); delete m; return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));   // the staging vectors are temporaries
-    m->fn = f32 ? (const void *)ev2g_mlp3_f32 : (s16.fn ? s16.fn : mlp_kernel_for(d));
+    m->fn = s16.fn ? s16.fn : (f32 ? (const void *)ev2g_mlp3_f32 : mlp_kernel_for(d));
     if (m->lds > 48 * 1024) HIPCHK(h, hipFuncSetAttribute(m->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds));
     *out = m;
     return EV2G_OK;

@@ -333,22 +333,41 @@ __global__ void __launch_bounds__(EV2G_MLP_BLOCK) ev2g_mlp3_fixed(MlpDev m, cons
 #endif
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
-template <int KS1, int NT1, int NT2, int NT3> struct MlpS16 {
+// NW > 1: the FLOAT32 network on the bf16 matrix cores (precision = EV2G_MLP_F32).  A float32 weight is stored as NW bf16 terms
+// (w = w0 + w1 (+ w2), each the bf16 rounding of what the ones before it left: 16 or 24 significant bits), an activation is split into three
+// terms when it is written to LDS, and a k-step accumulates the products w_i x_j with i + j <= 2 (5 MFMAs for NW = 2, 6 for NW = 3) into the
+// float32 accumulator: every product of two bf16 values is exact in float32, so what is lost is the dropped terms (2^-24 relative and
+// below for NW = 3: the same level as float32 operands) and the accumulation order.  The float32 MFMA (v_mfma_f32_32x32x2_f32, ev2g_mlp3_f32)
+// runs at 1/16 of the bf16 rate; here the cost is the weight stream, NW times the bf16 kernel's.
+template <int KS1, int NT1, int NT2, int NT3, int NW = 1> struct MlpS16 {
+    static constexpr int NX = NW == 1 ? 1 : 3;   // terms of an activation
     static constexpr int KS2 = (NT1 * 16 + 31) / 32, KS3 = (NT2 * 16 + 31) / 32;
     static constexpr int MT1 = (NT1 + 3) / 4, MT2 = (NT2 + 3) / 4, MT3 = (NT3 + 3) / 4;   // tile slots per wavefront
-    static constexpr int S1 = MT1 * KS1, S2 = MT2 * KS2, S3 = MT3 * KS3, STOT = S1 + S2 + S3;   // fragments of the sequence, per layer
+    static constexpr int S1 = MT1 * KS1 * NW, S2 = MT2 * KS2 * NW, S3 = MT3 * KS3 * NW, STOT = S1 + S2 + S3;   // fragments of the sequence, per layer
     static constexpr int SX = KS1 * 32 + 8, SH1 = KS2 * 32 + 8, SH2 = KS3 * 32 + 8;             // LDS row strides (bf16 elements; +16 bytes against bank conflicts)
     static constexpr int NB = (NT1 + NT2 + NT3) * 16;                                          // staged biases (floats)
-    static constexpr size_t lds_bytes = (size_t)EV2G_MLPS_ROWS * (SX + SH1 + SH2) * 2 + (size_t)NB * 4;
+    static constexpr int RING = NW == 1 ? EV2G_MLPS_RING : 36;                                 // (three operand copies per k-step take the registers)
+    static constexpr size_t lds_bytes = (size_t)EV2G_MLPS_ROWS * (SX + SH1 + SH2) * 2 * NX + (size_t)NB * 4;
 };
 
-template <int KS1, int NT1, int NT2, int NT3>
+// float32 -> NX bf16 terms, two values at a time (packed words); term k is the bf16 rounding of what terms 0..k-1 left
+template <int NX> __device__ __forceinline__ void ev2g_split_bf16(float a, float b, uint32_t (&w)[NX]) {
+#pragma unroll
+    for (int k = 0; k < NX; k++) {
+        w[k] = ev2g_pack_bf16(a, b);
+        if (k + 1 < NX) { a -= __uint_as_float(w[k] << 16); b -= __uint_as_float(w[k] & 0xffff0000u); }   // (exact: the term is a prefix of the value's bits)
+    }
+}
+
+template <int KS1, int NT1, int NT2, int NT3, int NW = 1>
 __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__restrict__ x, float *__restrict__ y, int n_rows) {
-    typedef MlpS16<KS1, NT1, NT2, NT3> C;
-    constexpr int RING = EV2G_MLPS_RING;
+    typedef MlpS16<KS1, NT1, NT2, NT3, NW> C;
+    constexpr int RING = C::RING, NX = C::NX;
     extern __shared__ __attribute__((aligned(16))) uint16_t mlds[];
-    uint16_t *bufX = mlds, *bufH1 = bufX + EV2G_MLPS_ROWS * C::SX, *bufH2 = bufH1 + EV2G_MLPS_ROWS * C::SH1;
-    float *lb = (float *)(bufH2 + EV2G_MLPS_ROWS * C::SH2);   // biases: layer 1 | layer 2 | layer 3
+    // operand buffers: NX copies (terms) of each, one behind the other
+    constexpr int BX = EV2G_MLPS_ROWS * C::SX, BH1 = EV2G_MLPS_ROWS * C::SH1, BH2 = EV2G_MLPS_ROWS * C::SH2;
+    uint16_t *bufX = mlds, *bufH1 = bufX + NX * BX, *bufH2 = bufH1 + NX * BH1;
+    float *lb = (float *)(bufH2 + NX * BH2);   // biases: layer 1 | layer 2 | layer 3
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
     const int row0 = blockIdx.x * EV2G_MLPS_ROWS;
     const int nr = min(EV2G_MLPS_ROWS, n_rows - row0);
@@ -374,20 +393,20 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
     const uint4 *w1 = (const uint4 *)m.w1 + lane, *w2 = (const uint4 *)m.w2 + lane, *w3 = (const uint4 *)m.w3 + lane;
     uint4 ring[RING];
     // fragment `seq` of this wavefront's sequence -> ring slot seq % RING (seq is a constant wherever this is called, after unrolling; the
-    // tile guard is a compile-time `true` except in a layer's last tile slot)
+    // tile guard is a compile-time `true` except in a layer's last tile slot).  Sequence order inside a layer: tile slot, k-step, weight term.
     auto request = [&](int seq) __attribute__((always_inline)) {
         if (seq >= C::STOT) return;
         const int L = seq < C::S1 ? 0 : (seq < C::S1 + C::S2 ? 1 : 2);
         const int r = seq - (L == 0 ? 0 : (L == 1 ? C::S1 : C::S1 + C::S2));
         const int KS = L == 0 ? KS1 : (L == 1 ? C::KS2 : C::KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3);
-        const int i = r / KS, ks = r - i * KS;
+        const int i = r / (KS * NW), rem = r - i * (KS * NW);   // rem = ks * NW + term: the fragment's place inside its tile
         const uint4 *w = L == 0 ? w1 : (L == 1 ? w2 : w3);
-        if (4 * i + 3 < NT || wave + 4 * i < NT) ring[seq % RING] = w[(unsigned)(((wave + 4 * i) * KS + ks) * 64)];
+        if (4 * i + 3 < NT || wave + 4 * i < NT) ring[seq % RING] = w[(unsigned)(((wave + 4 * i) * (KS * NW) + rem) * 64)];
     };
     MLP_STAMP(8)
     // The CU's vector-memory port takes ~64 cycles per wavefront and fragment with four wavefronts asking (3.3 k cycles for the whole ring):
     // the input rows arrive while the first fragments are being requested.  HEAD of them go out first, then the rows are converted (the
-    // port works the queue off meanwhile), then the rest of the ring; padding and biases come last, behind the requests.
+    // port works the queue off meanwhile), the rest of the ring between the conversion steps; padding and biases come last.
     constexpr int HEAD = EV2G_MLPS_HEAD < RING ? EV2G_MLPS_HEAD : RING;
     constexpr int PER = (RING - HEAD + NL2 - 1) / NL2;   // requests per conversion step
 #pragma unroll
@@ -401,7 +420,12 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
         if (c < 0) { r--; c += d_in; } else if (c >= d_in) { r++; c -= d_in; }
 #pragma unroll
         for (int it = 0; it < NL2; it++) {
-            if (f < total) *(uint32_t *)(bufX + r * C::SX + c) = ev2g_pack_bf16(xin[it].x, xin[it].y);
+            uint32_t wd[NX];
+            ev2g_split_bf16<NX>(xin[it].x, xin[it].y, wd);
+            if (f < total) {
+#pragma unroll
+                for (int k = 0; k < NX; k++) *(uint32_t *)(bufX + k * BX + r * C::SX + c) = wd[k];
+            }
             f += 512; r += q512; c += r512;
             if (c >= d_in) { c -= d_in; r++; }
             // the rest of the ring goes out BETWEEN the conversion steps: a request blocks its wavefront while the port is busy, the conversion
@@ -416,9 +440,13 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
             const int f = (it * 256 + tid) * 2;
             int r = (int)((float)f * rdin), c = f - r * d_in;
             if (c < 0) { r--; c += d_in; } else if (c >= d_in) { r++; c -= d_in; }
-            if (f < total) bufX[r * C::SX + c] = ev2g_f32_to_bf16(xin[it].x);
+            uint32_t wd[NX];
+            ev2g_split_bf16<NX>(xin[it].x, xin[it].y, wd);
+#pragma unroll
+            for (int k = 0; k < NX; k++) if (f < total) bufX[k * BX + r * C::SX + c] = (uint16_t)wd[k];
             if (++c == d_in) { c = 0; r++; }
-            if (f + 1 < total) bufX[r * C::SX + c] = ev2g_f32_to_bf16(xin[it].y);
+#pragma unroll
+            for (int k = 0; k < NX; k++) if (f + 1 < total) bufX[k * BX + r * C::SX + c] = (uint16_t)(wd[k] >> 16);
         }
     }
     MLP_STAMP(10)
@@ -428,12 +456,15 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
     }
     {   // zero padding: thread (row = tid / 16, j = tid % 16) clears columns j, j + 16, ... of its row's tail in every operand buffer
         const int pr = tid >> 4, pj = tid & 15;
-        for (int cc = d_in + pj; cc < KS1 * 32; cc += 16) bufX[pr * C::SX + cc] = 0;                 // columns d_in .. KS1*32
-        if (pr >= nr) for (int cc = pj; cc < d_in; cc += 16) bufX[pr * C::SX + cc] = 0;             // rows past the batch
         constexpr int P1 = C::KS2 * 32 - NT1 * 16, P2 = C::KS3 * 32 - NT2 * 16;                       // columns no tile writes
-        if (pj < P1) bufH1[pr * C::SH1 + NT1 * 16 + pj] = 0;
-        if (pj < P2) bufH2[pr * C::SH2 + NT2 * 16 + pj] = 0;
         static_assert(P1 <= 16 && P2 <= 16, "tail columns");
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            for (int cc = d_in + pj; cc < KS1 * 32; cc += 16) bufX[k * BX + pr * C::SX + cc] = 0;             // columns d_in .. KS1*32
+            if (pr >= nr) for (int cc = pj; cc < d_in; cc += 16) bufX[k * BX + pr * C::SX + cc] = 0;         // rows past the batch
+            if (pj < P1) bufH1[k * BH1 + pr * C::SH1 + NT1 * 16 + pj] = 0;
+            if (pj < P2) bufH2[k * BH2 + pr * C::SH2 + NT2 * 16 + pj] = 0;
+        }
 #pragma unroll
         for (int j = 0; j < (C::NB + 255) / 256; j++) { const int i = tid + j * 256; if (i < C::NB) lb[i] = bv[j]; }
     }
@@ -442,13 +473,15 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
     MLP_STAMP(2)
     const int brow = (lane & 15), kq = (lane >> 4);
     // one layer for this wavefront: operand fragments of the 16 rows from LDS (once), then its tile slots
-    auto layer = [&](auto Lc, const uint16_t *A, int sa, const float *bias, uint16_t *out, int so) __attribute__((always_inline)) {
+    auto layer = [&](auto Lc, const uint16_t *A, int sa, int ba, const float *bias, uint16_t *out, int so, int bo) __attribute__((always_inline)) {
         constexpr int L = decltype(Lc)::value;
         constexpr int KS = L == 0 ? KS1 : (L == 1 ? C::KS2 : C::KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3), MT = (NT + 3) / 4;
         constexpr int base = L == 0 ? 0 : (L == 1 ? C::S1 : C::S1 + C::S2);
-        uint4 bfr[KS];
+        uint4 bfr[NX][KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) bfr[ks] = *(const uint4 *)(A + brow * sa + ks * 32 + kq * 8);
+        for (int k = 0; k < NX; k++)
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) bfr[k][ks] = *(const uint4 *)(A + k * ba + brow * sa + ks * 32 + kq * 8);
         f32x4m bini[MT];
 #pragma unroll
         for (int i = 0; i < MT; i++) bini[i] = *(const f32x4m *)(bias + min(wave + 4 * i, NT - 1) * 16 + kq * 4);
@@ -459,21 +492,36 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
                 f32x4m acc0 = bini[i], acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
-                    bf16x8 a, b;
-                    __builtin_memcpy(&a, &ring[(base + i * KS + ks) % RING], 16); __builtin_memcpy(&b, &bfr[ks], 16);
-                    if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0, 0, 0, 0);
-                    request(base + i * KS + ks + RING);   // this slot is free again
+#pragma unroll
+                    for (int p = NW - 1; p >= 0; p--) {   // (the small terms first)
+                        const int sq = base + (i * KS + ks) * NW + p;
+                        bf16x8 a;
+                        __builtin_memcpy(&a, &ring[sq % RING], 16);
+#pragma unroll
+                        for (int xq = NX - 1; xq >= 0; xq--) {
+                            if (NW == 1 || p + xq <= 2) {
+                                bf16x8 b;
+                                __builtin_memcpy(&b, &bfr[xq][ks], 16);
+                                if ((ks + p + xq) & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1, 0, 0, 0);
+                                else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0, 0, 0, 0);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int p = 0; p < NW; p++) request(base + (i * KS + ks) * NW + p + RING);   // these slots are free again
                 }
                 const f32x4m acc = acc0 + acc1;
                 const int col = tile * 16 + kq * 4;   // this lane: columns col .. col + 3 of env row `brow`
                 if (L < 2) {
-                    const uint32_t lo = ev2g_pack_bf16(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f)), hi = ev2g_pack_bf16(fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
-                    *(uint2 *)(out + brow * so + col) = make_uint2(lo, hi);
+                    uint32_t lo[NX], hi[NX];
+                    ev2g_split_bf16<NX>(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), lo);
+                    ev2g_split_bf16<NX>(fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f), hi);
+#pragma unroll
+                    for (int k = 0; k < NX; k++) *(uint2 *)(out + k * bo + brow * so + col) = make_uint2(lo[k], hi[k]);
                 } else {
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { v[r] = ev2g_fast_tanh(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
+                    for (int r = 0; r < 4; r++) { v[r] = NW == 1 ? ev2g_fast_tanh(acc[r]) : tanhf(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
                     const int d_out = m.d_out;
                     if (brow < nr) {
                         float *yr = y + (size_t)(row0 + brow) * d_out + col;
@@ -488,19 +536,19 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
                 }
             } else {
 #pragma unroll
-                for (int ks = 0; ks < KS; ks++) request(base + i * KS + ks + RING);   // no tile in this slot: the sequence moves on all the same
+                for (int u = 0; u < KS * NW; u++) request(base + i * KS * NW + u + RING);   // no tile in this slot: the sequence moves on all the same
             }
         }
     };
-    layer(std::integral_constant<int, 0>{}, bufX, C::SX, lb, bufH1, C::SH1);
+    layer(std::integral_constant<int, 0>{}, bufX, C::SX, BX, lb, bufH1, C::SH1, BH1);
     MLP_STAMP(3)
     __syncthreads();
     MLP_STAMP(4)
-    layer(std::integral_constant<int, 1>{}, bufH1, C::SH1, lb + NT1 * 16, bufH2, C::SH2);
+    layer(std::integral_constant<int, 1>{}, bufH1, C::SH1, BH1, lb + NT1 * 16, bufH2, C::SH2, BH2);
     MLP_STAMP(5)
     __syncthreads();
     MLP_STAMP(6)
-    layer(std::integral_constant<int, 2>{}, bufH2, C::SH2, lb + (NT1 + NT2) * 16, nullptr, 0);
+    layer(std::integral_constant<int, 2>{}, bufH2, C::SH2, BH2, lb + (NT1 + NT2) * 16, nullptr, 0, 0);
     MLP_STAMP(7)
 }
 

@@ -284,14 +284,15 @@ class Engine:
     # ---- policy in the loop ----------------------------------------------------------------------
     def mlp_create(self, W1, b1, W2, b2, W3, b3, out_lo=-1.0, precision="bf16"):
         """Three-layer actor (torch.nn.Linear layout: W[out,in], b[out]; host float32 arrays) evaluated by one fused kernel.
-        precision: "bf16" (bf16 operands, fp32 accumulation: fastest) or "fp32" (float32 operands: what a float32-trained policy,
-        e.g. SB3's, computes -- agreement with a float32 forward at the 1e-6 level, about twice the time)."""
+        precision: "bf16" (bf16 operands, fp32 accumulation: fastest), "fp32" (float32 weights as two bf16 terms, five products per
+        k-step: within 1e-5 of a float64 forward -- what a float32-trained policy, e.g. SB3's, computes -- at twice the bf16 time) or
+        "fp32x3" (three terms, all 24 bits: 1e-7 level, 2.6x the bf16 time); see include/ev2g.h."""
         arrs = [np.ascontiguousarray(a, np.float32) for a in (W1, b1, W2, b2, W3, b3)]
         h1, d_in = arrs[0].shape
         h2, d_out = arrs[2].shape[0], arrs[4].shape[0]
         assert arrs[2].shape == (h2, h1) and arrs[4].shape == (d_out, h2) and arrs[1].shape == (h1,) and arrs[3].shape == (h2,) and arrs[5].shape == (d_out,)
         m = C.c_void_p()
-        prec = {"bf16": 0, "fp32": 1, "f32": 1}[precision]
+        prec = {"bf16": 0, "fp32": 1, "f32": 1, "fp32x3": 2, "f32x3": 2}[precision]
         self._check(self._lib.ev2g_mlp_create_ex(self._h, d_in, h1, h2, d_out, *[a.ctypes.data for a in arrs], float(out_lo), prec, C.byref(m)))
         return m
 

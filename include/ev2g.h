@@ -331,11 +331,17 @@ int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *view);
 typedef struct ev2g_mlp ev2g_mlp;
 int ev2g_mlp_create(ev2g_handle *h, int d_in, int h1, int h2, int d_out, const float *W1, const float *b1, const float *W2,
                     const float *b2, const float *W3, const float *b3, float out_lo, ev2g_mlp **out);
-/* The same with the operand precision chosen: EV2G_MLP_BF16 (the call above: bf16 operands, fastest) or EV2G_MLP_F32 -- float32
- * operands (v_mfma_f32_32x32x2_f32), for policies trained in float32 (SB3's are): the device forward then agrees with a float32
- * forward of the same weights at the 1e-6 level, at about twice the time. */
+/* The same with the operand precision chosen, for policies trained in float32 (SB3's are):
+ *   EV2G_MLP_BF16   (the call above) weights and activations rounded to bf16: fastest, actions within ~1e-2 of a float32 forward;
+ *   EV2G_MLP_F32    float32 weights held as TWO bf16 terms (16 significant bits), activations as three, five MFMA products per k-step: the
+ *                   device forward agrees with a float64 forward of the same weights to 1e-5 (observed 4e-6), at twice the bf16 time;
+ *   EV2G_MLP_F32X3  three terms per weight (all 24 bits), six products: agreement at the 1e-7 level -- what float32 operands give --
+ *                   at 2.6x the bf16 time.
+ * On the shipped layer widths all three run the same streaming kernel on the bf16 matrix cores (the weight stream is the cost: 1x, 2x,
+ * 3x the bytes); other widths fall back to generic kernels (bf16, and float32 operands on v_mfma_f32_32x32x2_f32 for both float32 modes). */
 #define EV2G_MLP_BF16 0
 #define EV2G_MLP_F32 1
+#define EV2G_MLP_F32X3 2
 int ev2g_mlp_create_ex(ev2g_handle *h, int d_in, int h1, int h2, int d_out, const float *W1, const float *b1, const float *W2,
                     const float *b2, const float *W3, const float *b3, float out_lo, int precision, ev2g_mlp **out);
 void ev2g_mlp_destroy(ev2g_handle *h, ev2g_mlp *m);

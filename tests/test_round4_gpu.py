@@ -257,3 +257,36 @@ def test_a_launch_that_falls_off_the_full_instantiation_says_which_argument_did_
     with pytest.warns(UserWarning, match="GENERAL instantiation.*NULL"):
         eng.step_n(1, acts, E * P, obs, 0, rew, 0, None, 0, mask, 0, auto_reset=False, persistent=True)
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rows,d_in,d_out,lo", [(4096, 162, 50, -1.0), (77, 63, 20, 0.0)])
+def test_float32x3_actor_is_at_the_float32_level(n_rows, d_in, d_out, lo):
+    """precision="fp32x3": three bf16 terms per float32 weight and activation, six exact products per k-step on the bf16 matrix cores --
+    the forward agrees with a float64 forward of the same weights to 1e-6 (the two-term mode "fp32" is held to 1e-5 by
+    test_round3_gpu.test_float32_actor_matches_a_float32_forward), and "fp32" is closer to it than "bf16" by orders of magnitude."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.actor import init_mlp_weights
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import GenConfig, generate
+    eng = Engine(generate(GenConfig.v2g_profit_plus_loads(8, 50, 1, seed=1)), _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"],
+                 _abi.STATE_KINDS["V2G_profit_max_loads"], device=0)
+    rng = np.random.default_rng(d_in + n_rows)
+    w = init_mlp_weights(d_in, d_out, seed=3)
+    x = (rng.normal(0, 1, (n_rows, d_in)) * rng.uniform(0.1, 3.0, d_in)).astype(np.float32)
+    W1, b1, W2, b2, W3, b3 = [a.astype(np.float64) for a in w]
+    h = np.maximum(x.astype(np.float64) @ W1.T + b1, 0)
+    h = np.maximum(h @ W2.T + b2, 0)
+    exact = np.tanh(h @ W3.T + b3)
+    exact = exact * 0.5 + 0.5 if lo == 0.0 else exact
+    err = {}
+    for prec in ("fp32x3", "fp32", "bf16"):
+        m = eng.mlp_create(*w, out_lo=lo, precision=prec)
+        dx, dy = eng.empty((n_rows, d_in), np.float32).upload(x), eng.empty((n_rows, d_out), np.float32)
+        eng.mlp_forward(m, dx, dy, n_rows)
+        err[prec] = float(np.abs(dy.to_host() - exact).max())
+        eng.mlp_destroy(m)
+    eng.close()
+    assert err["fp32x3"] <= 1e-6, err
+    assert err["fp32"] <= 1e-5, err
+    assert err["fp32x3"] < err["fp32"] < 0.01 * err["bf16"], err
