@@ -1,0 +1,5 @@
+#!/bin/bash
+# round 4, call X: battery-maths items rotated over the wavefronts (SIMDs) step by step
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; O=gpurun_out/r4x; mkdir -p $O
+V=build_variants
+for w in cfg2 cfg3; do timeout 500 python tools/ab_bench.py --workload $w --reps 16 --pool 4 $V/r4_head.so $V/r4_brot.so $V/r4_head.so $V/r4_brot.so 2>&1 | grep -v amdgpu.ids | sed 's/   digest \[.*//' | tee $O/ab_$w.txt; done
