@@ -1030,6 +1030,7 @@ struct ev2g_mlp {
     size_t lds = 0;
     const void *fn = nullptr;   // the kernel for this shape
     int rows = EV2G_MLP_ROWS;   // env rows per workgroup of that kernel
+    int threads = EV2G_MLP_BLOCK;
 };
 
 // the fixed-shape kernels exist for the layer widths of the shipped configs (obs 162 / 63 -> 400 -> 300 -> ports); anything else
@@ -1044,19 +1045,24 @@ static const void *mlp_kernel_for(const MlpDev &d) {
 }
 
 // the 16-row streaming kernel (ev2g_mlp3_s16) exists for the shipped shapes; EV2G_MLP_OLD=1 keeps round 3's 32-row kernel (A/B runs)
-struct MlpS16Pick { const void *fn; size_t lds; int ks1, nt1, nt2, nt3, nw; };
+struct MlpS16Pick { const void *fn; size_t lds; int ks1, nt1, nt2, nt3, nw, threads; };
 // nw: bf16 terms per weight -- 1: the bf16 network; 2 / 3: the float32 network as split bf16 operands (EV2G_MLP_F32 / EV2G_MLP_F32X3, ev2g_mlp.h)
 static MlpS16Pick mlp_s16_for(int d_in, int h1, int h2, int d_out, int nw) {
     const int ks1 = (d_in + 31) / 32, nt1 = (h1 + 15) / 16, nt2 = (h2 + 15) / 16, nt3 = (d_out + 15) / 16;
     const char *old = std::getenv("EV2G_MLP_OLD");
-    if (old && old[0] == '1') return {nullptr, 0, 0, 0, 0, 0, 0};
-#define EV2G_S16_CASE(K, A, B, Cc, N) \
-    if (ks1 == K && nt1 == A && nt2 == B && nt3 == Cc && nw == N) return {(const void *)ev2g_mlp3_s16<K, A, B, Cc, N>, MlpS16<K, A, B, Cc, N>::lds_bytes, ks1, nt1, nt2, nt3, nw};
-    EV2G_S16_CASE(6, 25, 19, 4, 1) EV2G_S16_CASE(2, 25, 19, 2, 1)
-    EV2G_S16_CASE(6, 25, 19, 4, 2) EV2G_S16_CASE(2, 25, 19, 2, 2)
-    EV2G_S16_CASE(6, 25, 19, 4, 3) EV2G_S16_CASE(2, 25, 19, 2, 3)
+    if (old && old[0] == '1') return {nullptr, 0, 0, 0, 0, 0, 0, 0};
+    // the bf16 network runs eight wavefronts per workgroup (two per SIMD: one's epilogue and LDS waits under the other's MFMAs -- 7.48 -> 7.39 us at
+    // 162 inputs, 6.35 -> 5.88 at 63); the float32 modes need the registers of four.  EV2G_MLP_WAVES=4 selects four for the bf16 network (A/B runs).
+    const char *w8 = std::getenv("EV2G_MLP_WAVES");
+    const int wv = (nw == 1 && !(w8 && w8[0] == '4')) ? 8 : 4;
+#define EV2G_S16_CASE(K, A, B, Cc, N, W) \
+    if (ks1 == K && nt1 == A && nt2 == B && nt3 == Cc && nw == N && wv == W) return {(const void *)ev2g_mlp3_s16<K, A, B, Cc, N, W>, MlpS16<K, A, B, Cc, N, W>::lds_bytes, ks1, nt1, nt2, nt3, nw, W * 64};
+    EV2G_S16_CASE(6, 25, 19, 4, 1, 4) EV2G_S16_CASE(2, 25, 19, 2, 1, 4)
+    EV2G_S16_CASE(6, 25, 19, 4, 2, 4) EV2G_S16_CASE(2, 25, 19, 2, 2, 4)
+    EV2G_S16_CASE(6, 25, 19, 4, 3, 4) EV2G_S16_CASE(2, 25, 19, 2, 3, 4)
+    EV2G_S16_CASE(6, 25, 19, 4, 1, 8) EV2G_S16_CASE(2, 25, 19, 2, 1, 8)
 #undef EV2G_S16_CASE
-    return {nullptr, 0, 0, 0, 0, 0, 0};
+    return {nullptr, 0, 0, 0, 0, 0, 0, 0};
 }
 
 static uint16_t host_bf16(float f) {   // round to nearest even (same as the kernel's)
@@ -1140,7 +1146,7 @@ int ev2g_mlp_create_ex(ev2g_handle *h, int d_in, int h1, int h2, int d_out, cons
     const bool f32 = precision != EV2G_MLP_BF16;
     const MlpS16Pick s16 = mlp_s16_for(d_in, h1, h2, d_out, precision == EV2G_MLP_BF16 ? 1 : (precision == EV2G_MLP_F32 ? 2 : 3));
     m->lds = s16.fn ? s16.lds : (f32 ? ev2g_mlp32_lds_bytes(d) : ev2g_mlp_lds_bytes(d));
-    if (s16.fn) m->rows = EV2G_MLPS_ROWS;
+    if (s16.fn) { m->rows = EV2G_MLPS_ROWS; m->threads = s16.threads; }
     if (m->lds > 160 * 1024) { delete m; return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create: layers too wide for the LDS-resident activations"); }
     int rc = 0;
     auto upw = [&](const std::vector<uint16_t> &v, const uint16_t **dst) { uint16_t *p; rc = upload(h, m->allocs, v.data(), v.size(), &p); *dst = p; return rc; };
@@ -1192,7 +1198,7 @@ int ev2g_mlp_forward(ev2g_handle *h, const ev2g_mlp *m, const float *x, float *y
     (void)hipSetDevice(h->device);
     MlpDev dev = m->dev;
     void *args[] = {&dev, &x, &y, &n_rows};
-    HIPCHK(h, hipLaunchKernel(m->fn, dim3((n_rows + m->rows - 1) / m->rows), dim3(EV2G_MLP_BLOCK), args, m->lds, h->stream));
+    HIPCHK(h, hipLaunchKernel(m->fn, dim3((n_rows + m->rows - 1) / m->rows), dim3(m->threads), args, m->lds, h->stream));
     return EV2G_OK;
 }
 

@@ -339,14 +339,15 @@ typedef float f32x4m __attribute__((ext_vector_type(4)));
 // float32 accumulator: every product of two bf16 values is exact in float32, so what is lost is the dropped terms (2^-24 relative and
 // below for NW = 3: the same level as float32 operands) and the accumulation order.  The float32 MFMA (v_mfma_f32_32x32x2_f32, ev2g_mlp3_f32)
 // runs at 1/16 of the bf16 rate; here the cost is the weight stream, NW times the bf16 kernel's.
-template <int KS1, int NT1, int NT2, int NT3, int NW = 1> struct MlpS16 {
+template <int KS1, int NT1, int NT2, int NT3, int NW = 1, int WV = 4> struct MlpS16 {   // WV: wavefronts per workgroup (4: one per SIMD; 8: two)
     static constexpr int NX = NW == 1 ? 1 : 3;   // terms of an activation
     static constexpr int KS2 = (NT1 * 16 + 31) / 32, KS3 = (NT2 * 16 + 31) / 32;
-    static constexpr int MT1 = (NT1 + 3) / 4, MT2 = (NT2 + 3) / 4, MT3 = (NT3 + 3) / 4;   // tile slots per wavefront
+    static constexpr int NTH = WV * 64;
+    static constexpr int MT1 = (NT1 + WV - 1) / WV, MT2 = (NT2 + WV - 1) / WV, MT3 = (NT3 + WV - 1) / WV;   // tile slots per wavefront
     static constexpr int S1 = MT1 * KS1 * NW, S2 = MT2 * KS2 * NW, S3 = MT3 * KS3 * NW, STOT = S1 + S2 + S3;   // fragments of the sequence, per layer
     static constexpr int SX = KS1 * 32 + 8, SH1 = KS2 * 32 + 8, SH2 = KS3 * 32 + 8;             // LDS row strides (bf16 elements; +16 bytes against bank conflicts)
     static constexpr int NB = (NT1 + NT2 + NT3) * 16;                                          // staged biases (floats)
-    static constexpr int RING = NW == 1 ? EV2G_MLPS_RING : 36;                                 // (three operand copies per k-step take the registers)
+    static constexpr int RING = (NW == 1 ? EV2G_MLPS_RING : 36) * 4 / WV;                                 // (three operand copies per k-step take the registers)
     static constexpr size_t lds_bytes = (size_t)EV2G_MLPS_ROWS * (SX + SH1 + SH2) * 2 * NX + (size_t)NB * 4;
 };
 
@@ -359,37 +360,38 @@ template <int NX> __device__ __forceinline__ void ev2g_split_bf16(float a, float
     }
 }
 
-template <int KS1, int NT1, int NT2, int NT3, int NW = 1>
-__global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__restrict__ x, float *__restrict__ y, int n_rows) {
-    typedef MlpS16<KS1, NT1, NT2, NT3, NW> C;
+template <int KS1, int NT1, int NT2, int NT3, int NW = 1, int WV = 4>
+__global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *__restrict__ x, float *__restrict__ y, int n_rows) {
+    typedef MlpS16<KS1, NT1, NT2, NT3, NW, WV> C;
+    constexpr int NTH = C::NTH;
     constexpr int RING = C::RING, NX = C::NX;
     extern __shared__ __attribute__((aligned(16))) uint16_t mlds[];
     // operand buffers: NX copies (terms) of each, one behind the other
     constexpr int BX = EV2G_MLPS_ROWS * C::SX, BH1 = EV2G_MLPS_ROWS * C::SH1, BH2 = EV2G_MLPS_ROWS * C::SH2;
     uint16_t *bufX = mlds, *bufH1 = bufX + NX * BX, *bufH2 = bufH1 + NX * BH1;
     float *lb = (float *)(bufH2 + NX * BH2);   // biases: layer 1 | layer 2 | layer 3
-    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & (WV - 1);
     const int row0 = blockIdx.x * EV2G_MLPS_ROWS;
     const int nr = min(EV2G_MLPS_ROWS, n_rows - row0);
     MLP_STAMP(0)
     // ---- requests, oldest first (vmcnt retires in order): input rows, biases, then the head of the weight sequence ----
     const int d_in = m.d_in, total = nr * d_in;
     const float *xs = x + (size_t)row0 * d_in;
-    constexpr int NL2 = (EV2G_MLPS_ROWS * KS1 * 32 / 2 + 255) / 256;   // 8-byte pieces per lane (16 rows of at most KS1*32 columns)
+    constexpr int NL2 = (EV2G_MLPS_ROWS * KS1 * 32 / 2 + NTH - 1) / NTH;   // 8-byte pieces per lane (16 rows of at most KS1*32 columns)
     const bool pairs = (d_in & 1) == 0 && (((size_t)xs) & 7) == 0;    // (uniform) an even row length: two neighbours never straddle a row
     // (unconditional loads from clamped addresses: a load inside a per-lane branch whose result merges with a default makes the compiler
     // drain vmcnt before the next one -- six round trips in a row instead of one)
     float2 xin[NL2];
     if (pairs) {
 #pragma unroll
-        for (int it = 0; it < NL2; it++) xin[it] = *(const float2 *)(xs + min((it * 256 + tid) * 2, total - 2));
+        for (int it = 0; it < NL2; it++) xin[it] = *(const float2 *)(xs + min((it * NTH + tid) * 2, total - 2));
     } else {
 #pragma unroll
-        for (int it = 0; it < NL2; it++) { const int f = (it * 256 + tid) * 2; xin[it].x = xs[min(f, total - 1)]; xin[it].y = xs[min(f + 1, total - 1)]; }
+        for (int it = 0; it < NL2; it++) { const int f = (it * NTH + tid) * 2; xin[it].x = xs[min(f, total - 1)]; xin[it].y = xs[min(f + 1, total - 1)]; }
     }
-    float bv[(C::NB + 255) / 256];   // the three bias vectors are ONE array on this path (ev2g_mlp_create_ex): b1 | b2 | b3, each padded to its tiles
+    float bv[(C::NB + NTH - 1) / NTH];   // the three bias vectors are ONE array on this path (ev2g_mlp_create_ex): b1 | b2 | b3, each padded to its tiles
 #pragma unroll
-    for (int j = 0; j < (C::NB + 255) / 256; j++) bv[j] = m.b1[min(tid + j * 256, C::NB - 1)];
+    for (int j = 0; j < (C::NB + NTH - 1) / NTH; j++) bv[j] = m.b1[min(tid + j * NTH, C::NB - 1)];
     const uint4 *w1 = (const uint4 *)m.w1 + lane, *w2 = (const uint4 *)m.w2 + lane, *w3 = (const uint4 *)m.w3 + lane;
     uint4 ring[RING];
     // fragment `seq` of this wavefront's sequence -> ring slot seq % RING (seq is a constant wherever this is called, after unrolling; the
@@ -401,20 +403,20 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
         const int KS = L == 0 ? KS1 : (L == 1 ? C::KS2 : C::KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3);
         const int i = r / (KS * NW), rem = r - i * (KS * NW);   // rem = ks * NW + term: the fragment's place inside its tile
         const uint4 *w = L == 0 ? w1 : (L == 1 ? w2 : w3);
-        if (4 * i + 3 < NT || wave + 4 * i < NT) ring[seq % RING] = w[(unsigned)(((wave + 4 * i) * (KS * NW) + rem) * 64)];
+        if (WV * i + WV - 1 < NT || wave + WV * i < NT) ring[seq % RING] = w[(unsigned)(((wave + WV * i) * (KS * NW) + rem) * 64)];
     };
     MLP_STAMP(8)
     // The CU's vector-memory port takes ~64 cycles per wavefront and fragment with four wavefronts asking (3.3 k cycles for the whole ring):
     // the input rows arrive while the first fragments are being requested.  HEAD of them go out first, then the rows are converted (the
     // port works the queue off meanwhile), the rest of the ring between the conversion steps; padding and biases come last.
-    constexpr int HEAD = EV2G_MLPS_HEAD < RING ? EV2G_MLPS_HEAD : RING;
+    constexpr int HEAD = (EV2G_MLPS_HEAD * 4 / WV) < RING ? (EV2G_MLPS_HEAD * 4 / WV) : RING;
     constexpr int PER = (RING - HEAD + NL2 - 1) / NL2;   // requests per conversion step
 #pragma unroll
     for (int sq = 0; sq < HEAD; sq++) request(sq);
     MLP_STAMP(9)
     // ---- input rows -> bf16 operand rows in LDS ----
-    if (pairs) {   // element pair p = it * 256 + tid sits at (row, column) = divmod(2 p, d_in): one division, then steps of 512 elements
-        const int q512 = 512 / d_in, r512 = 512 - q512 * d_in;   // (uniform)
+    if (pairs) {   // element pair p = it * NTH + tid sits at (row, column) = divmod(2 p, d_in): one division, then steps of 2 NTH elements
+        const int q512 = (2 * NTH) / d_in, r512 = 2 * NTH - q512 * d_in;   // (uniform)
         int f = tid * 2;
         int r = (int)((float)f * (1.0f / (float)d_in)), c = f - r * d_in;   // exact after the one-step correction (f < 2^23)
         if (c < 0) { r--; c += d_in; } else if (c >= d_in) { r++; c -= d_in; }
@@ -426,7 +428,7 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
 #pragma unroll
                 for (int k = 0; k < NX; k++) *(uint32_t *)(bufX + k * BX + r * C::SX + c) = wd[k];
             }
-            f += 512; r += q512; c += r512;
+            f += 2 * NTH; r += q512; c += r512;
             if (c >= d_in) { c -= d_in; r++; }
             // the rest of the ring goes out BETWEEN the conversion steps: a request blocks its wavefront while the port is busy, the conversion
             // of the other wavefronts fills that time (and their requests, this one's conversion)
@@ -437,7 +439,7 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
         const float rdin = 1.0f / (float)d_in;
 #pragma unroll
         for (int it = 0; it < NL2; it++) {
-            const int f = (it * 256 + tid) * 2;
+            const int f = (it * NTH + tid) * 2;
             int r = (int)((float)f * rdin), c = f - r * d_in;
             if (c < 0) { r--; c += d_in; } else if (c >= d_in) { r++; c -= d_in; }
             uint32_t wd[NX];
@@ -454,8 +456,8 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
 #pragma unroll
         for (int sq = HEAD; sq < RING; sq++) request(sq);
     }
-    {   // zero padding: thread (row = tid / 16, j = tid % 16) clears columns j, j + 16, ... of its row's tail in every operand buffer
-        const int pr = tid >> 4, pj = tid & 15;
+    if (tid < 256) {   // zero padding: thread (row = tid / 16, j = tid % 16) clears columns j, j + 16, ... of its row's tail in every operand buffer
+        const int pr = (tid >> 4) & 15, pj = tid & 15;   // (the first 256 threads)
         constexpr int P1 = C::KS2 * 32 - NT1 * 16, P2 = C::KS3 * 32 - NT2 * 16;                       // columns no tile writes
         static_assert(P1 <= 16 && P2 <= 16, "tail columns");
 #pragma unroll
@@ -465,9 +467,9 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
             if (pj < P1) bufH1[k * BH1 + pr * C::SH1 + NT1 * 16 + pj] = 0;
             if (pj < P2) bufH2[k * BH2 + pr * C::SH2 + NT2 * 16 + pj] = 0;
         }
-#pragma unroll
-        for (int j = 0; j < (C::NB + 255) / 256; j++) { const int i = tid + j * 256; if (i < C::NB) lb[i] = bv[j]; }
     }
+#pragma unroll
+    for (int j = 0; j < (C::NB + NTH - 1) / NTH; j++) { const int i = tid + j * NTH; if (i < C::NB) lb[i] = bv[j]; }
     MLP_STAMP(1)
     __syncthreads();
     MLP_STAMP(2)
@@ -475,7 +477,7 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
     // one layer for this wavefront: operand fragments of the 16 rows from LDS (once), then its tile slots
     auto layer = [&](auto Lc, const uint16_t *A, int sa, int ba, const float *bias, uint16_t *out, int so, int bo) __attribute__((always_inline)) {
         constexpr int L = decltype(Lc)::value;
-        constexpr int KS = L == 0 ? KS1 : (L == 1 ? C::KS2 : C::KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3), MT = (NT + 3) / 4;
+        constexpr int KS = L == 0 ? KS1 : (L == 1 ? C::KS2 : C::KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3), MT = (NT + WV - 1) / WV;
         constexpr int base = L == 0 ? 0 : (L == 1 ? C::S1 : C::S1 + C::S2);
         uint4 bfr[NX][KS];
 #pragma unroll
@@ -484,11 +486,11 @@ __global__ void __launch_bounds__(256) ev2g_mlp3_s16(MlpDev m, const float *__re
             for (int ks = 0; ks < KS; ks++) bfr[k][ks] = *(const uint4 *)(A + k * ba + brow * sa + ks * 32 + kq * 8);
         f32x4m bini[MT];
 #pragma unroll
-        for (int i = 0; i < MT; i++) bini[i] = *(const f32x4m *)(bias + min(wave + 4 * i, NT - 1) * 16 + kq * 4);
+        for (int i = 0; i < MT; i++) bini[i] = *(const f32x4m *)(bias + min(wave + WV * i, NT - 1) * 16 + kq * 4);
 #pragma unroll
         for (int i = 0; i < MT; i++) {
-            const int tile = wave + 4 * i;
-            if (4 * i + 3 < NT || tile < NT) {   // (uniform; a constant but for the last slot)
+            const int tile = wave + WV * i;
+            if (WV * i + WV - 1 < NT || tile < NT) {   // (uniform; a constant but for the last slot)
                 f32x4m acc0 = bini[i], acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {

@@ -290,3 +290,39 @@ def test_float32x3_actor_is_at_the_float32_level(n_rows, d_in, d_out, lo):
     assert err["fp32x3"] <= 1e-6, err
     assert err["fp32"] <= 1e-5, err
     assert err["fp32x3"] < err["fp32"] < 0.01 * err["bf16"], err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rows,d_in,d_out,lo,prec", [(37, 161, 49, -1.0, "bf16"), (4101, 170, 64, 0.0, "bf16"), (53, 33, 17, -1.0, "bf16"), (29, 64, 31, 0.0, "fp32"),
+                                                       (16, 192, 50, -1.0, "fp32x3")])
+def test_streaming_actor_ragged_shapes(n_rows, d_in, d_out, lo, prec):
+    """The 16-row streaming actor kernel at the edges of its instantiations (k-steps of 32 inputs: 161..192 / 33..64; output tiles of 16: 49..64 / 17..32):
+    odd input widths (scalar input loads instead of pairs), odd output widths (scalar stores), a last workgroup with a single row, padded
+    output columns that must not be written -- against the numpy forward with the same operand rounding."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.actor import init_mlp_weights, mlp_forward_numpy
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import GenConfig, generate
+    eng = Engine(generate(GenConfig.v2g_profit_plus_loads(8, 50, 1, seed=1)), _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"],
+                 _abi.STATE_KINDS["V2G_profit_max_loads"], device=0)
+    rng = np.random.default_rng(d_in * 7 + n_rows)
+    w = init_mlp_weights(d_in, d_out, seed=5)
+    x = (rng.normal(0, 1, (n_rows, d_in)) * rng.uniform(0.1, 3.0, d_in)).astype(np.float32)
+    m = eng.mlp_create(*w, out_lo=lo, precision=prec)
+    dx = eng.empty((n_rows, d_in), np.float32).upload(x)
+    guard = np.full((n_rows + 2, d_out), 7.0, np.float32)   # two rows behind the batch: must stay untouched
+    dy = eng.empty((n_rows + 2, d_out), np.float32).upload(guard)
+    eng.mlp_forward(m, dx, dy, n_rows)
+    y = dy.to_host()
+    assert np.all(y[n_rows:] == 7.0)
+    if prec == "bf16":
+        ref = mlp_forward_numpy(x, w, lo, bf16=True)
+    else:   # float64 forward
+        W1, b1, W2, b2, W3, b3 = [a.astype(np.float64) for a in w]
+        hh = np.maximum(np.maximum(x.astype(np.float64) @ W1.T + b1, 0) @ W2.T + b2, 0)
+        ref = np.tanh(hh @ W3.T + b3)
+        ref = ref * 0.5 + 0.5 if lo == 0.0 else ref
+    tol = 3e-3 if prec == "bf16" else (1e-5 if prec == "fp32" else 1e-6)
+    assert np.abs(y[:n_rows] - ref).max() <= tol, np.abs(y[:n_rows] - ref).max()
+    eng.mlp_destroy(m)
+    eng.close()
