@@ -411,6 +411,18 @@ EV2G_HD double ev2g_gen_setpoint_load(double w, double wsum, double need, int dt
 EV2G_HD int ev2g_gen_median_window(int dt) { return 5 * ((15 / dt) > 1 ? (15 / dt) : 1); }
 // median of the k values pad[t .. t + k) (k <= 80)
 EV2G_HD double ev2g_gen_median(const double *pad, int t, int k) {
+    if (k <= 16) {   // by rank (no array to sort: on the device an indexed local array is scratch memory): element i has rank #{x_j < x_i} + #{j < i: x_j == x_i};
+                     // the value(s) of the middle rank(s) are what the sort below finds
+        double lo = 0.0, hi = 0.0;
+        for (int i = 0; i < k; i++) {
+            const double xi = pad[t + i];
+            int r = 0;
+            for (int j = 0; j < k; j++) { const double xj = pad[t + j]; r += (xj < xi || (xj == xi && j < i)) ? 1 : 0; }
+            if (r == (k - 1) / 2) lo = xi;
+            if (r == k / 2) hi = xi;
+        }
+        return (k & 1) ? hi : 0.5 * (lo + hi);
+    }
     double win[80];
     for (int i = 0; i < k; i++) win[i] = pad[t + i];
     for (int i = 1; i < k; i++) { const double v = win[i]; int j = i - 1; while (j >= 0 && win[j] > v) { win[j + 1] = win[j]; j--; } win[j + 1] = v; }

@@ -37,7 +37,9 @@ struct RefillArgs {
     double *step_tab;                // fast path: [M, T, 8] per-step scalars (or null)
     unsigned long long *dbg;    // [16] cycle stamps of workgroup 0 (tools/refill_time.py --stamps), or null
 };
-#define RF_STAMP(i) if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = __builtin_readcyclecounter();
+#define RF_STAMP(i) if (a.dbg && threadIdx.x == 0) { if (blockIdx.x == 0) a.dbg[i] = __builtin_readcyclecounter(); \
+        if (blockIdx.x == gridDim.x - 1 && ((i) == 0 || (i) == 6)) a.dbg[8 + ((i) != 0)] = __builtin_readcyclecounter(); \
+        if (blockIdx.x == gridDim.x / 2 && ((i) == 0 || (i) == 6)) a.dbg[10 + ((i) != 0)] = __builtin_readcyclecounter(); }
 
 __device__ __forceinline__ double rf_wave_max(double v) {
     for (int d = 32; d > 0; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
@@ -300,29 +302,40 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
                 d_es[e] = on ? (int)l_dr[e * 3] : 0x7fffffff; d_ee[e] = on ? (int)l_dr[e * 3 + 1] : -1;
                 d_lim[e] = on ? peak - peak * l_dr[e * 3 + 2] / 100.0 : 0.0;
             }
-            // element i = step * 40 + j40, i = lane, lane + 64, ...: (step, j40) advance by (1, +24) with a carry -- no division per element
-            int step = lane / 40, j40 = lane - step * 40;
-            for (int i = lane; i < (T + 1) * 40; i += 64) {
-                double v;
-                if (j40 < 20) {   // (loads - pv) window, Transformer.get_load_pv_forecast transformer.py:173-188
-                    const int j = j40, kk = step + j;
-                    double l, pv;
-                    if (kk < T) { if (j == 0) { l = infl[kk]; pv = l_sol[kk]; } else { l = l_lf[kk]; pv = l_pvf[kk]; } }
-                    else if (step >= T - 1) { l = 1.0 * infl[T - 1]; pv = 1.0 * l_sol[T - 1]; }
-                    else { l = 1.0 * l_lf[T - 1]; pv = 1.0 * l_pvf[T - 1]; }
-                    v = l - pv;
-                } else {          // power limits, Transformer.get_power_limits transformer.py:142-171
-                    const int j = j40 - 20;
-                    v = peak * 1.0;
+            // Two loops of (T + 1) * 20 elements each instead of one over both halves of a row: the halves share nothing, and in one loop every
+            // wavefront executed both bodies for every element (round 3: 80 k of the kernel's 220 k cycles).  Element i = step * 20 + j, i = lane,
+            // lane + 64, ...: (step, j) advance by (3, +4) with a carry -- no division per element.
+            {   // (loads - pv) window, Transformer.get_load_pv_forecast transformer.py:173-188: columns 0..19
+                int step = lane / 20, j = lane - step * 20;
+                for (int i = lane; i < (T + 1) * 20; i += 64) {
+                    const int kk = step + j;
+                    // the actual series for the current step (j == 0) and behind the horizon of the last one, the forecast otherwise; the same
+                    // element [min(kk, T - 1)] of either pair (1.0 * x == x)
+                    const bool actual = (kk < T) ? (j == 0) : (step >= T - 1);
+                    const double *lsrc = actual ? infl : l_lf, *psrc = actual ? l_sol : l_pvf;
+                    const int ke = min(kk, T - 1);
+                    const double v = lsrc[ke] - psrc[ke];
+                    if (wt) wt[step * 40 + j] = v;
+                    if (ht) ht[(size_t)step * 60 + 20 + j] = v;
+                    step += 3; j += 4;
+                    if (j >= 20) { j -= 20; step += 1; }
+                }
+            }
+            {   // power limits, Transformer.get_power_limits transformer.py:142-171: columns 20..39
+                int step = lane / 20, j = lane - step * 20;
+                for (int i = lane; i < (T + 1) * 20; i += 64) {
+                    double v = peak * 1.0;
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        const int es = d_es[e], ee = d_ee[e];
-                        if (step + ahead >= es && ee >= step) {   // (an unused slot never matches: es = INT_MAX)
-                            int aa, bb;
-                            if (step > es) { aa = 0; bb = ee - step; } else { aa = es - step; bb = ee - step; }
-                            if (aa < 0) aa = -aa;
-                            if (bb < 0) bb = -bb;
-                            if (j >= aa && j < bb) v = d_lim[e];
+                        if (e < nd) {   // (uniform)
+                            const int es = d_es[e], ee = d_ee[e];
+                            if (step + ahead >= es && ee >= step) {
+                                int aa, bb;
+                                if (step > es) { aa = 0; bb = ee - step; } else { aa = es - step; bb = ee - step; }
+                                if (aa < 0) aa = -aa;
+                                if (bb < 0) bb = -bb;
+                                if (j >= aa && j < bb) v = d_lim[e];
+                            }
                         }
                     }
                     for (int e = 4; e < nd; e++) {
@@ -335,11 +348,11 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
                             if (j >= aa && j < bb) v = peak - peak * l_dr[e * 3 + 2] / 100.0;
                         }
                     }
+                    if (wt) wt[step * 40 + 20 + j] = v;
+                    if (ht) ht[(size_t)step * 60 + 40 + j] = v;
+                    step += 3; j += 4;
+                    if (j >= 20) { j -= 20; step += 1; }
                 }
-                if (wt) wt[i] = v;
-                if (ht) ht[(size_t)step * 60 + 20 + j40] = v;
-                step += 1; j40 += 24;
-                if (j40 >= 40) { j40 -= 40; step += 1; }
             }
         }
     }

@@ -93,9 +93,11 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
         static unsigned long long *d_dbg = nullptr;
         if (!d_dbg) { (void)hipMalloc((void **)&d_dbg, 16 * 8); (void)hipMemset(d_dbg, 0, 16 * 8); }
         else {
-            unsigned long long v[8];
+            unsigned long long v[12];
             (void)hipStreamSynchronize(h->stream);
-            (void)hipMemcpy(v, d_dbg, 64, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(v, d_dbg, 96, hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "[ev2g] refill: workgroup 0 runs %llu cycles; the middle workgroup starts %lld cycles after it and runs %llu; the last one starts %lld after and runs %llu\n",
+                         v[6] - v[0], (long long)(v[10] - v[0]), v[11] - v[10], (long long)(v[8] - v[0]), v[9] - v[8]);
             std::fprintf(stderr, "[ev2g] refill stamps (cycles): prices %llu | step tables %llu | pass 1 %llu | pass 2 %llu | transformer series %llu | observation tables %llu | setpoints %llu\n",
                          v[1] - v[0], v[2] - v[1], v[3] - v[2], v[4] - v[3], v[7] - v[4], v[5] - v[7], v[6] - v[5]);   // (series / tables: of the LAST transformer)
         }
@@ -104,6 +106,11 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
     const size_t lds = ev2g_refill_lds_bytes(s.T, s.P, h->sess_cap);
     if (lds > 160 * 1024) return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: the scenario's work arrays exceed the LDS");
     if (lds > 48 * 1024) HIPCHK(h, hipFuncSetAttribute((const void *)ev2g_refill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (std::getenv("EV2G_REFILL_STAMPS")) {   // development: how many of these one-wavefront workgroups a CU holds
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)ev2g_refill_kernel, 64, lds);
+        std::fprintf(stderr, "[ev2g] refill: %zu bytes of LDS per workgroup, %d workgroups per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor), %d workgroups\n", lds, nb, n);
+    }
     hipLaunchKernelGGL(ev2g_refill_kernel, dim3(n), dim3(64), lds, h->stream, s, h->st, a, h->d_ss_afap);
     HIPCHK(h, hipGetLastError());
     // (the observation tables of the refilled slots -- window, head and step table -- are rebuilt by the kernel itself, from LDS)
