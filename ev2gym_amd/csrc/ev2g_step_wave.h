@@ -12,6 +12,7 @@
 // The reduction is still LDS-staged and fixed-order (8 quantities x 8 lanes, two chains, 3 xor steps), i.e.
 // bit-reproducible, and identical in value to the generic kernel's (same tree).
 #pragma once
+#include <type_traits>
 #include "ev2g_step_v2.h"
 
 #ifndef EV2G_WAVE_BLOCK
@@ -610,6 +611,42 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                               // an unclamped index past the env reads a neighbour's slot (or, behind the last row, the array that
                               // follows `stage` in LDS) and is masked
                 const bool upper = P > 16;   // (uniform)
+#ifndef EV2G_NO_DPAR
+                // two or three envs per wavefront (the PublicPST benchmark shape: 3 x 20 ports): their reductions are independent -- all LDS
+                // reads first, then the three add / butterfly chains side by side -- instead of one env after the other, each behind its own
+                // LDS round trip (1.9 k of a workgroup-step's 10.8 k ticks at cfg3)
+                auto envs_at_once = [&](auto NEc) __attribute__((always_inline)) {
+                    constexpr int NE = decltype(NEc)::value;
+                    double ra0[NE], rb0[NE], ra1[NE], rb1[NE];
+#pragma unroll
+                    for (int w = 0; w < NE; w++) {
+                        const double *r0 = row + wbase + w * P + j;
+                        ra0[w] = r0[0]; rb0[w] = r0[8]; ra1[w] = 0.0; rb1[w] = 0.0;
+                        if (upper) { ra1[w] = r0[16]; rb1[w] = r0[24]; }
+                    }
+                    double acc[NE];
+#pragma unroll
+                    for (int w = 0; w < NE; w++) {
+                        const int a = wbase + w * P, b = a + P, i = a + j;
+                        double ac = 0.0, accb = 0.0;
+                        ac += (i < b) ? ra0[w] : 0.0;
+                        accb += (i + 8 < b) ? rb0[w] : 0.0;
+                        if (upper) { ac += (i + 16 < b) ? ra1[w] : 0.0; accb += (i + 24 < b) ? rb1[w] : 0.0; }
+                        acc[w] = ac + accb;
+                    }
+#pragma unroll
+                    for (int w = 0; w < NE; w++) acc[w] += xor1_f64(acc[w]);
+#pragma unroll
+                    for (int w = 0; w < NE; w++) acc[w] += xor2_f64(acc[w]);
+#pragma unroll
+                    for (int w = 0; w < NE; w++) acc[w] += xor4_f64(acc[w]);
+#pragma unroll
+                    for (int w = 0; w < NE; w++) if (j == 0) stage[k * RS + wbase + w * P] = acc[w];
+                };
+                if (EPW == 3) envs_at_once(std::integral_constant<int, 3>{});
+                else if (EPW == 2) envs_at_once(std::integral_constant<int, 2>{});
+                else
+#endif
 #pragma unroll 1
                 for (int w = 0; w < EPW; w++) {
                     const int a = wbase + w * P, b = a + P;
