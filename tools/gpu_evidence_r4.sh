@@ -24,3 +24,10 @@ EV2G_PT_LIB=build_variants/pt_plain.so timeout 200 python tools/phase_timing.py 
 EV2G_PT_LIB=build_variants/pt_outer.so timeout 200 python tools/phase_timing.py cfg2 --outer 2>&1 | grep -v amdgpu.ids > $O/r04_phase_cfg2_outer.txt
 EV2G_PT_LIB=build_variants/pt_plain.so timeout 200 python tools/phase_timing.py cfg3 2>&1 | grep -v amdgpu.ids > $O/r04_phase_cfg3.txt
 EV2G_PT_LIB=build_variants/pt_plain.so timeout 300 python tools/phase_timing.py cfg4 2>&1 | grep -v amdgpu.ids > $O/r04_phase_cfg4.txt
+for p in bf16 fp32 fp32x3; do MLP_PREC=$p timeout 200 python tools/mlp_time.py 2>&1 | grep -v amdgpu.ids; done > $O/r04_actor_time.txt
+EV2G_MLP_OLD=1 timeout 200 python tools/mlp_time.py 2>&1 | grep -v amdgpu.ids | sed 's/^/EV2G_MLP_OLD=1 (round 3 kernel): /' >> $O/r04_actor_time.txt
+EV2G_MLP_OLD=1 MLP_PREC=fp32 timeout 200 python tools/mlp_time.py 2>&1 | grep -v amdgpu.ids | sed 's/^/EV2G_MLP_OLD=1 (round 3 float32-operand kernel): /' >> $O/r04_actor_time.txt
+EV2G_LIB=$PWD/build_variants/mlpt.so timeout 200 python tools/mlp_stamps.py 2>&1 | grep -v amdgpu.ids > $O/r04_actor_stamps.txt
+PASSES=kt bash tools/prof_step.sh cfg2_rollout --workload cfg2 --actor mlp > $O/r04_cfg2_rollout_rocprofv3.txt 2>&1; tail -6 $O/r04_cfg2_rollout_rocprofv3.txt
+rm -rf gpurun_out/prof_*
+
