@@ -129,33 +129,9 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
     for (int q0 = 0; q0 < P; q0 += 64) {
         const int q = q0 + lane;
         int n = 0, p = 0;
-        // ev2g_gen_port_sessions, a lane per port -- but the ports of a wavefront spawn at different steps, and drawing a session (two normal
-        // deviates, the car model ...: a few hundred instructions) with one lane active at a time was most of this pass.  Every lane therefore
-        // first walks to ITS next successful spawn trial (a hash and a compare per step), then the lanes that found one draw their sessions
-        // together; the sequence of trials and draws of a port is the function's.
-        {
-            const bool mine = q < P;
-            if (mine) p = s.slot_port[q];
-            int t = 2, free_from = 0;
-            const int t_end = g.T - g.min_stay_steps - 1;
-            bool walking = mine;
-            while (__ballot(walking) != 0ull) {
-                bool found = false;
-                while (walking && !found) {
-                    if (t >= t_end) { walking = false; break; }
-                    if (free_from <= t) { const uint2 kt = l_kt[t]; found = kt.y != 0u && ev2g_gen_spawn_trial(kt.x, kt.y, p); }
-                    if (!found) t++;
-                }
-                if (found) {
-                    Ev2gGenSession e;
-                    if (ev2g_gen_make_session(g, rng, fleet, share_sum, t, p, l_stay[t], l_emean[t], &e)) {
-                        free_from = e.t_dep + 2;
-                        if (n < EV2G_RF_K) l_spawn[p * EV2G_RF_K + n] = (unsigned char)(e.t_arr - 1);
-                        n++;
-                    }
-                    t++;
-                }
-            }
+        if (q < P) {
+            p = s.slot_port[q];
+            n = ev2g_gen_port_sessions(g, rng, fleet, share_sum, p, tab, [&](int i, const Ev2gGenSession &e) { if (i < EV2G_RF_K) l_spawn[p * EV2G_RF_K + i] = (unsigned char)(e.t_arr - 1); });
         }
         const int incl = rf_wave_incl_scan(n, lane);
         const int base = carry + incl - n;
