@@ -15,8 +15,11 @@
 //   * demand-response events: their slices are applied lane-parallel, `any` / `max` over the slice by ballot / wave max;
 //   * power setpoints: sessions port by port, a lane per step, weight sums on the wavefront's xor tree (ev2g_tree64 on the host).
 // The observation tables of the refilled slots are rebuilt afterwards by the loader's own table kernels, restricted to those slots.
-// Scope: single-port chargers without a topology file (every shipped config; the fast path's shape), a pool loaded with
-// EV2G_FLAG_REFILLABLE (fixed-size session blocks per scenario).  A scenario that draws more sessions than its block holds keeps the
+// Scope: a pool loaded with EV2G_FLAG_REFILLABLE (fixed-size session blocks per scenario).  Single-port chargers (every shipped config; the
+// fast path's shape): a port's sessions are the slot's.  Chargers with several ports and topology files (round 4; up to 256 steps / 256
+// ports): an arriving EV takes its charger's FIRST FREE port (ev_charger.py:266-286) -- what ev2g_load_scenarios replays on the host for a
+// loaded batch is replayed here per charger (a lane each) between the two passes: every session then knows the slot it lands on and its rank
+// there, and the slots' first-session tables and next-window chains are written behind the second pass.  A scenario that draws more sessions than its block holds keeps the
 // first `cap` of them in device order and is counted in RefillArgs::overflow (the block is 25 % + 8 larger than the largest scenario of
 // the loaded batch; ev2g_pool_refill reports the count).
 #pragma once
@@ -36,6 +39,9 @@ struct RefillArgs {
     double *head_tab; int head_nh;   // fast path: observation head table [M, T+1, NH] (or null)
     double *step_tab;                // fast path: [M, T, 8] per-step scalars (or null)
     unsigned long long *dbg;    // [16] cycle stamps of workgroup 0 (tools/refill_time.py --stamps), or null
+    int multi;                  // chargers with several ports (or a topology file): an arriving EV takes the charger's first free port (ev_charger.py:266-286) --
+                                // the kernel replays that per charger before it places the sessions (needs T <= 256 and at most EV2G_RF_K sessions per port)
+    const double *tr_cap;       // [R] transformer capacities of a topology file (device copy), or null: cfg.transformer_max_power
 };
 #define RF_STAMP(i) if (a.dbg && threadIdx.x == 0) { if (blockIdx.x == 0) a.dbg[i] = __builtin_readcyclecounter(); \
         if (blockIdx.x == gridDim.x - 1 && ((i) == 0 || (i) == 6)) a.dbg[8 + ((i) != 0)] = __builtin_readcyclecounter(); \
@@ -72,9 +78,11 @@ __device__ inline double rf_afap(double cap0, double B, double pac, double max_c
 //   the transformer in work [T each]  ->  the median filter's padded row [T + 96]
 //   u64 id [cap]; ints t_arr, t_dep [cap], base / count per PORT [P]; uint8 spawn steps [P][EV2G_RF_K]
 #define EV2G_RF_K 8   // spawn steps remembered per port between the two passes (a port with more re-runs its trials in pass 2)
-__host__ __device__ inline size_t ev2g_refill_lds_bytes(int T, int P, int cap) {
+//   multi-port chargers / topology files (RefillArgs::multi) add: uint8 departure steps, resolved slot and rank in it [P][EV2G_RF_K] each;
+//   ints base / count per SLOT after the first-free replay, slot of a port, free-from step of a port [P each]
+__host__ __device__ inline size_t ev2g_refill_lds_bytes(int T, int P, int cap, int multi = 0) {
     return sizeof(double) * ((size_t)6 * T + 96 + 3 * 16 + 3 * (size_t)cap) + sizeof(unsigned long long) * (size_t)cap + sizeof(int) * (2 * (size_t)cap + 2 * (size_t)P) +
-           (((size_t)P * EV2G_RF_K + 7) & ~(size_t)7);
+           (((size_t)P * EV2G_RF_K + 7) & ~(size_t)7) + (multi ? 3 * (((size_t)P * EV2G_RF_K + 7) & ~(size_t)7) + sizeof(int) * 4 * (size_t)P : 0);
 }
 
 __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, RefillArgs a, double *ss_afap) {
@@ -90,6 +98,11 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
     unsigned long long *l_id = (unsigned long long *)(l_hi + cap);
     int *l_ta = (int *)(l_id + cap), *l_td = l_ta + cap, *l_pbase = l_td + cap, *l_pcnt = l_pbase + P;
     unsigned char *l_spawn = (unsigned char *)(l_pcnt + P);
+    constexpr int K = EV2G_RF_K;
+    const size_t spb = ((size_t)P * K + 7) & ~(size_t)7;
+    unsigned char *l_dep = l_spawn + spb, *l_res = l_dep + spb, *l_rank = l_res + spb;   // (multi only)
+    int *l_rbase = (int *)(l_rank + spb), *l_rcnt = l_rbase + P, *l_pslot = l_rcnt + P, *l_free = l_pslot + P;
+    const bool multi = a.multi != 0;
     const int ms = a.first_slot + blockIdx.x;                  // pool slot
     const unsigned long long m = (unsigned long long)(a.first_index + blockIdx.x);   // scenario index of the stream
     const ev2g_gen_config &c = a.cfg;
@@ -131,8 +144,10 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
         int n = 0, p = 0;
         if (q < P) {
             p = s.slot_port[q];
-            n = ev2g_gen_port_sessions(g, rng, fleet, share_sum, p, tab, [&](int i, const Ev2gGenSession &e) { if (i < EV2G_RF_K) l_spawn[p * EV2G_RF_K + i] = (unsigned char)(e.t_arr - 1); });
+            n = ev2g_gen_port_sessions(g, rng, fleet, share_sum, p, tab, [&](int i, const Ev2gGenSession &e) { if (i < EV2G_RF_K) { l_spawn[p * EV2G_RF_K + i] = (unsigned char)(e.t_arr - 1); if (multi) l_dep[p * EV2G_RF_K + i] = (unsigned char)e.t_dep; } });
+            if (multi) { l_pslot[p] = q; l_rcnt[q] = 0; l_free[p] = 0; }
         }
+        if (multi && n > K) { n = K; if (a.overflow) atomicAdd(a.overflow, 1); }   // (a port with more sessions than the replay remembers: cut, and counted)
         const int incl = rf_wave_incl_scan(n, lane);
         const int base = carry + incl - n;
         if (q < P) { l_pbase[p] = base; l_pcnt[p] = n; }
@@ -144,6 +159,45 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
         RW(int, scn_sess_end)[ms] = ms * cap + min(total, cap);
     }
     __syncthreads();
+    if (multi) {
+        // ---- first-free replay (ev_charger.py:266-286; the loader's, ev2g_load_scenarios): a charger's arrivals in profile order (arrival step, then
+        //      generator port) each take the charger's lowest port that is free at the end of the step before -- a lane per charger; afterwards every
+        //      remembered session knows the slot it lands on and its rank among that slot's sessions ----
+        for (int c0 = 0; c0 < s.C; c0 += 64) {
+            const int cc = c0 + lane;
+            if (cc < s.C) {
+                const int pb = s.cs_pbase[cc], np = s.cs_np[cc];
+                for (int j = 0; j < np; j++) l_rbase[pb + j] = 0;   // (cursor of generator port pb + j for the moment)
+                for (;;) {
+                    int bj = -1, bt = EV2G_INT_MAX;
+                    for (int j = 0; j < np; j++) {
+                        const int pp = pb + j, i = l_rbase[pp];
+                        if (i < l_pcnt[pp]) { const int ta = (int)l_spawn[pp * K + i] + 1; if (ta < bt) { bt = ta; bj = j; } }
+                    }
+                    if (bj < 0) break;
+                    const int pp = pb + bj, i = l_rbase[pp];
+                    l_rbase[pp] = i + 1;
+                    int jr = 0;
+                    while (jr < np - 1 && l_free[pb + jr] > bt - 1) jr++;   // (the generator's ports of a charger never hold more EVs than it has ports)
+                    l_free[pb + jr] = (int)l_dep[pp * K + i];              // freed inside step t_dep, before that step's arrivals
+                    const int qs = l_pslot[pb + jr];
+                    l_res[pp * K + i] = (unsigned char)qs;
+                    l_rank[pp * K + i] = (unsigned char)l_rcnt[qs];
+                    l_rcnt[qs] += 1;
+                }
+            }
+        }
+        __syncthreads();
+        int carry2 = 0;
+        for (int q0 = 0; q0 < P; q0 += 64) {   // device order: (scenario, slot, arrival)
+            const int q = q0 + lane;
+            const int n = (q < P) ? l_rcnt[q] : 0;
+            const int incl = rf_wave_incl_scan(n, lane);
+            if (q < P) l_rbase[q] = carry2 + incl - n;
+            carry2 += __shfl(incl, 63, 64);
+        }
+        __syncthreads();
+    }
 
     RF_STAMP(3)
     // ---- sessions, pass 2: draw again and write where they belong ----
@@ -155,9 +209,11 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
         const int base = l_pbase[p];
         const int n_eff = max(0, min(l_pcnt[p], cap - base));
         const size_t gs = (size_t)ms * P + q;
-        RW(int, port_first)[gs] = n_eff > 0 ? (int)(d0 + base) : -1;
-        RW(int, port_end)[gs] = n_eff > 0 ? (int)(d0 + base + n_eff) : -1;
-        if (n_eff == 0) RW(int2, port_first_win)[gs] = make_int2(EV2G_INT_MAX, EV2G_INT_MAX);
+        if (!multi) {
+            RW(int, port_first)[gs] = n_eff > 0 ? (int)(d0 + base) : -1;
+            RW(int, port_end)[gs] = n_eff > 0 ? (int)(d0 + base + n_eff) : -1;
+            if (n_eff == 0) RW(int2, port_first_win)[gs] = make_int2(EV2G_INT_MAX, EV2G_INT_MAX);
+        }
         const double V = s.cs_volt[cs];
         const int ph = s.cs_ph[cs];
         const double sq = sqrt((double)ph);
@@ -166,11 +222,23 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
         const double v_gate = s.cs_vk[(size_t)cs * 4 + ph];
         const double pac_min_sp = c.heterogeneous_ev_specs ? 0.0 : c.ev_min_ac_charge_power;
         auto write_session = [&](int i, const Ev2gGenSession &e) {
-            if (i >= n_eff) return;
-            const size_t d = d0 + base + i;
+            // where the session goes: behind the port's earlier ones -- or, after the first-free replay, at its rank on the slot it was given (same charger)
+            int dofs = base + i, qs = q;
+            bool to_pool = i < n_eff, to_lds = i < n_eff;
+            if (multi) { qs = l_res[p * K + i]; dofs = l_rbase[qs] + (int)l_rank[p * K + i]; to_pool = dofs < cap; to_lds = base + i < cap; }
+            if (!to_pool && !to_lds) return;
+            const size_t d = d0 + dofs;
             const Ev2gSessFields f = ev2g_gen_session_fields(g, rng, e, a.spec_row);
+            if (to_lds) {   // what the power setpoints need of this session (LDS, in the generator's order: port by port)
+                const int k = base + i;
+                l_id[k] = (unsigned long long)(e.t_arr - 1) * (unsigned long long)P + (unsigned long long)e.port;
+                l_ta[k] = e.t_arr; l_td[k] = e.t_dep;
+                l_need[k] = (e.B - e.cap0) * (100 + c.power_setpoint_flexiblity) / 100;
+                l_lo[k] = fmax(pac_min_sp, min_cs); l_hi[k] = fmin(e.pac, max_cs);
+            }
+            if (!to_pool) return;
             RW(int, ss_tarr)[d] = e.t_arr; RW(int, ss_tdep)[d] = e.t_dep; RW(int, ss_ntarr)[d] = EV2G_INT_MAX; RW(int, ss_ntdep)[d] = EV2G_INT_MAX;
-            RW(int, ss_phases)[d] = f.phases; RW(int, ss_lut)[d] = f.lut; RW(int, ss_slot)[d] = q;
+            RW(int, ss_phases)[d] = f.phases; RW(int, ss_lut)[d] = f.lut; RW(int, ss_slot)[d] = qs;
             RW(double, ss_cap0)[d] = e.cap0; RW(double, ss_B)[d] = e.B; RW(double, ss_des)[d] = f.desired; RW(double, ss_minB)[d] = f.minB;
             RW(double, ss_emerg)[d] = f.min_emerg; RW(double, ss_pacmax)[d] = e.pac; RW(double, ss_pacmin)[d] = f.pac_min;
             RW(double, ss_pdismax)[d] = f.pdis_max; RW(double, ss_pdismin)[d] = f.pdis_min; RW(double, ss_ts)[d] = f.ts; RW(double, ss_tsm)[d] = f.tsm;
@@ -190,7 +258,8 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
             SessTail tl;
             tl.des = f.desired; tl.nt_arr = EV2G_INT_MAX; tl.nt_dep = EV2G_INT_MAX;
             RW(SessTail, tail)[d] = tl;
-            if (i > 0) {   // this port's previous session learns its successor's window
+            if (multi) {   // (a slot's sessions come from several lanes: chained behind the pass, below)
+            } else if (i > 0) {   // this port's previous session learns its successor's window
                 RW(int, ss_ntarr)[d - 1] = e.t_arr; RW(int, ss_ntdep)[d - 1] = e.t_dep;
                 RW(SessTail, tail)[d - 1].nt_arr = e.t_arr; RW(SessTail, tail)[d - 1].nt_dep = e.t_dep;
             } else {
@@ -198,15 +267,10 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
             }
             const double eff = f.lut >= 0 ? a.lut_rowmax[f.lut] / 100.0 : f.eta_ch;
             ss_afap[d] = rf_afap(e.cap0, e.B, e.pac, mp, eff, e.t_arr, e.t_dep, dt);
-            // what the power setpoints need of this session (LDS, by its place in the scenario block)
-            const int k = base + i;
-            l_id[k] = (unsigned long long)(e.t_arr - 1) * (unsigned long long)P + (unsigned long long)e.port;
-            l_ta[k] = e.t_arr; l_td[k] = e.t_dep;
-            l_need[k] = (e.B - e.cap0) * (100 + c.power_setpoint_flexiblity) / 100;
-            l_lo[k] = fmax(pac_min_sp, min_cs); l_hi[k] = fmin(e.pac, max_cs);
         };
         if (l_pcnt[p] <= EV2G_RF_K && T <= 256) {   // the steps at which this port spawned are known from pass 1: only the sessions are drawn again
-            for (int i = 0; i < n_eff; i++) {
+            const int n_draw = multi ? l_pcnt[p] : n_eff;
+            for (int i = 0; i < n_draw; i++) {
                 const int t = l_spawn[p * EV2G_RF_K + i];
                 Ev2gGenSession e;
                 ev2g_gen_make_session(g, rng, fleet, share_sum, t, p, l_stay[t], l_emean[t], &e);
@@ -217,11 +281,30 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
         }
     }
 
+    if (multi) {   // ---- the slots' first-session tables and next-window chains, from what the pass wrote (a lane per slot) ----
+        __threadfence();
+        __syncthreads();
+        for (int q0 = 0; q0 < P; q0 += 64) {
+            const int q = q0 + lane;
+            if (q >= P) continue;
+            const int base = l_rbase[q], cnt = max(0, min(l_rcnt[q], cap - base));
+            const size_t gs = (size_t)ms * P + q, db = d0 + base;
+            RW(int, port_first)[gs] = cnt > 0 ? (int)db : -1;
+            RW(int, port_end)[gs] = cnt > 0 ? (int)(db + cnt) : -1;
+            RW(int2, port_first_win)[gs] = cnt > 0 ? make_int2(s.ss_tarr[db], s.ss_tdep[db]) : make_int2(EV2G_INT_MAX, EV2G_INT_MAX);
+            for (int j = 1; j < cnt; j++) {
+                const int ta = s.ss_tarr[db + j], td = s.ss_tdep[db + j];
+                RW(int, ss_ntarr)[db + j - 1] = ta; RW(int, ss_ntdep)[db + j - 1] = td;
+                RW(SessTail, tail)[db + j - 1].nt_arr = ta; RW(SessTail, tail)[db + j - 1].nt_dep = td;
+            }
+        }
+    }
+
     RF_STAMP(4)
     // ---- transformers ----
     for (int k = 0; k < R; k++) {
         const size_t o = ((size_t)ms * R + k) * T;
-        const double capk = c.transformer_max_power;
+        const double capk = a.tr_cap ? a.tr_cap[k] : c.transformer_max_power;
         double *infl = l_a, *maxp = l_b;   // this transformer's inflexible load and max_power, in LDS while the events work on them
         __syncthreads();
         double lvl = 0.0, mult = 0.0, mx = 0.0;

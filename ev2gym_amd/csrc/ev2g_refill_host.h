@@ -17,10 +17,19 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
         return fail(h, EV2G_ERR_STATE, "ev2g_pool_refill: the pool was not loaded with EV2G_FLAG_REFILLABLE (fixed-size session blocks)");
     const DevScn &s = h->scn;
     const ev2g_gen_config &c = *cfg;
-    if (s.npc != 1 || s.het || c.topo_n_ports) return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: single-port chargers without a topology file only");
+    // chargers with several ports, or a topology file: the kernel replays the reference's first-free port assignment per charger (RefillArgs::multi)
+    const bool topo = c.topo_n_ports != nullptr;
+    const bool multi = s.npc != 1 || s.het || topo;
+    if (topo && !(c.topo_transformer && c.topo_phases && c.topo_min_charge_current && c.topo_max_charge_current && c.topo_min_discharge_current &&
+                  c.topo_max_discharge_current && c.topo_voltage && c.topo_tr_max_power))
+        return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: a topology needs all nine topo_* arrays");
+    if (multi && (s.T > 256 || s.P > 256))
+        return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: multi-port chargers / topology files are re-drawn on the device up to 256 steps and 256 ports (use ev2g_generate + ev2g_load_scenarios beyond)");
+    long long cfg_ports = 0;
+    for (int i = 0; i < c.number_of_charging_stations && i < (1 << 20); i++) cfg_ports += topo ? c.topo_n_ports[i] : c.number_of_ports_per_cs;
     if (c.simulation_length != s.T || c.timescale != s.dt || c.number_of_charging_stations != s.C || c.number_of_transformers != s.R ||
-        c.number_of_ports_per_cs != 1)
-        return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: the config does not describe the shape of the resident pool (steps, timescale, chargers, transformers)");
+        cfg_ports != s.P || (!topo && c.number_of_ports_per_cs != s.npc))
+        return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: the config does not describe the shape of the resident pool (steps, timescale, chargers, ports, transformers)");
     if (c.scenario < 0 || c.scenario > 2 || c.simulation_days < 0 || c.simulation_days > 2) return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: scenario / simulation_days out of range");
     if (c.n_ev_specs < 0 || (c.n_ev_specs > 0 && !(c.spec_registrations && c.spec_battery_capacity && c.spec_max_ac_charge_power && c.spec_max_ac_discharge_power)))
         return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: n_ev_specs > 0 needs the four spec_* model arrays");
@@ -48,6 +57,7 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
     }
     if (c.tab_arrival_week) { refill_append(key, c.tab_arrival_week, 96 * 8); refill_append(key, c.tab_arrival_weekend, 96 * 8); refill_append(key, c.tab_stay, 48 * 8); refill_append(key, c.tab_energy, 48 * 8); }
     if (c.tab_pv && c.n_pv > 0) refill_append(key, c.tab_pv, (size_t)c.n_pv * 8);
+    if (topo) refill_append(key, c.topo_tr_max_power, (size_t)s.R * 8);   // (the chargers' own constants are the resident pool's)
     if (!h->d_refill_overflow) {   // its own allocation, freed by ev2g_destroy: it must survive ev2g_load_scenarios (which frees scn_allocs) and config changes
         HIPCHK(h, hipMalloc((void **)&h->d_refill_overflow, sizeof(int)));
         HIPCHK(h, hipMemsetAsync(h->d_refill_overflow, 0, sizeof(int), h->stream));
@@ -72,8 +82,10 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
         std::vector<double> pv;
         if (const char *err = ev2g_gen_pv_series(c, c.timescale, pv)) return fail(h, EV2G_ERR_ARG, err);
         if (upd(pv.data(), pv.size(), &a.pv_series)) return rc;
+        a.tr_cap = nullptr;
+        if (topo && upd(c.topo_tr_max_power, (size_t)s.R, &a.tr_cap)) return rc;
         if (!spec_row.empty()) { int *p; if ((rc = upload(h, rc_.allocs, spec_row.data(), spec_row.size(), &p))) return rc; a.spec_row = p; }
-        ev2g_gen_make_run(c, s.P, 1, seed, a.g0);
+        ev2g_gen_make_run(c, s.P, s.npc, seed, a.g0);
         a.g0.c = nullptr;
         a.g0.pv_per_day = pv.empty() ? 0 : 1440 / c.timescale;
         (void)hipStreamSynchronize(h->stream);   // the staging vectors are temporaries
@@ -88,6 +100,7 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
     a.head_tab = h->d_head_tab; a.head_nh = h->head_nh; a.step_tab = h->d_step_tab;
     if (c.demand_response && c.dr_events_per_day > 16 && (s.win_tab || h->d_head_tab))
         return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: at most 16 demand-response events per day");
+    a.multi = multi ? 1 : 0;
     a.dbg = nullptr;
     if (std::getenv("EV2G_REFILL_STAMPS")) {   // development: cycle stamps of workgroup 0, printed at the next call
         static unsigned long long *d_dbg = nullptr;
@@ -103,7 +116,7 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
         }
         a.dbg = d_dbg;
     }
-    const size_t lds = ev2g_refill_lds_bytes(s.T, s.P, h->sess_cap);
+    const size_t lds = ev2g_refill_lds_bytes(s.T, s.P, h->sess_cap, a.multi);
     if (lds > 160 * 1024) return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: the scenario's work arrays exceed the LDS");
     if (lds > 48 * 1024) HIPCHK(h, hipFuncSetAttribute((const void *)ev2g_refill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (std::getenv("EV2G_REFILL_STAMPS")) {   // development: how many of these one-wavefront workgroups a CU holds

@@ -447,8 +447,10 @@ void ev2g_gen_free(ev2g_gen_result *r);
  * for pool / envs episodes; this call re-draws pool slots [first_slot, first_slot + n) WITHOUT host work or PCIe traffic: slot
  * first_slot + j becomes scenario first_index + j of the stream (cfg, seed) -- bit for bit what ev2g_generate(cfg, ., seed) yields at
  * that index followed by ev2g_load_scenarios (one wavefront per scenario runs the generator's own code, csrc/ev2g_refill.h).
- * Requirements: the pool was loaded with EV2G_FLAG_REFILLABLE from a batch drawn with the same config (shape, fleet); single-port
- * chargers, no topology file.  Asynchronous on the handle's stream; refill slots that no env is currently stepping (e.g. the window
+ * Requirements: the pool was loaded with EV2G_FLAG_REFILLABLE from a batch drawn with the same config (shape, fleet, topology).  Chargers
+ * with several ports and charging_network_topology files are supported up to 256 steps and 256 ports (the kernel replays the reference's
+ * first-free port assignment, ev_charger.py:266-286, per charger; a generator port that draws more than 8 sessions is cut and counted as an
+ * overflow).  Asynchronous on the handle's stream; refill slots that no env is currently stepping (e.g. the window
  * the previous episode used).  Afterwards ev2g_peek is refused (the host holds no copy of the new scenarios).
  * ev2g_pool_refill_overflows: scenarios (since load) that drew more sessions than ev2g_pool_session_capacity slots and were
  * truncated (synchronises; 0 in practice: the blocks are 25 % + 8 larger than the largest scenario of the loaded batch). */
