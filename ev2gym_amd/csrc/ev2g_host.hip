@@ -1031,6 +1031,11 @@ struct ev2g_mlp {
     const void *fn = nullptr;   // the kernel for this shape
     int rows = EV2G_MLP_ROWS;   // env rows per workgroup of that kernel
     int threads = EV2G_MLP_BLOCK;
+    // batches of more rows than 16 x CUs: the same streaming kernel with 32 rows per workgroup -- a weight fragment then feeds two MFMAs, and the
+    // weights are streamed once per CU instead of once per 16-row workgroup (two or more of which would share a CU)
+    const void *fn_big = nullptr;
+    size_t lds_big = 0;
+    int rows_big = 0, threads_big = 0, big_from = 0;
 };
 
 // the fixed-shape kernels exist for the layer widths of the shipped configs (obs 162 / 63 -> 400 -> 300 -> ports); anything else
@@ -1147,6 +1152,16 @@ int ev2g_mlp_create_ex(ev2g_handle *h, int d_in, int h1, int h2, int d_out, cons
     const MlpS16Pick s16 = mlp_s16_for(d_in, h1, h2, d_out, precision == EV2G_MLP_BF16 ? 1 : (precision == EV2G_MLP_F32 ? 2 : 3));
     m->lds = s16.fn ? s16.lds : (f32 ? ev2g_mlp32_lds_bytes(d) : ev2g_mlp_lds_bytes(d));
     if (s16.fn) { m->rows = EV2G_MLPS_ROWS; m->threads = s16.threads; }
+    if (s16.fn && s16.nw == 1 && !std::getenv("EV2G_MLP_NO_BIG")) {
+        if (s16.ks1 == 6 && s16.nt3 == 4) { m->fn_big = (const void *)ev2g_mlp3_s16<6, 25, 19, 4, 1, 4, 2>; m->lds_big = MlpS16<6, 25, 19, 4, 1, 4, 2>::lds_bytes; }
+        else if (s16.ks1 == 2 && s16.nt3 == 2) { m->fn_big = (const void *)ev2g_mlp3_s16<2, 25, 19, 2, 1, 4, 2>; m->lds_big = MlpS16<2, 25, 19, 2, 1, 4, 2>::lds_bytes; }
+        if (m->fn_big) {
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+            m->rows_big = 2 * EV2G_MLPS_ROWS; m->threads_big = 256; m->big_from = EV2G_MLPS_ROWS * cus + 1;
+            if (m->lds_big > 48 * 1024) HIPCHK(h, hipFuncSetAttribute(m->fn_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_big));
+        }
+    }
     if (m->lds > 160 * 1024) { delete m; return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create: layers too wide for the LDS-resident activations"); }
     int rc = 0;
     auto upw = [&](const std::vector<uint16_t> &v, const uint16_t **dst) { uint16_t *p; rc = upload(h, m->allocs, v.data(), v.size(), &p); *dst = p; return rc; };
@@ -1198,7 +1213,10 @@ int ev2g_mlp_forward(ev2g_handle *h, const ev2g_mlp *m, const float *x, float *y
     (void)hipSetDevice(h->device);
     MlpDev dev = m->dev;
     void *args[] = {&dev, &x, &y, &n_rows};
-    HIPCHK(h, hipLaunchKernel(m->fn, dim3((n_rows + m->rows - 1) / m->rows), dim3(m->threads), args, m->lds, h->stream));
+    if (m->fn_big && n_rows >= m->big_from)
+        HIPCHK(h, hipLaunchKernel(m->fn_big, dim3((n_rows + m->rows_big - 1) / m->rows_big), dim3(m->threads_big), args, m->lds_big, h->stream));
+    else
+        HIPCHK(h, hipLaunchKernel(m->fn, dim3((n_rows + m->rows - 1) / m->rows), dim3(m->threads), args, m->lds, h->stream));
     return EV2G_OK;
 }
 

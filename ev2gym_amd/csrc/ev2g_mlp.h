@@ -339,7 +339,8 @@ typedef float f32x4m __attribute__((ext_vector_type(4)));
 // float32 accumulator: every product of two bf16 values is exact in float32, so what is lost is the dropped terms (2^-24 relative and
 // below for NW = 3: the same level as float32 operands) and the accumulation order.  The float32 MFMA (v_mfma_f32_32x32x2_f32, ev2g_mlp3_f32)
 // runs at 1/16 of the bf16 rate; here the cost is the weight stream, NW times the bf16 kernel's.
-template <int KS1, int NT1, int NT2, int NT3, int NW = 1, int WV = 4> struct MlpS16 {   // WV: wavefronts per workgroup (4: one per SIMD; 8: two)
+template <int KS1, int NT1, int NT2, int NT3, int NW = 1, int WV = 4, int RB = 1> struct MlpS16 {   // WV: wavefronts per workgroup (4: one per SIMD; 8: two); RB: blocks of 16 env rows per workgroup
+    static constexpr int ROWS = EV2G_MLPS_ROWS * RB;
     static constexpr int NX = NW == 1 ? 1 : 3;   // terms of an activation
     static constexpr int KS2 = (NT1 * 16 + 31) / 32, KS3 = (NT2 * 16 + 31) / 32;
     static constexpr int NTH = WV * 64;
@@ -348,7 +349,7 @@ template <int KS1, int NT1, int NT2, int NT3, int NW = 1, int WV = 4> struct Mlp
     static constexpr int SX = KS1 * 32 + 8, SH1 = KS2 * 32 + 8, SH2 = KS3 * 32 + 8;             // LDS row strides (bf16 elements; +16 bytes against bank conflicts)
     static constexpr int NB = (NT1 + NT2 + NT3) * 16;                                          // staged biases (floats)
     static constexpr int RING = (NW == 1 ? EV2G_MLPS_RING : 36) * 4 / WV;                                 // (three operand copies per k-step take the registers)
-    static constexpr size_t lds_bytes = (size_t)EV2G_MLPS_ROWS * (SX + SH1 + SH2) * 2 * NX + (size_t)NB * 4;
+    static constexpr size_t lds_bytes = (size_t)ROWS * (SX + SH1 + SH2) * 2 * NX + (size_t)NB * 4;
 };
 
 // float32 -> NX bf16 terms, two values at a time (packed words); term k is the bf16 rounding of what terms 0..k-1 left
@@ -360,24 +361,25 @@ template <int NX> __device__ __forceinline__ void ev2g_split_bf16(float a, float
     }
 }
 
-template <int KS1, int NT1, int NT2, int NT3, int NW = 1, int WV = 4>
+template <int KS1, int NT1, int NT2, int NT3, int NW = 1, int WV = 4, int RB = 1>
 __global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *__restrict__ x, float *__restrict__ y, int n_rows) {
-    typedef MlpS16<KS1, NT1, NT2, NT3, NW, WV> C;
+    typedef MlpS16<KS1, NT1, NT2, NT3, NW, WV, RB> C;
+    constexpr int ROWS = C::ROWS;
     constexpr int NTH = C::NTH;
     constexpr int RING = C::RING, NX = C::NX;
     extern __shared__ __attribute__((aligned(16))) uint16_t mlds[];
     // operand buffers: NX copies (terms) of each, one behind the other
-    constexpr int BX = EV2G_MLPS_ROWS * C::SX, BH1 = EV2G_MLPS_ROWS * C::SH1, BH2 = EV2G_MLPS_ROWS * C::SH2;
+    constexpr int BX = ROWS * C::SX, BH1 = ROWS * C::SH1, BH2 = ROWS * C::SH2;
     uint16_t *bufX = mlds, *bufH1 = bufX + NX * BX, *bufH2 = bufH1 + NX * BH1;
     float *lb = (float *)(bufH2 + NX * BH2);   // biases: layer 1 | layer 2 | layer 3
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & (WV - 1);
-    const int row0 = blockIdx.x * EV2G_MLPS_ROWS;
-    const int nr = min(EV2G_MLPS_ROWS, n_rows - row0);
+    const int row0 = blockIdx.x * ROWS;
+    const int nr = min(ROWS, n_rows - row0);
     MLP_STAMP(0)
     // ---- requests, oldest first (vmcnt retires in order): input rows, biases, then the head of the weight sequence ----
     const int d_in = m.d_in, total = nr * d_in;
     const float *xs = x + (size_t)row0 * d_in;
-    constexpr int NL2 = (EV2G_MLPS_ROWS * KS1 * 32 / 2 + NTH - 1) / NTH;   // 8-byte pieces per lane (16 rows of at most KS1*32 columns)
+    constexpr int NL2 = (ROWS * KS1 * 32 / 2 + NTH - 1) / NTH;   // 8-byte pieces per lane (16 rows of at most KS1*32 columns)
     const bool pairs = (d_in & 1) == 0 && (((size_t)xs) & 7) == 0;    // (uniform) an even row length: two neighbours never straddle a row
     // (unconditional loads from clamped addresses: a load inside a per-lane branch whose result merges with a default makes the compiler
     // drain vmcnt before the next one -- six round trips in a row instead of one)
@@ -457,7 +459,10 @@ __global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *
         for (int sq = HEAD; sq < RING; sq++) request(sq);
     }
     if (tid < 256) {   // zero padding: thread (row = tid / 16, j = tid % 16) clears columns j, j + 16, ... of its row's tail in every operand buffer
-        const int pr = (tid >> 4) & 15, pj = tid & 15;   // (the first 256 threads)
+        const int pj = tid & 15;   // (the first 256 threads)
+#pragma unroll
+        for (int rbp = 0; rbp < RB; rbp++) {
+        const int pr = ((tid >> 4) & 15) + 16 * rbp;
         constexpr int P1 = C::KS2 * 32 - NT1 * 16, P2 = C::KS3 * 32 - NT2 * 16;                       // columns no tile writes
         static_assert(P1 <= 16 && P2 <= 16, "tail columns");
 #pragma unroll
@@ -466,6 +471,7 @@ __global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *
             if (pr >= nr) for (int cc = pj; cc < d_in; cc += 16) bufX[k * BX + pr * C::SX + cc] = 0;         // rows past the batch
             if (pj < P1) bufH1[k * BH1 + pr * C::SH1 + NT1 * 16 + pj] = 0;
             if (pj < P2) bufH2[k * BH2 + pr * C::SH2 + NT2 * 16 + pj] = 0;
+        }
         }
     }
 #pragma unroll
@@ -479,11 +485,13 @@ __global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *
         constexpr int L = decltype(Lc)::value;
         constexpr int KS = L == 0 ? KS1 : (L == 1 ? C::KS2 : C::KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3), MT = (NT + WV - 1) / WV;
         constexpr int base = L == 0 ? 0 : (L == 1 ? C::S1 : C::S1 + C::S2);
-        uint4 bfr[NX][KS];
+        uint4 bfr[RB][NX][KS];
 #pragma unroll
-        for (int k = 0; k < NX; k++)
+        for (int rb = 0; rb < RB; rb++)
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) bfr[k][ks] = *(const uint4 *)(A + k * ba + brow * sa + ks * 32 + kq * 8);
+            for (int k = 0; k < NX; k++)
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) bfr[rb][k][ks] = *(const uint4 *)(A + k * ba + (rb * 16 + brow) * sa + ks * 32 + kq * 8);
         f32x4m bini[MT];
 #pragma unroll
         for (int i = 0; i < MT; i++) bini[i] = *(const f32x4m *)(bias + min(wave + WV * i, NT - 1) * 16 + kq * 4);
@@ -491,7 +499,9 @@ __global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *
         for (int i = 0; i < MT; i++) {
             const int tile = wave + WV * i;
             if (WV * i + WV - 1 < NT || tile < NT) {   // (uniform; a constant but for the last slot)
-                f32x4m acc0 = bini[i], acc1 = {0.f, 0.f, 0.f, 0.f};
+                f32x4m acc0[RB], acc1[RB];
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++) { acc0[rb] = bini[i]; acc1[rb] = f32x4m{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
 #pragma unroll
@@ -502,31 +512,37 @@ __global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *
 #pragma unroll
                         for (int xq = NX - 1; xq >= 0; xq--) {
                             if (NW == 1 || p + xq <= 2) {
-                                bf16x8 b;
-                                __builtin_memcpy(&b, &bfr[xq][ks], 16);
-                                if ((ks + p + xq) & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1, 0, 0, 0);
-                                else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0, 0, 0, 0);
+#pragma unroll
+                                for (int rb = 0; rb < RB; rb++) {   // (one weight fragment, RB blocks of rows)
+                                    bf16x8 b;
+                                    __builtin_memcpy(&b, &bfr[rb][xq][ks], 16);
+                                    if ((ks + p + xq) & 1) acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1[rb], 0, 0, 0);
+                                    else acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0[rb], 0, 0, 0);
+                                }
                             }
                         }
                     }
 #pragma unroll
                     for (int p = 0; p < NW; p++) request(base + (i * KS + ks) * NW + p + RING);   // these slots are free again
                 }
-                const f32x4m acc = acc0 + acc1;
-                const int col = tile * 16 + kq * 4;   // this lane: columns col .. col + 3 of env row `brow`
+                const int col = tile * 16 + kq * 4;   // this lane: columns col .. col + 3 of env rows `brow`, `brow + 16` ...
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++) {
+                const f32x4m acc = acc0[rb] + acc1[rb];
+                const int erow = rb * 16 + brow;
                 if (L < 2) {
                     uint32_t lo[NX], hi[NX];
                     ev2g_split_bf16<NX>(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), lo);
                     ev2g_split_bf16<NX>(fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f), hi);
 #pragma unroll
-                    for (int k = 0; k < NX; k++) *(uint2 *)(out + k * bo + brow * so + col) = make_uint2(lo[k], hi[k]);
+                    for (int k = 0; k < NX; k++) *(uint2 *)(out + k * bo + erow * so + col) = make_uint2(lo[k], hi[k]);
                 } else {
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) { v[r] = NW == 1 ? ev2g_fast_tanh(acc[r]) : tanhf(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
                     const int d_out = m.d_out;
-                    if (brow < nr) {
-                        float *yr = y + (size_t)(row0 + brow) * d_out + col;
+                    if (erow < nr) {
+                        float *yr = y + (size_t)(row0 + erow) * d_out + col;
                         if ((d_out & 1) == 0) {   // (uniform) even row length: the pairs are 8-byte aligned
                             if (col + 1 < d_out) *(float2 *)yr = make_float2(v[0], v[1]);
                             if (col + 3 < d_out) *(float2 *)(yr + 2) = make_float2(v[2], v[3]);
@@ -535,6 +551,7 @@ __global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *
                             for (int r = 0; r < 4; r++) if (col + r < d_out) yr[r] = v[r];
                         }
                     }
+                }
                 }
             } else {
 #pragma unroll

@@ -294,11 +294,12 @@ def test_float32x3_actor_is_at_the_float32_level(n_rows, d_in, d_out, lo):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_rows,d_in,d_out,lo,prec", [(37, 161, 49, -1.0, "bf16"), (4101, 170, 64, 0.0, "bf16"), (53, 33, 17, -1.0, "bf16"), (29, 64, 31, 0.0, "fp32"),
-                                                       (16, 192, 50, -1.0, "fp32x3")])
+                                                       (16, 192, 50, -1.0, "fp32x3"), (8192, 63, 20, 0.0, "bf16"), (8209, 162, 50, -1.0, "bf16"), (4097, 33, 31, -1.0, "bf16")])
 def test_streaming_actor_ragged_shapes(n_rows, d_in, d_out, lo, prec):
     """The 16-row streaming actor kernel at the edges of its instantiations (k-steps of 32 inputs: 161..192 / 33..64; output tiles of 16: 49..64 / 17..32):
     odd input widths (scalar input loads instead of pairs), odd output widths (scalar stores), a last workgroup with a single row, padded
-    output columns that must not be written -- against the numpy forward with the same operand rounding."""
+    output columns that must not be written; more rows than 16 x CUs (the 32-rows-per-workgroup instantiation: 4097+ rows) -- against the numpy
+    forward with the same operand rounding."""
     from ev2gym_amd import _abi
     from ev2gym_amd.actor import init_mlp_weights, mlp_forward_numpy
     from ev2gym_amd.engine import Engine
