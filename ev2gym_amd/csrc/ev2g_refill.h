@@ -466,7 +466,8 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
         prmin = rf_wave_min(prmin);
         const double sd = fmax(prmin, 1e-3);
         double *sp = l_a;   // [T] accumulators (the transformer loop is done with l_a)
-        for (int t = lane; t < T; t += 64) sp[t] = 0.0;
+        double *prel = l_x; // [T] price relative to the day's maximum: once per step instead of once per session and step (the same quotient)
+        for (int t = lane; t < T; t += 64) { sp[t] = 0.0; prel[t] = l_cp[t] / pmax; }
         for (int p = 0; p < P; p++) {   // port by port, a port's sessions in time order: the host's accumulation order
             const int base = l_pbase[p], cnt = max(0, min(l_pcnt[p], cap - base));
             for (int i = 0; i < cnt; i++) {
@@ -475,7 +476,7 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
                 const int ta = l_ta[k], td = l_td[k];
                 double leaf = 0.0;
                 for (int t = lane; t < T; t += 64) {
-                    const double w = ev2g_gen_setpoint_weight(rng, id, t, ta, td, l_cp[t] / pmax, sd);
+                    const double w = ev2g_gen_setpoint_weight(rng, id, t, ta, td, prel[t], sd);
                     l_b[t] = w;
                     leaf += w;
                 }
