@@ -3,15 +3,18 @@
 // env steps.
 //
 // The reference trains SB3 agents against one CPU env (train_stable_baselines.py:62-130); with thousands of envs resident
-// on the GPU a step of the engine takes ~12 us, so a policy evaluated through a dozen framework launches (GEMM, bias,
-// activation, casts ...) would be 90 % of a rollout step.  This kernel keeps the whole forward on chip:
-//   * one workgroup (4 wavefronts) per 32 env rows; activations live in LDS as bf16, accumulators in registers (fp32);
-//   * v_mfma_f32_32x32x16_bf16: output-column tiles of 32 go round-robin over the wavefronts, a tile is one MFMA chain over K;
-//   * weights are packed ONCE on the host into MFMA B-fragment order (bf16), so a lane's operand is one coalesced 16-byte
-//     load straight from L2 -- no LDS staging: with a single 32-row tile per workgroup a weight is used exactly once per
-//     workgroup, and the 0.45 MB of weights stay L2-resident across workgroups;
-//   * bias + activation are applied to the accumulators in registers, the next layer's A matrix is written back to LDS.
-// Precision: bf16 operands, fp32 accumulation (a policy network, not part of the simulator's float64 path).
+// on the GPU a step of the engine takes ~10 us, so a policy evaluated through a dozen framework launches (GEMM, bias,
+// activation, casts ...) would be 90 % of a rollout step.  The kernels here keep the whole forward on chip.  Three generations live in
+// this file (newest last, each described where it is defined):
+//   * ev2g_mlp3_s16 (round 4; what the shipped layer widths run): built around the weight stream -- 16 (or 32) env rows per workgroup on
+//     every CU, v_mfma_f32_16x16x32_bf16 with the weights as the A operand, one static fragment sequence per wavefront through a register
+//     ring; also the FLOAT32 network as split bf16 operands (two / three terms per weight);
+//   * ev2g_mlp3_any / ev2g_mlp3_f32: any layer widths (bf16 operands / float32 operands on v_mfma_f32_32x32x2_f32), 32 rows per workgroup;
+//   * ev2g_mlp3_fixed (rounds 2-3; EV2G_MLP_OLD=1, kept for A/B runs): 32-row workgroups, v_mfma_f32_32x32x16_bf16, weights as the B operand.
+// Common to all: weights are packed ONCE on the host into the MFMA fragment order of the kernel that will read them (bf16, or float32 for
+// ev2g_mlp3_f32), so a lane's operand is one coalesced 16-byte load straight from L2; activations live in LDS; bias + activation are
+// applied to the accumulators in registers.  Precision: bf16 operands with fp32 accumulation unless a float32 mode is chosen
+// (a policy network, not part of the simulator's float64 path).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
