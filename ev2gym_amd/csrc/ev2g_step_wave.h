@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         if (EPW != 1) {   // (uniform)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int kq = 0; kq < EV2G_NQ; kq++) esum[kq] = stage[kq * RS + (tid_l - q_l)];   // the env's sums (its head slot), every lane
+            for (int kq = 0; kq < EV2G_NQ - 1; kq++) esum[kq] = stage[kq * RS + (tid_l - q_l)];   // the env's sums (its head slot), every lane (quantity 7, the summed current, has no consumer on this path)
         }
         }
 
