@@ -1053,7 +1053,14 @@ static const void *mlp_kernel_for(const MlpDev &d) {
 struct MlpS16Pick { const void *fn; size_t lds; int ks1, nt1, nt2, nt3, nw, threads; };
 // nw: bf16 terms per weight -- 1: the bf16 network; 2 / 3: the float32 network as split bf16 operands (EV2G_MLP_F32 / EV2G_MLP_F32X3, ev2g_mlp.h)
 static MlpS16Pick mlp_s16_for(int d_in, int h1, int h2, int d_out, int nw) {
-    const int ks1 = (d_in + 31) / 32, nt1 = (h1 + 15) / 16, nt2 = (h2 + 15) / 16, nt3 = (d_out + 15) / 16;
+    // The instantiations are for the shipped shapes (162 / 63 observations -> 400 -> 300 -> 50 / 20 ports); a network that FITS one of them runs on
+    // it zero-padded (weights and biases of the missing rows / columns are zeros, ReLU(0) = 0): any input up to 192 (64), hidden layers up to
+    // 400 / 304, outputs up to 64 (32).  Small networks (both hidden layers under 128) keep the generic kernel: they would pay the full-size stream.
+    int ks1 = (d_in + 31) / 32, nt1 = (h1 + 15) / 16, nt2 = (h2 + 15) / 16, nt3 = (d_out + 15) / 16;
+    if (nt1 <= 25 && nt2 <= 19 && (h1 >= 128 || h2 >= 128)) {
+        if (ks1 <= 2 && nt3 <= 2) { ks1 = 2; nt1 = 25; nt2 = 19; nt3 = 2; }
+        else if (ks1 <= 6 && nt3 <= 4) { ks1 = 6; nt1 = 25; nt2 = 19; nt3 = 4; }
+    }
     const char *old = std::getenv("EV2G_MLP_OLD");
     if (old && old[0] == '1') return {nullptr, 0, 0, 0, 0, 0, 0, 0};
     // the bf16 network runs eight wavefronts per workgroup (two per SIMD: one's epilogue and LDS waits under the other's MFMAs -- 7.48 -> 7.39 us at

@@ -337,8 +337,9 @@ int ev2g_mlp_create(ev2g_handle *h, int d_in, int h1, int h2, int d_out, const f
  *                   device forward agrees with a float64 forward of the same weights to 1e-5 (observed 4e-6), at twice the bf16 time;
  *   EV2G_MLP_F32X3  three terms per weight (all 24 bits), six products: agreement at the 1e-7 level -- what float32 operands give --
  *                   at 2.6x the bf16 time.
- * On the shipped layer widths all three run the same streaming kernel on the bf16 matrix cores (the weight stream is the cost: 1x, 2x,
- * 3x the bytes); other widths fall back to generic kernels (bf16, and float32 operands on v_mfma_f32_32x32x2_f32 for both float32 modes). */
+ * Networks that fit the shipped shapes (inputs <= 192, hidden layers <= 400 / 304 with at least one >= 128, outputs <= 64) run all three modes on
+ * the same streaming kernel on the bf16 matrix cores, zero-padded where they are smaller (the weight stream is the cost: 1x, 2x, 3x the bytes);
+ * other networks fall back to generic kernels (bf16, and float32 operands on v_mfma_f32_32x32x2_f32 for both float32 modes). */
 #define EV2G_MLP_BF16 0
 #define EV2G_MLP_F32 1
 #define EV2G_MLP_F32X3 2

@@ -327,3 +327,35 @@ def test_streaming_actor_ragged_shapes(n_rows, d_in, d_out, lo, prec):
     assert np.abs(y[:n_rows] - ref).max() <= tol, np.abs(y[:n_rows] - ref).max()
     eng.mlp_destroy(m)
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rows,d_in,h1,h2,d_out,lo,prec", [(300, 122, 256, 256, 25, -1.0, "bf16"), (5000, 40, 128, 64, 9, 0.0, "bf16"), (61, 150, 400, 64, 64, -1.0, "fp32"),
+                                                             (45, 64, 200, 300, 32, 0.0, "fp32x3")])
+def test_streaming_actor_runs_smaller_networks_zero_padded(n_rows, d_in, h1, h2, d_out, lo, prec):
+    """A network that fits an instantiation of the streaming actor kernel (inputs <= 192, hidden <= 400 / 304, outputs <= 64) runs on it with the missing
+    rows and columns of its weights as zeros -- e.g. SB3's [256, 256] -- and must give the numpy forward of the network itself."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.actor import init_mlp_weights, mlp_forward_numpy
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import GenConfig, generate
+    eng = Engine(generate(GenConfig.v2g_profit_plus_loads(8, 50, 1, seed=1)), _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"],
+                 _abi.STATE_KINDS["V2G_profit_max_loads"], device=0)
+    rng = np.random.default_rng(d_in * 3 + n_rows)
+    w = init_mlp_weights(d_in, d_out, seed=9, h1=h1, h2=h2)
+    x = (rng.normal(0, 1, (n_rows, d_in)) * rng.uniform(0.1, 3.0, d_in)).astype(np.float32)
+    m = eng.mlp_create(*w, out_lo=lo, precision=prec)
+    dx, dy = eng.empty((n_rows, d_in), np.float32).upload(x), eng.empty((n_rows, d_out), np.float32)
+    eng.mlp_forward(m, dx, dy, n_rows)
+    y = dy.to_host()
+    if prec == "bf16":
+        ref = mlp_forward_numpy(x, w, lo, bf16=True)
+    else:
+        W1, b1, W2, b2, W3, b3 = [a.astype(np.float64) for a in w]
+        hh = np.maximum(np.maximum(x.astype(np.float64) @ W1.T + b1, 0) @ W2.T + b2, 0)
+        ref = np.tanh(hh @ W3.T + b3)
+        ref = ref * 0.5 + 0.5 if lo == 0.0 else ref
+    tol = 3e-3 if prec == "bf16" else (1e-5 if prec == "fp32" else 1e-6)
+    assert np.abs(y - ref).max() <= tol, np.abs(y - ref).max()
+    eng.mlp_destroy(m)
+    eng.close()
