@@ -359,3 +359,25 @@ def test_streaming_actor_runs_smaller_networks_zero_padded(n_rows, d_in, h1, h2,
     assert np.abs(y - ref).max() <= tol, np.abs(y - ref).max()
     eng.mlp_destroy(m)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_device_refill_of_multi_port_chargers_has_stated_limits():
+    """ev2g_pool_refill replays the first-free port assignment of multi-port chargers inside the kernel with one byte per remembered step: it refuses
+    (with an error, not a wrong pool) episodes longer than 256 steps; the single-port path has no such limit."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine, EngineError
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    rk, sk = _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"]
+    flags = _abi.FLAG_LOG_SOC | _abi.FLAG_REFILLABLE
+    for npc, ok in ((2, False), (1, True)):
+        g = GenConfig.v2g_profit_plus_loads(6, 8, 1, seed=4, number_of_ports_per_cs=npc, simulation_length=300, timescale=5)
+        eng = Engine(generate_native(g), rk, sk, device=0, flags=flags)
+        if ok:
+            eng.pool_refill(g, 4, 10, 0, 6)
+            eng.synchronize()
+            assert eng.pool_refill_overflows == 0
+        else:
+            with pytest.raises(EngineError):
+                eng.pool_refill(g, 4, 10, 0, 6)
+        eng.close()
