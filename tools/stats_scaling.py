@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Is the statistics kernel bound by throughput or by the latency of one env's chain?  Its time at 256 .. 8192 envs of the cfg2 shape
+(development probe): a throughput-bound kernel scales with the env count, a latency-bound one does not until the chip is full."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ev2gym_amd import _abi
+from ev2gym_amd.engine import Engine
+from bench import WORKLOADS
+from ev2gym_amd.scenario_gen import generate
+wl = WORKLOADS["cfg2"]
+for E in (256, 512, 1024, 2048, 4096, 8192):
+    eng = Engine(generate(wl["gen"](E, 0)), _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]], flags=_abi.FLAG_LOG_SOC)
+    P, T = eng.P, eng.T
+    acts = eng.empty((T, E, P)); eng.fill_uniform(acts, T * E * P, 1, wl["lo"], 1.0)
+    rew, done, mask, obs = eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8), eng.empty((E, eng.D))
+    eng.reset(); eng.step_n(T, acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=True)
+    out = eng.empty((E, 17)); eng.stats(out); eng.synchronize()
+    n = 40; t0 = time.perf_counter()
+    for _ in range(n): eng.stats(out)
+    eng.synchronize(); dt = (time.perf_counter() - t0) / n
+    print(f"{E:5d} envs: statistics kernel {dt * 1e6:7.1f} us")
+    eng.close()
