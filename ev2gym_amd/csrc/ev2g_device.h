@@ -1181,9 +1181,14 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                 int n = 0, nf = 0;
                 // historic_soc / active_steps (sign bit set = inactive step).  The first NK entries of a session are fetched by unconditional
                 // (clamped) loads issued together and KEPT in registers for the second pass; only the tail of longer sessions is read twice,
-                // in batches of eight.  Accumulation order is the sequential one.
+                // in batches of eight.  Accumulation order is the sequential one.  NK = 40 (80 registers, two wavefronts per SIMD) since the end of
+                // round 4: the kernel's time follows the number of dependent batches, not the occupancy -- NK 12 / 24 / 32 / 40 / 56: 43.5 / 41.6 /
+                // 39.9 / 38.6 / 55 us at cfg2, 52.0 -> 45.2 at cfg3, 482 -> 380 at cfg4 (profiles/r04_stats_log_pass_variants.txt).
 #ifndef EV2G_STATS_NK
-#define EV2G_STATS_NK 12
+#define EV2G_STATS_NK 40
+#endif
+#ifndef EV2G_STATS_TB
+#define EV2G_STATS_TB 8   // entries per batch of a session's tail (beyond the NK kept ones)
 #endif
                 constexpr int NK = EV2G_STATS_NK;
                 double xk[NK];
@@ -1197,12 +1202,12 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                         if (__double_as_longlong(xk[u]) >= 0) { fs += soc; nf++; }
                     }
                 }
-                for (int t = ta + NK; t <= tend; t += 8) {
-                    double x[8];
+                for (int t = ta + NK; t <= tend; t += EV2G_STATS_TB) {
+                    double x[EV2G_STATS_TB];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) x[u] = slog[(long long)min(t + u, tend) * P];
+                    for (int u = 0; u < EV2G_STATS_TB; u++) x[u] = slog[(long long)min(t + u, tend) * P];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
+                    for (int u = 0; u < EV2G_STATS_TB; u++) {
                         if (t + u <= tend) {
                             const double soc = fabs(x[u]) * invB;
                             hs += soc; n++;
@@ -1217,12 +1222,12 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
 #pragma unroll
                 for (int u = 0; u < NK; u++)
                     if (ta + u <= tend && __double_as_longlong(xk[u]) >= 0) mad += fabs(avg_f - fabs(xk[u]) * invB);
-                for (int t = ta + NK; t <= tend; t += 8) {
-                    double x[8];
+                for (int t = ta + NK; t <= tend; t += EV2G_STATS_TB) {
+                    double x[EV2G_STATS_TB];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) x[u] = slog[(long long)min(t + u, tend) * P];
+                    for (int u = 0; u < EV2G_STATS_TB; u++) x[u] = slog[(long long)min(t + u, tend) * P];
 #pragma unroll
-                    for (int u = 0; u < 8; u++)
+                    for (int u = 0; u < EV2G_STATS_TB; u++)
                         if (t + u <= tend && __double_as_longlong(x[u]) >= 0) mad += fabs(avg_f - fabs(x[u]) * invB);
                 }
                 mad += fabs(avg_f - soc_f);
