@@ -1190,7 +1190,12 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
 #ifndef EV2G_STATS_TB
 #define EV2G_STATS_TB 8   // entries per batch of a session's tail (beyond the NK kept ones)
 #endif
+#ifndef EV2G_STATS_LK
+#define EV2G_STATS_LK 16  // entries behind the kept ones that the first pass parks in LDS for the second (8 KB per wavefront; 16 / 32 / 48: 37.2 / 37.3 / 41.8 us at cfg2 against 38.5 without)
+#endif
                 constexpr int NK = EV2G_STATS_NK;
+                constexpr int LK = EV2G_STATS_LK;   // (a multiple of the tail batch)
+                extern __shared__ double l_keep[];  // [LK][64]
                 double xk[NK];
 #pragma unroll
                 for (int u = 0; u < NK; u++) xk[u] = slog[(long long)min(ta + u, tend) * P];
@@ -1206,6 +1211,10 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                     double x[EV2G_STATS_TB];
 #pragma unroll
                     for (int u = 0; u < EV2G_STATS_TB; u++) x[u] = slog[(long long)min(t + u, tend) * P];
+                    if (LK > 0 && t - ta - NK < LK) {   // the next LK entries behind the kept ones are parked in LDS for the second pass ([entry][lane]: no bank conflicts)
+#pragma unroll
+                        for (int u = 0; u < EV2G_STATS_TB; u++) l_keep[(t - ta - NK + u) * 64 + (int)threadIdx.x] = x[u];
+                    }
 #pragma unroll
                     for (int u = 0; u < EV2G_STATS_TB; u++) {
                         if (t + u <= tend) {
@@ -1224,8 +1233,13 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
                     if (ta + u <= tend && __double_as_longlong(xk[u]) >= 0) mad += fabs(avg_f - fabs(xk[u]) * invB);
                 for (int t = ta + NK; t <= tend; t += EV2G_STATS_TB) {
                     double x[EV2G_STATS_TB];
+                    if (LK > 0 && t - ta - NK < LK) {
 #pragma unroll
-                    for (int u = 0; u < EV2G_STATS_TB; u++) x[u] = slog[(long long)min(t + u, tend) * P];
+                        for (int u = 0; u < EV2G_STATS_TB; u++) x[u] = l_keep[(t - ta - NK + u) * 64 + (int)threadIdx.x];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < EV2G_STATS_TB; u++) x[u] = slog[(long long)min(t + u, tend) * P];
+                    }
 #pragma unroll
                     for (int u = 0; u < EV2G_STATS_TB; u++)
                         if (t + u <= tend && __double_as_longlong(x[u]) >= 0) mad += fabs(avg_f - fabs(x[u]) * invB);

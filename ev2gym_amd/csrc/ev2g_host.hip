@@ -1379,7 +1379,7 @@ static int launch_stats(ev2g_handle *h, double *stats, bool reset, double *obs, 
     const bool pair = (h->sess_cap > 0 ? per_scn <= 48 : h->S <= (long long)h->M * 24) && h->C <= 32 && !std::getenv("EV2G_STATS_ONE_ENV");
     const dim3 grid(pair ? (h->E + 1) / 2 : h->E);
 #define EV2G_STATS_LAUNCH(EPWS, RESET)                                                                                                    \
-    hipLaunchKernelGGL((ev2g_stats_kernel<EPWS, RESET>), grid, dim3(64), 0, h->stream, h->scn, h->st, (int)h->scn_off, (const double *)h->d_ss_afap, \
+    hipLaunchKernelGGL((ev2g_stats_kernel<EPWS, RESET>), grid, dim3(64), (size_t)EV2G_STATS_LK * 64 * sizeof(double), h->stream, h->scn, h->st, (int)h->scn_off, (const double *)h->d_ss_afap, \
                        h->current_step, stats, (int)off, obs, RESET ? (obs32 ? obs32 : (float *)h->extras.obs_f32) : (float *)nullptr)
     if (pair) { if (reset) EV2G_STATS_LAUNCH(2, true); else EV2G_STATS_LAUNCH(2, false); }
     else { if (reset) EV2G_STATS_LAUNCH(1, true); else EV2G_STATS_LAUNCH(1, false); }
