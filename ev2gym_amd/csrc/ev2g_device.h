@@ -96,6 +96,8 @@ struct DevScn {  // read-only scenario + layout, device pointers
     const SessRec *rec;  // [S] AoS twin of the ss_* arrays (v2 kernels)
     const SessTail *tail;  // [S] departure-side fields of the same sessions
     const double *win_tab;  // [E,R,T+1,40] precomputed (loads-pv)[20] | power_limits[20] per observation step, or nullptr
+    const double *head_tab; // fast path: [M,T+1,head_nh] columns 2.. of the observation of every step counter (prices | window), or nullptr
+    int head_nh;
 };
 
 // Per-port dynamic state: ONE 64-byte line per (env, port slot) -- one memory sector.  A launch that runs a single step (the RL loop with a
@@ -492,6 +494,11 @@ __device__ __forceinline__ void write_obs_env(const DevScn &s, OT *__restrict__ 
         return;
     }
     // V2G_profit_max(_loads) state.py:65-83, :108-135
+    if (s.head_tab) {   // fast path: the row is in the observation head table (built from the same functions at load): a copy instead of the window logic
+        const double *row = s.head_tab + ((long long)e * (T + 1) + sstep) * s.head_nh;
+        for (int c = l; c < 2 + s.head_nh; c += nl) obs_e[c] = (OT)((c == 0) ? (double)sstep : ((c == 1) ? usage_prev : row[c - 2]));
+        return;
+    }
     for (int c = l; c < 22; c += nl) {
         double v;
         if (c == 0) v = (double)sstep;

@@ -685,6 +685,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     }
     double *d_head_tab = nullptr;
     h->d_head_tab = nullptr; h->head_nh = 0;
+    s.head_tab = nullptr; s.head_nh = 0;
     if (h->wave_path && sk != EV2G_STATE_PUBLIC_PST) {
         const int NH = (sk == EV2G_STATE_V2G_PROFIT_MAX_LOADS) ? 60 : 20;
         const size_t n = (size_t)M * (T + 1) * NH;
@@ -694,6 +695,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         hipLaunchKernelGGL(ev2g_build_head_table_kernel, dim3(nb), dim3(256), 0, h->stream, s.price_ch, s.win_tab, 0, M, T, NH, d_head_tab);
         HIPCHK(h, hipGetLastError());
         h->d_head_tab = d_head_tab; h->head_nh = NH;
+        s.head_tab = d_head_tab; s.head_nh = NH;   // (the reset observation copies its head from row 0, write_obs_env)
     }
     // ---- state ----
     DevState &st = h->st;
