@@ -1311,6 +1311,15 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
     }
     if (RESET && e_valid) {   // EV2Gym.reset()'s state-init part for this env, on scenario (e + reset_off) mod M (ev2g_reset_kernel, one env per segment)
         const int scn_n = ev2g_scn(e, reset_off, s.M);
+        // the reset observation's head row (fast path: a copy of row 0 of the new scenario's head table) is requested before the state is
+        // re-armed, together with the ports' first-session tables: one round trip for the block's loads, then only stores
+        const bool hfast = s.head_tab != nullptr && s.state_kind != 1 && 2 + s.head_nh <= 2 * W && (r_obs || r_obs32);
+        double hrow0 = 0.0, hrow1 = 0.0;
+        if (hfast) {
+            const double *row = s.head_tab + (long long)scn_n * (T + 1) * s.head_nh;
+            hrow0 = row[min(max(lane - 2, 0), s.head_nh - 1)];
+            hrow1 = row[min(lane + W - 2, s.head_nh - 1)];
+        }
         for (int q = lane; q < P; q += W) {
             const long long g = (long long)e * P + q, gs = (long long)scn_n * P + q;
             const int2 w = s.port_first_win[gs];
@@ -1329,7 +1338,14 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
         for (int i = lane; i < T * (2 + R); i += W) st.hist[EV2G_HIST(e, 0, T, R) + i] = 0.0;   // this env's history rows: contiguous
         for (int r = lane; r < R; r += W) st.tr_power_now[(long long)e * R + r] = 0.0;
         if (lane == 0) st.env_fault[e] = 0;
-        if (r_obs) write_obs_env(s, r_obs + (long long)e * s.D, scn_n, 0, 0.0, lane, W);
-        if (r_obs32) write_obs_env(s, r_obs32 + (long long)e * s.D, scn_n, 0, 0.0, lane, W);
+        if (hfast) {   // columns 0, 1: step counter 0 and no usage yet; 2 ..: the head row
+            const int c0 = lane, c1 = lane + W, nc = 2 + s.head_nh;
+            const double v0 = (c0 < 2) ? 0.0 : hrow0;
+            if (r_obs) { double *o = r_obs + (long long)e * s.D; if (c0 < nc) o[c0] = v0; if (c1 < nc) o[c1] = hrow1; }
+            if (r_obs32) { float *o = r_obs32 + (long long)e * s.D; if (c0 < nc) o[c0] = (float)v0; if (c1 < nc) o[c1] = (float)hrow1; }
+        } else {
+            if (r_obs) write_obs_env(s, r_obs + (long long)e * s.D, scn_n, 0, 0.0, lane, W);
+            if (r_obs32) write_obs_env(s, r_obs32 + (long long)e * s.D, scn_n, 0, 0.0, lane, W);
+        }
     }
 }
