@@ -1335,7 +1335,9 @@ __global__ void __launch_bounds__(64) ev2g_stats_kernel(DevScn s, DevState st, i
             if (st.cs_profits) { st.cs_profits[gc] = 0.0; st.cs_e_ch[gc] = 0.0; st.cs_e_dis[gc] = 0.0; st.cs_power_now[gc] = 0.0; st.cs_cur_now[gc] = 0.0; }
         }
         for (int i = lane; i < 8; i += W) st.env_acc[(long long)e * 8 + i] = 0.0;
-        for (int i = lane; i < T * (2 + R); i += W) st.hist[EV2G_HIST(e, 0, T, R) + i] = 0.0;   // this env's history rows: contiguous
+        // (history rows: only charge_power_potential[0], which the first step reads, is cleared -- rows the new episode has not reached are ignored by
+        // the statistics kernel and by ev2g_peek; clearing all T x (2 + R) values of every env was a quarter of this block's bytes)
+        if (lane == 0) st.hist[EV2G_HIST(e, 0, T, R) + 1] = 0.0;
         for (int r = lane; r < R; r += W) st.tr_power_now[(long long)e * R + r] = 0.0;
         if (lane == 0) st.env_fault[e] = 0;
         if (hfast) {   // columns 0, 1: step counter 0 and no usage yet; 2 ..: the head row

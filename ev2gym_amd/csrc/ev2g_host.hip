@@ -1525,9 +1525,15 @@ int ev2g_peek(ev2g_handle *h, int env, ev2g_env_view *v) {
     HIPCHK(h, hipMemcpyAsync(hist_rows.data(), st.hist + (size_t)env * T * (2 + R), sizeof(double) * hist_rows.size(), hipMemcpyDeviceToHost, h->stream));
 #undef D2H
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    // rows the running episode has not written yet read as zeros (the reference's arrays are zero-initialised at reset); the slab itself may still
+    // hold the previous episode's values there -- after an in-kernel reset of a fused run, and after ev2g_get_stats_reset, which re-arms an env
+    // without clearing its history rows (the statistics kernel ignores them the same way).  usage / overload of step t exist once step t has run,
+    // the charge-power potential of step t once step t - 1 has.
+    const int cur = h->current_step;
     for (int t = 0; t < T; t++) {
-        usage[t] = hist_rows[(size_t)t * (2 + R)]; pot[t] = hist_rows[(size_t)t * (2 + R) + 1];
-        for (int r = 0; r < R; r++) over[(size_t)t * R + r] = hist_rows[(size_t)t * (2 + R) + 2 + r];
+        usage[t] = (t < cur) ? hist_rows[(size_t)t * (2 + R)] : 0.0;
+        pot[t] = (t <= cur) ? hist_rows[(size_t)t * (2 + R) + 1] : 0.0;
+        for (int r = 0; r < R; r++) over[(size_t)t * R + r] = (t < cur) ? hist_rows[(size_t)t * (2 + R) + 2 + r] : 0.0;
     }
     for (int q = 0; q < P; q++) {
         const PortLine &l = lines[q];
