@@ -314,9 +314,9 @@ typedef struct ev2g_env_view {
     double *cs_energy_charged;    /* [C] total_energy_charged               */
     double *cs_energy_discharged; /* [C] total_energy_discharged            */
     double *tr_power;             /* [R] Transformer.current_power          */
-    double *tr_overload;          /* [R,T] env.tr_overload                  */
-    double *power_usage;          /* [T] env.current_power_usage            */
-    double *power_potential;      /* [T] env.charge_power_potential         */
+    double *tr_overload;          /* [R,T] env.tr_overload                  (the three histories: entries of steps the running episode has   */
+    double *power_usage;          /* [T] env.current_power_usage             not reached yet are zeros, like the reference's arrays, whatever  */
+    double *power_potential;      /* [T] env.charge_power_potential          an earlier episode left in the device buffers)                   */
     int32_t *session_port;        /* [S_env] resolved port of every session */
     double *session_afap;         /* [S_env] EV.max_energy_AFAP             */
     double *session_final_cap;    /* [S_env] capacity at departure (NaN while not departed) */
