@@ -52,13 +52,13 @@ def measured_traffic(workload, launch, steps_per_launch, envs):
     WRITE_SIZE collected in separate --pmc runs, FETCH doubled per the gfx950 note in MI355X_MICROARCH.md) -- a stored figure of the same
     kernel on the same workload, NOT a measurement of this run (counters need rocprofv3 around the process): `roofline.traffic_source` names
     the file.  (None, None) when the shape was not profiled."""
-    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))[workload][launch]
         except Exception:
             continue
         if abs(t["steps_per_launch"] - steps_per_launch) > 1e-9 or envs != WORKLOADS[workload]["envs"]:
-            return None, None
+            continue   # (an older round may hold the matching shape)
         return (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0, "profiles/" + name + " (rocprofv3 PMC passes of an earlier run of this workload; not re-measured here)"
     return None, None
 
@@ -343,6 +343,85 @@ def refill_record(Engine, wl, rk, sk, local_rank, devx, E, rank, args, T, min_s=
         eng.close()
 
 
+def workload_bytes_env_step(wl, P, R, phi):
+    return P * (phi * wl["b_occ"] + (1 - phi) * wl["b_empty"]) + R * wl["b_tr"] + wl["b_env"]
+
+
+def kernel_roofline(bytes_env_step, E, steps_per_launch, launch_s, kernel):
+    achieved = bytes_env_step * E * steps_per_launch / launch_s / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "kernel": kernel,
+            "avg_launch_us": launch_s * 1e6, "steps_per_launch": steps_per_launch, "algorithmic_bytes_per_env_step": bytes_env_step}
+
+
+def other_workload_record(Engine, name, E, local_rank, devx, rank, args, min_s=0.12):
+    """One of the OTHER BASELINE single-GPU configs on the default line (configs[2] / configs[3]): its own scenario pool (two windows), whole
+    episodes -- persistent 112-step launch + statistics + reset onto the other window -- for `min_s` seconds; the step kernel's launch
+    duration by HIP events on the launch stream (ev2g_last_step_n_kernel_ms), the rate by the wall clock around synchronised episodes."""
+    import torch
+    wl = WORKLOADS[name]
+    rk, sk = _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]]
+    batch = generate_native(wl["gen"](2 * E, 4000 + rank)).sorted_by_busy_window(E)
+    phi = occupancy_fraction(batch)
+    eng = Engine(batch, rk, sk, device=local_rank, stream=devx.new_stream(make_current=False), n_active_envs=E,
+                 flags=0 if args.no_soc_log else _abi.FLAG_LOG_SOC)
+    try:
+        dev, P, D, T = devx.device, eng.P, eng.D, eng.T
+        acts = torch.empty((T, E, P), dtype=torch.float64, device=dev)
+        eng.fill_uniform(acts, T * E * P, 555 + rank, wl["lo"], 1.0)
+        obs = torch.empty((E, D), dtype=torch.float64, device=dev)
+        rew = torch.empty((E,), dtype=torch.float64, device=dev)
+        done = torch.empty((E,), dtype=torch.uint8, device=dev)
+        mask = torch.empty((E, P), dtype=torch.uint8, device=dev)
+        stats = torch.empty((E, _abi.N_STATS), dtype=torch.float64, device=dev)
+        loop = RolloutLoop(eng, E, P, T, eng.M, acts, obs, rew, done, mask, stats)
+        loop.reset(); loop.run(T, True); eng.synchronize()
+        n, spent, tim = 0, 0.0, []
+        while spent < min_s or n < 2:
+            t0 = time.perf_counter()
+            loop.run(T, True, timing=tim)
+            eng.synchronize()
+            spent += time.perf_counter() - t0
+            n += 1
+        eng.check_faults()
+        launch_s = float(np.median([x for x, _ in tim])) / 1e3
+        bes = workload_bytes_env_step(wl, P, batch.n_transformers, phi)
+        return {"workload": f"{name}: {wl['desc']}", "envs_per_gpu": E, "chargers": batch.n_chargers, "transformers": batch.n_transformers, "obs_dim": D,
+                "occupancy_phi": round(phi, 4), "value": E * T * n / spent, "unit": "env-steps/s", "ms_per_step": spent / (n * T) * 1e3,
+                "ms_per_episode": spent / n * 1e3, "episodes_timed": n, "launch": "persistent", "specialisation": eng.last_launch_specialisation,
+                "roofline": kernel_roofline(bes, E, T, launch_s, eng.kernel_name),
+                "contains": "whole episodes: 112-step persistent launch + statistics kernel + reset onto fresh scenarios (wall clock, synchronised per episode); "
+                            "roofline from the step kernel's own HIP-event duration (median over the timed launches)"}
+    finally:
+        eng.close()
+
+
+def strided_record(eng, loop, E, P, D, T, dev, bytes_env_step, stride0_launch_us, reps=5):
+    """The persistent launch whose outputs are all KEPT: observation / reward / done / mask blocks [T, E, *] with step strides (a trajectory
+    recorder's or a replay block's shape, generate_trajectories.py:69-83) instead of the headline's stride-0 rows that each step overwrites."""
+    import torch
+    obs = torch.empty((T, E, D), dtype=torch.float64, device=dev)
+    rew = torch.empty((T, E), dtype=torch.float64, device=dev)
+    done = torch.empty((T, E), dtype=torch.uint8, device=dev)
+    mask = torch.empty((T, E, P), dtype=torch.uint8, device=dev)
+    ms = []
+    for r in range(reps + 1):
+        loop.reset()
+        eng.step_n(T, loop.acts, E * P, obs, E * D, rew, E, done, E, mask, E * P, auto_reset=False, persistent=True)
+        k = eng.last_step_n_kernel_ms()
+        eng.stats(out=loop.stats)
+        if r:
+            ms.append(k)
+    spec = eng.last_launch_specialisation
+    loop.reset()
+    launch_s = float(np.median(ms)) / 1e3
+    out = {"outputs": f"obs [T,E,{D}] f64 + reward [T,E] + done [T,E] + mask [T,E,{P}], every step kept ({obs.numel() * 8 / 1e6:.0f} MB of observations per launch)",
+           "specialisation": spec, "us_per_step": launch_s * 1e6 / T, "env_steps_per_s_kernel_only": E * T / launch_s,
+           "roofline": kernel_roofline(bytes_env_step, E, T, launch_s, eng.kernel_name),
+           "vs_stride0_kernel_time": (launch_s * 1e6 / stride0_launch_us) if stride0_launch_us else None}
+    del obs, mask
+    return out
+
+
 def self_launch(n_gpus, argv):
     """`python bench.py --gpus N` with no rendezvous in the environment: re-run this file as N ranks (one per GPU) under
     torch.distributed.run on this node -- the command the driver would type itself -- and pass rank 0's JSON line through."""
@@ -419,6 +498,7 @@ def main():
                          "SB3-trained float32 policy computes, to 1e-5); mlp_torch: the same network through torch.nn (fp32)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-rollout-record", action="store_true", help="skip the short policy-in-the-loop pass (`rollout` in the line)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the short cfg3 / cfg4 passes (`other_workloads` in the cfg2 line)")
     ap.add_argument("--only-timed", action="store_true", help="profiling runs: nothing but the timed regions of the chosen launch mode "
                     "(no whole-episode pass, no HIP-event roofline pass, no rollout record), so that a kernel trace of `--launch per_step` "
                     "holds single-step dispatches only")
@@ -565,7 +645,7 @@ def main():
                    "contains": "112-step persistent launch + statistics kernel + reset onto fresh scenarios"}
 
     C_, R_ = batch.n_chargers, batch.n_transformers
-    bytes_env_step = P * (phi * wl["b_occ"] + (1 - phi) * wl["b_empty"]) + R_ * wl["b_tr"] + wl["b_env"]
+    bytes_env_step = workload_bytes_env_step(wl, P, R_, phi)
 
     def roofline(mode):
         # kernel-only duration, HIP events on the launch stream around every ev2g_step_n of an untimed pass
@@ -663,6 +743,22 @@ def main():
     if actor is None and not stub and not args.no_rollout_record and not args.only_timed and args.workload != "cfg4":
         refill = refill_record(Engine, wl, rk, sk, local_rank, devx, E, rank, args, T)
 
+    # the persistent launch with every output KEPT ([T,E,*] blocks), and the other BASELINE single-GPU configs, on the same line
+    strided, others = None, None
+    if actor is None and not stub and not args.only_timed and n_groups == 1 and "persistent" in modes:
+        try:
+            strided = strided_record(eng, loop, E, P, D, T, dev, bytes_env_step, (roof.get("persistent") or {}).get("avg_launch_us"))
+        except Exception as ex:   # (a record next to the headline: never lets the line fail)
+            strided = {"error": f"{type(ex).__name__}: {ex}"}
+    if actor is None and not stub and not args.only_timed and not args.no_other_workloads and args.workload == "cfg2":
+        others = {}
+        for name in ("cfg3", "cfg4"):
+            Eo = max(64, WORKLOADS[name]["envs"] * E // wl["envs"])
+            try:
+                others[name] = other_workload_record(Engine, name, Eo, local_rank, devx, rank, args)
+            except Exception as ex:
+                others[name] = {"error": f"{type(ex).__name__}: {ex}"}
+
     env_steps_total = world * E * args.steps
     value = env_steps_total / wall[best]
     per_rank, ranks_seen = None, None
@@ -706,6 +802,10 @@ def main():
         out["rollout"] = rollout
     if refill is not None:
         out["device_refill"] = refill
+    if strided is not None:
+        out["persistent_strided"] = strided
+    if others is not None:
+        out["other_workloads"] = others
     if stub:
         out["data"] = "STUB ENGINE on CPU (launcher / control-flow test, not a measurement)"
     for e_ in engines:

@@ -49,6 +49,37 @@ struct SessTail {
     int nt_arr, nt_dep;  // window of the next session on the same port (EV2G_INT_MAX = none)
 };
 
+// Round 5: the battery maths' operands that are the SAME for every session of one car model on one kind of charger (ev.py:68-113: the model's
+// powers, battery size, gates; the charger's voltage and phases) live in a small dictionary instead of in every session's record: a few
+// dozen 128-byte entries that stay in the vector L1, so the fetch in the middle of the battery-maths phase is an L1 hit instead of an L2
+// round trip to the session's own line (the one lever that reached 0.60 of the roofline in round 4's ablation).  What really differs per
+// session -- transition_soc and, without an efficiency table, the two efficiencies (utils.py:293-296,309-310) -- is SessDyn: it travels with the
+// arrival's other operands into the port's LDS state (ev2g_step_wave.h) and, across launches, into the port's PortDyn entry.
+// Laid out by consumer: a charging step reads chunks 0..3 (one 64-byte sector), a discharging step chunks 4..6.
+struct __attribute__((aligned(128))) ClsRec {
+    double pacmax, tsm;       // chunk 0  (charge)
+    double gate_ch, B;        // chunk 1  (charge)
+    double rB, v;             // chunk 2  (charge)
+    double rv, pad0;          // chunk 3  (charge)
+    double v_d, rv_d;         // chunk 4  (discharge: copies of v, rv)
+    double gate_dis, minB;    // chunk 5  (discharge)
+    double emerg, pdismax;    // chunk 6  (discharge)
+    double pad1[2];
+};
+#define EV2G_CLS_CAP 4096     // dictionary entries (12 bits of the port's LDS word); a batch with more distinct tuples keeps one ClsRec per SESSION instead
+struct __attribute__((aligned(32))) SessDyn {
+    double ts, eta_ch;        // EV.transition_soc, EV.charge_efficiency (a number: sessions without an efficiency table)
+    double eta_dis;           // EV.discharge_efficiency
+    int lut, cls;             // efficiency-table id (-1: none), dictionary entry (the session's own index when the batch has no dictionary)
+};
+typedef SessDyn PortDyn;      // the same four words for the EV attached to a port, written at its arrival: what a later launch's prologue reads
+__host__ __device__ inline ClsRec ev2g_cls_of(const SessRec &r) {
+    ClsRec c;
+    c.pacmax = r.pacmax; c.tsm = r.tsm; c.gate_ch = r.gate_ch; c.B = r.B; c.rB = r.rB; c.v = r.v; c.rv = r.rv; c.pad0 = 0.0;
+    c.v_d = r.v; c.rv_d = r.rv; c.gate_dis = r.gate_dis; c.minB = r.minB; c.emerg = r.emerg; c.pdismax = r.pdismax; c.pad1[0] = 0.0; c.pad1[1] = 0.0;
+    return c;
+}
+
 struct DevScn {  // read-only scenario + layout, device pointers
     int E;        // envs stepped concurrently (state arrays are [E, ...])
     int M;        // scenarios resident in the pool (scenario arrays are [M, ...]); env e runs scenario (e + off) mod M
@@ -95,6 +126,9 @@ struct DevScn {  // read-only scenario + layout, device pointers
     const int2 *port_first_win;
     const SessRec *rec;  // [S] AoS twin of the ss_* arrays (v2 kernels)
     const SessTail *tail;  // [S] departure-side fields of the same sessions
+    const SessDyn *sess_dyn;   // [S] per-session battery-maths operands + dictionary entry (fast path, round 5)
+    const ClsRec *cls_rec;     // dictionary [EV2G_CLS_CAP] (n_cls used), or one entry per session [S] when `dict` is 0
+    int dict, n_cls;
     const double *win_tab;  // [E,R,T+1,40] precomputed (loads-pv)[20] | power_limits[20] per observation step, or nullptr
     const double *head_tab; // fast path: [M,T+1,head_nh] columns 2.. of the observation of every step counter (prices | window), or nullptr
     int head_nh;
@@ -128,6 +162,7 @@ struct DevState {  // mutable engine state, device pointers
     double *slab_hist;   // == hist
     double *slab_sess;   // sess_final_cap | sess_abs_e         ([S] each)
     PortLine *line;                    // [E*P] per-port dynamic state (above)
+    PortDyn *port_dyn;                 // [E*P] SessDyn of the attached EV (fast path; written at its arrival, read by a launch's prologue)
     double *cs_sat_sum;                // [E*C] EV_Charger.total_user_satisfaction
     int *cs_served;                    // [E*C] EV_Charger.total_evs_served
     double *cs_profits, *cs_e_ch, *cs_e_dis;  // [E*C] (EV2G_FLAG_LOG_CS_HISTORY) else nullptr

@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <array>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -61,6 +63,15 @@ struct ev2g_handle {
     int sess_cap = 0;                           // EV2G_FLAG_REFILLABLE: session slots per scenario of the resident pool (0: packed storage)
     bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
     bool no_full = false, no_wide = false;      // EV2G_NO_FULL / EV2G_NO_WIDE at load time: A/B and routing tests only
+    bool no_strided = false;                    // EV2G_NO_STRIDED at load time: strided outputs run the general instantiation (round 4's routing; parity tests)
+    // battery-maths dictionary (ClsRec, ev2g_device.h): host mirror of the entries in use, so that ev2g_pool_refill can append the
+    // classes its fleet may draw; d_cls_rec has room for EV2G_CLS_CAP entries when DevScn::dict is set
+    typedef std::array<uint64_t, 11> ClsKey;
+    std::map<ClsKey, int> cls_map;
+    ClsRec *d_cls_rec = nullptr;
+    std::vector<double> cs_vk_host;             // [C,4] voltage*sqrt(k) and [C] phases of the loaded chargers (the refill's dictionary entries)
+    std::vector<int> cs_ph_host;
+    int load_gen = 0;                           // counts ev2g_load_scenarios calls (part of the refill cache's key)
     int last_spec = -1;                         // ev2g_last_launch_specialisation
     const char *general_reason = "";            // ev2g_last_launch_general_reason
     bool pow2_dt = false;                       // 60 / timescale is a power of two (15, 30, 60 minutes): compiled into ev2g_step_v2<.., 1>
@@ -120,6 +131,21 @@ static int dalloc(ev2g_handle *h, std::vector<void *> &pool, size_t n, T **dst) 
 static void free_pool(std::vector<void *> &pool) {
     for (void *p : pool) (void)hipFree(p);
     pool.clear();
+}
+
+// dictionary entry of a ClsRec (by value, bit for bit); -1 when the dictionary is full
+static int cls_find_or_add(std::map<ev2g_handle::ClsKey, int> &map, std::vector<ClsRec> &tab, const ClsRec &c) {
+    ev2g_handle::ClsKey k;
+    const double f[11] = {c.pacmax, c.tsm, c.gate_ch, c.B, c.rB, c.v, c.rv, c.gate_dis, c.minB, c.emerg, c.pdismax};
+    std::memcpy(k.data(), f, sizeof f);
+    auto it = map.find(k);
+    if (it != map.end()) return it->second;
+    if (map.size() >= EV2G_CLS_CAP) return -1;
+    const int id = (int)map.size();
+    map.emplace(k, id);
+    if ((size_t)id >= tab.size()) tab.resize((size_t)id + 1);
+    tab[(size_t)id] = c;
+    return id;
 }
 
 #include "ev2g_refill_host.h"
@@ -483,6 +509,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     if (het) h->fallback_reason = "chargers with different port counts (topology file)";
     h->wave_path = h->fallback_reason.empty();
     h->no_full = std::getenv("EV2G_NO_FULL") != nullptr; h->no_wide = std::getenv("EV2G_NO_WIDE") != nullptr; h->last_spec = -1;
+    h->no_strided = std::getenv("EV2G_NO_STRIDED") != nullptr;
     if (h->wave_path) {   // ev2g_step_wave addresses every array as base + 32-bit byte offset: all of them must stay below 4 GiB
         const unsigned long long lim = 1ull << 32;
         const unsigned long long biggest = std::max({(unsigned long long)E * P * 8, (unsigned long long)E * D * 8,
@@ -557,6 +584,32 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
             r.potc = r.v * ((evc < imax) ? evc : imax) / 1000.0;
         }
         tails[d].des = ss_des[d]; tails[d].nt_arr = ss_ntarr[d]; tails[d].nt_dep = ss_ntdep[d];
+    }
+    // Battery-maths dictionary (fast path): the distinct (car model x charger kind) operand tuples of the batch, and per session what is left
+    // (SessDyn).  More than EV2G_CLS_CAP tuples (arbitrary ev_* arrays through the ABI), or EV2G_NO_DICT: one ClsRec per session, entry = session.
+    std::vector<SessDyn> dyns((size_t)std::max<long long>(SD, 1));
+    std::memset(dyns.data(), 0, dyns.size() * sizeof(SessDyn));
+    std::vector<ClsRec> cls_tab;
+    h->cls_map.clear();
+    bool dict = h->wave_path && std::getenv("EV2G_NO_DICT") == nullptr;
+    if (h->wave_path) {
+        for (long long d = 0; d < SD && dict; d++) {
+            if (dev_to_host[d] < 0) continue;
+            const int k = cls_find_or_add(h->cls_map, cls_tab, ev2g_cls_of(recs[d]));
+            if (k < 0) { dict = false; break; }
+            dyns[d].cls = k;
+        }
+        if (!dict) {
+            h->cls_map.clear();
+            cls_tab.assign((size_t)std::max<long long>(SD, 1), ClsRec{});
+            for (long long d = 0; d < SD; d++) if (dev_to_host[d] >= 0) { cls_tab[d] = ev2g_cls_of(recs[d]); dyns[d].cls = (int)d; }
+        } else
+            cls_tab.resize(EV2G_CLS_CAP, ClsRec{});   // room for the classes a device refill may add
+        for (long long d = 0; d < SD; d++) {
+            if (dev_to_host[d] < 0) continue;
+            dyns[d].ts = ss_ts[d]; dyns[d].eta_ch = ss_etach[d]; dyns[d].eta_dis = ss_etadis[d]; dyns[d].lut = ss_lut[d];
+        }
+        if (b->n_lut > 4094) h->no_full = true;   // the full kernels keep table id + 1 in 12 bits of a port's LDS word
     }
 
     // ---- upload ----
@@ -657,6 +710,12 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     UP(dp, ss_afap) h->d_ss_afap = dp;
     { SessRec *rp; UP(rp, recs) s.rec = rp; }
     { SessTail *tp; UP(tp, tails) s.tail = tp; }
+    s.sess_dyn = nullptr; s.cls_rec = nullptr; s.dict = 0; s.n_cls = 0; h->d_cls_rec = nullptr;
+    if (h->wave_path) {
+        SessDyn *dp2; UP(dp2, dyns) s.sess_dyn = dp2;
+        ClsRec *cp; UP(cp, cls_tab) s.cls_rec = cp; h->d_cls_rec = cp;
+        s.dict = dict ? 1 : 0; s.n_cls = dict ? (int)h->cls_map.size() : 0;
+    }
 #undef UP
 #undef UPP
     s.win_tab = nullptr;
@@ -706,6 +765,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     {   // per-port state: one 64-byte line per port + one slab of EV2G_PS_* slices for what is not on the step's path
         AL(line, EP)
         HIPCHK(h, hipMemsetAsync(st.line, 0, EP * sizeof(PortLine), h->stream));
+        if (h->wave_path) { AL(port_dyn, EP) }
         const size_t slice = std::max(EP, EC) * 8;
         if ((rc = dalloc(h, sp, slice * EV2G_PS_N, &st.slab_port))) return rc;
         st.slab_port_slice = slice;
@@ -747,6 +807,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
     h->port_slot = port_slot;
     h->env_sess_start.assign(b->env_session_start, b->env_session_start + M + 1);
     h->host_to_dev = host_to_dev;
+    h->cs_vk_host = cs_vk; h->cs_ph_host.assign(b->cs_phases, b->cs_phases + C); h->load_gen += 1;
     h->sess_port = sess_port;
     h->sess_afap = sess_afap_host;
     h->loaded = true;
@@ -835,36 +896,42 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         const V2P *pp = (const V2P *)h->d_v2p;
         const DevState &st = h->st;
         const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.hist,
-                          st.env_acc, s.cs_pack, (char *)st.line, h->d_step_tab};
+                          st.env_acc, s.cs_pack, (char *)st.line, h->d_step_tab, (char *)st.port_dyn, s.dict};
         // every float64 output present, no extras, no charger histories: the specialisation without their checks (not for the run-time rewards)
         // ... in two flavours: float64 actions in / float64 observations out (a loop that consumes them, the benchmark), or the policy
         // network's hand-over, float32 actions in / float32 observations out and no float64 observation (ev2g_rollout)
         const bool f64io = io.actions && io.obs && !x.obs_f32, f32io = !io.actions && io.act32 && !io.obs && io.obs32;
-        const bool full = (f64io || f32io) && io.reward && io.done && io.mask && !x.cost && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) &&
-                          io.o_stride == 0 && io.r_stride == 0 && io.d_stride == 0 && io.m_stride == 0 && !auto_reset && t0 + k <= s.T &&
-                          std::min(s.reward_kind, 3) != 3 && !h->no_full;
+        const bool full0 = (f64io || f32io) && io.reward && io.done && io.mask && !x.cost && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) &&
+                           !auto_reset && t0 + k <= s.T && std::min(s.reward_kind, 3) != 3 && !h->no_full;
         // ... and: SoC log on, one observation-head column pair per lane at most (PublicPST has no head table), three lanes for the history store
-        const bool wide = full && (h->cfg.flags & EV2G_FLAG_LOG_SOC) && s.P >= 3 && !h->no_wide &&
-                          s.P >= (s.state_kind == EV2G_STATE_PUBLIC_PST ? 3 : (s.state_kind == EV2G_STATE_V2G_PROFIT_MAX_LOADS ? 30 : 10));
-        h->last_spec = (full && std::min(s.reward_kind, 3) != 3) ? (wide ? 2 : 1) : 0;
+        const bool wide0 = full0 && (h->cfg.flags & EV2G_FLAG_LOG_SOC) && s.P >= 3 && !h->no_wide &&
+                           s.P >= (s.state_kind == EV2G_STATE_PUBLIC_PST ? 3 : (s.state_kind == EV2G_STATE_V2G_PROFIT_MAX_LOADS ? 30 : 10));
+        // outputs with step strides ([K, E, *] blocks): the wide float64 instantiation with running output pointers (3); elsewhere stride 0 only
+        const bool strided = io.o_stride != 0 || io.r_stride != 0 || io.d_stride != 0 || io.m_stride != 0;
+        const bool str3 = strided && wide0 && f64io && !h->no_strided;
+        const bool full = full0 && (!strided || str3), wide = wide0 && full;
+        h->last_spec = full ? (str3 ? 3 : (wide ? 2 : 1)) : 0;
         {   // why not the full instantiation: the FIRST thing the caller passed (or configured) that rules it out -- ev2g_last_launch_general_reason
             const char *why = "";
             if (!full) {
-                if (h->no_full) why = "EV2G_NO_FULL is set";
+                if (h->no_full) why = "EV2G_NO_FULL is set (or the batch has more than 4094 efficiency tables)";
                 else if (std::min(s.reward_kind, 3) == 3) why = "the reward function is one of the eight selected at run time (only the shipped configs' three are compiled in)";
                 else if (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) why = "EV2G_FLAG_LOG_CS_HISTORY (charger histories)";
                 else if (x.cost) why = "a cost buffer is registered (ev2g_set_step_extras)";
                 else if (auto_reset) why = "auto_reset";
                 else if (!(io.reward && io.done && io.mask)) why = "a reward / done / mask output is NULL";
                 else if (!(f64io || f32io)) why = "the observation / action buffers are neither the float64 pair nor the float32 hand-over pair (e.g. obs NULL, or a float32 observation copy next to the float64 one)";
-                else if (io.o_stride || io.r_stride || io.d_stride || io.m_stride) why = "an output step stride is not 0";
+                else if (strided) why = "an output step stride is not 0 (strided outputs keep the specialisation only with float64 observations, EV2G_FLAG_LOG_SOC and an env wide enough for the wide instantiation)";
                 else why = "the launch would run past the episode end";
             }
             h->general_reason = why;
         }
 #define EV2G_WAVE_CASE(SK, RK)                                                                                              \
     case SK * 4 + RK:                                                                                                       \
-        if (full && RK != 3 && wide && f32io)                                                                               \
+        if (full && RK != 3 && str3)                                                                                        \
+            hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), false, 3>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
+                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
+        else if (full && RK != 3 && wide && f32io)                                                                          \
             hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), true, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
                                h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
         else if (full && RK != 3 && f32io)                                                                                  \
@@ -886,7 +953,8 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         switch (s.state_kind * 4 + std::min(s.reward_kind, 3)) {   // rewards beyond the three compiled-in ones share instantiation 3
 #ifdef EV2G_ONLY_00   /* tuning builds (tools/): one specialisation, seconds to compile */
             case 0:
-                if (wide && f32io) hipLaunchKernelGGL((ev2g_step_wave<0, 0, true, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
+                if (str3) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 3>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
+                else if (wide && f32io) hipLaunchKernelGGL((ev2g_step_wave<0, 0, true, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
                 else if (full && f32io) hipLaunchKernelGGL((ev2g_step_wave<0, 0, true, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
                 else if (wide) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
                 else if (full) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);

@@ -42,6 +42,7 @@ struct RefillArgs {
     int multi;                  // chargers with several ports (or a topology file): an arriving EV takes the charger's first free port (ev_charger.py:266-286) --
                                 // the kernel replays that per charger before it places the sessions (needs T <= 256 and at most EV2G_RF_K sessions per port)
     const double *tr_cap;       // [R] transformer capacities of a topology file (device copy), or null: cfg.transformer_max_power
+    const int *cls_of;          // [models][C] battery-maths dictionary entry of (car model, charger) when DevScn::dict is set (ev2g_pool_refill builds it), else null
 };
 #define RF_STAMP(i) if (a.dbg && threadIdx.x == 0) { if (blockIdx.x == 0) a.dbg[i] = __builtin_readcyclecounter(); \
         if (blockIdx.x == gridDim.x - 1 && ((i) == 0 || (i) == 6)) a.dbg[8 + ((i) != 0)] = __builtin_readcyclecounter(); \
@@ -255,6 +256,13 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
                 r.potc = r.v * ((evc < imax) ? evc : imax) / 1000.0;
             }
             RW(SessRec, rec)[d] = r;
+            if (s.sess_dyn) {   // fast path: the per-session operands and the dictionary entry (ev2g_device.h, ClsRec / SessDyn)
+                SessDyn dy;
+                dy.ts = f.ts; dy.eta_ch = f.eta_ch; dy.eta_dis = f.eta_dis; dy.lut = f.lut;
+                if (s.dict) dy.cls = a.cls_of[(size_t)e.model * s.C + cs];
+                else { dy.cls = (int)d; RW(ClsRec, cls_rec)[d] = ev2g_cls_of(r); }
+                RW(SessDyn, sess_dyn)[d] = dy;
+            }
             SessTail tl;
             tl.des = f.desired; tl.nt_arr = EV2G_INT_MAX; tl.nt_dep = EV2G_INT_MAX;
             RW(SessTail, tail)[d] = tl;

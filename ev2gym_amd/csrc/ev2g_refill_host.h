@@ -58,6 +58,7 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
     if (c.tab_arrival_week) { refill_append(key, c.tab_arrival_week, 96 * 8); refill_append(key, c.tab_arrival_weekend, 96 * 8); refill_append(key, c.tab_stay, 48 * 8); refill_append(key, c.tab_energy, 48 * 8); }
     if (c.tab_pv && c.n_pv > 0) refill_append(key, c.tab_pv, (size_t)c.n_pv * 8);
     if (topo) refill_append(key, c.topo_tr_max_power, (size_t)s.R * 8);   // (the chargers' own constants are the resident pool's)
+    refill_append(key, &h->load_gen, sizeof h->load_gen);   // (the dictionary entries below belong to the loaded pool)
     if (!h->d_refill_overflow) {   // its own allocation, freed by ev2g_destroy: it must survive ev2g_load_scenarios (which frees scn_allocs) and config changes
         HIPCHK(h, hipMalloc((void **)&h->d_refill_overflow, sizeof(int)));
         HIPCHK(h, hipMemsetAsync(h->d_refill_overflow, 0, sizeof(int), h->stream));
@@ -86,6 +87,44 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
         if (topo && upd(c.topo_tr_max_power, (size_t)s.R, &a.tr_cap)) return rc;
         if (!spec_row.empty()) { int *p; if ((rc = upload(h, rc_.allocs, spec_row.data(), spec_row.size(), &p))) return rc; a.spec_row = p; }
         ev2g_gen_make_run(c, s.P, s.npc, seed, a.g0);
+        a.cls_of = nullptr;
+        if (s.dict) {
+            // every (car model, charger) pair the generator can draw gets its dictionary entry now -- the operands exactly as the kernel's
+            // write_session forms them (ev2g_refill.h) -- so that the device only looks an index up; entries the loaded batch did not
+            // contain are appended to the resident dictionary
+            Ev2gGenRun g = a.g0;
+            g.c = &c;
+            const Ev2gFleet fleet = ev2g_fleet(g);
+            const int n_models = c.heterogeneous_ev_specs ? fleet.n : 1;
+            const Ev2gRng rng0 = ev2g_rng(seed, 0);
+            std::vector<int> cls_of((size_t)n_models * s.C);
+            std::vector<ClsRec> tab;   // (indexed by entry; only the new ones are filled)
+            const size_t n_before = h->cls_map.size();
+            for (int m = 0; m < n_models; m++) {
+                Ev2gGenSession e{0, 1, 2, m, c.heterogeneous_ev_specs ? fleet.battery(m) : c.ev_battery_capacity,
+                                 c.heterogeneous_ev_specs ? fleet.pac(m) : c.ev_max_ac_charge_power, 1.0};
+                const Ev2gSessFields f = ev2g_gen_session_fields(g, rng0, e, spec_row.empty() ? nullptr : spec_row.data());
+                for (int cs = 0; cs < s.C; cs++) {
+                    const int ph = h->cs_ph_host[(size_t)cs];
+                    const double v_gate = h->cs_vk_host[(size_t)cs * 4 + ph];
+                    SessRec r{};
+                    r.B = e.B; r.minB = f.minB; r.emerg = f.min_emerg; r.pacmax = e.pac; r.pdismax = f.pdis_max; r.tsm = f.tsm;
+                    r.gate_ch = f.pac_min * 1000.0 / v_gate;
+                    r.gate_dis = f.pdis_min * 1000.0 / v_gate;
+                    r.v = h->cs_vk_host[(size_t)cs * 4 + std::min(ph, f.phases)];
+                    r.rB = 1.0 / r.B; r.rv = 1.0 / r.v;
+                    const int k = cls_find_or_add(h->cls_map, tab, ev2g_cls_of(r));
+                    if (k < 0) return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: the fleet would take the battery-maths dictionary beyond its " + std::to_string(EV2G_CLS_CAP) +
+                                                                " entries (load the pool with EV2G_NO_DICT=1)");
+                    cls_of[(size_t)m * s.C + cs] = k;
+                }
+            }
+            if (h->cls_map.size() > n_before) {
+                HIPCHK(h, hipMemcpyAsync(h->d_cls_rec + n_before, tab.data() + n_before, (h->cls_map.size() - n_before) * sizeof(ClsRec), hipMemcpyHostToDevice, h->stream));
+                h->scn.n_cls = (int)h->cls_map.size();
+            }
+            int *p; if ((rc = upload(h, rc_.allocs, cls_of.data(), cls_of.size(), &p))) return rc; a.cls_of = p;
+        }
         a.g0.c = nullptr;
         a.g0.pv_per_day = pv.empty() ? 0 : 1440 / c.timescale;
         (void)hipStreamSynchronize(h->stream);   // the staging vectors are temporaries

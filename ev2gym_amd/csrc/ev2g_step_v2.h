@@ -173,6 +173,7 @@ struct V2P {
     EV2G_GP(double) slab_hist; EV2G_GP(double) slab_sess; unsigned long long sess_slice;   // bytes
     EV2G_GP(const double) head_tab;   // [E, T+1, NH] observation head rows (fast path only, ev2g_build_head_table_kernel)
     EV2G_GP(const SessRec) rec; EV2G_GP(const SessTail) tail; EV2G_GP(const int) ss_lut;
+    EV2G_GP(const SessDyn) sess_dyn; EV2G_GP(const ClsRec) cls_rec;   // fast path, round 5 (ev2g_device.h)
     EV2G_GP(PortLine) line;
     EV2G_GP(double) cs_sat_sum; EV2G_GP(int) cs_served;
     EV2G_GP(double) cs_profits; EV2G_GP(double) cs_e_ch; EV2G_GP(double) cs_e_dis;
@@ -205,7 +206,7 @@ inline void ev2g_v2_fill_params(V2P &p, const DevScn &s, const DevState &st) {
     CPS(slot_cs) CPS(slot_port) CPS(slot_obs) CPS(cs_slot0) CPS(tr_seg) CPS(tr_obs) CPS(port_first) CPS(port_first_win)
     CPS(cs_imax) CPS(cs_imin) CPS(cs_dmin) CPS(cs_dmax_abs) CPS(cs_maxp) CPS(cs_minp)
     CPS(price_ch) CPS(price_dis) CPS(setpoint) CPS(tr_infl) CPS(tr_solar) CPS(tr_base) CPS(tr_maxp) CPS(tr_minp)
-    CPS(win_tab) CPS(lut) CPS(rec) CPS(tail) CPS(ss_lut)
+    CPS(win_tab) CPS(lut) CPS(rec) CPS(tail) CPS(ss_lut) CPS(sess_dyn) CPS(cls_rec)
     CPT(line) CPT(cs_sat_sum) CPT(cs_served)
     CPT(cs_profits) CPT(cs_e_ch) CPT(cs_e_dis) CPT(cs_power_hist) CPT(cs_cur_hist) CPT(cs_power_now) CPT(cs_cur_now)
     CPT(env_acc) CPT(env_fault) CPT(hist) CPT(tr_power_now)

@@ -67,6 +67,29 @@ template <class B> __device__ __forceinline__ SessRec ldg32_rec_discharge(B base
     return u.r;
 }
 
+// Round 5 (full kernels): the same operands from the dictionary entry (ClsRec, ev2g_device.h) -- four chunks for a charging step, three for a
+// discharging one -- with the per-session ones (transition_soc, the efficiencies) supplied by the caller from the port's LDS state.
+template <class B> __device__ __forceinline__ SessRec ldg32_cls_charge(B base, unsigned boff) {
+    static_assert(sizeof(ClsRec) == 128 && offsetof(ClsRec, gate_ch) == 16 && offsetof(ClsRec, rB) == 32 && offsetof(ClsRec, rv) == 48 && offsetof(ClsRec, v_d) == 64 &&
+                  offsetof(ClsRec, gate_dis) == 80 && offsetof(ClsRec, emerg) == 96, "ClsRec layout");
+    d2v c[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) c[i] = ldg32<d2v>(base, boff + 16u * i);
+    asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+    SessRec r;
+    r.pacmax = c[0].x; r.tsm = c[0].y; r.gate_ch = c[1].x; r.B = c[1].y; r.rB = c[2].x; r.v = c[2].y; r.rv = c[3].x;
+    return r;
+}
+template <class B> __device__ __forceinline__ SessRec ldg32_cls_discharge(B base, unsigned boff) {
+    d2v c[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) c[i] = ldg32<d2v>(base, boff + 64u + 16u * i);
+    asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+    SessRec r;
+    r.v = c[0].x; r.rv = c[0].y; r.gate_dis = c[1].x; r.minB = c[1].y; r.emerg = c[2].x; r.pdismax = c[2].y;
+    return r;
+}
+
 // What the launch prologue needs, BY VALUE: with it the first data loads depend on one fetch (the kernarg segment)
 // instead of two (kernarg -> parameter block).  A launch starts with cold caches, so every dependent fetch in the
 // prologue is a full memory round trip -- paid per step by single-step launches.
@@ -78,6 +101,8 @@ struct WaveArgs {
     const double *cs_pack;   // [C][6] imax, |dmax|, imin, dmin, max power, min power
     char *lines;             // [E*P] PortLine
     const double *step_tab;  // [M, T, 8]; slots 6, 7: the scenario's occupancy / arrival masks of the step
+    char *port_dyn;          // [E*P] PortDyn: transition_soc, efficiencies, table id and dictionary entry of the attached EV
+    int dict;                // DevScn::dict: V2P::cls_rec is a dictionary (entry = bits 20..31 of the port's LDS word); 0: one ClsRec per session
 };
 
 // IO32: the actions are float32 (StepIO::act32) -- the policy-network interface; float32 observations (StepIO::obs32) are
@@ -94,11 +119,14 @@ struct WaveArgs {
 // FULLK = 2 additionally knows at compile time that the SoC log is on (EV2G_FLAG_LOG_SOC: the Python surface's and the benchmark's default)
 // and that the env is wide enough for one observation-head column pair per lane (P >= 30 for the 60-column head, P >= 10 for the
 // 20-column one): the second pair's prefetch and stores and the tail loop of narrow envs go too.
+// FULLK = 3 (round 5) is FULLK = 2 for outputs with STEP STRIDES -- the [K, E, *] blocks of a persistent launch whose every observation, reward, done
+// flag and mask is kept (generate_trajectories.py:69-83 style use; a replay block): four running pointers advanced with scalar adds per step,
+// everything else as compiled-out as in 2.
 template <int SK, int RK, bool IO32, int FULLK = 0>
 __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
                                                                      int k_steps, int auto_reset, WaveArgs wa) {
     extern __shared__ double lds[];
-    constexpr bool FULL = FULLK >= 1, WIDE = FULLK >= 2;
+    constexpr bool FULL = FULLK >= 1, WIDE = FULLK >= 2, STR = FULLK >= 3;
     constexpr bool F64 = FULL && !IO32, F32 = FULL && IO32;   // full with float64 actions in / observations out, or with the float32 hand-over
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
     const unsigned long long pt_k0 = __builtin_readcyclecounter();   // slot 7 := prologue, slot 6 := epilogue (tools/phase_timing.py --outer)
@@ -134,6 +162,11 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     int *s_ta = (int *)(s_cst + 4 * 64);
     int *s_td = s_ta + NS, *s_ss = s_td + NS, *s_cyc = s_ss + NS, *s_dirty = s_cyc + NS, *items = s_dirty + NS;
     int *cnt = items + NS;  // cnt[2*(kk&1) + {0 charge, 1 discharge}]
+    // Full kernels keep window, battery size and potential term in registers (below): the LDS behind s_bcap / s_potc / s_ta + s_td holds the attached
+    // EV's transition_soc and efficiencies instead -- what the battery maths used to fetch from the session's own record -- and bits 20..31 of
+    // s_dirty its dictionary entry (bits 8..19 the efficiency-table id + 1: a full kernel needs n_lut <= 4094, checked by the host)
+    double *s_ts = s_bcap, *s_etac = s_potc, *s_etad = (double *)s_ta;
+    constexpr int LUTMASK = FULL ? 0xfff : 0xffff;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const bool log_soc = WIDE ? true : (S->soc_log != nullptr);
     const bool log_cs = FULL ? false : (S->cs_profits != nullptr);   // EV2G_FLAG_LOG_CS_HISTORY: charger-level accumulators and histories (ev2gym_env.py:533-535)
@@ -198,13 +231,19 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 if (body || ((m_arr >> q) & 1ull)) hd = ldg32<i4v>(wa.lines, l64);   // (a port without either keeps the defaults: no event can touch it this step)
             } else body = (hd.x <= t) && (t <= hd.y);
             d2v b1 = {0.0, 0.0}, b2 = {0.0, 0.0}, b3 = {1.0, 0.0};
-            if (body) { b1 = ldg32<d2v>(wa.lines, l64 + 16u); b2 = ldg32<d2v>(wa.lines, l64 + 32u); b3 = ldg32<d2v>(wa.lines, l64 + 48u); }
+            d2v pd0 = {1.0, 1.0}; i4v pd1 = {0, 0, -1, 0};
+            static_assert(sizeof(PortDyn) == 32 && offsetof(PortDyn, eta_dis) == 16 && offsetof(PortDyn, lut) == 24 && offsetof(PortDyn, cls) == 28, "PortDyn layout");
+            if (body) {
+                b1 = ldg32<d2v>(wa.lines, l64 + 16u); b2 = ldg32<d2v>(wa.lines, l64 + 32u); b3 = ldg32<d2v>(wa.lines, l64 + 48u);
+                if (FULL) { pd0 = ldg32<d2v>(wa.port_dyn, (unsigned)g * 32u); pd1 = ldg32<i4v>(wa.port_dyn, (unsigned)g * 32u + 16u); }
+            }
             r_ta = hd.x; r_td = hd.y;
             if (!FULL) { s_ta[tid] = hd.x; s_td[tid] = hd.y; }
             s_ss[tid] = hd.z; s_cyc[tid] = ev2g_line_cycles(hd.w);
             // s_dirty: bits 0,1 = what the epilogue must write back; bits 8..23 = 1 + efficiency-table id of the attached EV,
             // so that the battery maths can issue the table look-up together with (not behind) the session-record load
-            s_dirty[tid] = (int)((unsigned)hd.w >> 16) << 8;
+            s_dirty[tid] = (int)(((unsigned)hd.w >> 16) << 8 | ((FULL && wa.dict) ? (unsigned)pd1.w << 20 : 0u));
+            if (FULL) { s_ts[tid] = pd0.x; s_etac[tid] = pd0.y; s_etad[tid] = __hiloint2double(pd1.y, pd1.x); }
             s_cap[tid] = b1.x; s_tot[tid] = b1.y; s_prev[tid] = b2.x; s_abse[tid] = log_soc ? b2.y : 0.0;
             r_bcap = b3.x; r_potc = b3.y;
             if (FULL) { if (body) r_rb = 1.0 / r_bcap; }
@@ -227,6 +266,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     unsigned hb_step = 0, hb_head = 0, hb_obs_port = 0, hb_obs_env = 0;
     const double *act_run = io.actions;   // the actions of the step in work
     const float *act32_run = F32 ? io.act32 + (long long)io.step0 * io.a_stride : nullptr;
+    double *obs_run = io.obs, *rew_run = io.reward;   // the outputs of the step in work (STR: advanced by their step strides; else the launch's one row)
+    uint8_t *done_run = io.done, *mask_run = io.mask;
     constexpr unsigned OB = F32 ? 4u : 8u;    // bytes per observation element the full kernel writes
     if (FULL) {
         const int scn0 = ev2g_scn(valid ? e : e0, off, M);
@@ -271,9 +312,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             }
             t = 0;
         }
-        double *obs = F64 ? io.obs : ((!FULL && io.obs) ? io.obs + (long long)kk * io.o_stride : nullptr);       // uniform bases (scalar arithmetic)
+        double *obs = F64 ? obs_run : ((!FULL && io.obs) ? io.obs + (long long)kk * io.o_stride : nullptr);       // uniform bases (scalar arithmetic)
         float *obs32 = F32 ? io.obs32 : ((!FULL && S->x_obs32) ? (float *)S->x_obs32 + (long long)(io.step0 + kk) * S->x_o32_stride : nullptr);
-        uint8_t *mask = FULL ? io.mask : (io.mask ? io.mask + (long long)kk * io.m_stride : nullptr);
+        uint8_t *mask = FULL ? mask_run : (io.mask ? io.mask + (long long)kk * io.m_stride : nullptr);
         const int sstep = t + 1;
         const bool last_step = (kk == k_steps - 1) || (!FULL && sstep >= T && !auto_reset);
         int *cntk = cnt + 2 * (kk & 1);
@@ -360,14 +401,16 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // the other lanes of such a wavefront read record 0.
         const bool ev_dep = occ && t >= td_a, ev_arr = (ta_a == sstep);
         d2v pf_c2 = {0.0, 0.0}, pf_c7 = {0.0, 0.0};   // an arrival: {B, RN(1/B)}, {cap0, potc} of the arriving session's record ...
-        int pf_lut = -1;                              // ... and its efficiency-table id
+        d2v pf_d0 = {1.0, 1.0};                       // ... and its SessDyn: {transition_soc, charge efficiency},
+        i4v pf_d1 = {0, 0, -1, 0};                    //     {discharge efficiency, efficiency-table id, dictionary entry}
         i4v pf_tl = {0, 0, 0, 0};                     // a departure: {des (two words), next window} of the leaving session's tail entry
         if (__ballot(ev_dep || ev_arr) != 0ull) {   // (uniform)
             const unsigned sse = (ev_dep || ev_arr) ? (unsigned)s_ss[tid_l] : 0u;
             static_assert(offsetof(SessRec, B) == 40 && offsetof(SessRec, rB) == 48 && offsetof(SessRec, cap0) == 112 && offsetof(SessRec, potc) == 120 && sizeof(SessTail) == 16 &&
                           offsetof(SessTail, nt_arr) == 8, "SessRec / SessTail layout");
             pf_c2 = ldg32<d2v_a8>(S->rec, sse * (unsigned)sizeof(SessRec) + 40u); pf_c7 = ldg32<d2v>(S->rec, sse * (unsigned)sizeof(SessRec) + 112u);
-            pf_tl = ldg32<i4v>(S->tail, sse * 16u); pf_lut = ldg32<int>(S->ss_lut, sse * 4u);
+            pf_tl = ldg32<i4v>(S->tail, sse * 16u);
+            pf_d0 = ldg32<d2v>(S->sess_dyn, sse * 32u); pf_d1 = ldg32<i4v>(S->sess_dyn, sse * 32u + 16u);
         }
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
         PT_MARK(0)
@@ -393,17 +436,21 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 else if (i >= nchp) h = items[NS - 1 - (i - nchp)];
                 if (h >= 0) {
                     const double amps_h = s_amps[h];
-                    const int lut_id = ((s_dirty[h] >> 8) & 0xffff) - 1;
+                    const int dw_h = s_dirty[h];
+                    const int lut_id = ((dw_h >> 8) & LUTMASK) - 1;
                     // table entry and session record are independent loads: one memory round trip, not two.  The look-up
                     // is unconditional (clamped index); whether it applies is decided where it is used.
                     const int li = (lut_id >= 0) ? ev_lut_index(lut_id, amps_h) : -1;
                     double lut_raw = ldg32<double>(S->lut, (unsigned)max(li, 0) * 8u);
-                    const unsigned r8 = (unsigned)s_ss[h] * (unsigned)sizeof(SessRec);
+                    // full kernels: the operands of the car model from the dictionary (an L1 hit), transition_soc / efficiency from LDS
+                    const unsigned r8 = ((FULL && wa.dict) ? (unsigned)dw_h >> 20 : (unsigned)s_ss[h]) * (unsigned)sizeof(SessRec);
                     const double cap0 = s_cap[h], prev0 = s_prev[h];
                     const int cyc0 = s_cyc[h];
                     EvRes o;
                     if (i < nchp) {   // (uniform: the discharge items start on a wavefront boundary)
-                        const SessRec r = ldg32_rec_charge(S->rec, r8);
+                        SessRec r;
+                        if (FULL) { const double ts_h = s_ts[h], eta_h = s_etac[h]; r = ldg32_cls_charge(S->cls_rec, r8); r.ts = ts_h; r.eta_ch = eta_h; }
+                        else r = ldg32_rec_charge(S->rec, r8);
                         asm volatile("" : "+v"(lut_raw));
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_BSPLIT)
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -412,7 +459,9 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                         const double lutv = (li >= 0) ? lut_raw : 1.0 / 100.0;
                         o = ev_math_charge(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, sixty_over_dt, dt_over_60, pow2_dt, lut_id >= 0);
                     } else {
-                        const SessRec r = ldg32_rec_discharge(S->rec, r8);
+                        SessRec r;
+                        if (FULL) { const double eta_h = s_etad[h]; r = ldg32_cls_discharge(S->cls_rec, r8); r.eta_dis = eta_h; }
+                        else r = ldg32_rec_discharge(S->rec, r8);
                         asm volatile("" : "+v"(lut_raw));
                         const double lutv = (li >= 0) ? lut_raw : 1.0 / 100.0;
                         o = ev_math_discharge(r, lutv, amps_h, cap0, prev0, s_tot[h], cyc0, dtd, lut_id >= 0, S->rdt, S->dt_fdiv != 0);   // (fetched here, by the discharging wavefronts only: not kept across the step loop)
@@ -443,7 +492,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // prefetched registers are plain values from here on, so their later uses -- after this phase's stores, and
         // across the loop back-edge for the next action -- no longer cost a conservative vmcnt(0) drain
         asm volatile("" : "+v"(a_next), "+v"(pf_pch), "+v"(pf_pdis), "+v"(pf_tr), "+v"(pf_ob0), "+v"(pf_h0), "+v"(pf_h1));
-        asm volatile("" : "+v"(pf_c2), "+v"(pf_c7), "+v"(pf_tl), "+v"(pf_lut));
+        asm volatile("" : "+v"(pf_c2), "+v"(pf_c7), "+v"(pf_tl), "+v"(pf_d0), "+v"(pf_d1));
         bool occ_any = false;   // an EV on this port before or after the step
         if (valid) {
             double profit = 0.0, satpen = 0.0, pot = 0.0;
@@ -499,7 +548,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 if (departed) {   // the next session arrives right behind a departure of this very step (the reference's spawner leaves a
                                   // gap, replayed scenarios need not): its record was not the one prefetched
                     const unsigned r8 = (unsigned)ss_now * (unsigned)sizeof(SessRec);
-                    pf_c2 = ldg32<d2v_a8>(S->rec, r8 + 40u); pf_c7 = ldg32<d2v>(S->rec, r8 + 112u); pf_lut = ldg32<int>(S->ss_lut, (unsigned)ss_now * 4u);
+                    pf_c2 = ldg32<d2v_a8>(S->rec, r8 + 40u); pf_c7 = ldg32<d2v>(S->rec, r8 + 112u);
+                    pf_d0 = ldg32<d2v>(S->sess_dyn, (unsigned)ss_now * 32u); pf_d1 = ldg32<i4v>(S->sess_dyn, (unsigned)ss_now * 32u + 16u);
                 }
                 cap = pf_c7.x;
                 const double B = pf_c2.x;
@@ -508,11 +558,14 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 if (FULL) { r_bcap = B; r_potc = potc; r_rb = pf_c2.y; } else { s_bcap[tid_l] = B; s_potc[tid_l] = potc; }
                 s_abse[tid_l] = 0.0;
                 b_bcap = B; b_potc = potc; b_tot = 0.0;
-                const int lut_new = pf_lut;
+                const int lut_new = pf_d1.z;
                 stg32<d2v>(wa.lines, l64 + 48u, (d2v){B, potc});   // (the table id travels in s_dirty and reaches the line's head chunk in the epilogue)
+                // the attached EV's SessDyn next to its line: what the prologue of a later launch reads (every instantiation writes it)
+                stg32<d2v>(wa.port_dyn, (unsigned)g_l * 32u, pf_d0); stg32<i4v>(wa.port_dyn, (unsigned)g_l * 32u + 16u, pf_d1);
+                if (FULL) { s_ts[tid_l] = pf_d0.x; s_etac[tid_l] = pf_d0.y; s_etad[tid_l] = __hiloint2double(pf_d1.y, pf_d1.x); }
                 stg32<double>(PA(EV2G_PS_PENERGY), g8, 0.0);
                 stg32<double>(PA(EV2G_PS_PCURRENT), g8, 0.0);
-                s_dirty[tid_l] = (s_dirty[tid_l] & 3) | 1 | ((lut_new + 1) << 8);
+                s_dirty[tid_l] = (int)((unsigned)((s_dirty[tid_l] & 3) | 1 | ((lut_new + 1) << 8)) | ((FULL && wa.dict) ? (unsigned)pf_d1.w << 20 : 0u));
             }
             const bool occ_after = (ta <= sstep) && (sstep <= td);
             if (RK == 3 && occ_after && S->reward_kind >= 9) {   // (pst_)V2G_profitmaxV2: every connected EV (reward.py:173-195)
@@ -731,7 +784,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             const double n0 = ea0 + reward, n1 = ea1 + costs, n2 = ea2 + esum[4], n3 = ea3 + esum[5], n4 = ea4 + esum[6];
             ea[0] = n0; ea[1] = n1; ea[2] = n2; ea[3] = n3; ea[4] = n4; ea[5] = potn;
             if (RK == 3) ea[6] = ea5;
-            if (FULL) { stg32<double>(io.reward, e8, reward); stg32<uint8_t>(io.done, (unsigned)e_l, (sstep >= T) ? 1 : 0); }
+            if (FULL) { stg32<double>(rew_run, e8, reward); stg32<uint8_t>(done_run, (unsigned)e_l, (sstep >= T) ? 1 : 0); }
             if (!FULL && io.reward) stg32<double>(io.reward + (long long)kk * io.r_stride, e8, reward);
             if (!FULL && io.done) stg32<uint8_t>(io.done + (long long)kk * io.d_stride, (unsigned)e_l, (sstep >= T) ? 1 : 0);
             if (!FULL && S->x_cost)   // cost_function (rl_agent/cost.py:8-27); the overload weight is applied here when the reward does not carry it
@@ -786,6 +839,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         PT_MARK(5)
         PT_STEP_END(cntk[0] + cntk[1] == 0)
         t += 1;
+        if (STR) { obs_run += io.o_stride; rew_run += io.r_stride; done_run += io.d_stride; mask_run += io.m_stride; }
         // The next step's phase A rewrites stage[0,4..7] / s_amps of this wavefront's own lanes only after this
         // wavefront finished reading them (program order); other wavefronts never touch these slots outside phase B,
         // which is fenced by the two barriers.
@@ -794,7 +848,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     if (valid) {
         const int d = s_dirty[tid];
         const unsigned g8 = (unsigned)g * 8u;
-        if (d & 3) stg32<i4v>(wa.lines, l64, (i4v){FULL ? r_ta : s_ta[tid], FULL ? r_td : s_td[tid], s_ss[tid], ev2g_line_pack(s_cyc[tid], ((d >> 8) & 0xffff) - 1)});
+        if (d & 3) stg32<i4v>(wa.lines, l64, (i4v){FULL ? r_ta : s_ta[tid], FULL ? r_td : s_td[tid], s_ss[tid], ev2g_line_pack(s_cyc[tid], ((d >> 8) & LUTMASK) - 1)});
         if (d & 1) {
             stg32<d2v>(wa.lines, l64 + 16u, (d2v){s_cap[tid], s_tot[tid]});
             stg32<d2v>(wa.lines, l64 + 32u, (d2v){s_prev[tid], s_abse[tid]});

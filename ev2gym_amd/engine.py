@@ -263,7 +263,11 @@ class Engine:
         self._spec_checks_left -= 1
         if self._lib.ev2g_last_launch_specialisation(self._h) == 0:
             why = (self._lib.ev2g_last_launch_general_reason(self._h) or b"").decode()
-            if why and not why.startswith("EV2G_NO_FULL"):
+            # only for arguments a caller would change to get the fast instantiation back (a missing output, mismatched buffers, strides
+            # a narrow env cannot specialise on): modes that are legitimate API use -- auto_reset (the gym / vec-env default), a registered
+            # cost buffer, charger histories, a run-time reward -- are not performance mistakes and stay silent
+            quiet = ("EV2G_NO_FULL", "auto_reset", "a cost buffer", "EV2G_FLAG_LOG_CS_HISTORY", "the reward function")
+            if why and not why.startswith(quiet):
                 self._spec_checks_left = 0
                 warnings.warn(f"ev2gym_amd: this launch ran the GENERAL instantiation of {self.kernel_name} (slower than the full one): {why}", stacklevel=3)
 

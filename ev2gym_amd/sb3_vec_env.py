@@ -198,7 +198,11 @@ class DeviceReplayCollector:
         col.set_weights(new_weights)                # the learner's updated actor
 
     `engine` must not have float32 hand-over buffers registered (`ev2g_set_step_extras`): the collector's rows are the hand-over.
-    Arrays are torch tensors when torch is importable (PyTorch-ROCm is the SB3 side's tensor type), DeviceBuffers otherwise."""
+    Arrays are torch tensors when torch is importable (PyTorch-ROCm is the SB3 side's tensor type), DeviceBuffers otherwise.
+
+    Stream order: the engine works on ITS OWN stream (non-blocking unless it was created on torch's), the torch side on torch's current
+    stream.  The blocks are allocated uninitialised and torch's stream is drained once before the engine first writes them (nothing torch
+    queued can land behind the reset observation); `sample()` / `terminal_observation()` wait for the engine's stream before torch reads."""
 
     def __init__(self, engine, weights, lo: float, capacity_episodes: int = 2, precision: str = "bf16", offset_stride: Optional[int] = None, use_torch: Optional[bool] = None):
         from . import _abi
@@ -221,7 +225,7 @@ class DeviceReplayCollector:
         def alloc(shape, dtype):
             if self._torch is not None:
                 td = {np.float32: self._torch.float32, np.float64: self._torch.float64, np.uint8: self._torch.uint8}[dtype]
-                return self._torch.zeros(shape, dtype=td, device=f"cuda:{eng.device if hasattr(eng, 'device') else 0}")
+                return self._torch.empty(shape, dtype=td, device=f"cuda:{eng.device if hasattr(eng, 'device') else 0}")
             return eng.empty(shape, dtype)
         E, P, D, T = self.E, self.P, self.D, self.T
         self.obs = [alloc((T + 1, E, D), np.float32) for _ in range(self.cap)]
@@ -235,6 +239,8 @@ class DeviceReplayCollector:
         self.offset = 0
         self.offset_stride = self.E if offset_stride is None else int(offset_stride)
         self.episodes = 0
+        if self._torch is not None:
+            self._torch.cuda.synchronize()   # the caching allocator may hand out memory with work of torch's stream still queued on it
         eng.reset_f32(self.obs[0], self.offset)
 
     def set_weights(self, weights):
@@ -260,6 +266,7 @@ class DeviceReplayCollector:
         """[E, D] float32: the observation after the block's last step (SB3's infos[i]["terminal_observation"]) -- a device view of the block's
         last row with torch, a host copy of it otherwise."""
         if self._torch is not None:
+            self.eng.synchronize()   # (the engine's stream wrote the row; torch's stream reads it)
             return self.obs[block][self.T]
         return self.obs[block].to_host()[self.T]
 
@@ -268,6 +275,7 @@ class DeviceReplayCollector:
         if self._torch is None:
             raise RuntimeError("sample() gathers with torch; without it read the blocks directly (col.obs[b], col.actions[b], ...)")
         torch = self._torch
+        self.eng.synchronize()   # collect_episode() is asynchronous on the engine's stream; the gathers below run on torch's
         rng = rng or np.random.default_rng()
         blocks = [(self.head - 1 - i) % self.cap for i in range(self.filled)]
         bi = rng.integers(0, len(blocks), batch_size)

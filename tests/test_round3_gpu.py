@@ -301,7 +301,7 @@ def test_fast_path_specialisations_agree_bit_for_bit(case, monkeypatch):
     rk, sk = _abi.REWARD_KINDS[reward], _abi.STATE_KINDS[state]
 
     def run(env, strided, per_step):
-        for k in ("EV2G_NO_FULL", "EV2G_NO_WIDE"):
+        for k in ("EV2G_NO_FULL", "EV2G_NO_WIDE", "EV2G_NO_STRIDED", "EV2G_NO_DICT"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
@@ -343,9 +343,15 @@ def test_fast_path_specialisations_agree_bit_for_bit(case, monkeypatch):
 
     s_ref, ref = run(("EV2G_NO_FULL",), strided=False, per_step=True)    # general kernel, step by step: every step's outputs
     assert s_ref == 0
-    s_str, strided = run((), strided=True, per_step=False)               # strided outputs select the general kernel too
+    s_str, strided = run(("EV2G_NO_STRIDED",), strided=True, per_step=False)   # strided outputs on such a handle select the general kernel too
     assert s_str == 0
     same(ref, strided)
+    s_str3, strided3 = run((), strided=True, per_step=False)             # round 5: strided outputs keep the wide instantiation (3: running output pointers)
+    assert s_str3 == (3 if want == 2 else 0)
+    same(ref, strided3)
+    s_nd, nodict = run(("EV2G_NO_DICT",), strided=False, per_step=True)  # round 5: without the battery-maths dictionary (one ClsRec per session)
+    assert s_nd == want
+    same(ref, nodict)
     s_plain, plain = run((), strided=False, per_step=True)
     assert s_plain == want
     same(ref, plain)
@@ -539,7 +545,7 @@ def test_general_kernel_specialisation_agrees_bit_for_bit(C, R, monkeypatch):
 
 
 @pytest.mark.parametrize("workload,K", [("cfg2", 112), ("cfg3", 112), ("cfg4", 5)])
-def test_full_size_specialised_kernels_equal_the_general_ones(workload, K):
+def test_full_size_specialised_kernels_equal_the_general_ones(workload, K, monkeypatch):
     """BASELINE.json's full sizes: the instantiations the benchmark runs (fast path "full + wide", `ev2g_step_v2<1024, 1>`) against the general
     ones -- every env, every step, every output, bit for bit (a full grid, the XCD-aware group mapping, the hoisted 32-bit offsets near their
     largest values).  The general instantiations are held to the oracle at these sizes by tests/test_engine_gpu.py."""
@@ -553,7 +559,9 @@ def test_full_size_specialised_kernels_equal_the_general_ones(workload, K):
     E = wl["envs"]
     batch = generate_native(wl["gen"](E, 7))
     rk, sk = _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]]
+    monkeypatch.setenv("EV2G_NO_STRIDED", "1")   # (strided outputs -> the general instantiation on this handle)
     eng = Engine(batch, rk, sk, flags=_abi.FLAG_LOG_SOC)
+    monkeypatch.delenv("EV2G_NO_STRIDED")
     P, D, T = eng.P, eng.D, eng.T
     K = min(K, T)
     d_act = eng.empty((K, E, P))

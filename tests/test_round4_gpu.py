@@ -23,24 +23,47 @@ def _workload(name, E=None, seed=7):
 
 
 @pytest.mark.parametrize("workload", ["cfg2", "cfg3"])
-def test_benchmarked_launch_shape_at_full_size_equals_the_general_instantiation(workload):
+def test_benchmarked_launch_shape_at_full_size_equals_the_general_instantiation(workload, monkeypatch):
     """the launch the benchmark times -- ONE persistent 112-step launch of the full + wide instantiation with
-    step stride 0 at BASELINE's full size -- against the general instantiation (one launch, strided outputs; held to the oracle at these
-    sizes by tests/test_engine_gpu.py): last-step outputs, all 17 statistics of every env and the port state of sampled envs, bit for bit."""
+    step stride 0 at BASELINE's full size -- against the general instantiation (one launch, strided outputs on a handle loaded with
+    EV2G_NO_STRIDED; held to the oracle at these sizes by tests/test_engine_gpu.py): last-step outputs, all 17 statistics of every env and the
+    port state of sampled envs, bit for bit.  Round 5: the same launch with every output KEPT ([T,E,*] blocks, instantiation 3:
+    bench.py's `persistent_strided`) against the general one at EVERY step."""
     from ev2gym_amd import _abi
     from ev2gym_amd.engine import Engine
     wl, E, batch, rk, sk = _workload(workload)
+    monkeypatch.setenv("EV2G_NO_STRIDED", "1")
     eng = Engine(batch, rk, sk, flags=_abi.FLAG_LOG_SOC)
+    monkeypatch.delenv("EV2G_NO_STRIDED")
     P, D, T = eng.P, eng.D, eng.T
     acts = eng.empty((T, E, P)); eng.fill_uniform(acts, T * E * P, 321, wl["lo"], 1.0)
     sample = [0, 1, E // 3, E // 2 + 5, E - 2, E - 1]
-    # general instantiation: strided outputs select it
+    # general instantiation: strided outputs select it on this handle
     g_obs, g_rew, g_done, g_mask = eng.empty((T, E, D)), eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
     eng.reset()
     eng.step_n(T, acts, E * P, g_obs, E * D, g_rew, E, g_done, E, g_mask, E * P, auto_reset=False, persistent=True)
     assert eng.last_launch_specialisation == 0
-    ref = dict(obs=g_obs.to_host()[-1].copy(), rew=g_rew.to_host()[-1].copy(), done=g_done.to_host()[-1].copy(), mask=g_mask.to_host()[-1].copy(),
+    G_rew, G_done, G_mask = g_rew.to_host().copy(), g_done.to_host().copy(), g_mask.to_host().copy()
+    Gh = g_obs.to_host()
+    G_obs_rows = {t: Gh[t].copy() for t in (0, 1, T // 2, T - 2, T - 1)}
+    del Gh
+    ref = dict(obs=G_obs_rows[T - 1], rew=G_rew[-1], done=G_done[-1], mask=G_mask[-1],
                stats=eng.stats().copy(), peek=[eng.peek(e) for e in sample])
+    eng.check_faults()
+    eng.close()
+    # the same blocks through instantiation 3 (full + wide with running output pointers)
+    eng = Engine(batch, rk, sk, flags=_abi.FLAG_LOG_SOC)
+    acts = eng.empty((T, E, P)); eng.fill_uniform(acts, T * E * P, 321, wl["lo"], 1.0)
+    g_obs, g_rew, g_done, g_mask = eng.empty((T, E, D)), eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
+    eng.reset()
+    eng.step_n(T, acts, E * P, g_obs, E * D, g_rew, E, g_done, E, g_mask, E * P, auto_reset=False, persistent=True)
+    assert eng.last_launch_specialisation == 3
+    assert np.array_equal(g_rew.to_host(), G_rew) and np.array_equal(g_done.to_host(), G_done) and np.array_equal(g_mask.to_host(), G_mask)
+    o3 = g_obs.to_host()
+    for t, row in G_obs_rows.items():
+        assert np.array_equal(o3[t], row, equal_nan=True), f"obs[{t}]"
+    del o3
+    assert np.array_equal(eng.stats(), ref["stats"], equal_nan=True)
     g_obs.free(); g_mask.free()
     # the benchmark's launch: everything present, stride 0, one launch per episode
     obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
@@ -248,8 +271,15 @@ def test_a_launch_that_falls_off_the_full_instantiation_says_which_argument_did_
         warnings.simplefilter("error")
         eng.step_n(2, acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=True)   # qualifies: no warning
     assert eng.last_launch_specialisation == 2
-    with pytest.warns(UserWarning, match="GENERAL instantiation.*stride"):
+    with warnings.catch_warnings():   # round 5: strided outputs keep the specialisation on a wide env with the SoC log (instantiation 3)
+        warnings.simplefilter("error")
         eng.step_n(2, acts.at(2 * E * P), E * P, obs, E * D, rew, E, done, E, mask, E * P, auto_reset=False, persistent=True)
+    assert eng.last_launch_specialisation == 3
+    eng.close()
+    eng = Engine(pool, rk, sk, flags=0)   # ... without the SoC log they do not: the general instantiation, and the caller is told why
+    eng.reset()
+    with pytest.warns(UserWarning, match="GENERAL instantiation.*stride"):
+        eng.step_n(2, acts, E * P, obs, E * D, rew, E, done, E, mask, E * P, auto_reset=False, persistent=True)
     assert eng.last_launch_specialisation == 0
     eng.close()
     eng = Engine(pool, rk, sk, flags=_abi.FLAG_LOG_SOC)
