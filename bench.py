@@ -739,6 +739,27 @@ def main():
         else:   # reported, never fatal for the measurement
             c_gather = {"error": err or "rank 0 could not create a communicator id"}
 
+    # what makes an N > 1 line self-verifying (RCCL with more than one rank has never run on hardware available to the build): every rank
+    # reports the communicator it is in -- the C-ABI communicator's rank count, a hash of the unique id it was handed -- and a block of GLOBAL
+    # env ids travels through the same all-gather as the statistics: block r must hold rank r's ids, first to last
+    self_check = None
+    if multi:
+        import hashlib
+        env_ids = torch.arange(E, dtype=torch.int64, device=dev) + rank * E
+        all_ids = torch.empty((world * E,), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(all_ids, env_ids)
+        firsts, lasts = [int(all_ids[r * E].item()) for r in range(world)], [int(all_ids[(r + 1) * E - 1].item()) for r in range(world)]
+        mine = {"rank": rank, "local_rank": local_rank, "device": str(dev), "c_abi_comm_world_size": (eng.comm_world_size if hasattr(eng, "comm_world_size") else None),
+                "unique_id_sha1": (hashlib.sha1(ids[0]).hexdigest()[:12] if (c_gather is not None and ids[0] is not None) else None),
+                "first_env": rank * E, "last_env": (rank + 1) * E - 1}
+        per = [None] * world
+        dist.all_gather_object(per, mine)
+        sys.stderr.write(f"[bench rank {rank}] {json.dumps(mine)}\n")
+        self_check = {"per_rank": per, "gathered_first_env_of_block": firsts, "gathered_last_env_of_block": lasts,
+                      "rank_major_order_ok": firsts == [r * E for r in range(world)] and lasts == [(r + 1) * E - 1 for r in range(world)],
+                      "one_unique_id_everywhere": len({p_["unique_id_sha1"] for p_ in per}) == 1,
+                      "every_rank_sees_world": all(p_["c_abi_comm_world_size"] in (None, world) for p_ in per)}
+
     refill = None
     if actor is None and not stub and not args.no_rollout_record and not args.only_timed and args.workload != "cfg4":
         refill = refill_record(Engine, wl, rk, sk, local_rank, devx, E, rank, args, T)
@@ -795,6 +816,7 @@ def main():
         "rccl_ranks_seen": ranks_seen, "per_rank_env_steps_per_s": per_rank,
         "rccl_collectives_issued": (gath.collectives if gath is not None else 0),
         "c_abi_rccl_gather": c_gather,
+        "rccl_self_check": self_check,
     }
     if actor is not None and not args.only_timed:
         out["actor_kernel_times"] = actor_times

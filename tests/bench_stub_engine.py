@@ -56,6 +56,43 @@ class StubEngine:
     def check_faults(self):
         pass
 
+    # ---- the C-ABI's own statistics exchange (ev2g_comm_* / ev2g_gather_stats, csrc/ev2g_host.hip), restated over the process group the test
+    #      runs on: the same protocol -- one int per rank first, unequal shards refused on EVERY rank before any statistics row moves ----
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        return bytes(range(128))
+
+    def comm_init(self, unique_id, rank, world_size):
+        assert len(unique_id) == _abi.COMM_ID_BYTES
+        self._comm = (int(rank), int(world_size))
+        self._comm_checked = -1
+        self.comm_gathers = 0
+
+    @property
+    def comm_world_size(self):
+        return getattr(self, "_comm", (0, 0))[1]
+
+    def gather_stats(self, out=None):
+        import torch
+        import torch.distributed as dist
+        if not self.comm_world_size:
+            raise RuntimeError("ev2g_gather_stats: no communicator (call ev2g_comm_init on every rank first)")
+        world = self.comm_world_size
+        if self._comm_checked != self.E:
+            mine = torch.tensor([self.E], dtype=torch.int32)
+            counts = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(counts, mine)
+            for r, c in enumerate(counts):
+                if int(c.item()) != self.E:
+                    raise RuntimeError(f"ev2g_gather_stats: rank {r} steps {int(c.item())} envs, this rank {self.E} "
+                                       "(the gather needs equal shards; pad the batch or use torch's uneven gather)")
+            self._comm_checked = self.E
+        st = torch.from_numpy(np.nan_to_num(self.ora.stats()))
+        res = out if out is not None else torch.empty((world * self.E, _abi.N_STATS), dtype=torch.float64)
+        dist.all_gather_into_tensor(res, st.contiguous())
+        self.comm_gathers += 1
+        return res
+
     def synchronize(self):
         pass
 

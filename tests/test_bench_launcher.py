@@ -40,6 +40,13 @@ def test_bench_gpus_2_starts_its_own_ranks_and_reports_what_the_communicator_saw
     assert "STUB" in out["data"]
     for m, r in out["roofline_by_launch_mode"].items():
         assert 0 < r["frac"] < 1 and r["kernel"] == "cpu-oracle-stub"
+    # round 5: the line verifies itself -- every rank's view of the communicator, and global env ids through the statistics' all-gather
+    sc = out["rccl_self_check"]
+    assert sc["rank_major_order_ok"] and sc["one_unique_id_everywhere"] and sc["every_rank_sees_world"]
+    assert [p["rank"] for p in sc["per_rank"]] == [0, 1] and sc["gathered_first_env_of_block"] == [0, 4] and sc["gathered_last_env_of_block"] == [3, 7]
+    assert all(p["c_abi_comm_world_size"] == 2 and p["unique_id_sha1"] for p in sc["per_rank"])
+    cg = out["c_abi_rccl_gather"]   # the C-ABI gather's protocol (restated by the stand-in engine): same rows as torch's gather
+    assert cg["ranks"] == 2 and cg["rows"] == 8 and cg["equals_torch_all_gather"]
 
 
 @pytest.mark.timeout(600)

@@ -239,3 +239,60 @@ def test_bench_full_episode_pass_runs_the_same_number_of_episodes_on_every_rank(
     assert a0 == a1 and int(a0[0]) >= 3 and int(a0[1]) == int(a0[0]) + 2 == int(a0[2])   # + the warm-up and the timed single episode
     l0, l1 = [int(open(tmp_path / f"local_{r}.txt").read()) for r in range(2)]
     assert int(a0[0]) == max(l0, l1)
+
+
+def _refusal_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from bench_stub_engine import StubEngine
+    from ev2gym_amd import _abi
+    from ev2gym_amd.dist import gather_stats_tensor
+    from ev2gym_amd.scenario_gen import GenConfig, generate
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pool = generate(GenConfig.v2g_profit_plus_loads(8, 6, seed=500 + rank))
+    ids = [StubEngine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    res = {}
+    # unequal shards: rank r steps 3 + r envs -- every rank must refuse, none may be left waiting in a collective
+    eng = StubEngine(pool, 0, 0, n_active_envs=3 + rank)
+    eng.reset(offset=0)
+    eng.comm_init(ids[0], rank, world)
+    try:
+        eng.gather_stats()
+        res["unequal"] = "gathered"
+    except RuntimeError as ex:
+        res["unequal"] = str(ex)
+    dist.barrier()   # (reached by both ranks only if neither hangs above)
+    eng.close()
+    # equal shards: the same rows torch's gather delivers, rank-major
+    eng = StubEngine(pool, 0, 0, n_active_envs=4)
+    eng.reset(offset=0)
+    eng.comm_init(ids[0], rank, world)
+    got = eng.gather_stats()
+    want = gather_stats_tensor(torch.from_numpy(np.nan_to_num(eng.ora.stats())))
+    res["equal_ok"] = bool(torch.equal(got, want)) and tuple(got.shape) == (world * 4, _abi.N_STATS) and eng.comm_world_size == world
+    eng.close()
+    import json
+    with open(os.path.join(out_dir, f"refusal_{rank}.json"), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_c_abi_gather_protocol_refuses_unequal_shards_on_every_rank(tmp_path):
+    """ev2g_gather_stats (csrc/ev2g_host.hip) all-gathers the ranks' env counts before the statistics and
+    refuses unequal shards instead of writing rows to wrong offsets.  The stand-in engine restates that protocol over gloo (RCCL with more
+    than one rank has never run on hardware available to the build): with shards of 3 and 4 envs BOTH ranks get the error that names the
+    offending rank -- and both reach the barrier behind it --, with equal shards the rows equal torch's own gather."""
+    import json
+    import torch.multiprocessing as mp
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_refusal_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [json.load(open(tmp_path / f"refusal_{r}.json")) for r in range(2)]
+    assert "needs equal shards" in r0["unequal"] and "rank 1 steps 4 envs, this rank 3" in r0["unequal"], r0
+    assert "needs equal shards" in r1["unequal"] and "rank 0 steps 3 envs, this rank 4" in r1["unequal"], r1
+    assert r0["equal_ok"] and r1["equal_ok"]
