@@ -895,6 +895,7 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
             return fail(h, EV2G_ERR_ARG, "ev2g_step_n: a step stride is negative or reaches 4 GiB (unsupported by the fast-path kernel)");
         const V2P *pp = (const V2P *)h->d_v2p;
         const DevState &st = h->st;
+        const FusedArgs fa0{};
         const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.hist,
                           st.env_acc, s.cs_pack, (char *)st.line, h->d_step_tab, (char *)st.port_dyn, s.dict};
         // every float64 output present, no extras, no charger histories: the specialisation without their checks (not for the run-time rewards)
@@ -930,36 +931,36 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
     case SK * 4 + RK:                                                                                                       \
         if (full && RK != 3 && str3)                                                                                        \
             hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), false, 3>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
-                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
+                               h->stream, pp, io, t0, k, auto_reset, wa, fa0);                                                   \
         else if (full && RK != 3 && wide && f32io)                                                                          \
             hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), true, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
-                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
+                               h->stream, pp, io, t0, k, auto_reset, wa, fa0);                                                   \
         else if (full && RK != 3 && f32io)                                                                                  \
             hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), true, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
-                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
+                               h->stream, pp, io, t0, k, auto_reset, wa, fa0);                                                   \
         else if (full && RK != 3 && wide)                                                                                   \
             hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), false, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
-                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
+                               h->stream, pp, io, t0, k, auto_reset, wa, fa0);                                                   \
         else if (full && RK != 3)                                                                                           \
             hipLaunchKernelGGL((ev2g_step_wave<SK, (RK == 3 ? 0 : RK), false, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, \
-                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
+                               h->stream, pp, io, t0, k, auto_reset, wa, fa0);                                                   \
         else if (!io.actions)                                                                                               \
             hipLaunchKernelGGL((ev2g_step_wave<SK, RK, true>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes,       \
-                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
+                               h->stream, pp, io, t0, k, auto_reset, wa, fa0);                                                   \
         else                                                                                                                \
             hipLaunchKernelGGL((ev2g_step_wave<SK, RK, false>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes,      \
-                               h->stream, pp, io, t0, k, auto_reset, wa);                                                   \
+                               h->stream, pp, io, t0, k, auto_reset, wa, fa0);                                                   \
         break;
         switch (s.state_kind * 4 + std::min(s.reward_kind, 3)) {   // rewards beyond the three compiled-in ones share instantiation 3
 #ifdef EV2G_ONLY_00   /* tuning builds (tools/): one specialisation, seconds to compile */
             case 0:
-                if (str3) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 3>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
-                else if (wide && f32io) hipLaunchKernelGGL((ev2g_step_wave<0, 0, true, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
-                else if (full && f32io) hipLaunchKernelGGL((ev2g_step_wave<0, 0, true, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
-                else if (wide) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
-                else if (full) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
-                else if (!io.actions) hipLaunchKernelGGL((ev2g_step_wave<0, 0, true>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
-                else hipLaunchKernelGGL((ev2g_step_wave<0, 0, false>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa);
+                if (str3) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 3>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa, fa0);
+                else if (wide && f32io) hipLaunchKernelGGL((ev2g_step_wave<0, 0, true, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa, fa0);
+                else if (full && f32io) hipLaunchKernelGGL((ev2g_step_wave<0, 0, true, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa, fa0);
+                else if (wide) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 2>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa, fa0);
+                else if (full) hipLaunchKernelGGL((ev2g_step_wave<0, 0, false, 1>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa, fa0);
+                else if (!io.actions) hipLaunchKernelGGL((ev2g_step_wave<0, 0, true>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa, fa0);
+                else hipLaunchKernelGGL((ev2g_step_wave<0, 0, false>), dim3(s.n_groups), dim3(EV2G_WAVE_BLOCK), h->lds_bytes, h->stream, pp, io, t0, k, auto_reset, wa, fa0);
                 break;
             default: return fail(h, EV2G_ERR_ARG, "EV2G_ONLY_00 build: only the cfg2 specialisation exists");
 #else
@@ -1106,6 +1107,7 @@ struct ev2g_mlp {
     const void *fn_big = nullptr;
     size_t lds_big = 0;
     int rows_big = 0, threads_big = 0, big_from = 0;
+    int s16_ks1 = 0, s16_nt1 = 0, s16_nt2 = 0, s16_nt3 = 0, s16_nw = 0;   // the streaming kernel's fragment packing (0: another kernel's)
 };
 
 // the fixed-shape kernels exist for the layer widths of the shipped configs (obs 162 / 63 -> 400 -> 300 -> ports); anything else
@@ -1228,7 +1230,7 @@ int ev2g_mlp_create_ex(ev2g_handle *h, int d_in, int h1, int h2, int d_out, cons
     const bool f32 = precision != EV2G_MLP_BF16;
     const MlpS16Pick s16 = mlp_s16_for(d_in, h1, h2, d_out, precision == EV2G_MLP_BF16 ? 1 : (precision == EV2G_MLP_F32 ? 2 : 3));
     m->lds = s16.fn ? s16.lds : (f32 ? ev2g_mlp32_lds_bytes(d) : ev2g_mlp_lds_bytes(d));
-    if (s16.fn) { m->rows = EV2G_MLPS_ROWS; m->threads = s16.threads; }
+    if (s16.fn) { m->rows = EV2G_MLPS_ROWS; m->threads = s16.threads; m->s16_ks1 = s16.ks1; m->s16_nt1 = s16.nt1; m->s16_nt2 = s16.nt2; m->s16_nt3 = s16.nt3; m->s16_nw = s16.nw; }
     if (s16.fn && s16.nw == 1 && !std::getenv("EV2G_MLP_NO_BIG")) {
         if (s16.ks1 == 6 && s16.nt3 == 4) { m->fn_big = (const void *)ev2g_mlp3_s16<6, 25, 19, 4, 1, 4, 2>; m->lds_big = MlpS16<6, 25, 19, 4, 1, 4, 2>::lds_bytes; }
         else if (s16.ks1 == 2 && s16.nt3 == 2) { m->fn_big = (const void *)ev2g_mlp3_s16<2, 25, 19, 2, 1, 4, 2>; m->lds_big = MlpS16<2, 25, 19, 2, 1, 4, 2>::lds_bytes; }
@@ -1305,6 +1307,56 @@ int ev2g_mlp_debug_stamps(ev2g_handle *h, const ev2g_mlp *m, unsigned long long 
 }
 #endif
 
+// ---- one launch per rollout segment (round 5): ev2g_step_wave<.., 1024, true> evaluates the policy between the steps, inside the launch ----
+// Eligible: the fast path with one env per wavefront (33..64 ports: BASELINE configs[1] / configs[4]), a head-table state (V2G_profit_max_loads /
+// V2G_profit_max), one of the three compiled-in rewards, EV2G_FLAG_LOG_SOC, no extras beyond the float32 hand-over, and the bf16 policy in the
+// streaming kernel's 162 -> 400 -> 300 -> 64 packing.  Anything else (and EV2G_NO_FUSED=1) keeps the two launches per step.
+static bool fused_eligible(const ev2g_handle *h, const ev2g_mlp *m) {
+    const DevScn &s = h->scn;
+    return h->wave_path && s.P >= 33 && s.P <= 64 && s.state_kind != EV2G_STATE_PUBLIC_PST && std::min(s.reward_kind, 3) != 3 && (h->cfg.flags & EV2G_FLAG_LOG_SOC) &&
+           !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) && !h->extras.cost && !h->no_full && !h->no_wide && (s.D & 1) == 0 &&
+           s.P >= (s.state_kind == EV2G_STATE_V2G_PROFIT_MAX_LOADS ? 30 : 10) &&
+           m->s16_ks1 == 6 && m->s16_nt1 == 25 && m->s16_nt2 == 19 && m->s16_nt3 == 4 && m->s16_nw == 1 && !std::getenv("EV2G_NO_FUSED");
+}
+// k steps from the current one; obs0: the [E, D] float32 rows the first forward reads; obs / act / reward / done / mask: the rows of the segment's first
+// step with their step strides (elements; 0 = one row, overwritten)
+static int launch_fused(ev2g_handle *h, const ev2g_mlp *m, int k, const float *obs0, float *obs, long long o_stride, float *act, long long a_stride,
+                        double *reward, long long r_stride, uint8_t *done, long long d_stride, uint8_t *mask, long long m_stride) {
+    const DevScn &s = h->scn;
+    const DevState &st = h->st;
+    const long long lim = 1ll << 32;
+    if (o_stride * 4 >= lim || a_stride * 4 >= lim || r_stride * 8 >= lim || d_stride >= lim || m_stride >= lim || o_stride < 0 || a_stride < 0 || r_stride < 0 || d_stride < 0 || m_stride < 0)
+        return fail(h, EV2G_ERR_ARG, "ev2g_collect / ev2g_rollout: a step stride is negative or reaches 4 GiB");
+    StepIO io = make_io(h, nullptr, a_stride, nullptr, o_stride, reward, r_stride, done, d_stride, mask, m_stride, 0, 0);
+    io.act32 = act; io.obs32 = obs;
+    const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.hist, st.env_acc, s.cs_pack, (char *)st.line, h->d_step_tab, (char *)st.port_dyn, s.dict};
+    FusedArgs fa{};
+    fa.m = m->dev; fa.obs0 = obs0;
+    const V2P *pp = (const V2P *)h->d_v2p;
+    const size_t lds = ev2g_fused_lds_bytes();
+    const dim3 grid((s.E + 15) / 16), block(EV2G_FUSED_BLOCK);
+    const int t0 = h->current_step;
+#define EV2G_FUSED_CASE(SK, RK)                                                                                                            \
+    case SK * 4 + RK: {                                                                                                                    \
+        auto kfn = ev2g_step_wave<SK, RK, true, 2, EV2G_FUSED_BLOCK, true>;                                                                 \
+        static bool attr_set = false;                                                                                                      \
+        if (!attr_set) { HIPCHK(h, hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; } \
+        hipLaunchKernelGGL(kfn, grid, block, lds, h->stream, pp, io, t0, k, 0, wa, fa);                                                     \
+    } break;
+    switch (s.state_kind * 4 + std::min(s.reward_kind, 3)) {
+        EV2G_FUSED_CASE(0, 0) EV2G_FUSED_CASE(0, 1) EV2G_FUSED_CASE(0, 2)
+#ifndef EV2G_ONLY_00
+        EV2G_FUSED_CASE(2, 0) EV2G_FUSED_CASE(2, 1) EV2G_FUSED_CASE(2, 2)
+#endif
+        default: return fail(h, EV2G_ERR_STATE, "internal: no fused instantiation for this plugin pair");
+    }
+#undef EV2G_FUSED_CASE
+    HIPCHK(h, hipGetLastError());
+    h->last_spec = 4;
+    h->general_reason = "";
+    return EV2G_OK;
+}
+
 int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward, int64_t r_stride, uint8_t *done, int64_t d_stride,
                  uint8_t *mask, int64_t m_stride, int auto_reset) {
     if (!h || !h->loaded) return fail(h, EV2G_ERR_STATE, "ev2g_rollout: no scenarios loaded");
@@ -1338,6 +1390,11 @@ int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward,
     int rc = EV2G_OK;
     static const bool use_graphs = [] { const char *e = std::getenv("EV2G_ROLLOUT_GRAPHS"); return !(e && e[0] == '0'); }();
     const bool whole = h->current_step + k_steps <= h->T;   // no episode end inside the segment: nothing but kernel launches
+    if (whole && k_steps >= 1 && reward && done && mask && fused_eligible(h, m)) {   // ONE launch: the policy between the steps, inside it
+        rc = launch_fused(h, m, k_steps, x.obs_f32, x.obs_f32, 0, (float *)x.actions_f32, 0, reward, r_stride, done, d_stride, mask, m_stride);
+        if (rc) return rc;
+        h->current_step += k_steps;
+    } else
     if (use_graphs && whole && k_steps >= 4) {
         ev2g_handle::RolloutGraph *hit = nullptr;
         for (auto &g : h->rollout_graphs)
@@ -1394,6 +1451,12 @@ int ev2g_collect(ev2g_handle *h, const ev2g_mlp *m, int k_steps, const ev2g_tran
         return fail(h, EV2G_ERR_ARG, "ev2g_collect: this configuration steps through the registered float32 hand-over buffers: register them with "
                                      "ev2g_set_step_extras (observation step stride 0) first");
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    if (direct && k_steps >= 1 && fused_eligible(h, m)) {   // ONE launch for the segment: rows read and written in place, the policy inside the launch
+        const int rc = launch_fused(h, m, k_steps, tr->obs, tr->obs + ED, (long long)ED, tr->actions, (long long)EP, tr->reward, h->E, tr->done, h->E, tr->mask, (long long)EP);
+        if (rc) return rc;
+        h->current_step += k_steps;
+        k_steps = 0;
+    }
     for (int i = 0; i < k_steps; i++) {
         float *obs_i = tr->obs + (size_t)i * ED, *obs_n = obs_i + ED, *act_i = tr->actions + (size_t)i * EP;
         int rc;

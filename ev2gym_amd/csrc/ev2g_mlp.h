@@ -574,6 +574,81 @@ __global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *
     MLP_STAMP(7)
 }
 
+// ---- the same network as a DEVICE FUNCTION of a 16-wavefront workgroup that also steps the 16 envs whose rows these are (ev2g_step_wave<.., 1024,
+// true>, ev2g_step_wave.h; round 5: one launch per rollout segment instead of two per step).  Same tiles, same fragment packing, same MFMA chain per
+// tile (two accumulators by k-step parity, bias as the first one's initial value, ReLU / tanh epilogues) as ev2g_mlp3_s16: the actions are bit-identical
+// to that kernel's.  What differs is where things live: the input rows are already bf16 in LDS (the step kernel writes every observation column there
+// next to its global store), the actions also go to LDS (the step's phase A reads them), the hidden activations use LDS that the step leaves free
+// between two steps, and a wavefront holds one tile's fragments at a time (128 registers per lane with four wavefronts per SIMD).
+//   X [16][SX] bf16 -> H1 [16][SH1] -> H2 [16][SH2] -> act [16][64] float (LDS) + y rows (global, d_out floats each, rows < nr)
+template <int KS, int NT, int L, int WVS>
+__device__ __forceinline__ void ev2g_mlp_inline_layer(const MlpDev &m, const uint16_t *A, int sa, const uint4 *Wl /* + lane */, const float *bias, uint16_t *out, int so,
+                                                      float *act_lds, float *y, int nr, int wave, int lane) {
+    constexpr int MT = (NT + WVS - 1) / WVS;
+    const int brow = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+        const int tile = wave + WVS * i;
+        if (WVS * i + WVS - 1 < NT || tile < NT) {   // (uniform; a constant but for the last slot)
+            uint4 fr[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) fr[ks] = Wl[(unsigned)((tile * KS + ks) * 64)];
+            f32x4m acc0 = *(const f32x4m *)(bias + tile * 16 + kq * 4), acc1 = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                bf16x8 a, b;
+                __builtin_memcpy(&a, &fr[ks], 16);
+                const uint4 bw = *(const uint4 *)(A + brow * sa + ks * 32 + kq * 8);
+                __builtin_memcpy(&b, &bw, 16);
+                if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0, 0, 0, 0);
+            }
+            const f32x4m acc = acc0 + acc1;
+            const int col = tile * 16 + kq * 4;   // this lane: columns col .. col + 3 of env row `brow`
+            if (L < 2) {
+                const uint32_t lo = ev2g_pack_bf16(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f)), hi = ev2g_pack_bf16(fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+                *(uint2 *)(out + brow * so + col) = make_uint2(lo, hi);
+            } else {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { v[r] = ev2g_fast_tanh(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
+                *(float4 *)(act_lds + brow * 64 + col) = make_float4(v[0], v[1], v[2], v[3]);   // (NT3 <= 4: columns 0..63)
+                const int d_out = m.d_out;
+                if (brow < nr) {
+                    float *yr = y + (size_t)brow * d_out + col;
+                    if ((d_out & 1) == 0) {
+                        if (col + 1 < d_out) *(float2 *)yr = make_float2(v[0], v[1]);
+                        if (col + 3 < d_out) *(float2 *)(yr + 2) = make_float2(v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) if (col + r < d_out) yr[r] = v[r];
+                    }
+                }
+            }
+        }
+    }
+}
+// barrier that orders LDS traffic only (the global stores above need no ordering inside the workgroup)
+__device__ __forceinline__ void ev2g_mlp_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int KS1, int NT1, int NT2, int NT3, int WVS>
+__device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t *bufX, uint16_t *bufH1, uint16_t *bufH2, float *act_lds, float *y, int nr, int tid) {
+    typedef MlpS16<KS1, NT1, NT2, NT3, 1, 4, 1> C;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint4 *w1 = (const uint4 *)m.w1 + lane, *w2 = (const uint4 *)m.w2 + lane, *w3 = (const uint4 *)m.w3 + lane;
+    if (tid < 256) {   // columns no tile writes (the next layer's k-steps read them): zeros
+        const int pj = tid & 15, pr = tid >> 4;
+        constexpr int P1 = C::KS2 * 32 - NT1 * 16, P2 = C::KS3 * 32 - NT2 * 16;
+        if (pj < P1) bufH1[pr * C::SH1 + NT1 * 16 + pj] = 0;
+        if (pj < P2) bufH2[pr * C::SH2 + NT2 * 16 + pj] = 0;
+    }
+    ev2g_mlp_inline_layer<KS1, NT1, 0, WVS>(m, bufX, C::SX, w1, m.b1, bufH1, C::SH1, nullptr, nullptr, nr, wave, lane);
+    ev2g_mlp_lds_barrier();
+    ev2g_mlp_inline_layer<C::KS2, NT2, 1, WVS>(m, bufH1, C::SH1, w2, m.b1 + NT1 * 16, bufH2, C::SH2, nullptr, nullptr, nr, wave, lane);
+    ev2g_mlp_lds_barrier();
+    ev2g_mlp_inline_layer<C::KS3, NT3, 2, WVS>(m, bufH2, C::SH2, w3, m.b1 + (NT1 + NT2) * 16, nullptr, 0, act_lds, y, nr, wave, lane);
+    ev2g_mlp_lds_barrier();
+}
+
 __global__ void __launch_bounds__(EV2G_MLP_BLOCK) ev2g_mlp3_any(MlpDev m, const float *__restrict__ x, float *__restrict__ y, int n_rows) {
     extern __shared__ __attribute__((aligned(16))) uint16_t mlds[];
     const int sA = ev2g_mlp_lds_stride(m.k1 > m.n2 ? m.k1 : m.n2), sB = ev2g_mlp_lds_stride(m.n1);

@@ -14,15 +14,29 @@
 #pragma once
 #include <type_traits>
 #include "ev2g_step_v2.h"
+#include "ev2g_mlp.h"
 
 #ifndef EV2G_WAVE_BLOCK
 #define EV2G_WAVE_BLOCK 256
 #endif
 
-__host__ __device__ inline size_t ev2g_wave_lds_bytes(int envs_per_group) {
-    const size_t NS = EV2G_WAVE_BLOCK;
+__host__ __device__ inline size_t ev2g_wave_lds_bytes(int envs_per_group, int block = EV2G_WAVE_BLOCK) {
+    const size_t NS = (size_t)block;
     return sizeof(double) * (EV2G_NQ * (NS + 8) + 7 * NS + 7 * (size_t)envs_per_group + 4 * 64) + sizeof(int) * (6 * NS + 8);
 }
+// the fused actor + step instantiation (ACT, below): 16 envs and 16 wavefronts per workgroup, plus the policy's input rows (bf16) and its actions (float) in LDS
+#define EV2G_FUSED_BLOCK 1024
+#define EV2G_FUSED_SX 200     // MlpS16<6, ..>::SX: bf16 elements per observation row in LDS
+__host__ __device__ inline size_t ev2g_fused_lds_bytes() {
+    return ev2g_wave_lds_bytes(EV2G_FUSED_BLOCK / 64, EV2G_FUSED_BLOCK) + (size_t)16 * EV2G_FUSED_SX * 2 + (size_t)16 * 64 * 4;
+}
+// What the fused instantiation needs besides the step's own arguments: the policy, and the observation rows its first forward reads.
+// StepIO then carries the OUTPUT blocks: obs32 = the rows the steps write (row of the launch's first step; o_stride floats between steps, 0: one row
+// overwritten, and then obs0 == obs32), act32 = the action rows the policy writes (a_stride floats between steps), reward / done / mask with their strides.
+struct FusedArgs {
+    MlpDev m;
+    const float *obs0;
+};
 
 // Global accesses as  uniform base (an SGPR pair) + 32-bit unsigned BYTE offset (one VGPR):  the
 // `global_load/store v, v_off, s[base:base+1]` form.  Indexing a pointer with a (sign-extended) int instead makes every
@@ -122,18 +136,24 @@ struct WaveArgs {
 // FULLK = 3 (round 5) is FULLK = 2 for outputs with STEP STRIDES -- the [K, E, *] blocks of a persistent launch whose every observation, reward, done
 // flag and mask is kept (generate_trajectories.py:69-83 style use; a replay block): four running pointers advanced with scalar adds per step,
 // everything else as compiled-out as in 2.
-template <int SK, int RK, bool IO32, int FULLK = 0>
-__global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
-                                                                     int k_steps, int auto_reset, WaveArgs wa) {
+// ACT (round 5; BLOCK = 1024, FULLK = 2, IO32): the policy network (FusedArgs::m, obs -> 400 -> 300 -> ports on the bf16 matrix cores) is evaluated INSIDE
+// the launch, between the steps, by the workgroup that steps the 16 envs whose rows it reads: one launch per rollout segment of k steps (ev2g_collect /
+// ev2g_rollout) instead of two per step -- no kernel boundary, so no cold start of either kernel, the port state stays in LDS across the segment
+// like in any persistent launch, observations reach the policy and actions reach the step through LDS, and the weights are streamed once per CU and step.
+// The outputs (observation / action / reward / done / mask rows of every step) go to the caller's blocks through running pointers.
+template <int SK, int RK, bool IO32, int FULLK = 0, int BLOCK = EV2G_WAVE_BLOCK, bool ACT = false>
+__global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
+                                                           int k_steps, int auto_reset, WaveArgs wa, FusedArgs fa) {
     extern __shared__ double lds[];
-    constexpr bool FULL = FULLK >= 1, WIDE = FULLK >= 2, STR = FULLK >= 3;
+    static_assert(!ACT || (IO32 && FULLK == 2 && BLOCK == EV2G_FUSED_BLOCK && SK != 1), "the fused actor + step instantiation");
+    constexpr bool FULL = FULLK >= 1, WIDE = FULLK >= 2, STR = FULLK >= 3 || ACT;
     constexpr bool F64 = FULL && !IO32, F32 = FULL && IO32;   // full with float64 actions in / observations out, or with the float32 hand-over
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
     const unsigned long long pt_k0 = __builtin_readcyclecounter();   // slot 7 := prologue, slot 6 := epilogue (tools/phase_timing.py --outer)
 #endif
     typedef const V2P __attribute__((address_space(4))) *ParamPtr;
     ParamPtr S = (ParamPtr)(unsigned long long)params;
-    constexpr int NS = EV2G_WAVE_BLOCK;
+    constexpr int NS = BLOCK;
     constexpr int RS = NS + 8;   // stage row stride: +16 banks per row, so the 8 rows one reduction read touches spread over all banks
     const int P = wa.P, T = wa.T, E = wa.E, D = wa.D, M = wa.M;
     int off = io.scn_off;   // scenario-pool window: env e runs scenario (e + off) mod M
@@ -145,7 +165,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     const gptr env_acc = (gptr)wa.env_acc;
 #define PA(k) (slabP + PS8 * (unsigned long long)(k))
     const int EPW = 64 / P;   // envs per wavefront
-    const int G = (EV2G_WAVE_BLOCK / 64) * EPW;    // envs per workgroup
+    const int G = (BLOCK / 64) * EPW;    // envs per workgroup
     int grp;
     {   // XCD-aware mapping: workgroup b runs on XCD b % 8; give each XCD a contiguous range of env groups
         const int nb = gridDim.x, b = blockIdx.x, per = nb >> 3;
@@ -167,6 +187,13 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     // s_dirty its dictionary entry (bits 8..19 the efficiency-table id + 1: a full kernel needs n_lut <= 4094, checked by the host)
     double *s_ts = s_bcap, *s_etac = s_potc, *s_etad = (double *)s_ta;
     constexpr int LUTMASK = FULL ? 0xfff : 0xffff;
+    // ACT: the policy's input rows (bf16; env w of the workgroup = wavefront w = row w) and its actions behind the step's own LDS; its hidden
+    // activations in the staging rows, which are dead between the end of a step and the next phase A (idle lanes re-zero their slots afterwards)
+    typedef MlpS16<6, 25, 19, 4, 1, 4, 1> MC;
+    uint16_t *bufX = (uint16_t *)(cnt + 8);
+    float *act_lds = (float *)(bufX + 16 * EV2G_FUSED_SX);
+    uint16_t *bufH1 = (uint16_t *)stage, *bufH2 = bufH1 + 16 * MC::SH1;
+    static_assert(EV2G_FUSED_SX == MC::SX && 16 * (MC::SH1 + MC::SH2) * 2 <= EV2G_NQ * (EV2G_FUSED_BLOCK + 8) * 8, "policy buffers");
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const bool log_soc = WIDE ? true : (S->soc_log != nullptr);
     const bool log_cs = FULL ? false : (S->cs_profits != nullptr);   // EV2G_FLAG_LOG_CS_HISTORY: charger-level accumulators and histories (ev2gym_env.py:533-535)
@@ -208,6 +235,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const d2v k_max = ldg32<d2v>(wa.cs_pack, c8 * 6u);   // (imax, |dmax|) of this lane's charger
         d2v k_min = {0.0, 0.0}, k_pow = {0.0, 0.0};            // gates and clamps, staged in LDS by the first P lanes of the workgroup
         if (tid < 64) { k_min = ldg32<d2v>(wa.cs_pack, cp8 * 6u + 16u); k_pow = ldg32<d2v>(wa.cs_pack, cp8 * 6u + 32u); }   // (wavefront 0 only)
+        if (ACT) a_next = 0.0;   // (the policy runs inside the launch: its actions arrive through LDS)
+        else
         a_next = IO32 ? (double)ldg32<float>(io.act32 + (long long)io.step0 * io.a_stride, (unsigned)(valid ? g : e0 * P) * 4u)
                       : ldg32<double>(io.actions, (unsigned)(valid ? g : e0 * P) * 8u);
         double l_pot = ldg32<double>(hist, ((ec * (unsigned)T + (unsigned)min(t, T - 1)) * 3u + 1u) * 8u);
@@ -258,6 +287,18 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     }
     if (tid < 4) cnt[tid] = 0;
     for (int k = 0; k < EV2G_NQ; k++) stage[k * RS + tid] = 0.0;
+    if (ACT) {   // the observation the first forward reads (the reset observation, or the last step's of an earlier segment): this wavefront's env row -> bf16
+        const bool env_ok = (e0 + wv) < E;   // (one env per wavefront)
+        const float *xr = fa.obs0 + (long long)(env_ok ? e0 + wv : e0) * D;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int c = 2 * lane + 128 * j;
+            float2 v = make_float2(0.f, 0.f);
+            if (env_ok && c + 1 < D) v = *(const float2 *)(xr + c);   // (D even on this path: 22 + 40 + 2 P, 22 + 2 P)
+            else if (env_ok && c < D) v.x = xr[c];
+            if (c < EV2G_FUSED_SX) *(uint32_t *)(bufX + wv * EV2G_FUSED_SX + c) = ev2g_pack_bf16(v.x, v.y);   // columns D .. 199: zeros (the k-steps' padding)
+        }
+    }
     __syncthreads();
 
     // FULL kernels have registers to spare (no extras, no second head pair): what the step loop otherwise re-derives every step with
@@ -265,9 +306,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
     // and its places in the observation -- is computed once and kept
     unsigned hb_step = 0, hb_head = 0, hb_obs_port = 0, hb_obs_env = 0;
     const double *act_run = io.actions;   // the actions of the step in work
-    const float *act32_run = F32 ? io.act32 + (long long)io.step0 * io.a_stride : nullptr;
+    const float *act32_run = (F32 && !ACT) ? io.act32 + (long long)io.step0 * io.a_stride : nullptr;
     double *obs_run = io.obs, *rew_run = io.reward;   // the outputs of the step in work (STR: advanced by their step strides; else the launch's one row)
     uint8_t *done_run = io.done, *mask_run = io.mask;
+    float *obs32_run = io.obs32, *act_out = ACT ? const_cast<float *>(io.act32) + (long long)e0 * P : nullptr;   // (ACT: the rows the policy writes, this workgroup's first env)
     constexpr unsigned OB = F32 ? 4u : 8u;    // bytes per observation element the full kernel writes
     if (FULL) {
         const int scn0 = ev2g_scn(valid ? e : e0, off, M);
@@ -313,7 +355,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             t = 0;
         }
         double *obs = F64 ? obs_run : ((!FULL && io.obs) ? io.obs + (long long)kk * io.o_stride : nullptr);       // uniform bases (scalar arithmetic)
-        float *obs32 = F32 ? io.obs32 : ((!FULL && S->x_obs32) ? (float *)S->x_obs32 + (long long)(io.step0 + kk) * S->x_o32_stride : nullptr);
+        float *obs32 = F32 ? obs32_run : ((!FULL && S->x_obs32) ? (float *)S->x_obs32 + (long long)(io.step0 + kk) * S->x_o32_stride : nullptr);
         uint8_t *mask = FULL ? mask_run : (io.mask ? io.mask + (long long)kk * io.m_stride : nullptr);
         const int sstep = t + 1;
         const bool last_step = (kk == k_steps - 1) || (!FULL && sstep >= T && !auto_reset);
@@ -322,7 +364,21 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         // before, which a busy step closes with a barrier and a quiet step leaves at zero
         if (tid_l < 2) cnt[2 * ((kk + 1) & 1) + tid_l] = 0;
 
-        const double a_cur = a_next;   // this step's action; the prefetch below replaces a_next by the next step's
+        double a_cur = a_next;   // this step's action; the prefetch below replaces a_next by the next step's
+        if (ACT) {
+            // ---- the policy, on the 16 observation rows of this workgroup's envs (ev2g_mlp3_inline, ev2g_mlp.h) ----
+            // first barrier: every wavefront's observation columns of the step before (or the prologue's rows) are in bufX, and nobody
+            // still reads the staging rows the hidden activations are about to use
+            lds_barrier();
+            ev2g_mlp3_inline<6, 25, 19, 4, BLOCK / 64>(fa.m, bufX, bufH1, bufH2, act_lds, act_out, min(16, E - e0), tid_l);   // (ends with a barrier: the actions are in LDS)
+            act_out += io.a_stride;
+            a_cur = valid ? (double)act_lds[wv * 64 + q_l] : 0.0;
+            // the staging slots of idle lanes must read as +0.0 in the per-env reduction (the lanes behind an env's last port never write them)
+            if (!valid) {
+#pragma unroll
+                for (int k = 0; k < EV2G_NQ; k++) stage[k * RS + tid_l] = 0.0;
+            }
+        }
         // ---- prefetch what the rest of this step needs (collected before the stores of phase C) ----
         // Every prefetch is ONE unconditional load from a clamped (always valid) address; the conditions are applied
         // where the value is consumed.  A load inside a divergent branch whose result merges with a default makes the
@@ -330,7 +386,8 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         const bool more = (kk + 1 < k_steps) && (FULL || sstep < T || auto_reset);
         const int ec = valid ? e_l : e0;   // clamped env for idle lanes
         const int gc = valid ? g_l : e0 * P;
-        if (F64) {   // a running pointer instead of a 64-bit scalar product per step
+        if (ACT) {
+        } else if (F64) {   // a running pointer instead of a 64-bit scalar product per step
             a_next = ldg32_nt<double>(act_run + (more ? io.a_stride : 0), (unsigned)gc * 8u);
             act_run += io.a_stride;
         } else if (F32) {
@@ -430,7 +487,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         __builtin_amdgcn_s_setprio(3);
         {
             const int nchp = (nch + 63) & ~63;
-            for (int i = tid_l; i < nchp + ndis; i += EV2G_WAVE_BLOCK) {
+            for (int i = tid_l; i < nchp + ndis; i += BLOCK) {
                 int h = -1;
                 if (i < nch) h = items[i];
                 else if (i >= nchp) h = items[NS - 1 - (i - nchp)];
@@ -594,6 +651,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
                 const unsigned o4 = WIDE ? hb_obs_port : (FULL ? hb_obs_env + ocol_l * 4u : (unsigned)(e_l * D + ocol) * 4u);
                 if (SK == 1) { stg32<float>(obs32, o4, (float)o0); stg32<float>(obs32, o4 + 4u, (float)o1); stg32<float>(obs32, o4 + 8u, (float)o2); }
                 else stg32<f2v>(obs32, o4, (f2v){(float)o0, (float)o1});
+                if (ACT) *(uint32_t *)(bufX + wv * EV2G_FUSED_SX + ocol_l) = ev2g_pack_bf16((float)o0, (float)o1);   // the policy's copy of the same two columns
             }
             if (log_cs) {   // cs_power / cs_current of the step (ev2gym_env.py:533-535) and the chargers' current_power_output / current_total_amps
                 const double pw = occ ? stage[0 * RS + tid_l] : 0.0, cur = occ ? b_cur : 0.0;
@@ -807,6 +865,10 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
             } else {
                 if (q_l == 0) stg32<f2v>(obs32, o4, (f2v){(float)sstep, (float)usage});
                 if (q_l < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)q_l * 8u, (f2v){(float)pf_h0.x, (float)pf_h0.y});
+                if (ACT) {
+                    if (q_l == 0) *(uint32_t *)(bufX + wv * EV2G_FUSED_SX) = ev2g_pack_bf16((float)sstep, (float)usage);
+                    if (q_l < NPAIR) *(uint32_t *)(bufX + wv * EV2G_FUSED_SX + 2 + 2 * q_l) = ev2g_pack_bf16((float)pf_h0.x, (float)pf_h0.y);
+                }
                 if (!WIDE) {
                     if (q_l + P < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)(q_l + P) * 8u, (f2v){(float)pf_h1.x, (float)pf_h1.y});
                     const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;
@@ -840,6 +902,7 @@ __global__ void __launch_bounds__(EV2G_WAVE_BLOCK, 4) ev2g_step_wave(const V2P *
         PT_STEP_END(cntk[0] + cntk[1] == 0)
         t += 1;
         if (STR) { obs_run += io.o_stride; rew_run += io.r_stride; done_run += io.d_stride; mask_run += io.m_stride; }
+        if (ACT) obs32_run += io.o_stride;
         // The next step's phase A rewrites stage[0,4..7] / s_amps of this wavefront's own lanes only after this
         // wavefront finished reading them (program order); other wavefronts never touch these slots outside phase B,
         // which is fenced by the two barriers.
