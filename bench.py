@@ -239,17 +239,24 @@ def rollout_record(Engine, batch, rk, sk, local_rank, devx, E, lo, rank, args, T
             eng.synchronize()
             spent += time.perf_counter() - t0
             n += 2 * T
+        loop.reset()   # one whole episode as ONE rollout segment: the kernel time per step of whatever ev2g_rollout launches (round 5: one fused launch)
+        eng.rollout(actor.mlp, T, rew, 0, done, 0, mask, 0)
+        seg_us, seg_spec = eng.last_step_n_kernel_ms() * 1e3 / T, eng.last_launch_specialisation
         loop.reset()   # HIP events around a train of 64 single-step launches fed by the actor's action buffer (one event pair per train)
         eng.step_n(64, None, 0, None, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=False)
         step_us = eng.last_step_n_kernel_ms() * 1e3 / 64
         actor_us = actor.forward_train_us(200)
         eng.check_faults()
-        return {"env_steps_per_s_per_gpu": E * n / spent, "us_per_step_wall": spent / n * 1e6, "step_kernel_us": step_us,
-                "actor_kernel_us": actor_us, "step_kernel": eng.kernel_name,
+        return {"env_steps_per_s_per_gpu": E * n / spent, "us_per_step_wall": spent / n * 1e6,
+                "fused_launch": seg_spec == 4, "launches_per_segment": 1 if seg_spec == 4 else "2 per step", "segment_kernel_us_per_step": seg_us,
+                "segment_roofline_frac_env_bytes_only": bytes_env_step * E / (seg_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                "step_kernel_us": step_us, "actor_kernel_us": actor_us, "step_kernel": eng.kernel_name,
                 "step_kernel_roofline_frac": bytes_env_step * E / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                 "actor": actor.describe, "steps_timed": n,
-                "note": "single-step launches with the policy between steps (the RL-loop mode); kernel times: HIP events around "
-                        "single-step env launches / a back-to-back train of 200 actor forwards"}
+                "note": "the policy between steps (the RL-loop mode).  Round 5: ev2g_rollout issues ONE launch per segment -- the policy runs inside the "
+                        "step kernel's launch (ev2g_step_wave<.., 1024, true>) -- where the shape is eligible (`fused_launch`); `segment_kernel_us_per_step` is that "
+                        "launch by HIP events.  step_kernel_us / actor_kernel_us: the two kernels of the unfused chain (EV2G_NO_FUSED=1, foreign policies), HIP "
+                        "events around single-step env launches / a back-to-back train of 200 actor forwards"}
     finally:
         eng.close()
 

@@ -56,7 +56,7 @@ class FusedMLPActor:
             self.obs32, self.act32 = eng.empty((E, D), np.float32), eng.empty((E, P), np.float32)
         eng.set_extras(obs_f32=self.obs32, obs_f32_stride=0, actions_f32=self.act32)
         self.describe = (f"fused MLP {D}->400->300->{P} tanh: one kernel per forward ({'bf16 operands' if precision == 'bf16' else ('float32 weights as two bf16 terms' if precision in ('fp32', 'f32') else 'float32 weights as three bf16 terms')} on the bf16 matrix cores, fp32 accumulate), float32 "
-                         "obs/action hand-over, actor + step enqueued by one C call per segment (ev2g_rollout)")
+                         "obs/action hand-over, one C call per segment (ev2g_rollout: ONE launch with the policy inside the step kernel's launch where the shape is eligible, else actor + step launches)")
 
     def run(self, loop, k):
         loop.eng.rollout(self.mlp, k, loop.rew, 0, loop.done, 0, loop.mask, 0, auto_reset=0)

@@ -581,71 +581,97 @@ __global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *
 // next to its global store), the actions also go to LDS (the step's phase A reads them), the hidden activations use LDS that the step leaves free
 // between two steps, and a wavefront holds one tile's fragments at a time (128 registers per lane with four wavefronts per SIMD).
 //   X [16][SX] bf16 -> H1 [16][SH1] -> H2 [16][SH2] -> act [16][64] float (LDS) + y rows (global, d_out floats each, rows < nr)
-template <int KS, int NT, int L, int WVS>
-__device__ __forceinline__ void ev2g_mlp_inline_layer(const MlpDev &m, const uint16_t *A, int sa, const uint4 *Wl /* + lane */, const float *bias, uint16_t *out, int so,
-                                                      float *act_lds, float *y, int nr, int wave, int lane) {
-    constexpr int MT = (NT + WVS - 1) / WVS;
-    const int brow = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < MT; i++) {
-        const int tile = wave + WVS * i;
-        if (WVS * i + WVS - 1 < NT || tile < NT) {   // (uniform; a constant but for the last slot)
-            uint4 fr[KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++) fr[ks] = Wl[(unsigned)((tile * KS + ks) * 64)];
-            f32x4m acc0 = *(const f32x4m *)(bias + tile * 16 + kq * 4), acc1 = f32x4m{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-                bf16x8 a, b;
-                __builtin_memcpy(&a, &fr[ks], 16);
-                const uint4 bw = *(const uint4 *)(A + brow * sa + ks * 32 + kq * 8);
-                __builtin_memcpy(&b, &bw, 16);
-                if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1, 0, 0, 0);
-                else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0, 0, 0, 0);
-            }
-            const f32x4m acc = acc0 + acc1;
-            const int col = tile * 16 + kq * 4;   // this lane: columns col .. col + 3 of env row `brow`
-            if (L < 2) {
-                const uint32_t lo = ev2g_pack_bf16(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f)), hi = ev2g_pack_bf16(fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
-                *(uint2 *)(out + brow * so + col) = make_uint2(lo, hi);
-            } else {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) { v[r] = ev2g_fast_tanh(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
-                *(float4 *)(act_lds + brow * 64 + col) = make_float4(v[0], v[1], v[2], v[3]);   // (NT3 <= 4: columns 0..63)
-                const int d_out = m.d_out;
-                if (brow < nr) {
-                    float *yr = y + (size_t)brow * d_out + col;
-                    if ((d_out & 1) == 0) {
-                        if (col + 1 < d_out) *(float2 *)yr = make_float2(v[0], v[1]);
-                        if (col + 3 < d_out) *(float2 *)(yr + 2) = make_float2(v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) if (col + r < d_out) yr[r] = v[r];
-                    }
-                }
-            }
-        }
-    }
-}
-// barrier that orders LDS traffic only (the global stores above need no ordering inside the workgroup)
+// barrier that orders LDS traffic only (the weight requests in flight and the action stores need no ordering inside the workgroup)
 __device__ __forceinline__ void ev2g_mlp_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-template <int KS1, int NT1, int NT2, int NT3, int WVS>
-__device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t *bufX, uint16_t *bufH1, uint16_t *bufH2, float *act_lds, float *y, int nr, int tid) {
+// Every wavefront walks ONE static sequence of weight fragments -- its tiles of layer 1, of layer 2, of layer 3 -- through a ring of RING register
+// slots: the head of the sequence is requested before the first barrier, fragment s + RING the moment fragment s has been consumed, across tile and
+// layer boundaries and barriers (weights do not depend on activations), so the CU's vector-memory port works from the first cycle on and only the
+// compute waits (the scheme of ev2g_mlp3_s16; a wavefront here holds 13 fragments instead of 26).  `act` rows are `as` floats apart.
+template <int KS1, int NT1, int NT2, int NT3, int WVS, int RING>
+__device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t *bufX, uint16_t *bufH1, uint16_t *bufH2, const float *lb, float *act, int as, float *y, int nr, int tid) {
     typedef MlpS16<KS1, NT1, NT2, NT3, 1, 4, 1> C;
+    constexpr int KS2 = C::KS2, KS3 = C::KS3;
+    constexpr int MT1 = (NT1 + WVS - 1) / WVS, MT2 = (NT2 + WVS - 1) / WVS, MT3 = (NT3 + WVS - 1) / WVS;
+    constexpr int S1 = MT1 * KS1, S2 = MT2 * KS2, S3 = MT3 * KS3, STOT = S1 + S2 + S3;
     const int lane = tid & 63, wave = tid >> 6;
     const uint4 *w1 = (const uint4 *)m.w1 + lane, *w2 = (const uint4 *)m.w2 + lane, *w3 = (const uint4 *)m.w3 + lane;
+    uint4 ring[RING];
+    auto request = [&](int seq) __attribute__((always_inline)) {   // (seq is a constant wherever this is called, after unrolling)
+        if (seq >= STOT) return;
+        const int L = seq < S1 ? 0 : (seq < S1 + S2 ? 1 : 2);
+        const int r = seq - (L == 0 ? 0 : (L == 1 ? S1 : S1 + S2));
+        const int KS = L == 0 ? KS1 : (L == 1 ? KS2 : KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3);
+        const int i = r / KS, ks = r - i * KS;
+        const uint4 *w = L == 0 ? w1 : (L == 1 ? w2 : w3);
+        if (WVS * i + WVS - 1 < NT || wave + WVS * i < NT) ring[seq % RING] = w[(unsigned)(((wave + WVS * i) * KS + ks) * 64)];
+    };
+    // (requesting the head of the sequence a phase EARLIER in the step kernel -- behind phase E, D or C of the step before -- was tried: the ring then
+    // lives across the step loop's back edge and the register allocator spills 40..119 registers)
+#pragma unroll
+    for (int sq = 0; sq < RING; sq++) request(sq);
+    // first barrier: every wavefront's observation columns of the step before (or the prologue's rows) are in bufX, and nobody still reads the
+    // staging rows the hidden activations are about to use
+    ev2g_mlp_lds_barrier();
     if (tid < 256) {   // columns no tile writes (the next layer's k-steps read them): zeros
         const int pj = tid & 15, pr = tid >> 4;
-        constexpr int P1 = C::KS2 * 32 - NT1 * 16, P2 = C::KS3 * 32 - NT2 * 16;
+        constexpr int P1 = KS2 * 32 - NT1 * 16, P2 = KS3 * 32 - NT2 * 16;
         if (pj < P1) bufH1[pr * C::SH1 + NT1 * 16 + pj] = 0;
         if (pj < P2) bufH2[pr * C::SH2 + NT2 * 16 + pj] = 0;
     }
-    ev2g_mlp_inline_layer<KS1, NT1, 0, WVS>(m, bufX, C::SX, w1, m.b1, bufH1, C::SH1, nullptr, nullptr, nr, wave, lane);
+    const int brow = lane & 15, kq = lane >> 4;
+    auto layer = [&](auto Lc, const uint16_t *A, int sa, const float *bias, uint16_t *out, int so) __attribute__((always_inline)) {
+        constexpr int L = decltype(Lc)::value;
+        constexpr int KS = L == 0 ? KS1 : (L == 1 ? KS2 : KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3), MT = (NT + WVS - 1) / WVS;
+        constexpr int base = L == 0 ? 0 : (L == 1 ? S1 : S1 + S2);
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const int tile = wave + WVS * i;
+            if (WVS * i + WVS - 1 < NT || tile < NT) {   // (uniform; a constant but for the last slot)
+                f32x4m acc0 = *(const f32x4m *)(bias + tile * 16 + kq * 4), acc1 = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const int sq = base + i * KS + ks;
+                    bf16x8 a, b;
+                    __builtin_memcpy(&a, &ring[sq % RING], 16);
+                    const uint4 bw = *(const uint4 *)(A + brow * sa + ks * 32 + kq * 8);
+                    __builtin_memcpy(&b, &bw, 16);
+                    if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0, 0, 0, 0);
+                    request(sq + RING);   // this slot is free again
+                }
+                const f32x4m acc = acc0 + acc1;
+                const int col = tile * 16 + kq * 4;   // this lane: columns col .. col + 3 of env row `brow`
+                if (L < 2) {
+                    const uint32_t lo = ev2g_pack_bf16(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f)), hi = ev2g_pack_bf16(fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+                    *(uint2 *)(out + brow * so + col) = make_uint2(lo, hi);
+                } else {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { v[r] = ev2g_fast_tanh(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
+                    *(float4 *)(act + brow * as + col) = make_float4(v[0], v[1], v[2], v[3]);   // (NT3 <= 4: columns 0..63)
+                    const int d_out = m.d_out;
+                    if (brow < nr) {
+                        float *yr = y + (size_t)brow * d_out + col;
+                        if ((d_out & 1) == 0) {
+                            if (col + 1 < d_out) *(float2 *)yr = make_float2(v[0], v[1]);
+                            if (col + 3 < d_out) *(float2 *)(yr + 2) = make_float2(v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) if (col + r < d_out) yr[r] = v[r];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < KS; u++) request(base + i * KS + u + RING);   // no tile in this slot: the sequence moves on all the same
+            }
+        }
+    };
+    layer(std::integral_constant<int, 0>{}, bufX, C::SX, lb, bufH1, C::SH1);
     ev2g_mlp_lds_barrier();
-    ev2g_mlp_inline_layer<C::KS2, NT2, 1, WVS>(m, bufH1, C::SH1, w2, m.b1 + NT1 * 16, bufH2, C::SH2, nullptr, nullptr, nr, wave, lane);
+    layer(std::integral_constant<int, 1>{}, bufH1, C::SH1, lb + NT1 * 16, bufH2, C::SH2);
     ev2g_mlp_lds_barrier();
-    ev2g_mlp_inline_layer<C::KS3, NT3, 2, WVS>(m, bufH2, C::SH2, w3, m.b1 + (NT1 + NT2) * 16, nullptr, 0, act_lds, y, nr, wave, lane);
+    layer(std::integral_constant<int, 2>{}, bufH2, C::SH2, lb + (NT1 + NT2) * 16, nullptr, 0);
     ev2g_mlp_lds_barrier();
 }
 

@@ -27,8 +27,12 @@ __host__ __device__ inline size_t ev2g_wave_lds_bytes(int envs_per_group, int bl
 // the fused actor + step instantiation (ACT, below): 16 envs and 16 wavefronts per workgroup, plus the policy's input rows (bf16) and its actions (float) in LDS
 #define EV2G_FUSED_BLOCK 1024
 #define EV2G_FUSED_SX 200     // MlpS16<6, ..>::SX: bf16 elements per observation row in LDS
+#ifndef EV2G_FUSED_RING
+#define EV2G_FUSED_RING 10    // weight fragments a wavefront keeps in flight (ev2g_mlp3_inline)
+#endif
+
 __host__ __device__ inline size_t ev2g_fused_lds_bytes() {
-    return ev2g_wave_lds_bytes(EV2G_FUSED_BLOCK / 64, EV2G_FUSED_BLOCK) + (size_t)16 * EV2G_FUSED_SX * 2 + (size_t)16 * 64 * 4;
+    return ev2g_wave_lds_bytes(EV2G_FUSED_BLOCK / 64, EV2G_FUSED_BLOCK) + (size_t)16 * EV2G_FUSED_SX * 2 + (size_t)(25 + 19 + 4) * 16 * 4;   // + input rows, biases
 }
 // What the fused instantiation needs besides the step's own arguments: the policy, and the observation rows its first forward reads.
 // StepIO then carries the OUTPUT blocks: obs32 = the rows the steps write (row of the launch's first step; o_stride floats between steps, 0: one row
@@ -191,7 +195,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     // activations in the staging rows, which are dead between the end of a step and the next phase A (idle lanes re-zero their slots afterwards)
     typedef MlpS16<6, 25, 19, 4, 1, 4, 1> MC;
     uint16_t *bufX = (uint16_t *)(cnt + 8);
-    float *act_lds = (float *)(bufX + 16 * EV2G_FUSED_SX);
+    float *lbias = (float *)(bufX + 16 * EV2G_FUSED_SX);   // the three bias vectors (MC::NB floats), staged once per launch
+    // the actions of env w: the first 64 floats of wavefront w's own slice of s_amps (dead between a step's phase C and the next phase A; the
+    // wavefront reads its actions -- one instruction, all lanes -- before it writes the amps over them)
+    float *act_lds = (float *)s_amps;
     uint16_t *bufH1 = (uint16_t *)stage, *bufH2 = bufH1 + 16 * MC::SH1;
     static_assert(EV2G_FUSED_SX == MC::SX && 16 * (MC::SH1 + MC::SH2) * 2 <= EV2G_NQ * (EV2G_FUSED_BLOCK + 8) * 8, "policy buffers");
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -298,6 +305,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
             else if (env_ok && c < D) v.x = xr[c];
             if (c < EV2G_FUSED_SX) *(uint32_t *)(bufX + wv * EV2G_FUSED_SX + c) = ev2g_pack_bf16(v.x, v.y);   // columns D .. 199: zeros (the k-steps' padding)
         }
+        if (tid < MC::NB) lbias[tid] = fa.m.b1[tid];   // (b1 | b2 | b3 are one array on this path, each padded to its tiles)
     }
     __syncthreads();
 
@@ -367,17 +375,15 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
         double a_cur = a_next;   // this step's action; the prefetch below replaces a_next by the next step's
         if (ACT) {
             // ---- the policy, on the 16 observation rows of this workgroup's envs (ev2g_mlp3_inline, ev2g_mlp.h) ----
-            // first barrier: every wavefront's observation columns of the step before (or the prologue's rows) are in bufX, and nobody
-            // still reads the staging rows the hidden activations are about to use
-            lds_barrier();
-            ev2g_mlp3_inline<6, 25, 19, 4, BLOCK / 64>(fa.m, bufX, bufH1, bufH2, act_lds, act_out, min(16, E - e0), tid_l);   // (ends with a barrier: the actions are in LDS)
+            ev2g_mlp3_inline<6, 25, 19, 4, BLOCK / 64, EV2G_FUSED_RING>(fa.m, bufX, bufH1, bufH2, lbias, act_lds, 128, act_out, min(16, E - e0), tid_l);   // (starts and ends with a barrier: the actions are in LDS)
             act_out += io.a_stride;
-            a_cur = valid ? (double)act_lds[wv * 64 + q_l] : 0.0;
+            a_cur = valid ? (double)act_lds[wv * 128 + q_l] : 0.0;
             // the staging slots of idle lanes must read as +0.0 in the per-env reduction (the lanes behind an env's last port never write them)
             if (!valid) {
 #pragma unroll
                 for (int k = 0; k < EV2G_NQ; k++) stage[k * RS + tid_l] = 0.0;
             }
+            PT_MARK(7)   // (phase-timing builds: slot 7 = the policy, including the wait at its first barrier)
         }
         // ---- prefetch what the rest of this step needs (collected before the stores of phase C) ----
         // Every prefetch is ONE unconditional load from a clamped (always valid) address; the conditions are applied
