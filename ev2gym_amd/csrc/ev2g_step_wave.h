@@ -59,6 +59,9 @@ template <class T, class B> __device__ __forceinline__ T ldg32_nt(B base, unsign
 template <class T, class B> __device__ __forceinline__ void stg32(B base, unsigned boff, T v) {
     *(T __attribute__((address_space(1))) *)((gptr)base + boff) = v;
 }
+template <class T, class B> __device__ __forceinline__ void stg32_nt(B base, unsigned boff, T v) {   // streaming store: written once, read by another kernel if at all
+    __builtin_nontemporal_store(v, (T __attribute__((address_space(1))) *)((gptr)base + boff));
+}
 typedef double d2v __attribute__((ext_vector_type(2)));   // builtin vectors: loadable from any address space
 typedef double d2v_a8 __attribute__((ext_vector_type(2), aligned(8)));   // the same at an 8-byte aligned address (global_load_dwordx4 needs dword alignment only)
 typedef int i2v __attribute__((ext_vector_type(2)));
@@ -151,6 +154,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     extern __shared__ double lds[];
     static_assert(!ACT || (IO32 && FULLK == 2 && BLOCK == EV2G_FUSED_BLOCK && SK != 1), "the fused actor + step instantiation");
     constexpr bool FULL = FULLK >= 1, WIDE = FULLK >= 2, STR = FULLK >= 3 || ACT;
+    constexpr bool STR_NT = FULLK >= 3;   // the kept observation rows (0.6 GB per cfg2 launch) as streaming stores: they should not displace the state lines in L2 (-2 %, profiles/r05_ab_strided_nt.txt)
     constexpr bool F64 = FULL && !IO32, F32 = FULL && IO32;   // full with float64 actions in / observations out, or with the float32 hand-over
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
     const unsigned long long pt_k0 = __builtin_readcyclecounter();   // slot 7 := prologue, slot 6 := epilogue (tools/phase_timing.py --outer)
@@ -650,8 +654,11 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
             const unsigned ocol_l = (unsigned)((SK == 1) ? 3 + 3 * q_l : (SK == 0 ? 62 + 2 * q_l : 22 + 2 * q_l));
             if (F64 || (!FULL && obs)) {
                 const unsigned o8 = WIDE ? hb_obs_port : (FULL ? hb_obs_env + ocol_l * 8u : (unsigned)(e_l * D + ocol) * 8u);
+                if (STR_NT) { stg32_nt<d2v>(obs, o8, (d2v){o0, o1}); if (SK == 1) stg32_nt<double>(obs, o8 + 16u, o2); }
+                else {
                 stg32<d2v>(obs, o8, (d2v){o0, o1});   // one 16-byte store (D and the column offset are even for SK != 1)
                 if (SK == 1) stg32<double>(obs, o8 + 16u, o2);
+                }
             }
             if (F32 || (!FULL && obs32)) {
                 const unsigned o4 = WIDE ? hb_obs_port : (FULL ? hb_obs_env + ocol_l * 4u : (unsigned)(e_l * D + ocol) * 4u);
@@ -894,8 +901,13 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                     stg32<double>(obs, o8 + 16u, usage);
                 }
             } else {  // V2G_profit_max(_loads) state.py:65-83, :108-135: columns 2.. are a copy of the head table row
+                if (STR_NT) {
+                    if (q_l == 0) stg32_nt<d2v>(obs, o8, (d2v){(double)sstep, usage});
+                    if (q_l < NPAIR) stg32_nt<d2v>(obs, o8 + 16u + (unsigned)q_l * 16u, pf_h0);
+                } else {
                 if (q_l == 0) stg32<d2v>(obs, o8, (d2v){(double)sstep, usage});
                 if (q_l < NPAIR) stg32<d2v>(obs, o8 + 16u + (unsigned)q_l * 16u, pf_h0);
+                }
                 if (!WIDE) {
                     if (q_l + P < NPAIR) stg32<d2v>(obs, o8 + 16u + (unsigned)(q_l + P) * 16u, pf_h1);
                     const unsigned h8 = (unsigned)((scn * (T + 1) + sstep) * NHEAD) * 8u;

@@ -45,12 +45,18 @@ def child(workload, pool, reps):
     bes = P * (phi * wl["b_occ"] + (1 - phi) * wl["b_empty"]) + batch.n_transformers * wl["b_tr"] + wl["b_env"]
     out = {"lib": os.environ.get("AB_LABEL") or os.environ.get("EV2G_LIB", "default"), "kernel": eng.kernel_name}
     off = 0
+    strided = bool(os.environ.get("AB_STRIDED"))   # persistent launches with every output kept: [T,E,*] blocks (instantiation 3)
+    if strided:
+        s_obs, s_rew, s_done, s_mask = eng.empty((T, E, D)), eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
     for mode, persistent, n in (("persistent", True, reps), ("per_step", False, max(3, reps // 6))):
         ms = []
         for r in range(n + 2):
             off = (off + E) % M
             eng.reset(obs, offset=off)
-            eng.step_n(T, None if io32 else acts, E * P, None if io32 else obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=persistent)
+            if strided and persistent:
+                eng.step_n(T, acts, E * P, s_obs, E * D, s_rew, E, s_done, E, s_mask, E * P, auto_reset=False, persistent=True)
+            else:
+                eng.step_n(T, None if io32 else acts, E * P, None if io32 else obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=persistent)
             k = eng.last_step_n_kernel_ms()
             eng.stats(out=stats)
             if r >= 2:
