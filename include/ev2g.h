@@ -256,7 +256,12 @@ const char *ev2g_fallback_reason(const ev2g_handle *h);
  * one such instantiation (1) for the reference's default plugin pair -- V2G_profit_max_loads + ProfitMax_TrPenalty_UserIncentives, single-port
  * chargers, everything of the float64 list above, EV2G_FLAG_LOG_SOC, 15 / 30 / 60-minute steps -- and 0 otherwise.  -1: no launch yet, or the
  * generic kernel.
- * Results are identical in all three (tests/test_round3_gpu.py); EV2G_NO_FULL / EV2G_NO_WIDE in the environment at load time force 0 / 1. */
+ * Round 5: 3 = 2 for outputs with STEP STRIDES (float64 [K,E,*] observation / reward / done / mask blocks of a persistent launch, every step kept:
+ * generate_trajectories.py:69-83 style use; needs what 2 needs); 4 = the fused actor + step launch of ev2g_rollout / ev2g_collect (the policy
+ * evaluated inside the step kernel's launch, one launch per segment; below).
+ * Results are identical in all of them (tests/test_round3_gpu.py, test_round4_gpu.py, test_round5_gpu.py); EV2G_NO_FULL / EV2G_NO_WIDE /
+ * EV2G_NO_STRIDED in the environment at load time force 0 / 1 / "strided outputs run 0"; EV2G_NO_DICT=1 at load time keeps the battery-maths operands
+ * one record per session instead of in the per-model dictionary, EV2G_NO_FUSED=1 keeps ev2g_rollout / ev2g_collect at two launches per step. */
 int ev2g_last_launch_specialisation(const ev2g_handle *h);
 /* When the last fast-path launch got the general instantiation (0): what the caller passed or configured that ruled the full one out (the
  * first such thing), "" otherwise.  The Python Engine warns once with it: the general instantiation is ~20 % slower, silently. */
@@ -350,7 +355,13 @@ void ev2g_mlp_destroy(ev2g_handle *h, ev2g_mlp *m);
 int ev2g_mlp_forward(ev2g_handle *h, const ev2g_mlp *m, const float *x, float *y, int n_rows);
 /* K rollout steps enqueued by one call: actor(obs_f32) -> actions_f32 -> EV2Gym.step, K times (the float32 buffers are the ones
  * registered with ev2g_set_step_extras, obs_f32_step_stride 0; d_in == obs dim, d_out == ports).  reward / done /
- * action_mask as in ev2g_step_n (mode EV2G_STEPN_PER_STEP_LAUNCH); auto_reset as there. */
+ * action_mask as in ev2g_step_n (mode EV2G_STEPN_PER_STEP_LAUNCH); auto_reset as there.
+ * Round 5: ONE launch per segment where the shape is eligible -- the fast path with one env per wavefront (33..64 ports: the shipped
+ * V2GProfitPlusLoads shape), a V2G_profit_max(_loads) state, a compiled-in reward, EV2G_FLAG_LOG_SOC, no cost buffer, all three outputs
+ * present, the segment inside the episode, and the bf16 policy in the 162 -> 400 -> 300 -> 64 packing: the workgroup that steps 16 envs
+ * evaluates the policy on their 16 observation rows between the steps (same MFMA chains as ev2g_mlp_forward: bit-identical actions), so
+ * neither kernel pays a cold start per step and the port state stays in LDS across the segment.  Anything else runs actor and step as two
+ * launches per step, as before (train_stable_baselines.py:62-130 is the loop this replaces). */
 int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward, int64_t reward_step_stride, uint8_t *done,
                  int64_t done_step_stride, uint8_t *action_mask, int64_t mask_step_stride, int auto_reset);
 /* Segments that contain no episode end are captured once as a HIP graph (keyed by their full launch signature) and replayed;
@@ -363,7 +374,8 @@ long long ev2g_rollout_graph_launches(const ev2g_handle *h);
  * observation row i + 1, reward / done / mask row i.  With next_obs[i] = obs[i + 1] these arrays ARE a replay-buffer segment (SB3's
  * ReplayBuffer(optimize_memory_usage=True) layout).  obs[0] is input: the observation the first action is computed from (the reset
  * observation, or the last row of the previous segment).  The segment must end at or before the episode end; statistics, the reset and
- * the terminal observation (= the segment's last observation row) are the caller's (ev2g_get_stats_reset).  All pointers DEVICE. */
+ * the terminal observation (= the segment's last observation row) are the caller's (ev2g_get_stats_reset).  All pointers DEVICE.
+ * Eligible shapes run the whole segment as ONE fused launch (see ev2g_rollout); rows and values are the same either way. */
 typedef struct {
     float *obs;         /* [k_steps + 1, E, D]; row 0 read, rows 1.. written */
     float *actions;     /* [k_steps, E, P] written */

@@ -10,6 +10,11 @@ import sys
 out, passes = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "all")
 HBM_PEAK = 8000.0
 summ = {"tag": os.path.basename(out).replace("prof_", "")}
+try:   # the commit this tree was pushed from (written by the caller before gpurun: the GPU box has no .git)
+    summ["source"] = open(".head_sha").read().strip()
+    print("## source:", summ["source"])
+except Exception:
+    pass
 
 try:
     line = json.loads(open(f"{out}/bench_line.json").read())
@@ -57,6 +62,9 @@ else:
 if line and step_avg_us:
     cfg = line["config"]
     spl = cfg["steps_per_episode"] if cfg["launch"] == "persistent" else 1
+    if "1024" in summ.get("kernel", "") and "true" in summ.get("kernel", "").split("1024")[-1]:   # the fused actor + step launch: one launch per episode-long segment
+        spl = cfg["steps_per_episode"]
+        print("## the step kernel of this trace is the FUSED actor + step launch (the policy inside it): bytes below are the env step's algorithmic bytes only")
     b = cfg["algorithmic_bytes_per_env_step"] * cfg["envs_per_gpu"] * spl
     ach = b / (step_avg_us * 1e-6) / 1e9
     summ.update(launch=cfg["launch"], steps_per_launch=spl, avg_launch_us=step_avg_us, algorithmic_bytes_per_launch=b,
