@@ -157,6 +157,8 @@ class RolloutLoop:
             else:
                 eng.step_n(k, self.acts[t], self.E * self.P, self.obs, 0, self.rew, 0, self.done, 0, self.mask, 0,
                            auto_reset=False, persistent=persistent)
+            if self.gath is not None and hasattr(self.gath, "flush"):
+                self.gath.flush()   # the statistics gather of the episode before, submitted BEHIND this launch (dist.AsyncStatsGather, "deferred")
             if timing is not None:
                 timing.append((eng.last_step_n_kernel_ms(), k))
             left -= k
@@ -813,7 +815,8 @@ def main():
                    "algorithmic_bytes_per_env_step": bytes_env_step, "soc_log": not args.no_soc_log,
                    "launch": best, "actor": args.actor if actor is None else actor.describe,
                    "actor_env_groups": (n_groups if actor is not None else None),
-                   "parallelism": f"env-sharded x{world}, RCCL all_gather of episode stats only (asynchronous, overlaps the next episode)"},
+                   "parallelism": f"env-sharded x{world}, RCCL all_gather of episode stats only (asynchronous; submitted behind the next episode's step kernel: dist.AsyncStatsGather)",
+                   "stats_gather_mode": (getattr(gath, "mode", None) if gath is not None else None)},
         "port_steps_per_s": value * P,
         "wall_s_by_launch_mode": {m: round(w, 6) for m, w in wall.items()},
         "env_steps_per_s_by_launch_mode": {m: env_steps_total / w for m, w in wall.items()},

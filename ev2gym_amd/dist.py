@@ -61,10 +61,20 @@ class AsyncStatsGather:
     statistics travel over xGMI; `finish()` waits for everything outstanding and returns the last result.
     """
 
-    def __init__(self, n_envs: int, world: int, device, dtype=None, group=None):
+    def __init__(self, n_envs: int, world: int, device, dtype=None, group=None, mode=None):
+        import os
         import torch
         dtype = dtype or torch.float64
         self.group, self.world = group, world
+        # WHEN the collective is handed to the GPU (EV2G_GATHER_MODE / `mode`):
+        #   "deferred" (default): launch() only marks the buffer; the caller calls flush() right AFTER it has enqueued the next episode's step
+        #              kernel.  A persistent step kernel occupies every wavefront slot of the chip (1024 workgroups on 256 CUs x 4): a collective
+        #              kernel that reaches the GPU first takes a slot and the displaced workgroup starts only when it leaves -- the whole
+        #              episode ends that much later (measured: 366 -> 466 us per launch).  Submitted behind the step kernel, the collective
+        #              waits for a slot instead and runs next to the following statistics kernel.
+        #   "overlap": issued inside launch(), asynchronously (rounds 2-4);  "inline": issued inside launch(), the current stream waits for it.
+        self.mode = mode or os.environ.get("EV2G_GATHER_MODE", "deferred")
+        self._pending = None
         self.send = [torch.zeros((n_envs, _abi.N_STATS), dtype=dtype, device=device) for _ in range(2)]
         self.recv = [torch.zeros((world * n_envs, _abi.N_STATS), dtype=dtype, device=device) for _ in range(2)]
         self.work = [None, None]
@@ -73,24 +83,41 @@ class AsyncStatsGather:
         self.collectives = 0   # all-gathers actually issued on the process group
 
     def buffer(self):
+        if self._pending == self.i:
+            self.flush()
         w = self.work[self.i]
         if w is not None:
             w.wait()
             self.work[self.i] = None
         return self.send[self.i]
 
-    def launch(self):
+    def _issue(self, i):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():   # also at world size 1: the same RCCL call, one rank
-            self.work[self.i] = dist.all_gather_into_tensor(self.recv[self.i], self.send[self.i], group=self.group, async_op=True)
+            w = dist.all_gather_into_tensor(self.recv[i], self.send[i], group=self.group, async_op=(self.mode != "inline"))
+            self.work[i] = w if self.mode != "inline" else None
             self.collectives += 1
         else:
-            self.recv[self.i].copy_(self.send[self.i])
+            self.recv[i].copy_(self.send[i])
+
+    def launch(self):
+        self.flush()   # (at most one deferred collective: an episode end without a step kernel behind it)
+        if self.mode == "deferred":
+            self._pending = self.i
+        else:
+            self._issue(self.i)
         self.last = self.i
         self.i ^= 1
         self.launched += 1
 
+    def flush(self):
+        """"deferred" mode: hand the marked collective to the GPU now (the caller has just enqueued the next step kernel); a no-op otherwise."""
+        if self._pending is not None:
+            i, self._pending = self._pending, None
+            self._issue(i)
+
     def finish(self):
+        self.flush()
         for k in (0, 1):
             if self.work[k] is not None:
                 self.work[k].wait()
