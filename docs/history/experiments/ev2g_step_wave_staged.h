@@ -1,4 +1,4 @@
-// tools/experiments/ev2g_step_wave_staged.h -- NOT part of the build.  Round-4 experiment (measured negative): the fast-path kernel with a fourth
+// docs/history/experiments/ev2g_step_wave_staged.h -- NOT part of the build.  Round-4 experiment (measured negative): the fast-path kernel with a fourth
 // specialisation level (FULLK = 3) that keeps the attached EVs session records in LDS slots for the whole launch (20 slots per wavefront, 9 chunks of
 // 16 bytes each: record + tail entry; co-operative copy by nine lanes per session; total energy and |energy| in the port lane registers; phase C
 // reads arrival / departure fields, battery size and potential term from the slot).  Parity: the whole GPU suite green (513 tests).  Time, cfg2
