@@ -605,8 +605,9 @@ __device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t
         const uint4 *w = L == 0 ? w1 : (L == 1 ? w2 : w3);
         if (WVS * i + WVS - 1 < NT || wave + WVS * i < NT) ring[seq % RING] = w[(unsigned)(((wave + WVS * i) * KS + ks) * 64)];
     };
-    // (requesting the head of the sequence a phase EARLIER in the step kernel -- behind phase E, D or C of the step before -- was tried: the ring then
-    // lives across the step loop's back edge and the register allocator spills 40..119 registers)
+    // (requesting the head of the sequence a phase EARLIER in the step kernel -- behind phase E, D or C of the step before -- was tried: the whole ring
+    // then lives across the step loop's back edge and the register allocator spills 40..119 registers; only layer 1's first tile (6 fragments)
+    // requested early fits -- and measured 1-2 % SLOWER than this, tools/gpu_r5e.sh: the head's latency is not what the policy phase waits for)
 #pragma unroll
     for (int sq = 0; sq < RING; sq++) request(sq);
     // first barrier: every wavefront's observation columns of the step before (or the prologue's rows) are in bufX, and nobody still reads the

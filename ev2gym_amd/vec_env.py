@@ -186,6 +186,9 @@ class EV2GymVec:
         # (an i.i.d. pool has no meaningful order: scenarios with similar busy windows next to each other, so that the envs a workgroup
         # advances in lockstep are busy and idle together -- ScenarioBatch.sorted_by_busy_window; not with device_refill, whose re-drawn
         # windows must stay where the generator's stream puts them)
+        # (the blocks are sorted INSIDE: episode windows are then aligned to them -- `_aligned` -- so that a window is one block, i.e. an i.i.d.
+        # sample of scenarios; inside a window env index and busy window are correlated: per-env monitors see that order, the batch does not care)
+        self._pool_sorted_blocks = not self.device_refill
         return full if self.device_refill else full.sorted_by_busy_window(self._n_req)
 
     # ---- buffers ---------------------------------------------------------------------------------
@@ -230,7 +233,7 @@ class EV2GymVec:
             self._last_offset = None   # names a window of the OLD pool: nothing of the new one has been used yet
             self._refill_next = self.engine.M * max(1, self.world_size)   # the new pool is a new stream of scenarios (its own seed)
         if seed is not None:
-            offset = int(np.random.default_rng(int(seed)).integers(0, M)) if M > self.num_envs else 0
+            offset = self._aligned(int(np.random.default_rng(int(seed)).integers(0, M)), M) if M > self.num_envs else 0
         else:
             offset = self._next_window(M)
         if self.device_refill and self._episodes > 0:
@@ -242,6 +245,15 @@ class EV2GymVec:
             self.stats = None
         return self._out(self._obs), {}
 
+    def _aligned(self, offset, M):
+        """A pool sorted by busy window inside blocks of num_envs scenarios (generated pools, `_draw_pool`): window offsets are multiples of the
+        block size -- an unaligned window would be the late-arrival tail of one block plus the early-arrival head of the next, no longer an
+        i.i.d. sample of scenarios."""
+        E = self.num_envs
+        if getattr(self, "_pool_sorted_blocks", False) and M >= 2 * E:
+            return (offset // E) * E % (M // E * E)
+        return offset
+
     def _next_window(self, M):
         """Scenario-pool windows WITHOUT replacement: a pass over the pool visits its M // E disjoint windows in a random order
         (from a random base offset), so no scenario is stepped twice before every other one has been; the next pass draws a new base
@@ -250,7 +262,7 @@ class EV2GymVec:
         if M <= E:
             return 0
         if not getattr(self, "_window_queue", None):
-            base = int(self._rng.integers(0, M))
+            base = self._aligned(int(self._rng.integers(0, M)), M)
             self._window_queue = [(base + int(k) * E) % M for k in self._rng.permutation(M // E)]
         return self._window_queue.pop()
 
