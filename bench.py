@@ -660,7 +660,9 @@ def main():
         # kernel-only duration, HIP events on the launch stream around every ev2g_step_n of an untimed pass
         loop.reset()
         tim = []
-        loop.run(max(min(args.steps, 2 * T), T), mode == "persistent", timing=tim)
+        # (persistent: 16 whole-episode launches -- one or two, as in rounds 1-4, sample the first launches after a reset, 1 % slower than the
+        # average rocprofv3 reports over the timed region's hundreds; per_step: two episodes = 224 launches)
+        loop.run(16 * T if mode == "persistent" else 2 * T, mode == "persistent", timing=tim)
         devx.synchronize()
         kern_ms = sum(x for x, _ in tim)
         kern_steps = sum(k for _, k in tim)

@@ -264,7 +264,10 @@ class EV2GymVec:
         if not getattr(self, "_window_queue", None):
             base = self._aligned(int(self._rng.integers(0, M)), M)
             self._window_queue = [(base + int(k) * E) % M for k in self._rng.permutation(M // E)]
-        return self._window_queue.pop()
+        q = self._window_queue
+        if len(q) > 1 and q[-1] == self._last_offset:   # (a new pass, or a seeded reset before: never the window the last episode ran on)
+            q[-1], q[0] = q[0], q[-1]
+        return q.pop()
 
     def _as_device_actions(self, actions):
         if self._torch is not None and self._torch.is_tensor(actions):

@@ -313,6 +313,6 @@ def test_reset_with_a_seed_draws_that_seeds_scenarios():
     s1, s2 = v1.step(act), v2.step(act)
     assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[1], s2[1])
     offs = {v1.reset(seed=k) and v1.engine.scenario_offset for k in range(12)}
-    assert len(offs) > 6, "different seeds select different windows of the pool"
+    assert len(offs) >= 4 and all(o % 16 == 0 for o in offs), "different seeds select different windows of the pool (8 aligned windows of 16 envs)"
     v1.close(); v2.close()
 
