@@ -104,3 +104,50 @@ def test_fused_rollout_through_the_hand_over_buffers_equals_the_two_kernel_chain
         assert np.array_equal(o1, o2) and np.array_equal(a1, a2)
     for k in ("rew", "done", "mask", "stats"):
         assert np.array_equal(one[k], two[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("no_dict", [False, True])
+def test_device_refill_brings_car_models_the_loaded_pool_never_held(no_dict, monkeypatch):
+    """Round 5, battery-maths dictionary (DESIGN par.2): the loader builds the (car model x charger kind) entries from the sessions it is handed;
+    ev2g_pool_refill must add the entries of every model its fleet can draw BEFORE the device draws them.  A pool loaded from a nearly empty batch
+    (four sessions, three of the fleet's models) and then refilled from a full-rate stream steps whole episodes exactly like a pool
+    loaded from the host-generated scenarios; the same with EV2G_NO_DICT (one entry per session, written by the device generator)."""
+    import dataclasses
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine, host_uniform
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    M, S1 = 16, 41
+    monkeypatch.setenv("EV2G_POOL_SESSION_CAP", "96")
+    if no_dict:
+        monkeypatch.setenv("EV2G_NO_DICT", "1")
+    else:
+        monkeypatch.delenv("EV2G_NO_DICT", raising=False)
+    cfg = GenConfig.v2g_profit_plus_loads(M, 50, 1, seed=S1)
+    host = generate_native(cfg)
+    sparse = generate_native(dataclasses.replace(GenConfig.v2g_profit_plus_loads(M, 50, 1, seed=977), spawn_multiplier=0.04))
+    n_models_sparse = len(np.unique(sparse.arrays["ev_B"])) if sparse.n_sessions else 0
+    assert sparse.n_sessions <= 12 and n_models_sparse < len(np.unique(host.arrays["ev_B"])), (sparse.n_sessions, n_models_sparse)
+    rk, sk = _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"]
+    flags = _abi.FLAG_LOG_SOC | _abi.FLAG_REFILLABLE
+
+    def episode(eng):
+        E, P, D, T = eng.E, eng.P, eng.D, eng.T
+        acts = eng.empty((T, E, P)).upload(host_uniform(T * E * P, 600, -1.0, 1.0).reshape(T, E, P))
+        obs, rew, done, mask = eng.empty((T, E, D)), eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
+        eng.reset()
+        eng.step_n(T, acts, E * P, obs, E * D, rew, E, done, E, mask, E * P, auto_reset=False, persistent=True)
+        out = [obs.to_host(), rew.to_host(), mask.to_host(), np.nan_to_num(eng.stats(), nan=-7.0)]
+        eng.check_faults()
+        return out
+
+    ref = Engine(host, rk, sk, flags=flags)
+    want = episode(ref)
+    ref.close()
+    eng = Engine(sparse, rk, sk, flags=flags)
+    assert eng.kernel_name.startswith("ev2g_step_wave")
+    eng.pool_refill(cfg, S1, 0, 0, M)
+    got = episode(eng)
+    assert eng.pool_refill_overflows == 0
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b, equal_nan=True)
+    eng.close()
