@@ -27,6 +27,7 @@
 static thread_local std::string g_create_error;
 #include "ev2g_gen_host.h"
 
+#define EV2G_EV_RING 32
 struct ev2g_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -79,7 +80,11 @@ struct ev2g_handle {
     std::string fallback_reason;                // why the common-shape fast path was NOT taken ("" when it was / does not apply)
     int current_step = 0;
     size_t lds_bytes = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // HIP-event pairs of the last EV2G_EV_RING timed calls (ev2g_step_n / ev2g_rollout / ev2g_collect): a caller that queues several launches and
+    // reads their durations afterwards (bench.py's roofline pass) does not have to drain the stream after each one
+    hipEvent_t ev0s[EV2G_EV_RING] = {}, ev1s[EV2G_EV_RING] = {};
+    int ev_slot = 0;
+    long long ev_calls = 0;
     bool timed = false;
     std::string err;
     CommState comm;                             // RCCL communicator of the statistics exchange (ev2g_comm_init), if any
@@ -187,8 +192,7 @@ int ev2g_create(const ev2g_config *cfg, ev2g_handle **out) {
         }
         h->own_stream = true;
     }
-    (void)hipEventCreate(&h->ev0);
-    (void)hipEventCreate(&h->ev1);
+    for (int i = 0; i < EV2G_EV_RING; i++) { (void)hipEventCreate(&h->ev0s[i]); (void)hipEventCreate(&h->ev1s[i]); }
     *out = h;
     return EV2G_OK;
 }
@@ -210,8 +214,7 @@ void ev2g_destroy(ev2g_handle *h) {
     if (h->d_refill_overflow) (void)hipFree(h->d_refill_overflow);
     ev2g_comm_destroy(h);
     drop_rollout_graphs(h);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (int i = 0; i < EV2G_EV_RING; i++) { if (h->ev0s[i]) (void)hipEventDestroy(h->ev0s[i]); if (h->ev1s[i]) (void)hipEventDestroy(h->ev1s[i]); }
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1029,7 +1032,8 @@ int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, in
     (void)hipSetDevice(h->device);
     int rc = EV2G_OK;
     const long long adv = (auto_reset == EV2G_AUTO_RESET_NEXT) ? h->E % h->M : 0;   // pool offset advance per in-run reset
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    h->ev_slot = (h->ev_slot + 1) % EV2G_EV_RING; h->ev_calls += 1;
+    HIPCHK(h, hipEventRecord(h->ev0s[h->ev_slot], h->stream));
     if (mode == EV2G_STEPN_PERSISTENT) {
         int k = k_steps;
         if (!auto_reset) k = std::min(k, h->T - h->current_step);
@@ -1056,7 +1060,7 @@ int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, in
                 h->current_step += kc;
                 i0 += kc;
             }
-            HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+            HIPCHK(h, hipEventRecord(h->ev1s[h->ev_slot], h->stream));
             h->timed = true;
             return rc;
         }
@@ -1089,7 +1093,7 @@ int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, in
             h->current_step += 1;
         }
     }
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev1s[h->ev_slot], h->stream));
     h->timed = true;
     return rc;
 }
@@ -1386,7 +1390,8 @@ int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward,
         }
         return EV2G_OK;
     };
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    h->ev_slot = (h->ev_slot + 1) % EV2G_EV_RING; h->ev_calls += 1;
+    HIPCHK(h, hipEventRecord(h->ev0s[h->ev_slot], h->stream));
     int rc = EV2G_OK;
     static const bool use_graphs = [] { const char *e = std::getenv("EV2G_ROLLOUT_GRAPHS"); return !(e && e[0] == '0'); }();
     const bool whole = h->current_step + k_steps <= h->T;   // no episode end inside the segment: nothing but kernel launches
@@ -1426,7 +1431,7 @@ int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward,
     } else {
         rc = enqueue(k_steps);
     }
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev1s[h->ev_slot], h->stream));
     h->timed = true;
     return rc;
 }
@@ -1450,7 +1455,8 @@ int ev2g_collect(ev2g_handle *h, const ev2g_mlp *m, int k_steps, const ev2g_tran
     if (!direct && !(x.obs_f32 && x.actions_f32 && x.obs_f32_step_stride == 0))
         return fail(h, EV2G_ERR_ARG, "ev2g_collect: this configuration steps through the registered float32 hand-over buffers: register them with "
                                      "ev2g_set_step_extras (observation step stride 0) first");
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    h->ev_slot = (h->ev_slot + 1) % EV2G_EV_RING; h->ev_calls += 1;
+    HIPCHK(h, hipEventRecord(h->ev0s[h->ev_slot], h->stream));
     if (direct && k_steps >= 1 && fused_eligible(h, m)) {   // ONE launch for the segment: rows read and written in place, the policy inside the launch
         const int rc = launch_fused(h, m, k_steps, tr->obs, tr->obs + ED, (long long)ED, tr->actions, (long long)EP, tr->reward, h->E, tr->done, h->E, tr->mask, (long long)EP);
         if (rc) return rc;
@@ -1476,16 +1482,21 @@ int ev2g_collect(ev2g_handle *h, const ev2g_mlp *m, int k_steps, const ev2g_tran
         }
         h->current_step += 1;
     }
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev1s[h->ev_slot], h->stream));
     h->timed = true;
     return EV2G_OK;
 }
 
 double ev2g_last_step_n_kernel_ms(ev2g_handle *h) {
-    if (!h || !h->timed) return -1.0;
-    if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0;
+    return ev2g_step_n_kernel_ms_back(h, 0);
+}
+
+double ev2g_step_n_kernel_ms_back(ev2g_handle *h, int back) {
+    if (!h || !h->timed || back < 0 || back >= EV2G_EV_RING || back >= h->ev_calls) return -1.0;
+    const int slot = ((h->ev_slot - back) % EV2G_EV_RING + EV2G_EV_RING) % EV2G_EV_RING;
+    if (hipEventSynchronize(h->ev1s[slot]) != hipSuccess) return -1.0;
     float ms = 0;
-    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, h->ev0s[slot], h->ev1s[slot]) != hipSuccess) return -1.0;
     return (double)ms;
 }
 

@@ -88,6 +88,7 @@ def load_library(path: Optional[str] = None):
         "ev2g_comm_get_unique_id": (C.c_int, [vp]),
         "ev2g_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
         "ev2g_comm_destroy": (None, [vp]),
+        "ev2g_step_n_kernel_ms_back": (dbl, [vp, C.c_int]),
         "ev2g_comm_world_size": (C.c_int, [vp]),
         "ev2g_comm_gathers": (C.c_longlong, [vp]),
         "ev2g_gather_stats": (C.c_int, [vp, vp]),
@@ -116,7 +117,7 @@ EXPORTED_SYMBOLS = [
     "ev2g_scenario_offset", "ev2g_set_step_extras", "ev2g_kernel_name", "ev2g_last_launch_specialisation", "ev2g_last_launch_general_reason", "ev2g_fallback_reason", "ev2g_step", "ev2g_step_n",
     "ev2g_check_faults", "ev2g_get_stats", "ev2g_get_stats_reset", "ev2g_get_stats_reset_f32", "ev2g_reset_f32", "ev2g_collect", "ev2g_stat_name", "ev2g_peek", "ev2g_malloc", "ev2g_free",
     "ev2g_memcpy_h2d", "ev2g_memcpy_d2h", "ev2g_synchronize", "ev2g_fill_uniform", "ev2g_host_uniform",
-    "ev2g_last_step_n_kernel_ms", "ev2g_mlp_create", "ev2g_mlp_create_ex", "ev2g_mlp_destroy", "ev2g_mlp_forward", "ev2g_rollout",
+    "ev2g_last_step_n_kernel_ms", "ev2g_step_n_kernel_ms_back", "ev2g_mlp_create", "ev2g_mlp_create_ex", "ev2g_mlp_destroy", "ev2g_mlp_forward", "ev2g_rollout",
     "ev2g_rollout_graph_launches", "ev2g_comm_get_unique_id", "ev2g_comm_init", "ev2g_comm_destroy", "ev2g_comm_world_size", "ev2g_comm_gathers", "ev2g_gather_stats",
     "ev2g_pool_refill", "ev2g_pool_refill_overflows", "ev2g_pool_session_capacity", "ev2g_gen_default_config", "ev2g_generate", "ev2g_gen_batch", "ev2g_gen_free", "ev2g_gen_table"]
 
@@ -318,6 +319,10 @@ class Engine:
 
     def last_step_n_kernel_ms(self) -> float:
         return float(self._lib.ev2g_last_step_n_kernel_ms(self._h))
+
+    def step_n_kernel_ms_back(self, back: int) -> float:
+        """HIP-event duration of the timed call `back` calls before the last one (the handle keeps 32): queue launches, read them afterwards."""
+        return float(self._lib.ev2g_step_n_kernel_ms_back(self._h, int(back)))
 
     def check_faults(self):
         bad = C.c_int32(-1)

@@ -399,6 +399,9 @@ void ev2g_host_uniform(double *dst, int64_t n, uint64_t seed, double lo, double 
 /* elapsed GPU time of the kernels enqueued by the last ev2g_step_n(), measured with HIP events on
  * the handle's stream; total over the K launches, in milliseconds. */
 double ev2g_last_step_n_kernel_ms(ev2g_handle *h);
+/* the same for the timed call `back` calls before the last one (0 = the last; the handle keeps the event pairs of its last 32 ev2g_step_n /
+ * ev2g_rollout / ev2g_collect calls): launches can be queued back to back and their durations read afterwards.  -1.0: out of range. */
+double ev2g_step_n_kernel_ms_back(ev2g_handle *h, int back);
 
 /* ---- scenario generator (host side, no GPU involved) ------------------------------------------------------------------
  * What EV2Gym.reset() draws for one episode -- EV sessions (EV_spawner utils.py:477-557, spawn_single_EV :177-345), prices
