@@ -151,3 +151,55 @@ def test_device_refill_brings_car_models_the_loaded_pool_never_held(no_dict, mon
     for a, b in zip(got, want):
         assert np.array_equal(a, b, equal_nan=True)
     eng.close()
+
+
+FUSED_SWEEP = list(range(12))
+
+
+@pytest.mark.parametrize("case", FUSED_SWEEP)
+def test_fused_launch_randomised_shapes_equal_the_two_kernel_chain(case, monkeypatch):
+    """A seeded sweep over what the fused actor + step launch is eligible for -- 33..64 ports, both head-table states, the three compiled-in
+    rewards, ragged env counts, random segment lengths, both action ranges -- against the two-launch chain, bit for bit (rows, statistics)."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.actor import init_mlp_weights
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    rng = np.random.default_rng(9000 + case)
+    C = int(rng.integers(33, 65))
+    E = int(rng.integers(1, 70))
+    state = ["V2G_profit_max_loads", "V2G_profit_max"][int(rng.integers(0, 2))]
+    reward = ["ProfitMax_TrPenalty_UserIncentives", "SquaredTrackingErrorReward", "profit_maximization"][int(rng.integers(0, 3))]
+    lo = [-1.0, 0.0][int(rng.integers(0, 2))]
+    pool = generate_native(GenConfig.v2g_profit_plus_loads(E + int(rng.integers(0, 9)), C, 1, seed=100 + case))
+    off = int(rng.integers(0, pool.n_envs))
+    T = pool.n_steps
+    cuts = sorted(set(int(x) for x in rng.integers(1, T, int(rng.integers(0, 6)))))
+    segs = [b - a for a, b in zip([0] + cuts, cuts + [T])]
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("EV2G_NO_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("EV2G_NO_FUSED", "1")
+        eng = Engine(pool, _abi.REWARD_KINDS[reward], _abi.STATE_KINDS[state], flags=_abi.FLAG_LOG_SOC, n_active_envs=E)
+        P, D = eng.P, eng.D
+        mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=case), out_lo=lo)
+        obs, act = eng.empty((T + 1, E, D), np.float32), eng.empty((T, E, P), np.float32)
+        rew, done, mask = eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
+        eng.reset_f32(obs, off)
+        t, specs = 0, set()
+        for k in segs:
+            eng.collect(mlp, k, obs.at(t * E * D), act.at(t * E * P), rew.at(t * E), done.at(t * E), mask.at(t * E * P))
+            specs.add(eng.last_launch_specialisation)
+            t += k
+        out = dict(obs=obs.to_host(), act=act.to_host(), rew=rew.to_host(), done=done.to_host(), mask=mask.to_host(), stats=eng.stats().copy())
+        eng.check_faults()
+        eng.mlp_destroy(mlp)
+        eng.close()
+        return specs, out
+
+    s2, two = run(False)
+    s1, one = run(True)
+    assert s1 == {4} and 4 not in s2, (s1, s2, C, E, state, reward)
+    for k in two:
+        assert np.array_equal(one[k], two[k], equal_nan=True), (k, C, E, state, reward, segs)
