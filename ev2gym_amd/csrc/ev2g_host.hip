@@ -1312,14 +1312,14 @@ int ev2g_mlp_debug_stamps(ev2g_handle *h, const ev2g_mlp *m, unsigned long long 
 #endif
 
 // ---- one launch per rollout segment (round 5): ev2g_step_wave<.., 1024, true> evaluates the policy between the steps, inside the launch ----
-// Eligible: the fast path with one env per wavefront (33..64 ports: BASELINE configs[1] / configs[4]), a head-table state (V2G_profit_max_loads /
+// Eligible: the fast path (3..64 ports: the shipped YAMLs' 25 chargers, BASELINE configs[1] / configs[4]'s 50; every env gets a wavefront of its own in
+// this instantiation, whatever its width), a head-table state (V2G_profit_max_loads /
 // V2G_profit_max), one of the three compiled-in rewards, EV2G_FLAG_LOG_SOC, no extras beyond the float32 hand-over, and the bf16 policy in the
 // streaming kernel's 162 -> 400 -> 300 -> 64 packing.  Anything else (and EV2G_NO_FUSED=1) keeps the two launches per step.
 static bool fused_eligible(const ev2g_handle *h, const ev2g_mlp *m) {
     const DevScn &s = h->scn;
-    return h->wave_path && s.P >= 33 && s.P <= 64 && s.state_kind != EV2G_STATE_PUBLIC_PST && std::min(s.reward_kind, 3) != 3 && (h->cfg.flags & EV2G_FLAG_LOG_SOC) &&
+    return h->wave_path && s.P >= 3 && s.P <= 64 && s.state_kind != EV2G_STATE_PUBLIC_PST && std::min(s.reward_kind, 3) != 3 && (h->cfg.flags & EV2G_FLAG_LOG_SOC) &&
            !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) && !h->extras.cost && !h->no_full && !h->no_wide && (s.D & 1) == 0 &&
-           s.P >= (s.state_kind == EV2G_STATE_V2G_PROFIT_MAX_LOADS ? 30 : 10) &&
            m->s16_ks1 == 6 && m->s16_nt1 == 25 && m->s16_nt2 == 19 && m->s16_nt3 == 4 && m->s16_nw == 1 && !std::getenv("EV2G_NO_FUSED");
 }
 // k steps from the current one; obs0: the [E, D] float32 rows the first forward reads; obs / act / reward / done / mask: the rows of the segment's first

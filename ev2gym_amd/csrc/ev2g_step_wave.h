@@ -172,7 +172,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     const unsigned long long PS8 = wa.slab_port_slice, SS8 = S->sess_slice;
     const gptr env_acc = (gptr)wa.env_acc;
 #define PA(k) (slabP + PS8 * (unsigned long long)(k))
-    const int EPW = 64 / P;   // envs per wavefront
+    // envs per wavefront.  The fused instantiation gives EVERY env a wavefront of its own, whatever its width (a policy row is an env: 16 rows per
+    // workgroup; the step's time is a chain of latencies, not lanes): the lanes behind the env's last port only copy observation-head pairs
+    const int EPW = ACT ? 1 : 64 / P;
     const int G = (BLOCK / 64) * EPW;    // envs per workgroup
     int grp;
     {   // XCD-aware mapping: workgroup b runs on XCD b % 8; give each XCD a contiguous range of env groups
@@ -213,9 +215,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
 
     // ---- home lane set-up ----
     const int elw = lane / P;            // env inside the wavefront
-    const int q = lane - elw * P;        // port slot (== reference port: one transformer, single-port chargers)
-    const int e = e0 + wv * EPW + elw;
+    const int q = ACT ? lane : lane - elw * P;        // port slot (== reference port: one transformer, single-port chargers)
+    const int e = ACT ? e0 + wv : e0 + wv * EPW + elw;
     const bool valid = (elw < EPW) && (e < E);
+    const bool hcopy = ACT && !valid && e < E && lane < 32;   // (ACT, envs narrower than their head pairs: lanes P .. NPAIR-1 copy the pairs the ports cannot)
     const int g = valid ? e * P + q : 0;
     const int ocol = (SK == 1) ? 3 + 3 * q : (SK == 0 ? 62 + 2 * q : 22 + 2 * q);
     const int cs = valid ? q : 0;
@@ -324,7 +327,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     float *obs32_run = io.obs32, *act_out = ACT ? const_cast<float *>(io.act32) + (long long)e0 * P : nullptr;   // (ACT: the rows the policy writes, this workgroup's first env)
     constexpr unsigned OB = F32 ? 4u : 8u;    // bytes per observation element the full kernel writes
     if (FULL) {
-        const int scn0 = ev2g_scn(valid ? e : e0, off, M);
+        const int scn0 = ev2g_scn((valid || hcopy) ? e : e0, off, M);
         hb_step = (unsigned)(scn0 * T) * 64u;
         hb_head = (unsigned)(scn0 * (T + 1)) * (unsigned)(((SK == 1) ? 0 : (SK == 0 ? 60 : 20)) * 8);
         hb_obs_env = (unsigned)(e * D) * OB;
@@ -867,7 +870,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                 stg32<double>(env_acc, a8 + 32u, n4);
             }
         }
-        if (valid && (F32 || (!FULL && obs32))) {
+        if ((valid || hcopy) && (F32 || (!FULL && obs32))) {
             const unsigned o4 = FULL ? hb_obs_env : (unsigned)(e_l * D) * 4u;
             if (SK == 1) {
                 if (q_l == 0) {

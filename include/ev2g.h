@@ -356,8 +356,8 @@ int ev2g_mlp_forward(ev2g_handle *h, const ev2g_mlp *m, const float *x, float *y
 /* K rollout steps enqueued by one call: actor(obs_f32) -> actions_f32 -> EV2Gym.step, K times (the float32 buffers are the ones
  * registered with ev2g_set_step_extras, obs_f32_step_stride 0; d_in == obs dim, d_out == ports).  reward / done /
  * action_mask as in ev2g_step_n (mode EV2G_STEPN_PER_STEP_LAUNCH); auto_reset as there.
- * Round 5: ONE launch per segment where the shape is eligible -- the fast path with one env per wavefront (33..64 ports: the shipped
- * V2GProfitPlusLoads shape), a V2G_profit_max(_loads) state, a compiled-in reward, EV2G_FLAG_LOG_SOC, no cost buffer, all three outputs
+ * Round 5: ONE launch per segment where the shape is eligible -- the fast path (3..64 ports per env: the shipped V2GProfitPlusLoads
+ * file's 25 chargers, BASELINE's 50), a V2G_profit_max(_loads) state, a compiled-in reward, EV2G_FLAG_LOG_SOC, no cost buffer, all three outputs
  * present, the segment inside the episode, and the bf16 policy in the 162 -> 400 -> 300 -> 64 packing: the workgroup that steps 16 envs
  * evaluates the policy on their 16 observation rows between the steps (same MFMA chains as ev2g_mlp_forward: bit-identical actions), so
  * neither kernel pays a cold start per step and the port state stays in LDS across the segment.  Anything else runs actor and step as two

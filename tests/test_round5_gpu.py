@@ -18,7 +18,8 @@ def _engine(E, M, C, seed, state="V2G_profit_max_loads", reward="ProfitMax_TrPen
     return eng, pool
 
 
-@pytest.mark.parametrize("state,E,C", [("V2G_profit_max_loads", 37, 50), ("V2G_profit_max_loads", 16, 64), ("V2G_profit_max", 21, 40)])
+@pytest.mark.parametrize("state,E,C", [("V2G_profit_max_loads", 37, 50), ("V2G_profit_max_loads", 16, 64), ("V2G_profit_max", 21, 40),
+                                       ("V2G_profit_max_loads", 19, 25), ("V2G_profit_max_loads", 33, 7), ("V2G_profit_max", 5, 22)])
 def test_fused_actor_and_step_launch_equals_the_two_kernel_chain(state, E, C, monkeypatch):
     """one launch per rollout segment -- the policy (obs -> 400 -> 300 -> ports, bf16 MFMA) evaluated INSIDE the step
     kernel's launch by the workgroup that steps the 16 envs whose rows it reads (ev2g_step_wave<.., 1024, true>) -- against round 4's chain of
@@ -153,19 +154,19 @@ def test_device_refill_brings_car_models_the_loaded_pool_never_held(no_dict, mon
     eng.close()
 
 
-FUSED_SWEEP = list(range(12))
+FUSED_SWEEP = list(range(20))
 
 
 @pytest.mark.parametrize("case", FUSED_SWEEP)
 def test_fused_launch_randomised_shapes_equal_the_two_kernel_chain(case, monkeypatch):
-    """A seeded sweep over what the fused actor + step launch is eligible for -- 33..64 ports, both head-table states, the three compiled-in
+    """A seeded sweep over what the fused actor + step launch is eligible for -- 3..64 ports (narrow envs: one wavefront each all the same), both head-table states, the three compiled-in
     rewards, ragged env counts, random segment lengths, both action ranges -- against the two-launch chain, bit for bit (rows, statistics)."""
     from ev2gym_amd import _abi
     from ev2gym_amd.actor import init_mlp_weights
     from ev2gym_amd.engine import Engine
     from ev2gym_amd.scenario_gen import GenConfig, generate_native
     rng = np.random.default_rng(9000 + case)
-    C = int(rng.integers(33, 65))
+    C = int(rng.integers(3, 65))
     E = int(rng.integers(1, 70))
     state = ["V2G_profit_max_loads", "V2G_profit_max"][int(rng.integers(0, 2))]
     reward = ["ProfitMax_TrPenalty_UserIncentives", "SquaredTrackingErrorReward", "profit_maximization"][int(rng.integers(0, 3))]
@@ -200,6 +201,8 @@ def test_fused_launch_randomised_shapes_equal_the_two_kernel_chain(case, monkeyp
 
     s2, two = run(False)
     s1, one = run(True)
-    assert s1 == {4} and 4 not in s2, (s1, s2, C, E, state, reward)
+    # (a network that fits the SMALL fragment packing -- at most 64 inputs and 32 outputs: V2G_profit_max with fewer than 22 ports -- keeps two launches)
+    fused = state == "V2G_profit_max_loads" or C >= 22
+    assert s1 == ({4} if fused else s2) and 4 not in s2, (s1, s2, C, E, state, reward)
     for k in two:
         assert np.array_equal(one[k], two[k], equal_nan=True), (k, C, E, state, reward, segs)
