@@ -436,7 +436,17 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
         bool occ = false;
         double cap_before = 0.0;
         int ta_a = EV2G_INT_MAX, td_a = -1;   // this port's window as phase A saw it (idle lanes: no event)
-        if (valid) {
+        // A wavefront none of whose ports holds an EV in this step or receives one at its end (workplace nights, early mornings: a third of the
+        // wavefront-steps at cfg2) has nothing to decide in phases A and C: every action is masked, every per-port observation column and mask entry
+        // is zero, nothing is staged (phase D skips such a wavefront already).  The full kernels know it from the windows in their registers.
+#ifdef EV2G_NO_EMPTY_WAVE_PATH
+        const bool wave_live = true;
+#else
+        // (one env per wavefront only: with two or three a wavefront is rarely empty and the test costs more than it saves -- cfg3 +0.8 %, cfg2 -3 %,
+        // profiles/r05_ab_empty_wavefront_path.txt)
+        const bool wave_live = !FULL || EPW != 1 || __ballot(valid && ((r_ta <= t && t <= r_td) || r_ta == sstep)) != 0ull;   // (uniform)
+#endif
+        if (valid && wave_live) {
             // every LDS operand of the phase in one batch (one wait) instead of one round trip per branch
             int ta = FULL ? r_ta : s_ta[tid_l], td = FULL ? r_td : s_td[tid_l];
             double cap_b = s_cap[tid_l], c_thr = s_cst[0 * 64 + q_l], c_dmin = s_cst[1 * 64 + q_l];
@@ -564,7 +574,22 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
         asm volatile("" : "+v"(a_next), "+v"(pf_pch), "+v"(pf_pdis), "+v"(pf_tr), "+v"(pf_ob0), "+v"(pf_h0), "+v"(pf_h1));
         asm volatile("" : "+v"(pf_c2), "+v"(pf_c7), "+v"(pf_tl), "+v"(pf_d0), "+v"(pf_d1));
         bool occ_any = false;   // an EV on this port before or after the step
-        if (valid) {
+        if (FULL && valid && !wave_live) {   // the empty wavefront's outputs: zeros
+            stg32<uint8_t>(mask, (unsigned)g_l, (uint8_t)0);
+            const unsigned ocol_l = (unsigned)((SK == 1) ? 3 + 3 * q_l : (SK == 0 ? 62 + 2 * q_l : 22 + 2 * q_l));
+            if (F64) {
+                const unsigned o8 = WIDE ? hb_obs_port : hb_obs_env + ocol_l * 8u;
+                if (STR_NT) { stg32_nt<d2v>(obs, o8, (d2v){0.0, 0.0}); if (SK == 1) stg32_nt<double>(obs, o8 + 16u, 0.0); }
+                else { stg32<d2v>(obs, o8, (d2v){0.0, 0.0}); if (SK == 1) stg32<double>(obs, o8 + 16u, 0.0); }
+            }
+            if (F32) {
+                const unsigned o4 = WIDE ? hb_obs_port : hb_obs_env + ocol_l * 4u;
+                if (SK == 1) { stg32<float>(obs32, o4, 0.f); stg32<float>(obs32, o4 + 4u, 0.f); stg32<float>(obs32, o4 + 8u, 0.f); }
+                else stg32<f2v>(obs32, o4, (f2v){0.f, 0.f});
+                if (ACT) *(uint32_t *)(bufX + wv * EV2G_FUSED_SX + ocol_l) = 0u;
+            }
+        }
+        if (valid && wave_live) {
             double profit = 0.0, satpen = 0.0, pot = 0.0;
             // every LDS operand of this phase in ONE batch (one wait), whichever branch consumes it: read one by one behind the
             // branches below, each of them was its own LDS round trip on the workgroup-step chain

@@ -150,10 +150,10 @@ def test_fast_path_kernels_keep_four_wavefronts_per_simd_and_do_not_spill():
         # full + wide -- must stay nearly free of them, each is a v_readlane / v_writelane pair in the step loop)
         assert v["VGPRs"] <= 128 and v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
         fullk, block, act = map(int, re.search(r"ev2g_step_waveILi\dELi\dELb\dELi(\d)ELi(\d+)ELb(\d)E", k).groups())
-        if fullk == 2 and not act:
-            assert v["SGPRs Spill"] <= 8, (k, v)
-        if fullk == 3:   # (four running output pointers more)
+        if fullk == 2 and not act:   # (round 5: + the empty-wavefront test's mask, kept across phases A .. C)
             assert v["SGPRs Spill"] <= 16, (k, v)
+        if fullk == 3:   # (four running output pointers more)
+            assert v["SGPRs Spill"] <= 24, (k, v)
         if act:          # (the policy's pointers and the running output pointers; the weight ring must stay in registers: no scratch, above)
             assert block == 1024 and v["SGPRs Spill"] <= 32, (k, v)
     # the streaming actor (ev2g_mlp.h): ten instantiations (two shapes x {bf16 with eight wavefronts, float32 as two / three bf16 terms, bf16 with 32 rows per
