@@ -607,7 +607,7 @@ __device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t
     };
     // (requesting the head of the sequence a phase EARLIER in the step kernel -- behind phase E, D or C of the step before -- was tried: the whole ring
     // then lives across the step loop's back edge and the register allocator spills 40..119 registers; only layer 1's first tile (6 fragments)
-    // requested early fits -- and measured 1-2 % SLOWER than this, tools/gpu_r5e.sh: the head's latency is not what the policy phase waits for)
+    // requested early fits -- and measured 1-2 % SLOWER than this, docs/history/experiments/round5/gpu_r5e.sh: the head's latency is not what the policy phase waits for)
 #pragma unroll
     for (int sq = 0; sq < RING; sq++) request(sq);
     // first barrier: every wavefront's observation columns of the step before (or the prologue's rows) are in bufX, and nobody still reads the
