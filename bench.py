@@ -794,7 +794,7 @@ def main():
             strided = strided_record(eng, loop, E, P, D, T, dev, bytes_env_step, (roof.get("persistent") or {}).get("avg_launch_us"))
         except Exception as ex:   # (a record next to the headline: never lets the line fail)
             strided = {"error": f"{type(ex).__name__}: {ex}"}
-    if actor is None and not stub and not args.only_timed and not args.no_other_workloads and args.workload == "cfg2":
+    if actor is None and not stub and not args.only_timed and not args.no_other_workloads and args.workload == "cfg2" and world == 1:   # (N = 1 records, like cpu_baseline)
         others = {}
         for name in ("cfg3", "cfg4"):
             Eo = max(64, WORKLOADS[name]["envs"] * E // wl["envs"])
