@@ -206,3 +206,52 @@ def test_fused_launch_randomised_shapes_equal_the_two_kernel_chain(case, monkeyp
     assert s1 == ({4} if fused else s2) and 4 not in s2, (s1, s2, C, E, state, reward)
     for k in two:
         assert np.array_equal(one[k], two[k], equal_nan=True), (k, C, E, state, reward, segs)
+
+
+@pytest.mark.parametrize("no_dict", [False, True])
+def test_fused_launch_on_a_device_refilled_pool(no_dict, monkeypatch):
+    """The fused actor + step launch on scenarios drawn ON THE DEVICE (port state lines, SessDyn / dictionary entries and occupancy masks written by
+    ev2g_refill_kernel), with and without the battery-maths dictionary: equal to the two-kernel chain on the same refilled pool, bit for bit."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.actor import init_mlp_weights
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    E, M = 23, 46
+    if no_dict:
+        monkeypatch.setenv("EV2G_NO_DICT", "1")
+    else:
+        monkeypatch.delenv("EV2G_NO_DICT", raising=False)
+    cfg = GenConfig.v2g_profit_plus_loads(M, 50, 1, seed=61)
+    pool = generate_native(cfg)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("EV2G_NO_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("EV2G_NO_FUSED", "1")
+        eng = Engine(pool, _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"],
+                     flags=_abi.FLAG_LOG_SOC | _abi.FLAG_REFILLABLE, n_active_envs=E)
+        eng.pool_refill(cfg, 61, 900, 0, M)   # scenarios 900.. of the stream: none of them was loaded
+        P, D, T = eng.P, eng.D, eng.T
+        mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=2), out_lo=-1.0)
+        obs, act = eng.empty((T + 1, E, D), np.float32), eng.empty((T, E, P), np.float32)
+        rew, done, mask = eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
+        eng.reset_f32(obs, 7)
+        t = 0
+        for k in (50, 1, 61):
+            eng.collect(mlp, k, obs.at(t * E * D), act.at(t * E * P), rew.at(t * E), done.at(t * E), mask.at(t * E * P))
+            t += k
+        spec = eng.last_launch_specialisation
+        out = dict(obs=obs.to_host(), act=act.to_host(), rew=rew.to_host(), done=done.to_host(), mask=mask.to_host(), stats=eng.stats().copy())
+        eng.check_faults()
+        assert eng.pool_refill_overflows == 0
+        eng.mlp_destroy(mlp)
+        eng.close()
+        return spec, out
+
+    s2, two = run(False)
+    s1, one = run(True)
+    assert s1 == 4 and s2 != 4
+    assert two["mask"].any() and np.abs(two["act"]).max() > 0.05
+    for k in two:
+        assert np.array_equal(one[k], two[k], equal_nan=True), k
