@@ -255,3 +255,44 @@ def test_fused_launch_on_a_device_refilled_pool(no_dict, monkeypatch):
     assert two["mask"].any() and np.abs(two["act"]).max() > 0.05
     for k in two:
         assert np.array_equal(one[k], two[k], equal_nan=True), k
+
+
+def test_fused_launch_at_the_benchmarked_size_equals_the_two_kernel_chain(monkeypatch):
+    """BASELINE configs[4]'s per-GPU shard (4096 envs x 50 chargers), a whole episode as ONE fused launch (what bench.py's `rollout` record and the
+    collector time) against 112 x (actor launch, step launch): a full grid of 256 workgroups x 1024 threads, every transition row, the
+    statistics of every env, bit for bit."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.actor import init_mlp_weights
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    E = 4096
+    pool = generate_native(GenConfig.v2g_profit_plus_loads(E, 50, 1, seed=77)).sorted_by_busy_window(E)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("EV2G_NO_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("EV2G_NO_FUSED", "1")
+        eng = Engine(pool, _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"], flags=_abi.FLAG_LOG_SOC)
+        P, D, T = eng.P, eng.D, eng.T
+        mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=4), out_lo=-1.0)
+        obs, act = eng.empty((T + 1, E, D), np.float32), eng.empty((T, E, P), np.float32)
+        rew, done, mask = eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
+        eng.reset_f32(obs, 0)
+        eng.collect(mlp, T, obs, act, rew, done, mask)
+        spec = eng.last_launch_specialisation
+        out = dict(act=act.to_host(), rew=rew.to_host(), done=done.to_host(), mask=mask.to_host(), stats=eng.stats().copy())
+        o = obs.to_host()
+        out["obs_rows"] = np.stack([o[t] for t in (0, 1, 2, T // 2, T - 1, T)])
+        out["obs_sum"] = o.astype(np.float64).sum(axis=(1, 2))
+        del o
+        eng.check_faults()
+        eng.mlp_destroy(mlp)
+        eng.close()
+        return spec, out
+
+    s2, two = run(False)
+    s1, one = run(True)
+    assert s1 == 4 and s2 != 4
+    for k in two:
+        assert np.array_equal(one[k], two[k], equal_nan=True), k
