@@ -63,6 +63,7 @@ struct ev2g_handle {
     } refill_cache;
     int sess_cap = 0;                           // EV2G_FLAG_REFILLABLE: session slots per scenario of the resident pool (0: packed storage)
     bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
+    int wave_epw = 1, wave_es = 64;             // ... its envs per wavefront and the lane stride between them (WaveArgs::epw / es)
     bool no_full = false, no_wide = false;      // EV2G_NO_FULL / EV2G_NO_WIDE at load time: A/B and routing tests only
     bool no_strided = false;                    // EV2G_NO_STRIDED at load time: strided outputs run the general instantiation (round 4's routing; parity tests)
     // battery-maths dictionary (ClsRec, ev2g_device.h): host mirror of the entries in use, so that ev2g_pool_refill can append the
@@ -84,6 +85,8 @@ struct ev2g_handle {
     // reads their durations afterwards (bench.py's roofline pass) does not have to drain the stream after each one
     hipEvent_t ev0s[EV2G_EV_RING] = {}, ev1s[EV2G_EV_RING] = {};
     int ev_slot = 0;
+    bool ev_valid[EV2G_EV_RING] = {};          // the slot's closing event was recorded (a call that failed half-way leaves it false: its duration reads -1)
+    unsigned fused_attr_mask = 0;               // fused instantiations whose dynamic-LDS attribute was set for THIS handle's device (bit = state kind * 4 + reward kind)
     long long ev_calls = 0;
     bool timed = false;
     std::string err;
@@ -522,7 +525,12 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
                                                      (h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) ? (unsigned long long)T * E * C * 8 : 0ull});
         if (biggest >= lim) { h->wave_path = false; h->fallback_reason = "an array of the batch reaches 4 GiB (32-bit byte offsets)"; }
     }
-    if (h->wave_path) s.G = (EV2G_WAVE_BLOCK / 64) * (64 / P);   // wave-aligned: 64/P envs per wavefront
+    if (h->wave_path) {   // wave-aligned: 64/P envs per wavefront, packed (EV2G_EPW_CAP / EV2G_EPW_ALIGN: A/B switches, read at load)
+        h->wave_epw = 64 / P; h->wave_es = P;
+        if (const char *c = std::getenv("EV2G_EPW_CAP")) h->wave_epw = std::max(1, std::min(h->wave_epw, std::atoi(c)));
+        if (std::getenv("EV2G_EPW_ALIGN") && 64 / h->wave_epw >= P) h->wave_es = 64 / h->wave_epw;
+        s.G = (EV2G_WAVE_BLOCK / 64) * h->wave_epw;
+    }
     {   // EV2G_KERNEL=v2 forces the general kernel on the common shape (parity tests compare the two)
         const char *kn = std::getenv("EV2G_KERNEL");
         if (h->wave_path && kn && std::string(kn) == "v2") {
@@ -900,7 +908,7 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
         const DevState &st = h->st;
         const FusedArgs fa0{};
         const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.hist,
-                          st.env_acc, s.cs_pack, (char *)st.line, h->d_step_tab, (char *)st.port_dyn, s.dict};
+                          st.env_acc, s.cs_pack, (char *)st.line, h->d_step_tab, (char *)st.port_dyn, s.dict, h->wave_epw, h->wave_es};
         // every float64 output present, no extras, no charger histories: the specialisation without their checks (not for the run-time rewards)
         // ... in two flavours: float64 actions in / float64 observations out (a loop that consumes them, the benchmark), or the policy
         // network's hand-over, float32 actions in / float32 observations out and no float64 observation (ev2g_rollout)
@@ -1032,7 +1040,7 @@ int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, in
     (void)hipSetDevice(h->device);
     int rc = EV2G_OK;
     const long long adv = (auto_reset == EV2G_AUTO_RESET_NEXT) ? h->E % h->M : 0;   // pool offset advance per in-run reset
-    h->ev_slot = (h->ev_slot + 1) % EV2G_EV_RING; h->ev_calls += 1;
+    h->ev_slot = (h->ev_slot + 1) % EV2G_EV_RING; h->ev_calls += 1; h->ev_valid[h->ev_slot] = false;
     HIPCHK(h, hipEventRecord(h->ev0s[h->ev_slot], h->stream));
     if (mode == EV2G_STEPN_PERSISTENT) {
         int k = k_steps;
@@ -1060,7 +1068,7 @@ int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, in
                 h->current_step += kc;
                 i0 += kc;
             }
-            HIPCHK(h, hipEventRecord(h->ev1s[h->ev_slot], h->stream));
+            HIPCHK(h, hipEventRecord(h->ev1s[h->ev_slot], h->stream)); h->ev_valid[h->ev_slot] = true;
             h->timed = true;
             return rc;
         }
@@ -1093,7 +1101,7 @@ int ev2g_step_n(ev2g_handle *h, int k_steps, int mode, const double *actions, in
             h->current_step += 1;
         }
     }
-    HIPCHK(h, hipEventRecord(h->ev1s[h->ev_slot], h->stream));
+    HIPCHK(h, hipEventRecord(h->ev1s[h->ev_slot], h->stream)); h->ev_valid[h->ev_slot] = true;
     h->timed = true;
     return rc;
 }
@@ -1333,7 +1341,7 @@ static int launch_fused(ev2g_handle *h, const ev2g_mlp *m, int k, const float *o
         return fail(h, EV2G_ERR_ARG, "ev2g_collect / ev2g_rollout: a step stride is negative or reaches 4 GiB");
     StepIO io = make_io(h, nullptr, a_stride, nullptr, o_stride, reward, r_stride, done, d_stride, mask, m_stride, 0, 0);
     io.act32 = act; io.obs32 = obs;
-    const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.hist, st.env_acc, s.cs_pack, (char *)st.line, h->d_step_tab, (char *)st.port_dyn, s.dict};
+    const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.hist, st.env_acc, s.cs_pack, (char *)st.line, h->d_step_tab, (char *)st.port_dyn, s.dict, 1, s.P};
     FusedArgs fa{};
     fa.m = m->dev; fa.obs0 = obs0;
     const V2P *pp = (const V2P *)h->d_v2p;
@@ -1343,8 +1351,10 @@ static int launch_fused(ev2g_handle *h, const ev2g_mlp *m, int k, const float *o
 #define EV2G_FUSED_CASE(SK, RK)                                                                                                            \
     case SK * 4 + RK: {                                                                                                                    \
         auto kfn = ev2g_step_wave<SK, RK, true, 2, EV2G_FUSED_BLOCK, true>;                                                                 \
-        static bool attr_set = false;                                                                                                      \
-        if (!attr_set) { HIPCHK(h, hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; } \
+        if (!(h->fused_attr_mask & (1u << (SK * 4 + RK)))) {   /* function attributes are per device: once per handle, not per process */       \
+            HIPCHK(h, hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+            h->fused_attr_mask |= 1u << (SK * 4 + RK);                                                                                     \
+        }                                                                                                                                  \
         hipLaunchKernelGGL(kfn, grid, block, lds, h->stream, pp, io, t0, k, 0, wa, fa);                                                     \
     } break;
     switch (s.state_kind * 4 + std::min(s.reward_kind, 3)) {
@@ -1390,7 +1400,7 @@ int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward,
         }
         return EV2G_OK;
     };
-    h->ev_slot = (h->ev_slot + 1) % EV2G_EV_RING; h->ev_calls += 1;
+    h->ev_slot = (h->ev_slot + 1) % EV2G_EV_RING; h->ev_calls += 1; h->ev_valid[h->ev_slot] = false;
     HIPCHK(h, hipEventRecord(h->ev0s[h->ev_slot], h->stream));
     int rc = EV2G_OK;
     static const bool use_graphs = [] { const char *e = std::getenv("EV2G_ROLLOUT_GRAPHS"); return !(e && e[0] == '0'); }();
@@ -1431,7 +1441,7 @@ int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward,
     } else {
         rc = enqueue(k_steps);
     }
-    HIPCHK(h, hipEventRecord(h->ev1s[h->ev_slot], h->stream));
+    HIPCHK(h, hipEventRecord(h->ev1s[h->ev_slot], h->stream)); h->ev_valid[h->ev_slot] = true;
     h->timed = true;
     return rc;
 }
@@ -1455,7 +1465,7 @@ int ev2g_collect(ev2g_handle *h, const ev2g_mlp *m, int k_steps, const ev2g_tran
     if (!direct && !(x.obs_f32 && x.actions_f32 && x.obs_f32_step_stride == 0))
         return fail(h, EV2G_ERR_ARG, "ev2g_collect: this configuration steps through the registered float32 hand-over buffers: register them with "
                                      "ev2g_set_step_extras (observation step stride 0) first");
-    h->ev_slot = (h->ev_slot + 1) % EV2G_EV_RING; h->ev_calls += 1;
+    h->ev_slot = (h->ev_slot + 1) % EV2G_EV_RING; h->ev_calls += 1; h->ev_valid[h->ev_slot] = false;
     HIPCHK(h, hipEventRecord(h->ev0s[h->ev_slot], h->stream));
     if (direct && k_steps >= 1 && fused_eligible(h, m)) {   // ONE launch for the segment: rows read and written in place, the policy inside the launch
         const int rc = launch_fused(h, m, k_steps, tr->obs, tr->obs + ED, (long long)ED, tr->actions, (long long)EP, tr->reward, h->E, tr->done, h->E, tr->mask, (long long)EP);
@@ -1482,7 +1492,7 @@ int ev2g_collect(ev2g_handle *h, const ev2g_mlp *m, int k_steps, const ev2g_tran
         }
         h->current_step += 1;
     }
-    HIPCHK(h, hipEventRecord(h->ev1s[h->ev_slot], h->stream));
+    HIPCHK(h, hipEventRecord(h->ev1s[h->ev_slot], h->stream)); h->ev_valid[h->ev_slot] = true;
     h->timed = true;
     return EV2G_OK;
 }
@@ -1494,6 +1504,7 @@ double ev2g_last_step_n_kernel_ms(ev2g_handle *h) {
 double ev2g_step_n_kernel_ms_back(ev2g_handle *h, int back) {
     if (!h || !h->timed || back < 0 || back >= EV2G_EV_RING || back >= h->ev_calls) return -1.0;
     const int slot = ((h->ev_slot - back) % EV2G_EV_RING + EV2G_EV_RING) % EV2G_EV_RING;
+    if (!h->ev_valid[slot]) return -1.0;
     if (hipEventSynchronize(h->ev1s[slot]) != hipSuccess) return -1.0;
     float ms = 0;
     if (hipEventElapsedTime(&ms, h->ev0s[slot], h->ev1s[slot]) != hipSuccess) return -1.0;

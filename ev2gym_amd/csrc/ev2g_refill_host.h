@@ -88,6 +88,8 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
         if (!spec_row.empty()) { int *p; if ((rc = upload(h, rc_.allocs, spec_row.data(), spec_row.size(), &p))) return rc; a.spec_row = p; }
         ev2g_gen_make_run(c, s.P, s.npc, seed, a.g0);
         a.cls_of = nullptr;
+        std::vector<int> cls_of;     // staging for asynchronous copies: these two live until the stream synchronisation below, like `pv`
+        std::vector<ClsRec> tab;     // (indexed by entry; only the new ones are filled)
         if (s.dict) {
             // every (car model, charger) pair the generator can draw gets its dictionary entry now -- the operands exactly as the kernel's
             // write_session forms them (ev2g_refill.h) -- so that the device only looks an index up; entries the loaded batch did not
@@ -97,8 +99,7 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
             const Ev2gFleet fleet = ev2g_fleet(g);
             const int n_models = c.heterogeneous_ev_specs ? fleet.n : 1;
             const Ev2gRng rng0 = ev2g_rng(seed, 0);
-            std::vector<int> cls_of((size_t)n_models * s.C);
-            std::vector<ClsRec> tab;   // (indexed by entry; only the new ones are filled)
+            cls_of.resize((size_t)n_models * s.C);
             const size_t n_before = h->cls_map.size();
             for (int m = 0; m < n_models; m++) {
                 Ev2gGenSession e{0, 1, 2, m, c.heterogeneous_ev_specs ? fleet.battery(m) : c.ev_battery_capacity,
@@ -114,6 +115,9 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
                     r.v = h->cs_vk_host[(size_t)cs * 4 + std::min(ph, f.phases)];
                     r.rB = 1.0 / r.B; r.rv = 1.0 / r.v;
                     const int k = cls_find_or_add(h->cls_map, tab, ev2g_cls_of(r));
+                    if (k < 0) {   // the entries this call added never reach the device: take them out of the host mirror again
+                        for (auto it = h->cls_map.begin(); it != h->cls_map.end();) it = ((size_t)it->second >= n_before) ? h->cls_map.erase(it) : std::next(it);
+                    }
                     if (k < 0) return fail(h, EV2G_ERR_ARG, "ev2g_pool_refill: the fleet would take the battery-maths dictionary beyond its " + std::to_string(EV2G_CLS_CAP) +
                                                                 " entries (load the pool with EV2G_NO_DICT=1)");
                     cls_of[(size_t)m * s.C + cs] = k;

@@ -124,6 +124,7 @@ struct WaveArgs {
     const double *step_tab;  // [M, T, 8]; slots 6, 7: the scenario's occupancy / arrival masks of the step
     char *port_dyn;          // [E*P] PortDyn: transition_soc, efficiencies, table id and dictionary entry of the attached EV
     int dict;                // DevScn::dict: V2P::cls_rec is a dictionary (entry = bits 20..31 of the port's LDS word); 0: one ClsRec per session
+    int epw, es;             // envs per wavefront (<= 64 / P) and the lane stride between them (>= P; P: packed, 64 / epw: aligned to lane rows)
 };
 
 // IO32: the actions are float32 (StepIO::act32) -- the policy-network interface; float32 observations (StepIO::obs32) are
@@ -174,7 +175,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
 #define PA(k) (slabP + PS8 * (unsigned long long)(k))
     // envs per wavefront.  The fused instantiation gives EVERY env a wavefront of its own, whatever its width (a policy row is an env: 16 rows per
     // workgroup; the step's time is a chain of latencies, not lanes): the lanes behind the env's last port only copy observation-head pairs
-    const int EPW = ACT ? 1 : 64 / P;
+    const int EPW = ACT ? 1 : wa.epw;
+    const int ES = ACT ? P : wa.es;      // lanes from one env of the wavefront to the next
     const int G = (BLOCK / 64) * EPW;    // envs per workgroup
     int grp;
     {   // XCD-aware mapping: workgroup b runs on XCD b % 8; give each XCD a contiguous range of env groups
@@ -214,10 +216,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     const bool pow2_dt = S->pow2_dt != 0;
 
     // ---- home lane set-up ----
-    const int elw = lane / P;            // env inside the wavefront
-    const int q = ACT ? lane : lane - elw * P;        // port slot (== reference port: one transformer, single-port chargers)
+    const int elw = lane / ES;           // env inside the wavefront
+    const int q = ACT ? lane : lane - elw * ES;       // port slot (== reference port: one transformer, single-port chargers)
     const int e = ACT ? e0 + wv : e0 + wv * EPW + elw;
-    const bool valid = (elw < EPW) && (e < E);
+    const bool valid = (elw < EPW) && (q < P) && (e < E);
     const bool hcopy = ACT && !valid && e < E && lane < 32;   // (ACT, envs narrower than their head pairs: lanes P .. NPAIR-1 copy the pairs the ports cannot)
     const int g = valid ? e * P + q : 0;
     const int ocol = (SK == 1) ? 3 + 3 * q : (SK == 0 ? 62 + 2 * q : 22 + 2 * q);
@@ -772,14 +774,14 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                     double ra0[NE], rb0[NE], ra1[NE], rb1[NE];
 #pragma unroll
                     for (int w = 0; w < NE; w++) {
-                        const double *r0 = row + wbase + w * P + j;
+                        const double *r0 = row + wbase + w * ES + j;
                         ra0[w] = r0[0]; rb0[w] = r0[8]; ra1[w] = 0.0; rb1[w] = 0.0;
                         if (upper) { ra1[w] = r0[16]; rb1[w] = r0[24]; }
                     }
                     double acc[NE];
 #pragma unroll
                     for (int w = 0; w < NE; w++) {
-                        const int a = wbase + w * P, b = a + P, i = a + j;
+                        const int a = wbase + w * ES, b = a + P, i = a + j;
                         double ac = 0.0, accb = 0.0;
                         ac += (i < b) ? ra0[w] : 0.0;
                         accb += (i + 8 < b) ? rb0[w] : 0.0;
@@ -793,7 +795,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
 #pragma unroll
                     for (int w = 0; w < NE; w++) acc[w] += xor4_f64(acc[w]);
 #pragma unroll
-                    for (int w = 0; w < NE; w++) if (j == 0) stage[k * RS + wbase + w * P] = acc[w];
+                    for (int w = 0; w < NE; w++) if (j == 0) stage[k * RS + wbase + w * ES] = acc[w];
                 };
                 if (EPW == 3) envs_at_once(std::integral_constant<int, 3>{});
                 else if (EPW == 2) envs_at_once(std::integral_constant<int, 2>{});
@@ -801,7 +803,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
 #endif
 #pragma unroll 1
                 for (int w = 0; w < EPW; w++) {
-                    const int a = wbase + w * P, b = a + P;
+                    const int a = wbase + w * ES, b = a + P;
                     const double *r0 = row + a + j;
                     const double ra0 = r0[0], rb0 = r0[8];
                     double ra1 = 0.0, rb1 = 0.0;
