@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libev2g_hip.so")
 SRC = os.path.join(HERE, "csrc", "ev2g_host.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("ev2g_device.h", "ev2g_step_v2.h", "ev2g_step_wave.h", "ev2g_mlp.h", "ev2g_comm.h", "ev2g_gen.h", "ev2g_gen_host.h", "ev2g_refill.h", "ev2g_refill_host.h")] + [
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("ev2g_device.h", "ev2g_step_v2.h", "ev2g_step_wave.h", "ev2g_step_big.h", "ev2g_mlp.h", "ev2g_comm.h", "ev2g_gen.h", "ev2g_gen_host.h", "ev2g_refill.h", "ev2g_refill_host.h")] + [
     os.path.join(HERE, "..", "include", "ev2g.h")]
 # -ffp-contract=off: the reference's operation order must survive (EV.my_ceil, ev.py:188-189)
 # -disable-machine-licm: the step kernels sit at the 128-VGPR / 4-waves-per-SIMD boundary; machine LICM hoists the constant

@@ -19,6 +19,7 @@
 #include "ev2g_device.h"
 #include "ev2g_step_v2.h"
 #include "ev2g_step_wave.h"
+#include "ev2g_step_big.h"
 #include "ev2g_mlp.h"
 #include "ev2g_comm.h"
 #include "ev2g_refill.h"
@@ -64,6 +65,10 @@ struct ev2g_handle {
     int sess_cap = 0;                           // EV2G_FLAG_REFILLABLE: session slots per scenario of the resident pool (0: packed storage)
     bool wave_path = false;                     // ev2g_step_wave: P <= 64, one transformer, single-port chargers
     int wave_epw = 1, wave_es = 64;             // ... its envs per wavefront and the lane stride between them (WaveArgs::epw / es)
+    bool big_path = false;                      // ev2g_step_big (512 < P <= 1024, two workgroups per CU) takes the launches ev2g_step_v2<1024, 1> would
+    std::string big_reason;                     // why not ("" when it does / when the shape is not a big env)
+    size_t lds_big = 0;
+    BigArgs big_args{};
     bool no_full = false, no_wide = false;      // EV2G_NO_FULL / EV2G_NO_WIDE at load time: A/B and routing tests only
     bool no_strided = false;                    // EV2G_NO_STRIDED at load time: strided outputs run the general instantiation (round 4's routing; parity tests)
     // battery-maths dictionary (ClsRec, ev2g_device.h): host mirror of the entries in use, so that ev2g_pool_refill can append the
@@ -659,6 +664,46 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
         }
         UP(dp, cs_pack) s.cs_pack = dp;
     }
+    {   // ev2g_step_big (ev2g_step_big.h): big single-env workgroups with two ports per home lane.  What it needs beyond the launch-time conditions
+        // of the specialised instantiation: single-port chargers, at most 64 transformers, at most EV2G_BIG_NCC distinct charger tuples, windows that fit
+        // 16-bit step numbers.  EV2G_NO_BIG keeps ev2g_step_v2<1024> (A/B runs, parity tests).
+        h->big_path = false; h->big_reason.clear(); h->big_args = BigArgs{};
+        if (h->block == 1024 && !h->wave_path) {
+            std::vector<unsigned char> ccls(P);
+            std::vector<double> ctab;
+            bool many = false;
+            for (int q = 0; q < P && !many; q++) {
+                const int c = slot_cs[q];
+                const double r[6] = {b->cs_max_charge_current[c], b->cs_min_charge_current[c], b->cs_min_discharge_current[c], cs_dmax_abs[c], cs_maxp[c], cs_minp[c]};
+                int k = 0;
+                const int n = (int)(ctab.size() / 6);
+                while (k < n && std::memcmp(&ctab[(size_t)k * 6], r, sizeof r) != 0) k++;
+                if (k == n) { if (n == EV2G_BIG_NCC) { many = true; break; } ctab.insert(ctab.end(), r, r + 6); }
+                ccls[q] = (unsigned char)k;
+            }
+            int tmax = T, tmin = 0;
+            for (long long d = 0; d < SD; d++) if (dev_to_host[d] >= 0) { tmax = std::max({tmax, ss_tarr[d], ss_tdep[d]}); tmin = std::min({tmin, ss_tarr[d], ss_tdep[d]}); }
+            bool even = D % 2 == 0;
+            for (int q = 0; q < P; q++) even = even && slot_obs[q] % 2 == 0;
+            const size_t lb = ev2g_big_lds_bytes(P, R);
+            if (std::getenv("EV2G_NO_BIG")) h->big_reason = "EV2G_NO_BIG is set";
+            else if (npc != 1) h->big_reason = "multi-port chargers";
+            else if (sk != EV2G_STATE_V2G_PROFIT_MAX_LOADS) h->big_reason = "the state function is not V2G_profit_max_loads";
+            else if (R > 64) h->big_reason = "more than 64 transformers";
+            else if (many) h->big_reason = "more than 16 distinct charger constant tuples";
+            else if (tmax > EV2G_BIG_TMAX / 2 || tmin < -1) h->big_reason = "a session window or the episode length exceeds 16383 steps";
+            else if (!even || D >= 65536) h->big_reason = "observation columns are not 16-byte aligned pairs";
+            else if (lb > 80 * 1024) h->big_reason = "the port state exceeds half of a CU's LDS";
+            else if (E < 1) h->big_reason = "no envs";
+            else {
+                unsigned char *cp; UP(cp, ccls) h->big_args.slot_ccls = cp;
+                UP(dp, ctab) h->big_args.ccls_tab = dp;
+                h->big_args.ncc = (int)(ctab.size() / 6);
+                h->lds_big = lb; h->big_path = true;
+                HIPCHK(h, hipFuncSetAttribute((const void *)ev2g_step_big<EV2G_BIG_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+            }
+        }
+    }
     UPP(ip, b->cs_phases, C) s.cs_ph = ip;
     UP(ip, tr_seg) s.tr_seg = ip;
     UP(ip, tr_obs) s.tr_obs = ip;
@@ -989,7 +1034,12 @@ static int launch_steps(ev2g_handle *h, const StepIO &io, int t0, int k, int aut
                       io.reward && io.done && io.mask && !h->extras.cost && !h->extras.obs_f32 && !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) &&
                       (h->cfg.flags & EV2G_FLAG_LOG_SOC) && io.o_stride == 0 && io.r_stride == 0 && io.d_stride == 0 && io.m_stride == 0 &&
                       !auto_reset && t0 + k <= s.T && h->pow2_dt && !h->no_full;
-    h->last_spec = h->block ? (spec ? 1 : 0) : -1;
+    h->last_spec = h->block ? (spec ? (h->big_path ? 5 : 1) : 0) : -1;
+    if (spec && h->big_path) {   // big envs: 512 threads, two ports per home lane, two workgroups per CU (ev2g_step_big.h)
+        hipLaunchKernelGGL(ev2g_step_big<EV2G_BIG_BLOCK>, dim3(s.E), dim3(EV2G_BIG_BLOCK), h->lds_big, h->stream, (const V2P *)h->d_v2p, io, t0, k, h->big_args);
+        HIPCHK(h, hipGetLastError());
+        return EV2G_OK;
+    }
     if (spec) {
         switch (h->block) {
         case 256: hipLaunchKernelGGL((ev2g_step_v2<256, 1>), dim3(s.n_groups), dim3(256), h->lds_bytes, h->stream, (const V2P *)h->d_v2p, io, t0, k, auto_reset); break;

@@ -1,0 +1,458 @@
+// ev2g_step_big.h -- the step kernel for BIG envs (512 < P <= 1024 ports, one env per workgroup; BASELINE configs[3]: 1000 chargers on
+// 50 transformers), launched the way ev2g_step_v2<.., SPEC = 1> is (default plugin pair, every float64 output with step stride 0, SoC log on).
+//
+// Why it exists (round 6).  ev2g_step_v2<1024> needs one 1024-thread workgroup per env and 148 bytes of LDS per port: ONE workgroup per CU, by
+// registers (16 wavefronts x 128 VGPRs) and by LDS (148 KB) alike.  Its step is a chain of phases separated by barriers -- home lanes, then the
+// battery maths on a fifth of the lanes, then home lanes again, a reduction, one wavefront of env-level work -- and with a single workgroup
+// resident nothing overlaps that chain: the CU streams its 91 KB per env-step at about half of what it could (0.41 of the roofline, traffic 1.05 x
+// algorithmic: the one BASELINE shape that really streams).  This kernel runs the same step with 512 threads, TWO PORTS PER HOME LANE, and 70
+// bytes of LDS per port, so that TWO workgroups (two envs) are resident per CU and one's memory phases run under the other's compute chain:
+//   * LDS per port: capacity, total / previous energy, abs-energy, battery size (40 B), two 8-byte hand-over words (amps -> energy, power), the
+//     window as two 16-bit step numbers, session index, one word of cycles | flags | charger class (12 B), a 2-byte work-list entry.  No per-port
+//     staging rows: the seven env-level sums are reduced from REGISTERS (DPP butterflies per wavefront, eight partials per quantity through LDS),
+//     only the port powers -- needed per transformer -- are staged, in the hand-over word the battery maths already writes;
+//   * what only the battery maths can know (the real current: over-current fault, the SoC log's activity sign, the last step's port readings) is
+//     written by the worker lane itself; the home lanes never read it back;
+//   * the charge-power-potential term of an attached EV is not kept in LDS: a lane whose EV stays fetches it from the port's own state line
+//     together with the departure / arrival operands (one request batch behind the battery maths);
+//   * charger constants come from a per-launch class table in LDS (<= 16 distinct charger tuples; the shipped configs have one);
+//   * one env per workgroup makes everything per-env wave-uniform: prices and scenario rows are scalar loads;
+//   * the 2000 window columns of the observation head (a copy of the scenario's window table row, state.py:128-151) are requested at the end of
+//     phase A and stored behind the battery maths by every wavefront: phase E is wavefront 0 alone, the others go straight into the next step;
+//   * three workgroup barriers per step (A | B | C + D | E), v2's one-env scheme has four.
+// Arithmetic: the same functions (ev_math_charge / ev_math_discharge, rnd5_x, ceil2_x) in the same order.  Transformer powers use v2's tree
+// (8 lanes per segment, two chains... one chain here as there: identical), so overloads agree bit for bit; the six env-level sums (profit, user term,
+// potential, charged / discharged energy, violations) use a different fixed tree than v2's (lane pair -> wavefront butterfly -> eight partials):
+// deterministic, but the last bit of reward / cost sums may differ from the general instantiation's (tests hold them to 1e-12, ints exactly).
+#pragma once
+#include "ev2g_step_v2.h"
+
+#define EV2G_BIG_BLOCK 512
+#define EV2G_BIG_NCC 16          // charger classes (distinct constant tuples) the LDS table holds
+#define EV2G_BIG_TMAX 32766      // windows are kept as 16-bit step numbers (0x7fff = none)
+
+struct BigArgs {
+    const unsigned char *slot_ccls;   // [P] charger class of every port slot
+    const double *ccls_tab;           // [ncc][6] imax, imin, dmin, |dmax|, max power, min power
+    int ncc;
+};
+
+__host__ __device__ inline size_t ev2g_big_lds_bytes(int P, int R) {
+    const size_t NP = ((size_t)P + 1) & ~(size_t)1;
+    return 8 * (7 * NP + (size_t)R + 5 * 8 + 8 + 8 + (size_t)EV2G_BIG_NCC * 6) + 4 * (3 * NP + 2 * (size_t)R + 4) + 2 * NP;
+}
+
+__device__ __forceinline__ int big_pack16(int v) { return (v == EV2G_INT_MAX) ? 0x7fff : (v & 0xffff); }
+__device__ __forceinline__ int big_unpack16(int v16) { const int v = (int)(short)v16; return (v == 0x7fff) ? EV2G_INT_MAX : v; }
+
+// uniform (scalar-cache) load of a read-only scenario value
+template <class T> __device__ __forceinline__ T big_sld(EV2G_GP(const T) p, long long i) {
+    return *((const T __attribute__((address_space(4))) *)(unsigned long long)p + i);
+}
+
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict__ params, StepIO io, int t0, int k_steps, BigArgs ba) {
+    extern __shared__ double lds[];
+    typedef const V2P __attribute__((address_space(4))) *ParamPtr;
+    ParamPtr S = (ParamPtr)(unsigned long long)params;
+    constexpr int NW = BLOCK / 64;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const int P = S->P, R = S->R, T = S->T, C = S->C, E = S->E, D = S->D, M = S->M;
+    int e;
+    {   // XCD-aware mapping: workgroup b runs on XCD b % 8; give each XCD a contiguous range of envs
+        const int nb = gridDim.x, b = blockIdx.x, per = nb >> 3;
+        e = (nb & 7) == 0 ? (b & 7) * per + (b >> 3) : b;
+    }
+    if (e >= E) return;
+    const int scn = ev2g_scn(e, io.scn_off, M);
+    const int NP = (P + 1) & ~1;
+    double *s_cap = lds, *s_tot = s_cap + NP, *s_prev = s_tot + NP, *s_abse = s_prev + NP, *s_bcap = s_abse + NP;
+    double *s_x = s_bcap + NP;        // phase A: amps; phase B: EV.current_energy of the step
+    double *s_y = s_x + NP;           // the port's power this step (0 unless the battery maths writes it): what the transformers add up
+    double *tsum = s_y + NP;          // [R] power of every transformer's chargers
+    double *wsum = tsum + R;          // [5][NW] per-wavefront partial sums: profit, user term, potential, charged, discharged
+    double *eacc = wsum + 5 * NW;     // [5] episode accumulators (+ 3 pad)
+    double *emg = eacc + 8;           // [NW] emergency-capacity violations of the step, per wavefront (counts)
+    double *ctab = emg + 8;           // [NCC][6] charger classes
+    int *s_tatd = (int *)(ctab + EV2G_BIG_NCC * 6);   // t_arr | t_dep << 16 of the attached-or-next session
+    int *s_ss = s_tatd + NP;
+    int *s_cycd = s_ss + NP;          // bit 0: cap/tot/prev/cycles changed, 1: window changed, 2: violation this step, 3: this step's item charged (else discharged);
+                                      // bits 8..23 charging cycles; bits 24..27 charger class
+    int *seg = s_cycd + NP, *trobs = seg + R + 1, *cnt = trobs + R;
+    unsigned short *items = (unsigned short *)(cnt + 3);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double dtd = (double)S->dt, sixty_over_dt = S->sixty_over_dt, dt_over_60 = S->dt_over_60;
+
+    // ---- launch prologue: this lane's two ports, global state -> LDS ----
+    int pk[2];          // action / mask index of the slot (low 16 bits) | its first observation column (high 16 bits)
+    double a_next[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int q = tid + u * BLOCK;
+        const bool valid = q < P;
+        const int qc = valid ? q : 0;
+        const int pref = S->slot_port[qc];
+        pk[u] = pref | (S->slot_obs[qc] << 16);
+        a_next[u] = io.actions[e * P + pref];
+        if (valid) {
+            const EV2G_GP(PortLine) ln = S->line + (e * P + q);
+            const int ta = ln->ta, td = ln->td;
+            s_tatd[q] = (int)((unsigned)big_pack16(ta) | ((unsigned)big_pack16(td) << 16));
+            s_ss[q] = ln->ss;
+            s_cycd[q] = (ev2g_line_cycles(ln->cyc_lut) << 8) | ((int)ba.slot_ccls[q] << 24);
+            const bool body = (ta <= t0) && (t0 <= td);
+            s_cap[q] = body ? ln->cap : 0.0; s_tot[q] = body ? ln->tot : 0.0; s_prev[q] = body ? ln->prev : 0.0;
+            s_abse[q] = body ? ln->abse : 0.0; s_bcap[q] = body ? ln->bcap : 1.0;
+        }
+    }
+    if (tid < 3) cnt[tid] = 0;
+    for (int i = tid; i <= R; i += BLOCK) seg[i] = S->tr_seg[i];
+    for (int i = tid; i < R; i += BLOCK) trobs[i] = S->tr_obs[i];
+    if (tid < 8) eacc[tid] = 0.0;
+    for (int i = tid; i < EV2G_BIG_NCC * 6; i += BLOCK) ctab[i] = (i < ba.ncc * 6) ? ba.ccls_tab[i] : 0.0;
+    __syncthreads();
+    // the observation-head pairs this lane copies every step: pair pi = tid + u * BLOCK of the 20 R window-column pairs; transformer r = pi / 20, pair jj = pi % 20
+    int hp_src[2], hp_dst[2];   // double offsets inside the scenario's window block (without the step term) / inside the env's observation row; -1: none
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int pi = tid + u * BLOCK;
+        if (pi < 20 * R) { const int r = pi / 20, jj = pi - r * 20; hp_src[u] = r * (T + 1) * 40 + 2 * jj; hp_dst[u] = trobs[r] + 2 * jj; }
+        else { hp_src[u] = 0; hp_dst[u] = -1; }
+    }
+    const long long scnT = (long long)scn * T;
+    EV2G_GP(const double) win_base = S->win_tab + (long long)scn * R * (T + 1) * 40;
+    double *const obs_e = io.obs + (long long)e * D;
+    uint8_t *const mask_e = io.mask + (long long)e * P;
+    int t = t0;
+
+    PT_DECL
+    for (int kk = 0; kk < k_steps; kk++) {
+        PT_MARK(7)
+        asm volatile("" : "+s"(S));
+        int tid_l = tid;
+        asm volatile("" : "+v"(tid_l));
+        const int sstep = t + 1;
+        const bool last_step = (kk == k_steps - 1);
+        const int eP = e * P;
+
+        // ---------------- A: home lanes, charger level (ev_charger.py:137-186) ----------------
+        int tatd[2];
+        bool occ[2];
+        double amps[2];
+        {
+            int cw[2];
+            double capb[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int q = tid_l + u * BLOCK, qc = (q < P) ? q : 0;
+                tatd[u] = s_tatd[qc]; cw[u] = s_cycd[qc]; capb[u] = s_cap[qc];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int q = tid_l + u * BLOCK;
+                const bool valid = q < P;
+                const int ta = (int)(short)(tatd[u] & 0xffff), td = tatd[u] >> 16;   // (0x7fff = none: never reached by t)
+                occ[u] = valid && (ta <= t) && (t <= td);
+                amps[u] = 0.0;
+                if (occ[u]) {
+                    double a = a_next[u];
+                    // one port per charger: a / sum(a) = a / a and -a / a, exactly +-1 for every finite action (ev_charger.py:143-149)
+                    if (a > 1.0) a = 1.0;
+                    else if (a < -1.0) a = -1.0;
+                    const double x = rnd5_x(a);
+                    const double *ct = ctab + ((cw[u] >> 24) & 15) * 6;
+                    if (x > 0.0) { amps[u] = x * ct[0]; if (amps[u] < ct[1] - 0.01) amps[u] = 0.0; }
+                    else if (x < 0.0) { amps[u] = x * ct[3]; if (amps[u] > ct[2] - 0.01) amps[u] = ct[2]; }
+                    if (amps[u] == 0.0) {   // an attached EV that gets no current: EV.step(0) logs the SoC as inactive and returns (ev.py:156-163)
+                        S->soc_log[((long long)e * T + t) * P + q] = -capb[u];
+                        if (last_step) { S->port_energy[eP + q] = 0.0; S->port_current[eP + q] = 0.0; }
+                    }
+                }
+                if (valid) { s_x[q] = amps[u]; s_y[q] = 0.0; }
+            }
+        }
+        {   // compact the ports that have battery maths to do: charging items from the front of `items`, discharging ones from its back;
+            // one LDS atomic per wavefront and list (ballot + lane prefix count)
+            const unsigned long long mc0 = __ballot(amps[0] > 0.0), mc1 = __ballot(amps[1] > 0.0);
+            const unsigned long long md0 = __ballot(amps[0] < 0.0), md1 = __ballot(amps[1] < 0.0);
+            int bch = 0, bdis = 0;
+            if (lane == 0) {
+                if (mc0 | mc1) bch = atomicAdd(&cnt[0], __popcll(mc0) + __popcll(mc1));
+                if (md0 | md1) bdis = atomicAdd(&cnt[1], __popcll(md0) + __popcll(md1));
+            }
+            bch = __shfl(bch, 0, 64);
+            bdis = __shfl(bdis, 0, 64);
+#define EV2G_MBCNT(m) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
+            if (amps[0] > 0.0) items[bch + EV2G_MBCNT(mc0)] = (unsigned short)tid_l;
+            else if (amps[0] < 0.0) items[NP - 1 - (bdis + EV2G_MBCNT(md0))] = (unsigned short)tid_l;
+            if (amps[1] > 0.0) items[bch + __popcll(mc0) + EV2G_MBCNT(mc1)] = (unsigned short)(tid_l + BLOCK);
+            else if (amps[1] < 0.0) items[NP - 1 - (bdis + __popcll(md0) + EV2G_MBCNT(md1))] = (unsigned short)(tid_l + BLOCK);
+#undef EV2G_MBCNT
+        }
+        // ---- requests whose answers are consumed behind the battery maths: the next step's actions, this step's observation-head pairs ----
+        {
+            const bool more = (kk + 1 < k_steps);
+            const double *an = io.actions + (long long)(more ? kk + 1 : kk) * io.a_stride + eP;
+#pragma unroll
+            for (int u = 0; u < 2; u++) a_next[u] = __builtin_nontemporal_load(an + (pk[u] & 0xffff));
+        }
+        d2_t hp[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) hp[u] = __builtin_nontemporal_load((const d2_t __attribute__((address_space(1))) *)(win_base + (long long)sstep * 40 + hp_src[u]));
+        // |charge price| column of lanes 0..19 (state.py:121-129); clamped index, masked where it is stored (unconditional: a load in a branch that
+        // merges with a default costs a vmcnt(0) drain, ev2g_step_v2.h)
+        const double hprice = S->price_ch[scnT + min(sstep + min(tid_l, 19), T - 1)];
+        PT_MARK(0)
+        lds_barrier();
+        PT_MARK(1)
+
+        // ---------------- B: worker lanes, battery maths on the compact list ----------------
+        __builtin_amdgcn_s_setprio(3);
+        {
+            const int nch = cnt[0], ndis = cnt[1];
+            const int nchp = (nch + 63) & ~63;  // discharge items start on a wavefront boundary
+            for (int i = tid_l; i < nchp + ndis; i += BLOCK) {
+                int h = -1;
+                if (i < nch) h = items[i];
+                else if (i >= nchp) h = items[NP - 1 - (i - nchp)];
+                if (h >= 0) {
+                    const int ssh = s_ss[h];
+                    const char __attribute__((address_space(1))) *rp = (const char __attribute__((address_space(1))) *)(S->rec + ssh);
+                    union { SessRec r; d2_t v[8]; } rr;
+                    const int r_lut = S->ss_lut[ssh];
+                    const double cap0 = s_cap[h], prev0 = s_prev[h], tot0 = s_tot[h];
+                    const int cw0 = s_cycd[h];
+                    const int cyc0 = (cw0 >> 8) & 0xffff;
+                    const double amps_h = s_x[h];
+                    const double imax_h = ctab[((cw0 >> 24) & 15) * 6];
+                    double lutv = 1.0 / 100.0;
+                    EvRes o;
+                    if (i < nchp) {   // (uniform)
+#pragma unroll
+                        for (int c = 0; c < 5; c++) rr.v[c] = *(const d2_t __attribute__((address_space(1))) *)(rp + 16 * c);
+                        if (r_lut >= 0) { const int li = ev_lut_index(r_lut, amps_h); if (li >= 0) lutv = S->lut[li]; }
+                        o = ev_math_charge(rr.r, lutv, amps_h, cap0, prev0, tot0, cyc0, sixty_over_dt, dt_over_60, true, r_lut >= 0);
+                    } else {
+#pragma unroll
+                        for (int c = 3; c < 7; c++) rr.v[c] = *(const d2_t __attribute__((address_space(1))) *)(rp + 16 * c);
+                        if (r_lut >= 0) { const int li = ev_lut_index(r_lut, amps_h); if (li >= 0) lutv = S->lut[li]; }
+                        o = ev_math_discharge(rr.r, lutv, amps_h, cap0, prev0, tot0, cyc0, dtd, r_lut >= 0, S->rdt, S->dt_fdiv != 0);
+                    }
+                    const bool changed = o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0;
+                    s_cap[h] = o.cap;
+                    s_prev[h] = o.prev_power;
+                    s_tot[h] = o.tot_e;
+                    s_cycd[h] = (cw0 & 0x0f000003) | (o.cycles << 8) | (changed ? 1 : 0) | (o.emerg ? 4 : 0) | ((i < nch) ? 8 : 0);
+                    s_x[h] = o.energy;
+                    s_abse[h] += fabs(o.energy);
+                    s_y[h] = o.energy * 60.0 / dtd;
+                    // what only this lane knows -- the real current: over-current fault (ev_charger.py:203-205), activity sign of the SoC log
+                    // (historic_soc / active_steps, ev.py:156,162,185: capacity before the step, negated if inactive), the last step's readings
+                    if (o.current - 0.0001 > imax_h) S->env_fault[e] = 1;
+                    S->soc_log[((long long)e * T + t) * P + h] = (o.current != 0.0) ? cap0 : -cap0;
+                    if (last_step) { S->port_energy[eP + h] = o.energy; S->port_current[eP + h] = o.current; }
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // ---- behind the battery maths: the observation head (requested a phase ago), then the requests of phase C ----
+        if (tid_l < 20) obs_e[2 + tid_l] = (sstep + tid_l < T) ? fabs(hprice) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (hp_dst[u] >= 0) *(d2_t *)(obs_e + hp_dst[u]) = hp[u];
+        // Departures and arrivals are known before the step (occupancy does not depend on the actions).  An arrival takes {B, cap0, potc} from the
+        // session record, a departure {des, next window} from the session's tail entry, an EV that stays its potential term from the port's state
+        // line: three 8-byte loads per port from clamped (always valid) addresses; the conditions are applied where the values are consumed.
+        double pf_ra[2], pf_rb[2], pf_rc[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int q = tid_l + u * BLOCK;
+            const int ta = (int)(short)(tatd[u] & 0xffff), td = tatd[u] >> 16;
+            const bool ev_dep = occ[u] && t >= td, ev_arr = (q < P) && (ta == sstep), stays = occ[u] && td > sstep;
+            const int sse = (ev_dep || ev_arr) ? s_ss[q] : 0;
+            const char *rp = (const char *)((const SessRec *)S->rec + sse), *tp = (const char *)((const SessTail *)S->tail + sse);
+            const char *lp = (const char *)((const PortLine *)S->line + (eP + (stays ? q : 0)));
+            pf_ra[u] = *(const double *)(ev_arr ? rp + offsetof(SessRec, B) : tp + offsetof(SessTail, des));
+            pf_rb[u] = *(const double *)(ev_arr ? rp + offsetof(SessRec, cap0) : tp + offsetof(SessTail, nt_arr));   // (the window: two ints)
+            pf_rc[u] = *(const double *)(ev_arr ? rp + offsetof(SessRec, potc) : lp + offsetof(PortLine, potc));
+        }
+        PT_MARK(2)
+        lds_barrier();
+        PT_MARK(1)
+        if (tid_l < 2) cnt[tid_l] = 0;
+        // wavefront 0: the transformer series of this step (consumed in phase E, behind the next barrier)
+        const long long erT = ((long long)scn * R + min(tid_l & 63, R - 1)) * T + t;   // (every wavefront asks: same lines, and no divergent load)
+        const double pf_infl = S->tr_infl[erT], pf_solar = S->tr_solar[erT], pf_maxp = S->tr_maxp[erT], pf_minp = S->tr_minp[erT];
+        const double pf_pch = big_sld<double>(S->price_ch, scnT + t), pf_pdis = big_sld<double>(S->price_dis, scnT + t);
+
+        // ---------------- C: home lanes: departures, arrivals, observation columns ----------------
+        double v_profit = 0.0, v_sat = 0.0, v_pot = 0.0, v_ech = 0.0, v_edis = 0.0;
+        bool any_emerg[2] = {false, false};
+        {
+            int cw[2], ssq[2];
+            double capq[2], enq[2], bcq[2], abq[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int q = tid_l + u * BLOCK, qc = (q < P) ? q : 0;
+                cw[u] = s_cycd[qc]; ssq[u] = s_ss[qc]; capq[u] = s_cap[qc]; enq[u] = s_x[qc]; bcq[u] = s_bcap[qc]; abq[u] = s_abse[qc];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int q = tid_l + u * BLOCK;
+                if (q < P) {
+                    int ta = (int)(short)(tatd[u] & 0xffff), td = tatd[u] >> 16;
+                    double cap = capq[u], bcap = bcq[u], potc = pf_rc[u];
+                    int cwn = cw[u] & ~12;   // (the step's flags are consumed here)
+                    double profit = 0.0, satpen = 0.0, pot = 0.0;
+                    bool departed = false;
+                    if (occ[u]) {
+                        const double energy = enq[u];   // 0 for idle EVs (phase A stored amps == 0)
+                        if (energy != 0.0) {  // profit += |E| * price, by the sign of the ACTION (ev_charger.py:178,194); a charge step can return a
+                                              // tiny negative energy when ceil2 left the capacity above the battery size
+                            const double ae = fabs(energy);
+                            if (cw[u] & 8) { profit = ae * pf_pch; v_ech += ae; } else { profit = ae * pf_pdis; v_edis += ae; }
+                        }
+                        any_emerg[u] = (cw[u] & 4) != 0;
+                        if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
+                            const int ss = ssq[u];
+                            const double des = pf_ra[u];
+                            const double score = (cap < des - 0.001) ? cap / des : 1.0;
+                            satpen = 100.0 * exp(-10.0 * score);   // ProfitMax_TrPenalty_UserIncentives (reward.py:41-42)
+                            const int gc = e * C + S->slot_cs[q];
+                            __hip_atomic_fetch_add(&S->cs_served[gc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_add(&S->cs_sat_sum[gc], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            S->sess_final_cap[ss] = cap;
+                            S->sess_abs_e[ss] = abq[u];
+                            const int nta = __double2loint(pf_rb[u]), ntd = __double2hiint(pf_rb[u]);   // window of the port's next session
+                            departed = true;
+                            ta = (nta == EV2G_INT_MAX) ? 0x7fff : nta; td = (ntd == EV2G_INT_MAX) ? 0x7fff : ntd;
+                            s_tatd[q] = (int)((unsigned)(ta & 0xffff) | ((unsigned)td << 16));
+                            ssq[u] = (nta != EV2G_INT_MAX) ? ss + 1 : -1;
+                            s_ss[q] = ssq[u];
+                            cwn = (cwn & 0x0f000003) | 2;   // cycles = 0
+                        }
+                    }
+                    if (ta == sstep) {  // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
+                        double B = pf_ra[u], c0 = pf_rb[u];
+                        if (departed) {   // the next session arrives right behind a departure of this very step: its record was not the one requested
+                            const SessRec &r = *(const SessRec *)(S->rec + ssq[u]);
+                            B = r.B; c0 = r.cap0; potc = r.potc;
+                        }
+                        cap = c0; bcap = B;
+                        s_cap[q] = cap; s_tot[q] = 0.0; s_prev[q] = 0.0; s_bcap[q] = B; s_abse[q] = 0.0;
+                        cwn = (cwn & 0x0f000003) | 1;   // cycles = 0
+                        S->line[eP + q].bcap = B;
+                        S->line[eP + q].potc = potc;
+                        S->port_energy[eP + q] = 0.0;
+                        S->port_current[eP + q] = 0.0;
+                    }
+                    if (cwn != cw[u]) s_cycd[q] = cwn;
+                    const bool occ_after = (ta <= sstep) && (sstep <= td);
+                    mask_e[pk[u] & 0xffff] = occ_after ? 1 : 0;
+                    d2_t ov = {0.0, 0.0};
+                    if (occ_after) {
+                        const double soc = cap / bcap;
+                        ov.x = soc; ov.y = (double)(td - sstep);
+                        if (soc < 1.0 && td > sstep) pot = potc;  // utils.py:771
+                    }
+                    {   // per-charger clamp (utils.py:779-789)
+                        const double *ct = ctab + ((cwn >> 24) & 15) * 6;
+                        const double mx = ct[4], mn = ct[5];
+                        pot = (pot > mx) ? mx : ((pot < mn) ? 0.0 : pot);
+                    }
+                    *(d2_t *)(obs_e + ((unsigned)pk[u] >> 16)) = ov;
+                    v_profit += profit; v_sat += satpen; v_pot += pot;
+                }
+            }
+        }
+        // per-wavefront partial sums of the env-level quantities, from registers (fixed tree: lane pair, DPP butterflies, one partial per wavefront)
+        {
+            const double w_profit = wave_sum_dpp(v_profit), w_pot = wave_sum_dpp(v_pot);
+            const double w_ech = wave_sum_dpp(v_ech), w_edis = wave_sum_dpp(v_edis);
+            double w_sat = 0.0;
+            if (__ballot(v_sat != 0.0) != 0ull) w_sat = wave_sum_dpp(v_sat);   // (uniform; departures are rare)
+            const int n_em = __popcll(__ballot(any_emerg[0])) + __popcll(__ballot(any_emerg[1]));
+            if (lane == 0) {
+                wsum[0 * NW + wv] = w_profit; wsum[1 * NW + wv] = w_sat; wsum[2 * NW + wv] = w_pot; wsum[3 * NW + wv] = w_ech; wsum[4 * NW + wv] = w_edis;
+                emg[wv] = (double)n_em;
+            }
+        }
+        PT_MARK(3)
+        // ---------------- D: power per transformer: 8 lanes per segment, DPP butterfly (the tree of ev2g_step_v2's one-env scheme) ----------------
+        if (tid_l < R * 8) {
+            const int r = tid_l >> 3, j = tid_l & 7;
+            const int b = seg[r + 1];
+            double acc = 0.0;
+            for (int i = seg[r] + j; i < b; i += 8) acc += s_y[i];
+            acc += xor1_f64(acc);
+            acc += xor2_f64(acc);
+            acc += xor4_f64(acc);
+            if (j == 0) tsum[r] = acc;
+        }
+        PT_MARK(4)
+        lds_barrier();
+        PT_MARK(1)
+
+        // ---------------- E: wavefront 0: transformers (transformer.py:258-302), reward, histories; the others start the next step ----------------
+        if (tid_l < 64) {
+            double over100 = 0.0, trp = 0.0;
+            if (tid_l < R) {
+                trp = tsum[tid_l];
+                double ptr = pf_infl + pf_solar;
+                ptr += trp;
+                const double over = (ptr > pf_maxp + 0.0001 || ptr < pf_minp - 0.0001) ? fabs(ptr - pf_maxp) : 0.0;
+                S->hist[EV2G_HIST(e, t, T, R) + 2 + tid_l] = over;
+                if (last_step) S->tr_power_now[e * R + tid_l] = ptr;
+                over100 = 100.0 * over;
+            }
+            const double q_over = wave_sum_dpp(over100);
+            const double usage = wave_sum_dpp(trp);
+            double tot = 0.0;
+            if (tid_l < 6) {
+                const double *wp = (tid_l < 5) ? wsum + tid_l * NW : emg;
+#pragma unroll
+                for (int w = 0; w < NW; w++) tot += wp[w];
+            }
+            const double costs = readlane_f64(tot, 0), q_sat = readlane_f64(tot, 1), potn = readlane_f64(tot, 2);
+            const double q_ech = readlane_f64(tot, 3), q_edis = readlane_f64(tot, 4), q_emerg = readlane_f64(tot, 5);
+            if (tid_l == 0) {
+                double *const p_hist = (double *)S->hist;
+                p_hist[EV2G_HIST(e, t, T, R)] = usage;
+                if (sstep < T) p_hist[EV2G_HIST(e, sstep, T, R) + 1] = potn;
+                const double reward = costs - q_over - q_sat;   // ProfitMax_TrPenalty_UserIncentives (reward.py:34-44)
+                const double a0 = eacc[0] + reward, a1 = eacc[1] + costs, a2 = eacc[2] + q_ech, a3 = eacc[3] + q_edis, a4 = eacc[4] + q_emerg;
+                io.reward[e] = reward;
+                io.done[e] = (sstep >= T) ? 1 : 0;
+                obs_e[0] = (double)sstep;
+                obs_e[1] = usage;
+                if (sstep >= T || last_step) {  // flush the episode accumulators (get_statistics reads them)
+                    double *ga = (double *)S->env_acc + e * 8;
+                    ga[0] += a0; ga[1] += a1; ga[2] += a2; ga[3] += a3; ga[4] += a4;
+                    eacc[0] = 0.0; eacc[1] = 0.0; eacc[2] = 0.0; eacc[3] = 0.0; eacc[4] = 0.0;
+                } else { eacc[0] = a0; eacc[1] = a1; eacc[2] = a2; eacc[3] = a3; eacc[4] = a4; }
+            }
+        }
+        PT_MARK(5)
+        PT_STEP_END(false)
+        t += 1;
+        // no barrier here: the next step's phase A touches s_x / s_y / items / cnt and reads the port state, none of which phase E uses; tsum / wsum / emg are
+        // rewritten only behind two more barriers, which wavefront 0 takes part in
+    }
+    PT_FLUSH
+    // ---- write the LDS-resident port state back ----
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int q = tid + u * BLOCK;
+        if (q < P) {
+            const int cw = s_cycd[q];
+            EV2G_GP(PortLine) ln = S->line + (e * P + q);
+            if (cw & 2) { const int w = s_tatd[q]; ln->ta = big_unpack16(w & 0xffff); ln->td = big_unpack16((w >> 16) & 0xffff); }
+            if (cw & 3) {   // the line carries the efficiency-table id of the attached EV next to its cycle count (the fast path reads it from there)
+                const int ssd = s_ss[q];
+                ln->ss = ssd; ln->cyc_lut = ev2g_line_pack((cw >> 8) & 0xffff, ssd >= 0 ? S->ss_lut[ssd] : -1);
+            }
+            if (cw & 1) { ln->cap = s_cap[q]; ln->tot = s_tot[q]; ln->prev = s_prev[q]; ln->abse = s_abse[q]; }
+        }
+    }
+}

@@ -259,6 +259,10 @@ const char *ev2g_fallback_reason(const ev2g_handle *h);
  * Round 5: 3 = 2 for outputs with STEP STRIDES (float64 [K,E,*] observation / reward / done / mask blocks of a persistent launch, every step kept:
  * generate_trajectories.py:69-83 style use; needs what 2 needs); 4 = the fused actor + step launch of ev2g_rollout / ev2g_collect (the policy
  * evaluated inside the step kernel's launch, one launch per segment; below).
+ * Round 6: 5 = big envs (512 < ports <= 1024, single-port chargers, <= 64 transformers, <= 16 distinct charger tuples, windows below 16384 steps):
+ * what 1 covers is run by "ev2g_step_big" -- 512 threads, two ports per home lane, 70 bytes of LDS per port, TWO workgroups per CU.  Port state,
+ * observations, masks and transformer powers are bit-identical to 0 / 1; rewards and the episode sums of profits / energies come from a different
+ * fixed summation tree (last-bit differences, tests hold them to 1e-12).  EV2G_NO_BIG=1 at load time keeps 1.
  * Results are identical in all of them (tests/test_round3_gpu.py, test_round4_gpu.py, test_round5_gpu.py); EV2G_NO_FULL / EV2G_NO_WIDE /
  * EV2G_NO_STRIDED in the environment at load time force 0 / 1 / "strided outputs run 0"; EV2G_NO_DICT=1 at load time keeps the battery-maths operands
  * one record per session instead of in the per-model dictionary, EV2G_NO_FUSED=1 keeps ev2g_rollout / ev2g_collect at two launches per step. */

@@ -531,17 +531,36 @@ def test_general_kernel_specialisation_agrees_bit_for_bit(C, R, monkeypatch):
 
     s0, name, ref = run(True, True)
     assert s0 == 0
-    for per_step in (True, False):
-        s1, _, got = run(False, per_step)
-        assert s1 == 1, name
-        xa, xb = (ref["out"], got["out"]) if per_step else (ref["out"][-1:], got["out"])
-        for ta, tb in zip(xa, xb):
-            for u, v in zip(ta, tb):
-                assert np.array_equal(u, v, equal_nan=True)
-        assert np.array_equal(ref["stats"], got["stats"], equal_nan=True)
-        for pa, pb in zip(ref["peek"], got["peek"]):
-            for k in pa:
-                assert np.array_equal(np.asarray(pa[k]), np.asarray(pb[k]), equal_nan=True), k
+    big = C > 512   # big envs: `ev2g_step_big` (two ports per home lane, two workgroups per CU) takes the specialised launches (5); EV2G_NO_BIG keeps `ev2g_step_v2<1024, 1>`
+    for no_big in ((True, False) if big else (True,)):
+        monkeypatch.delenv("EV2G_NO_BIG", raising=False)
+        if no_big:
+            monkeypatch.setenv("EV2G_NO_BIG", "1")
+        # the big-env kernel adds the six env-level sums up in its own fixed tree (registers, not staging rows): rewards and the episode sums of
+        # profits / energies may differ in the last bit from the general instantiation's; everything else -- observations (incl. the power usage:
+        # same transformer tree), masks, done flags, every port's state -- is bit-identical
+        loose = big and not no_big
+        for per_step in (True, False):
+            s1, _, got = run(False, per_step)
+            assert s1 == (5 if loose else 1), name
+            xa, xb = (ref["out"], got["out"]) if per_step else (ref["out"][-1:], got["out"])
+            for ta, tb in zip(xa, xb):
+                for i, (u, v) in enumerate(zip(ta, tb)):
+                    if loose and i == 1:
+                        assert np.allclose(u, v, rtol=1e-12, atol=1e-12), "reward"
+                    else:
+                        assert np.array_equal(u, v, equal_nan=True), i
+            if loose:
+                assert np.allclose(ref["stats"], got["stats"], rtol=1e-12, atol=1e-12, equal_nan=True)
+            else:
+                assert np.array_equal(ref["stats"], got["stats"], equal_nan=True)
+            for pa, pb in zip(ref["peek"], got["peek"]):
+                for k in pa:
+                    if loose and k == "power_potential":   # (a history of one of the six sums)
+                        assert np.allclose(np.asarray(pa[k]), np.asarray(pb[k]), rtol=1e-12, atol=1e-12, equal_nan=True), k
+                    else:
+                        assert np.array_equal(np.asarray(pa[k]), np.asarray(pb[k]), equal_nan=True), k
+    monkeypatch.delenv("EV2G_NO_BIG", raising=False)
 
 
 @pytest.mark.parametrize("workload,K", [("cfg2", 112), ("cfg3", 112), ("cfg4", 5)])
@@ -579,9 +598,12 @@ def test_full_size_specialised_kernels_equal_the_general_ones(workload, K, monke
     eng.reset()
     for t in range(K):
         eng.step(d_act.at(t * E * P), obs, rew, done, mask)
-        assert eng.last_launch_specialisation == (2 if workload != "cfg4" else 1)
+        assert eng.last_launch_specialisation == (2 if workload != "cfg4" else 5)
         assert np.array_equal(obs.to_host(), G[t], equal_nan=True), f"obs[{t}]"
-        assert np.array_equal(rew.to_host(), R_[t]), f"reward[{t}]"
+        if workload == "cfg4":   # (ev2g_step_big: its own fixed tree for the env-level sums, see test_general_kernel_specialisation_agrees_bit_for_bit)
+            assert np.allclose(rew.to_host(), R_[t], rtol=1e-12, atol=1e-12), f"reward[{t}]"
+        else:
+            assert np.array_equal(rew.to_host(), R_[t]), f"reward[{t}]"
         assert np.array_equal(done.to_host(), DN[t]) and np.array_equal(mask.to_host(), MK[t]), f"done / mask [{t}]"
     if K == T:
         assert np.array_equal(np.nan_to_num(eng.stats()), np.nan_to_num(stats_general))

@@ -1,0 +1,88 @@
+"""Round 6: the big-env kernel (`ev2g_step_big`, BASELINE configs[3]) at full size over whole episodes; performance guards live in test_bench_gpu.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _close(a, b, what, tol=1e-9):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert (np.isnan(a) == np.isnan(b)).all(), f"{what}: NaN pattern differs"
+    err = np.nan_to_num(np.abs(a - b) / np.maximum(1.0, np.abs(np.nan_to_num(b))))
+    assert err.max(initial=0.0) <= tol, f"{what}: max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+@pytest.mark.parametrize("no_big", [False, True], ids=["ev2g_step_big", "ev2g_step_v2_1024_spec"])
+def test_cfg4_full_size_whole_episode_against_the_oracle(no_big, monkeypatch):
+    """BASELINE configs[3] at its full size (2048 envs x 1000 chargers / 50 transformers), a WHOLE 112-step episode in one persistent launch with
+    outputs overwritten in place (what the benchmark runs: no 7 GB observation block): every departure, arrival and statistic of the episode.
+    The CPU oracle replays a sample of envs with the same actions; compared are the last step's observation / reward / done / mask, all 17
+    statistics, and per sampled env the complete histories (power usage, charge-power potential, every transformer's overload), the final port
+    state (capacity, energies, cycles, attached session) and every session's capacity at departure."""
+    from bench import WORKLOADS
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine, host_uniform
+    from ev2gym_amd.scenario_gen import generate_native
+    from oracle.oracle import Oracle
+    wl = WORKLOADS["cfg4"]
+    E = wl["envs"]
+    batch = generate_native(wl["gen"](E, 11))
+    rk, sk = _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]]
+    monkeypatch.delenv("EV2G_NO_BIG", raising=False)
+    if no_big:
+        monkeypatch.setenv("EV2G_NO_BIG", "1")
+    eng = Engine(batch, rk, sk, device=0, flags=_abi.FLAG_LOG_SOC)
+    monkeypatch.delenv("EV2G_NO_BIG", raising=False)
+    P, D, T = eng.P, eng.D, eng.T
+    rng = np.random.default_rng(5)
+    sample = np.unique(np.concatenate([[0, 1, 7, 8, E // 2, E - 9, E - 2, E - 1], rng.choice(E, 12, replace=False)]))
+    assert len(sample) >= 16
+    acts = eng.empty((T, E, P))
+    a_s = np.empty((T, len(sample), P))
+    for t in range(T):   # one counter stream per step: the host twin regenerates a step's block without holding 1.8 GB
+        eng.fill_uniform(acts.at(t * E * P), E * P, 9000 + t, -1.0, 1.0)
+        a_s[t] = host_uniform(E * P, 9000 + t, -1.0, 1.0).reshape(E, P)[sample]
+    obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
+    eng.reset(obs)
+    eng.step_n(T, acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=True)
+    assert eng.last_launch_specialisation == (1 if no_big else 5), (eng.kernel_name, eng.last_launch_specialisation)
+    eng.check_faults()
+    ora = Oracle(batch.select(sample), rk, sk)
+    ora.reset()
+    for t in range(T):
+        o, r, d, m, rc = ora.step(a_s[t].copy())
+        assert rc == 0
+    assert np.array_equal(mask.to_host()[sample], m), "action mask after the last step"
+    assert np.array_equal(done.to_host()[sample], d) and d.all()
+    _close(obs.to_host()[sample], o, "last observation")
+    _close(rew.to_host()[sample], r, "last reward")
+    st = eng.stats()
+    _close(st[sample], ora.stats(), "episode statistics (17) of the sampled envs")
+    assert np.isfinite(np.nan_to_num(st)).all()
+    for i, e in enumerate(sample):
+        pk, po = eng.peek(int(e)), ora.peek(i)
+        _close(pk["power_usage"], po["usage"], f"env {e}: current_power_usage")
+        _close(pk["power_potential"], po["potential"], f"env {e}: charge_power_potential")
+        _close(pk["tr_overload"], po["tr_overload"], f"env {e}: tr_overload")
+        _close(pk["tr_power"], po["tr_power"], f"env {e}: transformer power")
+        _close(pk["port_capacity"], po["cap"], f"env {e}: capacity")
+        _close(pk["port_total_energy"], po["tot_e"], f"env {e}: total energy")
+        _close(pk["port_prev_power"], po["prev_power"], f"env {e}: previous power")
+        _close(pk["port_energy"], po["energy"], f"env {e}: current energy")
+        _close(pk["port_current"], po["current"], f"env {e}: actual current")
+        assert np.array_equal(pk["port_cycles"], po["cycles"]), f"env {e}: charging cycles"
+        assert np.array_equal(pk["port_session"], po["session"]), f"env {e}: attached sessions (arrival / departure indexing)"
+        assert np.array_equal(pk["session_port"], po["session_port"]), f"env {e}: first-free port assignment"
+        s0, s1 = batch.arrays["env_session_start"][e], batch.arrays["env_session_start"][e + 1]
+        gone = batch.arrays["ev_t_dep"][s0:s1] <= T - 1   # sessions whose departure the episode processed (the engine records the capacity AT departure)
+        assert gone.any()
+        _close(pk["session_final_cap"][gone], po["session_cap"][gone], f"env {e}: capacity at departure")
+    ora.close()
+    eng.close()
