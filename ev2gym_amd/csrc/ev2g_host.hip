@@ -698,6 +698,15 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
             else {
                 unsigned char *cp; UP(cp, ccls) h->big_args.slot_ccls = cp;
                 UP(dp, ctab) h->big_args.ccls_tab = dp;
+                std::vector<double> ptab(15, std::nan(""));   // the distinct potential terms of the loaded sessions (the first 15: any other value is fetched from the state line)
+                int npot = 0;
+                for (long long d = 0; d < SD && npot < 15; d++) {
+                    if (dev_to_host[d] < 0) continue;
+                    int k = 0;
+                    while (k < npot && ptab[(size_t)k] != recs[d].potc) k++;
+                    if (k == npot) ptab[(size_t)npot++] = recs[d].potc;
+                }
+                UP(dp, ptab) h->big_args.potc_tab = dp;
                 h->big_args.ncc = (int)(ctab.size() / 6);
                 h->lds_big = lb; h->big_path = true;
                 HIPCHK(h, hipFuncSetAttribute((const void *)ev2g_step_big<EV2G_BIG_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));

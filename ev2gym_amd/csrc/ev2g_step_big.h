@@ -13,8 +13,10 @@
 //     only the port powers -- needed per transformer -- are staged, in the hand-over word the battery maths already writes;
 //   * what only the battery maths can know (the real current: over-current fault, the SoC log's activity sign, the last step's port readings) is
 //     written by the worker lane itself; the home lanes never read it back;
-//   * the charge-power-potential term of an attached EV is not kept in LDS: a lane whose EV stays fetches it from the port's own state line
-//     together with the departure / arrival operands (one request batch behind the battery maths);
+//   * the charge-power-potential term of an attached EV is not kept in LDS as a value: it takes a handful of distinct values (car model x charger),
+//     the launch holds them in a 15-entry LDS table and the port's word carries a 4-bit index (15: not in the table -- a device refill's new
+//     model -- fetch the port's own state line);
+//   * departures and arrivals are known before the step: their operands are requested in phase A, two barriers ahead of their use;
 //   * charger constants come from a per-launch class table in LDS (<= 16 distinct charger tuples; the shipped configs have one);
 //   * one env per workgroup makes everything per-env wave-uniform: prices and scenario rows are scalar loads;
 //   * the 2000 window columns of the observation head (a copy of the scenario's window table row, state.py:128-151) are requested at the end of
@@ -34,12 +36,13 @@
 struct BigArgs {
     const unsigned char *slot_ccls;   // [P] charger class of every port slot
     const double *ccls_tab;           // [ncc][6] imax, imin, dmin, |dmax|, max power, min power
+    const double *potc_tab;           // [15] the distinct charge-power-potential terms of the loaded sessions (unused entries: NaN)
     int ncc;
 };
 
 __host__ __device__ inline size_t ev2g_big_lds_bytes(int P, int R) {
     const size_t NP = ((size_t)P + 1) & ~(size_t)1;
-    return 8 * (7 * NP + (size_t)R + 5 * 8 + 8 + 8 + (size_t)EV2G_BIG_NCC * 6) + 4 * (3 * NP + 2 * (size_t)R + 4) + 2 * NP;
+    return 8 * (7 * NP + (size_t)R + 5 * 8 + 8 + 8 + (size_t)EV2G_BIG_NCC * 6 + 16) + 4 * (3 * NP + 2 * (size_t)R + 4) + 2 * (2 * NP);
 }
 
 __device__ __forceinline__ int big_pack16(int v) { return (v == EV2G_INT_MAX) ? 0x7fff : (v & 0xffff); }
@@ -74,12 +77,15 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
     double *eacc = wsum + 5 * NW;     // [5] episode accumulators (+ 3 pad)
     double *emg = eacc + 8;           // [NW] emergency-capacity violations of the step, per wavefront (counts)
     double *ctab = emg + 8;           // [NCC][6] charger classes
-    int *s_tatd = (int *)(ctab + EV2G_BIG_NCC * 6);   // t_arr | t_dep << 16 of the attached-or-next session
+    double *ptab = ctab + EV2G_BIG_NCC * 6;   // [16] distinct potential terms (entry 15 unused: index 15 = "not in the table, fetch the port's state line")
+    int *s_tatd = (int *)(ptab + 16);   // t_arr | t_dep << 16 of the attached-or-next session
     int *s_ss = s_tatd + NP;
     int *s_cycd = s_ss + NP;          // bit 0: cap/tot/prev/cycles changed, 1: window changed, 2: violation this step, 3: this step's item charged (else discharged);
-                                      // bits 8..23 charging cycles; bits 24..27 charger class
+                                      // bits 8..23 charging cycles; bits 24..27 charger class; bits 28..31 potential-term index of the attached EV
     int *seg = s_cycd + NP, *trobs = seg + R + 1, *cnt = trobs + R;
     unsigned short *items = (unsigned short *)(cnt + 3);
+    unsigned short *s_lut = items + NP;   // efficiency-table id + 1 of the attached EV (0: none), so that the battery maths issues the table look-up WITH the
+                                          // record loads, not behind a dependent fetch of the id
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double dtd = (double)S->dt, sixty_over_dt = S->sixty_over_dt, dt_over_60 = S->dt_over_60;
 
@@ -99,25 +105,35 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
             const int ta = ln->ta, td = ln->td;
             s_tatd[q] = (int)((unsigned)big_pack16(ta) | ((unsigned)big_pack16(td) << 16));
             s_ss[q] = ln->ss;
-            s_cycd[q] = (ev2g_line_cycles(ln->cyc_lut) << 8) | ((int)ba.slot_ccls[q] << 24);
+            s_lut[q] = (unsigned short)(ev2g_line_lut(ln->cyc_lut) + 1);
             const bool body = (ta <= t0) && (t0 <= td);
+            unsigned pidx = 15u;
+            if (body) { const double pc = ln->potc; for (int i = 14; i >= 0; i--) if (ba.potc_tab[i] == pc) pidx = (unsigned)i; }
+            s_cycd[q] = (int)((unsigned)(ev2g_line_cycles(ln->cyc_lut) << 8) | ((unsigned)ba.slot_ccls[q] << 24) | (pidx << 28));
             s_cap[q] = body ? ln->cap : 0.0; s_tot[q] = body ? ln->tot : 0.0; s_prev[q] = body ? ln->prev : 0.0;
             s_abse[q] = body ? ln->abse : 0.0; s_bcap[q] = body ? ln->bcap : 1.0;
         }
     }
+    // the first step's actions are collected HERE: a request still pending at the loop's entry would make every iteration's first use of the
+    // register a conservative vmcnt(0) -- a drain of the previous step's stores in the middle of phase A
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_next[0]), "+v"(a_next[1]));
     if (tid < 3) cnt[tid] = 0;
     for (int i = tid; i <= R; i += BLOCK) seg[i] = S->tr_seg[i];
     for (int i = tid; i < R; i += BLOCK) trobs[i] = S->tr_obs[i];
     if (tid < 8) eacc[tid] = 0.0;
     for (int i = tid; i < EV2G_BIG_NCC * 6; i += BLOCK) ctab[i] = (i < ba.ncc * 6) ? ba.ccls_tab[i] : 0.0;
+    if (tid < 16) ptab[tid] = (tid < 15) ? ba.potc_tab[tid] : 0.0;
     __syncthreads();
     // the observation-head pairs this lane copies every step: pair pi = tid + u * BLOCK of the 20 R window-column pairs; transformer r = pi / 20, pair jj = pi % 20
-    int hp_src[2], hp_dst[2];   // double offsets inside the scenario's window block (without the step term) / inside the env's observation row; -1: none
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int pi = tid + u * BLOCK;
-        if (pi < 20 * R) { const int r = pi / 20, jj = pi - r * 20; hp_src[u] = r * (T + 1) * 40 + 2 * jj; hp_dst[u] = trobs[r] + 2 * jj; }
-        else { hp_src[u] = 0; hp_dst[u] = -1; }
+    // ... and the 20 |charge price| columns (state.py:121-129) ride in pair slots 20 R .. 20 R + 19 (R <= 50: 1020 slots of 1024): hp_dst = -2 - column
+    // (the roles are re-derived from the lane id in every step -- a handful of integer operations and one LDS read -- instead of being kept in four
+    // registers across the loop: the kernel sits at the 128-register limit, and a spilled value comes back through vmcnt)
+#define EV2G_BIG_HP_ROLE(u, src, dst)                                                                                                    \
+    {                                                                                                                                    \
+        const int pi_ = tid_l + (u) * BLOCK;                                                                                             \
+        if (pi_ < 20 * R) { const int r_ = pi_ / 20, jj_ = pi_ - r_ * 20; src = r_ * (T + 1) * 40 + 2 * jj_; dst = trobs[r_] + 2 * jj_; } \
+        else if (pi_ < 20 * R + 20) { src = 0; dst = -2 - (pi_ - 20 * R); }                                                              \
+        else { src = 0; dst = -1; }                                                                                                      \
     }
     const long long scnT = (long long)scn * T;
     EV2G_GP(const double) win_base = S->win_tab + (long long)scn * R * (T + 1) * 40;
@@ -139,9 +155,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
         int tatd[2];
         bool occ[2];
         double amps[2];
+        double capb[2];   // capacity before the step: what the SoC log records (phase C writes it; the battery maths overwrites the LDS copy)
         {
             int cw[2];
-            double capb[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int q = tid_l + u * BLOCK, qc = (q < P) ? q : 0;
@@ -159,14 +175,13 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
                     // one port per charger: a / sum(a) = a / a and -a / a, exactly +-1 for every finite action (ev_charger.py:143-149)
                     if (a > 1.0) a = 1.0;
                     else if (a < -1.0) a = -1.0;
-                    const double x = rnd5_x(a);
+                    // rnd5 (ev_charger.py:157): |a| <= 1, so rint(a * 1e5) is inside the range in which the two-FMA form of the division by 1e5 is
+                    // exact (div_int_by_const, tests/test_fma_division.py): no fallback division to compile in
+                    const double n5 = rint(a * 100000.0), q5 = n5 * (1.0 / 100000.0);
+                    const double x = fma(fma(-q5, 100000.0, n5), 1.0 / 100000.0, q5);
                     const double *ct = ctab + ((cw[u] >> 24) & 15) * 6;
                     if (x > 0.0) { amps[u] = x * ct[0]; if (amps[u] < ct[1] - 0.01) amps[u] = 0.0; }
                     else if (x < 0.0) { amps[u] = x * ct[3]; if (amps[u] > ct[2] - 0.01) amps[u] = ct[2]; }
-                    if (amps[u] == 0.0) {   // an attached EV that gets no current: EV.step(0) logs the SoC as inactive and returns (ev.py:156-163)
-                        S->soc_log[((long long)e * T + t) * P + q] = -capb[u];
-                        if (last_step) { S->port_energy[eP + q] = 0.0; S->port_current[eP + q] = 0.0; }
-                    }
                 }
                 if (valid) { s_x[q] = amps[u]; s_y[q] = 0.0; }
             }
@@ -180,8 +195,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
                 if (mc0 | mc1) bch = atomicAdd(&cnt[0], __popcll(mc0) + __popcll(mc1));
                 if (md0 | md1) bdis = atomicAdd(&cnt[1], __popcll(md0) + __popcll(md1));
             }
-            bch = __shfl(bch, 0, 64);
-            bdis = __shfl(bdis, 0, 64);
+            bch = __builtin_amdgcn_readfirstlane(bch);
+            bdis = __builtin_amdgcn_readfirstlane(bdis);
 #define EV2G_MBCNT(m) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
             if (amps[0] > 0.0) items[bch + EV2G_MBCNT(mc0)] = (unsigned short)tid_l;
             else if (amps[0] < 0.0) items[NP - 1 - (bdis + EV2G_MBCNT(md0))] = (unsigned short)tid_l;
@@ -197,11 +212,50 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
             for (int u = 0; u < 2; u++) a_next[u] = __builtin_nontemporal_load(an + (pk[u] & 0xffff));
         }
         d2_t hp[2];
+        typedef double d2a8_t __attribute__((ext_vector_type(2), aligned(8)));
+        int hp_src[2], hp_dst[2];   // double offsets inside the scenario's window block (without the step term) / inside the env's observation row; -1: none
+        EV2G_BIG_HP_ROLE(0, hp_src[0], hp_dst[0])
+        EV2G_BIG_HP_ROLE(1, hp_src[1], hp_dst[1])
 #pragma unroll
-        for (int u = 0; u < 2; u++) hp[u] = __builtin_nontemporal_load((const d2_t __attribute__((address_space(1))) *)(win_base + (long long)sstep * 40 + hp_src[u]));
-        // |charge price| column of lanes 0..19 (state.py:121-129); clamped index, masked where it is stored (unconditional: a load in a branch that
-        // merges with a default costs a vmcnt(0) drain, ev2g_step_v2.h)
-        const double hprice = S->price_ch[scnT + min(sstep + min(tid_l, 19), T - 1)];
+        for (int u = 0; u < 2; u++) {   // ONE unconditional 16-byte load per slot from a selected, always valid address (a load in a branch that merges with a
+                                        // default costs a vmcnt(0) drain, ev2g_step_v2.h); a price lane reads the pair that holds its column (clamped inside the row)
+#ifdef EV2G_BIG_ABL_HP0   /* ablation (wrong results): the head rows of step 0 every step -- cache-resident instead of streamed */
+            EV2G_GP(const double) pw = win_base + hp_src[u];
+#else
+            EV2G_GP(const double) pw = win_base + (long long)sstep * 40 + hp_src[u];
+#endif
+            EV2G_GP(const double) pp = S->price_ch + scnT + min(sstep + (-2 - hp_dst[u]), T - 2);
+            hp[u] = __builtin_nontemporal_load((const d2a8_t __attribute__((address_space(1))) *)((hp_dst[u] < -1) ? pp : pw));
+        }
+        // Departures and arrivals are known before the step (occupancy does not depend on the actions): an arrival takes {B, cap0, potc} from the
+        // session record, a departure {des, next window} from the session's tail entry -- three 8-byte loads per port from clamped (always valid)
+        // addresses, requested HERE (a phase and two barriers ahead of their use in phase C; the registers are there: this kernel has no staging
+        // rows to address); the conditions are applied where the values are consumed.
+        // ONE set of operand registers per lane: a lane's two ports rarely have an event in the same step; when they do, the second port fetches
+        // its operands in phase C itself (`pf_u`: the port the set belongs to).
+        double pf_ra, pf_rb, pf_rc;
+        int pf_lut;   // efficiency-table id of an arriving session
+        int pf_u;
+        {
+            bool ev_dep[2], ev_arr[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int ta = (int)(short)(tatd[u] & 0xffff), td = tatd[u] >> 16;
+                ev_dep[u] = occ[u] && t >= td; ev_arr[u] = (tid_l + u * BLOCK < P) && (ta == sstep);
+            }
+            pf_u = (ev_dep[0] || ev_arr[0]) ? 0 : 1;
+            const bool ed = pf_u ? ev_dep[1] : ev_dep[0], ea = pf_u ? ev_arr[1] : ev_arr[0];
+            const int sse = (ed || ea) ? s_ss[tid_l + pf_u * BLOCK] : 0;
+            pf_lut = S->ss_lut[sse];
+            const char *rp = (const char *)((const SessRec *)S->rec + sse), *tp = (const char *)((const SessTail *)S->tail + sse);
+            pf_ra = *(const double *)(ea ? rp + offsetof(SessRec, B) : tp + offsetof(SessTail, des));
+            pf_rb = *(const double *)(ea ? rp + offsetof(SessRec, cap0) : tp + offsetof(SessTail, nt_arr));   // (the window: two ints)
+            pf_rc = *(const double *)(rp + offsetof(SessRec, potc));
+        }
+        // the transformer series of this step, for wavefront 0's phase E (every wavefront asks: same lines, no divergent load); inflexible load +
+        // solar power as their precomputed sum (Transformer.reset, transformer.py:262-263: the same addition, done once at load)
+        const long long erT = ((long long)scn * R + min(tid_l & 63, R - 1)) * T + t;
+        double pf_base = S->tr_base[erT], pf_maxp = S->tr_maxp[erT], pf_minp = S->tr_minp[erT];
         PT_MARK(0)
         lds_barrier();
         PT_MARK(1)
@@ -219,71 +273,79 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
                     const int ssh = s_ss[h];
                     const char __attribute__((address_space(1))) *rp = (const char __attribute__((address_space(1))) *)(S->rec + ssh);
                     union { SessRec r; d2_t v[8]; } rr;
-                    const int r_lut = S->ss_lut[ssh];
+                    const int r_lut = (int)s_lut[h] - 1;
                     const double cap0 = s_cap[h], prev0 = s_prev[h], tot0 = s_tot[h];
                     const int cw0 = s_cycd[h];
                     const int cyc0 = (cw0 >> 8) & 0xffff;
                     const double amps_h = s_x[h];
                     const double imax_h = ctab[((cw0 >> 24) & 15) * 6];
-                    double lutv = 1.0 / 100.0;
+                    // table entry and session record are independent loads: one memory round trip, not two.  The look-up is unconditional (clamped
+                    // index); whether it applies is decided where it is used.
+                    const int li = (r_lut >= 0) ? ev_lut_index(r_lut, amps_h) : -1;
+                    double lut_raw = S->lut[max(li, 0)];
                     EvRes o;
                     if (i < nchp) {   // (uniform)
 #pragma unroll
                         for (int c = 0; c < 5; c++) rr.v[c] = *(const d2_t __attribute__((address_space(1))) *)(rp + 16 * c);
-                        if (r_lut >= 0) { const int li = ev_lut_index(r_lut, amps_h); if (li >= 0) lutv = S->lut[li]; }
+                        asm volatile("" : "+v"(lut_raw), "+v"(rr.v[0]), "+v"(rr.v[1]), "+v"(rr.v[2]), "+v"(rr.v[3]), "+v"(rr.v[4]));
+                        const double lutv = (li >= 0) ? lut_raw : 1.0 / 100.0;
                         o = ev_math_charge(rr.r, lutv, amps_h, cap0, prev0, tot0, cyc0, sixty_over_dt, dt_over_60, true, r_lut >= 0);
                     } else {
 #pragma unroll
                         for (int c = 3; c < 7; c++) rr.v[c] = *(const d2_t __attribute__((address_space(1))) *)(rp + 16 * c);
-                        if (r_lut >= 0) { const int li = ev_lut_index(r_lut, amps_h); if (li >= 0) lutv = S->lut[li]; }
+                        asm volatile("" : "+v"(lut_raw), "+v"(rr.v[3]), "+v"(rr.v[4]), "+v"(rr.v[5]), "+v"(rr.v[6]));
+                        const double lutv = (li >= 0) ? lut_raw : 1.0 / 100.0;
                         o = ev_math_discharge(rr.r, lutv, amps_h, cap0, prev0, tot0, cyc0, dtd, r_lut >= 0, S->rdt, S->dt_fdiv != 0);
                     }
                     const bool changed = o.cycles != cyc0 || o.energy != 0.0 || o.cap != cap0 || o.prev_power != prev0;
                     s_cap[h] = o.cap;
                     s_prev[h] = o.prev_power;
                     s_tot[h] = o.tot_e;
-                    s_cycd[h] = (cw0 & 0x0f000003) | (o.cycles << 8) | (changed ? 1 : 0) | (o.emerg ? 4 : 0) | ((i < nch) ? 8 : 0);
+                    s_cycd[h] = (int)((unsigned)cw0 & 0xff000003u) | (o.cycles << 8) | (changed ? 1 : 0) | (o.emerg ? 4 : 0) | ((i < nch) ? 8 : 0) | ((o.current != 0.0) ? 16 : 0);
                     s_x[h] = o.energy;
                     s_abse[h] += fabs(o.energy);
                     s_y[h] = o.energy * 60.0 / dtd;
-                    // what only this lane knows -- the real current: over-current fault (ev_charger.py:203-205), activity sign of the SoC log
-                    // (historic_soc / active_steps, ev.py:156,162,185: capacity before the step, negated if inactive), the last step's readings
+                    // what only this lane knows -- the real current: over-current fault (ev_charger.py:203-205), the last step's reading, and whether the
+                    // step was active (flag 16: the SoC log's sign, written by the home lane in phase C).  No global store on this path in an
+                    // ordinary step: a store in flight here would have to drain before phase C may collect its requests
                     if (o.current - 0.0001 > imax_h) S->env_fault[e] = 1;
-                    S->soc_log[((long long)e * T + t) * P + h] = (o.current != 0.0) ? cap0 : -cap0;
-                    if (last_step) { S->port_energy[eP + h] = o.energy; S->port_current[eP + h] = o.current; }
+                    if (last_step) S->port_current[eP + h] = o.current;
                 }
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        // ---- behind the battery maths: the observation head (requested a phase ago), then the requests of phase C ----
-        if (tid_l < 20) obs_e[2 + tid_l] = (sstep + tid_l < T) ? fabs(hprice) : 0.0;
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-            if (hp_dst[u] >= 0) *(d2_t *)(obs_e + hp_dst[u]) = hp[u];
-        // Departures and arrivals are known before the step (occupancy does not depend on the actions).  An arrival takes {B, cap0, potc} from the
-        // session record, a departure {des, next window} from the session's tail entry, an EV that stays its potential term from the port's state
-        // line: three 8-byte loads per port from clamped (always valid) addresses; the conditions are applied where the values are consumed.
-        double pf_ra[2], pf_rb[2], pf_rc[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int q = tid_l + u * BLOCK;
-            const int ta = (int)(short)(tatd[u] & 0xffff), td = tatd[u] >> 16;
-            const bool ev_dep = occ[u] && t >= td, ev_arr = (q < P) && (ta == sstep), stays = occ[u] && td > sstep;
-            const int sse = (ev_dep || ev_arr) ? s_ss[q] : 0;
-            const char *rp = (const char *)((const SessRec *)S->rec + sse), *tp = (const char *)((const SessTail *)S->tail + sse);
-            const char *lp = (const char *)((const PortLine *)S->line + (eP + (stays ? q : 0)));
-            pf_ra[u] = *(const double *)(ev_arr ? rp + offsetof(SessRec, B) : tp + offsetof(SessTail, des));
-            pf_rb[u] = *(const double *)(ev_arr ? rp + offsetof(SessRec, cap0) : tp + offsetof(SessTail, nt_arr));   // (the window: two ints)
-            pf_rc[u] = *(const double *)(ev_arr ? rp + offsetof(SessRec, potc) : lp + offsetof(PortLine, potc));
-        }
         PT_MARK(2)
         lds_barrier();
         PT_MARK(1)
         if (tid_l < 2) cnt[tid_l] = 0;
-        // wavefront 0: the transformer series of this step (consumed in phase E, behind the next barrier)
-        const long long erT = ((long long)scn * R + min(tid_l & 63, R - 1)) * T + t;   // (every wavefront asks: same lines, and no divergent load)
-        const double pf_infl = S->tr_infl[erT], pf_solar = S->tr_solar[erT], pf_maxp = S->tr_maxp[erT], pf_minp = S->tr_minp[erT];
         const double pf_pch = big_sld<double>(S->price_ch, scnT + t), pf_pdis = big_sld<double>(S->price_dis, scnT + t);
+        // ONE collection point for everything requested in phase A, BEFORE this step's first global store: on gfx9-family ISAs vmcnt counts loads and
+        // stores together and they retire out of order with respect to each other, so a load consumed while younger stores are pending costs a
+        // full drain of those stores (ev2g_step_v2.h).  s_waitcnt vmcnt(0) expcnt(7) lgkmcnt(15); as outputs of the empty asm the registers are
+        // plain values from here on (also across the loop's back edge: the next step's actions).
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" : "+v"(a_next[0]), "+v"(a_next[1]), "+v"(hp[0]), "+v"(hp[1]), "+v"(pf_base), "+v"(pf_maxp), "+v"(pf_minp));
+        asm volatile("" : "+v"(pf_ra), "+v"(pf_rb), "+v"(pf_rc), "+v"(pf_lut));
+        // the observation head: |charge price| window and the transformers' load / PV / limit windows, copied from the scenario's tables
+        {
+            int tid_c = tid;
+            asm volatile("" : "+v"(tid_c));
+            const int tid_l = tid_c;   // (shadows: the roles again, not carried across the battery maths)
+            EV2G_BIG_HP_ROLE(0, hp_src[0], hp_dst[0])
+            EV2G_BIG_HP_ROLE(1, hp_src[1], hp_dst[1])
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+#ifdef EV2G_BIG_ABL_NOHS  /* ablation (wrong results): no head stores */
+            if (hp_dst[u] >= 0) asm volatile("" :: "v"(hp[u]));
+#else
+            if (hp_dst[u] >= 0) *(d2_t *)(obs_e + hp_dst[u]) = hp[u];
+#endif
+            else if (hp_dst[u] < -1) {   // a price column: zero past the horizon
+                const int c = -2 - hp_dst[u], k = sstep + c;
+                obs_e[2 + c] = (k < T) ? fabs((k > T - 2) ? hp[u].y : hp[u].x) : 0.0;
+            }
+        }
 
         // ---------------- C: home lanes: departures, arrivals, observation columns ----------------
         double v_profit = 0.0, v_sat = 0.0, v_pot = 0.0, v_ech = 0.0, v_edis = 0.0;
@@ -301,46 +363,67 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
                 const int q = tid_l + u * BLOCK;
                 if (q < P) {
                     int ta = (int)(short)(tatd[u] & 0xffff), td = tatd[u] >> 16;
-                    double cap = capq[u], bcap = bcq[u], potc = pf_rc[u];
-                    int cwn = cw[u] & ~12;   // (the step's flags are consumed here)
+                    double cap = capq[u], bcap = bcq[u];
+                    unsigned pidx = (unsigned)cw[u] >> 28;   // the attached EV's potential term: an index into the launch's value table (15: not in it)
+                    int cwn = cw[u] & ~28;   // (the step's flags are consumed here)
                     double profit = 0.0, satpen = 0.0, pot = 0.0;
                     bool departed = false;
+                    double e_ra = pf_ra, e_rb = pf_rb, e_rc = pf_rc;   // the event operands requested in phase A, if this is the port they were requested for
+                    int e_lut = pf_lut;
+                    const bool dep_now = occ[u] && t >= td;
+                    if ((dep_now || ta == sstep) && u != pf_u) {   // both ports of this lane have an event in this step (rare): fetch here, wait inside the branch
+                        const int sse = ssq[u];
+                        const char *rp = (const char *)((const SessRec *)S->rec + sse), *tp = (const char *)((const SessTail *)S->tail + sse);
+                        e_ra = *(const double *)(dep_now ? tp + offsetof(SessTail, des) : rp + offsetof(SessRec, B));
+                        e_rb = *(const double *)(dep_now ? tp + offsetof(SessTail, nt_arr) : rp + offsetof(SessRec, cap0));
+                        e_rc = *(const double *)(rp + offsetof(SessRec, potc));
+                        e_lut = S->ss_lut[sse];
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(e_ra), "+v"(e_rb), "+v"(e_rc), "+v"(e_lut));
+                    }
                     if (occ[u]) {
                         const double energy = enq[u];   // 0 for idle EVs (phase A stored amps == 0)
+                        // historic_soc / active_steps (ev.py:156,162,185): capacity before the step, negated if the step was inactive
+                        S->soc_log[((long long)e * T + t) * P + q] = (cw[u] & 16) ? capb[u] : -capb[u];
+                        if (last_step) { S->port_energy[eP + q] = energy; if (!(cw[u] & 16)) S->port_current[eP + q] = 0.0; }
                         if (energy != 0.0) {  // profit += |E| * price, by the sign of the ACTION (ev_charger.py:178,194); a charge step can return a
                                               // tiny negative energy when ceil2 left the capacity above the battery size
                             const double ae = fabs(energy);
                             if (cw[u] & 8) { profit = ae * pf_pch; v_ech += ae; } else { profit = ae * pf_pdis; v_edis += ae; }
                         }
                         any_emerg[u] = (cw[u] & 4) != 0;
-                        if (t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
+                        if (dep_now) {  // departure (ev_charger.py:209-229, ev.py:191-214)
                             const int ss = ssq[u];
-                            const double des = pf_ra[u];
+                            const double des = e_ra;
                             const double score = (cap < des - 0.001) ? cap / des : 1.0;
                             satpen = 100.0 * exp(-10.0 * score);   // ProfitMax_TrPenalty_UserIncentives (reward.py:41-42)
-                            const int gc = e * C + S->slot_cs[q];
+                            const int gc = e * C + (pk[u] & 0xffff);   // single-port chargers: the charger's index is the port's (a fetch of slot_cs here would drain this phase's stores)
                             __hip_atomic_fetch_add(&S->cs_served[gc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             __hip_atomic_fetch_add(&S->cs_sat_sum[gc], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             S->sess_final_cap[ss] = cap;
                             S->sess_abs_e[ss] = abq[u];
-                            const int nta = __double2loint(pf_rb[u]), ntd = __double2hiint(pf_rb[u]);   // window of the port's next session
+                            const int nta = __double2loint(e_rb), ntd = __double2hiint(e_rb);   // window of the port's next session
                             departed = true;
                             ta = (nta == EV2G_INT_MAX) ? 0x7fff : nta; td = (ntd == EV2G_INT_MAX) ? 0x7fff : ntd;
                             s_tatd[q] = (int)((unsigned)(ta & 0xffff) | ((unsigned)td << 16));
                             ssq[u] = (nta != EV2G_INT_MAX) ? ss + 1 : -1;
                             s_ss[q] = ssq[u];
-                            cwn = (cwn & 0x0f000003) | 2;   // cycles = 0
+                            cwn = (cwn & 0x0f000003) | 2;   // cycles = 0, no EV
                         }
                     }
                     if (ta == sstep) {  // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
-                        double B = pf_ra[u], c0 = pf_rb[u];
+                        double B = e_ra, c0 = e_rb, potc = e_rc;
+                        int lutn = e_lut;
                         if (departed) {   // the next session arrives right behind a departure of this very step: its record was not the one requested
                             const SessRec &r = *(const SessRec *)(S->rec + ssq[u]);
-                            B = r.B; c0 = r.cap0; potc = r.potc;
+                            B = r.B; c0 = r.cap0; potc = r.potc; lutn = S->ss_lut[ssq[u]];
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(B), "+v"(c0), "+v"(potc), "+v"(lutn));   // (the wait stays inside this rare branch)
                         }
+                        s_lut[q] = (unsigned short)(lutn + 1);
+                        pidx = 15u;
+                        for (int i = 14; i >= 0; i--) if (ptab[i] == potc) pidx = (unsigned)i;
                         cap = c0; bcap = B;
                         s_cap[q] = cap; s_tot[q] = 0.0; s_prev[q] = 0.0; s_bcap[q] = B; s_abse[q] = 0.0;
-                        cwn = (cwn & 0x0f000003) | 1;   // cycles = 0
+                        cwn = (int)(((unsigned)cwn & 0x0f000003u) | 1u | (pidx << 28));   // cycles = 0
                         S->line[eP + q].bcap = B;
                         S->line[eP + q].potc = potc;
                         S->port_energy[eP + q] = 0.0;
@@ -353,7 +436,13 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
                     if (occ_after) {
                         const double soc = cap / bcap;
                         ov.x = soc; ov.y = (double)(td - sstep);
-                        if (soc < 1.0 && td > sstep) pot = potc;  // utils.py:771
+                        if (soc < 1.0 && td > sstep) {  // utils.py:771
+                            if (pidx < 15u) pot = ptab[pidx];
+                            else {   // a value the loaded pool did not hold (a device refill's new car model): the state line has it
+                                pot = S->line[eP + q].potc;
+                                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pot));
+                            }
+                        }
                     }
                     {   // per-charger clamp (utils.py:779-789)
                         const double *ct = ctab + ((cwn >> 24) & 15) * 6;
@@ -398,7 +487,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
             double over100 = 0.0, trp = 0.0;
             if (tid_l < R) {
                 trp = tsum[tid_l];
-                double ptr = pf_infl + pf_solar;
+                double ptr = pf_base;
                 ptr += trp;
                 const double over = (ptr > pf_maxp + 0.0001 || ptr < pf_minp - 0.0001) ? fabs(ptr - pf_maxp) : 0.0;
                 S->hist[EV2G_HIST(e, t, T, R) + 2 + tid_l] = over;
