@@ -30,6 +30,9 @@
 #include "ev2g_step_v2.h"
 
 #define EV2G_BIG_BLOCK 512
+#ifndef EV2G_BIG_PRIO
+#define EV2G_BIG_PRIO 3
+#endif
 #define EV2G_BIG_NCC 16          // charger classes (distinct constant tuples) the LDS table holds
 #define EV2G_BIG_TMAX 32766      // windows are kept as 16-bit step numbers (0x7fff = none)
 
@@ -42,7 +45,7 @@ struct BigArgs {
 
 __host__ __device__ inline size_t ev2g_big_lds_bytes(int P, int R) {
     const size_t NP = ((size_t)P + 1) & ~(size_t)1;
-    return 8 * (7 * NP + (size_t)R + 5 * 8 + 8 + 8 + (size_t)EV2G_BIG_NCC * 6 + 16) + 4 * (3 * NP + 2 * (size_t)R + 4) + 2 * (2 * NP);
+    return 8 * (7 * NP + (size_t)R + 5 * 8 + 8 + 8 + (size_t)EV2G_BIG_NCC * 6 + 16) + 4 * (3 * NP + 2 * (size_t)R + 4 + 8) + 2 * (2 * NP + 2 * EV2G_BIG_BLOCK);
 }
 
 __device__ __forceinline__ int big_pack16(int v) { return (v == EV2G_INT_MAX) ? 0x7fff : (v & 0xffff); }
@@ -83,9 +86,12 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
     int *s_cycd = s_ss + NP;          // bit 0: cap/tot/prev/cycles changed, 1: window changed, 2: violation this step, 3: this step's item charged (else discharged);
                                       // bits 8..23 charging cycles; bits 24..27 charger class; bits 28..31 potential-term index of the attached EV
     int *seg = s_cycd + NP, *trobs = seg + R + 1, *cnt = trobs + R;
-    unsigned short *items = (unsigned short *)(cnt + 3);
+    int *cntev = cnt + 4;             // [NW] ports with a departure or an arrival in this step, per wavefront
+    unsigned short *items = (unsigned short *)(cntev + NW);
     unsigned short *s_lut = items + NP;   // efficiency-table id + 1 of the attached EV (0: none), so that the battery maths issues the table look-up WITH the
                                           // record loads, not behind a dependent fetch of the id
+    unsigned short *evl = s_lut + NP;     // [NW][128] the step's event ports, wavefront w's in lane order at evl + 128 w (a fixed place per wavefront: the
+                                          // order in which the LAST wavefront works them off -- and adds their terms up -- does not depend on timing)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double dtd = (double)S->dt, sixty_over_dt = S->sixty_over_dt, dt_over_60 = S->dt_over_60;
 
@@ -126,8 +132,6 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
     __syncthreads();
     // the observation-head pairs this lane copies every step: pair pi = tid + u * BLOCK of the 20 R window-column pairs; transformer r = pi / 20, pair jj = pi % 20
     // ... and the 20 |charge price| columns (state.py:121-129) ride in pair slots 20 R .. 20 R + 19 (R <= 50: 1020 slots of 1024): hp_dst = -2 - column
-    // (the roles are re-derived from the lane id in every step -- a handful of integer operations and one LDS read -- instead of being kept in four
-    // registers across the loop: the kernel sits at the 128-register limit, and a spilled value comes back through vmcnt)
 #define EV2G_BIG_HP_ROLE(u, src, dst)                                                                                                    \
     {                                                                                                                                    \
         const int pi_ = tid_l + (u) * BLOCK;                                                                                             \
@@ -135,11 +139,86 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
         else if (pi_ < 20 * R + 20) { src = 0; dst = -2 - (pi_ - 20 * R); }                                                              \
         else { src = 0; dst = -1; }                                                                                                      \
     }
+#define EV2G_BIG_HP_ROLE2(u, src, dst, tb)                                                                                                \
+    {                                                                                                                                    \
+        const int pi_ = tid_l + (u) * BLOCK;                                                                                             \
+        if (pi_ < 20 * R) { const int r_ = pi_ / 20, jj_ = pi_ - r_ * 20; src = r_ * (T + 1) * 40 + 2 * jj_; dst = (tb) + 2 * jj_; }       \
+        else if (pi_ < 20 * R + 20) { src = 0; dst = -2 - (pi_ - 20 * R); }                                                              \
+        else { src = 0; dst = -1; }                                                                                                      \
+    }
+    int hp_src[2], hp_dst[2];   // double offsets inside the scenario's window block (without the step term) / inside the env's observation row; -1: none
+    {
+        const int tid_l = tid;
+        EV2G_BIG_HP_ROLE(0, hp_src[0], hp_dst[0])
+        EV2G_BIG_HP_ROLE(1, hp_src[1], hp_dst[1])
+    }
     const long long scnT = (long long)scn * T;
     EV2G_GP(const double) win_base = S->win_tab + (long long)scn * R * (T + 1) * 40;
+    // The pointers every step uses, as per-env bases fetched ONCE: read through the parameter block where they are used (ev2g_step_v2's scheme, which
+    // keeps ~70 values out of the scalar registers) each costs a scalar-cache round trip on the step's chain -- phase A alone waited for four of them.
+    // One env per workgroup makes the bases uniform; what the register allocator cannot keep in SGPRs it parks in VGPR lanes (v_writelane: no latency).
+    EV2G_GP(const double) b_prch = S->price_ch + scnT;
+    EV2G_GP(const double) b_prdis = S->price_dis + scnT;
+    EV2G_GP(const double) b_trb = S->tr_base + (long long)scn * R * T;
+    EV2G_GP(const double) b_trx = S->tr_maxp + (long long)scn * R * T;
+    EV2G_GP(const double) b_trn = S->tr_minp + (long long)scn * R * T;
+    EV2G_GP(double) b_soc = S->soc_log + (long long)e * T * P;
+    EV2G_GP(double) b_hist = S->hist + EV2G_HIST(e, 0, T, R);
+    EV2G_GP(const SessRec) b_rec = S->rec;
+    EV2G_GP(const double) b_lut = S->lut;
     double *const obs_e = io.obs + (long long)e * D;
     uint8_t *const mask_e = io.mask + (long long)e * P;
+    // ---------------- E: the env-level results of a finished step `te` (the last wavefront but one, all 64 lanes): transformers (transformer.py:258-302), reward
+    // (reward.py:34-44), histories, the observation's first two columns.  It runs one phase late -- in the battery-maths slot of the NEXT step, where this
+    // wavefront has no items as a rule, or behind the loop for the launch's last step -- so that no wavefront waits for it: tsum / wsum / emg of step te
+    // stay untouched until the next step's phase C.  It fetches its own transformer series (inflexible load + solar power as their precomputed sum:
+    // Transformer.reset, transformer.py:262-263, the same addition done once at load).
+#define EV2G_BIG_PHASE_E(te, last_)                                                                                                            \
+    {                                                                                                                                         \
+        const int erT_ = min(lane, R - 1) * T + (te);                                                                                         \
+        const double pf_base_ = b_trb[erT_], pf_maxp_ = b_trx[erT_], pf_minp_ = b_trn[erT_];                                                  \
+        double over100_ = 0.0, trp_ = 0.0;                                                                                                    \
+        if (lane < R) {                                                                                                                       \
+            trp_ = tsum[lane];                                                                                                                \
+            double ptr_ = pf_base_;                                                                                                           \
+            ptr_ += trp_;                                                                                                                     \
+            const double over_ = (ptr_ > pf_maxp_ + 0.0001 || ptr_ < pf_minp_ - 0.0001) ? fabs(ptr_ - pf_maxp_) : 0.0;                        \
+            b_hist[(te) * (2 + R) + 2 + lane] = over_;                                                                                        \
+            if (last_) S->tr_power_now[e * R + lane] = ptr_;                                                                                  \
+            over100_ = 100.0 * over_;                                                                                                         \
+        }                                                                                                                                     \
+        const double q_over_ = wave_sum_dpp(over100_);                                                                                        \
+        const double usage_ = wave_sum_dpp(trp_);                                                                                             \
+        double tot_ = 0.0;                                                                                                                    \
+        if (lane < 6 && ((last_) || lane < 3)) {                                                                                              \
+            const double *wp_ = (lane < 5) ? wsum + lane * NW : emg;                                                                          \
+            _Pragma("unroll") for (int w_ = 0; w_ < NW; w_++) tot_ += wp_[w_];                                                                \
+        }                                                                                                                                     \
+        const double costs_ = readlane_f64(tot_, 0), q_sat_ = readlane_f64(tot_, 1), potn_ = readlane_f64(tot_, 2);                           \
+        const double q_ech_ = readlane_f64(tot_, 3), q_edis_ = readlane_f64(tot_, 4), q_emerg_ = readlane_f64(tot_, 5);   /* (the launch's totals) */ \
+        if (lane == 0) {                                                                                                                      \
+            b_hist[(te) * (2 + R)] = usage_;                                                                                                  \
+            if ((te) + 1 < T) b_hist[((te) + 1) * (2 + R) + 1] = potn_;                                                                       \
+            const double reward_ = costs_ - q_over_ - q_sat_;   /* ProfitMax_TrPenalty_UserIncentives (reward.py:34-44) */                    \
+            const double a0_ = eacc[0] + reward_, a1_ = eacc[1] + costs_;                                                                     \
+            io.reward[e] = reward_;                                                                                                           \
+            io.done[e] = ((te) + 1 >= T) ? 1 : 0;                                                                                             \
+            obs_e[0] = (double)((te) + 1);                                                                                                    \
+            obs_e[1] = usage_;                                                                                                                \
+            if (last_) {  /* flush the accumulators (get_statistics reads them): a launch of this kernel ends inside the episode */            \
+                double *ga_ = (double *)S->env_acc + e * 8;                                                                                   \
+                ga_[0] += a0_; ga_[1] += a1_; ga_[2] += q_ech_; ga_[3] += q_edis_; ga_[4] += q_emerg_;                                        \
+                eacc[0] = 0.0; eacc[1] = 0.0;                                                                                                 \
+            } else { eacc[0] = a0_; eacc[1] = a1_; }                                                                                          \
+        }                                                                                                                                     \
+    }
     int t = t0;
+    // charged / discharged energy and emergency-capacity violations feed nothing but the episode totals (get_statistics): each lane adds its ports'
+    // terms up over the LAUNCH and the lanes are summed once, at its last step -- two wavefront reductions and two ballots per wavefront-step less.
+    // (A launch's totals are a fixed function of its steps; launches of different lengths group the additions differently: last-bit differences
+    // between a 112-step launch and 112 single-step launches in these three statistics, nowhere else.)
+    double l_ech = 0.0, l_edis = 0.0;
+    int l_em = 0;
 
     PT_DECL
     for (int kk = 0; kk < k_steps; kk++) {
@@ -163,6 +242,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
                 const int q = tid_l + u * BLOCK, qc = (q < P) ? q : 0;
                 tatd[u] = s_tatd[qc]; cw[u] = s_cycd[qc]; capb[u] = s_cap[qc];
             }
+#ifdef EV2G_PT_ASPLIT
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PT_MARK(7)
+#endif
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int q = tid_l + u * BLOCK;
@@ -186,6 +269,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
                 if (valid) { s_x[q] = amps[u]; s_y[q] = 0.0; }
             }
         }
+#ifdef EV2G_PT_ASPLIT
+        PT_MARK(6)
+#endif
         {   // compact the ports that have battery maths to do: charging items from the front of `items`, discharging ones from its back;
             // one LDS atomic per wavefront and list (ballot + lane prefix count)
             const unsigned long long mc0 = __ballot(amps[0] > 0.0), mc1 = __ballot(amps[1] > 0.0);
@@ -204,6 +290,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
             else if (amps[1] < 0.0) items[NP - 1 - (bdis + __popcll(md0) + EV2G_MBCNT(md1))] = (unsigned short)(tid_l + BLOCK);
 #undef EV2G_MBCNT
         }
+#ifdef EV2G_PT_ASPLIT
+        PT_MARK(0)
+#endif
         // ---- requests whose answers are consumed behind the battery maths: the next step's actions, this step's observation-head pairs ----
         {
             const bool more = (kk + 1 < k_steps);
@@ -213,9 +302,6 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
         }
         d2_t hp[2];
         typedef double d2a8_t __attribute__((ext_vector_type(2), aligned(8)));
-        int hp_src[2], hp_dst[2];   // double offsets inside the scenario's window block (without the step term) / inside the env's observation row; -1: none
-        EV2G_BIG_HP_ROLE(0, hp_src[0], hp_dst[0])
-        EV2G_BIG_HP_ROLE(1, hp_src[1], hp_dst[1])
 #pragma unroll
         for (int u = 0; u < 2; u++) {   // ONE unconditional 16-byte load per slot from a selected, always valid address (a load in a branch that merges with a
                                         // default costs a vmcnt(0) drain, ev2g_step_v2.h); a price lane reads the pair that holds its column (clamped inside the row)
@@ -224,44 +310,41 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
 #else
             EV2G_GP(const double) pw = win_base + (long long)sstep * 40 + hp_src[u];
 #endif
-            EV2G_GP(const double) pp = S->price_ch + scnT + min(sstep + (-2 - hp_dst[u]), T - 2);
+            EV2G_GP(const double) pp = b_prch + min(sstep + (-2 - hp_dst[u]), T - 2);
             hp[u] = __builtin_nontemporal_load((const d2a8_t __attribute__((address_space(1))) *)((hp_dst[u] < -1) ? pp : pw));
         }
-        // Departures and arrivals are known before the step (occupancy does not depend on the actions): an arrival takes {B, cap0, potc} from the
-        // session record, a departure {des, next window} from the session's tail entry -- three 8-byte loads per port from clamped (always valid)
-        // addresses, requested HERE (a phase and two barriers ahead of their use in phase C; the registers are there: this kernel has no staging
-        // rows to address); the conditions are applied where the values are consumed.
-        // ONE set of operand registers per lane: a lane's two ports rarely have an event in the same step; when they do, the second port fetches
-        // its operands in phase C itself (`pf_u`: the port the set belongs to).
-        double pf_ra, pf_rb, pf_rc;
-        int pf_lut;   // efficiency-table id of an arriving session
-        int pf_u;
+        // Departures and arrivals are known before the step (occupancy does not depend on the actions) and they are few -- a dozen of each per step
+        // at 1000 ports -- but the code that handles one (an exp, a division, atomics, the arriving session's operands) is long, and a wavefront
+        // executes it whenever ONE of its lanes needs it: every wavefront, nearly every step.  So the home lanes only LIST the ports that have an
+        // event (per wavefront, in lane order, at a fixed place) and the last wavefront works the whole list off, once per step.
+        bool ev[2];
         {
-            bool ev_dep[2], ev_arr[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int ta = (int)(short)(tatd[u] & 0xffff), td = tatd[u] >> 16;
-                ev_dep[u] = occ[u] && t >= td; ev_arr[u] = (tid_l + u * BLOCK < P) && (ta == sstep);
+                ev[u] = (occ[u] && t >= td) || ((tid_l + u * BLOCK < P) && ta == sstep);
             }
-            pf_u = (ev_dep[0] || ev_arr[0]) ? 0 : 1;
-            const bool ed = pf_u ? ev_dep[1] : ev_dep[0], ea = pf_u ? ev_arr[1] : ev_arr[0];
-            const int sse = (ed || ea) ? s_ss[tid_l + pf_u * BLOCK] : 0;
-            pf_lut = S->ss_lut[sse];
-            const char *rp = (const char *)((const SessRec *)S->rec + sse), *tp = (const char *)((const SessTail *)S->tail + sse);
-            pf_ra = *(const double *)(ea ? rp + offsetof(SessRec, B) : tp + offsetof(SessTail, des));
-            pf_rb = *(const double *)(ea ? rp + offsetof(SessRec, cap0) : tp + offsetof(SessTail, nt_arr));   // (the window: two ints)
-            pf_rc = *(const double *)(rp + offsetof(SessRec, potc));
+            const unsigned long long me0 = __ballot(ev[0]), me1 = __ballot(ev[1]);
+            if ((me0 | me1) != 0ull) {   // (uniform)
+#define EV2G_MBCNT(m) ((int)__builtin_amdgcn_mbcnt_hi((unsigned)((m) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)(m), 0u)))
+                if (ev[0]) evl[wv * 128 + EV2G_MBCNT(me0)] = (unsigned short)tid_l;
+                if (ev[1]) evl[wv * 128 + __popcll(me0) + EV2G_MBCNT(me1)] = (unsigned short)(tid_l + BLOCK);
+#undef EV2G_MBCNT
+            }
+            if (lane == 0) cntev[wv] = __popcll(me0) + __popcll(me1);
         }
-        // the transformer series of this step, for wavefront 0's phase E (every wavefront asks: same lines, no divergent load); inflexible load +
-        // solar power as their precomputed sum (Transformer.reset, transformer.py:262-263: the same addition, done once at load)
-        const long long erT = ((long long)scn * R + min(tid_l & 63, R - 1)) * T + t;
-        double pf_base = S->tr_base[erT], pf_maxp = S->tr_maxp[erT], pf_minp = S->tr_minp[erT];
+#ifdef EV2G_PT_ASPLIT
+        PT_MARK(4)
+#else
         PT_MARK(0)
+#endif
         lds_barrier();
         PT_MARK(1)
 
         // ---------------- B: worker lanes, battery maths on the compact list ----------------
-        __builtin_amdgcn_s_setprio(3);
+#ifndef EV2G_BIG_NOPRIO
+        __builtin_amdgcn_s_setprio(EV2G_BIG_PRIO);
+#endif
         {
             const int nch = cnt[0], ndis = cnt[1];
             const int nchp = (nch + 63) & ~63;  // discharge items start on a wavefront boundary
@@ -271,7 +354,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
                 else if (i >= nchp) h = items[NP - 1 - (i - nchp)];
                 if (h >= 0) {
                     const int ssh = s_ss[h];
-                    const char __attribute__((address_space(1))) *rp = (const char __attribute__((address_space(1))) *)(S->rec + ssh);
+                    const char __attribute__((address_space(1))) *rp = (const char __attribute__((address_space(1))) *)(b_rec + ssh);
                     union { SessRec r; d2_t v[8]; } rr;
                     const int r_lut = (int)s_lut[h] - 1;
                     const double cap0 = s_cap[h], prev0 = s_prev[h], tot0 = s_tot[h];
@@ -282,7 +365,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
                     // table entry and session record are independent loads: one memory round trip, not two.  The look-up is unconditional (clamped
                     // index); whether it applies is decided where it is used.
                     const int li = (r_lut >= 0) ? ev_lut_index(r_lut, amps_h) : -1;
-                    double lut_raw = S->lut[max(li, 0)];
+                    double lut_raw = b_lut[max(li, 0)];
                     EvRes o;
                     if (i < nchp) {   // (uniform)
 #pragma unroll
@@ -314,26 +397,48 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        // the last wavefront: event i of the step (wavefront-major, lane order) -> lane i; its operands are requested here, behind this wavefront's own
+        // battery maths (if it has any) and a barrier ahead of their use: an arrival takes {B, cap0, potc, table id} from the session's record, a departure
+        // {des, next window} from its tail entry.  Lanes without an event read session 0 (clamped addresses, unconditional loads).
+        int ev_q = -1, ev_n = 0;
+        double pf_ra = 0.0, pf_rb = 0.0, pf_rc = 0.0;
+        int pf_lut = -1;
+        if (wv == NW - 2 && kk > 0) EV2G_BIG_PHASE_E(t - 1, false)   // (uniform) the step before: its env-level results, off every other wavefront's path
+        int pf_pk = 0;   // the event port's action / mask index | observation column (what its home lane keeps in `pk`)
+        if (wv == NW - 1) {   // (uniform)
+            int base = 0, w_of = -1, b_of = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const int c = cntev[w];
+                if (lane >= base && lane < base + c) { w_of = w; b_of = base; }
+                base += c;
+            }
+            ev_n = base;
+            if (w_of >= 0) ev_q = evl[w_of * 128 + (lane - b_of)];
+            const int qe = max(ev_q, 0);
+            const int tde = s_tatd[qe] >> 16;
+            const int sse = (ev_q >= 0) ? s_ss[qe] : 0;
+            const bool ea = !(((int)(short)(s_tatd[qe] & 0xffff) <= t) && t >= tde);   // not a departure: an arrival
+            pf_lut = S->ss_lut[sse];
+            pf_pk = S->slot_port[qe] | (S->slot_obs[qe] << 16);
+            const char *rp = (const char *)((const SessRec *)S->rec + sse), *tp = (const char *)((const SessTail *)S->tail + sse);
+            pf_ra = *(const double *)(ea ? rp + offsetof(SessRec, B) : tp + offsetof(SessTail, des));
+            pf_rb = *(const double *)(ea ? rp + offsetof(SessRec, cap0) : tp + offsetof(SessTail, nt_arr));   // (the window: two ints)
+            pf_rc = *(const double *)(rp + offsetof(SessRec, potc));
+        }
         PT_MARK(2)
         lds_barrier();
         PT_MARK(1)
         if (tid_l < 2) cnt[tid_l] = 0;
-        const double pf_pch = big_sld<double>(S->price_ch, scnT + t), pf_pdis = big_sld<double>(S->price_dis, scnT + t);
+        const double pf_pch = big_sld<double>(b_prch, t), pf_pdis = big_sld<double>(b_prdis, t);
         // ONE collection point for everything requested in phase A, BEFORE this step's first global store: on gfx9-family ISAs vmcnt counts loads and
         // stores together and they retire out of order with respect to each other, so a load consumed while younger stores are pending costs a
         // full drain of those stores (ev2g_step_v2.h).  s_waitcnt vmcnt(0) expcnt(7) lgkmcnt(15); as outputs of the empty asm the registers are
         // plain values from here on (also across the loop's back edge: the next step's actions).
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        asm volatile("" : "+v"(a_next[0]), "+v"(a_next[1]), "+v"(hp[0]), "+v"(hp[1]), "+v"(pf_base), "+v"(pf_maxp), "+v"(pf_minp));
-        asm volatile("" : "+v"(pf_ra), "+v"(pf_rb), "+v"(pf_rc), "+v"(pf_lut));
+        asm volatile("" : "+v"(a_next[0]), "+v"(a_next[1]), "+v"(hp[0]), "+v"(hp[1]));
+        asm volatile("" : "+v"(pf_ra), "+v"(pf_rb), "+v"(pf_rc), "+v"(pf_lut), "+v"(pf_pk));
         // the observation head: |charge price| window and the transformers' load / PV / limit windows, copied from the scenario's tables
-        {
-            int tid_c = tid;
-            asm volatile("" : "+v"(tid_c));
-            const int tid_l = tid_c;   // (shadows: the roles again, not carried across the battery maths)
-            EV2G_BIG_HP_ROLE(0, hp_src[0], hp_dst[0])
-            EV2G_BIG_HP_ROLE(1, hp_src[1], hp_dst[1])
-        }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
 #ifdef EV2G_BIG_ABL_NOHS  /* ablation (wrong results): no head stores */
@@ -347,126 +452,154 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
             }
         }
 
-        // ---------------- C: home lanes: departures, arrivals, observation columns ----------------
-        double v_profit = 0.0, v_sat = 0.0, v_pot = 0.0, v_ech = 0.0, v_edis = 0.0;
-        bool any_emerg[2] = {false, false};
+        // ---------------- C: home lanes: the step's port-level results; the last wavefront: the step's departures and arrivals ----------------
+        double v_profit = 0.0, v_sat = 0.0, v_pot = 0.0;
+        // what a port contributes once its occupancy after the step is known (ev2gym_env.py:452-457, rl_agent/state.py:136-151, utils.py:760-791):
+        // action mask, its two observation columns, its charge-power-potential term.  `cwq`: the port's word (charger class, potential-term index)
+#define EV2G_BIG_PORT_OUT(q_, pk_, occ_after_, cap_, bcap_, td_, cwq_)                                                                        \
+        {                                                                                                                                    \
+            mask_e[(pk_) & 0xffff] = (occ_after_) ? 1 : 0;                                                                                   \
+            d2_t ov_ = {0.0, 0.0};                                                                                                           \
+            double pot_ = 0.0;                                                                                                               \
+            if (occ_after_) {                                                                                                                \
+                const double soc_ = (cap_) / (bcap_);                                                                                        \
+                ov_.x = soc_; ov_.y = (double)((td_) - sstep);                                                                               \
+                if (soc_ < 1.0 && (td_) > sstep) {  /* utils.py:771 */                                                                       \
+                    const unsigned pidx_ = (unsigned)(cwq_) >> 28;                                                                           \
+                    if (pidx_ < 15u) pot_ = ptab[pidx_];                                                                                     \
+                    else {   /* a value the loaded pool did not hold (a device refill's new car model): the state line has it */              \
+                        pot_ = S->line[eP + (q_)].potc;                                                                                      \
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pot_));                                                                     \
+                    }                                                                                                                        \
+                }                                                                                                                            \
+                const double *ct_ = ctab + (((cwq_) >> 24) & 15) * 6;   /* per-charger clamp (utils.py:779-789) */                            \
+                const double mx_ = ct_[4], mn_ = ct_[5];                                                                                     \
+                pot_ = (pot_ > mx_) ? mx_ : ((pot_ < mn_) ? 0.0 : pot_);                                                                     \
+            }                                                                                                                                \
+            *(d2_t *)(obs_e + ((unsigned)(pk_) >> 16)) = ov_;                                                                                \
+            v_pot += pot_;                                                                                                                   \
+        }
         {
-            int cw[2], ssq[2];
-            double capq[2], enq[2], bcq[2], abq[2];
+            int cw[2];
+            double capq[2], enq[2], bcq[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int q = tid_l + u * BLOCK, qc = (q < P) ? q : 0;
-                cw[u] = s_cycd[qc]; ssq[u] = s_ss[qc]; capq[u] = s_cap[qc]; enq[u] = s_x[qc]; bcq[u] = s_bcap[qc]; abq[u] = s_abse[qc];
+                cw[u] = s_cycd[qc]; capq[u] = s_cap[qc]; enq[u] = s_x[qc]; bcq[u] = s_bcap[qc];
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int q = tid_l + u * BLOCK;
-                if (q < P) {
-                    int ta = (int)(short)(tatd[u] & 0xffff), td = tatd[u] >> 16;
-                    double cap = capq[u], bcap = bcq[u];
-                    unsigned pidx = (unsigned)cw[u] >> 28;   // the attached EV's potential term: an index into the launch's value table (15: not in it)
-                    int cwn = cw[u] & ~28;   // (the step's flags are consumed here)
-                    double profit = 0.0, satpen = 0.0, pot = 0.0;
-                    bool departed = false;
-                    double e_ra = pf_ra, e_rb = pf_rb, e_rc = pf_rc;   // the event operands requested in phase A, if this is the port they were requested for
-                    int e_lut = pf_lut;
-                    const bool dep_now = occ[u] && t >= td;
-                    if ((dep_now || ta == sstep) && u != pf_u) {   // both ports of this lane have an event in this step (rare): fetch here, wait inside the branch
-                        const int sse = ssq[u];
-                        const char *rp = (const char *)((const SessRec *)S->rec + sse), *tp = (const char *)((const SessTail *)S->tail + sse);
-                        e_ra = *(const double *)(dep_now ? tp + offsetof(SessTail, des) : rp + offsetof(SessRec, B));
-                        e_rb = *(const double *)(dep_now ? tp + offsetof(SessTail, nt_arr) : rp + offsetof(SessRec, cap0));
-                        e_rc = *(const double *)(rp + offsetof(SessRec, potc));
-                        e_lut = S->ss_lut[sse];
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(e_ra), "+v"(e_rb), "+v"(e_rc), "+v"(e_lut));
+                if (occ[u]) {
+                    const bool item = amps[u] != 0.0;       // the battery maths ran for this port: its flags in the port's word are this step's
+                    const double energy = enq[u];           // 0 for idle EVs (phase A stored amps == 0)
+                    const bool active = item && (cw[u] & 16);
+                    // historic_soc / active_steps (ev.py:156,162,185): capacity before the step, negated if the step was inactive
+                    b_soc[t * P + q] = active ? capb[u] : -capb[u];
+                    if (last_step) { S->port_energy[eP + q] = energy; if (!active) S->port_current[eP + q] = 0.0; }
+                    if (energy != 0.0) {  // profit += |E| * price, by the sign of the ACTION (ev_charger.py:178,194); a charge step can return a
+                                          // tiny negative energy when ceil2 left the capacity above the battery size
+                        const double ae = fabs(energy);
+                        if (cw[u] & 8) { v_profit += ae * pf_pch; l_ech += ae; } else { v_profit += ae * pf_pdis; l_edis += ae; }
                     }
-                    if (occ[u]) {
-                        const double energy = enq[u];   // 0 for idle EVs (phase A stored amps == 0)
-                        // historic_soc / active_steps (ev.py:156,162,185): capacity before the step, negated if the step was inactive
-                        S->soc_log[((long long)e * T + t) * P + q] = (cw[u] & 16) ? capb[u] : -capb[u];
-                        if (last_step) { S->port_energy[eP + q] = energy; if (!(cw[u] & 16)) S->port_current[eP + q] = 0.0; }
-                        if (energy != 0.0) {  // profit += |E| * price, by the sign of the ACTION (ev_charger.py:178,194); a charge step can return a
-                                              // tiny negative energy when ceil2 left the capacity above the battery size
-                            const double ae = fabs(energy);
-                            if (cw[u] & 8) { profit = ae * pf_pch; v_ech += ae; } else { profit = ae * pf_pdis; v_edis += ae; }
-                        }
-                        any_emerg[u] = (cw[u] & 4) != 0;
-                        if (dep_now) {  // departure (ev_charger.py:209-229, ev.py:191-214)
-                            const int ss = ssq[u];
-                            const double des = e_ra;
-                            const double score = (cap < des - 0.001) ? cap / des : 1.0;
-                            satpen = 100.0 * exp(-10.0 * score);   // ProfitMax_TrPenalty_UserIncentives (reward.py:41-42)
-                            const int gc = e * C + (pk[u] & 0xffff);   // single-port chargers: the charger's index is the port's (a fetch of slot_cs here would drain this phase's stores)
-                            __hip_atomic_fetch_add(&S->cs_served[gc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_fetch_add(&S->cs_sat_sum[gc], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            S->sess_final_cap[ss] = cap;
-                            S->sess_abs_e[ss] = abq[u];
-                            const int nta = __double2loint(e_rb), ntd = __double2hiint(e_rb);   // window of the port's next session
-                            departed = true;
-                            ta = (nta == EV2G_INT_MAX) ? 0x7fff : nta; td = (ntd == EV2G_INT_MAX) ? 0x7fff : ntd;
-                            s_tatd[q] = (int)((unsigned)(ta & 0xffff) | ((unsigned)td << 16));
-                            ssq[u] = (nta != EV2G_INT_MAX) ? ss + 1 : -1;
-                            s_ss[q] = ssq[u];
-                            cwn = (cwn & 0x0f000003) | 2;   // cycles = 0, no EV
-                        }
+                    l_em += (item && (cw[u] & 4)) ? 1 : 0;
+                }
+                if (q < P && !ev[u]) {   // no departure, no arrival: the port stays as it is (an event port is finished by the last wavefront, below)
+                    const int td = tatd[u] >> 16;
+                    EV2G_BIG_PORT_OUT(q, pk[u], occ[u], capq[u], bcq[u], td, cw[u])
+                }
+            }
+        }
+        // ---- the step's events (ev_charger.py:209-229, ev2gym_env.py:399-417, ev.py:115-136,191-214): lane i of the last wavefront takes event i ----
+        if (wv == NW - 1 && ev_n > 0) {   // (uniform)
+            for (int i0 = 0; i0 < ev_n; i0 += 64) {
+                if (i0 > 0) {   // more than 64 events in one step (rare): the next 64, their operands fetched here
+                    int base = 0, w_of = -1, b_of = 0;
+                    for (int w = 0; w < NW; w++) {
+                        const int c = cntev[w];
+                        if (i0 + lane >= base && i0 + lane < base + c) { w_of = w; b_of = base; }
+                        base += c;
+                    }
+                    ev_q = (w_of >= 0) ? (int)evl[w_of * 128 + (i0 + lane - b_of)] : -1;
+                    const int qe = max(ev_q, 0);
+                    const int w0 = s_tatd[qe];
+                    const int sse = (ev_q >= 0) ? s_ss[qe] : 0;
+                    const bool ea = !(((int)(short)(w0 & 0xffff) <= t) && t >= (w0 >> 16));
+                    const char *rp = (const char *)((const SessRec *)S->rec + sse), *tp = (const char *)((const SessTail *)S->tail + sse);
+                    pf_lut = S->ss_lut[sse];
+                    pf_ra = *(const double *)(ea ? rp + offsetof(SessRec, B) : tp + offsetof(SessTail, des));
+                    pf_rb = *(const double *)(ea ? rp + offsetof(SessRec, cap0) : tp + offsetof(SessTail, nt_arr));
+                    pf_rc = *(const double *)(rp + offsetof(SessRec, potc));
+                    pf_pk = S->slot_port[qe] | (S->slot_obs[qe] << 16);
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_ra), "+v"(pf_rb), "+v"(pf_rc), "+v"(pf_lut), "+v"(pf_pk));
+                }
+                if (ev_q >= 0) {
+                    const int q = ev_q;
+                    const int w0 = s_tatd[q];
+                    int ta = (int)(short)(w0 & 0xffff), td = w0 >> 16;
+                    int cwn = s_cycd[q], ssn = s_ss[q];
+                    double cap = s_cap[q], bcap = s_bcap[q];
+                    const int pkq = pf_pk;
+                    bool departed = false;
+                    if (ta <= t && t >= td) {  // departure (ev_charger.py:209-229, ev.py:191-214)
+                        const int ss = ssn;
+                        const double des = pf_ra;
+                        const double score = (cap < des - 0.001) ? cap / des : 1.0;
+                        v_sat += 100.0 * exp(-10.0 * score);   // ProfitMax_TrPenalty_UserIncentives (reward.py:41-42)
+                        const int gc = e * C + (pkq & 0xffff);   // single-port chargers: the charger's index is the port's
+                        __hip_atomic_fetch_add(&S->cs_served[gc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(&S->cs_sat_sum[gc], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        S->sess_final_cap[ss] = cap;
+                        S->sess_abs_e[ss] = s_abse[q];
+                        const int nta = __double2loint(pf_rb), ntd = __double2hiint(pf_rb);   // window of the port's next session
+                        departed = true;
+                        ta = (nta == EV2G_INT_MAX) ? 0x7fff : nta; td = (ntd == EV2G_INT_MAX) ? 0x7fff : ntd;
+                        s_tatd[q] = (int)((unsigned)(ta & 0xffff) | ((unsigned)td << 16));
+                        ssn = (nta != EV2G_INT_MAX) ? ss + 1 : -1;
+                        s_ss[q] = ssn;
+                        cwn = (cwn & 0x0f00001f) | 2;   // cycles = 0, no EV (the step's flags stay: the port's home lane may still be reading them)
                     }
                     if (ta == sstep) {  // arrival at the end of this step (ev2gym_env.py:399-417, ev.py:115-136)
-                        double B = e_ra, c0 = e_rb, potc = e_rc;
-                        int lutn = e_lut;
+                        double B = pf_ra, c0 = pf_rb, potc = pf_rc;
+                        int lutn = pf_lut;
                         if (departed) {   // the next session arrives right behind a departure of this very step: its record was not the one requested
-                            const SessRec &r = *(const SessRec *)(S->rec + ssq[u]);
-                            B = r.B; c0 = r.cap0; potc = r.potc; lutn = S->ss_lut[ssq[u]];
-                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(B), "+v"(c0), "+v"(potc), "+v"(lutn));   // (the wait stays inside this rare branch)
+                            const SessRec &r = *(const SessRec *)(S->rec + ssn);
+                            B = r.B; c0 = r.cap0; potc = r.potc; lutn = S->ss_lut[ssn];
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(B), "+v"(c0), "+v"(potc), "+v"(lutn));
                         }
                         s_lut[q] = (unsigned short)(lutn + 1);
-                        pidx = 15u;
+                        unsigned pidx = 15u;
                         for (int i = 14; i >= 0; i--) if (ptab[i] == potc) pidx = (unsigned)i;
                         cap = c0; bcap = B;
                         s_cap[q] = cap; s_tot[q] = 0.0; s_prev[q] = 0.0; s_bcap[q] = B; s_abse[q] = 0.0;
-                        cwn = (int)(((unsigned)cwn & 0x0f000003u) | 1u | (pidx << 28));   // cycles = 0
+                        cwn = (int)(((unsigned)cwn & 0x0f00001fu) | 1u | (pidx << 28));   // cycles = 0
                         S->line[eP + q].bcap = B;
                         S->line[eP + q].potc = potc;
                         S->port_energy[eP + q] = 0.0;
                         S->port_current[eP + q] = 0.0;
                     }
-                    if (cwn != cw[u]) s_cycd[q] = cwn;
+                    s_cycd[q] = cwn;
                     const bool occ_after = (ta <= sstep) && (sstep <= td);
-                    mask_e[pk[u] & 0xffff] = occ_after ? 1 : 0;
-                    d2_t ov = {0.0, 0.0};
-                    if (occ_after) {
-                        const double soc = cap / bcap;
-                        ov.x = soc; ov.y = (double)(td - sstep);
-                        if (soc < 1.0 && td > sstep) {  // utils.py:771
-                            if (pidx < 15u) pot = ptab[pidx];
-                            else {   // a value the loaded pool did not hold (a device refill's new car model): the state line has it
-                                pot = S->line[eP + q].potc;
-                                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pot));
-                            }
-                        }
-                    }
-                    {   // per-charger clamp (utils.py:779-789)
-                        const double *ct = ctab + ((cwn >> 24) & 15) * 6;
-                        const double mx = ct[4], mn = ct[5];
-                        pot = (pot > mx) ? mx : ((pot < mn) ? 0.0 : pot);
-                    }
-                    *(d2_t *)(obs_e + ((unsigned)pk[u] >> 16)) = ov;
-                    v_profit += profit; v_sat += satpen; v_pot += pot;
+                    EV2G_BIG_PORT_OUT(q, pkq, occ_after, cap, bcap, td, cwn)
                 }
             }
         }
-        // per-wavefront partial sums of the env-level quantities, from registers (fixed tree: lane pair, DPP butterflies, one partial per wavefront)
+#undef EV2G_BIG_PORT_OUT
+        // per-wavefront partial sums of the step's env-level quantities, from registers (fixed tree: lane pair, DPP butterflies, one partial per wavefront)
         {
             const double w_profit = wave_sum_dpp(v_profit), w_pot = wave_sum_dpp(v_pot);
-            const double w_ech = wave_sum_dpp(v_ech), w_edis = wave_sum_dpp(v_edis);
             double w_sat = 0.0;
-            if (__ballot(v_sat != 0.0) != 0ull) w_sat = wave_sum_dpp(v_sat);   // (uniform; departures are rare)
-            const int n_em = __popcll(__ballot(any_emerg[0])) + __popcll(__ballot(any_emerg[1]));
-            if (lane == 0) {
-                wsum[0 * NW + wv] = w_profit; wsum[1 * NW + wv] = w_sat; wsum[2 * NW + wv] = w_pot; wsum[3 * NW + wv] = w_ech; wsum[4 * NW + wv] = w_edis;
-                emg[wv] = (double)n_em;
+            if (__ballot(v_sat != 0.0) != 0ull) w_sat = wave_sum_dpp(v_sat);   // (uniform; departures are rare and only the last wavefront has them)
+            if (lane == 0) { wsum[0 * NW + wv] = w_profit; wsum[1 * NW + wv] = w_sat; wsum[2 * NW + wv] = w_pot; }
+            if (last_step) {   // (uniform) the launch's energy totals and violation count
+                const double w_ech = wave_sum_dpp(l_ech), w_edis = wave_sum_dpp(l_edis);
+                const double w_em = wave_sum_dpp((double)l_em);
+                if (lane == 0) { wsum[3 * NW + wv] = w_ech; wsum[4 * NW + wv] = w_edis; emg[wv] = w_em; }
             }
         }
+#ifndef EV2G_PT_ASPLIT
         PT_MARK(3)
+#endif
         // ---------------- D: power per transformer: 8 lanes per segment, DPP butterfly (the tree of ev2g_step_v2's one-env scheme) ----------------
         if (tid_l < R * 8) {
             const int r = tid_l >> 3, j = tid_l & 7;
@@ -478,56 +611,21 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
             acc += xor4_f64(acc);
             if (j == 0) tsum[r] = acc;
         }
+#ifdef EV2G_PT_ASPLIT
+        PT_MARK(3)
+#else
         PT_MARK(4)
+#endif
         lds_barrier();
         PT_MARK(1)
 
-        // ---------------- E: wavefront 0: transformers (transformer.py:258-302), reward, histories; the others start the next step ----------------
-        if (tid_l < 64) {
-            double over100 = 0.0, trp = 0.0;
-            if (tid_l < R) {
-                trp = tsum[tid_l];
-                double ptr = pf_base;
-                ptr += trp;
-                const double over = (ptr > pf_maxp + 0.0001 || ptr < pf_minp - 0.0001) ? fabs(ptr - pf_maxp) : 0.0;
-                S->hist[EV2G_HIST(e, t, T, R) + 2 + tid_l] = over;
-                if (last_step) S->tr_power_now[e * R + tid_l] = ptr;
-                over100 = 100.0 * over;
-            }
-            const double q_over = wave_sum_dpp(over100);
-            const double usage = wave_sum_dpp(trp);
-            double tot = 0.0;
-            if (tid_l < 6) {
-                const double *wp = (tid_l < 5) ? wsum + tid_l * NW : emg;
-#pragma unroll
-                for (int w = 0; w < NW; w++) tot += wp[w];
-            }
-            const double costs = readlane_f64(tot, 0), q_sat = readlane_f64(tot, 1), potn = readlane_f64(tot, 2);
-            const double q_ech = readlane_f64(tot, 3), q_edis = readlane_f64(tot, 4), q_emerg = readlane_f64(tot, 5);
-            if (tid_l == 0) {
-                double *const p_hist = (double *)S->hist;
-                p_hist[EV2G_HIST(e, t, T, R)] = usage;
-                if (sstep < T) p_hist[EV2G_HIST(e, sstep, T, R) + 1] = potn;
-                const double reward = costs - q_over - q_sat;   // ProfitMax_TrPenalty_UserIncentives (reward.py:34-44)
-                const double a0 = eacc[0] + reward, a1 = eacc[1] + costs, a2 = eacc[2] + q_ech, a3 = eacc[3] + q_edis, a4 = eacc[4] + q_emerg;
-                io.reward[e] = reward;
-                io.done[e] = (sstep >= T) ? 1 : 0;
-                obs_e[0] = (double)sstep;
-                obs_e[1] = usage;
-                if (sstep >= T || last_step) {  // flush the episode accumulators (get_statistics reads them)
-                    double *ga = (double *)S->env_acc + e * 8;
-                    ga[0] += a0; ga[1] += a1; ga[2] += a2; ga[3] += a3; ga[4] += a4;
-                    eacc[0] = 0.0; eacc[1] = 0.0; eacc[2] = 0.0; eacc[3] = 0.0; eacc[4] = 0.0;
-                } else { eacc[0] = a0; eacc[1] = a1; eacc[2] = a2; eacc[3] = a3; eacc[4] = a4; }
-            }
-        }
         PT_MARK(5)
         PT_STEP_END(false)
         t += 1;
-        // no barrier here: the next step's phase A touches s_x / s_y / items / cnt and reads the port state, none of which phase E uses; tsum / wsum / emg are
-        // rewritten only behind two more barriers, which wavefront 0 takes part in
     }
     PT_FLUSH
+    if (wv == NW - 2 && k_steps > 0) EV2G_BIG_PHASE_E(t - 1, true)   // the launch's last step
+#undef EV2G_BIG_PHASE_E
     // ---- write the LDS-resident port state back ----
     __syncthreads();
 #pragma unroll

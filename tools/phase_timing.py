@@ -26,7 +26,7 @@ from bench import WORKLOADS
 from ev2gym_amd.scenario_gen import generate
 wname = argv[0] if argv else "cfg2"
 wl = WORKLOADS[wname]
-E = wl["envs"]
+E = int(os.environ.get("AB_ENVS", wl["envs"]))
 batch = generate(wl["gen"](E, 0))
 eng = engine.Engine(batch, _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]], flags=_abi.FLAG_LOG_SOC)
 P, D, T = eng.P, eng.D, eng.T
