@@ -234,6 +234,7 @@ int ev2g_n_steps(const ev2g_handle *h) { return h ? h->T : 0; }
 int ev2g_current_step(const ev2g_handle *h) { return h ? h->current_step : 0; }
 const char *ev2g_kernel_name(const ev2g_handle *h) { return (h && h->loaded) ? h->kernel_name.c_str() : ""; }
 const char *ev2g_fallback_reason(const ev2g_handle *h) { return (h && h->loaded) ? h->fallback_reason.c_str() : ""; }
+const char *ev2g_big_kernel_reason(const ev2g_handle *h) { return (h && h->loaded) ? h->big_reason.c_str() : ""; }
 int ev2g_last_launch_specialisation(const ev2g_handle *h) { return (h && h->loaded) ? h->last_spec : -1; }
 const char *ev2g_last_launch_general_reason(const ev2g_handle *h) { return (h && h->loaded && h->last_spec == 0) ? h->general_reason : ""; }
 
@@ -689,7 +690,7 @@ int ev2g_load_scenarios(ev2g_handle *h, const ev2g_scenario_batch *b) {
             if (std::getenv("EV2G_NO_BIG")) h->big_reason = "EV2G_NO_BIG is set";
             else if (npc != 1) h->big_reason = "multi-port chargers";
             else if (sk != EV2G_STATE_V2G_PROFIT_MAX_LOADS) h->big_reason = "the state function is not V2G_profit_max_loads";
-            else if (R > 64) h->big_reason = "more than 64 transformers";
+            else if (20 * R + 20 > 2 * EV2G_BIG_BLOCK) h->big_reason = "more than 50 transformers (their 20 R window-column pairs + 20 price columns ride in 1024 pair slots)";
             else if (many) h->big_reason = "more than 16 distinct charger constant tuples";
             else if (tmax > EV2G_BIG_TMAX / 2 || tmin < -1) h->big_reason = "a session window or the episode length exceeds 16383 steps";
             else if (!even || D >= 65536) h->big_reason = "observation columns are not 16-byte aligned pairs";

@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
     // (A launch's totals are a fixed function of its steps; launches of different lengths group the additions differently: last-bit differences
     // between a 112-step launch and 112 single-step launches in these three statistics, nowhere else.)
     double l_ech = 0.0, l_edis = 0.0;
-    int l_em = 0;
+    int n_em = 0;   // (a count per wavefront, kept in a scalar register)
 
     PT_DECL
     for (int kk = 0; kk < k_steps; kk++) {
@@ -454,6 +454,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
 
         // ---------------- C: home lanes: the step's port-level results; the last wavefront: the step's departures and arrivals ----------------
         double v_profit = 0.0, v_sat = 0.0, v_pot = 0.0;
+        bool em[2] = {false, false};
         // what a port contributes once its occupancy after the step is known (ev2gym_env.py:452-457, rl_agent/state.py:136-151, utils.py:760-791):
         // action mask, its two observation columns, its charge-power-potential term.  `cwq`: the port's word (charger class, potential-term index)
 #define EV2G_BIG_PORT_OUT(q_, pk_, occ_after_, cap_, bcap_, td_, cwq_)                                                                        \
@@ -502,7 +503,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
                         const double ae = fabs(energy);
                         if (cw[u] & 8) { v_profit += ae * pf_pch; l_ech += ae; } else { v_profit += ae * pf_pdis; l_edis += ae; }
                     }
-                    l_em += (item && (cw[u] & 4)) ? 1 : 0;
+                    em[u] = item && (cw[u] & 4);
                 }
                 if (q < P && !ev[u]) {   // no departure, no arrival: the port stays as it is (an event port is finished by the last wavefront, below)
                     const int td = tatd[u] >> 16;
@@ -591,10 +592,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_big(const V2P *__restrict_
             double w_sat = 0.0;
             if (__ballot(v_sat != 0.0) != 0ull) w_sat = wave_sum_dpp(v_sat);   // (uniform; departures are rare and only the last wavefront has them)
             if (lane == 0) { wsum[0 * NW + wv] = w_profit; wsum[1 * NW + wv] = w_sat; wsum[2 * NW + wv] = w_pot; }
+            n_em += __popcll(__ballot(em[0])) + __popcll(__ballot(em[1]));
             if (last_step) {   // (uniform) the launch's energy totals and violation count
                 const double w_ech = wave_sum_dpp(l_ech), w_edis = wave_sum_dpp(l_edis);
-                const double w_em = wave_sum_dpp((double)l_em);
-                if (lane == 0) { wsum[3 * NW + wv] = w_ech; wsum[4 * NW + wv] = w_edis; emg[wv] = w_em; }
+                if (lane == 0) { wsum[3 * NW + wv] = w_ech; wsum[4 * NW + wv] = w_edis; emg[wv] = (double)n_em; }
             }
         }
 #ifndef EV2G_PT_ASPLIT

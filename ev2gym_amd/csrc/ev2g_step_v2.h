@@ -29,7 +29,10 @@
 #define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(); unsigned long long pt_acc[18] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long pt_cur[8] = {0,0,0,0,0,0,0,0};
 #define PT_MARK(i) { unsigned long long n_ = __builtin_readcyclecounter(); pt_cur[i] += n_ - pt_last; pt_last = n_; }
 #define PT_STEP_END(empty) { const int o_ = (empty) ? 8 : 0; for (int i_ = 0; i_ < 8; i_++) { pt_acc[o_ + i_] += pt_cur[i_]; pt_cur[i_] = 0; } pt_acc[16 + ((empty) ? 1 : 0)] += 1; }
-#define PT_FLUSH if (threadIdx.x == 0 && S->dbg) { for (int i_ = 0; i_ < 8; i_++) pt_acc[i_] += pt_cur[i_]; for (int i_ = 0; i_ < 18; i_++) S->dbg[(size_t)blockIdx.x * 18 + i_] += pt_acc[i_]; }
+#ifndef EV2G_PT_TID
+#define EV2G_PT_TID 0   /* the lane whose clock is recorded (tools: -DEV2G_PT_TID=448 looks at wavefront 7 of a 512-thread workgroup) */
+#endif
+#define PT_FLUSH if (threadIdx.x == EV2G_PT_TID && S->dbg) { for (int i_ = 0; i_ < 8; i_++) pt_acc[i_] += pt_cur[i_]; for (int i_ = 0; i_ < 18; i_++) S->dbg[(size_t)blockIdx.x * 18 + i_] += pt_acc[i_]; }
 #elif defined(EV2G_PHASE_MARKERS)   /* ISA analysis only: phase boundaries as comments in the -S output */
 #define PT_DECL
 #define PT_MARK(i) asm volatile("; PHASE_MARK " #i);

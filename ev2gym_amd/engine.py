@@ -61,6 +61,7 @@ def load_library(path: Optional[str] = None):
         "ev2g_last_launch_specialisation": (C.c_int, [vp]),
         "ev2g_last_launch_general_reason": (C.c_char_p, [vp]),
         "ev2g_fallback_reason": (C.c_char_p, [vp]),
+        "ev2g_big_kernel_reason": (C.c_char_p, [vp]),
         "ev2g_step": (C.c_int, [vp, vp, vp, vp, vp, vp]),
         "ev2g_step_n": (C.c_int, [vp, C.c_int, C.c_int, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, C.c_int]),
         "ev2g_check_faults": (C.c_int, [vp, C.POINTER(i32)]),
@@ -114,7 +115,7 @@ def load_library(path: Optional[str] = None):
 EXPORTED_SYMBOLS = [
     "ev2g_abi_version", "ev2g_create", "ev2g_destroy", "ev2g_last_error", "ev2g_load_scenarios", "ev2g_n_envs",
     "ev2g_n_scenarios", "ev2g_n_ports", "ev2g_obs_dim", "ev2g_n_steps", "ev2g_current_step", "ev2g_reset", "ev2g_reset_ex",
-    "ev2g_scenario_offset", "ev2g_set_step_extras", "ev2g_kernel_name", "ev2g_last_launch_specialisation", "ev2g_last_launch_general_reason", "ev2g_fallback_reason", "ev2g_step", "ev2g_step_n",
+    "ev2g_scenario_offset", "ev2g_set_step_extras", "ev2g_kernel_name", "ev2g_last_launch_specialisation", "ev2g_last_launch_general_reason", "ev2g_fallback_reason", "ev2g_big_kernel_reason", "ev2g_step", "ev2g_step_n",
     "ev2g_check_faults", "ev2g_get_stats", "ev2g_get_stats_reset", "ev2g_get_stats_reset_f32", "ev2g_reset_f32", "ev2g_collect", "ev2g_stat_name", "ev2g_peek", "ev2g_malloc", "ev2g_free",
     "ev2g_memcpy_h2d", "ev2g_memcpy_d2h", "ev2g_synchronize", "ev2g_fill_uniform", "ev2g_host_uniform",
     "ev2g_last_step_n_kernel_ms", "ev2g_step_n_kernel_ms_back", "ev2g_mlp_create", "ev2g_mlp_create_ex", "ev2g_mlp_destroy", "ev2g_mlp_forward", "ev2g_rollout",
@@ -217,6 +218,11 @@ class Engine:
     @property
     def fallback_reason(self) -> str:
         return (self._lib.ev2g_fallback_reason(self._h) or b"").decode()
+
+    @property
+    def big_kernel_reason(self) -> str:
+        """Why a big env (512 < ports <= 1024) does NOT get `ev2g_step_big` for its specialised launches ("" when it does / not a big env)."""
+        return (self._lib.ev2g_big_kernel_reason(self._h) or b"").decode()
 
     @property
     def scenario_offset(self) -> int:

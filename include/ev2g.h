@@ -248,6 +248,9 @@ int ev2g_current_step(const ev2g_handle *h);
  * "ev2g_step_kernel"), and -- when the common-shape fast path was not taken -- why ("" otherwise). */
 const char *ev2g_kernel_name(const ev2g_handle *h);
 const char *ev2g_fallback_reason(const ev2g_handle *h);
+/* Round 6: big envs (512 < ports <= 1024) loaded on "ev2g_step_v2<1024>" run their specialised launches (ev2g_last_launch_specialisation 5) on
+ * "ev2g_step_big" when the batch qualifies; this returns why it does NOT ("" when it does, or when the shape is not a big env). */
+const char *ev2g_big_kernel_reason(const ev2g_handle *h);
 /* Which instantiation of the fast-path kernel the last ev2g_step / ev2g_step_n launch used: 0 = the general one (any subset of outputs,
  * strides, extras, in-launch resets); 1 = "full" (all four outputs with step stride 0 -- float64 actions in and float64 observations out, or, with the float32 action and
  * observation buffers of ev2g_set_step_extras registered and no float64 ones passed, float32 in and out: ev2g_rollout --, no cost output, no charger
@@ -259,7 +262,7 @@ const char *ev2g_fallback_reason(const ev2g_handle *h);
  * Round 5: 3 = 2 for outputs with STEP STRIDES (float64 [K,E,*] observation / reward / done / mask blocks of a persistent launch, every step kept:
  * generate_trajectories.py:69-83 style use; needs what 2 needs); 4 = the fused actor + step launch of ev2g_rollout / ev2g_collect (the policy
  * evaluated inside the step kernel's launch, one launch per segment; below).
- * Round 6: 5 = big envs (512 < ports <= 1024, single-port chargers, <= 64 transformers, <= 16 distinct charger tuples, windows below 16384 steps):
+ * Round 6: 5 = big envs (512 < ports <= 1024, single-port chargers, <= 50 transformers, <= 16 distinct charger tuples, windows below 16384 steps):
  * what 1 covers is run by "ev2g_step_big" -- 512 threads, two ports per home lane, 70 bytes of LDS per port, TWO workgroups per CU.  Port state,
  * observations, masks and transformer powers are bit-identical to 0 / 1; rewards and the episode sums of profits / energies come from a different
  * fixed summation tree (last-bit differences, tests hold them to 1e-12).  EV2G_NO_BIG=1 at load time keeps 1.

@@ -164,6 +164,11 @@ def test_fast_path_kernels_keep_four_wavefronts_per_simd_and_do_not_spill():
         assert v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
     # the statistics kernel keeps 40 entries of a session in registers: at most 256 VGPRs (two wavefronts per SIMD), no scratch -- one wavefront per SIMD
     # measured 52 us instead of 37 (DESIGN par.3, round 4)
+    # the big-env kernel (round 6): two 512-thread workgroups per CU need <= 128 VGPRs; a spilled value would come back through vmcnt in the step loop
+    big = {k: v for k, v in res.items() if "ev2g_step_big" in k}
+    assert len(big) == 1, sorted(big)
+    for k, v in big.items():
+        assert v["VGPRs"] <= 128 and v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
     stats = {k: v for k, v in res.items() if "ev2g_stats_kernel" in k}
     assert len(stats) == 4, sorted(stats)
     for k, v in stats.items():

@@ -86,3 +86,83 @@ def test_cfg4_full_size_whole_episode_against_the_oracle(no_big, monkeypatch):
         _close(pk["session_final_cap"][gone], po["session_cap"][gone], f"env {e}: capacity at departure")
     ora.close()
     eng.close()
+
+
+BIG_SHAPES = [(513, 1), (1024, 50), (777, 7), (640, 33)]
+
+
+@pytest.mark.parametrize("C,R", BIG_SHAPES, ids=[f"c{c}_r{r}" for c, r in BIG_SHAPES])
+def test_big_env_kernel_every_step_against_the_oracle(C, R):
+    """`ev2g_step_big` on the edges of its range (513 and 1024 ports, one and fifty transformers, uneven transformer segments): a whole episode of
+    single-step launches, every output of every step against the CPU oracle; then the same episode as ONE launch (last outputs, statistics, port state)."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine, host_uniform
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    from oracle.oracle import Oracle
+    E = 5
+    batch = generate_native(GenConfig.v2g_profit_plus_loads(E, C, R, seed=100 + C))
+    rk, sk = _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"]
+    eng = Engine(batch, rk, sk, device=0, flags=_abi.FLAG_LOG_SOC)
+    assert eng.big_kernel_reason == "", eng.big_kernel_reason
+    ora = Oracle(batch, rk, sk)
+    P, D, T = eng.P, eng.D, eng.T
+    acts = eng.empty((T, E, P)); eng.fill_uniform(acts, T * E * P, 77, -1.0, 1.0)
+    a_h = host_uniform(T * E * P, 77, -1.0, 1.0).reshape(T, E, P)
+    obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
+    eng.reset(obs)
+    ora.reset()
+    for t in range(T):
+        eng.step_n(1, acts.at(t * E * P), E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False)
+        assert eng.last_launch_specialisation == 5
+        o, r, d, m, rc = ora.step(a_h[t].copy())
+        assert rc == 0
+        assert np.array_equal(mask.to_host(), m), f"mask[{t}]"
+        assert np.array_equal(done.to_host(), d), f"done[{t}]"
+        _close(obs.to_host(), o, f"obs[{t}]")
+        _close(rew.to_host(), r, f"reward[{t}]")
+    st_steps = eng.stats().copy()
+    _close(st_steps, ora.stats(), "episode statistics")
+    pk_steps = [eng.peek(e) for e in range(E)]
+    for e in range(E):
+        po = ora.peek(e)
+        _close(pk_steps[e]["port_capacity"], po["cap"], f"env {e}: capacity")
+        assert np.array_equal(pk_steps[e]["port_cycles"], po["cycles"])
+        assert np.array_equal(pk_steps[e]["port_session"], po["session"])
+    eng.check_faults()
+    # one launch for the whole episode: the same results (the three launch-level energy / violation totals may group their additions differently)
+    eng.reset(obs)
+    eng.step_n(T, acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=True)
+    assert eng.last_launch_specialisation == 5
+    assert np.array_equal(mask.to_host(), m) and np.array_equal(done.to_host(), d)
+    _close(obs.to_host(), o, "last observation of the one-launch episode")
+    assert np.allclose(eng.stats(), st_steps, rtol=1e-12, atol=1e-12, equal_nan=True)
+    for e in range(E):
+        pk = eng.peek(e)
+        for k in ("port_capacity", "port_total_energy", "port_prev_power", "port_energy", "port_current", "power_usage", "tr_overload", "session_final_cap"):
+            assert np.array_equal(pk[k], pk_steps[e][k], equal_nan=True), (e, k)
+        assert np.array_equal(pk["port_cycles"], pk_steps[e]["port_cycles"]) and np.array_equal(pk["port_session"], pk_steps[e]["port_session"])
+    ora.close()
+    eng.close()
+
+
+def test_big_env_kernel_says_why_it_does_not_apply(monkeypatch):
+    """Routing is never silent: a big env that does not qualify reports the reason and runs `ev2g_step_v2<1024, 1>` (specialisation 1)."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    rk, sk = _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"]
+    batch = generate_native(GenConfig.v2g_profit_plus_loads(3, 600, 60, seed=1))   # 60 transformers: 1220 pair slots > 1024
+    eng = Engine(batch, rk, sk, device=0, flags=_abi.FLAG_LOG_SOC)
+    assert "transformers" in eng.big_kernel_reason
+    E, P, D, T = eng.E, eng.P, eng.D, eng.T
+    acts = eng.empty((E, P)); eng.fill_uniform(acts, E * P, 3, -1.0, 1.0)
+    obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
+    eng.reset(obs)
+    eng.step(acts, obs, rew, done, mask)
+    assert eng.last_launch_specialisation == 1
+    eng.close()
+    monkeypatch.setenv("EV2G_NO_BIG", "1")
+    batch = generate_native(GenConfig.v2g_profit_plus_loads(3, 600, 12, seed=1))
+    eng = Engine(batch, rk, sk, device=0, flags=_abi.FLAG_LOG_SOC)
+    assert eng.big_kernel_reason == "EV2G_NO_BIG is set"
+    eng.close()
