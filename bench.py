@@ -52,7 +52,7 @@ def measured_traffic(workload, launch, steps_per_launch, envs):
     WRITE_SIZE collected in separate --pmc runs, FETCH doubled per the gfx950 note in MI355X_MICROARCH.md) -- a stored figure of the same
     kernel on the same workload, NOT a measurement of this run (counters need rocprofv3 around the process): `roofline.traffic_source` names
     the file.  (None, None) when the shape was not profiled."""
-    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))[workload][launch]
         except Exception:
@@ -61,6 +61,23 @@ def measured_traffic(workload, launch, steps_per_launch, envs):
             continue   # (an older round may hold the matching shape)
         return (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0, "profiles/" + name + " (rocprofv3 PMC passes of an earlier run of this workload; not re-measured here)"
     return None, None
+
+
+def host_cores():
+    """Physical cores / sockets / logical CPUs of this host from /proc/cpuinfo (SURVEY par.8d asks for the core count next to the CPU figure)."""
+    try:
+        phys, sockets, logical = set(), set(), 0
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                logical += 1
+            elif line.startswith("physical id"):
+                pid = line.split(":")[1].strip(); sockets.add(pid)
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip(); phys.add((pid, cid))
+        return dict(physical_cores=len(phys) or None, sockets=len(sockets) or None, logical_cpus=logical or os.cpu_count())
+    except Exception:
+        return dict(physical_cores=None, sockets=None, logical_cpus=os.cpu_count())
 
 
 def cpu_baseline(batch, rk, sk, lo, budget_s=float(os.environ.get("EV2G_BENCH_CPU_BUDGET", "12.0"))):
@@ -107,9 +124,11 @@ def cpu_baseline(batch, rk, sk, lo, budget_s=float(os.environ.get("EV2G_BENCH_CP
         mt_total += time.perf_counter() - t0
         mt_steps += E * T
         mt_eps += 1
-    all_cores = dict(value=mt_steps / mt_total, cores=nthr, episodes=mt_eps) if mt_eps else None
+    all_cores = dict(value=mt_steps / mt_total, cores=nthr, episodes=mt_eps, **host_cores(),
+                     note="threads = min(logical CPUs, envs / 8); the 512-env sample gives each thread 8 envs per episode, so thread start-up and the "
+                          "hyper-threads' shared cores keep the speed-up far below the thread count -- a bound on what the host reaches, not a tuned CPU port") if mt_eps else None
     ora.close()
-    return dict(value=steps / t_total, unit="env-steps/s", cores=1, kind="port", all_cores=all_cores,
+    return dict(value=steps / t_total, unit="env-steps/s", cores=1, kind="port", all_cores=all_cores, host=host_cores(),
                 sample=f"{n} envs x {episodes} episodes x {T} steps of the same workload, C oracle -O2, 1 thread; "
                        f"reference CPython step() measured at build time: 1075 env-steps/s/core at 50 chargers (BASELINE.md)")
 
@@ -362,6 +381,12 @@ def kernel_roofline(bytes_env_step, E, steps_per_launch, launch_s, kernel):
             "avg_launch_us": launch_s * 1e6, "steps_per_launch": steps_per_launch, "algorithmic_bytes_per_env_step": bytes_env_step}
 
 
+def launched_kernel(eng):
+    """Name of the kernel the last launch ran: big envs run their specialised launches on ev2g_step_big (specialisation 5) although the handle's
+    general kernel is ev2g_step_v2<1024>."""
+    return "ev2g_step_big<512>" if getattr(eng, "last_launch_specialisation", -1) == 5 else eng.kernel_name
+
+
 def other_workload_record(Engine, name, E, local_rank, devx, rank, args, min_s=0.12):
     """One of the OTHER BASELINE single-GPU configs on the default line (configs[2] / configs[3]): its own scenario pool (two windows), whole
     episodes -- persistent 112-step launch + statistics + reset onto the other window -- for `min_s` seconds; the step kernel's launch
@@ -402,7 +427,7 @@ def other_workload_record(Engine, name, E, local_rank, devx, rank, args, min_s=0
         return {"workload": f"{name}: {wl['desc']}", "envs_per_gpu": E, "chargers": batch.n_chargers, "transformers": batch.n_transformers, "obs_dim": D,
                 "occupancy_phi": round(phi, 4), "value": E * T * n / spent, "unit": "env-steps/s", "ms_per_step": spent / (n * T) * 1e3,
                 "ms_per_episode": spent / n * 1e3, "episodes_timed": n, "launch": "persistent", "specialisation": eng.last_launch_specialisation,
-                "roofline": kernel_roofline(bes, E, T, launch_s, eng.kernel_name),
+                "roofline": kernel_roofline(bes, E, T, launch_s, launched_kernel(eng)),
                 "contains": "whole episodes: 112-step persistent launch + statistics kernel + reset onto fresh scenarios (wall clock around batches of eight queued episodes); "
                             "roofline from the step kernel's own HIP-event duration (mean over the last batch's launches)"}
     finally:
@@ -685,7 +710,7 @@ def main():
         traffic, traffic_source = measured_traffic(args.workload, mode, kern_steps / n_launch, Eg)
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": eng.kernel_name, "avg_launch_us": launch_s * 1e6, "steps_per_launch": kern_steps / n_launch,
+                "kernel": launched_kernel(eng), "avg_launch_us": launch_s * 1e6, "steps_per_launch": kern_steps / n_launch,
                 "algorithmic_bytes_per_env_step": bytes_env_step}
 
     def actor_kernel_times():
