@@ -1386,9 +1386,11 @@ int ev2g_mlp_debug_stamps(ev2g_handle *h, const ev2g_mlp *m, unsigned long long 
 // streaming kernel's 162 -> 400 -> 300 -> 64 packing.  Anything else (and EV2G_NO_FUSED=1) keeps the two launches per step.
 static bool fused_eligible(const ev2g_handle *h, const ev2g_mlp *m) {
     const DevScn &s = h->scn;
-    return h->wave_path && s.P >= 3 && s.P <= 64 && s.state_kind != EV2G_STATE_PUBLIC_PST && std::min(s.reward_kind, 3) != 3 && (h->cfg.flags & EV2G_FLAG_LOG_SOC) &&
-           !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) && !h->extras.cost && !h->no_full && !h->no_wide && (s.D & 1) == 0 &&
-           m->s16_ks1 == 6 && m->s16_nt1 == 25 && m->s16_nt2 == 19 && m->s16_nt3 == 4 && m->s16_nw == 1 && !std::getenv("EV2G_NO_FUSED");
+    // (round 6: PublicPST too -- its 3 + 3 P <= 63 inputs and P <= 20 outputs in the 64 -> 400 -> 300 -> 32 packing; the other states in 192 -> 400 -> 300 -> 64)
+    const bool pst = s.state_kind == EV2G_STATE_PUBLIC_PST;
+    return h->wave_path && s.P >= 3 && s.P <= 64 && std::min(s.reward_kind, 3) != 3 && (h->cfg.flags & EV2G_FLAG_LOG_SOC) &&
+           !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) && !h->extras.cost && !h->no_full && !h->no_wide && (pst || (s.D & 1) == 0) &&
+           m->s16_ks1 == (pst ? 2 : 6) && m->s16_nt1 == 25 && m->s16_nt2 == 19 && m->s16_nt3 == (pst ? 2 : 4) && m->s16_nw == 1 && !std::getenv("EV2G_NO_FUSED");
 }
 // k steps from the current one; obs0: the [E, D] float32 rows the first forward reads; obs / act / reward / done / mask: the rows of the segment's first
 // step with their step strides (elements; 0 = one row, overwritten)
@@ -1420,6 +1422,7 @@ static int launch_fused(ev2g_handle *h, const ev2g_mlp *m, int k, const float *o
     switch (s.state_kind * 4 + std::min(s.reward_kind, 3)) {
         EV2G_FUSED_CASE(0, 0) EV2G_FUSED_CASE(0, 1) EV2G_FUSED_CASE(0, 2)
 #ifndef EV2G_ONLY_00
+        EV2G_FUSED_CASE(1, 0) EV2G_FUSED_CASE(1, 1) EV2G_FUSED_CASE(1, 2)
         EV2G_FUSED_CASE(2, 0) EV2G_FUSED_CASE(2, 1) EV2G_FUSED_CASE(2, 2)
 #endif
         default: return fail(h, EV2G_ERR_STATE, "internal: no fused instantiation for this plugin pair");

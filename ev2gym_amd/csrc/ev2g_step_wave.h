@@ -153,7 +153,7 @@ template <int SK, int RK, bool IO32, int FULLK = 0, int BLOCK = EV2G_WAVE_BLOCK,
 __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
                                                            int k_steps, int auto_reset, WaveArgs wa, FusedArgs fa) {
     extern __shared__ double lds[];
-    static_assert(!ACT || (IO32 && FULLK == 2 && BLOCK == EV2G_FUSED_BLOCK && SK != 1), "the fused actor + step instantiation");
+    static_assert(!ACT || (IO32 && FULLK == 2 && BLOCK == EV2G_FUSED_BLOCK), "the fused actor + step instantiation");
     constexpr bool FULL = FULLK >= 1, WIDE = FULLK >= 2, STR = FULLK >= 3 || ACT;
     constexpr bool STR_NT = FULLK >= 3;   // the kept observation rows (0.6 GB per cfg2 launch) as streaming stores: they should not displace the state lines in L2 (-2 %, profiles/r05_ab_strided_nt.txt)
     constexpr bool F64 = FULL && !IO32, F32 = FULL && IO32;   // full with float64 actions in / observations out, or with the float32 hand-over
@@ -201,14 +201,17 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     constexpr int LUTMASK = FULL ? 0xfff : 0xffff;
     // ACT: the policy's input rows (bf16; env w of the workgroup = wavefront w = row w) and its actions behind the step's own LDS; its hidden
     // activations in the staging rows, which are dead between the end of a step and the next phase A (idle lanes re-zero their slots afterwards)
-    typedef MlpS16<6, 25, 19, 4, 1, 4, 1> MC;
+    // (round 6: PublicPST -- 3 + 3 P <= 63 inputs, P <= 20 outputs -- rides the 64 -> 400 -> 300 -> 32 packing: a third of layer 1's weight stream)
+    typedef typename std::conditional<SK == 1, MlpS16<2, 25, 19, 2, 1, 4, 1>, MlpS16<6, 25, 19, 4, 1, 4, 1>>::type MC;
+    constexpr int FSX = MC::SX;          // bf16 elements per observation row in LDS
+    constexpr int FKS1 = (SK == 1) ? 2 : 6, FNT3 = (SK == 1) ? 2 : 4;
     uint16_t *bufX = (uint16_t *)(cnt + 8);
     float *lbias = (float *)(bufX + 16 * EV2G_FUSED_SX);   // the three bias vectors (MC::NB floats), staged once per launch
     // the actions of env w: the first 64 floats of wavefront w's own slice of s_amps (dead between a step's phase C and the next phase A; the
     // wavefront reads its actions -- one instruction, all lanes -- before it writes the amps over them)
     float *act_lds = (float *)s_amps;
     uint16_t *bufH1 = (uint16_t *)stage, *bufH2 = bufH1 + 16 * MC::SH1;
-    static_assert(EV2G_FUSED_SX == MC::SX && 16 * (MC::SH1 + MC::SH2) * 2 <= EV2G_NQ * (EV2G_FUSED_BLOCK + 8) * 8, "policy buffers");
+    static_assert(MC::SX <= EV2G_FUSED_SX && MC::NB <= (25 + 19 + 4) * 16 && 16 * (MC::SH1 + MC::SH2) * 2 <= EV2G_NQ * (EV2G_FUSED_BLOCK + 8) * 8, "policy buffers");
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const bool log_soc = WIDE ? true : (S->soc_log != nullptr);
     const bool log_cs = FULL ? false : (S->cs_profits != nullptr);   // EV2G_FLAG_LOG_CS_HISTORY: charger-level accumulators and histories (ev2gym_env.py:533-535)
@@ -310,9 +313,14 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
         for (int j = 0; j < 2; j++) {
             const int c = 2 * lane + 128 * j;
             float2 v = make_float2(0.f, 0.f);
-            if (env_ok && c + 1 < D) v = *(const float2 *)(xr + c);   // (D even on this path: 22 + 40 + 2 P, 22 + 2 P)
-            else if (env_ok && c < D) v.x = xr[c];
-            if (c < EV2G_FUSED_SX) *(uint32_t *)(bufX + wv * EV2G_FUSED_SX + c) = ev2g_pack_bf16(v.x, v.y);   // columns D .. 199: zeros (the k-steps' padding)
+            if (SK == 1) {   // (D = 3 + 3 P may be odd: rows are 4-byte aligned only)
+                if (env_ok && c < D) v.x = xr[c];
+                if (env_ok && c + 1 < D) v.y = xr[c + 1];
+            } else {
+                if (env_ok && c + 1 < D) v = *(const float2 *)(xr + c);   // (D even: 22 + 40 + 2 P, 22 + 2 P)
+                else if (env_ok && c < D) v.x = xr[c];
+            }
+            if (c < FSX) *(uint32_t *)(bufX + wv * FSX + c) = ev2g_pack_bf16(v.x, v.y);   // columns D .. : zeros (the k-steps' padding)
         }
         if (tid < MC::NB) lbias[tid] = fa.m.b1[tid];   // (b1 | b2 | b3 are one array on this path, each padded to its tiles)
     }
@@ -384,7 +392,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
         double a_cur = a_next;   // this step's action; the prefetch below replaces a_next by the next step's
         if (ACT) {
             // ---- the policy, on the 16 observation rows of this workgroup's envs (ev2g_mlp3_inline, ev2g_mlp.h) ----
-            ev2g_mlp3_inline<6, 25, 19, 4, BLOCK / 64, EV2G_FUSED_RING>(fa.m, bufX, bufH1, bufH2, lbias, act_lds, 128, act_out, min(16, E - e0), tid_l);   // (starts and ends with a barrier: the actions are in LDS)
+            ev2g_mlp3_inline<FKS1, 25, 19, FNT3, BLOCK / 64, EV2G_FUSED_RING>(fa.m, bufX, bufH1, bufH2, lbias, act_lds, 128, act_out, min(16, E - e0), tid_l);   // (starts and ends with a barrier: the actions are in LDS)
             act_out += io.a_stride;
             a_cur = valid ? (double)act_lds[wv * 128 + q_l] : 0.0;
             // the staging slots of idle lanes must read as +0.0 in the per-env reduction (the lanes behind an env's last port never write them)
@@ -588,7 +596,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                 const unsigned o4 = WIDE ? hb_obs_port : hb_obs_env + ocol_l * 4u;
                 if (SK == 1) { stg32<float>(obs32, o4, 0.f); stg32<float>(obs32, o4 + 4u, 0.f); stg32<float>(obs32, o4 + 8u, 0.f); }
                 else stg32<f2v>(obs32, o4, (f2v){0.f, 0.f});
-                if (ACT) *(uint32_t *)(bufX + wv * EV2G_FUSED_SX + ocol_l) = 0u;
+                if (ACT) {
+                    if (SK == 1) { bufX[wv * FSX + ocol_l] = 0; bufX[wv * FSX + ocol_l + 1] = 0; bufX[wv * FSX + ocol_l + 2] = 0; }   // (odd columns: three 16-bit words)
+                    else *(uint32_t *)(bufX + wv * FSX + ocol_l) = 0u;
+                }
             }
         }
         if (valid && wave_live) {
@@ -694,7 +705,12 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                 const unsigned o4 = WIDE ? hb_obs_port : (FULL ? hb_obs_env + ocol_l * 4u : (unsigned)(e_l * D + ocol) * 4u);
                 if (SK == 1) { stg32<float>(obs32, o4, (float)o0); stg32<float>(obs32, o4 + 4u, (float)o1); stg32<float>(obs32, o4 + 8u, (float)o2); }
                 else stg32<f2v>(obs32, o4, (f2v){(float)o0, (float)o1});
-                if (ACT) *(uint32_t *)(bufX + wv * EV2G_FUSED_SX + ocol_l) = ev2g_pack_bf16((float)o0, (float)o1);   // the policy's copy of the same two columns
+                if (ACT) {   // the policy's copy of the same columns
+                    if (SK == 1) {
+                        const uint32_t w01 = ev2g_pack_bf16((float)o0, (float)o1), w2 = ev2g_pack_bf16((float)o2, 0.f);
+                        bufX[wv * FSX + ocol_l] = (uint16_t)w01; bufX[wv * FSX + ocol_l + 1] = (uint16_t)(w01 >> 16); bufX[wv * FSX + ocol_l + 2] = (uint16_t)w2;
+                    } else *(uint32_t *)(bufX + wv * FSX + ocol_l) = ev2g_pack_bf16((float)o0, (float)o1);
+                }
             }
             if (log_cs) {   // cs_power / cs_current of the step (ev2gym_env.py:533-535) and the chargers' current_power_output / current_total_amps
                 const double pw = occ ? stage[0 * RS + tid_l] : 0.0, cur = occ ? b_cur : 0.0;
@@ -901,16 +917,21 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
             const unsigned o4 = FULL ? hb_obs_env : (unsigned)(e_l * D) * 4u;
             if (SK == 1) {
                 if (q_l == 0) {
-                    stg32<float>(obs32, o4, (float)((double)sstep / (double)T));
-                    stg32<float>(obs32, o4 + 4u, (float)((sstep < T) ? pf_ob0 : 0.0));
-                    stg32<float>(obs32, o4 + 8u, (float)usage);
+                    const float h0 = (float)((double)sstep / (double)T), h1 = (float)((sstep < T) ? pf_ob0 : 0.0), h2 = (float)usage;
+                    stg32<float>(obs32, o4, h0);
+                    stg32<float>(obs32, o4 + 4u, h1);
+                    stg32<float>(obs32, o4 + 8u, h2);
+                    if (ACT) {   // the policy's copy: columns 0, 1 as one word, column 2 on its own (column 3 belongs to port 0)
+                        *(uint32_t *)(bufX + wv * FSX) = ev2g_pack_bf16(h0, h1);
+                        bufX[wv * FSX + 2] = (uint16_t)ev2g_pack_bf16(h2, 0.f);
+                    }
                 }
             } else {
                 if (q_l == 0) stg32<f2v>(obs32, o4, (f2v){(float)sstep, (float)usage});
                 if (q_l < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)q_l * 8u, (f2v){(float)pf_h0.x, (float)pf_h0.y});
                 if (ACT) {
-                    if (q_l == 0) *(uint32_t *)(bufX + wv * EV2G_FUSED_SX) = ev2g_pack_bf16((float)sstep, (float)usage);
-                    if (q_l < NPAIR) *(uint32_t *)(bufX + wv * EV2G_FUSED_SX + 2 + 2 * q_l) = ev2g_pack_bf16((float)pf_h0.x, (float)pf_h0.y);
+                    if (q_l == 0) *(uint32_t *)(bufX + wv * FSX) = ev2g_pack_bf16((float)sstep, (float)usage);
+                    if (q_l < NPAIR) *(uint32_t *)(bufX + wv * FSX + 2 + 2 * q_l) = ev2g_pack_bf16((float)pf_h0.x, (float)pf_h0.y);
                 }
                 if (!WIDE) {
                     if (q_l + P < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)(q_l + P) * 8u, (f2v){(float)pf_h1.x, (float)pf_h1.y});

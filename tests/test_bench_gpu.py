@@ -37,16 +37,15 @@ def test_bench_line_contract(extra):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.0 < r["frac"] < 1.0
     ro = d["rollout"]   # the configs[4]-shaped record rides on the default line
     assert ro["env_steps_per_s_per_gpu"] > 1e6 and 1.0 < ro["step_kernel_us"] < 200.0 and 1.0 < ro["actor_kernel_us"] < 200.0
-    if not extra:   # cfg2's shape (one env per wavefront) is eligible for the fused actor + step launch; cfg3's (three envs per wavefront) is not
-        assert ro["fused_launch"] is True and ro["launches_per_segment"] == 1 and 1.0 < ro["segment_kernel_us_per_step"] < 200.0
-        assert ro["collector"]["step_kernel_specialisation"] == 4
+    # the fused actor + step launch: every fast-path shape whose policy fits its packings (round 6: PublicPST too)
+    assert ro["fused_launch"] is True and ro["launches_per_segment"] == 1 and 1.0 < ro["segment_kernel_us_per_step"] < 200.0
+    assert ro["collector"]["step_kernel_specialisation"] == 4
+    if not extra:
         ps = d["persistent_strided"]   # every output kept: the strided wide instantiation, with its own roofline record
         assert ps["specialisation"] == 3 and 0.0 < ps["roofline"]["frac"] < 1.0
         ow = d["other_workloads"]      # BASELINE configs[2], configs[3] on the driver's line
         for name, kern in (("cfg3", "ev2g_step_wave<1,1>"), ("cfg4", "ev2g_step_big<512>")):
             assert ow[name]["value"] > 1e5 and 0.0 < ow[name]["roofline"]["frac"] < 1.0 and ow[name]["roofline"]["kernel"].startswith(kern), ow[name]
-    else:
-        assert ro["fused_launch"] is False
     rf = d["device_refill"]   # scenario generation on the device: never truncated, cheaper than the episode it feeds
     assert rf["truncated_scenarios"] == 0 and rf["scenarios_per_window"] == 512 and 0.0 < rf["us_per_window"] < 1e4
     assert rf["ms_per_episode_with_refill"] >= 0.5 * rf["ms_per_episode_without_refill"] > 0.0

@@ -13,13 +13,14 @@ def _engine(E, M, C, seed, state="V2G_profit_max_loads", reward="ProfitMax_TrPen
     from ev2gym_amd import _abi
     from ev2gym_amd.engine import Engine
     from ev2gym_amd.scenario_gen import GenConfig, generate_native
-    pool = generate_native(GenConfig.v2g_profit_plus_loads(M, C, 1, seed=seed))
+    pool = generate_native(GenConfig.public_pst(M, C, seed=seed) if state == "PublicPST" else GenConfig.v2g_profit_plus_loads(M, C, 1, seed=seed))
     eng = Engine(pool, _abi.REWARD_KINDS[reward], _abi.STATE_KINDS[state], flags=_abi.FLAG_LOG_SOC, n_active_envs=E)
     return eng, pool
 
 
 @pytest.mark.parametrize("state,E,C", [("V2G_profit_max_loads", 37, 50), ("V2G_profit_max_loads", 16, 64), ("V2G_profit_max", 21, 40),
-                                       ("V2G_profit_max_loads", 19, 25), ("V2G_profit_max_loads", 33, 7), ("V2G_profit_max", 5, 22)])
+                                       ("V2G_profit_max_loads", 19, 25), ("V2G_profit_max_loads", 33, 7), ("V2G_profit_max", 5, 22),
+                                       ("PublicPST", 37, 20), ("PublicPST", 16, 11), ("PublicPST", 50, 3)])   # round 6: PublicPST in the 64 -> 400 -> 300 -> 32 packing
 def test_fused_actor_and_step_launch_equals_the_two_kernel_chain(state, E, C, monkeypatch):
     """one launch per rollout segment -- the policy (obs -> 400 -> 300 -> ports, bf16 MFMA) evaluated INSIDE the step
     kernel's launch by the workgroup that steps the 16 envs whose rows it reads (ev2g_step_wave<.., 1024, true>) -- against round 4's chain of
@@ -35,9 +36,10 @@ def test_fused_actor_and_step_launch_equals_the_two_kernel_chain(state, E, C, mo
             monkeypatch.setenv("EV2G_NO_FUSED", "1")
         else:
             monkeypatch.delenv("EV2G_NO_FUSED", raising=False)
-        eng, pool = _engine(E, 2 * E, C, 5, state)
+        pst = state == "PublicPST"
+        eng, pool = _engine(E, 2 * E, C, 5, state, "SquaredTrackingErrorReward" if pst and E != 16 else "ProfitMax_TrPenalty_UserIncentives")
         P, D, T = eng.P, eng.D, eng.T
-        mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=9), out_lo=-1.0)
+        mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=9), out_lo=0.0 if pst else -1.0)
         obs, act = eng.empty((T + 1, E, D), np.float32), eng.empty((T, E, P), np.float32)
         rew, done, mask = eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
         nxt = eng.empty((E, D), np.float32)
