@@ -166,3 +166,93 @@ def test_big_env_kernel_says_why_it_does_not_apply(monkeypatch):
     eng = Engine(batch, rk, sk, device=0, flags=_abi.FLAG_LOG_SOC)
     assert eng.big_kernel_reason == "EV2G_NO_BIG is set"
     eng.close()
+
+
+def test_big_env_kernel_on_a_device_refilled_pool(monkeypatch):
+    """`ev2g_step_big` keeps a 15-entry table of the potential terms of the LOADED sessions and 16-bit windows: a pool loaded nearly empty (few sessions,
+    few car models) and then re-drawn on the device brings values the table does not hold (index 15: the port's state line is fetched instead).  It must
+    step whole episodes exactly like a pool loaded from the host-generated scenarios of the same stream."""
+    import dataclasses
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine, host_uniform
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    M, S1, C, R = 6, 53, 600, 12
+    monkeypatch.setenv("EV2G_POOL_SESSION_CAP", "1400")
+    cfg = GenConfig.v2g_profit_plus_loads(M, C, R, seed=S1)
+    host = generate_native(cfg)
+    sparse = generate_native(dataclasses.replace(GenConfig.v2g_profit_plus_loads(M, C, R, seed=977), spawn_multiplier=0.004))
+    assert 0 < sparse.n_sessions <= 60, sparse.n_sessions
+    rk, sk = _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"]
+    flags = _abi.FLAG_LOG_SOC | _abi.FLAG_REFILLABLE
+
+    def episode(eng):
+        E, P, D, T = eng.E, eng.P, eng.D, eng.T
+        acts = eng.empty((T, E, P)).upload(host_uniform(T * E * P, 600, -1.0, 1.0).reshape(T, E, P))
+        obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
+        rows = []
+        eng.reset(obs)
+        for t0, k in ((0, 40), (40, 1), (41, 71)):   # three launches: the table index travels through the state lines between them
+            eng.step_n(k, acts.at(t0 * E * P), E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=True)
+            assert eng.last_launch_specialisation == 5, eng.big_kernel_reason
+            rows.append((obs.to_host().copy(), rew.to_host().copy(), mask.to_host().copy()))
+        eng.check_faults()
+        return rows, np.nan_to_num(eng.stats(), nan=-7.0)
+
+    ref = Engine(host, rk, sk, flags=flags)
+    want_rows, want_stats = episode(ref)
+    ref.close()
+    eng = Engine(sparse, rk, sk, flags=flags)
+    eng.pool_refill(cfg, S1, 0, 0, M)
+    got_rows, got_stats = episode(eng)
+    assert eng.pool_refill_overflows == 0
+    for (o1, r1, m1), (o2, r2, m2) in zip(got_rows, want_rows):
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(m1, m2)
+    assert np.array_equal(got_stats, want_stats)
+    eng.close()
+
+
+def test_big_env_kernel_with_several_charger_classes():
+    """Chargers of different ratings (three classes of current limits, hence of power clamps): the class table in LDS against the CPU oracle."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine, host_uniform
+    from ev2gym_amd.scenario import ScenarioBatch
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    from oracle.oracle import Oracle
+    E, C, R = 4, 700, 9
+    b = generate_native(GenConfig.v2g_profit_plus_loads(E, C, R, seed=31))
+    a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in b.arrays.items()}
+    cls = np.arange(C) % 3
+    for name, scale in (("cs_max_charge_current", (1.0, 0.5, 0.75)), ("cs_max_discharge_current", (1.0, 0.5, 1.0))):
+        assert a[name].shape == (C,)
+        a[name] = a[name] * np.asarray(scale)[cls]
+    a["cs_min_charge_current"] = np.asarray([0.0, 6.0, 0.0])[cls]   # (class 1 has a minimum current: actions below it are cut to zero, ev_charger.py:167-170)
+    batch = dataclasses_replace_arrays(b, a)
+    rk, sk = _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"]
+    eng = Engine(batch, rk, sk, device=0, flags=_abi.FLAG_LOG_SOC)
+    assert eng.big_kernel_reason == "", eng.big_kernel_reason
+    ora = Oracle(batch, rk, sk)
+    P, D, T = eng.P, eng.D, eng.T
+    acts = eng.empty((T, E, P)); eng.fill_uniform(acts, T * E * P, 5, -1.0, 1.0)
+    a_h = host_uniform(T * E * P, 5, -1.0, 1.0).reshape(T, E, P)
+    obs, rew, done, mask = eng.empty((E, D)), eng.empty((E,)), eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
+    eng.reset(obs)
+    ora.reset()
+    for t in range(T):
+        eng.step_n(1, acts.at(t * E * P), E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False)
+        assert eng.last_launch_specialisation == 5
+        o, r, d, m, rc = ora.step(a_h[t].copy())
+        assert rc == 0 and np.array_equal(mask.to_host(), m), f"mask[{t}]"
+        _close(obs.to_host(), o, f"obs[{t}]")
+        _close(rew.to_host(), r, f"reward[{t}]")
+    _close(eng.stats(), ora.stats(), "episode statistics")
+    eng.check_faults()
+    ora.close()
+    eng.close()
+
+
+def dataclasses_replace_arrays(batch, arrays):
+    """A ScenarioBatch with the same metadata and other arrays."""
+    import copy
+    nb = copy.copy(batch)
+    nb.arrays = arrays
+    return nb
