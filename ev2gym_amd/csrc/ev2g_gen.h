@@ -411,6 +411,12 @@ EV2G_HD double ev2g_gen_setpoint_load(double w, double wsum, double need, int dt
 EV2G_HD int ev2g_gen_median_window(int dt) { return 5 * ((15 / dt) > 1 ? (15 / dt) : 1); }
 // median of the k values pad[t .. t + k) (k <= 80)
 EV2G_HD double ev2g_gen_median(const double *pad, int t, int k) {
+    if (k == 5) {    // (15-minute steps) a selection network on five values read once: max(min(a,b), min(c,d)), min(max(a,b), max(c,d)) and e hold the median
+                     // among them -- the same element the ranks below pick (finite values, no negative zeros: sums of non-negative loads)
+        const double a = pad[t], b = pad[t + 1], c = pad[t + 2], d = pad[t + 3], e = pad[t + 4];
+        const double f = fmax(fmin(a, b), fmin(c, d)), g = fmin(fmax(a, b), fmax(c, d));
+        return fmax(fmin(e, f), fmin(fmax(e, f), g));
+    }
     if (k <= 16) {   // by rank (no array to sort: on the device an indexed local array is scratch memory): element i has rank #{x_j < x_i} + #{j < i: x_j == x_i};
                      // the value(s) of the middle rank(s) are what the sort below finds
         double lo = 0.0, hi = 0.0;

@@ -11,10 +11,15 @@
 //   * EV sessions: a lane per port slot -- a port's sessions depend on that port's history only -- in two passes (count, prefix over
 //     the slots, write): device order (scenario, slot, arrival) is the order they are produced in, so there is no sort; the loader's
 //     per-session work (session record with its gates, efficiency-table id, AFAP energy, next-window chain, first-session tables) is
-//     done where the session is drawn;
+//     done where the session is drawn.  Round 6: the spawn trials of all steps first (a bit per step), then the sessions of all lanes
+//     that hit drawn together, round by round;
 //   * demand-response events: their slices are applied lane-parallel, `any` / `max` over the slice by ballot / wave max;
-//   * power setpoints: sessions port by port, a lane per step, weight sums on the wavefront's xor tree (ev2g_tree64 on the host).
-// The observation tables of the refilled slots are rebuilt afterwards by the loader's own table kernels, restricted to those slots.
+//   * power setpoints: round 6 -- only the (session, step of its stay) pairs, packed side by side on the lanes, two batches at a time;
+//     a session's weight sum still on the host's 64-leaf tree (ev2g_tree64), the accumulation in the host's session order;
+//   * observation tables (head / window table, step table incl. the occupancy masks) from LDS, a row per store (round 6).
+// What bounds it (round 6, profiles/r06_refill_*.txt): ~85 KB written per scenario (54 KB of it the head table) by 16 one-wavefront
+// workgroups per CU whose chains are a mix of float64 elementary functions and LDS / lane exchanges: 226 -> 180 us per 4096-scenario window
+// at cfg2, 361 -> 250 us per 8192 at cfg3.
 // Scope: a pool loaded with EV2G_FLAG_REFILLABLE (fixed-size session blocks per scenario).  Single-port chargers (every shipped config; the
 // fast path's shape): a port's sessions are the slot's.  Chargers with several ports and topology files (round 4; up to 256 steps / 256
 // ports): an arriving EV takes its charger's FIRST FREE port (ev_charger.py:266-286) -- what ev2g_load_scenarios replays on the host for a
@@ -48,6 +53,11 @@ struct RefillArgs {
         if (blockIdx.x == gridDim.x - 1 && ((i) == 0 || (i) == 6)) a.dbg[8 + ((i) != 0)] = __builtin_readcyclecounter(); \
         if (blockIdx.x == gridDim.x / 2 && ((i) == 0 || (i) == 6)) a.dbg[10 + ((i) != 0)] = __builtin_readcyclecounter(); }
 
+#ifdef EV2G_RF_SUBSTAMPS   // development: cycles of workgroup 0 per part of the setpoint phase, accumulated in dbg[16 + i]
+#define RF_SUB(i) { const unsigned long long now_ = __builtin_readcyclecounter(); if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[16 + (i)] += now_ - sub_t; sub_t = now_; }
+#else
+#define RF_SUB(i)
+#endif
 __device__ __forceinline__ double rf_wave_max(double v) {
     for (int d = 32; d > 0; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
     return v;
@@ -124,6 +134,9 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
         l_cp[t] = pr;
         RW(double, price_ch)[(size_t)ms * T + t] = -pr;
         RW(double, price_dis)[(size_t)ms * T + t] = pr * c.discharge_price_factor;
+        // (the fast path's per-step scalars, ev2g_build_step_table_kernel's rows, are written where their values are at hand: slots 0, 1 here,
+        //  2..4 with the transformer's series, 5 with the setpoints, 6 / 7 -- the occupancy masks -- at the end)
+        if (a.step_tab) { double *o8 = a.step_tab + ((size_t)ms * T + t) * 8; o8[0] = -pr; o8[1] = pr * c.discharge_price_factor; }
     }
 
     RF_STAMP(1)
@@ -143,11 +156,51 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
     for (int q0 = 0; q0 < P; q0 += 64) {
         const int q = q0 + lane;
         int n = 0, p = 0;
+        if (q < P) p = s.slot_port[q];
+#ifndef EV2G_RF_SERIAL_PASS1
+        const int t_end = g.T - g.min_stay_steps - 1;
+        if (t_end <= 128) {
+            // ev2g_gen_port_sessions' walk (ev2g_gen.h) in two parts.  The spawn trials do not depend on the port's history -- one hash round on the
+            // step's key each -- so all of them are taken first, the step index uniform over the wavefront (the keys come from LDS as broadcasts,
+            // several in flight), and kept as a bit per step.  Then rounds: every lane jumps to its next hit at or behind the step its port is free
+            // from (a count-trailing-zeros, no loop) and the sessions of all lanes that have one are drawn TOGETHER -- the two normal draws of a
+            // session were executed once per session of the scenario with one lane active (a quarter of this kernel), now once per round (a port
+            // draws ~0.7 sessions per episode: ~4 rounds).  Same trials, same draws, same order per port.
+            unsigned long long m0 = 0ull, m1 = 0ull;
+            const int e0 = min(t_end, 64);
+#pragma unroll 4
+            for (int t = 2; t < e0; t++) { const uint2 kt = l_kt[t]; if (kt.y != 0u && ev2g_gen_spawn_trial(kt.x, kt.y, p)) m0 |= 1ull << t; }
+#pragma unroll 4
+            for (int t = 64; t < t_end; t++) { const uint2 kt = l_kt[t]; if (kt.y != 0u && ev2g_gen_spawn_trial(kt.x, kt.y, p)) m1 |= 1ull << (t - 64); }
+            if (q >= P) { m0 = 0ull; m1 = 0ull; }
+            int free_from = 2;
+            for (;;) {
+                const unsigned long long a0 = (free_from < 64) ? ((m0 >> free_from) << free_from) : 0ull;
+                const unsigned long long a1 = (free_from <= 64) ? m1 : ((free_from < 128) ? ((m1 >> (free_from - 64)) << (free_from - 64)) : 0ull);
+                const bool hit = (a0 | a1) != 0ull;
+                if (__ballot(hit) == 0ull) break;
+                if (hit) {
+                    const int t = a0 ? (__ffsll((long long)a0) - 1) : (63 + __ffsll((long long)a1));
+                    Ev2gGenSession e;
+                    if (ev2g_gen_make_session(g, rng, fleet, share_sum, t, p, l_stay[t], l_emean[t], &e)) {
+                        free_from = e.t_dep + 2;
+                        if (n < EV2G_RF_K) { l_spawn[p * EV2G_RF_K + n] = (unsigned char)(e.t_arr - 1); if (multi) l_dep[p * EV2G_RF_K + n] = (unsigned char)e.t_dep; }
+                        n++;
+                    } else {
+                        free_from = t + 1;
+                    }
+                }
+            }
+        } else if (q < P) {
+            n = ev2g_gen_port_sessions(g, rng, fleet, share_sum, p, tab, [&](int i, const Ev2gGenSession &e) { if (i < EV2G_RF_K) { l_spawn[p * EV2G_RF_K + i] = (unsigned char)(e.t_arr - 1); if (multi) l_dep[p * EV2G_RF_K + i] = (unsigned char)e.t_dep; } });
+        }
+        if (q < P && multi) { l_pslot[p] = q; l_rcnt[q] = 0; l_free[p] = 0; }
+#else
         if (q < P) {
-            p = s.slot_port[q];
             n = ev2g_gen_port_sessions(g, rng, fleet, share_sum, p, tab, [&](int i, const Ev2gGenSession &e) { if (i < EV2G_RF_K) { l_spawn[p * EV2G_RF_K + i] = (unsigned char)(e.t_arr - 1); if (multi) l_dep[p * EV2G_RF_K + i] = (unsigned char)e.t_dep; } });
             if (multi) { l_pslot[p] = q; l_rcnt[q] = 0; l_free[p] = 0; }
         }
+#endif
         if (multi && n > K) { n = K; if (a.overflow) atomicAdd(a.overflow, 1); }   // (a port with more sessions than the replay remembers: cut, and counted)
         const int incl = rf_wave_incl_scan(n, lane);
         const int base = carry + incl - n;
@@ -367,6 +420,7 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
             const double sol = c.solar_power ? ev2g_gen_solar_at(g, dr.sun, sa, sm, capk, t) : 0.0;
             RW(double, tr_maxp)[o + t] = mxv; RW(double, tr_minp)[o + t] = mnv; RW(double, tr_infl)[o + t] = il; RW(double, tr_solar)[o + t] = sol;
             RW(double, tr_base)[o + t] = il + sol;
+            if (a.step_tab && k == 0) { double *o8 = a.step_tab + ((size_t)ms * T + t) * 8; o8[2] = il + sol; o8[3] = mxv; o8[4] = mnv; }   // (one transformer on the fast path)
             const double lfv = c.inflexible_loads ? ev2g_gen_load_forecast_at(g, rng_tr, k, t, il, mnv, mxv) : 0.0;
             const double pvv = c.solar_power ? ev2g_gen_pv_forecast_at(g, rng_tr, k, t, sol) : 0.0;
             RW(double, tr_lf)[o + t] = lfv; RW(double, tr_pvf)[o + t] = pvv;
@@ -393,62 +447,60 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
                 d_es[e] = on ? (int)l_dr[e * 3] : 0x7fffffff; d_ee[e] = on ? (int)l_dr[e * 3 + 1] : -1;
                 d_lim[e] = on ? peak - peak * l_dr[e * 3 + 2] / 100.0 : 0.0;
             }
-            // Two loops of (T + 1) * 20 elements each instead of one over both halves of a row: the halves share nothing, and in one loop every
-            // wavefront executed both bodies for every element (round 3: 80 k of the kernel's 220 k cycles).  Element i = step * 20 + j, i = lane,
-            // lane + 64, ...: (step, j) advance by (3, +4) with a carry -- no division per element.
-            {   // (loads - pv) window, Transformer.get_load_pv_forecast transformer.py:173-188: columns 0..19
-                int step = lane / 20, j = lane - step * 20;
-                for (int i = lane; i < (T + 1) * 20; i += 64) {
-                    const int kk = step + j;
-                    // the actual series for the current step (j == 0) and behind the horizon of the last one, the forecast otherwise; the same
-                    // element [min(kk, T - 1)] of either pair (1.0 * x == x)
-                    const bool actual = (kk < T) ? (j == 0) : (step >= T - 1);
-                    const double *lsrc = actual ? infl : l_lf, *psrc = actual ? l_sol : l_pvf;
-                    const int ke = min(kk, T - 1);
-                    const double v = lsrc[ke] - psrc[ke];
-                    if (wt) wt[step * 40 + j] = v;
-                    if (ht) ht[(size_t)step * 60 + 20 + j] = v;
-                    step += 3; j += 4;
-                    if (j >= 20) { j -= 20; step += 1; }
-                }
-            }
-            {   // power limits, Transformer.get_power_limits transformer.py:142-171: columns 20..39
-                int step = lane / 20, j = lane - step * 20;
-                for (int i = lane; i < (T + 1) * 20; i += 64) {
-                    double v = peak * 1.0;
+            // One ROW per iteration, a lane per column (the head table's 60: |price|, loads - pv, power limits -- 20 each; the window table's 40
+            // without the prices): a row is one contiguous 480-byte store, every line written once.  (Rounds 3-5 wrote the 20-column strips in
+            // separate loops of 64 consecutive strip elements: 160-byte pieces of four rows per store, every line of a row completed by three
+            // stores far apart in time -- with 16 wavefronts per CU writing 54 KB each, the partially written lines left the L2 in between.)
+            {
+                double *rows = ht ? ht : wt;
+                const int ncol = ht ? 60 : 40, c_lpv = ht ? 20 : 0, c_lim = c_lpv + 20;
+                const int typ = (lane < c_lpv) ? 0 : ((lane < c_lim) ? 1 : 2);
+                const int j = lane - ((typ == 0) ? 0 : ((typ == 1) ? c_lpv : c_lim));   // column inside the strip (lanes behind the row: computed, not stored)
+                if (rows) {
+#pragma unroll 2
+                    for (int step = 0; step <= T; step++) {
+                        const int kk = step + j, ke = min(kk, T - 1);
+                        // |charge price| of the next 20 steps, zero past the horizon (state.py:75-83, :121-129)
+                        const double vp = (kk < T) ? l_cp[ke] : 0.0;
+                        // (loads - pv) window, Transformer.get_load_pv_forecast transformer.py:173-188: the actual series for the current step (j == 0) and
+                        // behind the horizon of the last one, the forecast otherwise; the same element [min(kk, T - 1)] of either pair (1.0 * x == x)
+                        const bool actual = (kk < T) ? (j == 0) : (step >= T - 1);
+                        const double *lsrc = actual ? infl : l_lf, *psrc = actual ? l_sol : l_pvf;
+                        const double vl = lsrc[ke] - psrc[ke];
+                        // power limits, Transformer.get_power_limits transformer.py:142-171
+                        double vm = peak * 1.0;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        if (e < nd) {   // (uniform)
-                            const int es = d_es[e], ee = d_ee[e];
+                        for (int e = 0; e < 4; e++) {
+                            if (e < nd) {   // (uniform)
+                                const int es = d_es[e], ee = d_ee[e];
+                                if (step + ahead >= es && ee >= step) {
+                                    int aa, bb;
+                                    if (step > es) { aa = 0; bb = ee - step; } else { aa = es - step; bb = ee - step; }
+                                    if (aa < 0) aa = -aa;
+                                    if (bb < 0) bb = -bb;
+                                    if (j >= aa && j < bb) vm = d_lim[e];
+                                }
+                            }
+                        }
+                        for (int e = 4; e < nd; e++) {
+                            const int es = (int)l_dr[e * 3], ee = (int)l_dr[e * 3 + 1];
                             if (step + ahead >= es && ee >= step) {
                                 int aa, bb;
                                 if (step > es) { aa = 0; bb = ee - step; } else { aa = es - step; bb = ee - step; }
                                 if (aa < 0) aa = -aa;
                                 if (bb < 0) bb = -bb;
-                                if (j >= aa && j < bb) v = d_lim[e];
+                                if (j >= aa && j < bb) vm = peak - peak * l_dr[e * 3 + 2] / 100.0;
                             }
                         }
+                        const double v = (typ == 0) ? vp : ((typ == 1) ? vl : vm);
+                        if (lane < ncol) rows[(size_t)step * ncol + lane] = v;
                     }
-                    for (int e = 4; e < nd; e++) {
-                        const int es = (int)l_dr[e * 3], ee = (int)l_dr[e * 3 + 1];
-                        if (step + ahead >= es && ee >= step) {
-                            int aa, bb;
-                            if (step > es) { aa = 0; bb = ee - step; } else { aa = es - step; bb = ee - step; }
-                            if (aa < 0) aa = -aa;
-                            if (bb < 0) bb = -bb;
-                            if (j >= aa && j < bb) v = peak - peak * l_dr[e * 3 + 2] / 100.0;
-                        }
-                    }
-                    if (wt) wt[step * 40 + 20 + j] = v;
-                    if (ht) ht[(size_t)step * 60 + 40 + j] = v;
-                    step += 3; j += 4;
-                    if (j >= 20) { j -= 20; step += 1; }
                 }
             }
         }
     }
     // the price columns of the head table (|charge price| for the next 20 steps, zero past the horizon; state.py:75-83, :121-129)
-    if (a.head_tab) {
+    if (a.head_tab && a.head_nh != 60) {   // (the 60-column table got them with its rows above)
         double *ht = a.head_tab + (size_t)ms * (size_t)(T + 1) * a.head_nh;
         int step = lane / 20, cc = lane - step * 20;   // element i = step * 20 + cc advances by 64 = 3 * 20 + 4
         for (int i = lane; i < (T + 1) * 20; i += 64) {
@@ -463,9 +515,12 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
     __syncthreads();
     RF_STAMP(5)
     double *sp_out = RW(double, setpoint) + (size_t)ms * T;
+#ifdef EV2G_RF_SUBSTAMPS
+    unsigned long long sub_t = __builtin_readcyclecounter();
+#endif
     const int n_sess = min(total, cap);
     if (!c.power_setpoint_enabled || n_sess == 0) {
-        for (int t = lane; t < T; t += 64) sp_out[t] = 0.0;
+        for (int t = lane; t < T; t += 64) { sp_out[t] = 0.0; if (a.step_tab) a.step_tab[((size_t)ms * T + t) * 8 + 5] = 0.0; }
     } else {
         double pmax = 0.0, prmin = INFINITY;
         for (int t = lane; t < T; t += 64) pmax = fmax(pmax, l_cp[t]);
@@ -476,6 +531,122 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
         double *sp = l_a;   // [T] accumulators (the transformer loop is done with l_a)
         double *prel = l_x; // [T] price relative to the day's maximum: once per step instead of once per session and step (the same quotient)
         for (int t = lane; t < T; t += 64) { sp[t] = 0.0; prel[t] = l_cp[t] / pmax; }
+#ifndef EV2G_RF_SERIAL_SETPOINTS
+        // A session's weights are zero outside its stay (ev2g_gen_setpoint_weight) and a zero weight adds 0.0 to the accumulators, so only the
+        // (session, step-of-its-stay) pairs need the normal draw and the division: ~30 of a session's 112 steps.  Consecutive sessions (in the
+        // host's accumulation order) are PACKED into the wavefront, a lane per pair, as long as their stays fit 64 lanes together, and TWO such
+        // batches are in work at a time (their draws and divisions are independent chains the wavefront interleaves): this phase is a chain of
+        // dependent operations per session, not a number of instructions.  Sessions are described by a lane each (read by v_readlane, no LDS
+        // round trip per member); the accumulators sp[lane], sp[lane + 64] stay in registers.  Bit for bit the host's values: a session's weight
+        // sum is still taken on the 64-leaf tree with leaf (t mod 64) -- each member's weights are fetched from LDS to the lanes of their leaves,
+        // zeros elsewhere, the butterflies in the host's order 32 .. 1 -- and the accumulators receive the sessions one after the other.
+        int *l_ord = (int *)l_dr;                  // [<= 64] sessions in accumulation order (the events' LDS is free by now)
+        double *l_wb = l_x + T;                    // [2][64] weights (later: loads) of the pairs in work (the transformer's rows are free by now)
+        const int ns_u = __builtin_amdgcn_readfirstlane(n_sess);   // (the same on every lane; said so for the compiler)
+        bool packed_ok = ns_u <= 64 && T <= 128;
+        int d_k = 0, d_w0 = 0, d_L = 0;
+        if (packed_ok) {
+            int carry_o = 0;
+            for (int p0 = 0; p0 < P; p0 += 64) {   // rank of every port's first session in the accumulation order (generator ports ascending)
+                const int p = p0 + lane;
+                int base = 0, cnt = 0;
+                if (p < P) { base = l_pbase[p]; cnt = max(0, min(l_pcnt[p], cap - base)); }
+                const int incl = rf_wave_incl_scan(cnt, lane);
+                const int r0 = carry_o + incl - cnt;
+                for (int i = 0; i < cnt; i++) l_ord[r0 + i] = base + i;
+                carry_o += __shfl(incl, 63, 64);
+            }
+            __syncthreads();
+            bool plain = true;
+            if (lane < ns_u) {   // lane j describes session j of the order: its record, the first step of its stay, the stay's length
+                d_k = l_ord[lane];
+                d_w0 = l_ta[d_k] + 1;
+                d_L = max(min(l_td[d_k], T) - d_w0, 0);
+                plain = d_L <= 64 && l_hi[d_k] >= 0.0;   // (a negative upper bound would make fmin(0, hi) nonzero outside the stay: the serial walk below)
+            }
+            packed_ok = __ballot(!plain) == 0ull;
+        }
+        RF_SUB(0)
+        if (packed_ok) {
+            double acc0 = 0.0, acc1 = 0.0;   // sp[lane], sp[lane + 64]
+            int j = 0;
+            while (j < ns_u) {
+                // ---- two batches: sessions bj[u] .. bj[u] + bn[u] - 1 with their stays side by side on the lanes ----
+                int bj[2], bn[2], myk[2], myt[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    int nb = 0, tot = 0;
+                    bj[u] = j; myk[u] = -1; myt[u] = 0;
+                    while (j < ns_u) {
+                        const int L = __builtin_amdgcn_readlane(d_L, j);
+                        if (tot + L > 64) break;
+                        const int k = __builtin_amdgcn_readlane(d_k, j), w0 = __builtin_amdgcn_readlane(d_w0, j);
+                        if (lane >= tot && lane < tot + L) { myk[u] = k; myt[u] = w0 + (lane - tot); }
+                        tot += L; nb++; j++;
+                    }
+                    bn[u] = nb;
+                }
+                RF_SUB(1)
+                // ---- one weight per lane and batch (inside the stay: ev2g_gen_setpoint_weight's `win`) ----
+                double w[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const double x = fabs(rng.normal(EV2G_RS_SETPOINT, l_id[max(myk[u], 0)], (uint64_t)myt[u], 1 - prel[myt[u]], sd));
+                    w[u] = (myk[u] >= 0) ? x : 0.0;
+                    l_wb[u * 64 + lane] = w[u];
+                }
+                __syncthreads();
+                RF_SUB(2)
+                // ---- every member's weight sum on the host's tree: leaf v holds the weight of the member's step t with t mod 64 == v ----
+                double my_wsum[2] = {1.0, 1.0};
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    int off = 0;
+                    for (int b = 0; b < bn[u]; b++) {
+                        const int jj = bj[u] + b;
+                        const int L = __builtin_amdgcn_readlane(d_L, jj), k = __builtin_amdgcn_readlane(d_k, jj), w0 = __builtin_amdgcn_readlane(d_w0, jj);
+                        const int dl = (lane - w0) & 63;       // this leaf's step of the stay is w0 + dl
+                        double leaf = (dl < L) ? l_wb[u * 64 + off + dl] : 0.0;
+                        leaf += __shfl_xor(leaf, 32, 64); leaf += __shfl_xor(leaf, 16, 64);          // ev2g_tree64: 32, 16, ...
+                        leaf += dpp_mov_f64<0x128>(leaf); leaf += xor4_f64(leaf); leaf += xor2_f64(leaf); leaf += xor1_f64(leaf);   // ... 8, 4, 2, 1
+                        if (myk[u] == k) my_wsum[u] = fmax(leaf, 1e-12);
+                        off += L;
+                    }
+                }
+                RF_SUB(3)
+                // ---- one load per lane and batch ----
+                double val[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int kk = max(myk[u], 0);
+                    const double x = ev2g_gen_setpoint_load(w[u], my_wsum[u], l_need[kk], dt, l_lo[kk], l_hi[kk]);
+                    val[u] = (myk[u] >= 0) ? x : 0.0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 2; u++) l_wb[u * 64 + lane] = val[u];
+                __syncthreads();
+                RF_SUB(4)
+                // ---- the sessions add theirs to the accumulators one after the other ----
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    int off = 0;
+                    for (int b = 0; b < bn[u]; b++) {
+                        const int jj = bj[u] + b;
+                        const int L = __builtin_amdgcn_readlane(d_L, jj), w0 = __builtin_amdgcn_readlane(d_w0, jj);
+                        const int e0 = lane - w0, e1 = lane + 64 - w0;
+                        if (e0 >= 0 && e0 < L) acc0 += l_wb[u * 64 + off + e0];
+                        if (e1 >= 0 && e1 < L) acc1 += l_wb[u * 64 + off + e1];
+                        off += L;
+                    }
+                }
+                __syncthreads();
+                RF_SUB(5)
+            }
+            if (lane < T) sp[lane] = acc0;
+            if (lane + 64 < T) sp[lane + 64] = acc1;
+        } else
+#endif
         for (int p = 0; p < P; p++) {   // port by port, a port's sessions in time order: the host's accumulation order
             const int base = l_pbase[p], cnt = max(0, min(l_pcnt[p], cap - base));
             for (int i = 0; i < cnt; i++) {
@@ -495,35 +666,68 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
             }
         }
         __syncthreads();
+        RF_SUB(6)
         const int kw = ev2g_gen_median_window(dt), left = kw / 2;
         for (int i = lane; i < T + kw - 1; i += 64) { const int t = i - left; l_pad[i] = sp[t < 0 ? 0 : (t >= T ? T - 1 : t)]; }
         __syncthreads();
-        for (int t = lane; t < T; t += 64) sp_out[t] = ev2g_gen_median(l_pad, t, kw);
+        for (int t = lane; t < T; t += 64) { const double v = ev2g_gen_median(l_pad, t, kw); sp_out[t] = v; if (a.step_tab) a.step_tab[((size_t)ms * T + t) * 8 + 5] = v; }
     }
-    // the fast path's per-step scalars (ev2g_build_step_table_kernel's rows: one transformer)
+    RF_SUB(7)
+    // the fast path's occupancy / arrival masks of every step (step-table slots 6, 7; ev2g_build_occ_mask_kernel's values, ev2g_device.h)
     if (a.step_tab) {
         __syncthreads();
-        for (int t = lane; t < T; t += 64) {
-            double *o8 = a.step_tab + ((size_t)ms * T + t) * 8;
-            const size_t i = (size_t)ms * T + t;
-            o8[0] = s.price_ch[i]; o8[1] = s.price_dis[i]; o8[2] = s.tr_base[i]; o8[3] = s.tr_maxp[i]; o8[4] = s.tr_minp[i];
-            o8[5] = s.setpoint[i];
-        }
-        // slots 6, 7: the scenario's occupancy / arrival masks of every step -- ev2g_build_occ_mask_kernel's walk (ev2g_device.h), a lane per port slot,
-        // over the session windows this wavefront holds in LDS
-        int cur = 0, end = 0;
-        if (lane < P) { const int p = s.slot_port[lane]; cur = l_pbase[p]; end = cur + max(0, min(l_pcnt[p], cap - cur)); }
-        int ta = (cur < end) ? l_ta[cur] : EV2G_INT_MAX, td = (cur < end) ? l_td[cur] : EV2G_INT_MAX;
-        for (int t = 0; t < T; t++) {
-            const bool occ = (ta <= t) && (t <= td);
-            if (occ && t >= td) { cur++; ta = (cur < end) ? l_ta[cur] : EV2G_INT_MAX; td = (cur < end) ? l_td[cur] : EV2G_INT_MAX; }
-            const unsigned long long m_occ = __ballot(occ), m_arr = __ballot(ta == t + 1);
-            if (lane == 0) {
-                double *o8 = a.step_tab + ((size_t)ms * T + t) * 8;
-                o8[6] = __longlong_as_double((long long)m_occ); o8[7] = __longlong_as_double((long long)m_arr);
+        RF_SUB(8)
+        if (T <= 128) {
+            // A lane per port slot gathers its sessions' stays as a bit per step (occupied: t_arr .. t_dep; arriving at the end of step t: t_arr == t + 1),
+            // then one ballot per step turns the rows into the per-step masks over the ports; lane (t mod 64) keeps step t's pair and stores it.
+            // (The walk over the steps with a session cursor per lane -- an LDS round trip in the chain of every departure -- was a sixth of this kernel.)
+            unsigned long long o0 = 0ull, o1 = 0ull, r0 = 0ull, r1 = 0ull;
+            if (lane < P) {
+                const int p = s.slot_port[lane];
+                const int cur = l_pbase[p], end = cur + max(0, min(l_pcnt[p], cap - cur));
+                for (int i = cur; i < end; i++) {
+                    const int ta = l_ta[i], td = l_td[i];          // 1 <= ta <= td < T
+                    const int lo0 = min(ta, 64), hi0 = min(td + 1, 64);          // [ta, td] cut to steps 0..63
+                    if (hi0 > lo0) o0 |= ((hi0 - lo0 >= 64) ? ~0ull : ((1ull << (hi0 - lo0)) - 1ull)) << lo0;
+                    const int lo1 = max(ta, 64) - 64, hi1 = max(td + 1, 64) - 64;   // ... and to steps 64..127
+                    if (hi1 > lo1) o1 |= ((hi1 - lo1 >= 64) ? ~0ull : ((1ull << (hi1 - lo1)) - 1ull)) << lo1;
+                    if (ta - 1 < 64) r0 |= 1ull << (ta - 1); else r1 |= 1ull << (ta - 1 - 64);
+                }
+            }
+            unsigned long long k_occ = 0ull, k_arr = 0ull;
+            const int n0 = min(T, 64);
+            for (int t = 0; t < n0; t++) {
+                const unsigned long long m_occ = __ballot((o0 >> t) & 1ull), m_arr = __ballot((r0 >> t) & 1ull);
+                if (lane == t) { k_occ = m_occ; k_arr = m_arr; }
+            }
+            if (lane < n0) {
+                double *o8 = a.step_tab + ((size_t)ms * T + lane) * 8;
+                o8[6] = __longlong_as_double((long long)k_occ); o8[7] = __longlong_as_double((long long)k_arr);
+            }
+            for (int t = 64; t < T; t++) {
+                const unsigned long long m_occ = __ballot((o1 >> (t - 64)) & 1ull), m_arr = __ballot((r1 >> (t - 64)) & 1ull);
+                if (lane == t - 64) { k_occ = m_occ; k_arr = m_arr; }
+            }
+            if (lane + 64 < T) {
+                double *o8 = a.step_tab + ((size_t)ms * T + lane + 64) * 8;
+                o8[6] = __longlong_as_double((long long)k_occ); o8[7] = __longlong_as_double((long long)k_arr);
+            }
+        } else {
+            int cur = 0, end = 0;
+            if (lane < P) { const int p = s.slot_port[lane]; cur = l_pbase[p]; end = cur + max(0, min(l_pcnt[p], cap - cur)); }
+            int ta = (cur < end) ? l_ta[cur] : EV2G_INT_MAX, td = (cur < end) ? l_td[cur] : EV2G_INT_MAX;
+            for (int t = 0; t < T; t++) {
+                const bool occ = (ta <= t) && (t <= td);
+                if (occ && t >= td) { cur++; ta = (cur < end) ? l_ta[cur] : EV2G_INT_MAX; td = (cur < end) ? l_td[cur] : EV2G_INT_MAX; }
+                const unsigned long long m_occ = __ballot(occ), m_arr = __ballot(ta == t + 1);
+                if (lane == 0) {
+                    double *o8 = a.step_tab + ((size_t)ms * T + t) * 8;
+                    o8[6] = __longlong_as_double((long long)m_occ); o8[7] = __longlong_as_double((long long)m_arr);
+                }
             }
         }
     }
+    RF_SUB(9)
     RF_STAMP(6)
 #undef RW
 }

@@ -147,11 +147,16 @@ static int ev2g_pool_refill_impl(ev2g_handle *h, const ev2g_gen_config *cfg, uin
     a.dbg = nullptr;
     if (std::getenv("EV2G_REFILL_STAMPS")) {   // development: cycle stamps of workgroup 0, printed at the next call
         static unsigned long long *d_dbg = nullptr;
-        if (!d_dbg) { (void)hipMalloc((void **)&d_dbg, 16 * 8); (void)hipMemset(d_dbg, 0, 16 * 8); }
+        if (!d_dbg) { (void)hipMalloc((void **)&d_dbg, 32 * 8); (void)hipMemset(d_dbg, 0, 32 * 8); }
         else {
-            unsigned long long v[12];
+            unsigned long long v[32];
             (void)hipStreamSynchronize(h->stream);
-            (void)hipMemcpy(v, d_dbg, 96, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(v, d_dbg, 256, hipMemcpyDeviceToHost);
+            if (v[16] | v[17] | v[18]) {   // (-DEV2G_RF_SUBSTAMPS: the setpoint phase in parts, summed over the calls so far)
+                std::fprintf(stderr, "[ev2g] refill setpoint parts (cycles, summed): order %llu | batches %llu | weights %llu | sums %llu | loads %llu | accumulate %llu | median prep %llu | median %llu | step rows %llu | masks %llu\n",
+                             v[16], v[17], v[18], v[19], v[20], v[21], v[22], v[23], v[24], v[25]);
+                (void)hipMemset(d_dbg + 16, 0, 16 * 8);
+            }
             std::fprintf(stderr, "[ev2g] refill: workgroup 0 runs %llu cycles; the middle workgroup starts %lld cycles after it and runs %llu; the last one starts %lld after and runs %llu\n",
                          v[6] - v[0], (long long)(v[10] - v[0]), v[11] - v[10], (long long)(v[8] - v[0]), v[9] - v[8]);
             std::fprintf(stderr, "[ev2g] refill stamps (cycles): prices %llu | step tables %llu | pass 1 %llu | pass 2 %llu | transformer series %llu | observation tables %llu | setpoints %llu\n",
