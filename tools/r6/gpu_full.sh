@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: whole GPU suite + the default bench line on the tree as it stands
 cd "$GRAFT_REPO_ROOT"; O=gpurun_out/${1:-r6_full}; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -5 | tee $O/gpu_tests.txt
+timeout 1500 python -m pytest tests -m gpu -q -x > $O/gpu_tests_full.txt 2>&1; grep -E "passed|failed|error" $O/gpu_tests_full.txt | tail -3 | tee $O/gpu_tests.txt
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
 python - <<PY
 import json
