@@ -1403,12 +1403,14 @@ static int launch_fused(ev2g_handle *h, const ev2g_mlp *m, int k, const float *o
         return fail(h, EV2G_ERR_ARG, "ev2g_collect / ev2g_rollout: a step stride is negative or reaches 4 GiB");
     StepIO io = make_io(h, nullptr, a_stride, nullptr, o_stride, reward, r_stride, done, d_stride, mask, m_stride, 0, 0);
     io.act32 = act; io.obs32 = obs;
-    const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.hist, st.env_acc, s.cs_pack, (char *)st.line, h->d_step_tab, (char *)st.port_dyn, s.dict, 1, s.P};
+    // round 6: PublicPST envs of at most 32 ports go TWO to a wavefront (32 policy rows per workgroup; EV2G_FUSED_ONE_ENV=1: the one-env form, for A/B)
+    const int ae = (s.state_kind == EV2G_STATE_PUBLIC_PST && s.P <= 32 && !std::getenv("EV2G_FUSED_ONE_ENV")) ? 2 : 1;
+    const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.hist, st.env_acc, s.cs_pack, (char *)st.line, h->d_step_tab, (char *)st.port_dyn, s.dict, ae, ae == 1 ? s.P : 32};
     FusedArgs fa{};
     fa.m = m->dev; fa.obs0 = obs0;
     const V2P *pp = (const V2P *)h->d_v2p;
-    const size_t lds = ev2g_fused_lds_bytes();
-    const dim3 grid((s.E + 15) / 16), block(EV2G_FUSED_BLOCK);
+    const size_t lds = ev2g_fused_lds_bytes(ae);
+    const dim3 grid((s.E + 16 * ae - 1) / (16 * ae)), block(EV2G_FUSED_BLOCK);
     const int t0 = h->current_step;
 #define EV2G_FUSED_CASE(SK, RK)                                                                                                            \
     case SK * 4 + RK: {                                                                                                                    \
@@ -1419,15 +1421,26 @@ static int launch_fused(ev2g_handle *h, const ev2g_mlp *m, int k, const float *o
         }                                                                                                                                  \
         hipLaunchKernelGGL(kfn, grid, block, lds, h->stream, pp, io, t0, k, 0, wa, fa);                                                     \
     } break;
-    switch (s.state_kind * 4 + std::min(s.reward_kind, 3)) {
+#define EV2G_FUSED_CASE2(RK)                                                                                                               \
+    case 16 + RK: {                                                                                                                        \
+        auto kfn = ev2g_step_wave<1, RK, true, 2, EV2G_FUSED_BLOCK, true, 2>;                                                               \
+        if (!(h->fused_attr_mask & (1u << (16 + RK)))) {                                                                                   \
+            HIPCHK(h, hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+            h->fused_attr_mask |= 1u << (16 + RK);                                                                                         \
+        }                                                                                                                                  \
+        hipLaunchKernelGGL(kfn, grid, block, lds, h->stream, pp, io, t0, k, 0, wa, fa);                                                     \
+    } break;
+    switch (ae == 2 ? 16 + std::min(s.reward_kind, 3) : s.state_kind * 4 + std::min(s.reward_kind, 3)) {
         EV2G_FUSED_CASE(0, 0) EV2G_FUSED_CASE(0, 1) EV2G_FUSED_CASE(0, 2)
 #ifndef EV2G_ONLY_00
         EV2G_FUSED_CASE(1, 0) EV2G_FUSED_CASE(1, 1) EV2G_FUSED_CASE(1, 2)
         EV2G_FUSED_CASE(2, 0) EV2G_FUSED_CASE(2, 1) EV2G_FUSED_CASE(2, 2)
+        EV2G_FUSED_CASE2(0) EV2G_FUSED_CASE2(1) EV2G_FUSED_CASE2(2)
 #endif
         default: return fail(h, EV2G_ERR_STATE, "internal: no fused instantiation for this plugin pair");
     }
 #undef EV2G_FUSED_CASE
+#undef EV2G_FUSED_CASE2
     HIPCHK(h, hipGetLastError());
     h->last_spec = 4;
     h->general_reason = "";

@@ -587,9 +587,10 @@ __device__ __forceinline__ void ev2g_mlp_lds_barrier() { asm volatile("s_waitcnt
 // slots: the head of the sequence is requested before the first barrier, fragment s + RING the moment fragment s has been consumed, across tile and
 // layer boundaries and barriers (weights do not depend on activations), so the CU's vector-memory port works from the first cycle on and only the
 // compute waits (the scheme of ev2g_mlp3_s16; a wavefront here holds 13 fragments instead of 26).  `act` rows are `as` floats apart.
-template <int KS1, int NT1, int NT2, int NT3, int WVS, int RING>
+// RB (round 6): blocks of 16 env rows per workgroup -- a weight fragment feeds RB MFMAs (rows 0..15, 16..31), each row's chain as in the one-block form.
+template <int KS1, int NT1, int NT2, int NT3, int WVS, int RING, int RB = 1>
 __device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t *bufX, uint16_t *bufH1, uint16_t *bufH2, const float *lb, float *act, int as, float *y, int nr, int tid) {
-    typedef MlpS16<KS1, NT1, NT2, NT3, 1, 4, 1> C;
+    typedef MlpS16<KS1, NT1, NT2, NT3, 1, 4, RB> C;
     constexpr int KS2 = C::KS2, KS3 = C::KS3;
     constexpr int MT1 = (NT1 + WVS - 1) / WVS, MT2 = (NT2 + WVS - 1) / WVS, MT3 = (NT3 + WVS - 1) / WVS;
     constexpr int S1 = MT1 * KS1, S2 = MT2 * KS2, S3 = MT3 * KS3, STOT = S1 + S2 + S3;
@@ -613,7 +614,7 @@ __device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t
     // first barrier: every wavefront's observation columns of the step before (or the prologue's rows) are in bufX, and nobody still reads the
     // staging rows the hidden activations are about to use
     ev2g_mlp_lds_barrier();
-    if (tid < 256) {   // columns no tile writes (the next layer's k-steps read them): zeros
+    if (tid < 256 * RB) {   // columns no tile writes (the next layer's k-steps read them): zeros
         const int pj = tid & 15, pr = tid >> 4;
         constexpr int P1 = KS2 * 32 - NT1 * 16, P2 = KS3 * 32 - NT2 * 16;
         if (pj < P1) bufH1[pr * C::SH1 + NT1 * 16 + pj] = 0;
@@ -628,37 +629,47 @@ __device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t
         for (int i = 0; i < MT; i++) {
             const int tile = wave + WVS * i;
             if (WVS * i + WVS - 1 < NT || tile < NT) {   // (uniform; a constant but for the last slot)
-                f32x4m acc0 = *(const f32x4m *)(bias + tile * 16 + kq * 4), acc1 = f32x4m{0.f, 0.f, 0.f, 0.f};
+                f32x4m acc0[RB], acc1[RB];
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++) { acc0[rb] = *(const f32x4m *)(bias + tile * 16 + kq * 4); acc1[rb] = f32x4m{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
                     const int sq = base + i * KS + ks;
-                    bf16x8 a, b;
+                    bf16x8 a;
                     __builtin_memcpy(&a, &ring[sq % RING], 16);
-                    const uint4 bw = *(const uint4 *)(A + brow * sa + ks * 32 + kq * 8);
-                    __builtin_memcpy(&b, &bw, 16);
-                    if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0, 0, 0, 0);
+#pragma unroll
+                    for (int rb = 0; rb < RB; rb++) {   // (one weight fragment, RB blocks of rows)
+                        bf16x8 b;
+                        const uint4 bw = *(const uint4 *)(A + (rb * 16 + brow) * sa + ks * 32 + kq * 8);
+                        __builtin_memcpy(&b, &bw, 16);
+                        if (ks & 1) acc1[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1[rb], 0, 0, 0);
+                        else acc0[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0[rb], 0, 0, 0);
+                    }
                     request(sq + RING);   // this slot is free again
                 }
-                const f32x4m acc = acc0 + acc1;
-                const int col = tile * 16 + kq * 4;   // this lane: columns col .. col + 3 of env row `brow`
-                if (L < 2) {
-                    const uint32_t lo = ev2g_pack_bf16(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f)), hi = ev2g_pack_bf16(fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
-                    *(uint2 *)(out + brow * so + col) = make_uint2(lo, hi);
-                } else {
-                    float v[4];
+                const int col = tile * 16 + kq * 4;   // this lane: columns col .. col + 3 of env rows `brow`, `brow + 16`
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { v[r] = ev2g_fast_tanh(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
-                    *(float4 *)(act + brow * as + col) = make_float4(v[0], v[1], v[2], v[3]);   // (NT3 <= 4: columns 0..63)
-                    const int d_out = m.d_out;
-                    if (brow < nr) {
-                        float *yr = y + (size_t)brow * d_out + col;
-                        if ((d_out & 1) == 0) {
-                            if (col + 1 < d_out) *(float2 *)yr = make_float2(v[0], v[1]);
-                            if (col + 3 < d_out) *(float2 *)(yr + 2) = make_float2(v[2], v[3]);
-                        } else {
+                for (int rb = 0; rb < RB; rb++) {
+                    const f32x4m acc = acc0[rb] + acc1[rb];
+                    const int erow = rb * 16 + brow;
+                    if (L < 2) {
+                        const uint32_t lo = ev2g_pack_bf16(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f)), hi = ev2g_pack_bf16(fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+                        *(uint2 *)(out + erow * so + col) = make_uint2(lo, hi);
+                    } else {
+                        float v[4];
 #pragma unroll
-                            for (int r = 0; r < 4; r++) if (col + r < d_out) yr[r] = v[r];
+                        for (int r = 0; r < 4; r++) { v[r] = ev2g_fast_tanh(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
+                        *(float4 *)(act + erow * as + col) = make_float4(v[0], v[1], v[2], v[3]);   // (NT3 <= 4: columns 0..63)
+                        const int d_out = m.d_out;
+                        if (erow < nr) {
+                            float *yr = y + (size_t)erow * d_out + col;
+                            if ((d_out & 1) == 0) {
+                                if (col + 1 < d_out) *(float2 *)yr = make_float2(v[0], v[1]);
+                                if (col + 3 < d_out) *(float2 *)(yr + 2) = make_float2(v[2], v[3]);
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) if (col + r < d_out) yr[r] = v[r];
+                            }
                         }
                     }
                 }

@@ -30,9 +30,12 @@ __host__ __device__ inline size_t ev2g_wave_lds_bytes(int envs_per_group, int bl
 #ifndef EV2G_FUSED_RING
 #define EV2G_FUSED_RING 10    // weight fragments a wavefront keeps in flight (ev2g_mlp3_inline)
 #endif
+#ifndef EV2G_FUSED_RING2
+#define EV2G_FUSED_RING2 7    // the same with two envs per wavefront (AE = 2): the second row block's accumulators and operand take 12 registers
+#endif
 
-__host__ __device__ inline size_t ev2g_fused_lds_bytes() {
-    return ev2g_wave_lds_bytes(EV2G_FUSED_BLOCK / 64, EV2G_FUSED_BLOCK) + (size_t)16 * EV2G_FUSED_SX * 2 + (size_t)(25 + 19 + 4) * 16 * 4;   // + input rows, biases
+__host__ __device__ inline size_t ev2g_fused_lds_bytes(int envs_per_wave = 1) {
+    return ev2g_wave_lds_bytes(EV2G_FUSED_BLOCK / 64 * envs_per_wave, EV2G_FUSED_BLOCK) + (size_t)16 * EV2G_FUSED_SX * 2 + (size_t)(25 + 19 + 4) * 16 * 4;   // + input rows, biases
 }
 // What the fused instantiation needs besides the step's own arguments: the policy, and the observation rows its first forward reads.
 // StepIO then carries the OUTPUT blocks: obs32 = the rows the steps write (row of the launch's first step; o_stride floats between steps, 0: one row
@@ -149,11 +152,14 @@ struct WaveArgs {
 // ev2g_rollout) instead of two per step -- no kernel boundary, so no cold start of either kernel, the port state stays in LDS across the segment
 // like in any persistent launch, observations reach the policy and actions reach the step through LDS, and the weights are streamed once per CU and step.
 // The outputs (observation / action / reward / done / mask rows of every step) go to the caller's blocks through running pointers.
-template <int SK, int RK, bool IO32, int FULLK = 0, int BLOCK = EV2G_WAVE_BLOCK, bool ACT = false>
+// AE (round 6; ACT with PublicPST, P <= 32): TWO envs per wavefront in the fused instantiation (lanes 0..31 / 32..63), 32 policy rows per workgroup -- every weight
+// fragment feeds two MFMAs, the weight stream per env halves, and 8192 envs are one round of 256 workgroups instead of two rounds of 512.
+template <int SK, int RK, bool IO32, int FULLK = 0, int BLOCK = EV2G_WAVE_BLOCK, bool ACT = false, int AE = 1>
 __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
                                                            int k_steps, int auto_reset, WaveArgs wa, FusedArgs fa) {
     extern __shared__ double lds[];
     static_assert(!ACT || (IO32 && FULLK == 2 && BLOCK == EV2G_FUSED_BLOCK), "the fused actor + step instantiation");
+    static_assert(AE == 1 || (ACT && SK == 1 && AE == 2), "two envs per wavefront in the fused instantiation: PublicPST only");
     constexpr bool FULL = FULLK >= 1, WIDE = FULLK >= 2, STR = FULLK >= 3 || ACT;
     constexpr bool STR_NT = FULLK >= 3;   // the kept observation rows (0.6 GB per cfg2 launch) as streaming stores: they should not displace the state lines in L2 (-2 %, profiles/r05_ab_strided_nt.txt)
     constexpr bool F64 = FULL && !IO32, F32 = FULL && IO32;   // full with float64 actions in / observations out, or with the float32 hand-over
@@ -175,8 +181,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
 #define PA(k) (slabP + PS8 * (unsigned long long)(k))
     // envs per wavefront.  The fused instantiation gives EVERY env a wavefront of its own, whatever its width (a policy row is an env: 16 rows per
     // workgroup; the step's time is a chain of latencies, not lanes): the lanes behind the env's last port only copy observation-head pairs
-    const int EPW = ACT ? 1 : wa.epw;
-    const int ES = ACT ? P : wa.es;      // lanes from one env of the wavefront to the next
+    const int EPW = ACT ? AE : wa.epw;
+    const int ES = ACT ? (AE == 1 ? P : 32) : wa.es;      // lanes from one env of the wavefront to the next
     const int G = (BLOCK / 64) * EPW;    // envs per workgroup
     int grp;
     {   // XCD-aware mapping: workgroup b runs on XCD b % 8; give each XCD a contiguous range of env groups
@@ -202,7 +208,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     // ACT: the policy's input rows (bf16; env w of the workgroup = wavefront w = row w) and its actions behind the step's own LDS; its hidden
     // activations in the staging rows, which are dead between the end of a step and the next phase A (idle lanes re-zero their slots afterwards)
     // (round 6: PublicPST -- 3 + 3 P <= 63 inputs, P <= 20 outputs -- rides the 64 -> 400 -> 300 -> 32 packing: a third of layer 1's weight stream)
-    typedef typename std::conditional<SK == 1, MlpS16<2, 25, 19, 2, 1, 4, 1>, MlpS16<6, 25, 19, 4, 1, 4, 1>>::type MC;
+    typedef typename std::conditional<SK == 1, MlpS16<2, 25, 19, 2, 1, 4, AE>, MlpS16<6, 25, 19, 4, 1, 4, AE>>::type MC;
     constexpr int FSX = MC::SX;          // bf16 elements per observation row in LDS
     constexpr int FKS1 = (SK == 1) ? 2 : 6, FNT3 = (SK == 1) ? 2 : 4;
     uint16_t *bufX = (uint16_t *)(cnt + 8);
@@ -210,8 +216,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     // the actions of env w: the first 64 floats of wavefront w's own slice of s_amps (dead between a step's phase C and the next phase A; the
     // wavefront reads its actions -- one instruction, all lanes -- before it writes the amps over them)
     float *act_lds = (float *)s_amps;
-    uint16_t *bufH1 = (uint16_t *)stage, *bufH2 = bufH1 + 16 * MC::SH1;
-    static_assert(MC::SX <= EV2G_FUSED_SX && MC::NB <= (25 + 19 + 4) * 16 && 16 * (MC::SH1 + MC::SH2) * 2 <= EV2G_NQ * (EV2G_FUSED_BLOCK + 8) * 8, "policy buffers");
+    uint16_t *bufH1 = (uint16_t *)stage, *bufH2 = bufH1 + 16 * AE * MC::SH1;
+    static_assert(AE * MC::SX <= EV2G_FUSED_SX && MC::NB <= (25 + 19 + 4) * 16 && 16 * AE * (MC::SH1 + MC::SH2) * 2 <= EV2G_NQ * (EV2G_FUSED_BLOCK + 8) * 8, "policy buffers");
+    constexpr int ACT_AS = (AE == 1) ? 128 : 64;   // floats between two envs' action rows in s_amps (a wavefront's slice holds its envs' rows)
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const bool log_soc = WIDE ? true : (S->soc_log != nullptr);
     const bool log_cs = FULL ? false : (S->cs_profits != nullptr);   // EV2G_FLAG_LOG_CS_HISTORY: charger-level accumulators and histories (ev2gym_env.py:533-535)
@@ -220,16 +227,17 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
 
     // ---- home lane set-up ----
     const int elw = lane / ES;           // env inside the wavefront
-    const int q = ACT ? lane : lane - elw * ES;       // port slot (== reference port: one transformer, single-port chargers)
-    const int e = ACT ? e0 + wv : e0 + wv * EPW + elw;
+    const int q = (ACT && AE == 1) ? lane : lane - elw * ES;       // port slot (== reference port: one transformer, single-port chargers)
+    const int e = (ACT && AE == 1) ? e0 + wv : e0 + wv * EPW + elw;
     const bool valid = (elw < EPW) && (q < P) && (e < E);
-    const bool hcopy = ACT && !valid && e < E && lane < 32;   // (ACT, envs narrower than their head pairs: lanes P .. NPAIR-1 copy the pairs the ports cannot)
+    const bool hcopy = ACT && AE == 1 && !valid && e < E && lane < 32;   // (ACT, envs narrower than their head pairs: lanes P .. NPAIR-1 copy the pairs the ports cannot)
     const int g = valid ? e * P + q : 0;
     const int ocol = (SK == 1) ? 3 + 3 * q : (SK == 0 ? 62 + 2 * q : 22 + 2 * q);
     const int cs = valid ? q : 0;
     int t = t0;
     const bool head = valid && q == 0;   // one lane per env: env-level scalars
     const int elg = wv * EPW + elw;      // env inside the workgroup
+    const int arow = (AE == 1) ? wv : min(elg, 16 * AE - 1);   // (ACT) this lane's env as a row of the policy's buffers
     // ---- launch prologue.  A single-step launch (the RL loop with a policy between steps) pays it every step, with cold caches.
     // Round trip 1: what does not depend on data -- charger constants, the first action, the env accumulators and, for a single-step launch,
     // the scenario's occupancy / arrival masks of this step (step table slots 6, 7: occupancy does not depend on the actions); for a longer
@@ -307,11 +315,11 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     if (tid < 4) cnt[tid] = 0;
     for (int k = 0; k < EV2G_NQ; k++) stage[k * RS + tid] = 0.0;
     if (ACT) {   // the observation the first forward reads (the reset observation, or the last step's of an earlier segment): this wavefront's env row -> bf16
-        const bool env_ok = (e0 + wv) < E;   // (one env per wavefront)
-        const float *xr = fa.obs0 + (long long)(env_ok ? e0 + wv : e0) * D;
+        const bool env_ok = (e0 + arow) < E;   // (one env per wavefront; AE = 2: one per half)
+        const float *xr = fa.obs0 + (long long)(env_ok ? e0 + arow : e0) * D;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const int c = 2 * lane + 128 * j;
+            const int c = (AE == 1) ? 2 * lane + 128 * j : 2 * (lane & 31) + 64 * j;
             float2 v = make_float2(0.f, 0.f);
             if (SK == 1) {   // (D = 3 + 3 P may be odd: rows are 4-byte aligned only)
                 if (env_ok && c < D) v.x = xr[c];
@@ -320,7 +328,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                 if (env_ok && c + 1 < D) v = *(const float2 *)(xr + c);   // (D even: 22 + 40 + 2 P, 22 + 2 P)
                 else if (env_ok && c < D) v.x = xr[c];
             }
-            if (c < FSX) *(uint32_t *)(bufX + wv * FSX + c) = ev2g_pack_bf16(v.x, v.y);   // columns D .. : zeros (the k-steps' padding)
+            if (c < FSX) *(uint32_t *)(bufX + arow * FSX + c) = ev2g_pack_bf16(v.x, v.y);   // columns D .. : zeros (the k-steps' padding)
         }
         if (tid < MC::NB) lbias[tid] = fa.m.b1[tid];   // (b1 | b2 | b3 are one array on this path, each padded to its tiles)
     }
@@ -392,9 +400,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
         double a_cur = a_next;   // this step's action; the prefetch below replaces a_next by the next step's
         if (ACT) {
             // ---- the policy, on the 16 observation rows of this workgroup's envs (ev2g_mlp3_inline, ev2g_mlp.h) ----
-            ev2g_mlp3_inline<FKS1, 25, 19, FNT3, BLOCK / 64, EV2G_FUSED_RING>(fa.m, bufX, bufH1, bufH2, lbias, act_lds, 128, act_out, min(16, E - e0), tid_l);   // (starts and ends with a barrier: the actions are in LDS)
+            ev2g_mlp3_inline<FKS1, 25, 19, FNT3, BLOCK / 64, (AE == 1 ? EV2G_FUSED_RING : EV2G_FUSED_RING2), AE>(fa.m, bufX, bufH1, bufH2, lbias, act_lds, ACT_AS, act_out, min(16 * AE, E - e0), tid_l);   // (starts and ends with a barrier: the actions are in LDS)
             act_out += io.a_stride;
-            a_cur = valid ? (double)act_lds[wv * 128 + q_l] : 0.0;
+            a_cur = valid ? (double)act_lds[arow * ACT_AS + q_l] : 0.0;
             // the staging slots of idle lanes must read as +0.0 in the per-env reduction (the lanes behind an env's last port never write them)
             if (!valid) {
 #pragma unroll
@@ -597,8 +605,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                 if (SK == 1) { stg32<float>(obs32, o4, 0.f); stg32<float>(obs32, o4 + 4u, 0.f); stg32<float>(obs32, o4 + 8u, 0.f); }
                 else stg32<f2v>(obs32, o4, (f2v){0.f, 0.f});
                 if (ACT) {
-                    if (SK == 1) { bufX[wv * FSX + ocol_l] = 0; bufX[wv * FSX + ocol_l + 1] = 0; bufX[wv * FSX + ocol_l + 2] = 0; }   // (odd columns: three 16-bit words)
-                    else *(uint32_t *)(bufX + wv * FSX + ocol_l) = 0u;
+                    if (SK == 1) { bufX[arow * FSX + ocol_l] = 0; bufX[arow * FSX + ocol_l + 1] = 0; bufX[arow * FSX + ocol_l + 2] = 0; }   // (odd columns: three 16-bit words)
+                    else *(uint32_t *)(bufX + arow * FSX + ocol_l) = 0u;
                 }
             }
         }
@@ -708,8 +716,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                 if (ACT) {   // the policy's copy of the same columns
                     if (SK == 1) {
                         const uint32_t w01 = ev2g_pack_bf16((float)o0, (float)o1), w2 = ev2g_pack_bf16((float)o2, 0.f);
-                        bufX[wv * FSX + ocol_l] = (uint16_t)w01; bufX[wv * FSX + ocol_l + 1] = (uint16_t)(w01 >> 16); bufX[wv * FSX + ocol_l + 2] = (uint16_t)w2;
-                    } else *(uint32_t *)(bufX + wv * FSX + ocol_l) = ev2g_pack_bf16((float)o0, (float)o1);
+                        bufX[arow * FSX + ocol_l] = (uint16_t)w01; bufX[arow * FSX + ocol_l + 1] = (uint16_t)(w01 >> 16); bufX[arow * FSX + ocol_l + 2] = (uint16_t)w2;
+                    } else *(uint32_t *)(bufX + arow * FSX + ocol_l) = ev2g_pack_bf16((float)o0, (float)o1);
                 }
             }
             if (log_cs) {   // cs_power / cs_current of the step (ev2gym_env.py:533-535) and the chargers' current_power_output / current_total_amps
@@ -922,16 +930,16 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                     stg32<float>(obs32, o4 + 4u, h1);
                     stg32<float>(obs32, o4 + 8u, h2);
                     if (ACT) {   // the policy's copy: columns 0, 1 as one word, column 2 on its own (column 3 belongs to port 0)
-                        *(uint32_t *)(bufX + wv * FSX) = ev2g_pack_bf16(h0, h1);
-                        bufX[wv * FSX + 2] = (uint16_t)ev2g_pack_bf16(h2, 0.f);
+                        *(uint32_t *)(bufX + arow * FSX) = ev2g_pack_bf16(h0, h1);
+                        bufX[arow * FSX + 2] = (uint16_t)ev2g_pack_bf16(h2, 0.f);
                     }
                 }
             } else {
                 if (q_l == 0) stg32<f2v>(obs32, o4, (f2v){(float)sstep, (float)usage});
                 if (q_l < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)q_l * 8u, (f2v){(float)pf_h0.x, (float)pf_h0.y});
                 if (ACT) {
-                    if (q_l == 0) *(uint32_t *)(bufX + wv * FSX) = ev2g_pack_bf16((float)sstep, (float)usage);
-                    if (q_l < NPAIR) *(uint32_t *)(bufX + wv * FSX + 2 + 2 * q_l) = ev2g_pack_bf16((float)pf_h0.x, (float)pf_h0.y);
+                    if (q_l == 0) *(uint32_t *)(bufX + arow * FSX) = ev2g_pack_bf16((float)sstep, (float)usage);
+                    if (q_l < NPAIR) *(uint32_t *)(bufX + arow * FSX + 2 + 2 * q_l) = ev2g_pack_bf16((float)pf_h0.x, (float)pf_h0.y);
                 }
                 if (!WIDE) {
                     if (q_l + P < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)(q_l + P) * 8u, (f2v){(float)pf_h1.x, (float)pf_h1.y});

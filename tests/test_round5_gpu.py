@@ -20,7 +20,8 @@ def _engine(E, M, C, seed, state="V2G_profit_max_loads", reward="ProfitMax_TrPen
 
 @pytest.mark.parametrize("state,E,C", [("V2G_profit_max_loads", 37, 50), ("V2G_profit_max_loads", 16, 64), ("V2G_profit_max", 21, 40),
                                        ("V2G_profit_max_loads", 19, 25), ("V2G_profit_max_loads", 33, 7), ("V2G_profit_max", 5, 22),
-                                       ("PublicPST", 37, 20), ("PublicPST", 16, 11), ("PublicPST", 50, 3)])   # round 6: PublicPST in the 64 -> 400 -> 300 -> 32 packing
+                                       ("PublicPST", 37, 20), ("PublicPST", 16, 11), ("PublicPST", 50, 3),    # round 6: PublicPST in the 64 -> 400 -> 300 -> 32 packing
+                                       ("PublicPST", 65, 20), ("PublicPST", 33, 19)])                     # ... two envs per wavefront (32 policy rows per workgroup), ragged last workgroup / last wavefront
 def test_fused_actor_and_step_launch_equals_the_two_kernel_chain(state, E, C, monkeypatch):
     """one launch per rollout segment -- the policy (obs -> 400 -> 300 -> ports, bf16 MFMA) evaluated INSIDE the step
     kernel's launch by the workgroup that steps the 16 envs whose rows it reads (ev2g_step_wave<.., 1024, true>) -- against round 4's chain of
