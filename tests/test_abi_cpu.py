@@ -115,6 +115,17 @@ int main() {
     double leaves[64];
     for (int i = 0; i < 64; i++) leaves[i] = i + 1;
     if (ev2g_tree64(leaves) != 2080.0) return 3;
+    // the median filter of the power setpoints: the five-value selection network (15-minute steps) picks the element the rank walk picks (k = 15: 5-minute steps)
+    for (uint32_t it = 0; it < 200000; it++) {
+        double pad[15];
+        for (int i = 0; i < 15; i++) pad[i] = (double)(ev2g_hash32(it * 15u + (uint32_t)i) %% 9u) * 0.25;   // many ties
+        double s5[5], s15[15];
+        for (int i = 0; i < 5; i++) s5[i] = pad[i];
+        for (int i = 0; i < 15; i++) s15[i] = pad[i];
+        for (int i = 1; i < 5; i++) for (int j = i; j > 0 && s5[j - 1] > s5[j]; j--) { const double t = s5[j]; s5[j] = s5[j - 1]; s5[j - 1] = t; }
+        for (int i = 1; i < 15; i++) for (int j = i; j > 0 && s15[j - 1] > s15[j]; j--) { const double t = s15[j]; s15[j] = s15[j - 1]; s15[j - 1] = t; }
+        if (ev2g_gen_median(pad, 0, 5) != s5[2] || ev2g_gen_median(pad, 0, 15) != s15[7]) return 4;
+    }
     std::printf("%%.3e %%.3e %%.3e %%.3e\\n", w[0], w[1], w[2], w[3]);
     return (w[0] < 2e-15 && w[1] < 2e-15 && w[2] < 2e-15 && w[3] < 2e-15 && ev2g_rng(1, 2).uni(3, 4, 5) < 1.0) ? 0 : 1;
 }

@@ -154,6 +154,11 @@ def _refill_cfgs():
         # round 4: chargers with several ports -- an arriving EV takes its charger's first free port (ev_charger.py:266-286), replayed in the kernel
         "v2gppl_c12_np3": lambda M, seed: GenConfig.v2g_profit_plus_loads(M, 12, 2, seed=seed, number_of_ports_per_cs=3, spawn_multiplier=6.0),
         "topology": lambda M, seed: GenConfig.v2g_profit_plus_loads(M, seed=seed, topology=_refill_topology(), spawn_multiplier=8.0),
+        # round 6: the shapes the refill kernel's packed paths hand back to the serial walks -- more than 128 steps (spawn-trial bit rows, mask bit rows,
+        # register accumulators of the setpoints), stays longer than 64 steps (a session no longer fits the wavefront's lanes), more than 64 sessions per scenario
+        "pst_c20_dt5_t288": lambda M, seed: GenConfig.public_pst(M, 20, seed=seed, timescale=5, simulation_length=288),
+        "pst_c20_dt5_t120": lambda M, seed: GenConfig.public_pst(M, 20, seed=seed, timescale=5, simulation_length=120),
+        "pst_c64_busy": lambda M, seed: GenConfig.public_pst(M, 64, seed=seed, spawn_multiplier=8.0),   # 57..75 sessions per scenario: both setpoint paths in one window
     }
 
 
@@ -165,7 +170,7 @@ def _refill_topology():
                 voltage=np.where(np.arange(C) % 3, 400.0, 230.0), phases=np.where(np.arange(C) % 4 == 1, 1, 3), tr_max_power=np.array([90.0, 60.0, 45.0]))
 
 
-@pytest.mark.parametrize("name", ["v2gppl_c50", "pst_c20", "v2gppl_c30_r3", "homog_pst_public", "v2gppl_c12_np3", "topology"])
+@pytest.mark.parametrize("name", ["v2gppl_c50", "pst_c20", "v2gppl_c30_r3", "homog_pst_public", "v2gppl_c12_np3", "topology", "pst_c20_dt5_t288", "pst_c20_dt5_t120", "pst_c64_busy"])
 def test_device_generated_scenarios_equal_the_host_generator_bit_for_bit(name):
     """ev2g_pool_refill draws scenarios ON THE DEVICE (EV2Gym.reset()'s per-episode draw, ev2gym_env.py:243-296, without host work):
     pool slot s refilled as scenario i of the stream (config, seed) must hold what ev2g_generate yields at index i -- same seed, same
