@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
         int *l_ord = (int *)l_dr;                  // [<= 64] sessions in accumulation order (the events' LDS is free by now)
         double *l_wb = l_x + T;                    // [2][64] weights (later: loads) of the pairs in work (the transformer's rows are free by now)
         const int ns_u = __builtin_amdgcn_readfirstlane(n_sess);   // (the same on every lane; said so for the compiler)
-        bool packed_ok = ns_u <= 64 && T <= 128;
+        bool packed_ok = ns_u <= 64 && T <= 128 && T >= 16;   // (a lane per session descriptor; two accumulators per lane; l_wb's 128 doubles inside X's 2 T + 96 free ones)
         int d_k = 0, d_w0 = 0, d_L = 0;
         if (packed_ok) {
             int carry_o = 0;
