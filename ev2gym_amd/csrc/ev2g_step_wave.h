@@ -161,7 +161,11 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     static_assert(!ACT || (IO32 && FULLK == 2 && BLOCK == EV2G_FUSED_BLOCK), "the fused actor + step instantiation");
     static_assert(AE == 1 || (ACT && SK == 1 && AE == 2), "two envs per wavefront in the fused instantiation: PublicPST only");
     constexpr bool FULL = FULLK >= 1, WIDE = FULLK >= 2, STR = FULLK >= 3 || ACT;
-    constexpr bool STR_NT = FULLK >= 3;   // the kept observation rows (0.6 GB per cfg2 launch) as streaming stores: they should not displace the state lines in L2 (-2 %, profiles/r05_ab_strided_nt.txt)
+#ifdef EV2G_STR_NT_OFF   // (A/B: the kept rows as ordinary stores)
+    constexpr bool STR_NT = false;
+#else
+    constexpr bool STR_NT = FULLK >= 3;
+#endif   // the kept observation rows (0.6 GB per cfg2 launch) as streaming stores: they should not displace the state lines in L2 (-2 %, profiles/r05_ab_strided_nt.txt)
     constexpr bool F64 = FULL && !IO32, F32 = FULL && IO32;   // full with float64 actions in / observations out, or with the float32 hand-over
 #if defined(EV2G_PHASE_TIMING) && defined(EV2G_PT_OUTER)
     const unsigned long long pt_k0 = __builtin_readcyclecounter();   // slot 7 := prologue, slot 6 := epilogue (tools/phase_timing.py --outer)
