@@ -424,7 +424,14 @@ def other_workload_record(Engine, name, E, local_rank, devx, rank, args, min_s=0
             loop.run(T, True, timing=tim)
             launch_s = tim[0][0] / 1e3
         bes = workload_bytes_env_step(wl, P, batch.n_transformers, phi)
-        return {"workload": f"{name}: {wl['desc']}", "envs_per_gpu": E, "chargers": batch.n_chargers, "transformers": batch.n_transformers, "obs_dim": D,
+        extra = {}
+        if name == "cfg3" and not args.no_rollout_record:   # round 6: the fused actor + step launch covers PublicPST (two envs per wavefront): its device-resident collector on the driver's line
+            try:
+                extra["collector"] = collector_record(Engine, batch, rk, sk, local_rank, devx, E, wl["lo"], rank, args, T, min_s=0.15)
+                extra["collector"]["actor"] = f"fused MLP {D}->400->300->{P} tanh, bf16 operands on the matrix cores, inside the step kernel's launch when step_kernel_specialisation == 4"
+            except Exception as ex:   # (the stand-in engines of the CPU tests have no collector)
+                extra["collector"] = {"error": str(ex)}
+        return {**extra, "workload": f"{name}: {wl['desc']}", "envs_per_gpu": E, "chargers": batch.n_chargers, "transformers": batch.n_transformers, "obs_dim": D,
                 "occupancy_phi": round(phi, 4), "value": E * T * n / spent, "unit": "env-steps/s", "ms_per_step": spent / (n * T) * 1e3,
                 "ms_per_episode": spent / n * 1e3, "episodes_timed": n, "launch": "persistent", "specialisation": eng.last_launch_specialisation,
                 "roofline": kernel_roofline(bes, E, T, launch_s, launched_kernel(eng)),

@@ -70,3 +70,7 @@ def test_default_bench_line_holds_the_roofline_fractions():
     assert ow["cfg3"]["roofline"]["frac"] >= 0.32, ow["cfg3"]               # 0.35
     assert ow["cfg4"]["roofline"]["frac"] >= 0.52, ow["cfg4"]               # ev2g_step_big: 0.58-0.62 (ev2g_step_v2<1024, 1>: 0.41)
     assert ow["cfg4"]["roofline"]["kernel"] == "ev2g_step_big<512>" and ow["cfg4"]["specialisation"] == 5
+    # the device-resident collector at cfg3: the fused actor + step launch with two PublicPST envs per wavefront (one round of 256 workgroups): 727-737 M measured,
+    # 497 M with one env per wavefront, 409-431 M as two launches per step
+    col = ow["cfg3"]["collector"]
+    assert col["step_kernel_specialisation"] == 4 and col["env_steps_per_s_per_gpu"] >= 6.0e8, col
