@@ -256,3 +256,63 @@ def dataclasses_replace_arrays(batch, arrays):
     nb = copy.copy(batch)
     nb.arrays = arrays
     return nb
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_randomised_device_refill_equals_the_host_generator(case):
+    """Round 6 restructured ev2g_refill_kernel (spawn trials as a bit row + converged session draws, packed setpoint pairs, masks by ballot, tables a row per
+    store).  A randomised sweep over what tests/test_fuzz_gpu.py draws -- shapes, timescales (96 .. 112 steps), scenarios, fleets, setpoints, demand response,
+    multi-port chargers, topology files -- holds the device draw to ev2g_generate bit for bit by behaviour: a pool loaded from OTHER scenarios and refilled
+    on the device steps a whole episode (observations, rewards, masks of every step, the statistics) exactly like a pool loaded from the host-generated ones."""
+    import dataclasses
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine, EngineError, host_uniform
+    from ev2gym_amd.scenario_gen import generate_native
+    from tests.test_fuzz_gpu import _draw
+    rng, cfg = _draw(500 + case)
+    M = 12
+    S1 = int(cfg.seed)
+    mk = lambda n, seed: dataclasses.replace(cfg, n_envs=n, seed=seed)   # noqa: E731
+    host = generate_native(mk(M + 5, S1))
+    other = generate_native(mk(M, S1 + 7919))
+    if host.n_sessions == 0 or other.n_sessions == 0:
+        pytest.skip("a draw without sessions")
+    pst = bool(cfg.power_setpoint_enabled) and host.n_transformers == 1 and int(np.max(host.arrays.get("cs_n_ports", np.ones(1)))) == 1
+    kinds = ("SquaredTrackingErrorReward", "PublicPST") if pst else ("ProfitMax_TrPenalty_UserIncentives", "V2G_profit_max_loads")
+    rk, sk = _abi.REWARD_KINDS[kinds[0]], _abi.STATE_KINDS[kinds[1]]
+    flags = _abi.FLAG_LOG_SOC | _abi.FLAG_REFILLABLE
+    lo = 0.0 if pst else -1.0
+
+    def episode(eng):
+        E, P, D, T = eng.E, eng.P, eng.D, eng.T
+        act, obs, rew = eng.empty((E, P)), eng.empty((E, D)), eng.empty((E,))
+        done, mask = eng.empty((E,), np.uint8), eng.empty((E, P), np.uint8)
+        eng.reset(obs)
+        out = [obs.to_host().copy()]
+        for t in range(T):
+            act.upload(host_uniform(E * P, 900 + t, lo, 1.0).reshape(E, P))
+            eng.step(act, obs, rew, done, mask)
+            out += [obs.to_host().copy(), rew.to_host().copy(), mask.to_host().copy()]
+        out.append(np.nan_to_num(eng.stats(), nan=-7.0))
+        try:
+            eng.check_faults()
+        except EngineError:   # (multi-port chargers under out-of-range actions: the reference's over-current exception is a per-env flag here)
+            pass
+        return out
+
+    eng = Engine(other, rk, sk, device=0, flags=flags)
+    try:
+        eng.pool_refill(mk(M, S1), S1, 3, 0, M)   # slots 0..M-1 <- scenarios 3..M+2 of the stream
+    except EngineError as e:
+        eng.close()
+        pytest.skip(f"outside the device generator's stated limits: {e}")
+    if eng.pool_refill_overflows:
+        eng.close()
+        pytest.skip("the refilled scenarios draw more sessions than the loaded pool's blocks hold (counted, not silent)")
+    got = episode(eng)
+    eng.close()
+    ref_eng = Engine(host.select(np.arange(3, M + 3)), rk, sk, device=0, flags=flags)
+    ref = episode(ref_eng)
+    ref_eng.close()
+    for i, (x, y) in enumerate(zip(got, ref)):
+        assert np.array_equal(x, y), f"output {i} differs between the device-generated and the host-generated pool"
