@@ -38,6 +38,7 @@ struct ev2g_handle {
     DevScn scn{};
     DevState st{};
     std::vector<void *> scn_allocs, st_allocs, user_allocs;
+    std::vector<void *> user_host_allocs;       // ev2g_host_malloc: page-locked host buffers of the caller's per-step copies
     // host mirrors for peek / stats
     int E = 0, M = 0, T = 0, C = 0, npc = 0, P = 0, R = 0, D = 0;   // E envs stepped concurrently, M scenarios in the pool
     long long scn_off = 0;                      // env e runs scenario (e + scn_off) mod M
@@ -218,6 +219,8 @@ void ev2g_destroy(ev2g_handle *h) {
     free_pool(h->scn_allocs);
     free_pool(h->st_allocs);
     free_pool(h->user_allocs);
+    for (void *p : h->user_host_allocs) (void)hipHostFree(p);
+    h->user_host_allocs.clear();
     free_pool(h->refill_cache.allocs);
     if (h->d_refill_overflow) (void)hipFree(h->d_refill_overflow);
     ev2g_comm_destroy(h);
@@ -1857,6 +1860,25 @@ void ev2g_free(ev2g_handle *h, void *p) {
     if (it != h->user_allocs.end()) h->user_allocs.erase(it);
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(p);
+}
+void *ev2g_host_malloc(ev2g_handle *h, size_t bytes) {
+    if (!h) return nullptr;
+    (void)hipSetDevice(h->device);
+    void *p = nullptr;
+    if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) {
+        h->err = "ev2g_host_malloc: hipHostMalloc failed";
+        return nullptr;
+    }
+    h->user_host_allocs.push_back(p);
+    return p;
+}
+void ev2g_host_free(ev2g_handle *h, void *p) {
+    if (!h || !p) return;
+    auto it = std::find(h->user_host_allocs.begin(), h->user_host_allocs.end(), p);
+    if (it == h->user_host_allocs.end()) return;   // (not ours, or freed already)
+    h->user_host_allocs.erase(it);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipHostFree(p);
 }
 int ev2g_memcpy_h2d(ev2g_handle *h, void *dst, const void *src, size_t bytes) {
     if (!h) return EV2G_ERR_ARG;

@@ -76,6 +76,8 @@ def load_library(path: Optional[str] = None):
         "ev2g_free": (None, [vp, vp]),
         "ev2g_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "ev2g_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "ev2g_host_malloc": (vp, [vp, C.c_size_t]),
+        "ev2g_host_free": (None, [vp, vp]),
         "ev2g_synchronize": (C.c_int, [vp]),
         "ev2g_fill_uniform": (C.c_int, [vp, vp, i64, C.c_uint64, dbl, dbl]),
         "ev2g_host_uniform": (None, [vp, i64, C.c_uint64, dbl, dbl]),
@@ -117,7 +119,7 @@ EXPORTED_SYMBOLS = [
     "ev2g_n_scenarios", "ev2g_n_ports", "ev2g_obs_dim", "ev2g_n_steps", "ev2g_current_step", "ev2g_reset", "ev2g_reset_ex",
     "ev2g_scenario_offset", "ev2g_set_step_extras", "ev2g_kernel_name", "ev2g_last_launch_specialisation", "ev2g_last_launch_general_reason", "ev2g_fallback_reason", "ev2g_big_kernel_reason", "ev2g_step", "ev2g_step_n",
     "ev2g_check_faults", "ev2g_get_stats", "ev2g_get_stats_reset", "ev2g_get_stats_reset_f32", "ev2g_reset_f32", "ev2g_collect", "ev2g_stat_name", "ev2g_peek", "ev2g_malloc", "ev2g_free",
-    "ev2g_memcpy_h2d", "ev2g_memcpy_d2h", "ev2g_synchronize", "ev2g_fill_uniform", "ev2g_host_uniform",
+    "ev2g_memcpy_h2d", "ev2g_memcpy_d2h", "ev2g_host_malloc", "ev2g_host_free", "ev2g_synchronize", "ev2g_fill_uniform", "ev2g_host_uniform",
     "ev2g_last_step_n_kernel_ms", "ev2g_step_n_kernel_ms_back", "ev2g_mlp_create", "ev2g_mlp_create_ex", "ev2g_mlp_destroy", "ev2g_mlp_forward", "ev2g_rollout",
     "ev2g_rollout_graph_launches", "ev2g_comm_get_unique_id", "ev2g_comm_init", "ev2g_comm_destroy", "ev2g_comm_world_size", "ev2g_comm_gathers", "ev2g_gather_stats",
     "ev2g_pool_refill", "ev2g_pool_refill_overflows", "ev2g_pool_session_capacity", "ev2g_gen_default_config", "ev2g_generate", "ev2g_gen_batch", "ev2g_gen_free", "ev2g_gen_table"]
@@ -244,6 +246,22 @@ class Engine:
 
     def empty(self, shape, dtype=np.float64) -> DeviceBuffer:
         return DeviceBuffer(self, shape, dtype)
+
+    def pinned(self, shape, dtype=np.float64) -> np.ndarray:
+        """A numpy array over page-locked host memory (ev2g_host_malloc): the destination / source of per-step copies (the SB3 VecEnv
+        hand-over).  The memory belongs to the handle: the array must not be used after `close()`."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = self._lib.ev2g_host_malloc(self._h, max(n, 1))
+        if not p:
+            raise EngineError("ev2g_host_malloc failed")
+        buf = (C.c_char * max(n, 1)).from_address(p)
+        return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    def memcpy_d2h(self, host_array: np.ndarray, dev_ptr, nbytes: int):
+        """One device -> host copy of `nbytes` from a raw device address into a (pinned or ordinary) C-contiguous host array."""
+        assert host_array.flags.c_contiguous and host_array.nbytes >= nbytes
+        self._check(self._lib.ev2g_memcpy_d2h(self._h, host_array.ctypes.data, _ptr(dev_ptr), int(nbytes)))
 
     def synchronize(self):
         self._check(self._lib.ev2g_synchronize(self._h))

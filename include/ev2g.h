@@ -397,6 +397,11 @@ void *ev2g_malloc(ev2g_handle *h, size_t bytes);
 void ev2g_free(ev2g_handle *h, void *p);
 int ev2g_memcpy_h2d(ev2g_handle *h, void *dst, const void *src, size_t bytes);
 int ev2g_memcpy_d2h(ev2g_handle *h, void *dst, const void *src, size_t bytes);
+/* page-locked host memory (hipHostMalloc) for the buffers a host loop copies every step: the per-step numpy hand-over of the Stable-Baselines3 VecEnv
+ * protocol (train_stable_baselines.py:62-130: observations / rewards / dones down, actions up) runs at the PCIe rate from such a buffer, at less than half
+ * of it from pageable memory.  Freed by ev2g_host_free or with the handle. */
+void *ev2g_host_malloc(ev2g_handle *h, size_t bytes);
+void ev2g_host_free(ev2g_handle *h, void *p);
 int ev2g_synchronize(ev2g_handle *h);
 /* fills [n] doubles with uniform(lo,hi) from a counter-based generator (Philox-free splitmix64
  * keyed on (seed, index)); the same function exists on the host as ev2g_host_uniform so CPU and
