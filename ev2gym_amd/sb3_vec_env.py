@@ -43,7 +43,7 @@ class EV2GymSB3VecEnv(_SB3VecEnv):
     (utils.py:84-101), `episode = {"r", "l"}` (what SB3's Monitor would add) and `terminal_observation`.
     """
 
-    def __init__(self, vec: Optional[EV2GymVec] = None, obs_dtype=np.float32, **vec_kwargs):
+    def __init__(self, vec: Optional[EV2GymVec] = None, obs_dtype=np.float32, copy_obs: bool = True, **vec_kwargs):
         if vec is None:
             vec_kwargs.setdefault("use_torch", False)
             vec = EV2GymVec(**vec_kwargs)
@@ -78,17 +78,28 @@ class EV2GymSB3VecEnv(_SB3VecEnv):
             self._d_obs32, self._d_act32 = self._d_blk.ptr, eng.empty((E, P), np.float32)
             self._d_rew, self._d_done, self._d_mask = self._d_blk.ptr + self._o_rew, self._d_blk.ptr + self._o_done, self._d_blk.ptr + self._o_mask
             eng.set_extras(cost=vec._cost, obs_f32=self._d_obs32, obs_f32_stride=0, actions_f32=self._d_act32)
-            self._h_blk = eng.pinned((self._blk_bytes,), np.uint8)
-            self._h_obs = self._h_blk[:E * D * 4].view(np.float32).reshape(E, D)
-            self._h_rew = self._h_blk[self._o_rew:self._o_rew + E * 8].view(np.float64)
-            self._h_done = self._h_blk[self._o_done:self._o_done + E]
-            self._h_mask = self._h_blk[self._o_mask:self._o_mask + E * P].reshape(E, P)
-            self._h_mask[:] = 0
+            # copy_obs=False (opt-in): the observations returned by reset() / step() are VIEWS of two page-locked blocks used in turn -- an array stays valid
+            # until the second next step() (SB3's own loops keep the last observation only; anything that collects the returned arrays must copy them).
+            # The fresh array per step that the default returns is a third of the adapter's step time at 4096 x 50.
+            self._copy_obs = bool(copy_obs)
+            self._blocks = []
+            for _ in range(1 if self._copy_obs else 2):
+                blk = eng.pinned((self._blk_bytes,), np.uint8)
+                blk[:] = 0
+                mask = blk[self._o_mask:self._o_mask + E * P].reshape(E, P)
+                self._blocks.append(dict(blk=blk, obs=blk[:E * D * 4].view(np.float32).reshape(E, D), rew=blk[self._o_rew:self._o_rew + E * 8].view(np.float64),
+                                         done=blk[self._o_done:self._o_done + E], mask=mask, infos=[{"action_mask": mask[i]} for i in range(E)]))
+            self._cur = 0
+            self._use_block(0)
             self._h_act = eng.pinned((E, P), np.float32)
-            self._infos = [{"action_mask": self._h_mask[i]} for i in range(E)]
         self._ep_return = np.zeros(self.num_envs)
         self._seeds = [None] * self.num_envs
         self._options = [{} for _ in range(self.num_envs)]
+
+    def _use_block(self, k):
+        b = self._blocks[k]
+        self._cur = k
+        self._h_blk, self._h_obs, self._h_rew, self._h_done, self._h_mask, self._infos = b["blk"], b["obs"], b["rew"], b["done"], b["mask"], b["infos"]
 
     # ---- VecEnv protocol ---------------------------------------------------------------------------
     def _host(self, x):
@@ -99,8 +110,9 @@ class EV2GymSB3VecEnv(_SB3VecEnv):
         self._ep_return[:] = 0.0
         self.reset_infos = [{} for _ in range(self.num_envs)]
         if self._fast:
+            self._use_block((self._cur + 1) % len(self._blocks))
             self.vec.engine.memcpy_d2h(self._h_blk, self._d_obs32, self._o_rew)   # (the reset observation: the block's first segment)
-            return self._h_obs.copy()
+            return self._h_obs.copy() if self._copy_obs else self._h_obs
         return self._host(obs).astype(self.obs_dtype, copy=False)
 
     def step_async(self, actions) -> None:
@@ -114,6 +126,7 @@ class EV2GymSB3VecEnv(_SB3VecEnv):
         np.copyto(self._h_act, self._actions)
         self._d_act32.upload(self._h_act)
         eng.step(None, None, self._d_rew, self._d_done, self._d_mask)     # float32 actions in, float32 observations out (the extras)
+        self._use_block((self._cur + 1) % len(self._blocks))
         eng.memcpy_d2h(self._h_blk, self._d_blk, self._blk_bytes)        # observations | rewards | dones | masks: one copy
         obs, rew = self._h_obs, self._h_rew
         done = self._h_done.astype(bool)
@@ -133,7 +146,7 @@ class EV2GymSB3VecEnv(_SB3VecEnv):
             vec.reset(_keep_stats=True)
             eng.memcpy_d2h(self._h_blk, self._d_obs32, self._o_rew)   # the next episode's reset observation (rew / done / mask of the terminal step stay)
             self._ep_return[:] = 0.0
-        return obs.copy(), rew.astype(np.float32), done, infos
+        return (obs.copy() if self._copy_obs else obs), rew.astype(np.float32), done, infos
 
     def step_wait(self):
         if self._fast:

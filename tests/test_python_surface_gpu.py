@@ -128,9 +128,9 @@ def test_vec_env_rejects_unfused_plugins():
         EV2GymVec(config_file=os.path.join(CFG, "PublicPST.yaml"), num_envs=4, state_function=lambda env: None)
 
 
-@pytest.mark.parametrize("use_torch,obs_dtype", [(False, np.float64), (True, np.float64), (False, np.float32)],
-                         ids=["ctypes_buffers", "torch_tensors", "float32_fast_path"])
-def test_sb3_vec_env_protocol_matches_oracle(use_torch, obs_dtype):
+@pytest.mark.parametrize("use_torch,obs_dtype,copy_obs", [(False, np.float64, True), (True, np.float64, True), (False, np.float32, True), (False, np.float32, False)],
+                         ids=["ctypes_buffers", "torch_tensors", "float32_fast_path", "float32_views_of_pinned_blocks"])
+def test_sb3_vec_env_protocol_matches_oracle(use_torch, obs_dtype, copy_obs):
     """SB3 VecEnv protocol (step_async/step_wait, reset at episode end with terminal_observation, numpy out); with float32
     observations and engine-owned buffers the adapter hands float32 over in both directions (its fast path)."""
     from ev2gym_amd import _abi
@@ -138,7 +138,7 @@ def test_sb3_vec_env_protocol_matches_oracle(use_torch, obs_dtype):
     from oracle.oracle import Oracle
     sf, rf = "V2G_profit_max_loads", "ProfitMax_TrPenalty_UserIncentives"
     venv = EV2GymSB3VecEnv(config_file=os.path.join(CFG, "V2GProfitPlusLoads.yaml"), num_envs=24, state_function=sf,
-                           reward_function=rf, seed=9, use_torch=use_torch, obs_dtype=obs_dtype)
+                           reward_function=rf, seed=9, use_torch=use_torch, obs_dtype=obs_dtype, copy_obs=copy_obs)
     otol = 1e-9 if obs_dtype == np.float64 else 2e-7     # float32 observations: one rounding
     assert venv._fast == (obs_dtype == np.float32)
     E, P, T = venv.num_envs, venv.vec.number_of_ports, venv.vec.simulation_length
@@ -152,8 +152,10 @@ def test_sb3_vec_env_protocol_matches_oracle(use_torch, obs_dtype):
     ret = np.zeros(E)
     for t in range(T + 3):            # runs across the episode boundary
         a = rng.uniform(-1, 1, (E, P)).astype(np.float32)     # SB3 hands float32 actions
+        prev, prev_copy = obs, obs.copy()
         venv.step_async(a)
         obs, rew, done, infos = venv.step_wait()
+        assert np.array_equal(prev, prev_copy) and (copy_obs or not np.shares_memory(prev, obs))   # the array of the step before is still intact (views: two blocks in turn)
         if t == T:
             ret[:] = 0.0
         o_obs, o_rew, o_done, o_mask, rc = ora.step(a.astype(np.float64))

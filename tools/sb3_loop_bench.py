@@ -6,7 +6,7 @@ import numpy as np
 from ev2gym_amd.sb3_vec_env import EV2GymSB3VecEnv
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ev2gym_amd", "example_config_files", "V2GProfitPlusLoads_50cs.yaml")
-venv = EV2GymSB3VecEnv(config_file=cfg, num_envs=E, seed=0, state_function="V2G_profit_max_loads", reward_function="ProfitMax_TrPenalty_UserIncentives")
+venv = EV2GymSB3VecEnv(config_file=cfg, num_envs=E, seed=0, state_function="V2G_profit_max_loads", reward_function="ProfitMax_TrPenalty_UserIncentives", copy_obs=os.environ.get("SB3_COPY_OBS", "1") != "0")
 obs = venv.reset()
 T, P = venv.vec.simulation_length, venv.vec.number_of_ports
 rng = np.random.default_rng(0)
