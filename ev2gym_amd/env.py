@@ -311,8 +311,17 @@ class EV2Gym(EnvBase):
         self._evs = {}
         self.EVs_profiles = [self._ev(k) for k in range(scenario.n_sessions)]
         if self._d is None:
-            self._d = dict(act=e.empty((1, e.P)), obs=e.empty((1, e.D)), rew=e.empty((1,)), done=e.empty((1,), np.uint8),
-                           mask=e.empty((1, e.P), np.uint8))
+            # what a step hands down -- observation, reward, done, mask -- in ONE device block, mirrored by one page-locked host block: one copy per step
+            # instead of three into pageable arrays (round 6; with ev2g_peek's staging block: 2.7 k -> 6 k steps/s of the single-env loop)
+            o_rew = e.D * 8
+            o_done, o_mask = o_rew + 8, o_rew + 16
+            nbytes = (o_mask + e.P + 15) & ~15
+            blk = e.empty((nbytes,), np.uint8)
+            hb = e.pinned((nbytes,), np.uint8)
+            hb[:] = 0
+            self._d = dict(act=e.empty((1, e.P)), blk=blk, obs=blk.ptr, rew=blk.ptr + o_rew, done=blk.ptr + o_done, mask=blk.ptr + o_mask, nbytes=nbytes,
+                           h_blk=hb, h_obs=hb[:o_rew].view(np.float64), h_rew=hb[o_rew:o_rew + 8].view(np.float64), h_done=hb[o_done:o_done + 1],
+                           h_mask=hb[o_mask:o_mask + e.P], h_act=e.pinned((1, e.P), np.float64), stale=True)
 
     # ---- snapshot plumbing ------------------------------------------------------------------------
     def _ev(self, k):
@@ -362,6 +371,7 @@ class EV2Gym(EnvBase):
                 self._scenario_seed = seed
         self._episodes += 1
         self.engine.reset(self._d["obs"])
+        self._d["stale"] = True
         self._snapshot = None
         self._max_obs_step = 0
         self.done = False
@@ -376,7 +386,15 @@ class EV2Gym(EnvBase):
         self._max_obs_step = max(self._max_obs_step, self.current_step)
         if self._host_state:
             return np.asarray(self.state_function(self), dtype=np.float64)
-        return self._d["obs"].to_host()[0]
+        self._pull()
+        return self._d["h_obs"].copy()
+
+    def _pull(self):
+        """The step's (or the reset's) hand-over block, once."""
+        d = self._d
+        if d["stale"]:
+            self.engine.memcpy_d2h(d["h_blk"], d["blk"], d["nbytes"])
+            d["stale"] = False
 
     def step(self, actions, visualize=False):
         assert not self.done, "Episode is done, please reset the environment"   # ev2gym_env.py:343
@@ -388,8 +406,10 @@ class EV2Gym(EnvBase):
             pass
         a = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).reshape(1, -1))
         assert a.shape[1] == self.number_of_ports
-        self._d["act"].upload(a)
+        np.copyto(self._d["h_act"], a)
+        self._d["act"].upload(self._d["h_act"])
         self.engine.step(self._d["act"], self._d["obs"], self._d["rew"], self._d["done"], self._d["mask"])
+        self._d["stale"] = True
         self.engine.check_faults()
         self._snapshot = None
         self.departing_evs = [ev for ev in self.EVs_profiles if ev.time_of_departure == t and ev.time_of_arrival <= t]
@@ -403,10 +423,12 @@ class EV2Gym(EnvBase):
         if self._host_reward:
             reward = self.reward_function(self, total_costs, user_satisfaction_list, invalid)
         else:
-            reward = float(self._d["rew"].to_host()[0])
+            self._pull()
+            reward = float(self._d["h_rew"][0])
         self.total_reward += reward
         cost = self.cost_function(self, total_costs, user_satisfaction_list, invalid) if self.cost_function else None
-        mask = self._d["mask"].to_host()[0].astype(np.float64)
+        self._pull()
+        mask = self._d["h_mask"].astype(np.float64)
         self._last_obs = self._get_observation()
         if self.current_step >= self.simulation_length:   # _check_termination ev2gym_env.py:449-496
             self.done = True
