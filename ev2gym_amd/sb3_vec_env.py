@@ -86,9 +86,10 @@ class EV2GymSB3VecEnv(_SB3VecEnv):
             for _ in range(1 if self._copy_obs else 2):
                 blk = eng.pinned((self._blk_bytes,), np.uint8)
                 blk[:] = 0
-                mask = blk[self._o_mask:self._o_mask + E * P].reshape(E, P)
+                mask = np.zeros((E, P), np.uint8)   # (an ordinary array, refreshed from the block every step: the info dicts users may keep must not point into memory that goes with the handle)
                 self._blocks.append(dict(blk=blk, obs=blk[:E * D * 4].view(np.float32).reshape(E, D), rew=blk[self._o_rew:self._o_rew + E * 8].view(np.float64),
-                                         done=blk[self._o_done:self._o_done + E], mask=mask, infos=[{"action_mask": mask[i]} for i in range(E)]))
+                                         done=blk[self._o_done:self._o_done + E], mask_src=blk[self._o_mask:self._o_mask + E * P].reshape(E, P), mask=mask,
+                                         infos=[{"action_mask": mask[i]} for i in range(E)]))
             self._cur = 0
             self._use_block(0)
             self._h_act = eng.pinned((E, P), np.float32)
@@ -100,6 +101,7 @@ class EV2GymSB3VecEnv(_SB3VecEnv):
         b = self._blocks[k]
         self._cur = k
         self._h_blk, self._h_obs, self._h_rew, self._h_done, self._h_mask, self._infos = b["blk"], b["obs"], b["rew"], b["done"], b["mask"], b["infos"]
+        self._h_mask_src = b["mask_src"]
 
     # ---- VecEnv protocol ---------------------------------------------------------------------------
     def _host(self, x):
@@ -128,6 +130,7 @@ class EV2GymSB3VecEnv(_SB3VecEnv):
         eng.step(None, None, self._d_rew, self._d_done, self._d_mask)     # float32 actions in, float32 observations out (the extras)
         self._use_block((self._cur + 1) % len(self._blocks))
         eng.memcpy_d2h(self._h_blk, self._d_blk, self._blk_bytes)        # observations | rewards | dones | masks: one copy
+        np.copyto(self._h_mask, self._h_mask_src)
         obs, rew = self._h_obs, self._h_rew
         done = self._h_done.astype(bool)
         self._ep_return += rew
