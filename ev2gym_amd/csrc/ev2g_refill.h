@@ -493,7 +493,11 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
                             }
                         }
                         const double v = (typ == 0) ? vp : ((typ == 1) ? vl : vm);
+#ifndef EV2G_RF_NO_NT_TABLES   // streaming stores: 54 KB per scenario written once and read by a later episode's step kernel (-3.5 % of the window, tools/r6/gpu_rf6.sh)
+                        if (lane < ncol) __builtin_nontemporal_store(v, &rows[(size_t)step * ncol + lane]);
+#else
                         if (lane < ncol) rows[(size_t)step * ncol + lane] = v;
+#endif
                     }
                 }
             }
