@@ -24,3 +24,5 @@ timeout 200 python tools/refill_time.py cfg2 2>&1 | tail -1 > $O/r06_refill_time
 timeout 200 python tools/sb3_collect_bench.py cfg2 2>&1 | grep -v amdgpu.ids | tail -1 > $O/r06_collector_cfg2.json; timeout 200 python tools/sb3_collect_bench.py cfg3 2>&1 | grep -v amdgpu.ids | tail -1 > $O/r06_collector_cfg3.json; cut -c1-200 $O/r06_collector_cfg3.json
 for w in cfg2 cfg3 cfg4; do timeout 200 python tools/stats_time.py $w 2>&1 | grep -v amdgpu.ids | tail -1; done | tee $O/r06_stats_time.txt
 EV2G_PT_LIB=build_variants/libev2g_pt.so timeout 300 python tools/phase_timing.py cfg4 2>&1 | grep -v amdgpu.ids | head -9 > $O/r06_phase_cfg4.txt
+timeout 200 python tools/sb3_loop_bench.py 2>&1 | grep -v amdgpu.ids | tail -1 > $O/r06_host_loops.txt; SB3_COPY_OBS=0 timeout 200 python tools/sb3_loop_bench.py 2>&1 | grep -v amdgpu.ids | tail -1 | sed 's/^/copy_obs=False: /' >> $O/r06_host_loops.txt
+timeout 200 python tools/facade_loop_bench.py 2>&1 | grep -v amdgpu.ids | tail -2 >> $O/r06_host_loops.txt; cat $O/r06_host_loops.txt
