@@ -316,3 +316,31 @@ def test_randomised_device_refill_equals_the_host_generator(case):
     ref_eng.close()
     for i, (x, y) in enumerate(zip(got, ref)):
         assert np.array_equal(x, y), f"output {i} differs between the device-generated and the host-generated pool"
+
+
+def test_page_locked_host_buffers_round_trip():
+    """ev2g_host_malloc / ev2g_host_free (include/ev2g.h; Engine.pinned): page-locked host arrays as the source and the destination of the per-step copies
+    (the SB3 VecEnv hand-over, ev2g_peek's staging): a round trip through device memory returns the bytes, partial copies honour the byte count, freeing
+    twice or freeing foreign pointers is harmless, and what is not freed goes with the handle."""
+    import ctypes as C
+    from ev2gym_amd import _abi
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario import ScenarioBatch
+    z = np.load(os.path.join(ROOT, "tests", "golden", "v2gppl_c50_rand_s9.npz"))
+    eng = Engine(ScenarioBatch.from_single(z).tile(4), _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"], device=0)
+    a = eng.pinned((1000, 7), np.float64)
+    b = eng.pinned((1000, 7), np.float64)
+    assert a.shape == (1000, 7) and a.flags.c_contiguous and a.ctypes.data % 4096 == 0
+    a[:] = np.random.default_rng(3).normal(size=a.shape)
+    b[:] = -1.0
+    d = eng.empty(a.shape)
+    d.upload(a)
+    eng.memcpy_d2h(b, d, 500 * 7 * 8)            # the first 500 rows only
+    assert np.array_equal(b[:500], a[:500]) and (b[500:] == -1.0).all()
+    eng.memcpy_d2h(b, d, a.nbytes)
+    assert np.array_equal(a, b)
+    eng._lib.ev2g_host_free(eng._h, C.c_void_p(a.ctypes.data))
+    eng._lib.ev2g_host_free(eng._h, C.c_void_p(a.ctypes.data))      # (already freed: ignored)
+    eng._lib.ev2g_host_free(eng._h, C.c_void_p(12345))               # (not ours: ignored)
+    assert np.array_equal(b[3], b[3])                                # b is still valid
+    eng.close()                                                      # b goes with the handle
