@@ -85,8 +85,8 @@ __device__ inline double rf_afap(double cap0, double B, double pac, double max_c
 
 // LDS (dynamic), kept under 10 KB at the shipped shapes so that 16 one-wavefront workgroups share a CU (4096 scenarios = one round):
 //   doubles l_cp[T] | l_a[T] | l_b[T] | X[3T + 96] | demand-response events [16][3] | per staged session need, lo, hi [cap]
-//   X is, phase after phase: the spawner's per-step {stay, energy} + uint2 {key, threshold} [T]  ->  solar, load forecast, PV forecast of
-//   the transformer in work [T each]  ->  the median filter's padded row [T + 96]
+//   X is, phase after phase: the spawner's per-step {stay, energy} + uint2 {key, threshold} [T]  ->  actual and forecast (loads - pv) of
+//   the transformer in work [T each] and its peak limit [1, at 3T]  ->  the median filter's padded row [T + 96]
 //   u64 id [cap]; ints t_arr, t_dep [cap], base / count per PORT [P]; uint8 spawn steps [P][EV2G_RF_K]
 #define EV2G_RF_K 8   // spawn steps remembered per port between the two passes (a port with more re-runs its trials in pass 2)
 //   multi-port chargers / topology files (RefillArgs::multi) add: uint8 departure steps, resolved slot and rank in it [P][EV2G_RF_K] each;
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
     const int T = s.T, P = s.P, R = s.R, cap = a.cap;
     double *l_cp = rlds, *l_a = l_cp + T, *l_b = l_a + T, *l_x = l_b + T;
     double *l_stay = l_x, *l_emean = l_x + T; uint2 *l_kt = (uint2 *)(l_x + 2 * T);          // phase 1 (sessions)
-    double *l_sol = l_x, *l_lf = l_x + T, *l_pvf = l_x + 2 * T;                                 // phase 2 (transformers)
+    double *l_dact = l_x, *l_dfc = l_x + T, *l_pk = l_x + 3 * T;                                // phase 2 (transformers): actual / forecast (loads - pv), the peak limit
     double *l_pad = l_x;                                                                        // phase 3 (setpoints)
     double *l_dr = l_x + 3 * T + 96;
     double *l_need = l_dr + 3 * 16, *l_lo = l_need + cap, *l_hi = l_lo + cap;
@@ -424,11 +424,11 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
             const double lfv = c.inflexible_loads ? ev2g_gen_load_forecast_at(g, rng_tr, k, t, il, mnv, mxv) : 0.0;
             const double pvv = c.solar_power ? ev2g_gen_pv_forecast_at(g, rng_tr, k, t, sol) : 0.0;
             RW(double, tr_lf)[o + t] = lfv; RW(double, tr_pvf)[o + t] = pvv;
-            l_sol[t] = sol; l_lf[t] = lfv; l_pvf[t] = pvv;
+            l_dact[t] = il - sol; l_dfc[t] = lfv - pvv;   // the two (loads - pv) series the observation windows below are cut from
             peak = fmax(peak, mxv);
         }
         peak = rf_wave_max(peak);
-        if (lane == 0) RW(double, tr_peak)[(size_t)ms * R + k] = peak;
+        if (lane == 0) { RW(double, tr_peak)[(size_t)ms * R + k] = peak; l_pk[0] = peak * 1.0; }
         // ---- this transformer's observation windows (ev2g_build_window_table_kernel's values: load_minus_pv_at / power_limit_at), from LDS;
         //      on the fast path (one transformer) they are also columns 20..59 of the observation head table ----
         RF_STAMP(7)
@@ -457,16 +457,44 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
                 const int typ = (lane < c_lpv) ? 0 : ((lane < c_lim) ? 1 : 2);
                 const int j = lane - ((typ == 0) ? 0 : ((typ == 1) ? c_lpv : c_lim));   // column inside the strip (lanes behind the row: computed, not stored)
                 if (rows) {
+                    // Round 6 (third session): the rows 0 .. T-2 of a transformer with at most one event -- every shipped config -- by ONE LDS read per lane
+                    // and row.  A lane's column is a slide over one series (|price|, the forecast (loads - pv), the actual one for the window's first
+                    // column, the constant peak limit: base + stride * min(kk, T-1), stride 0 for the limit) with one override inside a lane-constant
+                    // range of kk = step + j: zero past the horizon for a price column; the event's limit for kk in [event start, event end) once the
+                    // event is known (step + ahead >= start  <=>  kk >= start - ahead + j).  That is transformer.py:142-188 / state.py:75-83 evaluated
+                    // like the general loop below does (which keeps rows T-1 and T, where the padding switches to the actual series, and any
+                    // transformer with more events): ~12 instead of ~45 instructions per row -- the phase was 71 k of the scenario's ~200 k cycles.
+                    int s_begin = 0;
+                    if (nd <= 1 && T >= 2) {   // (uniform)
+                        const double *src = (typ == 0) ? l_cp : ((typ == 1) ? ((j == 0) ? l_dact : l_dfc) : l_pk);
+                        const int stride = (typ == 2) ? 0 : 1;
+                        int lo = 0x7fffffff, hi = 0x7fffffff;
+                        double ov = 0.0;
+                        if (typ == 0) lo = T;
+                        if (typ == 2 && nd == 1) { lo = max(d_es[0], d_es[0] - ahead + j); hi = d_ee[0]; ov = d_lim[0]; }
+                        double *out = rows + lane;
+                        int kk = j;
+#pragma unroll 4
+                        for (int step = 0; step <= T - 2; step++, kk++, out += ncol) {
+                            const double x = src[min(kk, T - 1) * stride];
+                            const double v = (kk >= lo && kk < hi) ? ov : x;
+#ifndef EV2G_RF_NO_NT_TABLES
+                            if (lane < ncol) __builtin_nontemporal_store(v, out);
+#else
+                            if (lane < ncol) *out = v;
+#endif
+                        }
+                        s_begin = T - 1;
+                    }
 #pragma unroll 2
-                    for (int step = 0; step <= T; step++) {
+                    for (int step = s_begin; step <= T; step++) {
                         const int kk = step + j, ke = min(kk, T - 1);
                         // |charge price| of the next 20 steps, zero past the horizon (state.py:75-83, :121-129)
                         const double vp = (kk < T) ? l_cp[ke] : 0.0;
                         // (loads - pv) window, Transformer.get_load_pv_forecast transformer.py:173-188: the actual series for the current step (j == 0) and
                         // behind the horizon of the last one, the forecast otherwise; the same element [min(kk, T - 1)] of either pair (1.0 * x == x)
                         const bool actual = (kk < T) ? (j == 0) : (step >= T - 1);
-                        const double *lsrc = actual ? infl : l_lf, *psrc = actual ? l_sol : l_pvf;
-                        const double vl = lsrc[ke] - psrc[ke];
+                        const double vl = (actual ? l_dact : l_dfc)[ke];
                         // power limits, Transformer.get_power_limits transformer.py:142-171
                         double vm = peak * 1.0;
 #pragma unroll
