@@ -472,17 +472,24 @@ __global__ void __launch_bounds__(64) ev2g_refill_kernel(DevScn s, DevState st, 
                         double ov = 0.0;
                         if (typ == 0) lo = T;
                         if (typ == 2 && nd == 1) { lo = max(d_es[0], d_es[0] - ahead + j); hi = d_ee[0]; ov = d_lim[0]; }
-                        double *out = rows + lane;
-                        int kk = j;
-#pragma unroll 4
-                        for (int step = 0; step <= T - 2; step++, kk++, out += ncol) {
-                            const double x = src[min(kk, T - 1) * stride];
-                            const double v = (kk >= lo && kk < hi) ? ov : x;
+                        if (lane < ncol) {   // (one exec mask around the whole loop, four rows' reads in flight: per row, the branch and the wait were the chain)
+                            double *out = rows + lane;
+                            int kk = j, step = 0;
+                            auto put = [&](double *o, double v) {
 #ifndef EV2G_RF_NO_NT_TABLES
-                            if (lane < ncol) __builtin_nontemporal_store(v, out);
+                                __builtin_nontemporal_store(v, o);
 #else
-                            if (lane < ncol) *out = v;
+                                *o = v;
 #endif
+                            };
+                            for (; step + 4 <= T - 1; step += 4, kk += 4, out += 4 * ncol) {
+                                double x[4];
+#pragma unroll
+                                for (int u = 0; u < 4; u++) x[u] = src[min(kk + u, T - 1) * stride];
+#pragma unroll
+                                for (int u = 0; u < 4; u++) put(out + u * ncol, (kk + u >= lo && kk + u < hi) ? ov : x[u]);
+                            }
+                            for (; step <= T - 2; step++, kk++, out += ncol) put(out, (kk >= lo && kk < hi) ? ov : src[min(kk, T - 1) * stride]);
                         }
                         s_begin = T - 1;
                     }
