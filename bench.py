@@ -340,16 +340,17 @@ def refill_record(Engine, wl, rk, sk, local_rank, devx, E, rank, args, T, min_s=
         refill_us = (time.perf_counter() - t0) / 10 * 1e6
 
         def episode(k, refill):
-            off = (k % 3) * E
-            eng.reset(obs, offset=off)
+            # episode k steps window k % 3; its statistics and the reset onto window (k + 1) % 3 are ONE launch (ev2g_get_stats_reset, like the timed
+            # region's full_episode); the window of the episode before, (k + 2) % 3, gets new scenarios in stream order behind them
             eng.step_n(T, acts, E * P, obs, 0, rew, 0, done, 0, mask, 0, auto_reset=False, persistent=True)
-            eng.stats(out=stats)
-            if refill:   # the window of the episode before gets new scenarios, in stream order behind this episode's kernels
+            eng.stats_reset(stats, obs, offset=((k + 1) % 3) * E)
+            if refill:
                 nonlocal_nxt[0] += E
                 eng.pool_refill(cfg, cfg.seed, nonlocal_nxt[0], ((k + 2) % 3) * E, E)
         nonlocal_nxt = [nxt]
         rates = {}
         for refill in (False, True):
+            eng.reset(obs, offset=0)
             episode(0, refill); eng.synchronize()
             n, spent = 0, 0.0
             while spent < min_s:
@@ -366,7 +367,7 @@ def refill_record(Engine, wl, rk, sk, local_rank, devx, E, rank, args, T, min_s=
                 "env_steps_per_s_with_refill_per_gpu": E * T / rates[True], "truncated_scenarios": eng.pool_refill_overflows,
                 "session_slots_per_scenario": eng.pool_session_capacity,
                 "note": "every episode runs scenarios never stepped before, drawn on the device (bit-identical to ev2g_generate); "
-                        "whole episodes = 112-step persistent launch + statistics kernel + reset (+ ev2g_pool_refill of one window)"}
+                        "whole episodes = 112-step persistent launch + statistics and reset onto the next window in one launch (+ ev2g_pool_refill of one window)"}
     finally:
         eng.close()
 
