@@ -234,7 +234,7 @@ class PipelinedLoops:
             f.result()
 
 
-def rollout_record(Engine, batch, rk, sk, local_rank, devx, E, lo, rank, args, T, bytes_env_step, min_s=0.2):
+def rollout_record(Engine, batch, rk, sk, local_rank, devx, E, lo, rank, args, T, bytes_env_step, min_s=0.2, precision="bf16"):
     """BASELINE configs[4] shape per GPU: the fused actor (obs -> 400 -> 300 -> P, tanh) produces the actions on the device
     between single-step env launches (`ev2g_rollout`).  Returns env-steps/s of this rank and both kernel durations."""
     import torch
@@ -248,7 +248,7 @@ def rollout_record(Engine, batch, rk, sk, local_rank, devx, E, lo, rank, args, T
         done = torch.empty((E,), dtype=torch.uint8, device=dev)
         mask = torch.empty((E, P), dtype=torch.uint8, device=dev)
         stats = torch.empty((E, _abi.N_STATS), dtype=torch.float64, device=dev)
-        actor = FusedMLPActor(eng, E, P, D, lo, dev, seed=1234 + rank)
+        actor = FusedMLPActor(eng, E, P, D, lo, dev, seed=1234 + rank, precision=precision)
         loop = RolloutLoop(eng, E, P, T, eng.M, None, obs, rew, done, mask, stats, None, actor)
         loop.reset()
         loop.run(T, False)
@@ -268,7 +268,7 @@ def rollout_record(Engine, batch, rk, sk, local_rank, devx, E, lo, rank, args, T
         step_us = eng.last_step_n_kernel_ms() * 1e3 / 64
         actor_us = actor.forward_train_us(200)
         eng.check_faults()
-        return {"env_steps_per_s_per_gpu": E * n / spent, "us_per_step_wall": spent / n * 1e6,
+        return {"env_steps_per_s_per_gpu": E * n / spent, "us_per_step_wall": spent / n * 1e6, "precision": precision,
                 "fused_launch": seg_spec == 4, "launches_per_segment": 1 if seg_spec == 4 else "2 per step", "segment_kernel_us_per_step": seg_us,
                 "segment_roofline_frac_env_bytes_only": bytes_env_step * E / (seg_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                 "step_kernel_us": step_us, "actor_kernel_us": actor_us, "step_kernel": eng.kernel_name,
@@ -755,6 +755,13 @@ def main():
             rollout["collector"] = collector_record(Engine, batch, rk, sk, local_rank, devx, E, wl["lo"], rank, args, T)
         except Exception as ex:   # (a record next to the headline: never lets the line fail)
             rollout["collector"] = {"error": str(ex)}
+        if sk != _abi.STATE_KINDS["PublicPST"]:   # the same loop with the FLOAT32 policy (two bf16 terms per weight, three per activation: what an SB3 float32 actor computes to 1e-5)
+            try:
+                r32 = rollout_record(Engine, batch, rk, sk, local_rank, devx, E, wl["lo"], rank, args, T, bytes_env_step, precision="fp32")
+                rollout["fp32"] = {k_: r32[k_] for k_ in ("env_steps_per_s_per_gpu", "us_per_step_wall", "precision", "fused_launch", "launches_per_segment",
+                                                            "segment_kernel_us_per_step", "actor_kernel_us", "actor", "steps_timed")}
+            except Exception as ex:
+                rollout["fp32"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     # outside the timed regions: the C-ABI's own RCCL gather (ev2g_comm_init / ev2g_gather_stats, the path of hosts without
     # torch.distributed) next to torch's, on the same statistics

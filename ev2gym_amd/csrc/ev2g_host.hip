@@ -1303,6 +1303,9 @@ int ev2g_mlp_create_ex(ev2g_handle *h, int d_in, int h1, int h2, int d_out, cons
 #ifdef EV2G_MLP_TIMING
     { unsigned long long *p; if (dalloc(h, m->allocs, 16, &p)) { delete m; return EV2G_ERR_HIP; } d.dbg = p; }
 #endif
+#ifdef EV2G_F32_STAMPS
+    { unsigned long long *p; if (dalloc(h, m->allocs, 8 * 16 * 8, &p)) { delete m; return EV2G_ERR_HIP; } d.dbg = p; }
+#endif
     if (precision != EV2G_MLP_BF16 && precision != EV2G_MLP_F32 && precision != EV2G_MLP_F32X3) { delete m; return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create_ex: precision must be EV2G_MLP_BF16, EV2G_MLP_F32 or EV2G_MLP_F32X3"); }
     const bool f32 = precision != EV2G_MLP_BF16;
     const MlpS16Pick s16 = mlp_s16_for(d_in, h1, h2, d_out, precision == EV2G_MLP_BF16 ? 1 : (precision == EV2G_MLP_F32 ? 2 : 3));
@@ -1376,6 +1379,13 @@ int ev2g_mlp_forward(ev2g_handle *h, const ev2g_mlp *m, const float *x, float *y
     return EV2G_OK;
 }
 
+#ifdef EV2G_F32_STAMPS
+extern "C" int ev2g_mlp_debug_f32_stamps(ev2g_handle *h, const ev2g_mlp *m, unsigned long long *out1024) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out1024, m->dev.dbg, 8 * 16 * 8 * 8, hipMemcpyDeviceToHost));   // [workgroup 0..7][wavefront][stamp 0..7]
+    return 0;
+}
+#endif
 #ifdef EV2G_MLP_TIMING
 int ev2g_mlp_debug_stamps(ev2g_handle *h, const ev2g_mlp *m, unsigned long long *out8) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1395,7 +1405,9 @@ static bool fused_eligible(const ev2g_handle *h, const ev2g_mlp *m) {
     const bool pst = s.state_kind == EV2G_STATE_PUBLIC_PST;
     return h->wave_path && s.P >= 3 && s.P <= 64 && std::min(s.reward_kind, 3) != 3 && (h->cfg.flags & EV2G_FLAG_LOG_SOC) &&
            !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) && !h->extras.cost && !h->no_full && !h->no_wide && (pst || (s.D & 1) == 0) &&
-           m->s16_ks1 == (pst ? 2 : 6) && m->s16_nt1 == 25 && m->s16_nt2 == 19 && m->s16_nt3 == (pst ? 2 : 4) && m->s16_nw == 1 && !std::getenv("EV2G_NO_FUSED");
+           m->s16_ks1 == (pst ? 2 : 6) && m->s16_nt1 == 25 && m->s16_nt2 == 19 && m->s16_nt3 == (pst ? 2 : 4) &&
+           (m->s16_nw == 1 || (m->s16_nw == 2 && !pst && !std::getenv("EV2G_NO_FUSED_F32"))) &&   // (last session of round 6: the float32 policy, two bf16 terms per weight, for the head-table states)
+           !std::getenv("EV2G_NO_FUSED");
 }
 // k steps from the current one; obs0: the [E, D] float32 rows the first forward reads; obs / act / reward / done / mask: the rows of the segment's first
 // step with their step strides (elements; 0 = one row, overwritten)
@@ -1414,7 +1426,8 @@ static int launch_fused(ev2g_handle *h, const ev2g_mlp *m, int k, const float *o
     FusedArgs fa{};
     fa.m = m->dev; fa.obs0 = obs0;
     const V2P *pp = (const V2P *)h->d_v2p;
-    const size_t lds = ev2g_fused_lds_bytes(ae);
+    const int nwf = m->s16_nw;
+    const size_t lds = ev2g_fused_lds_bytes(ae, nwf);
     const dim3 grid((s.E + 16 * ae - 1) / (16 * ae)), block(EV2G_FUSED_BLOCK);
     const int t0 = h->current_step;
 #define EV2G_FUSED_CASE(SK, RK)                                                                                                            \
@@ -1435,9 +1448,20 @@ static int launch_fused(ev2g_handle *h, const ev2g_mlp *m, int k, const float *o
         }                                                                                                                                  \
         hipLaunchKernelGGL(kfn, grid, block, lds, h->stream, pp, io, t0, k, 0, wa, fa);                                                     \
     } break;
-    switch (ae == 2 ? 16 + std::min(s.reward_kind, 3) : s.state_kind * 4 + std::min(s.reward_kind, 3)) {
+#define EV2G_FUSED_CASEF(SK, RK)   /* the float32 policy (two bf16 terms per weight) inside the launch */                                  \
+    case 20 + SK * 4 + RK: {                                                                                                               \
+        auto kfn = ev2g_step_wave<SK, RK, true, 2, EV2G_FUSED_BLOCK, true, 1, 2>;                                                           \
+        if (!(h->fused_attr_mask & (1u << (20 + SK * 4 + RK)))) {                                                                          \
+            HIPCHK(h, hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+            h->fused_attr_mask |= 1u << (20 + SK * 4 + RK);                                                                                \
+        }                                                                                                                                  \
+        hipLaunchKernelGGL(kfn, grid, block, lds, h->stream, pp, io, t0, k, 0, wa, fa);                                                     \
+    } break;
+    switch (nwf == 2 ? 20 + s.state_kind * 4 + std::min(s.reward_kind, 3) : (ae == 2 ? 16 + std::min(s.reward_kind, 3) : s.state_kind * 4 + std::min(s.reward_kind, 3))) {
         EV2G_FUSED_CASE(0, 0) EV2G_FUSED_CASE(0, 1) EV2G_FUSED_CASE(0, 2)
+        EV2G_FUSED_CASEF(0, 0) EV2G_FUSED_CASEF(0, 1) EV2G_FUSED_CASEF(0, 2)
 #ifndef EV2G_ONLY_00
+        EV2G_FUSED_CASEF(2, 0) EV2G_FUSED_CASEF(2, 1) EV2G_FUSED_CASEF(2, 2)
         EV2G_FUSED_CASE(1, 0) EV2G_FUSED_CASE(1, 1) EV2G_FUSED_CASE(1, 2)
         EV2G_FUSED_CASE(2, 0) EV2G_FUSED_CASE(2, 1) EV2G_FUSED_CASE(2, 2)
         EV2G_FUSED_CASE2(0) EV2G_FUSED_CASE2(1) EV2G_FUSED_CASE2(2)
@@ -1446,6 +1470,7 @@ static int launch_fused(ev2g_handle *h, const ev2g_mlp *m, int k, const float *o
     }
 #undef EV2G_FUSED_CASE
 #undef EV2G_FUSED_CASE2
+#undef EV2G_FUSED_CASEF
     HIPCHK(h, hipGetLastError());
     h->last_spec = 4;
     h->general_reason = "";

@@ -39,6 +39,18 @@ struct MlpDev {
 #else
 #define MLP_STAMP(i)
 #endif
+// the inline float32 policy's k-step (ev2g_mlp3_inline_f32): 0 = the compiler's interleaving of LDS reads, weight requests and MFMAs; 1 = the five MFMAs as one
+// back-to-back group behind one wait; 2 = 1 + the next k-step's operand terms read from LDS ahead of the group.  Measured at cfg2 (profiles/r06_fused_float32_policy.txt):
+// 2 with a ring of 4 fragments (no scratch) +2.5 % over 0 with a ring of 8; 1 and 2 with deeper rings spill 20..68 bytes per lane and lose 1..2.5 %.
+#ifndef EV2G_F32_GROUP
+#define EV2G_F32_GROUP 2
+#endif
+// tuning builds (-DEV2G_F32_STAMPS, tools/r6/f32_stamps.py): every wavefront of the first 8 workgroups stamps the layers of the inline float32 policy (the last forward's stay)
+#ifdef EV2G_F32_STAMPS
+#define F32_STAMP(i) if (m.dbg && blockIdx.x < 8 && (threadIdx.x & 63) == 0) m.dbg[((blockIdx.x * 16 + (threadIdx.x >> 6)) * 8) + i] = __builtin_readcyclecounter();
+#else
+#define F32_STAMP(i)
+#endif
 
 __host__ __device__ inline int ev2g_mlp_lds_stride(int k) { return k + 8; }   // bf16 elements per LDS row: +16 bytes against bank conflicts
 __host__ __device__ inline size_t ev2g_mlp_lds_bytes(const MlpDev &m) {
@@ -685,6 +697,222 @@ __device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t
     ev2g_mlp_lds_barrier();
     layer(std::integral_constant<int, 2>{}, bufH2, C::SH2, lb + (NT1 + NT2) * 16, nullptr, 0);
     ev2g_mlp_lds_barrier();
+}
+
+// ---- the FLOAT32 network (EV2G_MLP_F32: two bf16 terms per weight, three per activation, five MFMA products per k-step) as a device function of the
+// same 16-wavefront workgroup (ev2g_step_wave<.., ACT, 1, 2>).  Same tiles, same fragment packing, same per-tile MFMA chain -- terms, order, accumulator by
+// parity -- and the same epilogues as ev2g_mlp3_s16<.., NW = 2>: the actions are bit-identical to that kernel's.  What the 160 KB of LDS next to the step's
+// state dictate:
+//   * the input rows stay FLOAT32 in LDS (16 x (KS1*32 + 4) floats: two thirds of the three bf16 copies) and a wavefront splits its operand fragment into
+//     the three terms when it reads it -- ONCE per k-step for both of its layer-1 tiles (layer 1 walks k-step, tile, term; the other layers tile, k-step,
+//     term), so the split costs each wavefront 6 x 44 VALU operations per forward;
+//   * the hidden activations are split where they are produced (three bf16 copies each, like the stand-alone kernel): H1's three copies and two of H2's
+//     in the step's staging rows (61.7 of 66 KB), H2's third copy over the input rows, which are dead after layer 1 -- the padding columns behind d_in
+//     are re-zeroed at the end (the step rewrites every real column before the next forward);
+//   * the biases are read from global memory (L1 / L2 hits, requested a layer ahead), not staged.
+template <int KS1, int NT1, int NT2, int NT3, int WVS, int RING>
+__device__ __forceinline__ void ev2g_mlp3_inline_f32(const MlpDev &m, float *bufX, int sxf, uint16_t *h1, uint16_t *h2ab, uint16_t *h2c, float *act, int as, float *y, int nr, int tid) {
+    constexpr int NW = 2, NX = 3;
+    typedef MlpS16<KS1, NT1, NT2, NT3, 1, 4, 1> C;
+    constexpr int KS2 = C::KS2, KS3 = C::KS3;
+    constexpr int MT1 = (NT1 + WVS - 1) / WVS, MT2 = (NT2 + WVS - 1) / WVS, MT3 = (NT3 + WVS - 1) / WVS;
+    constexpr int S1 = MT1 * KS1 * NW, S2 = MT2 * KS2 * NW, S3 = MT3 * KS3 * NW, STOT = S1 + S2 + S3;
+    constexpr int BH1 = 16 * C::SH1, BH2 = 16 * C::SH2;
+    static_assert(RING % NW == 0 && RING >= 2 * NW, "ring slots come in pairs of weight terms");
+    // (A/B switch: layer 3's few tiles on wavefronts W3OFF .. W3OFF + NT3 - 1.  Wavefronts 4..7 reach layer 2's closing barrier ~3 k cycles before the two-tile ones
+    // (0 .. 2), so their ring is full of layer-3 fragments by then -- and layer 3 takes the same 3.5 k cycles: it waits for its own LDS-read -> MFMA chain per k-step,
+    // not for weights; profiles/r06_fused_float32_policy.txt.  Default 0.)
+#ifndef EV2G_F32_W3OFF
+#define EV2G_F32_W3OFF 0
+#endif
+    constexpr int W3OFF = (MT3 == 1 && NT3 + EV2G_F32_W3OFF <= WVS) ? EV2G_F32_W3OFF : 0;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint4 *w1 = (const uint4 *)m.w1 + lane, *w2 = (const uint4 *)m.w2 + lane, *w3 = (const uint4 *)m.w3 + lane;
+    const float *ball = m.b1;   // b1 | b2 | b3, each padded to its tiles
+    uint4 ring[RING];
+    auto request = [&](int seq) __attribute__((always_inline)) {   // (seq is a constant wherever this is called, after unrolling)
+        if (seq >= STOT) return;
+        const int L = seq < S1 ? 0 : (seq < S1 + S2 ? 1 : 2);
+        const int r = seq - (L == 0 ? 0 : (L == 1 ? S1 : S1 + S2));
+        const int KS = L == 0 ? KS1 : (L == 1 ? KS2 : KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3);
+        int i, rem;   // tile slot; ks * NW + term
+        if (L == 0) { const int ks = r / (MT1 * NW), r2 = r - ks * (MT1 * NW); i = r2 / NW; rem = ks * NW + (r2 - i * NW); }
+        else { i = r / (KS * NW); rem = r - i * (KS * NW); }
+        const uint4 *w = L == 0 ? w1 : (L == 1 ? w2 : w3);
+        if (L == 2) { if ((unsigned)(wave - W3OFF) < (unsigned)NT3) ring[seq % RING] = w[(unsigned)(((wave - W3OFF) * (KS * NW) + rem) * 64)]; }
+        else
+        if (WVS * i + WVS - 1 < NT || wave + WVS * i < NT) ring[seq % RING] = w[(unsigned)(((wave + WVS * i) * (KS * NW) + rem) * 64)];
+    };
+    F32_STAMP(0)
+    const int brow = lane & 15, kq = lane >> 4;
+    f32x4m bias1[MT1];
+#pragma unroll
+    for (int i = 0; i < MT1; i++) bias1[i] = *(const f32x4m *)(ball + min(wave + WVS * i, NT1 - 1) * 16 + kq * 4);
+#pragma unroll
+    for (int sq = 0; sq < RING; sq++) request(sq);
+    ev2g_mlp_lds_barrier();   // the step's observation columns are in bufX; nobody reads the staging rows any more
+    F32_STAMP(1)
+    if (tid < 256) {   // H1's columns no tile writes (layer 2's last k-step reads them): zeros, in every copy
+        const int pj = tid & 15, pr = tid >> 4;
+        constexpr int P1 = KS2 * 32 - NT1 * 16;
+        if (pj < P1) {
+#pragma unroll
+            for (int k = 0; k < NX; k++) h1[k * BH1 + pr * C::SH1 + NT1 * 16 + pj] = 0;
+        }
+    }
+    // the MFMA chain of one (tile, k-step): the small terms first, accumulator by the parity of k-step + terms (ev2g_mlp3_s16)
+    auto chain = [&](int ks, int sq0, const uint4 (&bt)[NX], f32x4m &acc0, f32x4m &acc1) __attribute__((always_inline)) {
+        typedef unsigned u32x4m __attribute__((ext_vector_type(4)));
+        u32x4m av[NW], bv[NX];
+#pragma unroll
+        for (int p = 0; p < NW; p++) __builtin_memcpy(&av[p], &ring[(sq0 + p) % RING], 16);
+#pragma unroll
+        for (int k = 0; k < NX; k++) __builtin_memcpy(&bv[k], &bt[k], 16);
+#if EV2G_F32_GROUP
+        // every operand of the k-step collected BEFORE its first MFMA, then the five MFMAs back to back: a wait or a load between two MFMAs on the same accumulator
+        // costs ~40 cycles each (MI355X_MICROARCH.md, per-instruction constants)
+        asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]));
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int p = NW - 1; p >= 0; p--) {
+            bf16x8 a;
+            __builtin_memcpy(&a, &av[p], 16);
+#pragma unroll
+            for (int xq = NX - 1; xq >= 0; xq--) {
+                if (p + xq <= 2) {
+                    bf16x8 b;
+                    __builtin_memcpy(&b, &bv[xq], 16);
+                    if ((ks + p + xq) & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0, 0, 0, 0);
+                }
+            }
+        }
+#if EV2G_F32_GROUP
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    };
+    auto hidden_out = [&](const f32x4m &acc, uint16_t *o0, uint16_t *o1, uint16_t *o2, int so, int col) __attribute__((always_inline)) {
+        uint32_t lo[NX], hi[NX];
+        ev2g_split_bf16<NX>(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), lo);
+        ev2g_split_bf16<NX>(fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f), hi);
+        *(uint2 *)(o0 + brow * so + col) = make_uint2(lo[0], hi[0]);
+        *(uint2 *)(o1 + brow * so + col) = make_uint2(lo[1], hi[1]);
+        *(uint2 *)(o2 + brow * so + col) = make_uint2(lo[2], hi[2]);
+    };
+    // ---- layer 1: float32 rows -> three terms per operand fragment, once per k-step for both tile slots ----
+    f32x4m bias2[MT2];
+#pragma unroll
+    for (int i = 0; i < MT2; i++) bias2[i] = *(const f32x4m *)(ball + NT1 * 16 + min(wave + WVS * i, NT2 - 1) * 16 + kq * 4);   // (a layer ahead)
+    {
+        f32x4m acc0[MT1], acc1[MT1];
+#pragma unroll
+        for (int i = 0; i < MT1; i++) { acc0[i] = bias1[i]; acc1[i] = f32x4m{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS1; ks++) {
+            const float4 xa = *(const float4 *)(bufX + brow * sxf + ks * 32 + kq * 8), xb = *(const float4 *)(bufX + brow * sxf + ks * 32 + kq * 8 + 4);
+            uint32_t t0[NX], t1[NX], t2[NX], t3[NX];
+            ev2g_split_bf16<NX>(xa.x, xa.y, t0); ev2g_split_bf16<NX>(xa.z, xa.w, t1); ev2g_split_bf16<NX>(xb.x, xb.y, t2); ev2g_split_bf16<NX>(xb.z, xb.w, t3);
+            uint4 bt[NX];
+#pragma unroll
+            for (int k = 0; k < NX; k++) bt[k] = make_uint4(t0[k], t1[k], t2[k], t3[k]);
+#pragma unroll
+            for (int i = 0; i < MT1; i++) {
+                const int sq0 = (ks * MT1 + i) * NW;
+                if (WVS * i + WVS - 1 < NT1 || wave + WVS * i < NT1) chain(ks, sq0, bt, acc0[i], acc1[i]);   // (uniform; a constant but for the last slot)
+#pragma unroll
+                for (int p = 0; p < NW; p++) request(sq0 + p + RING);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT1; i++) {
+            const int tile = wave + WVS * i;
+            if (WVS * i + WVS - 1 < NT1 || tile < NT1) hidden_out(acc0[i] + acc1[i], h1, h1 + BH1, h1 + 2 * BH1, C::SH1, tile * 16 + kq * 4);
+        }
+    }
+    F32_STAMP(2)
+    ev2g_mlp_lds_barrier();
+    F32_STAMP(3)
+    if (tid < 256) {   // H2's tail columns (its third copy lies over the input rows: only now)
+        const int pj = tid & 15, pr = tid >> 4;
+        constexpr int P2 = KS3 * 32 - NT2 * 16;
+        if (pj < P2) { h2ab[pr * C::SH2 + NT2 * 16 + pj] = 0; h2ab[BH2 + pr * C::SH2 + NT2 * 16 + pj] = 0; h2c[pr * C::SH2 + NT2 * 16 + pj] = 0; }
+    }
+    // ---- layers 2 and 3: tile slot, k-step, term ----
+    auto layer = [&](auto Lc, const uint16_t *a0, const uint16_t *a1, const uint16_t *a2, int sa, const f32x4m *bias) __attribute__((always_inline)) {
+        constexpr int L = decltype(Lc)::value;
+        constexpr int KS = L == 1 ? KS2 : KS3, NT = L == 1 ? NT2 : NT3, MT = (NT + WVS - 1) / WVS;
+        constexpr int base = L == 1 ? S1 : S1 + S2;
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const int tile = L == 2 ? wave - W3OFF : wave + WVS * i;
+            if (L == 2 ? (unsigned)tile < (unsigned)NT : (WVS * i + WVS - 1 < NT || tile < NT)) {   // (uniform)
+                f32x4m acc0 = bias[i], acc1 = f32x4m{0.f, 0.f, 0.f, 0.f};
+#if EV2G_F32_GROUP >= 2   // the next k-step's operand terms are read from LDS before this one's MFMA group (12 registers more)
+                uint4 btn[NX];
+                btn[0] = *(const uint4 *)(a0 + brow * sa + kq * 8); btn[1] = *(const uint4 *)(a1 + brow * sa + kq * 8); btn[2] = *(const uint4 *)(a2 + brow * sa + kq * 8);
+#endif
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const int sq0 = base + (i * KS + ks) * NW;
+                    uint4 bt[NX];
+#if EV2G_F32_GROUP >= 2
+                    bt[0] = btn[0]; bt[1] = btn[1]; bt[2] = btn[2];
+                    if (ks + 1 < KS) {
+                        btn[0] = *(const uint4 *)(a0 + brow * sa + (ks + 1) * 32 + kq * 8);
+                        btn[1] = *(const uint4 *)(a1 + brow * sa + (ks + 1) * 32 + kq * 8);
+                        btn[2] = *(const uint4 *)(a2 + brow * sa + (ks + 1) * 32 + kq * 8);
+                    }
+#else
+                    bt[0] = *(const uint4 *)(a0 + brow * sa + ks * 32 + kq * 8);
+                    bt[1] = *(const uint4 *)(a1 + brow * sa + ks * 32 + kq * 8);
+                    bt[2] = *(const uint4 *)(a2 + brow * sa + ks * 32 + kq * 8);
+#endif
+                    chain(ks, sq0, bt, acc0, acc1);
+#pragma unroll
+                    for (int p = 0; p < NW; p++) request(sq0 + p + RING);
+                }
+                const f32x4m acc = acc0 + acc1;
+                const int col = tile * 16 + kq * 4;
+                if (L == 1) hidden_out(acc, h2ab, h2ab + BH2, h2c, C::SH2, col);
+                else {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { v[r] = tanhf(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
+                    *(float4 *)(act + brow * as + col) = make_float4(v[0], v[1], v[2], v[3]);   // (NT3 <= 4: columns 0..63)
+                    const int d_out = m.d_out;
+                    if (brow < nr) {
+                        float *yr = y + (size_t)brow * d_out + col;
+                        if ((d_out & 1) == 0) {
+                            if (col + 1 < d_out) *(float2 *)yr = make_float2(v[0], v[1]);
+                            if (col + 3 < d_out) *(float2 *)(yr + 2) = make_float2(v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) if (col + r < d_out) yr[r] = v[r];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < KS * NW; u++) request(base + i * KS * NW + u + RING);   // no tile in this slot: the sequence moves on all the same
+            }
+        }
+    };
+    f32x4m bias3[MT3];
+#pragma unroll
+    for (int i = 0; i < MT3; i++) bias3[i] = *(const f32x4m *)(ball + (NT1 + NT2) * 16 + min(max(wave - W3OFF, 0) + WVS * i, NT3 - 1) * 16 + kq * 4);
+    layer(std::integral_constant<int, 1>{}, h1, h1 + BH1, h1 + 2 * BH1, C::SH1, bias2);
+    F32_STAMP(4)
+    ev2g_mlp_lds_barrier();
+    F32_STAMP(5)
+    layer(std::integral_constant<int, 2>{}, h2ab, h2ab + BH2, h2c, C::SH2, bias3);
+    F32_STAMP(6)
+    ev2g_mlp_lds_barrier();
+    F32_STAMP(7)
+    {   // the input rows' padding columns, which H2's third copy overwrote
+        const int d_in = m.d_in, pr = tid >> 6;
+        for (int cc = d_in + lane; cc < KS1 * 32; cc += 64) bufX[pr * sxf + cc] = 0.f;
+    }
 }
 
 __global__ void __launch_bounds__(EV2G_MLP_BLOCK) ev2g_mlp3_any(MlpDev m, const float *__restrict__ x, float *__restrict__ y, int n_rows) {

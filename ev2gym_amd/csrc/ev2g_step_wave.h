@@ -34,7 +34,13 @@ __host__ __device__ inline size_t ev2g_wave_lds_bytes(int envs_per_group, int bl
 #define EV2G_FUSED_RING2 7    // the same with two envs per wavefront (AE = 2): the second row block's accumulators and operand take 12 registers
 #endif
 
-__host__ __device__ inline size_t ev2g_fused_lds_bytes(int envs_per_wave = 1) {
+#define EV2G_FUSED_SXF 196    // the float32 policy (NWF = 2): floats per observation row in LDS (6 k-steps of 32 + 16 bytes against bank conflicts)
+#ifndef EV2G_FUSED_RINGF
+#define EV2G_FUSED_RINGF 4    // ... and its weight fragments in flight per wavefront (two terms per k-step; 6 / 8 measure the same as 4 and leave no registers for EV2G_F32_GROUP = 2)
+#endif
+__host__ __device__ inline size_t ev2g_fused_lds_bytes(int envs_per_wave = 1, int weight_terms = 1) {
+    if (weight_terms > 1)   // float32 input rows (H2's third copy lies over them between layers 1 and 3), biases from global memory: 163 488 of the 163 840 bytes
+        return ev2g_wave_lds_bytes(EV2G_FUSED_BLOCK / 64 * envs_per_wave, EV2G_FUSED_BLOCK) + (size_t)16 * EV2G_FUSED_SXF * 4;
     return ev2g_wave_lds_bytes(EV2G_FUSED_BLOCK / 64 * envs_per_wave, EV2G_FUSED_BLOCK) + (size_t)16 * EV2G_FUSED_SX * 2 + (size_t)(25 + 19 + 4) * 16 * 4;   // + input rows, biases
 }
 // What the fused instantiation needs besides the step's own arguments: the policy, and the observation rows its first forward reads.
@@ -154,12 +160,15 @@ struct WaveArgs {
 // The outputs (observation / action / reward / done / mask rows of every step) go to the caller's blocks through running pointers.
 // AE (round 6; ACT with PublicPST, P <= 32): TWO envs per wavefront in the fused instantiation (lanes 0..31 / 32..63), 32 policy rows per workgroup -- every weight
 // fragment feeds two MFMAs, the weight stream per env halves, and 8192 envs are one round of 256 workgroups instead of two rounds of 512.
-template <int SK, int RK, bool IO32, int FULLK = 0, int BLOCK = EV2G_WAVE_BLOCK, bool ACT = false, int AE = 1>
+// NWF (round 6, last session; ACT with a head-table state, AE = 1): the FLOAT32 policy (EV2G_MLP_F32: two bf16 terms per weight, three per activation)
+// inside the launch -- ev2g_mlp3_inline_f32 (ev2g_mlp.h): the input rows stay float32 in LDS, the hidden activations' three copies fill the staging rows.
+template <int SK, int RK, bool IO32, int FULLK = 0, int BLOCK = EV2G_WAVE_BLOCK, bool ACT = false, int AE = 1, int NWF = 1>
 __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict__ params, StepIO io, int t0,
                                                            int k_steps, int auto_reset, WaveArgs wa, FusedArgs fa) {
     extern __shared__ double lds[];
     static_assert(!ACT || (IO32 && FULLK == 2 && BLOCK == EV2G_FUSED_BLOCK), "the fused actor + step instantiation");
     static_assert(AE == 1 || (ACT && SK == 1 && AE == 2), "two envs per wavefront in the fused instantiation: PublicPST only");
+    static_assert(NWF == 1 || (ACT && SK != 1 && AE == 1 && NWF == 2), "the float32 policy inside the launch: head-table states, one env per wavefront");
     constexpr bool FULL = FULLK >= 1, WIDE = FULLK >= 2, STR = FULLK >= 3 || ACT;
 #ifdef EV2G_STR_NT_OFF   // (A/B: the kept rows as ordinary stores)
     constexpr bool STR_NT = false;
@@ -221,6 +230,10 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     // wavefront reads its actions -- one instruction, all lanes -- before it writes the amps over them)
     float *act_lds = (float *)s_amps;
     uint16_t *bufH1 = (uint16_t *)stage, *bufH2 = bufH1 + 16 * AE * MC::SH1;
+    // NWF = 2: float32 input rows in bufX's place (no staged biases); H1's three copies, then two of H2's in the staging rows, H2's third over the input rows
+    constexpr int FSXF = EV2G_FUSED_SXF;
+    float *bufXf = (float *)(cnt + 8);
+    static_assert(NWF == 1 || (FKS1 * 32 + 4 <= FSXF && (3 * MC::SH1 + 2 * MC::SH2) * 16 * 2 <= EV2G_NQ * (EV2G_FUSED_BLOCK + 8) * 8 && MC::SH2 * 16 * 2 <= 16 * FSXF * 4), "float32 policy buffers");
     static_assert(AE * MC::SX <= EV2G_FUSED_SX && MC::NB <= (25 + 19 + 4) * 16 && 16 * AE * (MC::SH1 + MC::SH2) * 2 <= EV2G_NQ * (EV2G_FUSED_BLOCK + 8) * 8, "policy buffers");
     constexpr int ACT_AS = (AE == 1) ? 128 : 64;   // floats between two envs' action rows in s_amps (a wavefront's slice holds its envs' rows)
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -242,6 +255,11 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     const bool head = valid && q == 0;   // one lane per env: env-level scalars
     const int elg = wv * EPW + elw;      // env inside the workgroup
     const int arow = (AE == 1) ? wv : min(elg, 16 * AE - 1);   // (ACT) this lane's env as a row of the policy's buffers
+    // the policy's copy of an observation column pair (even column): packed bf16, or the float32 values themselves
+    auto xput2 = [&](int col, float a, float b) __attribute__((always_inline)) {
+        if (NWF > 1) *(float2 *)(bufXf + arow * FSXF + col) = make_float2(a, b);
+        else *(uint32_t *)(bufX + arow * FSX + col) = ev2g_pack_bf16(a, b);
+    };
     // ---- launch prologue.  A single-step launch (the RL loop with a policy between steps) pays it every step, with cold caches.
     // Round trip 1: what does not depend on data -- charger constants, the first action, the env accumulators and, for a single-step launch,
     // the scenario's occupancy / arrival masks of this step (step table slots 6, 7: occupancy does not depend on the actions); for a longer
@@ -332,9 +350,11 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                 if (env_ok && c + 1 < D) v = *(const float2 *)(xr + c);   // (D even: 22 + 40 + 2 P, 22 + 2 P)
                 else if (env_ok && c < D) v.x = xr[c];
             }
+            if (NWF > 1) { if (c < FKS1 * 32) xput2(c, v.x, v.y); }
+            else
             if (c < FSX) *(uint32_t *)(bufX + arow * FSX + c) = ev2g_pack_bf16(v.x, v.y);   // columns D .. : zeros (the k-steps' padding)
         }
-        if (tid < MC::NB) lbias[tid] = fa.m.b1[tid];   // (b1 | b2 | b3 are one array on this path, each padded to its tiles)
+        if (NWF == 1 && tid < MC::NB) lbias[tid] = fa.m.b1[tid];   // (b1 | b2 | b3 are one array on this path, each padded to its tiles)
     }
     __syncthreads();
 
@@ -404,6 +424,9 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
         double a_cur = a_next;   // this step's action; the prefetch below replaces a_next by the next step's
         if (ACT) {
             // ---- the policy, on the 16 observation rows of this workgroup's envs (ev2g_mlp3_inline, ev2g_mlp.h) ----
+            if (NWF > 1)
+                ev2g_mlp3_inline_f32<FKS1, 25, 19, FNT3, BLOCK / 64, EV2G_FUSED_RINGF>(fa.m, bufXf, FSXF, bufH1, bufH1 + 3 * 16 * MC::SH1, (uint16_t *)bufXf, act_lds, ACT_AS, act_out, min(16, E - e0), tid_l);
+            else
             ev2g_mlp3_inline<FKS1, 25, 19, FNT3, BLOCK / 64, (AE == 1 ? EV2G_FUSED_RING : EV2G_FUSED_RING2), AE>(fa.m, bufX, bufH1, bufH2, lbias, act_lds, ACT_AS, act_out, min(16 * AE, E - e0), tid_l);   // (starts and ends with a barrier: the actions are in LDS)
             act_out += io.a_stride;
             a_cur = valid ? (double)act_lds[arow * ACT_AS + q_l] : 0.0;
@@ -610,7 +633,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                 else stg32<f2v>(obs32, o4, (f2v){0.f, 0.f});
                 if (ACT) {
                     if (SK == 1) { bufX[arow * FSX + ocol_l] = 0; bufX[arow * FSX + ocol_l + 1] = 0; bufX[arow * FSX + ocol_l + 2] = 0; }   // (odd columns: three 16-bit words)
-                    else *(uint32_t *)(bufX + arow * FSX + ocol_l) = 0u;
+                    else xput2((int)ocol_l, 0.f, 0.f);
                 }
             }
         }
@@ -721,7 +744,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                     if (SK == 1) {
                         const uint32_t w01 = ev2g_pack_bf16((float)o0, (float)o1), w2 = ev2g_pack_bf16((float)o2, 0.f);
                         bufX[arow * FSX + ocol_l] = (uint16_t)w01; bufX[arow * FSX + ocol_l + 1] = (uint16_t)(w01 >> 16); bufX[arow * FSX + ocol_l + 2] = (uint16_t)w2;
-                    } else *(uint32_t *)(bufX + arow * FSX + ocol_l) = ev2g_pack_bf16((float)o0, (float)o1);
+                    } else xput2((int)ocol_l, (float)o0, (float)o1);
                 }
             }
             if (log_cs) {   // cs_power / cs_current of the step (ev2gym_env.py:533-535) and the chargers' current_power_output / current_total_amps
@@ -942,8 +965,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                 if (q_l == 0) stg32<f2v>(obs32, o4, (f2v){(float)sstep, (float)usage});
                 if (q_l < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)q_l * 8u, (f2v){(float)pf_h0.x, (float)pf_h0.y});
                 if (ACT) {
-                    if (q_l == 0) *(uint32_t *)(bufX + arow * FSX) = ev2g_pack_bf16((float)sstep, (float)usage);
-                    if (q_l < NPAIR) *(uint32_t *)(bufX + arow * FSX + 2 + 2 * q_l) = ev2g_pack_bf16((float)pf_h0.x, (float)pf_h0.y);
+                    if (q_l == 0) xput2(0, (float)sstep, (float)usage);
+                    if (q_l < NPAIR) xput2(2 + 2 * q_l, (float)pf_h0.x, (float)pf_h0.y);
                 }
                 if (!WIDE) {
                     if (q_l + P < NPAIR) stg32<f2v>(obs32, o4 + 8u + (unsigned)(q_l + P) * 8u, (f2v){(float)pf_h1.x, (float)pf_h1.y});

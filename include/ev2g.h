@@ -268,7 +268,8 @@ const char *ev2g_big_kernel_reason(const ev2g_handle *h);
  * fixed summation tree (last-bit differences, tests hold them to 1e-12).  EV2G_NO_BIG=1 at load time keeps 1.
  * Results are identical in all of them (tests/test_round3_gpu.py, test_round4_gpu.py, test_round5_gpu.py); EV2G_NO_FULL / EV2G_NO_WIDE /
  * EV2G_NO_STRIDED in the environment at load time force 0 / 1 / "strided outputs run 0"; EV2G_NO_DICT=1 at load time keeps the battery-maths operands
- * one record per session instead of in the per-model dictionary, EV2G_NO_FUSED=1 keeps ev2g_rollout / ev2g_collect at two launches per step. */
+ * one record per session instead of in the per-model dictionary, EV2G_NO_FUSED=1 keeps ev2g_rollout / ev2g_collect at two launches per step
+ * (EV2G_NO_FUSED_F32=1: only the float32 policy). */
 int ev2g_last_launch_specialisation(const ev2g_handle *h);
 /* When the last fast-path launch got the general instantiation (0): what the caller passed or configured that ruled the full one out (the
  * first such thing), "" otherwise.  The Python Engine warns once with it: the general instantiation is ~20 % slower, silently. */
@@ -368,7 +369,10 @@ int ev2g_mlp_forward(ev2g_handle *h, const ev2g_mlp *m, const float *x, float *y
  * present, the segment inside the episode, and the bf16 policy in the 162 -> 400 -> 300 -> 64 packing: the workgroup that steps 16 envs
  * evaluates the policy on their 16 observation rows between the steps (same MFMA chains as ev2g_mlp_forward: bit-identical actions), so
  * neither kernel pays a cold start per step and the port state stays in LDS across the segment.  Anything else runs actor and step as two
- * launches per step, as before (train_stable_baselines.py:62-130 is the loop this replaces). */
+ * launches per step, as before (train_stable_baselines.py:62-130 is the loop this replaces).
+ * Round 6: PublicPST too (two envs per wavefront), and the FLOAT32 policy (EV2G_MLP_F32) for the two head-table states: the same five-product chain per
+ * k-step as ev2g_mlp_forward's (bit-identical actions), input rows kept float32 in LDS and split into their three bf16 terms where they are read;
+ * EV2G_NO_FUSED_F32=1 keeps that policy at two launches per step.  EV2G_MLP_F32X3 policies always run two launches per step. */
 int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward, int64_t reward_step_stride, uint8_t *done,
                  int64_t done_step_stride, uint8_t *action_mask, int64_t mask_step_stride, int auto_reset);
 /* Segments that contain no episode end are captured once as a HIP graph (keyed by their full launch signature) and replayed;

@@ -344,3 +344,107 @@ def test_page_locked_host_buffers_round_trip():
     eng._lib.ev2g_host_free(eng._h, C.c_void_p(12345))               # (not ours: ignored)
     assert np.array_equal(b[3], b[3])                                # b is still valid
     eng.close()                                                      # b goes with the handle
+
+
+@pytest.mark.parametrize("state,E,C,reward", [("V2G_profit_max_loads", 37, 50, "ProfitMax_TrPenalty_UserIncentives"), ("V2G_profit_max_loads", 16, 64, "SquaredTrackingErrorReward"),
+                                              ("V2G_profit_max", 21, 40, "profit_maximization"), ("V2G_profit_max_loads", 19, 25, "ProfitMax_TrPenalty_UserIncentives"),
+                                              ("V2G_profit_max_loads", 33, 7, "profit_maximization"), ("V2G_profit_max", 5, 22, "SquaredTrackingErrorReward")])
+def test_fused_launch_with_the_float32_policy_equals_the_two_kernel_chain(state, E, C, reward, monkeypatch):
+    """VERDICT round 5, item 4 (float32 half): the FLOAT32 policy (EV2G_MLP_F32: two bf16 terms per weight, three per activation, five MFMA products per
+    k-step -- what an SB3 float32 actor computes to 1e-5) evaluated INSIDE the step kernel's launch (ev2g_step_wave<.., ACT, 1, 2> + ev2g_mlp3_inline_f32)
+    against the chain of two launches per step (EV2G_NO_FUSED=1: ev2g_mlp3_s16<.., NW = 2> then a single-step launch): every observation / action /
+    reward / done / mask row of a whole episode collected in segments of mixed length, the statistics and the next episode's reset observation, bit for bit
+    (same tiles, same term split, same MFMA chain per tile).  Ragged batches, narrow and full-width envs, both head-table states, the three rewards."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.actor import init_mlp_weights
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("EV2G_NO_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("EV2G_NO_FUSED", "1")
+        pool = generate_native(GenConfig.v2g_profit_plus_loads(2 * E, C, 1, seed=5))
+        eng = Engine(pool, _abi.REWARD_KINDS[reward], _abi.STATE_KINDS[state], flags=_abi.FLAG_LOG_SOC, n_active_envs=E)
+        P, D, T = eng.P, eng.D, eng.T
+        mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=9), out_lo=-1.0, precision="fp32")
+        obs, act = eng.empty((T + 1, E, D), np.float32), eng.empty((T, E, P), np.float32)
+        rew, done, mask = eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
+        nxt = eng.empty((E, D), np.float32)
+        stats = eng.empty((E, _abi.N_STATS))
+        eng.reset_f32(obs, 3)
+        t, specs = 0, set()
+        for k in [1, 1, 5, 17, 1, 40, 2, 1, 30] + [1] * 14:
+            assert t + k <= T
+            eng.collect(mlp, k, obs.at(t * E * D), act.at(t * E * P), rew.at(t * E), done.at(t * E), mask.at(t * E * P))
+            specs.add(eng.last_launch_specialisation)
+            t += k
+        assert t == T
+        eng.stats_reset_f32(stats, nxt, 3 + E)
+        eng.check_faults()
+        out = dict(obs=obs.to_host(), act=act.to_host(), rew=rew.to_host(), done=done.to_host(), mask=mask.to_host(), stats=stats.to_host(), nxt=nxt.to_host())
+        eng.mlp_destroy(mlp)
+        eng.close()
+        return specs, out
+
+    s_two, two = run(False)
+    assert 4 not in s_two
+    s_one, one = run(True)
+    assert s_one == {4}, s_one   # every segment ran the fused instantiation
+    assert np.abs(two["act"]).max() > 0.05 and np.isfinite(two["obs"]).all()
+    for k in two:
+        assert np.array_equal(one[k], two[k], equal_nan=True), k
+    # and the switch: EV2G_NO_FUSED_F32=1 keeps the float32 policy on two launches per step while the bf16 one stays fused
+    monkeypatch.setenv("EV2G_NO_FUSED_F32", "1")
+    s_off, off = run(True)
+    monkeypatch.delenv("EV2G_NO_FUSED_F32")
+    assert 4 not in s_off and np.array_equal(off["act"], two["act"])
+
+
+def test_fused_float32_policy_at_the_benchmarked_size(monkeypatch):
+    """BASELINE configs[4]'s per-GPU shard (4096 envs x 50 chargers) with the float32 policy: a whole episode as ONE fused launch against 112 x (actor
+    launch, step launch), every action / reward / done / mask row and the statistics bit for bit; and the actions of sampled rows against a float64
+    numpy forward of the same network on the float32 observations the launch wrote (the 1e-5 level the two-term weights give)."""
+    from ev2gym_amd import _abi
+    from ev2gym_amd.actor import init_mlp_weights
+    from ev2gym_amd.engine import Engine
+    from ev2gym_amd.scenario_gen import GenConfig, generate_native
+    E = 4096
+    pool = generate_native(GenConfig.v2g_profit_plus_loads(E, 50, 1, seed=78)).sorted_by_busy_window(E)
+    weights = init_mlp_weights(162, 50, seed=4)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("EV2G_NO_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("EV2G_NO_FUSED", "1")
+        eng = Engine(pool, _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"], flags=_abi.FLAG_LOG_SOC)
+        P, D, T = eng.P, eng.D, eng.T
+        mlp = eng.mlp_create(*weights, out_lo=-1.0, precision="fp32")
+        obs, act = eng.empty((T + 1, E, D), np.float32), eng.empty((T, E, P), np.float32)
+        rew, done, mask = eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
+        eng.reset_f32(obs, 0)
+        eng.collect(mlp, T, obs, act, rew, done, mask)
+        spec = eng.last_launch_specialisation
+        out = dict(act=act.to_host(), rew=rew.to_host(), done=done.to_host(), mask=mask.to_host(), stats=eng.stats().copy())
+        o = obs.to_host()
+        out["obs_rows"] = np.stack([o[t] for t in (0, 1, 2, T // 2, T - 1, T)])
+        out["obs_sum"] = o.astype(np.float64).sum(axis=(1, 2))
+        del o
+        eng.check_faults()
+        eng.mlp_destroy(mlp)
+        eng.close()
+        return spec, out
+
+    s2, two = run(False)
+    s1, one = run(True)
+    assert s1 == 4 and s2 != 4
+    for k in two:
+        assert np.array_equal(one[k], two[k], equal_nan=True), k
+    W1, b1, W2, b2, W3, b3 = [np.asarray(a, np.float64) for a in weights]
+    T = one["act"].shape[0]
+    for i, t in enumerate((0, 1, 2, T // 2, T - 1)):
+        x = one["obs_rows"][i][::97].astype(np.float64)
+        y = np.tanh(np.maximum(np.maximum(x @ W1.T + b1, 0.0) @ W2.T + b2, 0.0) @ W3.T + b3)
+        assert np.abs(one["act"][t][::97] - y).max() < 5e-5, (t, np.abs(one["act"][t][::97] - y).max())
