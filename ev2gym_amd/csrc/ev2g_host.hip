@@ -1406,7 +1406,7 @@ static bool fused_eligible(const ev2g_handle *h, const ev2g_mlp *m) {
     return h->wave_path && s.P >= 3 && s.P <= 64 && std::min(s.reward_kind, 3) != 3 && (h->cfg.flags & EV2G_FLAG_LOG_SOC) &&
            !(h->cfg.flags & EV2G_FLAG_LOG_CS_HISTORY) && !h->extras.cost && !h->no_full && !h->no_wide && (pst || (s.D & 1) == 0) &&
            m->s16_ks1 == (pst ? 2 : 6) && m->s16_nt1 == 25 && m->s16_nt2 == 19 && m->s16_nt3 == (pst ? 2 : 4) &&
-           (m->s16_nw == 1 || (m->s16_nw == 2 && !pst && !std::getenv("EV2G_NO_FUSED_F32"))) &&   // (last session of round 6: the float32 policy, two bf16 terms per weight, for the head-table states)
+           (m->s16_nw == 1 || (m->s16_nw == 2 && !std::getenv("EV2G_NO_FUSED_F32"))) &&   // (last session of round 6: the float32 policy, two bf16 terms per weight; one env per wavefront)
            !std::getenv("EV2G_NO_FUSED");
 }
 // k steps from the current one; obs0: the [E, D] float32 rows the first forward reads; obs / act / reward / done / mask: the rows of the segment's first
@@ -1421,7 +1421,7 @@ static int launch_fused(ev2g_handle *h, const ev2g_mlp *m, int k, const float *o
     StepIO io = make_io(h, nullptr, a_stride, nullptr, o_stride, reward, r_stride, done, d_stride, mask, m_stride, 0, 0);
     io.act32 = act; io.obs32 = obs;
     // round 6: PublicPST envs of at most 32 ports go TWO to a wavefront (32 policy rows per workgroup; EV2G_FUSED_ONE_ENV=1: the one-env form, for A/B)
-    const int ae = (s.state_kind == EV2G_STATE_PUBLIC_PST && s.P <= 32 && !std::getenv("EV2G_FUSED_ONE_ENV")) ? 2 : 1;
+    const int ae = (s.state_kind == EV2G_STATE_PUBLIC_PST && s.P <= 32 && m->s16_nw == 1 && !std::getenv("EV2G_FUSED_ONE_ENV")) ? 2 : 1;
     const WaveArgs wa{s.P, s.T, s.E, s.D, s.M, st.slab_port, st.slab_port_slice, st.hist, st.env_acc, s.cs_pack, (char *)st.line, h->d_step_tab, (char *)st.port_dyn, s.dict, ae, ae == 1 ? s.P : 32};
     FusedArgs fa{};
     fa.m = m->dev; fa.obs0 = obs0;
@@ -1462,6 +1462,7 @@ static int launch_fused(ev2g_handle *h, const ev2g_mlp *m, int k, const float *o
         EV2G_FUSED_CASEF(0, 0) EV2G_FUSED_CASEF(0, 1) EV2G_FUSED_CASEF(0, 2)
 #ifndef EV2G_ONLY_00
         EV2G_FUSED_CASEF(2, 0) EV2G_FUSED_CASEF(2, 1) EV2G_FUSED_CASEF(2, 2)
+        EV2G_FUSED_CASEF(1, 0) EV2G_FUSED_CASEF(1, 1) EV2G_FUSED_CASEF(1, 2)
         EV2G_FUSED_CASE(1, 0) EV2G_FUSED_CASE(1, 1) EV2G_FUSED_CASE(1, 2)
         EV2G_FUSED_CASE(2, 0) EV2G_FUSED_CASE(2, 1) EV2G_FUSED_CASE(2, 2)
         EV2G_FUSED_CASE2(0) EV2G_FUSED_CASE2(1) EV2G_FUSED_CASE2(2)

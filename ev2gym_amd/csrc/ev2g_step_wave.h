@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     extern __shared__ double lds[];
     static_assert(!ACT || (IO32 && FULLK == 2 && BLOCK == EV2G_FUSED_BLOCK), "the fused actor + step instantiation");
     static_assert(AE == 1 || (ACT && SK == 1 && AE == 2), "two envs per wavefront in the fused instantiation: PublicPST only");
-    static_assert(NWF == 1 || (ACT && SK != 1 && AE == 1 && NWF == 2), "the float32 policy inside the launch: head-table states, one env per wavefront");
+    static_assert(NWF == 1 || (ACT && AE == 1 && NWF == 2), "the float32 policy inside the launch: one env per wavefront (16 policy rows per workgroup)");
     constexpr bool FULL = FULLK >= 1, WIDE = FULLK >= 2, STR = FULLK >= 3 || ACT;
 #ifdef EV2G_STR_NT_OFF   // (A/B: the kept rows as ordinary stores)
     constexpr bool STR_NT = false;
@@ -632,6 +632,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                 if (SK == 1) { stg32<float>(obs32, o4, 0.f); stg32<float>(obs32, o4 + 4u, 0.f); stg32<float>(obs32, o4 + 8u, 0.f); }
                 else stg32<f2v>(obs32, o4, (f2v){0.f, 0.f});
                 if (ACT) {
+                    if (SK == 1 && NWF > 1) { bufXf[arow * FSXF + ocol_l] = 0.f; bufXf[arow * FSXF + ocol_l + 1] = 0.f; bufXf[arow * FSXF + ocol_l + 2] = 0.f; }
+                    else
                     if (SK == 1) { bufX[arow * FSX + ocol_l] = 0; bufX[arow * FSX + ocol_l + 1] = 0; bufX[arow * FSX + ocol_l + 2] = 0; }   // (odd columns: three 16-bit words)
                     else xput2((int)ocol_l, 0.f, 0.f);
                 }
@@ -741,6 +743,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                 if (SK == 1) { stg32<float>(obs32, o4, (float)o0); stg32<float>(obs32, o4 + 4u, (float)o1); stg32<float>(obs32, o4 + 8u, (float)o2); }
                 else stg32<f2v>(obs32, o4, (f2v){(float)o0, (float)o1});
                 if (ACT) {   // the policy's copy of the same columns
+                    if (SK == 1 && NWF > 1) { bufXf[arow * FSXF + ocol_l] = (float)o0; bufXf[arow * FSXF + ocol_l + 1] = (float)o1; bufXf[arow * FSXF + ocol_l + 2] = (float)o2; }
+                    else
                     if (SK == 1) {
                         const uint32_t w01 = ev2g_pack_bf16((float)o0, (float)o1), w2 = ev2g_pack_bf16((float)o2, 0.f);
                         bufX[arow * FSX + ocol_l] = (uint16_t)w01; bufX[arow * FSX + ocol_l + 1] = (uint16_t)(w01 >> 16); bufX[arow * FSX + ocol_l + 2] = (uint16_t)w2;
@@ -956,6 +960,8 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
                     stg32<float>(obs32, o4, h0);
                     stg32<float>(obs32, o4 + 4u, h1);
                     stg32<float>(obs32, o4 + 8u, h2);
+                    if (ACT && NWF > 1) { bufXf[arow * FSXF] = h0; bufXf[arow * FSXF + 1] = h1; bufXf[arow * FSXF + 2] = h2; }
+                    else
                     if (ACT) {   // the policy's copy: columns 0, 1 as one word, column 2 on its own (column 3 belongs to port 0)
                         *(uint32_t *)(bufX + arow * FSX) = ev2g_pack_bf16(h0, h1);
                         bufX[arow * FSX + 2] = (uint16_t)ev2g_pack_bf16(h2, 0.f);

@@ -370,7 +370,7 @@ int ev2g_mlp_forward(ev2g_handle *h, const ev2g_mlp *m, const float *x, float *y
  * evaluates the policy on their 16 observation rows between the steps (same MFMA chains as ev2g_mlp_forward: bit-identical actions), so
  * neither kernel pays a cold start per step and the port state stays in LDS across the segment.  Anything else runs actor and step as two
  * launches per step, as before (train_stable_baselines.py:62-130 is the loop this replaces).
- * Round 6: PublicPST too (two envs per wavefront), and the FLOAT32 policy (EV2G_MLP_F32) for the two head-table states: the same five-product chain per
+ * Round 6: PublicPST too (two envs per wavefront), and the FLOAT32 policy (EV2G_MLP_F32; one env per wavefront for every state): the same five-product chain per
  * k-step as ev2g_mlp_forward's (bit-identical actions), input rows kept float32 in LDS and split into their three bf16 terms where they are read;
  * EV2G_NO_FUSED_F32=1 keeps that policy at two launches per step.  EV2G_MLP_F32X3 policies always run two launches per step. */
 int ev2g_rollout(ev2g_handle *h, const ev2g_mlp *m, int k_steps, double *reward, int64_t reward_step_stride, uint8_t *done,

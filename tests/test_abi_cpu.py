@@ -156,8 +156,8 @@ def test_fast_path_kernels_keep_four_wavefronts_per_simd_and_do_not_spill():
     # 3 states x (4 rewards + 3 rewards x {full, full + wide}) x {float64, float32 hand-over} + 3 states x 3 rewards x {full + wide with strided float64 outputs}
     # + 2 head-table states x 3 rewards x {the fused actor + step launch: 1024 threads, the policy between the steps}
     # (round 6) + PublicPST x 3 rewards x {the fused actor + step launch, the same with two envs per wavefront}
-    # (round 6, last session) + 2 head-table states x 3 rewards x {the fused launch with the FLOAT32 policy: two bf16 terms per weight, ring of 8 fragments}
-    assert len(wave) == 87, sorted(wave)
+    # (round 6, last session) + 3 states x 3 rewards x {the fused launch with the FLOAT32 policy: two bf16 terms per weight, one env per wavefront}
+    assert len(wave) == 90, sorted(wave)
     for k, v in wave.items():
         # (SGPRs parked in VGPR lanes are no memory traffic, and the VGPR count includes the lanes they use; the headline instantiations --
         # full + wide -- must stay nearly free of them, each is a v_readlane / v_writelane pair in the step loop)

@@ -69,7 +69,8 @@ def test_fused_actor_and_step_launch_equals_the_two_kernel_chain(state, E, C, mo
         assert np.array_equal(one[k], two[k], equal_nan=True), k
 
 
-def test_fused_rollout_through_the_hand_over_buffers_equals_the_two_kernel_chain(monkeypatch):
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_fused_rollout_through_the_hand_over_buffers_equals_the_two_kernel_chain(precision, monkeypatch):
     """The same for ev2g_rollout (float32 observation / action hand-over buffers with step stride 0, reward / done / mask per step): the fused
     launch overwrites the one observation row step after step, like the two-kernel chain does."""
     from ev2gym_amd import _abi
@@ -83,7 +84,7 @@ def test_fused_rollout_through_the_hand_over_buffers_equals_the_two_kernel_chain
             monkeypatch.delenv("EV2G_NO_FUSED", raising=False)
         eng, pool = _engine(E, E, C, 6)
         P, D, T = eng.P, eng.D, eng.T
-        mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=10), out_lo=-1.0)
+        mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=10), out_lo=-1.0, precision=precision)
         obs32, act32 = eng.empty((E, D), np.float32), eng.empty((E, P), np.float32)
         rew, done, mask = eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
         eng.set_extras(obs_f32=obs32, actions_f32=act32)
@@ -160,8 +161,9 @@ def test_device_refill_brings_car_models_the_loaded_pool_never_held(no_dict, mon
 FUSED_SWEEP = list(range(20))
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])   # (fp32: the float32 policy inside the launch, last session of round 6)
 @pytest.mark.parametrize("case", FUSED_SWEEP)
-def test_fused_launch_randomised_shapes_equal_the_two_kernel_chain(case, monkeypatch):
+def test_fused_launch_randomised_shapes_equal_the_two_kernel_chain(case, precision, monkeypatch):
     """A seeded sweep over what the fused actor + step launch is eligible for -- 3..64 ports (narrow envs: one wavefront each all the same), both head-table states, the three compiled-in
     rewards, ragged env counts, random segment lengths, both action ranges -- against the two-launch chain, bit for bit (rows, statistics)."""
     from ev2gym_amd import _abi
@@ -187,7 +189,7 @@ def test_fused_launch_randomised_shapes_equal_the_two_kernel_chain(case, monkeyp
             monkeypatch.setenv("EV2G_NO_FUSED", "1")
         eng = Engine(pool, _abi.REWARD_KINDS[reward], _abi.STATE_KINDS[state], flags=_abi.FLAG_LOG_SOC, n_active_envs=E)
         P, D = eng.P, eng.D
-        mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=case), out_lo=lo)
+        mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=case), out_lo=lo, precision=precision)
         obs, act = eng.empty((T + 1, E, D), np.float32), eng.empty((T, E, P), np.float32)
         rew, done, mask = eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
         eng.reset_f32(obs, off)

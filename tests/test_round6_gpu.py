@@ -348,13 +348,14 @@ def test_page_locked_host_buffers_round_trip():
 
 @pytest.mark.parametrize("state,E,C,reward", [("V2G_profit_max_loads", 37, 50, "ProfitMax_TrPenalty_UserIncentives"), ("V2G_profit_max_loads", 16, 64, "SquaredTrackingErrorReward"),
                                               ("V2G_profit_max", 21, 40, "profit_maximization"), ("V2G_profit_max_loads", 19, 25, "ProfitMax_TrPenalty_UserIncentives"),
-                                              ("V2G_profit_max_loads", 33, 7, "profit_maximization"), ("V2G_profit_max", 5, 22, "SquaredTrackingErrorReward")])
+                                              ("V2G_profit_max_loads", 33, 7, "profit_maximization"), ("V2G_profit_max", 5, 22, "SquaredTrackingErrorReward"),
+                                              ("PublicPST", 37, 20, "SquaredTrackingErrorReward"), ("PublicPST", 16, 11, "ProfitMax_TrPenalty_UserIncentives"), ("PublicPST", 50, 3, "profit_maximization")])
 def test_fused_launch_with_the_float32_policy_equals_the_two_kernel_chain(state, E, C, reward, monkeypatch):
     """VERDICT round 5, item 4 (float32 half): the FLOAT32 policy (EV2G_MLP_F32: two bf16 terms per weight, three per activation, five MFMA products per
     k-step -- what an SB3 float32 actor computes to 1e-5) evaluated INSIDE the step kernel's launch (ev2g_step_wave<.., ACT, 1, 2> + ev2g_mlp3_inline_f32)
     against the chain of two launches per step (EV2G_NO_FUSED=1: ev2g_mlp3_s16<.., NW = 2> then a single-step launch): every observation / action /
     reward / done / mask row of a whole episode collected in segments of mixed length, the statistics and the next episode's reset observation, bit for bit
-    (same tiles, same term split, same MFMA chain per tile).  Ragged batches, narrow and full-width envs, both head-table states, the three rewards."""
+    (same tiles, same term split, same MFMA chain per tile).  Ragged batches, narrow and full-width envs, the three fused states, the three rewards."""
     from ev2gym_amd import _abi
     from ev2gym_amd.actor import init_mlp_weights
     from ev2gym_amd.engine import Engine
@@ -365,10 +366,11 @@ def test_fused_launch_with_the_float32_policy_equals_the_two_kernel_chain(state,
             monkeypatch.delenv("EV2G_NO_FUSED", raising=False)
         else:
             monkeypatch.setenv("EV2G_NO_FUSED", "1")
-        pool = generate_native(GenConfig.v2g_profit_plus_loads(2 * E, C, 1, seed=5))
+        pst = state == "PublicPST"   # (one env per wavefront with this policy: 16 rows per workgroup)
+        pool = generate_native(GenConfig.public_pst(2 * E, C, seed=5) if pst else GenConfig.v2g_profit_plus_loads(2 * E, C, 1, seed=5))
         eng = Engine(pool, _abi.REWARD_KINDS[reward], _abi.STATE_KINDS[state], flags=_abi.FLAG_LOG_SOC, n_active_envs=E)
         P, D, T = eng.P, eng.D, eng.T
-        mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=9), out_lo=-1.0, precision="fp32")
+        mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=9), out_lo=0.0 if pst else -1.0, precision="fp32")
         obs, act = eng.empty((T + 1, E, D), np.float32), eng.empty((T, E, P), np.float32)
         rew, done, mask = eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
         nxt = eng.empty((E, D), np.float32)
