@@ -1304,7 +1304,7 @@ int ev2g_mlp_create_ex(ev2g_handle *h, int d_in, int h1, int h2, int d_out, cons
     { unsigned long long *p; if (dalloc(h, m->allocs, 16, &p)) { delete m; return EV2G_ERR_HIP; } d.dbg = p; }
 #endif
 #ifdef EV2G_F32_STAMPS
-    { unsigned long long *p; if (dalloc(h, m->allocs, 8 * 16 * 8, &p)) { delete m; return EV2G_ERR_HIP; } d.dbg = p; }
+    { unsigned long long *p; if (dalloc(h, m->allocs, 8 * 16 * 8 + 8 * 16 * 16, &p)) { delete m; return EV2G_ERR_HIP; } d.dbg = p; }
 #endif
     if (precision != EV2G_MLP_BF16 && precision != EV2G_MLP_F32 && precision != EV2G_MLP_F32X3) { delete m; return fail(h, EV2G_ERR_ARG, "ev2g_mlp_create_ex: precision must be EV2G_MLP_BF16, EV2G_MLP_F32 or EV2G_MLP_F32X3"); }
     const bool f32 = precision != EV2G_MLP_BF16;
@@ -1382,7 +1382,7 @@ int ev2g_mlp_forward(ev2g_handle *h, const ev2g_mlp *m, const float *x, float *y
 #ifdef EV2G_F32_STAMPS
 extern "C" int ev2g_mlp_debug_f32_stamps(ev2g_handle *h, const ev2g_mlp *m, unsigned long long *out1024) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out1024, m->dev.dbg, 8 * 16 * 8 * 8, hipMemcpyDeviceToHost));   // [workgroup 0..7][wavefront][stamp 0..7]
+    HIPCHK(h, hipMemcpy(out1024, m->dev.dbg, (8 * 16 * 8 + 8 * 16 * 16) * 8, hipMemcpyDeviceToHost));   // [workgroup 0..7][wavefront][stamp 0..7], then [workgroup][wavefront][16]: layer 3's k-steps
     return 0;
 }
 #endif

@@ -48,8 +48,10 @@ struct MlpDev {
 // tuning builds (-DEV2G_F32_STAMPS, tools/r6/f32_stamps.py): every wavefront of the first 8 workgroups stamps the layers of the inline float32 policy (the last forward's stay)
 #ifdef EV2G_F32_STAMPS
 #define F32_STAMP(i) if (m.dbg && blockIdx.x < 8 && (threadIdx.x & 63) == 0) m.dbg[((blockIdx.x * 16 + (threadIdx.x >> 6)) * 8) + i] = __builtin_readcyclecounter();
+#define F32_STAMP2(i) if (m.dbg && blockIdx.x < 8 && (threadIdx.x & 63) == 0) m.dbg[1024 + ((blockIdx.x * 16 + (threadIdx.x >> 6)) * 16) + (i)] = __builtin_readcyclecounter();
 #else
 #define F32_STAMP(i)
+#define F32_STAMP2(i)
 #endif
 
 __host__ __device__ inline int ev2g_mlp_lds_stride(int k) { return k + 8; }   // bf16 elements per LDS row: +16 bytes against bank conflicts
@@ -79,6 +81,30 @@ __device__ __forceinline__ uint32_t ev2g_pack_bf16(float a, float b) {
 __device__ __forceinline__ float ev2g_fast_tanh(float x) {
     const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);   // exp(2x) = 2^(2x / ln 2)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// tanh of the float32 policies' output layer (EV2G_MLP_F32 / F32X3 in ev2g_mlp3_s16 and the fused launch's ev2g_mlp3_inline_f32: one function, so their actions stay
+// bit-identical): t = exp(-2|x|) on the hardware exp2 (1 ulp), then (1 - t) / (1 + t) by an IEEE division -- absolute error below 1.5e-7 everywhere (near 0 the
+// difference 1 - t carries t's rounding, 6e-8; beyond |x| = 9 the result is exactly 1).  The library tanhf it replaces cost the fused launch ~1.3 k cycles per
+// step on the critical path of layer 3's four wavefronts (profiles/r06_fused_float32_policy.txt); EV2G_F32_TANH=0 builds keep it.
+// the inline float32 policy's input rows: 1 = every wavefront splits ITS OWN row into the three bf16 terms at the policy's entry (22 VALU operations), into staging chunks
+// that are dead in layer 1; 0 = every wavefront splits the operand fragments it reads (6 x 44 operations per wavefront and forward: layer 1 was VALU-issue-bound, 9.5 k cycles)
+#ifndef EV2G_F32_XSPLIT
+#define EV2G_F32_XSPLIT 1
+#endif
+#ifndef EV2G_F32_L1AHEAD   // layer 1 (two tiles' accumulators per wavefront): the next k-step's operand terms read ahead of the MFMA group (12 registers)
+#define EV2G_F32_L1AHEAD 0
+#endif
+#ifndef EV2G_F32_TANH
+#define EV2G_F32_TANH 1
+#endif
+__device__ __forceinline__ float ev2g_tanh_f32(float x) {
+#if EV2G_F32_TANH
+    const float t = __builtin_amdgcn_exp2f(fabsf(x) * -2.885390081777927f);   // exp(-2|x|)
+    return copysignf((1.0f - t) / (1.0f + t), x);
+#else
+    return tanhf(x);
+#endif
 }
 
 // Epilogue of one 32 x 32 output tile held in MFMA accumulators: bias, activation, and either the next layer's A matrix
@@ -554,7 +580,7 @@ __global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *
                 } else {
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { v[r] = NW == 1 ? ev2g_fast_tanh(acc[r]) : tanhf(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
+                    for (int r = 0; r < 4; r++) { v[r] = NW == 1 ? ev2g_fast_tanh(acc[r]) : ev2g_tanh_f32(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
                     const int d_out = m.d_out;
                     if (erow < nr) {
                         float *yr = y + (size_t)(row0 + erow) * d_out + col;
@@ -711,14 +737,21 @@ __device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t
 //     are re-zeroed at the end (the step rewrites every real column before the next forward);
 //   * the biases are read from global memory (L1 / L2 hits, requested a layer ahead), not staged.
 template <int KS1, int NT1, int NT2, int NT3, int WVS, int RING>
-__device__ __forceinline__ void ev2g_mlp3_inline_f32(const MlpDev &m, float *bufX, int sxf, uint16_t *h1, uint16_t *h2ab, uint16_t *h2c, float *act, int as, float *y, int nr, int tid) {
+__device__ __forceinline__ void ev2g_mlp3_inline_f32(const MlpDev &m, float *bufX, int sxf, uint16_t *h1, uint16_t *h2ab, uint16_t *h2c, uint16_t *xs, int xcs, float *act, int as, float *y, int nr, int tid) {
     constexpr int NW = 2, NX = 3;
     typedef MlpS16<KS1, NT1, NT2, NT3, 1, 4, 1> C;
     constexpr int KS2 = C::KS2, KS3 = C::KS3;
     constexpr int MT1 = (NT1 + WVS - 1) / WVS, MT2 = (NT2 + WVS - 1) / WVS, MT3 = (NT3 + WVS - 1) / WVS;
-    constexpr int S1 = MT1 * KS1 * NW, S2 = MT2 * KS2 * NW, S3 = MT3 * KS3 * NW, STOT = S1 + S2 + S3;
+    // Layer 3 (NT3 tiles: one wavefront each, the other wavefronts idle) through a ring of ITS OWN: with the shared ring's few slots a lone wavefront pays a
+    // memory round trip per two k-steps (stamps: 330 cycles per k-step at RING = 4); the registers of layers 1 / 2 (a second tile's accumulators, the split
+    // temporaries) are free there.  R3 fragments are requested when the wavefront leaves layer 2 -- they fly under the wait at that layer's closing barrier.
+#ifndef EV2G_F32_RING3
+#define EV2G_F32_RING3 8
+#endif
+    constexpr int R3 = (MT3 == 1) ? EV2G_F32_RING3 : 0, R3M = R3 > 0 ? R3 : 1;
+    constexpr int S1 = MT1 * KS1 * NW, S2 = MT2 * KS2 * NW, S3 = R3 > 0 ? 0 : MT3 * KS3 * NW, STOT = S1 + S2 + S3;
     constexpr int BH1 = 16 * C::SH1, BH2 = 16 * C::SH2;
-    static_assert(RING % NW == 0 && RING >= 2 * NW, "ring slots come in pairs of weight terms");
+    static_assert(RING % NW == 0 && RING >= 2 * NW && R3 % NW == 0, "ring slots come in pairs of weight terms");
     // (A/B switch: layer 3's few tiles on wavefronts W3OFF .. W3OFF + NT3 - 1.  Wavefronts 4..7 reach layer 2's closing barrier ~3 k cycles before the two-tile ones
     // (0 .. 2), so their ring is full of layer-3 fragments by then -- and layer 3 takes the same 3.5 k cycles: it waits for its own LDS-read -> MFMA chain per k-step,
     // not for weights; profiles/r06_fused_float32_policy.txt.  Default 0.)
@@ -744,12 +777,37 @@ __device__ __forceinline__ void ev2g_mlp3_inline_f32(const MlpDev &m, float *buf
         if (WVS * i + WVS - 1 < NT || wave + WVS * i < NT) ring[seq % RING] = w[(unsigned)(((wave + WVS * i) * (KS * NW) + rem) * 64)];
     };
     F32_STAMP(0)
+    uint4 ring3[R3M];
+    const int tile3 = wave - W3OFF;   // this wavefront's layer-3 tile, if 0 <= tile3 < NT3
+    auto request3 = [&](int r) __attribute__((always_inline)) {   // fragment r = ks * NW + term of that tile (callers: wavefronts that own one)
+        if (R3 > 0 && r < KS3 * NW) ring3[r % R3M] = w3[(unsigned)((tile3 * (KS3 * NW) + r) * 64)];
+    };
     const int brow = lane & 15, kq = lane >> 4;
     f32x4m bias1[MT1];
 #pragma unroll
     for (int i = 0; i < MT1; i++) bias1[i] = *(const f32x4m *)(ball + min(wave + WVS * i, NT1 - 1) * 16 + kq * 4);
 #pragma unroll
     for (int sq = 0; sq < RING; sq++) request(sq);
+#if EV2G_F32_XSPLIT
+    // This wavefront's OWN input row (its env's observation: its own LDS writes, in program order) -> the three bf16 terms, into its own 512-byte chunks of three
+    // staging rows (xs + c * xcs + wave * 256 elements; chunks no other wavefront touches outside the battery-maths phase, and dead in layer 1: H2's first two
+    // copies land there in layer 2).  The 24 16-byte pieces of a row sit at piece (j ^ row): the rows are 512 bytes apart -- all on the same banks -- and a
+    // ds_read_b128 lane group holds the rows {0..3, 12..15} at one k-quarter and {4..11} at the next, whose piece numbers differ in bit 0 only: no conflicts.
+    {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int c = h == 0 ? 2 * lane : 128 + 2 * lane;   // columns 0..127, then 128..191 (lanes 0..31)
+            if (c < KS1 * 32) {
+                const float2 v = *(const float2 *)(bufX + wave * sxf + c);
+                uint32_t wd[NX];
+                ev2g_split_bf16<NX>(v.x, v.y, wd);
+                const int at = wave * 256 + (((c >> 3) ^ wave) << 3) + (c & 7);
+#pragma unroll
+                for (int k = 0; k < NX; k++) *(uint32_t *)(xs + k * xcs + at) = wd[k];
+            }
+        }
+    }
+#endif
     ev2g_mlp_lds_barrier();   // the step's observation columns are in bufX; nobody reads the staging rows any more
     F32_STAMP(1)
     if (tid < 256) {   // H1's columns no tile writes (layer 2's last k-step reads them): zeros, in every copy
@@ -761,11 +819,11 @@ __device__ __forceinline__ void ev2g_mlp3_inline_f32(const MlpDev &m, float *buf
         }
     }
     // the MFMA chain of one (tile, k-step): the small terms first, accumulator by the parity of k-step + terms (ev2g_mlp3_s16)
-    auto chain = [&](int ks, int sq0, const uint4 (&bt)[NX], f32x4m &acc0, f32x4m &acc1) __attribute__((always_inline)) {
+    auto chain = [&](int ks, const uint4 &w_t0, const uint4 &w_t1, const uint4 (&bt)[NX], f32x4m &acc0, f32x4m &acc1) __attribute__((always_inline)) {
         typedef unsigned u32x4m __attribute__((ext_vector_type(4)));
         u32x4m av[NW], bv[NX];
-#pragma unroll
-        for (int p = 0; p < NW; p++) __builtin_memcpy(&av[p], &ring[(sq0 + p) % RING], 16);
+        __builtin_memcpy(&av[0], &w_t0, 16);
+        __builtin_memcpy(&av[1], &w_t1, 16);
 #pragma unroll
         for (int k = 0; k < NX; k++) __builtin_memcpy(&bv[k], &bt[k], 16);
 #if EV2G_F32_GROUP
@@ -808,18 +866,35 @@ __device__ __forceinline__ void ev2g_mlp3_inline_f32(const MlpDev &m, float *buf
         f32x4m acc0[MT1], acc1[MT1];
 #pragma unroll
         for (int i = 0; i < MT1; i++) { acc0[i] = bias1[i]; acc1[i] = f32x4m{0.f, 0.f, 0.f, 0.f}; }
+#if EV2G_F32_XSPLIT && EV2G_F32_L1AHEAD
+        uint4 btn[NX];
+#pragma unroll
+        for (int k = 0; k < NX; k++) btn[k] = *(const uint4 *)(xs + k * xcs + brow * 256 + ((kq ^ brow) << 3));
+#endif
 #pragma unroll
         for (int ks = 0; ks < KS1; ks++) {
+            uint4 bt[NX];
+#if EV2G_F32_XSPLIT && EV2G_F32_L1AHEAD
+#pragma unroll
+            for (int k = 0; k < NX; k++) bt[k] = btn[k];
+            if (ks + 1 < KS1) {
+#pragma unroll
+                for (int k = 0; k < NX; k++) btn[k] = *(const uint4 *)(xs + k * xcs + brow * 256 + ((((ks + 1) * 4 + kq) ^ brow) << 3));
+            }
+#elif EV2G_F32_XSPLIT
+#pragma unroll
+            for (int k = 0; k < NX; k++) bt[k] = *(const uint4 *)(xs + k * xcs + brow * 256 + (((ks * 4 + kq) ^ brow) << 3));
+#else
             const float4 xa = *(const float4 *)(bufX + brow * sxf + ks * 32 + kq * 8), xb = *(const float4 *)(bufX + brow * sxf + ks * 32 + kq * 8 + 4);
             uint32_t t0[NX], t1[NX], t2[NX], t3[NX];
             ev2g_split_bf16<NX>(xa.x, xa.y, t0); ev2g_split_bf16<NX>(xa.z, xa.w, t1); ev2g_split_bf16<NX>(xb.x, xb.y, t2); ev2g_split_bf16<NX>(xb.z, xb.w, t3);
-            uint4 bt[NX];
 #pragma unroll
             for (int k = 0; k < NX; k++) bt[k] = make_uint4(t0[k], t1[k], t2[k], t3[k]);
+#endif
 #pragma unroll
             for (int i = 0; i < MT1; i++) {
                 const int sq0 = (ks * MT1 + i) * NW;
-                if (WVS * i + WVS - 1 < NT1 || wave + WVS * i < NT1) chain(ks, sq0, bt, acc0[i], acc1[i]);   // (uniform; a constant but for the last slot)
+                if (WVS * i + WVS - 1 < NT1 || wave + WVS * i < NT1) chain(ks, ring[sq0 % RING], ring[(sq0 + 1) % RING], bt, acc0[i], acc1[i]);   // (uniform; a constant but for the last slot)
 #pragma unroll
                 for (int p = 0; p < NW; p++) request(sq0 + p + RING);
             }
@@ -868,17 +943,25 @@ __device__ __forceinline__ void ev2g_mlp3_inline_f32(const MlpDev &m, float *buf
                     bt[1] = *(const uint4 *)(a1 + brow * sa + ks * 32 + kq * 8);
                     bt[2] = *(const uint4 *)(a2 + brow * sa + ks * 32 + kq * 8);
 #endif
-                    chain(ks, sq0, bt, acc0, acc1);
+                    if (L == 2 && R3 > 0) {
+                        chain(ks, ring3[(ks * NW) % R3M], ring3[(ks * NW + 1) % R3M], bt, acc0, acc1);
+#pragma unroll
+                        for (int p = 0; p < NW; p++) request3(ks * NW + p + R3);
+                    } else {
+                    chain(ks, ring[sq0 % RING], ring[(sq0 + 1) % RING], bt, acc0, acc1);
 #pragma unroll
                     for (int p = 0; p < NW; p++) request(sq0 + p + RING);
+                    }
+                    if (L == 2) { F32_STAMP2(ks) }
                 }
+                if (L == 2) { F32_STAMP2(15) }
                 const f32x4m acc = acc0 + acc1;
                 const int col = tile * 16 + kq * 4;
                 if (L == 1) hidden_out(acc, h2ab, h2ab + BH2, h2c, C::SH2, col);
                 else {
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { v[r] = tanhf(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
+                    for (int r = 0; r < 4; r++) { v[r] = ev2g_tanh_f32(acc[r]); if (m.out_lo == 0.0f) v[r] = v[r] * 0.5f + 0.5f; }
                     *(float4 *)(act + brow * as + col) = make_float4(v[0], v[1], v[2], v[3]);   // (NT3 <= 4: columns 0..63)
                     const int d_out = m.d_out;
                     if (brow < nr) {
@@ -902,6 +985,10 @@ __device__ __forceinline__ void ev2g_mlp3_inline_f32(const MlpDev &m, float *buf
 #pragma unroll
     for (int i = 0; i < MT3; i++) bias3[i] = *(const f32x4m *)(ball + (NT1 + NT2) * 16 + min(max(wave - W3OFF, 0) + WVS * i, NT3 - 1) * 16 + kq * 4);
     layer(std::integral_constant<int, 1>{}, h1, h1 + BH1, h1 + 2 * BH1, C::SH1, bias2);
+    if (R3 > 0 && (unsigned)tile3 < (unsigned)NT3) {   // (uniform)
+#pragma unroll
+        for (int r = 0; r < R3; r++) request3(r);
+    }
     F32_STAMP(4)
     ev2g_mlp_lds_barrier();
     F32_STAMP(5)

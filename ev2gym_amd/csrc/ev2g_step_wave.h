@@ -233,6 +233,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
     // NWF = 2: float32 input rows in bufX's place (no staged biases); H1's three copies, then two of H2's in the staging rows, H2's third over the input rows
     constexpr int FSXF = EV2G_FUSED_SXF;
     float *bufXf = (float *)(cnt + 8);
+    static_assert(NWF == 1 || (3 * 16 * MC::SH1 * 2 <= 5 * RS * 8 && EV2G_NQ == 8 && FKS1 * 32 <= 256), "the input rows' bf16 terms live in staging rows 5..7, behind H1's three copies");
     static_assert(NWF == 1 || (FKS1 * 32 + 4 <= FSXF && (3 * MC::SH1 + 2 * MC::SH2) * 16 * 2 <= EV2G_NQ * (EV2G_FUSED_BLOCK + 8) * 8 && MC::SH2 * 16 * 2 <= 16 * FSXF * 4), "float32 policy buffers");
     static_assert(AE * MC::SX <= EV2G_FUSED_SX && MC::NB <= (25 + 19 + 4) * 16 && 16 * AE * (MC::SH1 + MC::SH2) * 2 <= EV2G_NQ * (EV2G_FUSED_BLOCK + 8) * 8, "policy buffers");
     constexpr int ACT_AS = (AE == 1) ? 128 : 64;   // floats between two envs' action rows in s_amps (a wavefront's slice holds its envs' rows)
@@ -425,7 +426,7 @@ __global__ void __launch_bounds__(BLOCK, 4) ev2g_step_wave(const V2P *__restrict
         if (ACT) {
             // ---- the policy, on the 16 observation rows of this workgroup's envs (ev2g_mlp3_inline, ev2g_mlp.h) ----
             if (NWF > 1)
-                ev2g_mlp3_inline_f32<FKS1, 25, 19, FNT3, BLOCK / 64, EV2G_FUSED_RINGF>(fa.m, bufXf, FSXF, bufH1, bufH1 + 3 * 16 * MC::SH1, (uint16_t *)bufXf, act_lds, ACT_AS, act_out, min(16, E - e0), tid_l);
+                ev2g_mlp3_inline_f32<FKS1, 25, 19, FNT3, BLOCK / 64, EV2G_FUSED_RINGF>(fa.m, bufXf, FSXF, bufH1, bufH1 + 3 * 16 * MC::SH1, (uint16_t *)bufXf, (uint16_t *)(stage + 5 * RS), RS * 4, act_lds, ACT_AS, act_out, min(16, E - e0), tid_l);
             else
             ev2g_mlp3_inline<FKS1, 25, 19, FNT3, BLOCK / 64, (AE == 1 ? EV2G_FUSED_RING : EV2G_FUSED_RING2), AE>(fa.m, bufX, bufH1, bufH2, lbias, act_lds, ACT_AS, act_out, min(16 * AE, E - e0), tid_l);   // (starts and ends with a barrier: the actions are in LDS)
             act_out += io.a_stride;

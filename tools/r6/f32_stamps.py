@@ -23,10 +23,11 @@ for rep in range(2):
     eng.collect(mlp, T, obs, act, rew, done, mask)
     eng.synchronize()
     ms = eng.last_step_n_kernel_ms()
-    out = (C.c_ulonglong * 1024)()
+    out = (C.c_ulonglong * 3072)()
     eng._lib.ev2g_mlp_debug_f32_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     eng._lib.ev2g_mlp_debug_f32_stamps(eng._h, mlp, out)
-    v = np.array(list(out), np.int64).reshape(8, 16, 8)
+    v2 = np.array(list(out)[1024:], np.int64).reshape(8, 16, 16)
+    v = np.array(list(out)[:1024], np.int64).reshape(8, 16, 8)
 print(f"fused float32 policy, cfg2, one launch of {T} steps, spec {eng.last_launch_specialisation}: {ms*1e3/T:.2f} us/step")
 d = np.diff(v, axis=2)   # [wg][wave][7]
 print("mean over 8 workgroups, cycles (s_memtime at 100 MHz? -> printed raw):")
@@ -34,3 +35,8 @@ print("wave " + " ".join(f"{n:>17s}" for n in names) + "   total")
 for w in range(16):
     print(f"{w:4d} " + " ".join(f"{d[:, w, i].mean():17.0f}" for i in range(7)) + f"   {(v[:, w, 7] - v[:, w, 0]).mean():.0f}")
 print("span (first entry -> last exit) per workgroup:", [int(v[g, :, 7].max() - v[g, :, 0].min()) for g in range(8)])
+print("layer 3, wavefronts that own a tile: cycles from the layer's start (stamp 5) to the end of each k-step, then to the epilogue's start; workgroup 0..3")
+for g in range(4):
+    for w in range(16):
+        if v2[g, w, 0] > v[g, w, 5]:
+            print(f"  wg {g} wave {w:2d}: " + " ".join(f"{int(v2[g, w, i] - v[g, w, 5]):5d}" for i in list(range(10)) + [15]) + f"   layer end {int(v[g, w, 6] - v[g, w, 5])}")
