@@ -647,11 +647,13 @@ __device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t
     // (requesting the head of the sequence a phase EARLIER in the step kernel -- behind phase E, D or C of the step before -- was tried: the whole ring
     // then lives across the step loop's back edge and the register allocator spills 40..119 registers; only layer 1's first tile (6 fragments)
     // requested early fits -- and measured 1-2 % SLOWER than this, docs/history/experiments/round5/gpu_r5e.sh: the head's latency is not what the policy phase waits for)
+    F32_STAMP(0)
 #pragma unroll
     for (int sq = 0; sq < RING; sq++) request(sq);
     // first barrier: every wavefront's observation columns of the step before (or the prologue's rows) are in bufX, and nobody still reads the
     // staging rows the hidden activations are about to use
     ev2g_mlp_lds_barrier();
+    F32_STAMP(1)
     if (tid < 256 * RB) {   // columns no tile writes (the next layer's k-steps read them): zeros
         const int pj = tid & 15, pr = tid >> 4;
         constexpr int P1 = KS2 * 32 - NT1 * 16, P2 = KS3 * 32 - NT2 * 16;
@@ -718,11 +720,17 @@ __device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t
         }
     };
     layer(std::integral_constant<int, 0>{}, bufX, C::SX, lb, bufH1, C::SH1);
+    F32_STAMP(2)
     ev2g_mlp_lds_barrier();
+    F32_STAMP(3)
     layer(std::integral_constant<int, 1>{}, bufH1, C::SH1, lb + NT1 * 16, bufH2, C::SH2);
+    F32_STAMP(4)
     ev2g_mlp_lds_barrier();
+    F32_STAMP(5)
     layer(std::integral_constant<int, 2>{}, bufH2, C::SH2, lb + (NT1 + NT2) * 16, nullptr, 0);
+    F32_STAMP(6)
     ev2g_mlp_lds_barrier();
+    F32_STAMP(7)
 }
 
 // ---- the FLOAT32 network (EV2G_MLP_F32: two bf16 terms per weight, three per activation, five MFMA products per k-step) as a device function of the

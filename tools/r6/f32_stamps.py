@@ -14,7 +14,8 @@ E = wl["envs"]
 batch = generate_native(wl["gen"](E, 0)).sorted_by_busy_window(E)
 eng = engine.Engine(batch, _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]], flags=_abi.FLAG_LOG_SOC)
 P, D, T = eng.P, eng.D, eng.T
-mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=1), out_lo=wl["lo"], precision="fp32")
+PREC = os.environ.get("STAMP_PRECISION", "fp32")   # (bf16: the same stamps in ev2g_mlp3_inline)
+mlp = eng.mlp_create(*init_mlp_weights(D, P, seed=1), out_lo=wl["lo"], precision=PREC)
 obs, act = eng.empty((T + 1, E, D), np.float32), eng.empty((T, E, P), np.float32)
 rew, done, mask = eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
 names = ["entry->barrier 1", "layer 1", "wait barrier 2", "layer 2", "wait barrier 3", "layer 3", "wait barrier 4"]
@@ -28,7 +29,7 @@ for rep in range(2):
     eng._lib.ev2g_mlp_debug_f32_stamps(eng._h, mlp, out)
     v2 = np.array(list(out)[1024:], np.int64).reshape(8, 16, 16)
     v = np.array(list(out)[:1024], np.int64).reshape(8, 16, 8)
-print(f"fused float32 policy, cfg2, one launch of {T} steps, spec {eng.last_launch_specialisation}: {ms*1e3/T:.2f} us/step")
+print(f"fused {PREC} policy, cfg2, one launch of {T} steps, spec {eng.last_launch_specialisation}: {ms*1e3/T:.2f} us/step")
 d = np.diff(v, axis=2)   # [wg][wave][7]
 print("mean over 8 workgroups, cycles (s_memtime at 100 MHz? -> printed raw):")
 print("wave " + " ".join(f"{n:>17s}" for n in names) + "   total")
@@ -38,5 +39,5 @@ print("span (first entry -> last exit) per workgroup:", [int(v[g, :, 7].max() - 
 print("layer 3, wavefronts that own a tile: cycles from the layer's start (stamp 5) to the end of each k-step, then to the epilogue's start; workgroup 0..3")
 for g in range(4):
     for w in range(16):
-        if v2[g, w, 0] > v[g, w, 5]:
+        if PREC != "bf16" and v2[g, w, 0] > v[g, w, 5]:
             print(f"  wg {g} wave {w:2d}: " + " ".join(f"{int(v2[g, w, i] - v[g, w, 5]):5d}" for i in list(range(10)) + [15]) + f"   layer end {int(v[g, w, 6] - v[g, w, 5])}")
