@@ -12,12 +12,16 @@ timeout 400 python bench.py --workload cfg4 > $O/r06_bench_cfg4.json 2> $O/bench
 timeout 300 python bench.py --actor mlp --no-cpu-baseline > $O/r06_bench_cfg2_actor_mlp.json 2> $O/bench_actor.err; echo "actor rc=$?"
 timeout 300 python bench.py --workload cfg3 --actor mlp --no-cpu-baseline > $O/r06_bench_cfg3_actor_mlp.json 2> $O/bench_actor3.err; echo "actor cfg3 rc=$?"
 timeout 300 python bench.py --actor mlp_fp32 --no-cpu-baseline > $O/r06_bench_cfg2_actor_mlp_fp32.json 2> $O/bench_actor32.err; echo "actor32 rc=$?"
+timeout 300 python bench.py --workload cfg3 --actor mlp_fp32 --no-cpu-baseline > $O/r06_bench_cfg3_actor_mlp_fp32.json 2> $O/bench_actor32_3.err; echo "actor32 cfg3 rc=$?"
+EV2G_NO_FUSED_F32=1 timeout 300 python bench.py --actor mlp_fp32 --no-cpu-baseline --no-other-workloads > $O/r06_bench_cfg2_actor_mlp_fp32_two_launches.json 2> $O/bench_actor32_nf.err; echo "actor32 unfused rc=$?"
 EV2G_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --no-cpu-baseline --no-other-workloads > $O/r06_bench_cfg2_torchrun_world1_forced_dist.json 2> $O/bench_dist.err; echo "dist rc=$?"
 for spec in "cfg2_persistent --workload cfg2 --launch persistent" "cfg2_per_step --workload cfg2 --launch per_step" "cfg3_persistent --workload cfg3 --launch persistent" "cfg4_persistent --workload cfg4 --launch persistent"; do
   set -- $spec; tag=$1; shift
   PASS_TIMEOUT=240 bash tools/prof_step.sh $tag "$@" > $O/r06_${tag}_rocprofv3.txt 2>&1; tail -8 $O/r06_${tag}_rocprofv3.txt
   mkdir -p $O/summaries; cp gpurun_out/prof_$tag/summary.json $O/summaries/r06_$tag.json
 done
+PASSES=kt PASS_TIMEOUT=240 bash tools/prof_step.sh cfg2_actor_fp32 --workload cfg2 --actor mlp_fp32 > $O/r06_cfg2_actor_fp32_rocprofv3.txt 2>&1; tail -6 $O/r06_cfg2_actor_fp32_rocprofv3.txt
+PASSES=kt PASS_TIMEOUT=240 bash tools/prof_step.sh cfg2_actor_bf16 --workload cfg2 --actor mlp > $O/r06_cfg2_actor_bf16_rocprofv3.txt 2>&1; tail -6 $O/r06_cfg2_actor_bf16_rocprofv3.txt
 python tools/collect_evidence.py $O/r06_hbm_traffic.json cfg2_persistent=cfg2:persistent cfg2_per_step=cfg2:per_step cfg3_persistent=cfg3:persistent cfg4_persistent=cfg4:persistent > /dev/null
 rm -rf gpurun_out/prof_*   # raw rocprofv3 output: too large to travel back (the summaries above carry what is committed)
 timeout 200 python tools/refill_time.py cfg2 2>&1 | tail -1 > $O/r06_refill_time.txt; timeout 200 python tools/refill_time.py cfg3 2>&1 | tail -1 >> $O/r06_refill_time.txt; cut -c1-160 $O/r06_refill_time.txt
