@@ -45,6 +45,12 @@ struct MlpDev {
 #ifndef EV2G_F32_GROUP
 #define EV2G_F32_GROUP 2
 #endif
+// the bf16 inline policy (ev2g_mlp3_inline), layers in which a wavefront may hold two tiles: bit 0 = layer 1, bit 1 = layer 2 walk k-step, tile slot (one operand read, two
+// independent MFMAs per k-step).  Measured at cfg2 (profiles/r06_fused_bf16_kstep_outer.txt): 0: 502 M, 1: 505 M, 2: 509 M, 3: 502 M env-steps/s -- the policy phase is bound
+// by the weight stream (437 KB per workgroup and forward at ~51 B/clk/CU): what one layer gains the other gives back (stamps); layer 2 alone keeps +1.3 %.
+#ifndef EV2G_BF16_KSOUTER
+#define EV2G_BF16_KSOUTER 2
+#endif
 // tuning builds (-DEV2G_F32_STAMPS, tools/r6/f32_stamps.py): every wavefront of the first 8 workgroups stamps the layers of the inline float32 policy (the last forward's stay)
 #ifdef EV2G_F32_STAMPS
 #define F32_STAMP(i) if (m.dbg && blockIdx.x < 8 && (threadIdx.x & 63) == 0) m.dbg[((blockIdx.x * 16 + (threadIdx.x >> 6)) * 8) + i] = __builtin_readcyclecounter();
@@ -640,7 +646,9 @@ __device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t
         const int L = seq < S1 ? 0 : (seq < S1 + S2 ? 1 : 2);
         const int r = seq - (L == 0 ? 0 : (L == 1 ? S1 : S1 + S2));
         const int KS = L == 0 ? KS1 : (L == 1 ? KS2 : KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3);
-        const int i = r / KS, ks = r - i * KS;
+        const int MTL = L == 0 ? MT1 : (L == 1 ? MT2 : MT3);
+        const bool kso = RB == 1 && MTL == 2 && ((L == 0 && (EV2G_BF16_KSOUTER & 1)) || (L == 1 && (EV2G_BF16_KSOUTER & 2)));   // k-step, tile slot (below)
+        const int i = kso ? r % MTL : r / KS, ks = kso ? r / MTL : r - i * KS;
         const uint4 *w = L == 0 ? w1 : (L == 1 ? w2 : w3);
         if (WVS * i + WVS - 1 < NT || wave + WVS * i < NT) ring[seq % RING] = w[(unsigned)(((wave + WVS * i) * KS + ks) * 64)];
     };
@@ -665,6 +673,40 @@ __device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t
         constexpr int L = decltype(Lc)::value;
         constexpr int KS = L == 0 ? KS1 : (L == 1 ? KS2 : KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3), MT = (NT + WVS - 1) / WVS;
         constexpr int base = L == 0 ? 0 : (L == 1 ? S1 : S1 + S2);
+        // EV2G_BF16_KSOUTER (bit 0: layer 1, bit 1: layer 2; one block of rows): a two-tile wavefront walks k-step, tile slot -- ONE operand read and two independent
+        // MFMAs per k-step -- instead of one tile after the other: its chain of (LDS read -> MFMA -> request) round trips halves (same chain per tile: bit-identical)
+        constexpr bool KSO = RB == 1 && MT == 2 && L < 2 && ((L == 0 && (EV2G_BF16_KSOUTER & 1)) || (L == 1 && (EV2G_BF16_KSOUTER & 2)));
+        if (KSO) {
+            f32x4m acc0[MT], acc1[MT];
+#pragma unroll
+            for (int i = 0; i < MT; i++) { acc0[i] = *(const f32x4m *)(bias + min(wave + WVS * i, NT - 1) * 16 + kq * 4); acc1[i] = f32x4m{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                bf16x8 b;
+                const uint4 bw = *(const uint4 *)(A + brow * sa + ks * 32 + kq * 8);
+                __builtin_memcpy(&b, &bw, 16);
+#pragma unroll
+                for (int i = 0; i < MT; i++) {
+                    const int sq = base + ks * MT + i;
+                    if (WVS * i + WVS - 1 < NT || wave + WVS * i < NT) {   // (uniform; a constant but for the last slot)
+                        bf16x8 a;
+                        __builtin_memcpy(&a, &ring[sq % RING], 16);
+                        if (ks & 1) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc1[i], 0, 0, 0);
+                        else acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0[i], 0, 0, 0);
+                    }
+                    request(sq + RING);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; i++) {
+                const int tile = wave + WVS * i;
+                if (WVS * i + WVS - 1 < NT || tile < NT) {
+                    const f32x4m acc = acc0[i] + acc1[i];
+                    const uint32_t lo = ev2g_pack_bf16(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f)), hi = ev2g_pack_bf16(fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+                    *(uint2 *)(out + brow * so + tile * 16 + kq * 4) = make_uint2(lo, hi);
+                }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < MT; i++) {
             const int tile = wave + WVS * i;

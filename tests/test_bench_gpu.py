@@ -40,6 +40,8 @@ def test_bench_line_contract(extra):
     # the fused actor + step launch: every fast-path shape whose policy fits its packings (round 6: PublicPST too)
     assert ro["fused_launch"] is True and ro["launches_per_segment"] == 1 and 1.0 < ro["segment_kernel_us_per_step"] < 200.0
     assert ro["collector"]["step_kernel_specialisation"] == 4
+    if "fp32" in ro:   # (head-table states) the same loop with the float32 policy: fused too since the last session of round 6
+        assert ro["fp32"]["precision"] == "fp32" and ro["fp32"]["fused_launch"] is True and ro["fp32"]["env_steps_per_s_per_gpu"] > 1e6, ro["fp32"]
     if not extra:
         ps = d["persistent_strided"]   # every output kept: the strided wide instantiation, with its own roofline record
         assert ps["specialisation"] == 3 and 0.0 < ps["roofline"]["frac"] < 1.0
@@ -74,3 +76,7 @@ def test_default_bench_line_holds_the_roofline_fractions():
     # 497 M with one env per wavefront, 409-431 M as two launches per step
     col = ow["cfg3"]["collector"]
     assert col["step_kernel_specialisation"] == 4 and col["env_steps_per_s_per_gpu"] >= 6.0e8, col
+    # the policy in the loop at cfg2 (BASELINE configs[4]'s per-GPU shard): bf16 operands 495-505 M measured, the float32 policy inside the launch 313-319 M (168-171 M as two launches per step)
+    ro = d["rollout"]
+    assert ro["fused_launch"] is True and ro["env_steps_per_s_per_gpu"] >= 4.2e8, ro
+    assert ro["fp32"]["fused_launch"] is True and ro["fp32"]["env_steps_per_s_per_gpu"] >= 2.6e8, ro["fp32"]
