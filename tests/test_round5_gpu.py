@@ -170,7 +170,7 @@ def test_fused_launch_randomised_shapes_equal_the_two_kernel_chain(case, precisi
     from ev2gym_amd.actor import init_mlp_weights
     from ev2gym_amd.engine import Engine
     from ev2gym_amd.scenario_gen import GenConfig, generate_native
-    rng = np.random.default_rng(9000 + case)
+    rng = np.random.default_rng(9000 + case + 1000 * int(os.environ.get("EV2G_FUSED_SWEEP_OFFSET", "0")))   # (tools/r6/gpu_fused_sweep.sh: the sweep under other seed offsets)
     C = int(rng.integers(3, 65))
     E = int(rng.integers(1, 70))
     state = ["V2G_profit_max_loads", "V2G_profit_max"][int(rng.integers(0, 2))]
