@@ -95,6 +95,16 @@ __device__ __forceinline__ float ev2g_fast_tanh(float x) {
 // step on the critical path of layer 3's four wavefronts (profiles/r06_fused_float32_policy.txt); EV2G_F32_TANH=0 builds keep it.
 // the inline float32 policy's input rows: 1 = every wavefront splits ITS OWN row into the three bf16 terms at the policy's entry (22 VALU operations), into staging chunks
 // that are dead in layer 1; 0 = every wavefront splits the operand fragments it reads (6 x 44 operations per wavefront and forward: layer 1 was VALU-issue-bound, 9.5 k cycles)
+// The inline policies' weight requests through a SCALAR base: the wavefront's number read as a scalar (`tid >> 6` alone is a vector value to the compiler) makes the tile guards
+// scalar branches and a request `global_load_dwordx4 v, v_lane16, s[base]` behind scalar adds instead of three vector instructions and an address register pair.  Measured at
+// cfg2 (profiles/r06_fused_float32_policy.txt, r06_fused_bf16_kstep_outer.txt): float32 policy +1.4 % (324 -> 329 M: its layer 2 is MFMA / issue-bound), bf16 policy +0.2 %
+// (weight-stream-bound: off).
+#ifndef EV2G_BF16_SADDR
+#define EV2G_BF16_SADDR 0
+#endif
+#ifndef EV2G_F32_SADDR
+#define EV2G_F32_SADDR 1
+#endif
 #ifndef EV2G_F32_XSPLIT
 #define EV2G_F32_XSPLIT 1
 #endif
@@ -638,8 +648,26 @@ __device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t
     constexpr int KS2 = C::KS2, KS3 = C::KS3;
     constexpr int MT1 = (NT1 + WVS - 1) / WVS, MT2 = (NT2 + WVS - 1) / WVS, MT3 = (NT3 + WVS - 1) / WVS;
     constexpr int S1 = MT1 * KS1, S2 = MT2 * KS2, S3 = MT3 * KS3, STOT = S1 + S2 + S3;
+#if EV2G_BF16_SADDR   // (as in ev2g_mlp3_inline_f32 below: the wavefront's number as a scalar, weight requests through a scalar base)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    typedef const char __attribute__((address_space(1))) *wgptr;
+    typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+    const wgptr w1 = (wgptr)(unsigned long long)m.w1, w2 = (wgptr)(unsigned long long)m.w2, w3 = (wgptr)(unsigned long long)m.w3;
+    auto frag = [&](wgptr w, int idx) __attribute__((always_inline)) -> uint4 {
+        wgptr fb = w + (unsigned long long)(unsigned)idx * 1024ull;
+        unsigned l16 = lane16;
+        asm volatile("" : "+s"(fb), "+v"(l16));
+        const u32x4g v = *(const u32x4g __attribute__((address_space(1))) *)(fb + l16);
+        uint4 r;
+        __builtin_memcpy(&r, &v, 16);
+        return r;
+    };
+#else
     const int lane = tid & 63, wave = tid >> 6;
     const uint4 *w1 = (const uint4 *)m.w1 + lane, *w2 = (const uint4 *)m.w2 + lane, *w3 = (const uint4 *)m.w3 + lane;
+    auto frag = [&](const uint4 *w, int idx) __attribute__((always_inline)) -> uint4 { return w[(unsigned)(idx * 64)]; };
+#endif
     uint4 ring[RING];
     auto request = [&](int seq) __attribute__((always_inline)) {   // (seq is a constant wherever this is called, after unrolling)
         if (seq >= STOT) return;
@@ -649,8 +677,8 @@ __device__ __forceinline__ void ev2g_mlp3_inline(const MlpDev &m, const uint16_t
         const int MTL = L == 0 ? MT1 : (L == 1 ? MT2 : MT3);
         const bool kso = RB == 1 && MTL == 2 && ((L == 0 && (EV2G_BF16_KSOUTER & 1)) || (L == 1 && (EV2G_BF16_KSOUTER & 2)));   // k-step, tile slot (below)
         const int i = kso ? r % MTL : r / KS, ks = kso ? r / MTL : r - i * KS;
-        const uint4 *w = L == 0 ? w1 : (L == 1 ? w2 : w3);
-        if (WVS * i + WVS - 1 < NT || wave + WVS * i < NT) ring[seq % RING] = w[(unsigned)(((wave + WVS * i) * KS + ks) * 64)];
+        const auto w = L == 0 ? w1 : (L == 1 ? w2 : w3);
+        if (WVS * i + WVS - 1 < NT || wave + WVS * i < NT) ring[seq % RING] = frag(w, (wave + WVS * i) * KS + ks);
     };
     // (requesting the head of the sequence a phase EARLIER in the step kernel -- behind phase E, D or C of the step before -- was tried: the whole ring
     // then lives across the step loop's back edge and the register allocator spills 40..119 registers; only layer 1's first tile (6 fragments)
@@ -809,8 +837,28 @@ __device__ __forceinline__ void ev2g_mlp3_inline_f32(const MlpDev &m, float *buf
 #define EV2G_F32_W3OFF 0
 #endif
     constexpr int W3OFF = (MT3 == 1 && NT3 + EV2G_F32_W3OFF <= WVS) ? EV2G_F32_W3OFF : 0;
+#if EV2G_F32_SADDR
+    // the wavefront's number as a SCALAR (it is uniform by construction; `tid >> 6` alone is a vector value to the compiler): the tile guards become scalar branches and a
+    // weight request is `global_load_dwordx4 v, v_lane16, s[base]` behind two scalar adds instead of three vector instructions and an address register pair per request
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    typedef const char __attribute__((address_space(1))) *wgptr;
+    typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+    const wgptr w1 = (wgptr)(unsigned long long)m.w1, w2 = (wgptr)(unsigned long long)m.w2, w3 = (wgptr)(unsigned long long)m.w3;
+    auto frag = [&](wgptr w, int idx) __attribute__((always_inline)) -> uint4 {   // fragment idx (1 KB each) of a layer's packed weights, this lane's 16 bytes
+        wgptr fb = w + (unsigned long long)(unsigned)idx * 1024ull;
+        unsigned l16 = lane16;
+        asm volatile("" : "+s"(fb), "+v"(l16));   // (the scalar base stays a scalar pair and the lane offset a 32-bit value extended HERE: base + zext(offset) is the `saddr` form of the load)
+        const u32x4g v = *(const u32x4g __attribute__((address_space(1))) *)(fb + l16);
+        uint4 r;
+        __builtin_memcpy(&r, &v, 16);
+        return r;
+    };
+#else
     const int lane = tid & 63, wave = tid >> 6;
     const uint4 *w1 = (const uint4 *)m.w1 + lane, *w2 = (const uint4 *)m.w2 + lane, *w3 = (const uint4 *)m.w3 + lane;
+    auto frag = [&](const uint4 *w, int idx) __attribute__((always_inline)) -> uint4 { return w[(unsigned)(idx * 64)]; };
+#endif
     const float *ball = m.b1;   // b1 | b2 | b3, each padded to its tiles
     uint4 ring[RING];
     auto request = [&](int seq) __attribute__((always_inline)) {   // (seq is a constant wherever this is called, after unrolling)
@@ -821,16 +869,16 @@ __device__ __forceinline__ void ev2g_mlp3_inline_f32(const MlpDev &m, float *buf
         int i, rem;   // tile slot; ks * NW + term
         if (L == 0) { const int ks = r / (MT1 * NW), r2 = r - ks * (MT1 * NW); i = r2 / NW; rem = ks * NW + (r2 - i * NW); }
         else { i = r / (KS * NW); rem = r - i * (KS * NW); }
-        const uint4 *w = L == 0 ? w1 : (L == 1 ? w2 : w3);
-        if (L == 2) { if ((unsigned)(wave - W3OFF) < (unsigned)NT3) ring[seq % RING] = w[(unsigned)(((wave - W3OFF) * (KS * NW) + rem) * 64)]; }
+        const auto w = L == 0 ? w1 : (L == 1 ? w2 : w3);
+        if (L == 2) { if ((unsigned)(wave - W3OFF) < (unsigned)NT3) ring[seq % RING] = frag(w, (wave - W3OFF) * (KS * NW) + rem); }
         else
-        if (WVS * i + WVS - 1 < NT || wave + WVS * i < NT) ring[seq % RING] = w[(unsigned)(((wave + WVS * i) * (KS * NW) + rem) * 64)];
+        if (WVS * i + WVS - 1 < NT || wave + WVS * i < NT) ring[seq % RING] = frag(w, (wave + WVS * i) * (KS * NW) + rem);
     };
     F32_STAMP(0)
     uint4 ring3[R3M];
     const int tile3 = wave - W3OFF;   // this wavefront's layer-3 tile, if 0 <= tile3 < NT3
     auto request3 = [&](int r) __attribute__((always_inline)) {   // fragment r = ks * NW + term of that tile (callers: wavefronts that own one)
-        if (R3 > 0 && r < KS3 * NW) ring3[r % R3M] = w3[(unsigned)((tile3 * (KS3 * NW) + r) * 64)];
+        if (R3 > 0 && r < KS3 * NW) ring3[r % R3M] = frag(w3, tile3 * (KS3 * NW) + r);
     };
     const int brow = lane & 15, kq = lane >> 4;
     f32x4m bias1[MT1];

@@ -173,7 +173,8 @@ def test_fast_path_kernels_keep_four_wavefronts_per_simd_and_do_not_spill():
         if fullk == 3:   # (four running output pointers more)
             assert v["SGPRs Spill"] <= 24, (k, v)
         if act:          # (the policy's pointers and the running output pointers; the weight ring must stay in registers: no scratch, above)
-            assert block == 1024 and v["SGPRs Spill"] <= 32, (k, v)
+            # (the fused PublicPST launch with the float32 policy -- scalar weight bases on top of PublicPST's three columns per port -- parks up to 51 scalars in lanes)
+            assert block == 1024 and v["SGPRs Spill"] <= (56 if sk == 1 else 32), (k, v)
     # the streaming actor (ev2g_mlp.h): ten instantiations (two shapes x {bf16 with eight wavefronts, float32 as two / three bf16 terms, bf16 with 32 rows per
     # workgroup}); a register ring that the compiler could not keep in registers would land in scratch and cost the forward its weight stream
     actor = {k: v for k, v in res.items() if "ev2g_mlp3_s16" in k}

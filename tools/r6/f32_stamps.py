@@ -9,7 +9,8 @@ from ev2gym_amd import engine, _abi
 from bench import WORKLOADS
 from ev2gym_amd.actor import init_mlp_weights
 from ev2gym_amd.scenario_gen import generate_native
-wl = WORKLOADS["cfg2"]
+WL = os.environ.get("STAMP_WORKLOAD", "cfg2")
+wl = WORKLOADS[WL]
 E = wl["envs"]
 batch = generate_native(wl["gen"](E, 0)).sorted_by_busy_window(E)
 eng = engine.Engine(batch, _abi.REWARD_KINDS[wl["reward"]], _abi.STATE_KINDS[wl["state"]], flags=_abi.FLAG_LOG_SOC)
@@ -29,7 +30,7 @@ for rep in range(2):
     eng._lib.ev2g_mlp_debug_f32_stamps(eng._h, mlp, out)
     v2 = np.array(list(out)[1024:], np.int64).reshape(8, 16, 16)
     v = np.array(list(out)[:1024], np.int64).reshape(8, 16, 8)
-print(f"fused {PREC} policy, cfg2, one launch of {T} steps, spec {eng.last_launch_specialisation}: {ms*1e3/T:.2f} us/step")
+print(f"fused {PREC} policy, {WL}, one launch of {T} steps, spec {eng.last_launch_specialisation}: {ms*1e3/T:.2f} us/step")
 d = np.diff(v, axis=2)   # [wg][wave][7]
 print("mean over 8 workgroups, cycles (s_memtime at 100 MHz? -> printed raw):")
 print("wave " + " ".join(f"{n:>17s}" for n in names) + "   total")
