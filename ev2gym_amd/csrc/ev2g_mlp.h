@@ -99,6 +99,9 @@ __device__ __forceinline__ float ev2g_fast_tanh(float x) {
 // scalar branches and a request `global_load_dwordx4 v, v_lane16, s[base]` behind scalar adds instead of three vector instructions and an address register pair.  Measured at
 // cfg2 (profiles/r06_fused_float32_policy.txt, r06_fused_bf16_kstep_outer.txt): float32 policy +1.4 % (324 -> 329 M: its layer 2 is MFMA / issue-bound), bf16 policy +0.2 %
 // (weight-stream-bound: off).
+#ifndef EV2G_S16_SADDR   // the same in the stand-alone streaming actor (ev2g_mlp3_s16)
+#define EV2G_S16_SADDR 1
+#endif
 #ifndef EV2G_BF16_SADDR
 #define EV2G_BF16_SADDR 0
 #endif
@@ -429,7 +432,11 @@ __global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *
     constexpr int BX = ROWS * C::SX, BH1 = ROWS * C::SH1, BH2 = ROWS * C::SH2;
     uint16_t *bufX = mlds, *bufH1 = bufX + NX * BX, *bufH2 = bufH1 + NX * BH1;
     float *lb = (float *)(bufH2 + NX * BH2);   // biases: layer 1 | layer 2 | layer 3
+#if EV2G_S16_SADDR
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((tid >> 6) & (WV - 1));   // (uniform by construction: a scalar for the tile guards and the weight bases)
+#else
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & (WV - 1);
+#endif
     const int row0 = blockIdx.x * ROWS;
     const int nr = min(ROWS, n_rows - row0);
     MLP_STAMP(0)
@@ -451,7 +458,24 @@ __global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *
     float bv[(C::NB + NTH - 1) / NTH];   // the three bias vectors are ONE array on this path (ev2g_mlp_create_ex): b1 | b2 | b3, each padded to its tiles
 #pragma unroll
     for (int j = 0; j < (C::NB + NTH - 1) / NTH; j++) bv[j] = m.b1[min(tid + j * NTH, C::NB - 1)];
+#if EV2G_S16_SADDR
+    const unsigned lane16 = (unsigned)lane * 16u;
+    typedef const char __attribute__((address_space(1))) *wgptr;
+    typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+    const wgptr w1 = (wgptr)(unsigned long long)m.w1, w2 = (wgptr)(unsigned long long)m.w2, w3 = (wgptr)(unsigned long long)m.w3;
+    auto frag = [&](wgptr w, int idx) __attribute__((always_inline)) -> uint4 {   // (ev2g_mlp3_inline_f32: scalar base + zero-extended lane offset = the `saddr` form)
+        wgptr fb = w + (unsigned long long)(unsigned)idx * 1024ull;
+        unsigned l16 = lane16;
+        asm volatile("" : "+s"(fb), "+v"(l16));
+        const u32x4g v = *(const u32x4g __attribute__((address_space(1))) *)(fb + l16);
+        uint4 r;
+        __builtin_memcpy(&r, &v, 16);
+        return r;
+    };
+#else
     const uint4 *w1 = (const uint4 *)m.w1 + lane, *w2 = (const uint4 *)m.w2 + lane, *w3 = (const uint4 *)m.w3 + lane;
+    auto frag = [&](const uint4 *w, int idx) __attribute__((always_inline)) -> uint4 { return w[(unsigned)(idx * 64)]; };
+#endif
     uint4 ring[RING];
     // fragment `seq` of this wavefront's sequence -> ring slot seq % RING (seq is a constant wherever this is called, after unrolling; the
     // tile guard is a compile-time `true` except in a layer's last tile slot).  Sequence order inside a layer: tile slot, k-step, weight term.
@@ -461,8 +485,8 @@ __global__ void __launch_bounds__(WV * 64) ev2g_mlp3_s16(MlpDev m, const float *
         const int r = seq - (L == 0 ? 0 : (L == 1 ? C::S1 : C::S1 + C::S2));
         const int KS = L == 0 ? KS1 : (L == 1 ? C::KS2 : C::KS3), NT = L == 0 ? NT1 : (L == 1 ? NT2 : NT3);
         const int i = r / (KS * NW), rem = r - i * (KS * NW);   // rem = ks * NW + term: the fragment's place inside its tile
-        const uint4 *w = L == 0 ? w1 : (L == 1 ? w2 : w3);
-        if (WV * i + WV - 1 < NT || wave + WV * i < NT) ring[seq % RING] = w[(unsigned)(((wave + WV * i) * (KS * NW) + rem) * 64)];
+        const auto w = L == 0 ? w1 : (L == 1 ? w2 : w3);
+        if (WV * i + WV - 1 < NT || wave + WV * i < NT) ring[seq % RING] = frag(w, (wave + WV * i) * (KS * NW) + rem);
     };
     MLP_STAMP(8)
     // The CU's vector-memory port takes ~64 cycles per wavefront and fragment with four wavefronts asking (3.3 k cycles for the whole ring):
