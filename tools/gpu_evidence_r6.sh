@@ -25,7 +25,7 @@ PASSES=kt PASS_TIMEOUT=240 bash tools/prof_step.sh cfg2_actor_bf16 --workload cf
 python tools/collect_evidence.py $O/r06_hbm_traffic.json cfg2_persistent=cfg2:persistent cfg2_per_step=cfg2:per_step cfg3_persistent=cfg3:persistent cfg4_persistent=cfg4:persistent > /dev/null
 rm -rf gpurun_out/prof_*   # raw rocprofv3 output: too large to travel back (the summaries above carry what is committed)
 timeout 200 python tools/refill_time.py cfg2 2>&1 | tail -1 > $O/r06_refill_time.txt; timeout 200 python tools/refill_time.py cfg3 2>&1 | tail -1 >> $O/r06_refill_time.txt; cut -c1-160 $O/r06_refill_time.txt
-timeout 200 python tools/sb3_collect_bench.py cfg2 2>&1 | grep -v amdgpu.ids | tail -1 > $O/r06_collector_cfg2.json; timeout 200 python tools/sb3_collect_bench.py cfg3 2>&1 | grep -v amdgpu.ids | tail -1 > $O/r06_collector_cfg3.json; cut -c1-200 $O/r06_collector_cfg3.json
+timeout 200 python tools/sb3_collect_bench.py cfg2 2>&1 | grep -v amdgpu.ids | tail -1 > $O/r06_collector_cfg2.json; timeout 200 python tools/sb3_collect_bench.py cfg3 2>&1 | grep -v amdgpu.ids | tail -1 > $O/r06_collector_cfg3.json; timeout 200 python tools/sb3_collect_bench.py cfg2 12 fp32 2>&1 | grep -v amdgpu.ids | tail -1 > $O/r06_collector_cfg2_fp32.json; cut -c1-200 $O/r06_collector_cfg3.json
 for w in cfg2 cfg3 cfg4; do timeout 200 python tools/stats_time.py $w 2>&1 | grep -v amdgpu.ids | tail -1; done | tee $O/r06_stats_time.txt
 EV2G_PT_LIB=build_variants/libev2g_pt.so timeout 300 python tools/phase_timing.py cfg4 2>&1 | grep -v amdgpu.ids | head -9 > $O/r06_phase_cfg4.txt
 timeout 200 python tools/sb3_loop_bench.py 2>&1 | grep -v amdgpu.ids | tail -1 > $O/r06_host_loops.txt; SB3_COPY_OBS=0 timeout 200 python tools/sb3_loop_bench.py 2>&1 | grep -v amdgpu.ids | tail -1 | sed 's/^/copy_obs=False: /' >> $O/r06_host_loops.txt
