@@ -404,26 +404,29 @@ def test_fused_launch_with_the_float32_policy_equals_the_two_kernel_chain(state,
     assert 4 not in s_off and np.array_equal(off["act"], two["act"])
 
 
-def test_fused_float32_policy_at_the_benchmarked_size(monkeypatch):
-    """BASELINE configs[4]'s per-GPU shard (4096 envs x 50 chargers) with the float32 policy: a whole episode as ONE fused launch against 112 x (actor
+@pytest.mark.parametrize("shape", ["cfg2", "cfg3"])
+def test_fused_float32_policy_at_the_benchmarked_size(shape, monkeypatch):
+    """BASELINE configs[4]'s per-GPU shard (4096 envs x 50 chargers; and configs[2]'s 8192 x 20 PublicPST envs, one env per wavefront: 512 workgroups) with the float32 policy: a whole episode as ONE fused launch against 112 x (actor
     launch, step launch), every action / reward / done / mask row and the statistics bit for bit; and the actions of sampled rows against a float64
     numpy forward of the same network on the float32 observations the launch wrote (the 1e-5 level the two-term weights give)."""
     from ev2gym_amd import _abi
     from ev2gym_amd.actor import init_mlp_weights
     from ev2gym_amd.engine import Engine
     from ev2gym_amd.scenario_gen import GenConfig, generate_native
-    E = 4096
-    pool = generate_native(GenConfig.v2g_profit_plus_loads(E, 50, 1, seed=78)).sorted_by_busy_window(E)
-    weights = init_mlp_weights(162, 50, seed=4)
+    pst = shape == "cfg3"
+    E = 8192 if pst else 4096
+    pool = generate_native(GenConfig.public_pst(E, 20, seed=78) if pst else GenConfig.v2g_profit_plus_loads(E, 50, 1, seed=78)).sorted_by_busy_window(E)
+    weights = init_mlp_weights(63 if pst else 162, 20 if pst else 50, seed=4)
 
     def run(fused):
         if fused:
             monkeypatch.delenv("EV2G_NO_FUSED", raising=False)
         else:
             monkeypatch.setenv("EV2G_NO_FUSED", "1")
-        eng = Engine(pool, _abi.REWARD_KINDS["ProfitMax_TrPenalty_UserIncentives"], _abi.STATE_KINDS["V2G_profit_max_loads"], flags=_abi.FLAG_LOG_SOC)
+        eng = Engine(pool, _abi.REWARD_KINDS["SquaredTrackingErrorReward" if pst else "ProfitMax_TrPenalty_UserIncentives"],
+                     _abi.STATE_KINDS["PublicPST" if pst else "V2G_profit_max_loads"], flags=_abi.FLAG_LOG_SOC)
         P, D, T = eng.P, eng.D, eng.T
-        mlp = eng.mlp_create(*weights, out_lo=-1.0, precision="fp32")
+        mlp = eng.mlp_create(*weights, out_lo=0.0 if pst else -1.0, precision="fp32")
         obs, act = eng.empty((T + 1, E, D), np.float32), eng.empty((T, E, P), np.float32)
         rew, done, mask = eng.empty((T, E)), eng.empty((T, E), np.uint8), eng.empty((T, E, P), np.uint8)
         eng.reset_f32(obs, 0)
@@ -449,4 +452,6 @@ def test_fused_float32_policy_at_the_benchmarked_size(monkeypatch):
     for i, t in enumerate((0, 1, 2, T // 2, T - 1)):
         x = one["obs_rows"][i][::97].astype(np.float64)
         y = np.tanh(np.maximum(np.maximum(x @ W1.T + b1, 0.0) @ W2.T + b2, 0.0) @ W3.T + b3)
+        if pst:
+            y = 0.5 * y + 0.5   # (out_lo = 0: the action box of configs without V2G)
         assert np.abs(one["act"][t][::97] - y).max() < 5e-5, (t, np.abs(one["act"][t][::97] - y).max())
